@@ -1,0 +1,317 @@
+"""ctypes binding of the CPU oracle (oracle/so3_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Never imported by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libso3_oracle.so")
+GOLDEN = os.path.join(_HERE, "..", "tests", "golden")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("so3_oracle.c", "so3_oracle_impl.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _arr(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+_DT = {"f32": np.float32, "f64": np.float64}
+_CR = {"f32": C.c_float, "f64": C.c_double}
+
+_knots_cache = None
+
+
+def knots():
+    """The reference's fp32 knot / Haar-weight vectors (fixture, distributions.py:15,21)."""
+    global _knots_cache
+    if _knots_cache is None:
+        z = np.load(os.path.join(GOLDEN, "igso3_knots.npz"))
+        _knots_cache = (_arr(z["knots"], np.float32), _arr(z["haar_w"], np.float32))
+    return _knots_cache
+
+
+def cosine_beta_schedule(T):
+    out = np.empty(T, np.float64)
+    lib().so3o_cosine_beta_schedule(C.c_int(T), _p(out))
+    return out
+
+
+SCHED_ROWS = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+              "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2")
+
+
+def schedule_from_betas(betas):
+    betas = _arr(betas, np.float64)
+    T = len(betas)
+    out = np.empty((12, T), np.float32)
+    lib().so3o_schedule_from_betas(_p(betas), C.c_int(T), _p(out))
+    return out
+
+
+def posemb_freqs(half=28):
+    out = np.empty(half, np.float32)
+    lib().so3o_posemb_freqs(C.c_int(half), _p(out))
+    return out
+
+
+def eps_ft(omega, eps):
+    omega = _arr(omega, np.float32).ravel()
+    eps = _arr(eps, np.float32).ravel()
+    stride = 0 if eps.size == 1 else 1
+    out = np.empty_like(omega)
+    lib().so3o_eps_ft(_p(omega), _p(eps), C.c_long(stride), _p(out), C.c_long(omega.size))
+    return out
+
+
+def igso3_dlogf(omega, eps):
+    omega = _arr(omega, np.float32).ravel()
+    eps = _arr(eps, np.float32).ravel()
+    stride = 0 if eps.size == 1 else 1
+    out = np.empty(omega.size, np.float64)
+    lib().so3o_igso3_dlogf(_p(omega), _p(eps), C.c_long(stride), _p(out), C.c_long(omega.size))
+    return out
+
+
+def igso3_build_tables(eps):
+    eps = _arr(eps, np.float32).ravel()
+    k, w = knots()
+    trap = np.empty((eps.size, 999), np.float32)
+    lib().so3o_igso3_build_tables(_p(eps), C.c_long(eps.size), _p(k), _p(w), _p(trap))
+    return trap
+
+
+def igso3_log_prob(R, eps):
+    R = _arr(R, np.float32).reshape(-1, 9)
+    eps = _arr(eps, np.float32).ravel()
+    stride = 0 if eps.size == 1 else 1
+    out = np.empty(R.shape[0], np.float32)
+    lib().so3o_igso3_log_prob(_p(R), _p(eps), C.c_long(stride), _p(out), C.c_long(R.shape[0]))
+    return out
+
+
+def _fn(name, prec):
+    return getattr(lib(), f"so3o_{name}_{prec}")
+
+
+def quat_to_rmat(q, prec="f32"):
+    q = _arr(q, _DT[prec]).reshape(-1, 4)
+    out = np.empty((q.shape[0], 3, 3), _DT[prec])
+    _fn("quat_to_rmat", prec)(_p(q), _p(out), C.c_long(q.shape[0]))
+    return out
+
+
+def log_rmat_vec(R, prec="f32"):
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    out = np.empty((R.shape[0], 3), _DT[prec])
+    _fn("log_rmat_vec", prec)(_p(R), _p(out), C.c_long(R.shape[0]))
+    return out
+
+
+def vec2skew(v):
+    """util.py:87-92"""
+    v = np.asarray(v)
+    S = np.zeros(v.shape[:-1] + (3, 3), v.dtype)
+    S[..., 2, 1] = v[..., 0]; S[..., 1, 2] = -v[..., 0]
+    S[..., 2, 0] = -v[..., 1]; S[..., 0, 2] = v[..., 1]
+    S[..., 1, 0] = v[..., 2]; S[..., 0, 1] = -v[..., 2]
+    return S
+
+
+def exp_vec(w, prec="f32"):
+    w = _arr(w, _DT[prec]).reshape(-1, 3)
+    out = np.empty((w.shape[0], 3, 3), _DT[prec])
+    _fn("exp_vec", prec)(_p(w), _p(out), C.c_long(w.shape[0]))
+    return out
+
+
+def so3_scale(R, k, prec="f32"):
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    k = _arr(k, _DT[prec]).ravel()
+    stride = 0 if k.size == 1 else 1
+    out = np.empty((R.shape[0], 3, 3), _DT[prec])
+    _fn("so3_scale", prec)(_p(R), _p(k), C.c_long(stride), _p(out), C.c_long(R.shape[0]))
+    return out
+
+
+def aa_to_rmat(axis, ang, prec="f32"):
+    axis = _arr(axis, _DT[prec]).reshape(-1, 3)
+    ang = _arr(ang, _DT[prec]).ravel()
+    out = np.empty((axis.shape[0], 3, 3), _DT[prec])
+    _fn("aa_to_rmat", prec)(_p(axis), _p(ang), _p(out), C.c_long(axis.shape[0]))
+    return out
+
+
+def rmat_to_aa(R, prec="f32"):
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    n = R.shape[0]
+    axis = np.empty((n, 3), _DT[prec])
+    ang = np.empty((n, 1), _DT[prec])
+    _fn("rmat_to_aa", prec)(_p(R), _p(axis), _p(ang), C.c_long(n))
+    return axis, ang
+
+
+def so3_lerp(a, b, w, prec="f32"):
+    b = _arr(b, _DT[prec]).reshape(-1, 9)
+    a = _arr(a, _DT[prec]).reshape(-1, 9)
+    w = _arr(w, _DT[prec]).ravel()
+    n = b.shape[0]
+    out = np.empty((n, 3, 3), _DT[prec])
+    _fn("so3_lerp", prec)(_p(a), C.c_long(0 if a.shape[0] == 1 else 9), _p(b), _p(w),
+                          C.c_long(0 if w.size == 1 else 1), _p(out), C.c_long(n))
+    return out
+
+
+def rmat_dist(a, b, prec="f32"):
+    a = _arr(a, _DT[prec]).reshape(-1, 9)
+    b = _arr(b, _DT[prec]).reshape(-1, 9)
+    out = np.empty(a.shape[0], _DT[prec])
+    _fn("rmat_dist", prec)(_p(a), _p(b), _p(out), C.c_long(a.shape[0]))
+    return out
+
+
+def igso3_sample(trap, axes, unif, row_idx=None, weight_row=-1, mean=None, prec="f32"):
+    """trap [n_rows,999]; returns (rotations [n,3,3], angles [n])."""
+    trap = _arr(trap, np.float32).reshape(-1, 999)
+    axes = _arr(axes, np.float32).reshape(-1, 3)
+    unif = _arr(unif, np.float32).ravel()
+    n = unif.size
+    k, _ = knots()
+    ri = _arr(row_idx, np.int64) if row_idx is not None else None
+    m = _arr(mean, _DT[prec]) if mean is not None else None
+    out = np.empty((n, 3, 3), _DT[prec])
+    ang = np.empty(n, np.float32)
+    _fn("igso3_sample", prec)(_p(trap), _p(ri), C.c_long(weight_row), _p(k), _p(axes), _p(unif), _p(m),
+                              _p(out), _p(ang), C.c_long(n))
+    return out, ang
+
+
+N_PARAMS = 4 * (65 * 65 + 65) + 3 * 65 + 3
+
+
+def mlp_fwd(params, R, t, prec="f32", return_acts=False):
+    params = _arr(params, np.float32).ravel()
+    assert params.size == N_PARAMS
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    t = _arr(t, np.int64).ravel()
+    n = R.shape[0]
+    out = np.empty((n, 3), _DT[prec])
+    acts = np.empty((n, 5, 65), _DT[prec]) if return_acts else None
+    fr = posemb_freqs()
+    _fn("mlp_fwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(out),
+                         _p(acts), C.c_long(n))
+    return (out, acts) if return_acts else out
+
+
+def mlp_bwd(params, R, t, dout, prec="f32"):
+    params = _arr(params, np.float32).ravel()
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    t = _arr(t, np.int64).ravel()
+    dout = _arr(dout, _DT[prec]).reshape(-1, 3)
+    n = R.shape[0]
+    dp = np.empty(N_PARAMS, np.float64)
+    fr = posemb_freqs()
+    _fn("mlp_bwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(dout),
+                         _p(dp), C.c_long(n))
+    return dp
+
+
+def q_sample_target(x0, noise, sched, t, prec="f32"):
+    """returns (x_t, target); sched = schedule_from_betas table."""
+    x0 = _arr(x0, _DT[prec]).reshape(-1, 9)
+    noise = _arr(noise, _DT[prec]).reshape(-1, 9)
+    t = _arr(t, np.int64).ravel()
+    n = x0.shape[0]
+    xt = np.empty((n, 3, 3), _DT[prec])
+    tg = np.empty((n, 3), _DT[prec])
+    s3 = _arr(sched[3], np.float32)
+    s4 = _arr(sched[4], np.float32)
+    _fn("q_sample_target", prec)(_p(x0), _p(noise), _p(s3), _p(s4), _p(t), _p(xt), _p(tg), C.c_long(n))
+    return xt, tg
+
+
+def p_mean(x, v, a, b, c1, c2, prec="f32"):
+    """returns (x0hat, mean) for one shared timestep's coefficients."""
+    x = _arr(x, _DT[prec]).reshape(-1, 9)
+    v = _arr(v, _DT[prec]).reshape(-1, 3)
+    n = x.shape[0]
+    x0h = np.empty((n, 3, 3), _DT[prec])
+    mean = np.empty((n, 3, 3), _DT[prec])
+    cr = _CR[prec]
+    f = _fn("p_mean", prec)
+    f.argtypes = [C.c_void_p, C.c_void_p, cr, cr, cr, cr, C.c_void_p, C.c_void_p, C.c_long]
+    f(_p(x), _p(v), cr(a), cr(b), cr(c1), cr(c2), _p(x0h), _p(mean), n)
+    return x0h, mean
+
+
+def rmul(a, b, prec="f32"):
+    a = _arr(a, _DT[prec]).reshape(-1, 9)
+    b = _arr(b, _DT[prec]).reshape(-1, 9)
+    out = np.empty((a.shape[0], 3, 3), _DT[prec])
+    _fn("rmul", prec)(_p(a), _p(b), _p(out), C.c_long(a.shape[0]))
+    return out
+
+
+def domega_dR(R, prec="f32"):
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    out = np.empty((R.shape[0], 3, 3), _DT[prec])
+    _fn("domega_dR", prec)(_p(R), _p(out), C.c_long(R.shape[0]))
+    return out
+
+
+def p_sample_step(params, sched, trap_p, x, t, axes, unif):
+    """fp32, OpenMP over the batch: the timed CPU baseline and chain checker."""
+    params = _arr(params, np.float32).ravel()
+    sched = _arr(sched, np.float32)
+    T = sched.shape[1]
+    trap_p = _arr(trap_p, np.float32).reshape(T, 999)
+    x = _arr(x, np.float32).reshape(-1, 9)
+    n = x.shape[0]
+    axes = _arr(axes, np.float32) if axes is not None else np.zeros((n, 3), np.float32)
+    unif = _arr(unif, np.float32) if unif is not None else np.zeros(n, np.float32)
+    out = np.empty((n, 3, 3), np.float32)
+    k, _ = knots()
+    fr = posemb_freqs()
+    lib().so3o_p_sample_step_f32(_p(params), _p(fr), _p(sched), C.c_int(T), _p(trap_p), _p(k), _p(x),
+                                 C.c_int(int(t)), _p(axes), _p(unif), _p(out), C.c_long(n))
+    return out
+
+
+def omp_threads():
+    return int(lib().so3o_omp_threads())
+
+
+def flat_params(state):
+    """state: mapping with net_{0,2,4,6,8}_{weight,bias} (tests/golden/score_mlp.npz naming)."""
+    parts = []
+    for l in (0, 2, 4, 6, 8):
+        parts.append(np.asarray(state[f"net_{l}_weight"], np.float32).ravel())
+        parts.append(np.asarray(state[f"net_{l}_bias"], np.float32).ravel())
+    return np.concatenate(parts)

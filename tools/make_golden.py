@@ -1,0 +1,420 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors for the SO(3) diffusion hot path.
+
+Runs ONLY in the build container, where the read-only reference checkout lives
+at /root/reference.  It imports the reference's own Python modules (with stub
+modules for its absent third-party dependencies), feeds
+them seeded inputs, records every RNG draw in call order and writes small
+``.npz`` fixtures under ``tests/golden/``.  The fixtures are data only (inputs
+and expected outputs); no reference source travels.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import os
+import sys
+import types
+import math
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.path.abspath(OUT)
+
+
+# --------------------------------------------------------------------------
+# stub modules for the reference's absent dependencies
+# --------------------------------------------------------------------------
+def _install_stubs():
+    # denoising_diffusion_pytorch: the 5 helpers diffusion.py:8-14 imports.
+    # Definitions restated from the upstream lucidrains package (mid-2021);
+    # the fork the reference pins is un-vendored, so the schedule is "parity
+    # unpinned"  and betas travel as an explicit fixture.
+    ddp = types.ModuleType("denoising_diffusion_pytorch")
+    ddp_inner = types.ModuleType("denoising_diffusion_pytorch.denoising_diffusion_pytorch")
+
+    def extract(a, t, x_shape):
+        b, *_ = t.shape
+        out = a.gather(-1, t)
+        return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+    def exists(x):
+        return x is not None
+
+    def default(val, d):
+        if exists(val):
+            return val
+        return d() if callable(d) else d
+
+    def noise_like(shape, device, repeat=False):
+        return torch.randn(shape, device=device)
+
+    def cosine_beta_schedule(timesteps, s=0.008):
+        steps = timesteps + 1
+        x = np.linspace(0, steps, steps)
+        alphas_cumprod = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+        alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+        betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+        return np.clip(betas, a_min=0, a_max=0.999)
+
+    for f in (extract, exists, default, noise_like, cosine_beta_schedule):
+        setattr(ddp_inner, f.__name__, f)
+    ddp.denoising_diffusion_pytorch = ddp_inner
+    sys.modules["denoising_diffusion_pytorch"] = ddp
+    sys.modules["denoising_diffusion_pytorch.denoising_diffusion_pytorch"] = ddp_inner
+
+    se3 = types.ModuleType("se3_transformer_pytorch")
+    se3_inner = types.ModuleType("se3_transformer_pytorch.se3_transformer_pytorch")
+    for name in ("LinearSE3", "Fiber", "NormSE3"):
+        setattr(se3_inner, name, type(name, (), {}))
+    se3.se3_transformer_pytorch = se3_inner
+    sys.modules["se3_transformer_pytorch"] = se3
+    sys.modules["se3_transformer_pytorch.se3_transformer_pytorch"] = se3_inner
+
+    bio = types.ModuleType("Bio")
+    biopdb = types.ModuleType("Bio.PDB")
+    for name in ("PDBParser", "Structure", "Polypeptide", "PPBuilder"):
+        setattr(biopdb, name, type(name, (), {}))
+    bio.PDB = biopdb
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.PDB"] = biopdb
+    return cosine_beta_schedule
+
+
+class RNGRecorder:
+    """Wraps torch.randn / rand / randint and keeps copies of what they return."""
+
+    def __init__(self):
+        self.log = []
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ("randn", "rand", "randint"):
+            orig = getattr(torch, name)
+            self._orig[name] = orig
+
+            def wrapped(*a, _orig=orig, _name=name, **k):
+                out = _orig(*a, **k)
+                self.log.append((_name, out.detach().clone()))
+                return out
+
+            setattr(torch, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self._orig.items():
+            setattr(torch, name, orig)
+
+
+class RNGReplay:
+    """Replays a recorded list of draws (cast to the requested dtype)."""
+
+    def __init__(self, log, dtype=None):
+        self.log = list(log)
+        self.dtype = dtype
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ("randn", "rand", "randint"):
+            orig = getattr(torch, name)
+            self._orig[name] = orig
+
+            def wrapped(*a, _name=name, **k):
+                n, out = self.log.pop(0)
+                assert n == _name, (n, _name)
+                if self.dtype is not None and out.is_floating_point():
+                    out = out.to(self.dtype)
+                return out.clone()
+
+            setattr(torch, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self._orig.items():
+            setattr(torch, name, orig)
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def main():
+    cosine_beta_schedule = _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    import util as rutil
+    import distributions as rdist
+    import diffusion as rdiff
+    import so3_train as rtrain
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    pi = math.pi
+
+    # ------------------------------------------------------------------ knots
+    knots = pi * torch.linspace(0, 1.0, 1000) ** 3.0  # distributions.py:15
+    haar_w = (1 - knots.cos()) / pi                    # distributions.py:21 (fp32)
+    np.savez(os.path.join(OUT, "igso3_knots.npz"), knots=npy(knots), haar_w=npy(haar_w))
+
+    # --------------------------------------------------------------- schedule
+    sched = {}
+    for T in (100, 1000):
+        betas = cosine_beta_schedule(T)
+        proc = rdiff.SO3Diffusion(lambda x, t: None, timesteps=T)
+        sched[f"betas64_{T}"] = betas.astype(np.float64)
+        for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                     "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+                     "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                     "posterior_variance", "posterior_log_variance_clipped",
+                     "posterior_mean_coef1", "posterior_mean_coef2"):
+            sched[f"{name}_{T}"] = npy(getattr(proc, name))
+    np.savez(os.path.join(OUT, "schedule.npz"), **sched)
+
+    # ----------------------------------------------------------------- eps_ft
+    g = torch.Generator().manual_seed(11)
+    eps_list = torch.tensor([0.0047, 0.0064, 0.023, 0.05, 0.118, 0.2, 0.5, 0.8, 1.0, 1.5], dtype=torch.float32)
+    om = torch.cat([torch.zeros(1), torch.rand(62, generator=g) * pi, torch.tensor([pi])]).float()
+    d = rdist.IsotropicGaussianSO3(eps_list)
+    vals = d._eps_ft(om[:, None])  # [64, 10] fp32
+    np.savez(os.path.join(OUT, "eps_ft.npz"), eps=npy(eps_list), omega=npy(om), vals=npy(vals))
+
+    # ----------------------------------------------------------------- tables
+    proc = rdiff.SO3Diffusion(lambda x, t: None, timesteps=1000)
+    t_rows = torch.tensor([0, 1, 10, 100, 600, 998, 999])
+    eps_q = proc.sqrt_one_minus_alphas_cumprod[t_rows]
+    eps_p = (0.5 * proc.posterior_log_variance_clipped[t_rows]).exp()
+    eps_misc = torch.tensor([0.01, 0.05, 0.118, 0.3, 1.0, 1.5], dtype=torch.float32)
+    all_eps = torch.cat([eps_q, eps_p[1:], eps_misc])
+    d = rdist.IsotropicGaussianSO3(all_eps)
+    np.savez(os.path.join(OUT, "igso3_tables.npz"), eps=npy(all_eps), trap=npy(d.trap.T.contiguous()),
+             t_rows=npy(t_rows), n_q=len(eps_q), n_p=len(eps_p) - 1)
+    # scalar-eps construction must equal the batched column
+    d1 = rdist.IsotropicGaussianSO3(torch.tensor(1.0))
+    assert torch.equal(d1.trap[:, 0], rdist.IsotropicGaussianSO3(torch.tensor([1.0, 0.3])).trap[:, 0])
+
+    # --------------------------------------------------------- rotation algebra
+    g = torch.Generator().manual_seed(5)
+    B = 64
+    q = torch.randn(B, 4, generator=g)
+    R = rutil.quat_to_rmat(q)
+    q2 = torch.randn(B, 4, generator=g)
+    R2 = rutil.quat_to_rmat(q2)
+    k = (torch.rand(B, generator=g) * 4 - 2)
+    w = torch.rand(B, 1, generator=g)
+    axis_in = torch.randn(B, 3, generator=g)
+    ang_in = torch.rand(B, 1, generator=g) * pi
+    rot = {"q": npy(q), "q2": npy(q2), "k": npy(k), "w": npy(w), "axis_in": npy(axis_in), "ang_in": npy(ang_in)}
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        Rd, R2d = rutil.quat_to_rmat(q.to(dt)), rutil.quat_to_rmat(q2.to(dt))
+        if tag == "64":
+            # fp64 evaluation of the *same fp32 inputs* for ops that take R
+            Rd, R2d = R.to(dt), R2.to(dt)
+        rot[f"R_{tag}"] = npy(rutil.quat_to_rmat(q.to(dt)))
+        rot[f"R2_{tag}"] = npy(rutil.quat_to_rmat(q2.to(dt)))
+        rot[f"log_{tag}"] = npy(rutil.log_rmat(Rd))
+        rot[f"scale_{tag}"] = npy(rutil.so3_scale(Rd, k.to(dt)))
+        rot[f"aa2r_{tag}"] = npy(rutil.aa_to_rmat(axis_in.to(dt), ang_in.to(dt)))
+        ax, an = rutil.rmat_to_aa(Rd)
+        rot[f"r2aa_axis_{tag}"] = npy(ax)
+        rot[f"r2aa_angle_{tag}"] = npy(an)
+        rot[f"lerp_{tag}"] = npy(rutil.so3_lerp(Rd, R2d, w.to(dt)))
+        rot[f"dist_{tag}"] = npy(rutil.rmat_dist(Rd, R2d))
+    # special cases: identity, exact pi rotations (util.py:500-512 smoke block)
+    eye = torch.eye(3)[None]
+    rot["log_eye"] = npy(rutil.log_rmat(eye))
+    np.savez(os.path.join(OUT, "rotation_ops.npz"), **rot)
+
+    # ------------------------------------------------------------ igso3 sample
+    samp = {}
+    torch.manual_seed(3)
+    with RNGRecorder() as rec:
+        d = rdist.IsotropicGaussianSO3(torch.tensor(0.5))
+        out = d.sample([B])
+    samp["scalar_eps"] = np.float32(0.5)
+    samp["scalar_trap"] = npy(d.trap[:, 0])
+    samp["scalar_axes"] = npy(rec.log[0][1])
+    samp["scalar_unif"] = npy(rec.log[1][1])
+    samp["scalar_out"] = npy(out)
+    eps_b = torch.rand(B) * 0.9 + 0.02
+    with RNGRecorder() as rec:
+        d = rdist.IsotropicGaussianSO3(eps_b)
+        out = d.sample()
+    samp["batched_eps"] = npy(eps_b)
+    samp["batched_trap"] = npy(d.trap.T.contiguous())
+    samp["batched_axes"] = npy(rec.log[0][1])
+    samp["batched_unif"] = npy(rec.log[1][1])
+    samp["batched_out"] = npy(out)
+    np.savez(os.path.join(OUT, "igso3_sample.npz"), **samp)
+
+    # ------------------------------------------------------- log_prob + score
+    lp = {}
+    g = torch.Generator().manual_seed(9)
+    Rl = rutil.quat_to_rmat(torch.randn(B, 4, generator=g))
+    # a few small-angle rotations as well
+    small = rutil.aa_to_rmat(torch.randn(8, 3, generator=g), torch.rand(8, 1, generator=g) * 0.2)
+    Rl = torch.cat([Rl, small])
+    lp["R"] = npy(Rl)
+    for i, e in enumerate((0.2, 0.5, 1.0)):
+        Rg = Rl.clone().requires_grad_(True)
+        d = rdist.IsotropicGaussianSO3(torch.tensor(e))
+        l = d.log_prob(Rg)
+        (gr,) = torch.autograd.grad(l.sum(), Rg)
+        lp[f"eps_{i}"] = np.float32(e)
+        lp[f"logp_{i}"] = npy(l)
+        lp[f"grad_{i}"] = npy(gr)
+    np.savez(os.path.join(OUT, "igso3_logprob.npz"), **lp)
+
+    # -------------------------------------------------------------- score MLP
+    torch.manual_seed(0)
+    net = rtrain.RotPredict(out_type="skewvec")
+    sd = net.state_dict()
+    mlp = {k_.replace(".", "_"): npy(v) for k_, v in sd.items()}
+    g = torch.Generator().manual_seed(21)
+    xin = rutil.quat_to_rmat(torch.randn(B, 4, generator=g))
+    tin = torch.randint(0, 1000, (B,), generator=g)
+    tgt = torch.randn(B, 3, generator=g)
+    out = net(xin, tin)
+    loss = torch.nn.functional.mse_loss(out, tgt)
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    mlp.update(x=npy(xin), t=npy(tin), target=npy(tgt), out=npy(out), loss=npy(loss),
+               out_t1=npy(net(xin, tin[:1])), emb=npy(net.time_embedding(tin)))
+    for (name, _), gr in zip(net.named_parameters(), grads):
+        mlp["grad_" + name.replace(".", "_")] = npy(gr)
+    net64 = rtrain.RotPredict(out_type="skewvec").double()
+    net64.load_state_dict({k_: v.double() for k_, v in sd.items()})
+    mlp["out_64"] = npy(net64(xin.double(), tin))
+    np.savez(os.path.join(OUT, "score_mlp.npz"), **mlp)
+
+    # ---------------------------------------------------------- training step
+    tr = {}
+    for T in (100, 1000):
+        for seed in (0, 1, 2):
+            torch.manual_seed(100 + seed)
+            x0 = rutil.quat_to_rmat(torch.randn(B, 4))
+            proc = rdiff.SO3Diffusion(net, timesteps=T, loss_type="skewvec")
+            captured = {}
+            orig_q = proc.q_sample
+
+            def q_spy(x_start, t, noise=None, _o=orig_q, _c=captured):
+                _c["noise"] = noise.detach().clone()
+                out_ = _o(x_start=x_start, t=t, noise=noise)
+                _c["x_t"] = out_.detach().clone()
+                return out_
+
+            proc.q_sample = q_spy
+            with RNGRecorder() as rec:
+                loss = proc(x0)
+            grads = torch.autograd.grad(loss, list(net.parameters()))
+            assert [n for n, _ in rec.log] == ["randint", "randn", "rand"], [n for n, _ in rec.log]
+            t = rec.log[0][1]
+            eps = proc.sqrt_one_minus_alphas_cumprod[t]
+            target = rutil.skew2vec(rutil.log_rmat(captured["noise"])) * (1 / eps)[..., None]
+            pre = f"T{T}_s{seed}_"
+            tr[pre + "x0"] = npy(x0)
+            tr[pre + "t"] = npy(t)
+            tr[pre + "axes"] = npy(rec.log[1][1])
+            tr[pre + "unif"] = npy(rec.log[2][1])
+            tr[pre + "noise"] = npy(captured["noise"])
+            tr[pre + "x_t"] = npy(captured["x_t"])
+            tr[pre + "target"] = npy(target)
+            tr[pre + "net_out"] = npy(net(captured["x_t"], t))
+            tr[pre + "loss"] = npy(loss)
+            tr[pre + "grad_flat"] = np.concatenate([npy(g_).ravel() for g_ in grads])
+    np.savez(os.path.join(OUT, "train_step.npz"), **tr)
+
+    # ---------------------------------------------- teacher-forced reverse steps
+    ps = {}
+    proc = rdiff.SO3Diffusion(net, timesteps=1000, loss_type="skewvec")
+    proc64 = rdiff.SO3Diffusion(net64, timesteps=1000, loss_type="skewvec").double()
+    torch.manual_seed(77)
+    xs = rutil.quat_to_rmat(torch.randn(B, 4))
+    ps["x"] = npy(xs)
+    for tval in (0, 1, 50, 500, 950, 998, 999):
+        tt = torch.full((B,), tval, dtype=torch.long)
+        pre = f"t{tval}_"
+        with torch.no_grad():
+            v = net(xs, tt)
+            x0hat = proc.predict_start_from_noise(xs, tt, v)
+            mean, _, logvar = proc.q_posterior(x0hat, xs, tt)
+            with RNGRecorder() as rec:
+                xprev = proc.p_sample(xs, tt)
+            ps[pre + "v"] = npy(v)
+            ps[pre + "x0hat"] = npy(x0hat)
+            ps[pre + "mean"] = npy(mean)
+            ps[pre + "xprev"] = npy(xprev)
+            sigma = (0.5 * logvar).exp()[0]
+            ps[pre + "sigma"] = npy(sigma)
+            # fp64 evaluation of the same fp32 inputs
+            v64 = net64(xs.double(), tt)
+            x0hat64 = proc64.predict_start_from_noise(xs.double(), tt, v64)
+            mean64, _, _ = proc64.q_posterior(x0hat64, xs.double(), tt)
+            ps[pre + "v_64"] = npy(v64)
+            ps[pre + "x0hat_64"] = npy(x0hat64)
+            ps[pre + "mean_64"] = npy(mean64)
+            # fp64 with the fp32 net output teacher-forced (isolates rotation math)
+            x0hat64f = proc64.predict_start_from_noise(xs.double(), tt, v.double())
+            mean64f, _, _ = proc64.q_posterior(x0hat64f, xs.double(), tt)
+            ps[pre + "x0hat_64f"] = npy(x0hat64f)
+            ps[pre + "mean_64f"] = npy(mean64f)
+            if tval > 0:
+                assert [n for n, _ in rec.log] == ["randn", "rand"]
+                axes, unif = rec.log[0][1], rec.log[1][1]
+                dist = rdist.IsotropicGaussianSO3(sigma)
+                with RNGReplay(rec.log):
+                    smp = dist.sample([B])
+                assert torch.equal(mean @ smp, xprev)
+                ax_s, ang_s = rutil.rmat_to_aa(smp)
+                ps[pre + "axes"] = npy(axes)
+                ps[pre + "unif"] = npy(unif)
+                ps[pre + "trap"] = npy(dist.trap[:, 0])
+                ps[pre + "sample"] = npy(smp)
+                # recover the sampled angle exactly as the reference computed it
+                with RNGReplay(rec.log):
+                    _ax = torch.randn(B, 3)
+                    _u = torch.rand(B)
+                idx_1 = (dist.trap <= _u[None, ...]).sum(dim=0)
+                idx_0 = torch.clamp(idx_1 - 1, min=0)
+                ts_ = torch.gather(dist.trap, 0, idx_0[..., None])[..., 0]
+                te_ = torch.gather(dist.trap, 0, idx_1[..., None])[..., 0]
+                wgt = torch.clamp((_u - ts_) / torch.clamp(te_ - ts_, min=1e-6), 0, 1)
+                ang = torch.lerp(dist.trap_loc[idx_0, 0], dist.trap_loc[idx_1, 0], wgt)
+                ps[pre + "angle"] = npy(ang)
+                smp64 = rutil.aa_to_rmat(axes.double(), ang.double()[:, None])
+                ps[pre + "xprev_64f"] = npy(mean64f @ smp64)
+            else:
+                assert rec.log == []
+                ps[pre + "xprev_64f"] = npy(mean64f)
+    np.savez(os.path.join(OUT, "p_sample_steps.npz"), **ps)
+
+    # ------------------------------------------------------ short reverse chain
+    ch = {}
+    T = 20
+    betas = cosine_beta_schedule(T)
+    proc = rdiff.SO3Diffusion(net, timesteps=T, loss_type="skewvec", betas=betas)
+    torch.manual_seed(5)
+    rdiff.tqdm = lambda it, **k: it
+    with torch.no_grad(), RNGRecorder() as rec:
+        xfin = proc.p_sample_loop((16,))
+    names = [n for n, _ in rec.log]
+    assert names == ["randn", "rand"] * T, names  # init pair + (T-1) step pairs
+    ch["betas"] = betas
+    ch["axes"] = np.stack([npy(rec.log[2 * i][1]) for i in range(T)])
+    ch["unif"] = np.stack([npy(rec.log[2 * i + 1][1]) for i in range(T)])
+    ch["x_final"] = npy(xfin)
+    np.savez(os.path.join(OUT, "p_sample_chain.npz"), **ch)
+
+    tot = 0
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            sz = os.path.getsize(os.path.join(OUT, f))
+            tot += sz
+            print(f"{f:28s} {sz/1024:8.1f} KB")
+    print("total KB", tot / 1024)
+
+
+if __name__ == "__main__":
+    main()
