@@ -1,0 +1,72 @@
+// so3x_common.hpp -- launch plumbing and AoS<->register staging shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/so3x.h"
+
+namespace so3x {
+
+constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kTile = 256;   // samples per block-iteration in the pointwise kernels
+
+// ~8 blocks per CU on 256 CUs, grid-stride over tiles beyond that (guide: G11)
+inline int grid_for_tiles(int64_t ntiles) { return (int)(ntiles < 2048 ? (ntiles < 1 ? 1 : ntiles) : 2048); }
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SO3X_OK : (int)e;
+}
+
+// The reference's tensors are AoS [n][W] fp32 (W = 9 rotations, 3 vectors, 4 quats):
+// a lane-per-sample access would be a 36-B-strided gather.  Instead the block moves
+// the tile's W*256 contiguous floats with 16-B-per-lane coalesced loads into LDS and
+// each lane then reads its W floats at stride W (W odd -> bank-conflict free).
+template <int W>
+__device__ __forceinline__ void tile_to_lds(const float* __restrict__ g, int64_t base, int cnt, float* lds) {
+  const float* src = g + base * W;
+  if (cnt == kTile && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int i = threadIdx.x; i < W * (kTile / 4); i += kBlock) d4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < cnt * W; i += kBlock) lds[i] = src[i];
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void lds_to_tile(float* __restrict__ g, int64_t base, int cnt, const float* lds) {
+  float* dst = g + base * W;
+  if (cnt == kTile && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* s4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+    for (int i = threadIdx.x; i < W * (kTile / 4); i += kBlock) d4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < cnt * W; i += kBlock) dst[i] = lds[i];
+  }
+}
+
+// Load this lane's W floats of tile sample threadIdx.x (block-wide; contains barriers).
+template <int W>
+__device__ __forceinline__ void load_rows(const float* __restrict__ g, int64_t base, int cnt, float* lds, float* r) {
+  __syncthreads();  // previous users of lds are done
+  tile_to_lds<W>(g, base, cnt, lds);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < W; j++) r[j] = lds[threadIdx.x * W + j];
+}
+
+template <int W>
+__device__ __forceinline__ void store_rows(float* __restrict__ g, int64_t base, int cnt, float* lds, const float* r) {
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < W; j++) lds[threadIdx.x * W + j] = r[j];
+  __syncthreads();
+  lds_to_tile<W>(g, base, cnt, lds);
+}
+
+// scalar-per-sample operand with stride 0 (broadcast) or 1
+__device__ __forceinline__ float load_scalar(const float* p, int64_t stride, int64_t i) { return p[i * stride]; }
+
+}  // namespace so3x

@@ -1,0 +1,275 @@
+// so3x_diffusion.hip -- fused SO3Diffusion steps:
+//   q_sample + training target (diffusion.py:339-355), reverse mean (291-313) and the
+//   chain-resident reverse sampler p_sample / p_sample_loop (315-337) with the score
+//   network on the matrix cores.
+#include "so3x_common.hpp"
+#include "so3x_math.hpp"
+#include "so3x_igso3.hpp"
+#include "so3x_mlp.hpp"
+
+using namespace so3x;
+using namespace so3x::mlp;
+
+namespace {
+
+// rows of the [13][T] schedule table (so3x_schedule_from_betas)
+enum { S_SQRT_AC = 3, S_SQRT_1MAC = 4, S_RECIP = 6, S_RECIPM1 = 7, S_COEF1 = 10, S_COEF2 = 11, S_SIGMA = 12 };
+
+// ---------------------------------------------------------------------------------------
+// A12: noise draw + forward noising + regression target, one pass, 84 B/sample algorithmic
+// (36 x0 in, 36 x_t + 12 target out; +8 for t).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q, const float* __restrict__ x0,
+                  const int64_t* __restrict__ t, int quirk_col0, const float* __restrict__ noise_in,
+                  const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
+                  int64_t index_base, float* __restrict__ x_t, float* __restrict__ target, float* __restrict__ noise_out,
+                  int64_t n) {
+  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  const int64_t wrow_t = quirk_col0 ? t[0] : -1;  // distributions.py:42-43: column 0 == sample 0's eps
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTile;
+    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
+    const int64_t idx = base + threadIdx.x;
+    const bool live = threadIdx.x < cnt;
+    const int64_t tt = t[live ? idx : base];
+    float nz[9];
+    if (noise_in) {
+      load_rows<9>(noise_in, base, cnt, sm, nz);
+    } else {
+      float ax[3], u;
+      if (axes) {
+        float a[3];
+        load_rows<3>(axes, base, cnt, sm, a);
+        float nrm = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);       // distributions.py:36
+        ax[0] = a[0] / nrm; ax[1] = a[1] / nrm; ax[2] = a[2] / nrm;
+        float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // util.py:201
+        ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
+        u = live ? unif[idx] : 0.5f;
+      } else {
+        Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
+        unit_axis(r.x, r.y, ax);
+        u = u01(r.z);
+      }
+      const float* row = trap_q + tt * 999;
+      const float* wrow = wrow_t >= 0 ? trap_q + wrow_t * 999 : row;
+      const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u);
+      exp_axis_angle(ax, ang, nz);
+    }
+    float x[9], w[3], xs[9], xt[9];
+    load_rows<9>(x0, base, cnt, sm, x);
+    const float k = sched[S_SQRT_AC * T + tt];
+    log3(x, w);
+    w[0] *= k; w[1] *= k; w[2] *= k;
+    exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
+    mul33(xs, nz, xt);                // x_blend @ noise, :346
+    if (x_t) store_rows<9>(x_t, base, cnt, sm, xt);
+    if (target) {
+      float lw[3];
+      log3(nz, lw);                   // skew2vec(log_rmat(noise)) * (1/eps), :355
+      const float ie = 1.0f / sched[S_SQRT_1MAC * T + tt];
+      float tg[3] = {lw[0] * ie, lw[1] * ie, lw[2] * ie};
+      store_rows<3>(target, base, cnt, sm, tg);
+    }
+    if (noise_out) store_rows<9>(noise_out, base, cnt, sm, nz);
+  }
+}
+
+// reverse mean of one sample: predict_start_from_noise (diffusion.py:291-297) then
+// q_posterior (299-302).  log(x) is evaluated once (the reference does it twice, 292 & 301).
+__device__ __forceinline__ void p_mean_one(const float* x, const float* v, float a, float b, float c1, float c2,
+                                           float* x0hat, float* mean) {
+  float w[3], wa[3], xa[9], nv[3], nt[9], wh[3], e1[9], e2[9];
+  log3(x, w);
+  wa[0] = w[0] * a; wa[1] = w[1] * a; wa[2] = w[2] * a;
+  exp3(wa, xa);
+  nv[0] = v[0] * b; nv[1] = v[1] * b; nv[2] = v[2] * b;
+  exp3(nv, nt);
+  mul33_bt(xa, nt, x0hat);
+  log3(x0hat, wh);
+  wh[0] *= c1; wh[1] *= c1; wh[2] *= c1;
+  exp3(wh, e1);
+  w[0] *= c2; w[1] *= c2; w[2] *= c2;
+  exp3(w, e2);
+  mul33(e1, e2, mean);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, const float* __restrict__ v, int t,
+         float* __restrict__ x0hat, float* __restrict__ mean, int64_t n) {
+  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
+  const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t], c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTile;
+    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
+    float xx[9], vv[3], xh[9], mm[9];
+    load_rows<9>(x, base, cnt, sm, xx);
+    load_rows<3>(v, base, cnt, sm, vv);
+    p_mean_one(xx, vv, a, b, c1, c2, xh, mm);
+    if (x0hat) store_rows<9>(x0hat, base, cnt, sm, xh);
+    store_rows<9>(mean, base, cnt, sm, mm);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// A13: chain-resident reverse sampler.
+//  * one wave owns 64 samples; each lane keeps its rotation in 9 VGPRs for ALL n_steps
+//    steps (HBM traffic for a whole chain: 72 B/sample);
+//  * the score network runs on the matrix cores as two 32-sample tiles per wave, weights
+//    LDS-resident (so3x_mlp.hpp); the time embedding enters as a per-timestep effective
+//    bias row (prep kernel), so the per-step reads are: 96 floats of bias, 5 schedule
+//    scalars, the 4 KB CDF row of sigma_t (L1/L2-resident, shared by every wave);
+//  * waves never synchronise with each other after the weight image is loaded;
+//  * noise: Philox keyed (seed; global sample index, rng_offset + t) or explicit draws.
+// ---------------------------------------------------------------------------------------
+template <int PREC>
+__global__ void __launch_bounds__(256, 2)
+k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ sched, int T,
+                 const float* __restrict__ trap_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
+                 int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
+                 uint64_t rng_offset, int64_t index_base, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  load_image(gimg, lds, image_bytes<PREC, CHAIN>());
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int64_t nchunks = (n + 63) / 64;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const int64_t idx = chunk * 64 + lane;
+    const bool live = idx < n;
+    const int64_t idc = live ? idx : n - 1;
+    float R[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) R[j] = x_in[idc * 9 + j];
+#pragma unroll 1
+    for (int s = 0; s < n_steps; s++) {
+      const int t = t_start - s;
+      const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t];
+      const float c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
+      // ---- score network: v = RotPredict(x, t)  (diffusion.py:309)
+      float xs[9], xa[9], xb[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        xs[j] = __shfl_xor(R[j], 32);
+        xa[j] = h ? xs[j] : R[j];  // tile A = samples 0..31 of the chunk: column c lives in lane c
+        xb[j] = h ? R[j] : xs[j];  // tile B = samples 32..63: column c lives in lane 32 + c
+      }
+      const float* beff = beff_tab + (size_t)t * 96;
+      float va[3], vb[3], v[3];
+      forward_tile<PREC, CHAIN>(lds, xa, beff, 0, nullptr, va, lane);
+      forward_tile<PREC, CHAIN>(lds, xb, beff, 0, nullptr, vb, lane);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float o = __shfl_xor(vb[j], 32);  // tile B results sit in lanes 0..31, owners are lanes 32..63
+        v[j] = h ? o : va[j];
+      }
+      // ---- posterior mean (diffusion.py:310-311)
+      float xh[9], mean[9];
+      p_mean_one(R, v, a, b, c1, c2, xh, mean);
+      if (t == 0) {  // diffusion.py:320-321 -- no noise at t == 0
+#pragma unroll
+        for (int j = 0; j < 9; j++) R[j] = mean[j];
+      } else {
+        float ax[3], u;
+        if (axes) {
+          float a0 = axes[idc * 3], a1 = axes[idc * 3 + 1], a2 = axes[idc * 3 + 2];
+          float nrm = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+          ax[0] = a0 / nrm; ax[1] = a1 / nrm; ax[2] = a2 / nrm;
+          float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+          ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
+          u = unif[idc];
+        } else {
+          Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset + (uint64_t)t);
+          unit_axis(r.x, r.y, ax);
+          u = u01(r.z);
+        }
+        const float* row = trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
+        const float ang = igso3_angle(row, row, SO3X_KNOTS_DATA, u);
+        float nz[9];
+        exp_axis_angle(ax, ang, nz);
+        mul33(mean, nz, R);                            // model_mean @ sample, :326
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) x_out[idx * 9 + j] = R[j];
+    }
+  }
+}
+
+template <int PREC>
+int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
+                 const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                 uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
+  constexpr int IMG = image_bytes<PREC, CHAIN>();
+  static int attr_set = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p_sample_chain<PREC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
+    if (e != hipSuccess) return (int)e;
+    attr_set = 1;
+  }
+  const int64_t nchunks = (n + 63) / 64;
+  const int64_t want = (nchunks + 3) / 4;
+  const int max_blocks = IMG > 80 * 1024 ? 256 : 512;  // LDS-limited: 1 or 2 resident blocks per CU
+  const int grid = (int)(want < max_blocks ? want : max_blocks);
+  hipLaunchKernelGGL((k_p_sample_chain<PREC>), dim3(grid), dim3(256), IMG, s, ws, beff, sched, T, trap_p, x_in, x_out,
+                     t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
+  return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const float* x0, const int64_t* t,
+                         int quirk_col0, const float* noise_in, const float* axes, const float* unif, uint64_t seed,
+                         uint64_t rng_offset, int64_t index_base, float* x_t, float* target, float* noise_out, int64_t n) {
+  if (n < 0 || T <= 0 || (n && (!sched || !x0 || !t)) || (n && !noise_in && !trap_q) ||
+      ((axes == nullptr) != (unif == nullptr)))
+    return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_q_sample_target, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, sched,
+                     T, trap_q, x0, t, quirk_col0, noise_in, axes, unif, seed, rng_offset, index_base, x_t, target, noise_out, n);
+  return check_launch();
+}
+
+int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, const float* v, int t, float* x0hat,
+                float* mean, int64_t n) {
+  if (n < 0 || T <= 0 || t < 0 || t >= T || (n && (!sched || !x || !v || !mean))) return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_p_mean, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, sched, T, x, v,
+                     t, x0hat, mean, n);
+  return check_launch();
+}
+
+size_t so3x_p_sample_workspace_bytes(int T, int precision) {
+  const int p = precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16;
+  return beff_offset(p, CHAIN) + (size_t)(T > 0 ? T : 0) * 96 * sizeof(float);
+}
+
+int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,
+                        const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                        uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, int precision, void* workspace,
+                        size_t workspace_bytes) {
+  if (n < 0 || T <= 0 || n_steps < 0 || t_start < 0 || t_start >= T || t_start - n_steps + 1 < 0 ||
+      (n && (!params || !sched || !trap_p || !x_in || !x_out)) || ((axes == nullptr) != (unif == nullptr)) ||
+      (axes && n_steps > 1))
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < so3x_p_sample_workspace_bytes(T, precision)) return SO3X_ERR_WORKSPACE;
+  if (n == 0 || n_steps == 0) return SO3X_OK;
+  int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace);
+  if (rc) return rc;
+  const float* beff = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + beff_offset(precision, CHAIN));
+  if (precision == SO3X_PREC_F32)
+    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes,
+                                       unif, seed, rng_offset, index_base, n);
+  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, beff, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes,
+                                      unif, seed, rng_offset, index_base, n);
+}
+
+}  // extern "C"

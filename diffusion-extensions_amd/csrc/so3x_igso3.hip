@@ -1,0 +1,207 @@
+// so3x_igso3.hip -- isotropic Gaussian on SO(3): density, CDF tables, inverse-CDF
+// sampling, log-prob + score (reference distributions.py:8-81).
+#include "so3x_common.hpp"
+#include "so3x_math.hpp"
+#include "so3x_igso3.hpp"
+
+using namespace so3x;
+
+namespace {
+
+// ------------------------------------------------------------------ A1 pointwise
+__global__ void __launch_bounds__(kBlock)
+k_eps_ft(const float* __restrict__ omega, const float* __restrict__ eps, int64_t eps_stride, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = (float)eps_ft_f64((double)omega[i], (double)eps[i * eps_stride]);
+}
+
+// ------------------------------------------------------------------ A2 table build
+// One 256-thread block per CDF row.  fp64 pdf at the 1000 knots, fp32 Haar product
+// and trapezoid terms, double-accumulated prefix sum (torch's CPU cumsum accumulates
+// fp32 in double; pinned by the goldens), fp32 normalisation.  distributions.py:15-30.
+__global__ void __launch_bounds__(kBlock) k_build_tables(const float* __restrict__ eps, float* __restrict__ trap) {
+  __shared__ float pdf[1024];
+  __shared__ double wave_tot[4];
+  __shared__ float s_last;
+  const int row = blockIdx.x;
+  const double e = (double)eps[row];
+  for (int k = threadIdx.x; k < 1000; k += kBlock) {
+    float f = (float)eps_ft_f64((double)SO3X_KNOTS_DATA[k], e);   // .float() at :72
+    float p = f * SO3X_HAAR_W_DATA[k];                             // fp32 product, :21
+    if (SO3X_KNOTS_DATA[k] == 0.0f) p = 0.0f;                      // :23
+    pdf[k] = p;
+  }
+  __syncthreads();
+  // each thread owns 4 consecutive trapezoid terms (999 = 4*249 + 3)
+  double loc[4];
+  double run = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int k = 4 * threadIdx.x + j;
+    float term = 0.0f;
+    if (k < 999) {
+      float sum = pdf[k] + pdf[k + 1];                             // :26
+      float dl = SO3X_KNOTS_DATA[k + 1] - SO3X_KNOTS_DATA[k];      // :27
+      term = dl * sum / 2.0f;                                      // :28
+    }
+    run += (double)term;
+    loc[j] = run;
+  }
+  // inclusive scan of the per-thread totals: wave shuffles, then 4 wave totals via LDS
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  double pre = incl - run;
+  for (int w = 0; w < wid; w++) pre += wave_tot[w];
+  float vals[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) vals[j] = (float)(pre + loc[j]);     // cumsum output cast, :28
+  if (threadIdx.x == 249) s_last = vals[2];                         // k = 998
+  __syncthreads();
+  const float last = s_last;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int k = 4 * threadIdx.x + j;
+    if (k < 999) trap[(int64_t)row * 999 + k] = vals[j] / last;    // :29
+  }
+}
+
+// ------------------------------------------------------------------ A2 sampling
+__global__ void __launch_bounds__(kBlock)
+k_igso3_sample(const float* __restrict__ trap, const int64_t* __restrict__ row_idx, int64_t row_const, int quirk_col0,
+               const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
+               int64_t index_base, const float* __restrict__ mean, float* __restrict__ out, float* __restrict__ angle_out,
+               float* __restrict__ axis_out, int64_t n) {
+  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  const int64_t wrow_i = (quirk_col0 && row_idx) ? row_idx[0] : -1;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTile;
+    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
+    const int64_t idx = base + threadIdx.x;
+    const bool live = threadIdx.x < cnt;
+    float ax[3], u;
+    if (axes) {
+      float a[3];
+      load_rows<3>(axes, base, cnt, sm, a);
+      float nrm = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);   // distributions.py:36
+      ax[0] = a[0] / nrm; ax[1] = a[1] / nrm; ax[2] = a[2] / nrm;
+      float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // util.py:201 renormalises
+      ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
+      u = live ? unif[idx] : 0.5f;
+    } else {
+      Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
+      unit_axis(r.x, r.y, ax);
+      u = u01(r.z);
+    }
+    const int64_t ri = live ? (row_idx ? row_idx[idx] : row_const) : (row_idx ? row_idx[base] : row_const);
+    const float* row = trap + ri * 999;
+    const float* wrow = wrow_i >= 0 ? trap + wrow_i * 999 : row;
+    float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u);
+    float r9[9], o[9];
+    exp_axis_angle(ax, ang, r9);
+    if (mean) {
+      float m[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) m[j] = mean[j];
+      mul33(m, r9, o);                                              // distributions.py:50
+    } else {
+#pragma unroll
+      for (int j = 0; j < 9; j++) o[j] = r9[j];
+    }
+    if (angle_out && live) angle_out[idx] = ang;
+    if (axis_out) store_rows<3>(axis_out, base, cnt, sm, ax);
+    store_rows<9>(out, base, cnt, sm, o);
+  }
+}
+
+// ------------------------------------------------------------------ A3 log-prob + score
+// 56 algorithmic bytes per evaluation (36 R + 4 eps in, 4 logp + 12 score out): HBM-bound
+// by design.  The density is evaluated in fp64 exactly as the reference does
+// (distributions.py:53-72), cast to fp32, then log'd in fp32 (:77).
+__global__ void __launch_bounds__(kBlock)
+k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int64_t eps_stride, float* __restrict__ logp,
+                float* __restrict__ score_vec, float* __restrict__ grad_R, int64_t n) {
+  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTile;
+    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
+    const int64_t idx = base + threadIdx.x;
+    const bool live = threadIdx.x < cnt;
+    float r[9], w[3];
+    load_rows<9>(R, base, cnt, sm, r);
+    const float e = live ? eps[idx * eps_stride] : 1.0f;
+    log3(r, w);
+    const float ang = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);   // rmat_to_aa angle, util.py:217
+    double dlogf;
+    const float f = (float)eps_ft_and_dlog_f64((double)ang, (double)e, &dlogf);
+    if (live) logp[idx] = logf(f);
+    const float dl = (float)dlogf;
+    if (score_vec) {
+      float sv[3] = {dl * (w[0] / ang), dl * (w[1] / ang), dl * (w[2] / ang)};
+      store_rows<3>(score_vec, base, cnt, sm, sv);
+    }
+    if (grad_R) {
+      // d omega / dR = [ c/(4s) (R - R^T) - (s/2) I ] / (s^2 + c^2)   
+      float v0 = r[7] - r[5], v1 = r[2] - r[6], v2 = r[3] - r[1];
+      float s = sqrtf(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
+      float c = (r[0] + r[4] + r[8] - 1.0f) * 0.5f;
+      float inv = dl / (s * s + c * c);
+      float k = c / (4.0f * s);
+      float g[9];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) g[3 * i + j] = (k * (r[3 * i + j] - r[3 * j + i]) - (i == j ? 0.5f * s : 0.0f)) * inv;
+      store_rows<9>(grad_R, base, cnt, sm, g);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int so3x_igso3_eps_ft(so3x_stream_t s, const float* omega, const float* eps, int64_t eps_stride, float* out, int64_t n) {
+  if (n < 0 || (n && (!omega || !eps || !out)) || (eps_stride != 0 && eps_stride != 1)) return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_eps_ft, dim3(grid_for_tiles((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)s, omega, eps,
+                     eps_stride, out, n);
+  return check_launch();
+}
+
+int so3x_igso3_build_tables(so3x_stream_t s, const float* eps, int64_t n_rows, float* trap) {
+  if (n_rows < 0 || n_rows > 0x7fffffff || (n_rows && (!eps || !trap))) return SO3X_ERR_INVALID_ARG;
+  if (n_rows == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_build_tables, dim3((unsigned)n_rows), dim3(kBlock), 0, (hipStream_t)s, eps, trap);
+  return check_launch();
+}
+
+int so3x_igso3_sample(so3x_stream_t s, const float* trap, const int64_t* row_idx, int64_t row_const, int quirk_col0,
+                      const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset, int64_t index_base,
+                      const float* mean, float* out, float* angle_out, float* axis_out, int64_t n) {
+  if (n < 0 || (n && (!trap || !out)) || ((axes == nullptr) != (unif == nullptr)) || row_const < 0)
+    return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_igso3_sample, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, trap,
+                     row_idx, row_const, quirk_col0, axes, unif, seed, rng_offset, index_base, mean, out, angle_out, axis_out, n);
+  return check_launch();
+}
+
+int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, int64_t eps_stride, float* logp,
+                             float* score_vec, float* grad_R, int64_t n) {
+  if (n < 0 || (n && (!R || !eps || !logp)) || (eps_stride != 0 && eps_stride != 1)) return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_logprob_score, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, R, eps,
+                     eps_stride, logp, score_vec, grad_R, n);
+  return check_launch();
+}
+
+}  // extern "C"

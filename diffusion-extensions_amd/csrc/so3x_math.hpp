@@ -1,0 +1,178 @@
+// so3x_math.hpp -- per-sample SO(3) device math shared by every kernel.
+//
+// One lane = one rotation held in 9 VGPRs (row-major).  The closed forms replace
+// the reference's generic torch.matrix_exp / torch.svd (util.py:204,360,105):
+//   log  : atan2 form of util.py:164-192 (+ skew2vec, util.py:79-84)
+//   exp  : Rodrigues  I + A K + B K^2  for torch.matrix_exp(vec2skew(w))
+// Everything is fp32 (the reference's working precision); no fast-math, NaN
+// semantics of the reference (axis = 0/0 at angle 0) are kept where documented.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace so3x {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+// sin and cos of an fp32 angle with a 3-term Cody-Waite reduction by pi/2 done with FMAs
+// (the product k*hi is not rounded inside an fma), then the classic degree-7/8 minimax
+// polynomials on [-pi/4, pi/4].  Absolute error ~1e-7 for |a| < 1e5 rad, which covers every
+// angle on the path: time-embedding angles t*freq <= T, and Rodrigues angles up to
+// pi*sqrt(1/abar_T) ~ 6.4e4 with the cosine schedule.  Replaces ocml's
+// sincosf (whose Payne-Hanek slow path costs ~100 VGPRs once inlined 5x per sample-step).
+__device__ __forceinline__ void sincos_cw(float a, float* sn, float* cs) {
+  const float k = rintf(a * 0x1.45f306p-1f);
+  float r = fmaf(-k, 0x1.921fb6p+0f, a);
+  r = fmaf(-k, -0x1.777a5cp-25f, r);
+  r = fmaf(-k, -0x1.ee59dap-50f, r);
+  const int q = (int)k;
+  const float z = r * r;
+  const float S = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float C = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                       fmaf(-0.5f, z, 1.0f));
+  const float s1 = (q & 1) ? C : S;
+  const float c1 = (q & 1) ? S : C;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// vee(R - R^T)-based log, as a 3-vector.  util.py:164-192.
+//   s = |v|/2, c = (tr R - 1)/2, angle = atan2(s, c), w = v * angle/(2 s);
+//   angle == 0 -> 0 (util.py:174).  s == 0 with c < 0 (exact pi) is the reference's
+//   eigh branch (util.py:178-191, which takes an eigenvector ROW -- a reference bug);
+//   the correct axis from diag((R+I)/2) is used instead (parity unpinned there).
+__device__ __forceinline__ void log3(const float* R, float* w) {
+  float v0 = R[7] - R[5], v1 = R[2] - R[6], v2 = R[3] - R[1];
+  float s = sqrtf(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
+  float c = (R[0] + R[4] + R[8] - 1.0f) * 0.5f;
+  float ang = atan2f(s, c);
+  float scale = ang / (2.0f * s);
+  if (ang == 0.0f) scale = 0.0f;
+  w[0] = scale * v0; w[1] = scale * v1; w[2] = scale * v2;
+  if (s == 0.0f && ang != 0.0f) {  // exact pi rotation: rare, divergent on purpose
+    float d0 = (R[0] + 1.f) * 0.5f, d1 = (R[4] + 1.f) * 0.5f, d2 = (R[8] + 1.f) * 0.5f;
+    float a0, a1, a2;
+    if (d0 >= d1 && d0 >= d2) { a0 = sqrtf(d0); a1 = (R[1] + R[3]) / (4.f * a0); a2 = (R[2] + R[6]) / (4.f * a0); }
+    else if (d1 >= d2)        { a1 = sqrtf(d1); a0 = (R[1] + R[3]) / (4.f * a1); a2 = (R[5] + R[7]) / (4.f * a1); }
+    else                      { a2 = sqrtf(d2); a0 = (R[2] + R[6]) / (4.f * a2); a1 = (R[5] + R[7]) / (4.f * a2); }
+    w[0] = ang * a0; w[1] = ang * a1; w[2] = ang * a2;
+  }
+}
+
+// exp(hat(w)); hat per util.py:87-92.  |w| reaches ~6e4 rad at t = T-1
+// (sqrt_recip_alphas_cumprod = 20291), hence sincos_cw.
+__device__ __forceinline__ void exp3(const float* w, float* R) {
+  float x = w[0], y = w[1], z = w[2];
+  float t2 = x * x + y * y + z * z;
+  float th = sqrtf(t2);
+  float A, B;
+  if (th < 1e-4f) {
+    A = 1.0f - t2 * (1.0f / 6.0f);
+    B = 0.5f - t2 * (1.0f / 24.0f);
+  } else {
+    float sn, cs;
+    sincos_cw(th, &sn, &cs);
+    A = sn / th;
+    B = (1.0f - cs) / t2;
+  }
+  R[0] = 1.0f + B * (x * x - t2); R[1] = B * x * y - A * z;       R[2] = B * x * z + A * y;
+  R[3] = B * x * y + A * z;       R[4] = 1.0f + B * (y * y - t2); R[5] = B * y * z - A * x;
+  R[6] = B * x * z - A * y;       R[7] = B * y * z + A * x;       R[8] = 1.0f + B * (z * z - t2);
+}
+
+// exp(hat(axis * ang)) for a UNIT axis and ang in [0, pi] (noise rotations).
+__device__ __forceinline__ void exp_axis_angle(const float* ax, float ang, float* R) {
+  float sn, cs;
+  sincos_cw(ang, &sn, &cs);
+  float x = ax[0], y = ax[1], z = ax[2], C = 1.0f - cs;
+  R[0] = 1.0f + C * (x * x - 1.0f); R[1] = C * x * y - sn * z;        R[2] = C * x * z + sn * y;
+  R[3] = C * x * y + sn * z;        R[4] = 1.0f + C * (y * y - 1.0f); R[5] = C * y * z - sn * x;
+  R[6] = C * x * z - sn * y;        R[7] = C * y * z + sn * x;        R[8] = 1.0f + C * (z * z - 1.0f);
+}
+
+__device__ __forceinline__ void mul33(const float* a, const float* b, float* o) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+__device__ __forceinline__ void mul33_bt(const float* a, const float* b, float* o) {  // a @ b^T
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      o[3 * i + j] = a[3 * i] * b[3 * j] + a[3 * i + 1] * b[3 * j + 1] + a[3 * i + 2] * b[3 * j + 2];
+}
+__device__ __forceinline__ void mul33_at(const float* a, const float* b, float* o) {  // a^T @ b
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) o[3 * i + j] = a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
+}
+
+// quat_to_rmat, util.py:222-252
+__device__ __forceinline__ void quat_to_rmat(const float* q, float* o) {
+  float r = q[0], i = q[1], j = q[2], k = q[3];
+  float ts = 2.0f / (r * r + i * i + j * j + k * k);
+  o[0] = 1.f - ts * (j * j + k * k); o[1] = ts * (i * j - k * r);       o[2] = ts * (i * k + j * r);
+  o[3] = ts * (i * j + k * r);       o[4] = 1.f - ts * (i * i + k * k); o[5] = ts * (j * k - i * r);
+  o[6] = ts * (i * k - j * r);       o[7] = ts * (j * k + i * r);       o[8] = 1.f - ts * (i * i + j * j);
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG: (seed) key, (sample index, stream offset) counter -> 4 x u32.
+// Results depend only on (seed, global sample index, offset): identical for any
+// launch geometry or number of GPUs.
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+
+// [0,1) with 24 random bits, the granularity of torch.rand for fp32 (distributions.py:38)
+__device__ __forceinline__ float u01(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+// Uniform direction on S^2 from two uniforms: distributionally identical to the
+// reference's normalised Gaussian 3-vector (distributions.py:35-36) at 2 draws, not 3.
+__device__ __forceinline__ void unit_axis(uint32_t a, uint32_t b, float* ax) {
+  float z = 2.0f * u01(a) - 1.0f + (1.0f / 16777216.0f);  // centred: z in (-1, 1)
+  float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+  float sn, cs;
+  sincos_cw(2.0f * kPi * u01(b), &sn, &cs);
+  ax[0] = r * cs; ax[1] = r * sn; ax[2] = z;
+}
+
+// Inverse-CDF angle, distributions.py:39-49, on one CDF row (999 fp32, global or LDS)
+// and the 1000 knot angles.  wrow = the row the interpolation weight is gathered from
+// (== row unless the column-0 quirk is on).
+__device__ __forceinline__ float igso3_angle(const float* row, const float* wrow, const float* knots, float u) {
+  int lo = 0, hi = 999;  // idx1 = #{k : row[k] <= u}  (row is non-decreasing)
+#pragma unroll 1
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (row[mid] <= u) lo = mid + 1; else hi = mid;
+  }
+  int idx1 = lo > 998 ? 998 : lo;  // row[998] == 1 > u, so this clamp never bites
+  int idx0 = idx1 - 1 < 0 ? 0 : idx1 - 1;
+  float ts = wrow[idx0], te = wrow[idx1];
+  float df = fmaxf(te - ts, 1e-6f);
+  float wt = fminf(fmaxf((u - ts) / df, 0.0f), 1.0f);
+  float a0 = knots[idx0 + 1], a1 = knots[idx1 + 1];
+  float dl = a1 - a0;
+  return wt < 0.5f ? a0 + wt * dl : a1 - dl * (1.0f - wt);  // torch.lerp's two-sided form
+}
+
+}  // namespace so3x

@@ -1,0 +1,162 @@
+// so3x_mlp.hip -- standalone score-network ops: weight-image prep, forward, backward.
+#include <math.h>
+#include "so3x_common.hpp"
+#include "so3x_mlp.hpp"
+
+using namespace so3x;
+using namespace so3x::mlp;
+
+namespace so3x {
+namespace mlp {
+
+const Freqs& host_freqs() {
+  static const Freqs fr = [] {
+    Freqs f;
+    so3x_posemb_freqs(NFREQ, f.f);
+    return f;
+  }();
+  return fr;
+}
+
+size_t image_bytes_rt(int precision, int variant) {
+  if (precision == SO3X_PREC_F32) return variant == CHAIN ? image_bytes<SO3X_PREC_F32, CHAIN>() : image_bytes<SO3X_PREC_F32, FULL>();
+  return variant == CHAIN ? image_bytes<SO3X_PREC_BF16, CHAIN>() : image_bytes<SO3X_PREC_BF16, FULL>();
+}
+size_t beff_offset(int precision, int variant) { return (image_bytes_rt(precision, variant) + 255) & ~(size_t)255; }
+
+}  // namespace mlp
+}  // namespace so3x
+
+namespace {
+
+// ---- prep: flat state_dict parameters -> permuted/padded weight image ----------------
+template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image(const float* __restrict__ params, void* __restrict__ img) {
+  constexpr int NF = n_frags<PREC, VAR>();
+  constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;  // elements per lane per fragment
+  const int total = NF * 64 * EPL;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
+    const float v = image_value<PREC, VAR>(params, frag, lane, j);
+    if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
+    else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
+  }
+}
+
+// ---- prep: per-timestep effective bias of layer 0 (appendix C.3) ---------------------
+//   beff[t][o] = b_0[o] + sum_e W_0[o][9+e] * emb_e(t)   (o < 65), other rows 0.
+__global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ params, Freqs fr, int T, float* __restrict__ beff) {
+  __shared__ float emb[NEMB];
+  const int t = blockIdx.x;
+  if (threadIdx.x < NEMB) emb[threadIdx.x] = emb_value((int64_t)t, threadIdx.x, fr);
+  __syncthreads();
+  const int o = threadIdx.x;
+  if (o < 96) {
+    float acc = 0.0f;
+    if (o < D) {
+      const float* W = params + o * D + 9;
+      acc = params[D * D + o];
+#pragma unroll 8
+      for (int e = 0; e < NEMB; e++) acc = fmaf(W[e], emb[e], acc);
+    }
+    beff[(size_t)t * 96 + o] = acc;
+  }
+}
+
+// ---- standalone forward ---------------------------------------------------------------
+// 4 waves per block; each wave walks 32-sample tiles.  Both lanes of a sample column read
+// the sample's 9 rotation entries straight from global (36-B stride; compute-bound kernel).
+template <int PREC, int VAR>
+__global__ void __launch_bounds__(256, 2)
+k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
+          const int64_t* __restrict__ t, int64_t t_stride, Freqs fr, float* __restrict__ out, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  load_image(gimg, lds, image_bytes<PREC, VAR>());
+  __syncthreads();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    int64_t idx = tile * 32 + col;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    float x[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) x[j] = R[idx * 9 + j];
+    const int64_t tt = t[idx * t_stride];
+    float v[3];
+    forward_tile<PREC, VAR>(lds, x, VAR == CHAIN ? beff_tab + (size_t)tt * 96 : nullptr, tt, &fr, v, lane);
+    if (live && h == 0) { out[idx * 3] = v[0]; out[idx * 3 + 1] = v[1]; out[idx * 3 + 2] = v[2]; }
+  }
+}
+
+template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws) {
+  hipLaunchKernelGGL((k_prep_image<PREC, VAR>), dim3(32), dim3(256), 0, s, params, ws);
+  if (VAR == CHAIN && T > 0) {
+    float* beff = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR));
+    hipLaunchKernelGGL(k_prep_beff, dim3(T), dim3(128), 0, s, params, host_freqs(), T, beff);
+  }
+  return check_launch();
+}
+
+template <int PREC, int VAR>
+int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n) {
+  constexpr int IMG = image_bytes<PREC, VAR>();
+  static int attr_set = 0;  // idempotent: raising the dynamic-LDS cap of this kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<PREC, VAR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
+    if (e != hipSuccess) return (int)e;
+    attr_set = 1;
+  }
+  const int64_t ntiles = (n + 31) / 32;
+  const int64_t want = (ntiles + 3) / 4;
+  const int max_blocks = IMG > 80 * 1024 ? 256 : 512;  // LDS-limited residency: 1 or 2 blocks per CU
+  const int grid = (int)(want < max_blocks ? want : max_blocks);
+  hipLaunchKernelGGL((k_mlp_fwd<PREC, VAR>), dim3(grid), dim3(256), IMG, s, ws, (const float*)nullptr, R, t, t_stride,
+                     host_freqs(), out, n);
+  return check_launch();
+}
+
+}  // namespace
+
+namespace so3x {
+namespace mlp {
+int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace) {
+  if (precision == SO3X_PREC_F32)
+    return variant == CHAIN ? launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace)
+                            : launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace);
+  return variant == CHAIN ? launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace)
+                          : launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace);
+}
+}  // namespace mlp
+}  // namespace so3x
+
+extern "C" {
+
+size_t so3x_mlp_workspace_bytes(int64_t n, int precision) {
+  (void)n;
+  // weight image (FULL variant) + backward scratch (partial-gradient slabs, see so3x_mlp_bwd)
+  return beff_offset(precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16, FULL) + (size_t)512 * NPARAMS * sizeof(float);
+}
+
+int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
+                 int64_t n, int precision, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !out)) || (t_stride != 0 && t_stride != 1)) return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < image_bytes_rt(precision, FULL)) return SO3X_ERR_WORKSPACE;
+  if (n == 0) return SO3X_OK;
+  int rc = launch_prep((hipStream_t)s, params, precision, FULL, 0, workspace);
+  if (rc) return rc;
+  if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);
+  return launch_fwd_t<SO3X_PREC_BF16, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);
+}
+
+int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride,
+                 const float* dout, float* dparams, int64_t n, int precision, void* workspace, size_t workspace_bytes) {
+  (void)s; (void)params; (void)R; (void)t; (void)t_stride; (void)dout; (void)dparams; (void)n; (void)precision;
+  (void)workspace; (void)workspace_bytes;
+  return SO3X_ERR_UNSUPPORTED;  // TODO(next commit): fused recompute backward
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// so3x_mlp.hpp -- the RotPredict score network (so3_train.py:11-49, models.py:13-25)
+// on the CDNA4 matrix cores, shared by so3x_mlp.hip (standalone fwd/bwd) and
+// so3x_diffusion.hip (fused reverse chain).
+//
+// Orientation: H_{l+1}[feature, sample] = W_l . H_l with the
+// WEIGHTS as the MFMA A operand and the ACTIVATIONS as the B operand.  A 32x32 result
+// tile then has its sample on the lane (col = lane & 31) and its 32 features in the 16
+// accumulator registers of the two lane halves:
+//       row(reg, h) = (reg & 3) + 8 * (reg >> 2) + 4 * h,     h = lane >> 5.
+// The next layer contracts over the feature (row) index, so an accumulator tile is
+// consumed as the next B operand with NO lane movement and NO LDS round trip:
+//   * fp32  (v_mfma_f32_32x32x2_f32):  k-step = one accumulator register; lane half h
+//           supplies k = h, i.e. feature row(reg, h).
+//   * bf16  (v_mfma_f32_32x32x16_bf16): k-step s of a tile = registers 8s..8s+7 packed
+//           to bf16; element j of half h is feature 16s + 8(j>>2) + 4h + (j&3).
+// The weight fragments are laid out once per launch, by a prep kernel, in exactly that
+// permuted k order (the "image"), copied to LDS by every workgroup and read with one
+// ds_read per MFMA.
+//
+// Feature space of a hidden activation: 96 rows = 3 tiles.  Rows 0..64 are the 65
+// features, row 68 (tile 2, reg 0, upper lane half) is forced to 1.0 after the
+// activation and carries the next layer's bias as an ordinary weight column; all other
+// rows of tile 2 are zero.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/so3x.h"
+#include "so3x_math.hpp"
+
+namespace so3x {
+namespace mlp {
+
+constexpr int D = 65;
+constexpr int NEMB = 56;   // 28 sines then 28 cosines, models.py:24
+constexpr int NFREQ = 28;
+constexpr int ONE_ROW = 68;  // hidden-feature row that carries the constant 1
+constexpr int LAYER_STRIDE = D * D + D;
+constexpr int NPARAMS = 4 * LAYER_STRIDE + 3 * D + 3;
+static_assert(NPARAMS == SO3X_MLP_PARAMS, "param count");
+
+struct Freqs { float f[NFREQ]; };  // passed by value as a kernel argument
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int dout_of(int l) { return l < 4 ? D : 3; }
+__host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- image geometry -------------------------------------------------------------
+// variant CHAIN: layer 0 sees only the 9 rotation entries (the 56 time-embedding
+// inputs are folded into a per-timestep effective bias, appendix C.3);
+// variant FULL : layer 0 sees [R(9), 1, emb(56)] per sample (per-sample timesteps).
+enum Variant { CHAIN = 0, FULL = 1 };
+
+// number of k-steps
+template <int PREC> __host__ __device__ constexpr int ks_hidden() { return PREC == SO3X_PREC_F32 ? 33 : 5; }
+template <int PREC, int VAR> __host__ __device__ constexpr int ks_layer0() {
+  return PREC == SO3X_PREC_F32 ? (VAR == CHAIN ? 5 : 33) : (VAR == CHAIN ? 1 : 5);
+}
+// a fragment = what the 64 lanes read for one MFMA: 64 x 4 B (fp32) or 64 x 16 B (bf16)
+template <int PREC> __host__ __device__ constexpr int frag_bytes() { return PREC == SO3X_PREC_F32 ? 256 : 1024; }
+template <int PREC, int VAR> __host__ __device__ constexpr int frag_l0() { return 0; }
+template <int PREC, int VAR> __host__ __device__ constexpr int frag_hidden(int l /*1..3*/) {
+  return 3 * ks_layer0<PREC, VAR>() + (l - 1) * 3 * ks_hidden<PREC>();
+}
+template <int PREC, int VAR> __host__ __device__ constexpr int frag_last() { return frag_hidden<PREC, VAR>(4); }
+template <int PREC, int VAR> __host__ __device__ constexpr int n_frags() { return frag_last<PREC, VAR>() + ks_hidden<PREC>(); }
+template <int PREC, int VAR> __host__ __device__ constexpr int image_bytes() { return n_frags<PREC, VAR>() * frag_bytes<PREC>(); }
+
+// hidden feature index fed by (k-step ks, lane half h, element j)
+template <int PREC> __host__ __device__ inline int hidden_feature(int ks, int h, int j) {
+  if (PREC == SO3X_PREC_F32) {
+    const int tin = ks < 16 ? 0 : (ks < 32 ? 1 : 2);
+    const int reg = ks < 16 ? ks : (ks < 32 ? ks - 16 : 0);
+    return 32 * tin + row_of(reg, h);
+  } else {
+    const int tin = ks >> 1, s = ks & 1;  // ks 0..4 -> (0,0)(0,1)(1,0)(1,1)(2,0)
+    return 32 * tin + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+  }
+}
+// layer-0 input slot fed by (ks, h, j): fp32 slot = 2 ks + h, bf16 slot = 16 ks + 8 h + j
+template <int PREC> __host__ __device__ inline int l0_slot(int ks, int h, int j) {
+  return PREC == SO3X_PREC_F32 ? 2 * ks + h : 16 * ks + 8 * h + j;
+}
+// slot -> column of net.0.weight (0..64), -2 = bias (constant-one input), -1 = zero padding.
+//  fp32 FULL: [0..8] R, [9] one, [10..65] emb.   bf16 FULL: [0..8] R, [9] one, [16..71] emb.
+template <int PREC, int VAR> __host__ __device__ inline int l0_slot_to_col(int slot) {
+  if (slot < 9) return slot;
+  if (VAR == CHAIN) return -1;
+  if (slot == 9) return -2;
+  const int e0 = PREC == SO3X_PREC_F32 ? 10 : 16;
+  if (slot >= e0 && slot < e0 + NEMB) return 9 + (slot - e0);
+  return -1;
+}
+template <int PREC> __host__ __device__ constexpr int l0_emb_slot0() { return PREC == SO3X_PREC_F32 ? 10 : 16; }
+
+// weight-image element value: fragment `frag`, lane, element j (bf16 only)
+template <int PREC, int VAR>
+__device__ inline float image_value(const float* __restrict__ params, int frag, int lane, int j) {
+  const int i = lane & 31, h = lane >> 5;
+  int l, tout, ks;
+  constexpr int K0 = ks_layer0<PREC, VAR>(), KH = ks_hidden<PREC>();
+  if (frag < 3 * K0) { l = 0; tout = frag / K0; ks = frag % K0; }
+  else if (frag < frag_last<PREC, VAR>()) { int f = frag - 3 * K0; l = 1 + f / (3 * KH); f %= 3 * KH; tout = f / KH; ks = f % KH; }
+  else { l = 4; tout = 0; ks = frag - frag_last<PREC, VAR>(); }
+  const int o = 32 * tout + i;
+  if (o >= dout_of(l)) return 0.0f;
+  const float* W = params + l * LAYER_STRIDE;
+  const float* bias = W + dout_of(l) * D;
+  if (l == 0) {
+    const int col = l0_slot_to_col<PREC, VAR>(l0_slot<PREC>(ks, h, j));
+    return col >= 0 ? W[o * D + col] : (col == -2 ? bias[o] : 0.0f);
+  }
+  const int f = hidden_feature<PREC>(ks, h, j);
+  return f < D ? W[o * D + f] : (f == ONE_ROW ? bias[o] : 0.0f);
+}
+
+// ---- activations ------------------------------------------------------------------
+template <int PREC> __device__ __forceinline__ float silu(float x) {
+  if (PREC == SO3X_PREC_F32) return x / (1.0f + expf(-x));                 // accurate path (parity gate G5)
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));                      // v_exp_f32 + v_rcp_f32
+}
+
+// time embedding element e of timestep t: models.py:22-24 -- the angle is formed in fp32
+// (int64 t promoted to fp32, times the fp32 frequency), then sin / cos of that fp32 angle.
+__device__ __forceinline__ float emb_value(int64_t t, int e, const Freqs& fr) {
+  const float a = (float)t * fr.f[e < NFREQ ? e : e - NFREQ];
+  float sn, cs;
+  sincos_cw(a, &sn, &cs);
+  return e < NFREQ ? sn : cs;
+}
+
+// Per-wave state of one 32-sample tile flowing through the network.
+template <int PREC> struct Tile;
+
+template <> struct Tile<SO3X_PREC_F32> {
+  float h[3][16];  // hidden activations in accumulator layout (tile 2: only reg 0 is live)
+};
+template <> struct Tile<SO3X_PREC_BF16> {
+  bf16x8 b[5];  // the 5 packed k-steps of the next layer's B operand
+};
+
+template <int PREC> __device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; i++) z[i] = 0.0f;
+  return z;
+}
+
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// activation + repack of the three accumulator tiles into the next layer's operand
+template <int PREC> __device__ __forceinline__ void activate(const f32x16 (&acc)[3], Tile<PREC>& out, int h);
+
+template <> __device__ __forceinline__ void activate<SO3X_PREC_F32>(const f32x16 (&acc)[3], Tile<SO3X_PREC_F32>& out, int h) {
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) out.h[t][r] = silu<SO3X_PREC_F32>(acc[t][r]);
+  out.h[2][0] = h ? 1.0f : silu<SO3X_PREC_F32>(acc[2][0]);  // row 64 (h=0) / the constant-one row 68 (h=1)
+}
+
+template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 p;
+#pragma unroll
+      for (int j = 0; j < 8; j++) p[j] = (__bf16)silu<SO3X_PREC_BF16>(acc[t][8 * s + j]);
+      out.b[2 * t + s] = p;
+    }
+  bf16x8 p;
+#pragma unroll
+  for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
+  p[0] = (__bf16)(h ? 1.0f : silu<SO3X_PREC_BF16>(acc[2][0]));
+  out.b[4] = p;
+}
+
+// One hidden layer (NT output tiles) from LDS-resident weight fragments.
+template <int PREC, int NT>
+__device__ __forceinline__ void hidden_layer(const char* __restrict__ wl /*LDS, first fragment of the layer*/,
+                                             const Tile<PREC>& in, f32x16 (&acc)[NT], int lane) {
+  __builtin_amdgcn_sched_barrier(0);  // keep this layer's LDS weight reads from being hoisted above the previous layer
+  if constexpr (PREC == SO3X_PREC_F32) {
+    const float* w = reinterpret_cast<const float*>(wl);
+#pragma unroll
+    for (int to = 0; to < NT; to++) {
+      f32x16 a = zero16<PREC>();
+#pragma unroll
+      for (int ks = 0; ks < 33; ks++) {
+        const float b = ks < 16 ? in.h[0][ks] : (ks < 32 ? in.h[1][ks - 16] : in.h[2][0]);
+        a = mfma_f32(w[(to * 33 + ks) * 64 + lane], b, a);
+      }
+      acc[to] = a;
+    }
+  } else {
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+#pragma unroll
+    for (int to = 0; to < NT; to++) {
+      f32x16 a = zero16<PREC>();
+#pragma unroll
+      for (int ks = 0; ks < 5; ks++) a = mfma_bf16(w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
+      acc[to] = a;
+    }
+  }
+}
+
+// Layer 0, CHAIN variant: accumulators start from the per-timestep effective bias
+// beff[96] (global/L2, identical address across a lane half -> broadcast load) and add
+// W_0[:, 0:9] . R.   x = the 9 rotation entries of this lane's sample column.
+template <int PREC>
+__device__ __forceinline__ void layer0_chain(const char* __restrict__ wl, const float* __restrict__ beff, const float* x,
+                                             f32x16 (&acc)[3], int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int to = 0; to < 3; to++) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (to == 2 && q > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) a[4 * q + r] = 0.0f;
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(beff + 32 * to + 8 * q + 4 * h);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      }
+    }
+    acc[to] = a;
+  }
+  if constexpr (PREC == SO3X_PREC_F32) {
+    const float* w = reinterpret_cast<const float*>(wl);
+    float xs[5];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {  // slot 2m + h; slot 9 is padding
+      const float lo = x[2 * m], hi = (2 * m + 1 < 9) ? x[2 * m + 1] : 0.0f;
+      xs[m] = h ? hi : lo;
+    }
+#pragma unroll
+    for (int to = 0; to < 3; to++)
+#pragma unroll
+      for (int m = 0; m < 5; m++) acc[to] = mfma_f32(w[(to * 5 + m) * 64 + lane], xs[m], acc[to]);
+  } else {
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x[8] : 0.0f) : x[j]);  // slot 8h + j
+#pragma unroll
+    for (int to = 0; to < 3; to++) acc[to] = mfma_bf16(w[to * 64 + lane], b, acc[to]);
+  }
+}
+
+// Layer 0, FULL variant: per-sample timestep; every lane evaluates the embedding
+// entries of its own k-slots (the two lanes of a sample split the 56 sin/cos).
+// The embedding k-steps are a real loop (not unrolled): 56 inlined sincos would
+// otherwise be hoisted together and blow the register budget.
+template <int PREC>
+__device__ __forceinline__ void layer0_full(const char* __restrict__ wl, const float* x, int64_t t, const Freqs& fr,
+                                            f32x16 (&acc)[3], int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int to = 0; to < 3; to++) acc[to] = zero16<PREC>();
+  if constexpr (PREC == SO3X_PREC_F32) {
+    const float* w = reinterpret_cast<const float*>(wl);
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) {  // slots 0..9: R and the constant one
+      const float lo = x[2 * ks];
+      const float hi = (2 * ks + 1 < 9) ? x[2 * ks + 1] : 1.0f;
+      const float b = h ? hi : lo;
+#pragma unroll
+      for (int to = 0; to < 3; to++) acc[to] = mfma_f32(w[(to * 33 + ks) * 64 + lane], b, acc[to]);
+    }
+#pragma unroll 1
+    for (int ks = 5; ks < 33; ks++) {  // slots 10..65: emb[2 ks + h - 10]
+      const float b = emb_value(t, 2 * ks + h - 10, fr);
+#pragma unroll
+      for (int to = 0; to < 3; to++) acc[to] = mfma_f32(w[(to * 33 + ks) * 64 + lane], b, acc[to]);
+    }
+  } else {
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+    {
+      bf16x8 b;  // slots 8h + j: R[0..7] | R[8], 1, 0...
+#pragma unroll
+      for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x[8] : (j == 1 ? 1.0f : 0.0f)) : x[j]);
+#pragma unroll
+      for (int to = 0; to < 3; to++) acc[to] = mfma_bf16(w[(to * 5) * 64 + lane], b, acc[to]);
+    }
+#pragma unroll 1
+    for (int ks = 1; ks < 5; ks++) {  // slots 16 ks + 8 h + j -> emb[16 (ks-1) + 8 h + j]
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int e = 16 * (ks - 1) + 8 * h + j;
+        b[j] = (__bf16)(e < NEMB ? emb_value(t, e < NEMB ? e : 0, fr) : 0.0f);
+      }
+#pragma unroll
+      for (int to = 0; to < 3; to++) acc[to] = mfma_bf16(w[(to * 5 + ks) * 64 + lane], b, acc[to]);
+    }
+  }
+}
+
+// The whole network on one 32-sample tile.  Returns the 3 outputs of sample column
+// (lane & 31) in v[0..2]; only lanes of the LOWER half (h == 0) hold valid values.
+template <int PREC, int VAR>
+__device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS weight image*/, const float* x,
+                                             const float* __restrict__ beff, int64_t t, const Freqs* fr, float* v, int lane) {
+  const int h = lane >> 5;
+  constexpr int FB = frag_bytes<PREC>();
+  f32x16 acc[3];
+  Tile<PREC> cur;
+  if constexpr (VAR == CHAIN) layer0_chain<PREC>(img, beff, x, acc, lane);
+  else layer0_full<PREC>(img, x, t, *fr, acc, lane);
+  activate<PREC>(acc, cur, h);
+#pragma unroll
+  for (int l = 1; l < 4; l++) {
+    hidden_layer<PREC, 3>(img + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane);
+    activate<PREC>(acc, cur, h);
+  }
+  f32x16 last[1];
+  hidden_layer<PREC, 1>(img + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
+  v[0] = last[0][0]; v[1] = last[0][1]; v[2] = last[0][2];  // rows 0,1,2 = regs 0,1,2 of the lower half
+}
+
+// cooperative copy of the weight image (global workspace -> LDS), 16 B per lane
+__device__ __forceinline__ void load_image(const void* __restrict__ gimg, char* lds, int bytes) {
+  const float4* s = reinterpret_cast<const float4*>(gimg);
+  float4* d = reinterpret_cast<float4*>(lds);
+  for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+
+// ---- host-side launch helpers implemented in so3x_mlp.hip -------------------------
+size_t image_bytes_rt(int precision, int variant);
+// writes the weight image at workspace[0 .. image) and, for CHAIN with T > 0, the
+// effective-bias table beff[T][96] right after it (16-B aligned).
+int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace);
+size_t beff_offset(int precision, int variant);
+const Freqs& host_freqs();
+
+}  // namespace mlp
+}  // namespace so3x

@@ -1,0 +1,431 @@
+"""ctypes binding of libso3x.so (include/so3x.h) for torch tensors on an MI355X.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every
+computation on the hot path happens in the hand-written HIP kernels behind the
+C ABI.  There is NO CPU path and NO fallback: a missing library, a missing
+symbol, a CPU tensor or a failed launch raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libso3x.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "so3x.h")
+
+PREC_F32 = 0
+PREC_BF16 = 1
+N_PARAMS = 17358
+SCHED_ROWS = 13
+TRAP = 999
+
+# every entry point declared in include/so3x.h (checked against the header by the tests)
+SYMBOLS = (
+    "so3x_abi_version", "so3x_error_string", "so3x_schedule_from_betas", "so3x_cosine_beta_schedule",
+    "so3x_igso3_knots", "so3x_posemb_freqs", "so3x_quat_to_rmat", "so3x_log_rmat", "so3x_log_rmat_vec",
+    "so3x_exp_skewvec", "so3x_so3_scale", "so3x_aa_to_rmat", "so3x_rmat_to_aa", "so3x_so3_lerp",
+    "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_sample",
+    "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
+    "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
+)
+
+
+class So3xError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libso3x.so (once).  Fails loudly: there is no alternative implementation."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise So3xError(
+                        f"so3x: {LIB_PATH} not found -- build it with `make -C {os.path.join(_PKG, 'csrc')}` "
+                        "(or __graft_entry__.build()); this backend has no CPU / PyTorch fallback")
+                l = C.CDLL(LIB_PATH)
+                missing = [s for s in SYMBOLS if not hasattr(l, s)]
+                if missing:
+                    raise So3xError(f"so3x: {LIB_PATH} lacks symbols {missing}")
+                l.so3x_error_string.restype = C.c_char_p
+                l.so3x_mlp_workspace_bytes.restype = C.c_size_t
+                l.so3x_p_sample_workspace_bytes.restype = C.c_size_t
+                if l.so3x_abi_version() != 1:
+                    raise So3xError("so3x: ABI version mismatch")
+                _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise So3xError(f"so3x: {what} failed: {lib().so3x_error_string(rc).decode()} (code {rc})")
+
+
+def _dev(x, name, dtype=torch.float32):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"so3x: {name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise So3xError(f"so3x: {name} lives on {x.device}; the MI355X backend has no CPU path "
+                        "(move the tensor/module to a 'cuda' device)")
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    return x.contiguous()
+
+
+def _ptr(x):
+    return C.c_void_p(x.data_ptr()) if x is not None else None
+
+
+def _stream(x):
+    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+def _u64(v):
+    return C.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
+
+
+class _Guard:
+    def __init__(self, x):
+        self.g = torch.cuda.device(x.device)
+
+    def __enter__(self):
+        self.g.__enter__()
+
+    def __exit__(self, *a):
+        self.g.__exit__(*a)
+
+
+# ----------------------------------------------------------------------------- host-side
+def cosine_beta_schedule(T):
+    import numpy as np
+    out = np.empty(T, np.float64)
+    _check(lib().so3x_cosine_beta_schedule(C.c_int(T), out.ctypes.data_as(C.c_void_p)), "cosine_beta_schedule")
+    return out
+
+
+def schedule_from_betas(betas):
+    import numpy as np
+    betas = np.ascontiguousarray(betas, np.float64)
+    T = betas.shape[0]
+    out = np.empty((SCHED_ROWS, T), np.float32)
+    _check(lib().so3x_schedule_from_betas(betas.ctypes.data_as(C.c_void_p), C.c_int(T),
+                                          out.ctypes.data_as(C.c_void_p)), "schedule_from_betas")
+    return out
+
+
+def igso3_knots():
+    import numpy as np
+    k = np.empty(1000, np.float32)
+    w = np.empty(1000, np.float32)
+    _check(lib().so3x_igso3_knots(k.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)), "igso3_knots")
+    return k, w
+
+
+def posemb_freqs(half_dim=28):
+    import numpy as np
+    out = np.empty(half_dim, np.float32)
+    _check(lib().so3x_posemb_freqs(C.c_int(half_dim), out.ctypes.data_as(C.c_void_p)), "posemb_freqs")
+    return out
+
+
+# ----------------------------------------------------------------------------- workspaces
+_ws = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- rotations
+def _rot_in(x, name):
+    if x.shape[-2:] != (3, 3):
+        raise ValueError(f"so3x: {name} must end in (3, 3), got {tuple(x.shape)}")
+    return _dev(x, name)
+
+
+def quat_to_rmat(q):
+    q = _dev(q, "quaternions")
+    n = q.numel() // 4
+    out = torch.empty(q.shape[:-1] + (3, 3), dtype=torch.float32, device=q.device)
+    with _Guard(q):
+        _check(lib().so3x_quat_to_rmat(_stream(q), _ptr(q), _ptr(out), _i64(n)), "quat_to_rmat")
+    return out
+
+
+def log_rmat(R):
+    R = _rot_in(R, "r_mat")
+    out = torch.empty_like(R)
+    with _Guard(R):
+        _check(lib().so3x_log_rmat(_stream(R), _ptr(R), _ptr(out), _i64(R.numel() // 9)), "log_rmat")
+    return out
+
+
+def log_rmat_vec(R):
+    R = _rot_in(R, "r_mat")
+    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    with _Guard(R):
+        _check(lib().so3x_log_rmat_vec(_stream(R), _ptr(R), _ptr(out), _i64(R.numel() // 9)), "log_rmat_vec")
+    return out
+
+
+def exp_skewvec(v):
+    v = _dev(v, "vec")
+    out = torch.empty(v.shape[:-1] + (3, 3), dtype=torch.float32, device=v.device)
+    with _Guard(v):
+        _check(lib().so3x_exp_skewvec(_stream(v), _ptr(v), _ptr(out), _i64(v.numel() // 3)), "exp_skewvec")
+    return out
+
+
+def _per_sample(s, n, name, device):
+    """scalar operand: numel 1 -> stride 0, numel n -> stride 1"""
+    s = _dev(s if isinstance(s, torch.Tensor) else torch.tensor(s, device=device), name)
+    if s.numel() == 1:
+        return s.reshape(1), 0
+    if s.numel() == n:
+        return s.reshape(n), 1
+    raise ValueError(f"so3x: {name} must have 1 or {n} elements, got {tuple(s.shape)}")
+
+
+def so3_scale(R, scalars):
+    R = _rot_in(R, "rmat")
+    n = R.numel() // 9
+    k, stride = _per_sample(scalars, n, "scalars", R.device)
+    out = torch.empty_like(R)
+    with _Guard(R):
+        _check(lib().so3x_so3_scale(_stream(R), _ptr(R), _ptr(k), _i64(stride), _ptr(out), _i64(n)), "so3_scale")
+    return out
+
+
+def aa_to_rmat(axis, ang):
+    axis = _dev(axis, "rot_axis")
+    n = axis.numel() // 3
+    ang = _dev(ang, "ang")
+    if ang.numel() != n:
+        ang = ang.expand(axis.shape[:-1] + (1,)).contiguous()
+    out = torch.empty(axis.shape[:-1] + (3, 3), dtype=torch.float32, device=axis.device)
+    with _Guard(axis):
+        _check(lib().so3x_aa_to_rmat(_stream(axis), _ptr(axis), _ptr(ang), _ptr(out), _i64(n)), "aa_to_rmat")
+    return out
+
+
+def rmat_to_aa(R):
+    R = _rot_in(R, "r_mat")
+    n = R.numel() // 9
+    axis = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    ang = torch.empty(R.shape[:-2] + (1,), dtype=torch.float32, device=R.device)
+    with _Guard(R):
+        _check(lib().so3x_rmat_to_aa(_stream(R), _ptr(R), _ptr(axis), _ptr(ang), _i64(n)), "rmat_to_aa")
+    return axis, ang
+
+
+def so3_lerp(a, b, w):
+    b = _rot_in(b, "rot_b")
+    n = b.numel() // 9
+    a = _rot_in(a, "rot_a")
+    if a.numel() == 9:
+        a_stride = 0
+    elif a.numel() == b.numel():
+        a_stride = 9
+    else:
+        raise ValueError("so3x: rot_a must be one (3,3) matrix or match rot_b")
+    wt, w_stride = _per_sample(w, n, "weight", b.device)
+    out = torch.empty_like(b)
+    with _Guard(b):
+        _check(lib().so3x_so3_lerp(_stream(b), _ptr(a), _i64(a_stride), _ptr(b), _ptr(wt), _i64(w_stride), _ptr(out),
+                                   _i64(n)), "so3_lerp")
+    return out
+
+
+def rmat_dist(a, b):
+    a = _rot_in(a, "input")
+    b = _rot_in(b, "target")
+    if a.shape != b.shape:
+        a, b = torch.broadcast_tensors(a, b)
+        a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(a.shape[:-2], dtype=torch.float32, device=a.device)
+    with _Guard(a):
+        _check(lib().so3x_rmat_dist(_stream(a), _ptr(a), _ptr(b), _ptr(out), _i64(a.numel() // 9)), "rmat_dist")
+    return out
+
+
+def rmul(a, b, transpose_b=False):
+    a = _rot_in(a, "a")
+    b = _rot_in(b, "b")
+    n = max(a.numel(), b.numel()) // 9
+    sa = 0 if (a.numel() == 9 and n > 1) else 9
+    sb = 0 if (b.numel() == 9 and n > 1) else 9
+    shape = a.shape if a.numel() >= b.numel() else b.shape
+    out = torch.empty(shape, dtype=torch.float32, device=a.device)
+    with _Guard(a):
+        _check(lib().so3x_rmul(_stream(a), _ptr(a), _i64(sa), _ptr(b), _i64(sb), C.c_int(int(transpose_b)), _ptr(out),
+                               _i64(n)), "rmul")
+    return out
+
+
+# ----------------------------------------------------------------------------- IGSO(3)
+def igso3_eps_ft(omega, eps):
+    omega = _dev(omega, "omega")
+    n = omega.numel()
+    e, stride = _per_sample(eps, n, "eps", omega.device)
+    out = torch.empty_like(omega)
+    with _Guard(omega):
+        _check(lib().so3x_igso3_eps_ft(_stream(omega), _ptr(omega), _ptr(e), _i64(stride), _ptr(out), _i64(n)), "igso3_eps_ft")
+    return out
+
+
+def igso3_build_tables(eps):
+    eps = _dev(eps, "eps").reshape(-1)
+    trap = torch.empty((eps.numel(), TRAP), dtype=torch.float32, device=eps.device)
+    with _Guard(eps):
+        _check(lib().so3x_igso3_build_tables(_stream(eps), _ptr(eps), _i64(eps.numel()), _ptr(trap)), "igso3_build_tables")
+    return trap
+
+
+def igso3_sample(trap, n, row_idx=None, row_const=0, quirk_col0=False, axes=None, unif=None, seed=0, rng_offset=0,
+                 index_base=0, mean=None, want_angle=False, want_axis=False):
+    trap = _dev(trap, "trap")
+    dev = trap.device
+    ri = _dev(row_idx, "row_idx", torch.int64).reshape(-1) if row_idx is not None else None
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    mn = _dev(mean, "mean").reshape(9) if mean is not None else None
+    out = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+    ang = torch.empty(n, dtype=torch.float32, device=dev) if want_angle else None
+    axo = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_axis else None
+    with _Guard(trap):
+        _check(lib().so3x_igso3_sample(_stream(trap), _ptr(trap), _ptr(ri), _i64(row_const), C.c_int(int(quirk_col0)),
+                                       _ptr(ax), _ptr(un), _u64(seed), _u64(rng_offset), _i64(index_base), _ptr(mn),
+                                       _ptr(out), _ptr(ang), _ptr(axo), _i64(n)), "igso3_sample")
+    return out, ang, axo
+
+
+def igso3_logprob_score(R, eps, want_score=True, want_grad=False):
+    R = _rot_in(R, "rotations")
+    n = R.numel() // 9
+    e, stride = _per_sample(eps, n, "eps", R.device)
+    logp = torch.empty(R.shape[:-2] + (1,), dtype=torch.float32, device=R.device)
+    score = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device) if want_score else None
+    grad = torch.empty_like(R) if want_grad else None
+    with _Guard(R):
+        _check(lib().so3x_igso3_logprob_score(_stream(R), _ptr(R), _ptr(e), _i64(stride), _ptr(logp), _ptr(score),
+                                              _ptr(grad), _i64(n)), "igso3_logprob_score")
+    return logp, score, grad
+
+
+# ----------------------------------------------------------------------------- score MLP
+def _t_arg(t, n):
+    t = _dev(t, "t", torch.int64).reshape(-1)
+    if t.numel() == 1:
+        return t, 0
+    if t.numel() == n:
+        return t, 1
+    raise ValueError(f"so3x: t must have 1 or {n} elements, got {t.numel()}")
+
+
+def mlp_fwd(params, R, t, precision=PREC_F32):
+    params = _dev(params, "params").reshape(-1)
+    if params.numel() != N_PARAMS:
+        raise ValueError(f"so3x: params must hold {N_PARAMS} values")
+    R = _rot_in(R, "x")
+    n = R.numel() // 9
+    tt, stride = _t_arg(t, n)
+    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision))
+    ws = _workspace(R.device, nb)
+    with _Guard(R):
+        _check(lib().so3x_mlp_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n),
+                                  C.c_int(precision), _ptr(ws), C.c_size_t(ws.numel())), "mlp_fwd")
+    return out
+
+
+def mlp_bwd(params, R, t, dout, precision=PREC_F32):
+    params = _dev(params, "params").reshape(-1)
+    R = _rot_in(R, "x")
+    n = R.numel() // 9
+    tt, stride = _t_arg(t, n)
+    dout = _dev(dout, "dout").reshape(-1, 3)
+    dparams = torch.empty(N_PARAMS, dtype=torch.float32, device=R.device)
+    nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision))
+    ws = _workspace(R.device, nb)
+    with _Guard(R):
+        _check(lib().so3x_mlp_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
+                                  _i64(n), C.c_int(precision), _ptr(ws), C.c_size_t(ws.numel())), "mlp_bwd")
+    return dparams
+
+
+# ----------------------------------------------------------------------------- diffusion
+def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None, unif=None, seed=0, rng_offset=0,
+                    index_base=0, want_x_t=True, want_target=True, want_noise=False):
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    x0 = _rot_in(x0, "x_start")
+    n = x0.numel() // 9
+    tt = _dev(t, "t", torch.int64).reshape(-1)
+    if tt.numel() != n:
+        raise ValueError("so3x: t must have one entry per sample")
+    tq = _dev(trap_q, "trap_q") if trap_q is not None else None
+    nz = _rot_in(noise, "noise") if noise is not None else None
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    dev = x0.device
+    x_t = torch.empty_like(x0) if want_x_t else None
+    tg = torch.empty(x0.shape[:-2] + (3,), dtype=torch.float32, device=dev) if want_target else None
+    nzo = torch.empty_like(x0) if want_noise else None
+    with _Guard(x0):
+        _check(lib().so3x_q_sample_target(_stream(x0), _ptr(sched), C.c_int(T), _ptr(tq), _ptr(x0), _ptr(tt),
+                                          C.c_int(int(quirk_col0)), _ptr(nz), _ptr(ax), _ptr(un), _u64(seed),
+                                          _u64(rng_offset), _i64(index_base), _ptr(x_t), _ptr(tg), _ptr(nzo), _i64(n)),
+               "q_sample_target")
+    return x_t, tg, nzo
+
+
+def p_mean(sched, x, v, t, want_x0hat=False):
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    x = _rot_in(x, "x")
+    v = _dev(v, "noise").reshape(-1, 3)
+    n = x.numel() // 9
+    x0h = torch.empty_like(x) if want_x0hat else None
+    mean = torch.empty_like(x)
+    with _Guard(x):
+        _check(lib().so3x_p_mean(_stream(x), _ptr(sched), C.c_int(T), _ptr(x), _ptr(v), C.c_int(int(t)), _ptr(x0h),
+                                 _ptr(mean), _i64(n)), "p_mean")
+    return x0h, mean
+
+
+def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0, index_base=0,
+                   precision=PREC_BF16, out=None):
+    params = _dev(params, "params").reshape(-1)
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    trap_p = _dev(trap_p, "trap_p")
+    x = _rot_in(x, "x")
+    n = x.numel() // 9
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    if out is None:
+        out = torch.empty_like(x)
+    nb = lib().so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(precision))
+    ws = _workspace(x.device, nb)
+    with _Guard(x):
+        _check(lib().so3x_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(x), _ptr(out),
+                                         C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un), _u64(seed),
+                                         _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision), _ptr(ws),
+                                         C.c_size_t(ws.numel())), "p_sample_chain")
+    return out

@@ -1,0 +1,180 @@
+"""SO3Diffusion with the reference's constructor, buffers and methods
+(reference diffusion.py:280-374 and the schedule buffers of GaussianDiffusion.__init__,
+diffusion.py:57-92), running on the fused HIP kernels of libso3x.
+
+Fast paths
+  * p_losses          -> one launch: noise draw + q_sample + regression target
+  * p_sample          -> one launch: score MLP + posterior mean + noise (when denoise_fn
+                         is a so3x RotPredict); generic denoise_fn: MLP in torch, rest fused
+  * p_sample_loop     -> ONE launch for the whole T-step chain (rotations stay in VGPRs)
+Reference behaviours kept by default and switchable: the column-0 CDF gather of the
+batched-eps sampler (`quirk_col0`), IGSO3(eps=1) chain initialisation.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import backend as _b
+from . import rng as _rng
+from .distributions import IsotropicGaussianSO3
+from .so3_train import RotPredict
+
+__all__ = ["SO3Diffusion", "cosine_beta_schedule", "extract"]
+
+_SCHED_NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                "posterior_mean_coef1", "posterior_mean_coef2")
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    """float64 betas of the un-vendored denoising_diffusion_pytorch helper the reference imports
+    (reference diffusion.py:8-14, 60).  Parity with the reference's fork is unpinned; pass
+    `betas=` explicitly to remove the doubt."""
+    if s != 0.008:
+        raise NotImplementedError("only the default s=0.008 is provided")
+    return _b.cosine_beta_schedule(int(timesteps))
+
+
+def extract(a, t, x_shape):
+    """a[t] reshaped to broadcast against x_shape (the lucidrains helper)."""
+    b = t.shape[0]
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+class SO3Diffusion(nn.Module):
+    def __init__(self, denoise_fn, timesteps=1000, loss_type="skewvec", betas=None, quirk_col0=True):
+        super().__init__()
+        self.denoise_fn = denoise_fn
+        if betas is not None:
+            betas = betas.detach().cpu().numpy() if isinstance(betas, torch.Tensor) else np.asarray(betas)
+        else:
+            betas = cosine_beta_schedule(timesteps)
+        betas = np.ascontiguousarray(betas, np.float64)
+        (timesteps,) = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        if loss_type != "skewvec":
+            raise NotImplementedError("so3x: only loss_type='skewvec' (reference so3_train.py:63) is implemented")
+        self.quirk_col0 = quirk_col0
+        self.index_base = 0  # global index of this process's first sample (data-parallel shards)
+
+        sched = _b.schedule_from_betas(betas)  # float64 math, fp32 storage, as diffusion.py:62-92
+        for i, name in enumerate(_SCHED_NAMES):
+            self.register_buffer(name, torch.from_numpy(sched[i].copy()))
+        self.register_buffer("identity", torch.eye(3))
+        # kernel-side views: the packed [13, T] table and the two CDF-row tables (built lazily on the GPU)
+        self.register_buffer("_sched", torch.from_numpy(sched.copy()), persistent=False)
+        self._trap_q = None  # rows for eps_t = sqrt(1 - abar_t)          (p_losses / q_sample)
+        self._trap_p = None  # rows for sigma_t = exp(0.5 * logvar_t)     (p_sample)
+
+    # ------------------------------------------------------------------ tables
+    def _tables(self):
+        dev = self._sched.device
+        if self._trap_q is None or self._trap_q.device != dev:
+            self._trap_q = _b.igso3_build_tables(self._sched[4])
+            self._trap_p = _b.igso3_build_tables(self._sched[12])
+        return self._trap_q, self._trap_p
+
+    def _fused_net(self):
+        return self.denoise_fn if isinstance(self.denoise_fn, RotPredict) else None
+
+    @staticmethod
+    def _shared_t(t):
+        """p_sample draws its noise from model_stdev[0] (reference diffusion.py:325): one timestep per call."""
+        if isinstance(t, int):
+            return t
+        return int(t.reshape(-1)[0].item())
+
+    # ------------------------------------------------------------------ reference API
+    def q_mean_variance(self, x_start, t):
+        from .util import so3_lerp
+        mean = so3_lerp(self.identity, x_start, self.sqrt_alphas_cumprod[t])
+        variance = extract(1.0 - self.alphas_cumprod, t, x_start.shape)
+        log_variance = extract(self.log_one_minus_alphas_cumprod, t, x_start.shape)
+        return mean, variance, log_variance
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """so3_scale(x_t, sqrt(1/abar)) @ exp(hat(noise * sqrt(1/abar - 1)))^T  (reference diffusion.py:291-297)"""
+        x0hat, _ = _b.p_mean(self._sched, x_t, noise, self._shared_t(t), want_x0hat=True)
+        return x0hat
+
+    def q_posterior(self, x_start, x_t, t):
+        c_1 = _b.so3_scale(x_start, self.posterior_mean_coef1[t])
+        c_2 = _b.so3_scale(x_t, self.posterior_mean_coef2[t])
+        posterior_mean = _b.rmul(c_1, c_2)
+        return posterior_mean, extract(self.posterior_variance, t, t.shape), \
+            extract(self.posterior_log_variance_clipped, t, t.shape)
+
+    def p_mean_variance(self, x, t, clip_denoised: bool = False):
+        predict = self.denoise_fn(x, t)
+        _, model_mean = _b.p_mean(self._sched, x, predict, self._shared_t(t))
+        return model_mean, extract(self.posterior_variance, t, t.shape), \
+            extract(self.posterior_log_variance_clipped, t, t.shape)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, clip_denoised=False, repeat_noise=False, axes=None, unif=None):
+        """One reverse step (reference diffusion.py:315-326).  t: int64 tensor [B] or [1] (all equal) or int."""
+        t0 = self._shared_t(t)
+        _, trap_p = self._tables()
+        net = self._fused_net()
+        off = _rng.next_offset(self.num_timesteps) if axes is None else 0
+        if net is not None:
+            return _b.p_sample_chain(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
+                                     seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
+                                     precision=net.precision_code)
+        tt = t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device, dtype=torch.long)
+        predict = self.denoise_fn(x, tt)
+        _, mean = _b.p_mean(self._sched, x, predict, t0)
+        if t0 == 0:
+            return mean
+        n = x.numel() // 9
+        smp, _, _ = _b.igso3_sample(trap_p, n, row_const=t0, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off + t0,
+                                    index_base=self.index_base)
+        return _b.rmul(mean, smp.reshape(x.shape))
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, x_init=None):
+        """Full reverse chain (reference diffusion.py:328-337).  Initial state IGSO3(eps=1), as the
+        reference (its comment says Haar; the code is IGSO3(1))."""
+        device = self.betas.device
+        b = shape[0]
+        if x_init is None:
+            x = IsotropicGaussianSO3(eps=torch.ones([], device=device)).sample(shape, index_base=self.index_base)
+        else:
+            x = x_init
+        T = self.num_timesteps
+        net = self._fused_net()
+        if net is not None:
+            _, trap_p = self._tables()
+            off = _rng.next_offset(T)
+            return _b.p_sample_chain(net.flat_params_nograd(), self._sched, trap_p, x, T - 1, T, seed=_rng.seed(),
+                                     rng_offset=off, index_base=self.index_base, precision=net.precision_code)
+        for i in reversed(range(T)):
+            x = self.p_sample(x, torch.full((b,), i, device=device, dtype=torch.long))
+        return x
+
+    def q_sample(self, x_start, t, noise=None, axes=None, unif=None):
+        """so3_scale(x_start, sqrt(abar_t)) @ noise  (reference diffusion.py:339-346)."""
+        trap_q, _ = self._tables()
+        x_t, _, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
+                                       axes=axes, unif=unif, seed=_rng.seed(),
+                                       rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
+                                       index_base=self.index_base, want_target=False)
+        return x_t
+
+    def p_losses(self, x_start, t, noise=None, axes=None, unif=None):
+        """MSE between the network output and vee(log noise)/eps_t (reference diffusion.py:348-369)."""
+        trap_q, _ = self._tables()
+        x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
+                                                axes=axes, unif=unif, seed=_rng.seed(),
+                                                rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
+                                                index_base=self.index_base)
+        x_recon = self.denoise_fn(x_noisy, t)
+        return F.mse_loss(x_recon, target)
+
+    def forward(self, x, *args, **kwargs):
+        b = x.shape[0]
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+        return self.p_losses(x, t, *args, **kwargs)

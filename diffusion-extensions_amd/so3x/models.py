@@ -1,0 +1,21 @@
+"""SinusoidalPosEmb with the reference's interface (reference models.py:13-25).
+On the hot path the embedding is evaluated inside the fused score-network kernels;
+this module exists for API/state_dict compatibility and standalone use."""
+import math
+
+import torch
+from torch import nn
+
+__all__ = ["SinusoidalPosEmb"]
+
+
+class SinusoidalPosEmb(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x):
+        half = self.dim // 2
+        freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
+        ang = x[:, None] * freqs[None, :]
+        return torch.cat((ang.sin(), ang.cos()), dim=-1)

@@ -1,0 +1,88 @@
+"""Data-parallel plumbing: one process per GPU, batch axis sharded, one RCCL all-reduce
+of the flat 17,358-float gradient per training step.  Sampling
+needs no collective: samples are independent and the Philox streams are keyed by the
+GLOBAL sample index, so results are identical for any world size."""
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["Ctx", "init", "finalize", "shard_range", "broadcast_parameters", "allreduce_gradients", "mean_scalar"]
+
+
+@dataclass
+class Ctx:
+    rank: int
+    world_size: int
+    local_rank: int
+    device: torch.device
+    owns_pg: bool = False
+
+
+def shard_range(n: int, rank: int, world_size: int):
+    """Contiguous [lo, hi) of rank's share of n samples; remainders go to the low ranks."""
+    base, rem = divmod(int(n), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init(backend: str = None, device: str = None) -> Ctx:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  backend defaults to
+    'nccl' (= RCCL on ROCm) on GPUs; 'gloo' is used by the CPU tests of this plumbing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        device = f"cuda:{local}" if torch.cuda.is_available() else "cpu"
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    owns = False
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if dev.type == "cuda" else "gloo"), rank=rank, world_size=world)
+        owns = True
+    return Ctx(rank, world, local, dev, owns)
+
+
+def finalize(ctx: Ctx):
+    if ctx.owns_pg and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def broadcast_parameters(module: torch.nn.Module, ctx: Ctx, src: int = 0):
+    if ctx.world_size == 1:
+        return
+    flat = torch.cat([p.data.reshape(-1) for p in module.parameters()])
+    dist.broadcast(flat, src)
+    off = 0
+    for p in module.parameters():
+        n = p.numel()
+        p.data.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def allreduce_gradients(module: torch.nn.Module, ctx: Ctx):
+    """One flat all-reduce (sum) then 1/W: equal shard sizes make the mean of per-rank
+    mean-losses the global mean loss (diffusion.py:357 uses a mean over B*3 elements)."""
+    if ctx.world_size == 1:
+        return
+    params = [p for p in module.parameters() if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / ctx.world_size)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+def mean_scalar(x: torch.Tensor, ctx: Ctx) -> float:
+    if ctx.world_size > 1:
+        x = x.clone()
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        x = x / ctx.world_size
+    return float(x.item())

@@ -1,0 +1,138 @@
+"""RotPredict score network with the reference's constructor, forward signature and
+state_dict keys (reference so3_train.py:11-49), plus the training entry point.
+
+forward/backward run in the fused MFMA kernels (so3x_mlp_fwd / so3x_mlp_bwd): the
+time embedding, the 5 linear layers and the 4 SiLUs are one launch each way."""
+import argparse
+import json
+import os
+import time
+
+import torch
+from torch import nn
+
+from . import backend as _b
+from .models import SinusoidalPosEmb
+
+__all__ = ["RotPredict", "BATCH", "main"]
+
+BATCH = 64
+_PRECISIONS = {"fp32": _b.PREC_F32, "bf16": _b.PREC_BF16}
+
+
+class _ScoreMLPFn(torch.autograd.Function):
+    """autograd bridge: only the 17,358 parameters need gradients -- the rotation inputs
+    and targets of loss_type='skewvec' carry none."""
+
+    @staticmethod
+    def forward(ctx, x, t, flat_params, precision):
+        ctx.save_for_backward(x, t, flat_params)
+        ctx.precision = precision
+        return _b.mlp_fwd(flat_params, x, t, precision)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, t, flat_params = ctx.saved_tensors
+        dparams = _b.mlp_bwd(flat_params, x, t, dout.contiguous(), ctx.precision)
+        return None, None, dparams, None
+
+
+class RotPredict(nn.Module):
+    def __init__(self, d_model=65, out_type="rotmat", in_type="rotmat", precision="fp32"):
+        super().__init__()
+        self.in_type = in_type
+        self.out_type = out_type
+        if in_type != "rotmat" or d_model != 65:
+            raise NotImplementedError("so3x: the fused score network is built for in_type='rotmat', d_model=65")
+        if out_type != "skewvec":
+            # the reference's 'rotmat' head (six2rmat, so3_train.py:47-48) is off the SO3Diffusion
+            # 'skewvec' path (so3_train.py:60,63) and is not part of this backend
+            raise NotImplementedError("so3x: only out_type='skewvec' is implemented")
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {list(_PRECISIONS)}")
+        self.precision = precision
+        self.d_out = 3
+        self.time_embedding = SinusoidalPosEmb(d_model - 9)
+        self.net = nn.Sequential(
+            nn.Linear(d_model, d_model), nn.SiLU(),
+            nn.Linear(d_model, d_model), nn.SiLU(),
+            nn.Linear(d_model, d_model), nn.SiLU(),
+            nn.Linear(d_model, d_model), nn.SiLU(),
+            nn.Linear(d_model, self.d_out),
+        )
+        self._flat_cache = None
+
+    def flat_params(self) -> torch.Tensor:
+        """The 17,358 parameters in state_dict order; differentiable (autograd routes the
+        fused gradient back to each nn.Linear through the cat)."""
+        return torch.cat([p.reshape(-1) for p in self.net.parameters()])
+
+    def flat_params_nograd(self) -> torch.Tensor:
+        """Cached flat copy for sampling; rebuilt when any parameter changed."""
+        key = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        if self._flat_cache is None or self._flat_cache[0] != key:
+            with torch.no_grad():
+                self._flat_cache = (key, self.flat_params().detach())
+        return self._flat_cache[1]
+
+    @property
+    def precision_code(self) -> int:
+        return _PRECISIONS[self.precision]
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            return _ScoreMLPFn.apply(x, t, self.flat_params(), self.precision_code)
+        return _b.mlp_fwd(self.flat_params_nograd(), x, t, self.precision_code)
+
+
+def main(argv=None):
+    """Training loop of the reference's so3_train.py:54-81 (two-mode toy data, Adam 3e-4),
+    data-parallel over the GPUs of one node when launched with torchrun."""
+    from .diffusion import SO3Diffusion
+    from . import parallel
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=BATCH, help="global batch (reference: 64)")
+    ap.add_argument("--steps", type=int, default=400000)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--precision", default="fp32", choices=list(_PRECISIONS))
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--log-every", type=int, default=10)
+    ap.add_argument("--save-every", type=int, default=1000)
+    ap.add_argument("--weights", default="weights/weights_so3.pt")
+    args = ap.parse_args(argv)
+
+    ctx = parallel.init()
+    device = ctx.device
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision=args.precision).to(device)
+    net.train()
+    parallel.broadcast_parameters(net, ctx)
+    process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
+    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr)
+    z90 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    rotations = torch.stack((z90, z90.T), dim=0).to(device)
+    lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)
+    process.index_base = lo
+    gen = torch.Generator(device=device).manual_seed(1234 + ctx.rank)
+    t0 = time.time()
+    for i in range(1, args.steps + 1):
+        idx = torch.randint(0, 2, (hi - lo,), device=device, generator=gen)
+        truepos = rotations[idx]
+        loss = process(truepos)
+        optim.zero_grad()
+        loss.backward()
+        parallel.allreduce_gradients(net, ctx)
+        optim.step()
+        if i % args.log_every == 0:
+            lval = parallel.mean_scalar(loss.detach(), ctx)
+            if ctx.rank == 0:
+                print(json.dumps({"step": i, "loss": lval, "elapsed_s": round(time.time() - t0, 3)}), flush=True)
+        if i % args.save_every == 0 and ctx.rank == 0:
+            os.makedirs(os.path.dirname(args.weights) or ".", exist_ok=True)
+            torch.save(net.state_dict(), args.weights)
+    parallel.finalize(ctx)
+
+
+if __name__ == "__main__":
+    main()

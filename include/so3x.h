@@ -1,0 +1,169 @@
+/*
+ * so3x.h -- C ABI of libso3x.so, the MI355X-native (gfx950) backend of the SO(3)
+ * diffusion hot path of qazwsxal/diffusion-extensions.
+ *
+ * The reference is pure Python/PyTorch with no FFI layer of its own; each entry
+ * point below names the reference function (file:line under the reference
+ * checkout) whose work it replaces.  The Python host classes that keep the
+ * reference's public names (SO3Diffusion, IsotropicGaussianSO3, RotPredict,
+ * util.*) bind these symbols with ctypes -- INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.
+ *  - every function returns int: 0 = SO3X_OK, > 0 = a hipError_t from the
+ *    launch, < 0 = an SO3X_ERR_* argument error.  Nothing throws.
+ *  - device pointers unless a parameter is marked [host]; fp32, contiguous,
+ *    rotations row-major [n][3][3] (36 B per sample, AoS as the reference's
+ *    tensors); int64 timesteps.
+ *  - no hidden allocation and no host synchronisation: the caller owns all
+ *    buffers, passes the workspace, and names the HIP stream (hipStream_t as
+ *    void*).  All launches are graph-capturable.  Reentrant, no mutable globals.
+ *  - "quirk" flags reproduce documented reference behaviour bit-faithfully and
+ *    can be switched off.
+ */
+#ifndef SO3X_H
+#define SO3X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO3X_ABI_VERSION 1
+
+#define SO3X_OK 0
+#define SO3X_ERR_INVALID_ARG (-1)
+#define SO3X_ERR_WORKSPACE (-2)
+#define SO3X_ERR_UNSUPPORTED (-3)
+
+/* MLP operand precision: rotation state and rotation math are always fp32. */
+#define SO3X_PREC_F32 0  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)                 */
+#define SO3X_PREC_BF16 1 /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+
+#define SO3X_KNOTS 1000      /* CDF knots, distributions.py:15                    */
+#define SO3X_TRAP 999        /* CDF row length, distributions.py:26-30            */
+#define SO3X_MLP_PARAMS 17358 /* RotPredict(d_model=65, skewvec), so3_train.py:26-36 */
+#define SO3X_SCHED_ROWS 13
+
+typedef void* so3x_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------ host-side */
+int so3x_abi_version(void);
+const char* so3x_error_string(int code);
+
+/* GaussianDiffusion.__init__ buffers (diffusion.py:62-92) from float64 betas.
+ * [host] betas[T] -> [host] out[13][T] fp32, rows:
+ *  0 betas 1 alphas_cumprod 2 alphas_cumprod_prev 3 sqrt_alphas_cumprod
+ *  4 sqrt_one_minus_alphas_cumprod 5 log_one_minus_alphas_cumprod
+ *  6 sqrt_recip_alphas_cumprod 7 sqrt_recipm1_alphas_cumprod 8 posterior_variance
+ *  9 posterior_log_variance_clipped 10 posterior_mean_coef1 11 posterior_mean_coef2
+ *  12 posterior sigma = exp(0.5*row 9)  (diffusion.py:324) */
+int so3x_schedule_from_betas(const double* betas, int T, float* out);
+
+/* cosine_beta_schedule(T, s=0.008) of the un-vendored denoising_diffusion_pytorch
+ * helper (diffusion.py:60 call site).  [host] betas[T] float64. */
+int so3x_cosine_beta_schedule(int T, double* betas);
+
+/* The reference's fp32 knot vector pi*linspace(0,1,1000)**3 (distributions.py:15)
+ * and Haar weights (1-cos knots)/pi evaluated in fp32 (distributions.py:21),
+ * compiled in from the golden fixture.  [host] out arrays of 1000 floats. */
+int so3x_igso3_knots(float* knots, float* haar_w);
+
+/* SinusoidalPosEmb frequencies, models.py:18-21.  [host] out[half_dim]. */
+int so3x_posemb_freqs(int half_dim, float* out);
+
+/* ------------------------------------------------------------ rotation algebra */
+/* util.py:222-252  quat_to_rmat: q[n][4] (real first, any norm) -> R[n][3][3] */
+int so3x_quat_to_rmat(so3x_stream_t s, const float* q, float* R, int64_t n);
+/* util.py:164-192  log_rmat: R -> skew-symmetric log [n][3][3] */
+int so3x_log_rmat(so3x_stream_t s, const float* R, float* log_out, int64_t n);
+/* util.py:164-192 + 79-84  skew2vec(log_rmat(R)): R -> [n][3] */
+int so3x_log_rmat_vec(so3x_stream_t s, const float* R, float* vec_out, int64_t n);
+/* torch.matrix_exp(vec2skew(v)) (diffusion.py:294; util.py:87-92): v[n][3] -> R */
+int so3x_exp_skewvec(so3x_stream_t s, const float* v, float* R, int64_t n);
+/* util.py:349-361  so3_scale: exp(k log R); k_stride 0 = one scalar for all, 1 = per sample */
+int so3x_so3_scale(so3x_stream_t s, const float* R, const float* k, int64_t k_stride, float* out, int64_t n);
+/* util.py:195-205  aa_to_rmat: axis[n][3] (any norm), angle[n] -> R */
+int so3x_aa_to_rmat(so3x_stream_t s, const float* axis, const float* angle, float* R, int64_t n);
+/* util.py:208-219  rmat_to_aa: R -> axis[n][3] (NaN at angle 0, as the reference), angle[n] */
+int so3x_rmat_to_aa(so3x_stream_t s, const float* R, float* axis, float* angle, int64_t n);
+/* util.py:325-338  so3_lerp: a_stride 0 (one matrix for all, e.g. identity) or 9; w_stride 0 or 1 */
+int so3x_so3_lerp(so3x_stream_t s, const float* a, int64_t a_stride, const float* b, const float* w,
+                  int64_t w_stride, float* out, int64_t n);
+/* util.py:315-322  rmat_dist: ||log(a^T b)||_F -> [n] */
+int so3x_rmat_dist(so3x_stream_t s, const float* a, const float* b, float* out, int64_t n);
+/* batched a @ b and a @ b^T (diffusion.py:297,302,326,346); strides 0 (broadcast) or 9 */
+int so3x_rmul(so3x_stream_t s, const float* a, int64_t a_stride, const float* b, int64_t b_stride,
+              int transpose_b, float* out, int64_t n);
+
+/* --------------------------------------------------------------------- IGSO(3) */
+/* distributions.py:53-72  _eps_ft pointwise (float64 inside, fp32 out): omega[n], eps (stride 0/1) */
+int so3x_igso3_eps_ft(so3x_stream_t s, const float* omega, const float* eps, int64_t eps_stride,
+                      float* out, int64_t n);
+/* distributions.py:15-30  CDF table rows: eps[n_rows] -> trap[n_rows][999] */
+int so3x_igso3_build_tables(so3x_stream_t s, const float* eps, int64_t n_rows, float* trap);
+/* distributions.py:33-51  inverse-CDF sampling.
+ *  trap [n_rows][999]; row_idx int64[n] or NULL (then every sample uses row `row_const`);
+ *  quirk_col0 != 0: the interpolation weight is gathered from the row of sample 0
+ *      (row_idx[0]) -- distributions.py:42-43 with batched eps; 0 = own row.
+ *  axes[n][3] / unif[n]: explicit draws (parity runs); both NULL = in-kernel Philox4x32-10
+ *      keyed by seed, counter = (index_base + i, rng_offset) so results do not depend on
+ *      launch geometry or GPU count.
+ *  mean: 9 floats or NULL (identity).  angle_out[n], axis_out[n][3] optional. */
+int so3x_igso3_sample(so3x_stream_t s, const float* trap, const int64_t* row_idx, int64_t row_const,
+                      int quirk_col0, const float* axes, const float* unif, uint64_t seed,
+                      uint64_t rng_offset, int64_t index_base, const float* mean, float* out,
+                      float* angle_out, float* axis_out, int64_t n);
+/* distributions.py:74-77 log_prob, and its gradient (distributions.py:189-190 obtains it by
+ * autograd): logp[n]; score_vec[n][3] = (f'/f)*axis (tangent form) and/or grad_R[n][3][3]
+ * = d logp / dR (autograd-shaped); either may be NULL. */
+int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, int64_t eps_stride,
+                             float* logp, float* score_vec, float* grad_R, int64_t n);
+
+/* ------------------------------------------------------------------- score MLP */
+/* models.py:13-25 + so3_train.py:39-49, out_type="skewvec".  params = the 17,358
+ * fp32 values in state_dict order net.{0,2,4,6,8}.{weight,bias}.  t int64, t_stride
+ * 0 (one timestep for the whole batch, the (1,)-shaped t of so3_test.py:31) or 1. */
+size_t so3x_mlp_workspace_bytes(int64_t n, int precision);
+int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
+                 int64_t t_stride, float* out, int64_t n, int precision, void* workspace,
+                 size_t workspace_bytes);
+/* autograd of the above for a given dL/dout[n][3] -> dparams[17358] (overwritten). */
+int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
+                 int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,
+                 void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------- diffusion steps */
+/* SO3Diffusion.q_sample + the p_losses target (diffusion.py:339-355), fused with the
+ * noise draw: noise ~ IGSO3(sqrt(1-abar_t)) from trap_q rows [T][999];
+ * x_t = so3_scale(x0, sqrt(abar_t)) @ noise; target = vee(log noise)/eps_t.
+ * sched = device copy of the [13][T] table.  noise_in != NULL teacher-forces the noise
+ * (then trap_q/axes/unif are ignored).  x_t, target, noise_out optional outputs. */
+int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q,
+                         const float* x0, const int64_t* t, int quirk_col0, const float* noise_in,
+                         const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
+                         int64_t index_base, float* x_t, float* target, float* noise_out, int64_t n);
+
+/* Reverse mean for a given network output v (diffusion.py:291-313): x0hat (optional) and
+ * posterior mean, one shared timestep t. */
+int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, const float* v, int t,
+                float* x0hat, float* mean, int64_t n);
+
+/* SO3Diffusion.p_sample / p_sample_loop (diffusion.py:315-337) with the RotPredict score
+ * network fused in: applies n_steps reverse steps t_start, t_start-1, ... to x in place
+ * (x_out may alias x_in).  trap_p = CDF rows of the posterior sigma [T][999].
+ * axes/unif: explicit draws for ONE step (n_steps must be 1), else in-kernel Philox with
+ * counter (index_base + i, rng_offset + t). */
+size_t so3x_p_sample_workspace_bytes(int T, int precision);
+int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T,
+                        const float* trap_p, const float* x_in, float* x_out, int t_start,
+                        int n_steps, const float* axes, const float* unif, uint64_t seed,
+                        uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
+                        void* workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SO3X_H */

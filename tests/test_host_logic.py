@@ -1,0 +1,172 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol that
+include/so3x.h declares, host-side entry points match the goldens, the Python host
+layer keeps the reference's interface, refuses CPU tensors loudly, and the
+data-parallel plumbing works over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, PKG
+
+from so3x import backend as B
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "so3x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(so3x_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = C.CDLL(B.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/so3x.h but not exported"
+    assert declared == set(B.SYMBOLS)
+    assert B.lib().so3x_abi_version() == 1
+
+
+def test_no_oracle_or_cpu_fallback_in_product():
+    # the product package must not import or reference the oracle (test infrastructure only)
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower(), f"{f} mentions the oracle"
+
+
+def test_schedule_matches_golden(golden):
+    g = golden["schedule"]
+    for T in (100, 1000):
+        betas = B.cosine_beta_schedule(T)
+        assert np.array_equal(betas, g[f"betas64_{T}"])
+        tab = B.schedule_from_betas(betas)
+        names = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                 "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                 "posterior_mean_coef1", "posterior_mean_coef2")
+        for i, nme in enumerate(names):
+            assert np.allclose(tab[i], g[f"{nme}_{T}"], rtol=2e-7, atol=0), nme
+        assert np.allclose(tab[12], np.exp(0.5 * tab[9].astype(np.float64)), rtol=2e-7)
+    assert abs(float(tab[6][999]) - 20291) < 1 and tab[10][0] == 1 and tab[11][0] == 0
+
+
+def test_knots_and_freqs_match_fixture(golden):
+    k, w = B.igso3_knots()
+    g = golden["igso3_knots"]
+    assert np.array_equal(k, g["knots"]) and np.array_equal(w, g["haar_w"])
+    import math
+    fr = B.posemb_freqs(28)
+    ref = torch.exp(torch.arange(28) * -(math.log(10000) / 27)).numpy()
+    assert np.array_equal(fr, ref)
+
+
+def test_error_paths_return_codes_not_crashes():
+    lib = B.lib()
+    assert lib.so3x_so3_scale(None, None, None, C.c_int64(1), None, C.c_int64(4)) == -1
+    assert lib.so3x_quat_to_rmat(None, None, None, C.c_int64(0)) == 0
+    assert lib.so3x_p_sample_chain(None, None, None, C.c_int(10), None, None, None, C.c_int(3), C.c_int(5), None, None,
+                                   C.c_uint64(0), C.c_uint64(0), C.c_int64(0), C.c_int64(8), C.c_int(1), None,
+                                   C.c_size_t(0)) == -1  # t_start - n_steps + 1 < 0
+    assert b"workspace" in lib.so3x_error_string(-2)
+    ws = lib.so3x_p_sample_workspace_bytes(C.c_int(1000), C.c_int(1))
+    assert 53 * 1024 + 1000 * 96 * 4 <= ws <= 60 * 1024 + 1000 * 96 * 4
+
+
+def test_cpu_tensors_are_refused_loudly():
+    from so3x import util
+    with pytest.raises(B.So3xError, match="no CPU path"):
+        util.quat_to_rmat(torch.randn(4, 4))
+    with pytest.raises(B.So3xError):
+        util.so3_scale(torch.eye(3)[None], torch.ones(1))
+
+
+def test_reference_interface_is_kept(golden):
+    from so3x.diffusion import SO3Diffusion
+    from so3x.so3_train import RotPredict
+    from so3x import util, distributions
+    net = RotPredict(out_type="skewvec")
+    keys = list(net.state_dict().keys())
+    assert keys == [f"net.{l}.{k}" for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")]
+    assert sum(p.numel() for p in net.parameters()) == 17358
+    assert net.flat_params().numel() == 17358
+    # checkpoints interchange with the reference's: load the golden (reference-initialised) weights
+    g = golden["score_mlp"]
+    net.load_state_dict({f"net.{l}.{k}": torch.from_numpy(g[f"net_{l}_{k}"]) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")})
+    proc = SO3Diffusion(net, timesteps=100, loss_type="skewvec")
+    assert proc.num_timesteps == 100 and proc.identity.shape == (3, 3)
+    gs = golden["schedule"]
+    for nme in ("betas", "sqrt_alphas_cumprod", "posterior_mean_coef1", "posterior_log_variance_clipped"):
+        assert np.allclose(getattr(proc, nme).numpy(), gs[f"{nme}_100"], rtol=2e-7, atol=0)
+    for m in ("forward", "p_losses", "q_sample", "p_sample", "p_sample_loop", "predict_start_from_noise", "q_posterior",
+              "p_mean_variance", "q_mean_variance"):
+        assert callable(getattr(proc, m))
+    for f in ("quat_to_rmat", "rmat_dist", "so3_lerp", "so3_scale", "log_rmat", "skew2vec", "vec2skew", "aa_to_rmat",
+              "rmat_to_aa"):
+        assert callable(getattr(util, f))
+    v = torch.randn(5, 3)
+    assert torch.equal(util.skew2vec(util.vec2skew(v)), v)
+    S = util.vec2skew(v)
+    assert torch.equal(S, -S.transpose(-1, -2)) and torch.equal(S[:, 2, 1], v[:, 0]) and torch.equal(S[:, 2, 0], -v[:, 1])
+    explicit = SO3Diffusion(net, betas=torch.linspace(1e-4, 0.02, 50))
+    assert explicit.num_timesteps == 50
+    with pytest.raises(NotImplementedError):
+        RotPredict(out_type="rotmat")
+    assert hasattr(distributions.IsotropicGaussianSO3, "sample") and hasattr(distributions.IsotropicGaussianSO3, "log_prob")
+
+
+def test_shard_ranges_cover_batch_exactly():
+    from so3x.parallel import shard_range
+    for n in (0, 1, 7, 64, 2 ** 20, 2 ** 22 + 3):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from so3x import parallel
+from so3x.so3_train import RotPredict
+ctx = parallel.init(backend="gloo", device="cpu")
+assert ctx.world_size == 2
+torch.manual_seed(ctx.rank)            # different init per rank on purpose
+net = RotPredict(out_type="skewvec")
+parallel.broadcast_parameters(net, ctx)
+flat = torch.cat([p.data.reshape(-1) for p in net.parameters()])
+ref = [torch.zeros_like(flat) for _ in range(2)]
+torch.distributed.all_gather(ref, flat)
+assert torch.equal(ref[0], ref[1]), "parameters differ after broadcast"
+for i, p in enumerate(net.parameters()):
+    p.grad = torch.full_like(p, float(ctx.rank + 1) * (i + 1))
+parallel.allreduce_gradients(net, ctx)
+for i, p in enumerate(net.parameters()):
+    assert torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))), "gradient mean wrong"
+m = parallel.mean_scalar(torch.tensor(float(ctx.rank)), ctx)
+assert abs(m - 0.5) < 1e-7
+lo, hi = parallel.shard_range(10, ctx.rank, ctx.world_size)
+assert (lo, hi) == ((0, 5) if ctx.rank == 0 else (5, 10))
+parallel.finalize(ctx)
+print("OK", ctx.rank)
+'''
+
+
+def test_gloo_world_size_2_gradient_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), PKG], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "OK" in o
