@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SO(3) reverse-diffusion sample-steps/s (BASELINE.json metric).
+
+Workload (BASELINE config 3): B = 2^20 rotations per GPU, T = 1000-step reverse chain with
+the RotPredict score network (bf16 MFMA operands, fp32 accumulate, fp32 rotation state),
+synthetic random-quaternion inputs, seed-0 default-init weights, in-kernel Philox noise.
+One "step" = one p_sample application to the whole batch; K steps run as consecutive
+timesteps T-1, T-2, ... (wrapping after t = 0) inside the chain-resident kernel.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Multi-GPU = the batch axis sharded (weak scaling, 2^20 per
+GPU), no data-path collective (samples are independent; Philox streams keyed by the global
+sample index).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+MLP_FLOP_PER_SAMPLE = 34190          # 2*(4*65*65 + 65*3), SURVEY.md 8d
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # dense, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0                # spec, same table
+IGSO3_BYTES_PER_EVAL = 56            # 36 R + 4 eps in, 4 logp + 12 score out, SURVEY.md 8d
+
+
+def run_steps(B, params, sched, trap_p, x, T, nsteps, seed, index_base, precision, rng_offset=0):
+    """nsteps consecutive reverse steps starting at t = T-1, wrapping; one launch per <= T steps."""
+    done = 0
+    launches = 0
+    t = T - 1
+    while done < nsteps:
+        seg = min(nsteps - done, t + 1)
+        B.p_sample_chain(params, sched, trap_p, x, t, seg, seed=seed, rng_offset=rng_offset + done, index_base=index_base,
+                         precision=precision, out=x)
+        done += seg
+        launches += 1
+        t = t - seg
+        if t < 0:
+            t = T - 1
+    return launches
+
+
+def cpu_baseline(T, params_np, betas, budget_s=12.0):
+    """The oracle (C restatement, OpenMP over the batch) timed on this box's host cores on a bounded
+    sample of the same workload: n rotations x a few reverse steps around the middle of the chain."""
+    from oracle import oracle as O
+    sched = O.schedule_from_betas(betas)
+    trap_p = O.igso3_build_tables(np.exp(np.float32(0.5) * sched[9]))
+    rng = np.random.default_rng(0)
+    n = 1 << 15
+    x = O.quat_to_rmat(rng.standard_normal((n, 4)).astype(np.float32))
+    axes = rng.standard_normal((n, 3)).astype(np.float32)
+    unif = rng.random(n, dtype=np.float32)
+    O.p_sample_step(params_np, sched, trap_p, x[:1024], 500, axes[:1024], unif[:1024])  # warm
+    t0 = time.perf_counter()
+    steps = 0
+    tt = T // 2
+    while True:
+        x = O.p_sample_step(params_np, sched, trap_p, x, tt, axes, unif)
+        steps += 1
+        tt = tt - 1 if tt > 0 else T - 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 200:
+            break
+    return {"value": n * steps / el, "unit": "sample-steps/s", "cores": O.omp_threads(), "kind": "port",
+            "sample": f"{n} rotations x {steps} reverse steps (t from {T // 2} down), {el:.1f} s of CPU work"}
+
+
+def igso3_eval_roofline(B, torch, n=1 << 20, reps=20):
+    """BASELINE config 2: IGSO(3) log-density + score, per-sample eps, HBM-bound kernel."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(0)
+    R = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+    eps = torch.rand(n, device=dev, generator=g) * 0.9 + 0.1
+    for _ in range(3):
+        B.igso3_logprob_score(R, eps)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        B.igso3_logprob_score(R, eps)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = IGSO3_BYTES_PER_EVAL * n / (ms * 1e-3) / 1e9
+    return {"kernel": "k_logprob_score", "evals_per_s": n / (ms * 1e-3), "bound": "hbm", "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "n": n, "ms": ms}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch-log2", type=int, default=20, help="rotations per GPU = 2^this (BASELINE: 20)")
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    from so3x import backend as B
+    from so3x import parallel
+    from so3x.so3_train import RotPredict
+    from so3x.diffusion import SO3Diffusion
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    ctx = parallel.init()
+    dev = ctx.device
+    if dev.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+
+    T = args.timesteps
+    n = 1 << args.batch_log2
+    prec = B.PREC_BF16 if args.precision == "bf16" else B.PREC_F32
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision=args.precision)          # seed-0 default init (CPU generator)
+    q = torch.randn(n, 4, generator=torch.Generator().manual_seed(ctx.rank))  # synthetic random quaternions
+    net = net.to(dev)
+    proc = SO3Diffusion(net, timesteps=T).to(dev)
+    _, trap_p = proc._tables()
+    params = net.flat_params_nograd()
+    x = B.quat_to_rmat(q.to(dev))
+    index_base = ctx.rank * n
+
+    def barrier():
+        torch.cuda.synchronize()
+        if ctx.world_size > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(B, params, proc._sched, trap_p, x, T, args.warmup, 0, index_base, prec)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                        # same (current) stream the C ABI launches on
+    launches = run_steps(B, params, proc._sched, trap_p, x, T, args.steps, 0, index_base, prec, rng_offset=args.warmup)
+    ev1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    barrier()
+    dev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+    if ctx.world_size > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    el = float(tmax.item())
+    ok = bool(torch.isfinite(x).all().item())
+
+    if ctx.rank == 0:
+        total = ctx.world_size * n * args.steps
+        flop_per_launch = MLP_FLOP_PER_SAMPLE * n * args.steps / launches
+        ms_per_launch = dev_ms / launches
+        tflops = flop_per_launch / (ms_per_launch * 1e-3) / 1e12
+        line = {
+            "metric": "SO(3) sample-steps/sec, reverse p_sample chain with score MLP", "value": total / el,
+            "unit": "sample-steps/s", "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: full reverse p_sample chain with RotPredict score MLP",
+                       "batch_per_gpu": n, "global_batch": ctx.world_size * n, "timesteps": T,
+                       "mlp_operands": args.precision, "rotation_state": "fp32", "noise": "in-kernel Philox4x32-10",
+                       "parallelism": f"batch-sharded x{ctx.world_size}, no collective"},
+            "finite": ok,
+            "roofline": {"kernel": "k_p_sample_chain", "bound": "mfma", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": launches, "ms_per_launch": ms_per_launch,
+                         "flop_per_sample_step": MLP_FLOP_PER_SAMPLE,
+                         "note": "algorithmic MLP flops only; kernel also does ~600 fp32 VALU ops + 570 transcendentals "
+                                 "per sample-step (see DESIGN.md); chain HBM traffic is 72 B/sample per launch"},
+        }
+        if not args.no_extras:
+            try:
+                line["igso3_eval"] = igso3_eval_roofline(B, torch)
+            except Exception as e:  # report, never hide
+                line["igso3_eval"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(T, params.cpu().numpy(), B.cosine_beta_schedule(T))
+        print(json.dumps(line), flush=True)
+    parallel.finalize(ctx)
+
+
+if __name__ == "__main__":
+    main()
