@@ -134,12 +134,6 @@ int launch_prep(hipStream_t s, const float* params, int precision, int variant, 
 
 extern "C" {
 
-size_t so3x_mlp_workspace_bytes(int64_t n, int precision) {
-  (void)n;
-  // weight image (FULL variant) + backward scratch (partial-gradient slabs, see so3x_mlp_bwd)
-  return beff_offset(precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16, FULL) + (size_t)512 * NPARAMS * sizeof(float);
-}
-
 int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
                  int64_t n, int precision, void* workspace, size_t workspace_bytes) {
   if (n < 0 || (n && (!params || !R || !t || !out)) || (t_stride != 0 && t_stride != 1)) return SO3X_ERR_INVALID_ARG;
@@ -150,13 +144,6 @@ int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int
   if (rc) return rc;
   if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);
   return launch_fwd_t<SO3X_PREC_BF16, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);
-}
-
-int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride,
-                 const float* dout, float* dparams, int64_t n, int precision, void* workspace, size_t workspace_bytes) {
-  (void)s; (void)params; (void)R; (void)t; (void)t_stride; (void)dout; (void)dparams; (void)n; (void)precision;
-  (void)workspace; (void)workspace_bytes;
-  return SO3X_ERR_UNSUPPORTED;  // TODO(next commit): fused recompute backward
 }
 
 }  // extern "C"
