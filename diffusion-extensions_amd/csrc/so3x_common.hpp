@@ -66,6 +66,56 @@ __device__ __forceinline__ void store_rows(float* __restrict__ g, int64_t base, 
   lds_to_tile<W>(g, base, cnt, lds);
 }
 
+// ---- wave-private variant: one wave = 64 samples, no workgroup barrier -----------------
+// The same coalesced AoS<->lane transposition, but through a per-wave LDS slice (W*64
+// floats).  A wave's LDS operations complete in issue order, so only the compiler has to
+// be told not to reorder them (wave_barrier); waves of a workgroup never wait for each other.
+constexpr int kWave = 64;
+
+template <int W>
+__device__ __forceinline__ void wave_load_rows(const float* __restrict__ g, int64_t base, int cnt, float* wlds, float* r) {
+  const int lane = threadIdx.x & 63;
+  const float* src = g + base * W;
+  __builtin_amdgcn_wave_barrier();
+  if (cnt == kWave && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(wlds);
+#pragma unroll
+    for (int i = 0; i < (W * 16 + 63) / 64; i++) {
+      const int k = lane + 64 * i;
+      if (k < W * 16) d4[k] = s4[k];
+    }
+  } else {
+    for (int i = lane; i < cnt * W; i += 64) wlds[i] = src[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < W; j++) r[j] = wlds[lane * W + j];
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int W>
+__device__ __forceinline__ void wave_store_rows(float* __restrict__ g, int64_t base, int cnt, float* wlds, const float* r) {
+  const int lane = threadIdx.x & 63;
+  float* dst = g + base * W;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < W; j++) wlds[lane * W + j] = r[j];
+  __builtin_amdgcn_wave_barrier();
+  if (cnt == kWave && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* s4 = reinterpret_cast<const float4*>(wlds);
+#pragma unroll
+    for (int i = 0; i < (W * 16 + 63) / 64; i++) {
+      const int k = lane + 64 * i;
+      if (k < W * 16) d4[k] = s4[k];
+    }
+  } else {
+    for (int i = lane; i < cnt * W; i += 64) dst[i] = wlds[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // scalar-per-sample operand with stride 0 (broadcast) or 1
 __device__ __forceinline__ float load_scalar(const float* p, int64_t stride, int64_t i) { return p[i * stride]; }
 

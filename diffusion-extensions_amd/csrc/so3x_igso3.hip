@@ -121,46 +121,64 @@ k_igso3_sample(const float* __restrict__ trap, const int64_t* __restrict__ row_i
   }
 }
 
+// exact-identity input: the reference's fp64 limit expression; out of line so the fp64 code does not
+// inflate the streaming kernel's register budget
+__device__ __attribute__((noinline)) float logp_identity_f64(float e) {
+  double dlogf;
+  return logf((float)eps_ft_and_dlog_f64(0.0, (double)e, &dlogf));
+}
+
 // ------------------------------------------------------------------ A3 log-prob + score
 // 56 algorithmic bytes per evaluation (36 R + 4 eps in, 4 logp + 12 score out): HBM-bound
-// by design.  The density is evaluated in fp64 exactly as the reference does
-// (distributions.py:53-72), cast to fp32, then log'd in fp32 (:77).
+// by design.  The reference evaluates the density in fp64, casts to fp32 and logs in fp32
+// (distributions.py:53-77); igso3_logf_dlog_f32 reproduces that result in fp32 arithmetic
+// (so3x_igso3.hpp) -- the fp64 form was VALU-bound at 27 % of HBM peak.
 __global__ void __launch_bounds__(kBlock)
 k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int64_t eps_stride, float* __restrict__ logp,
                 float* __restrict__ score_vec, float* __restrict__ grad_R, int64_t n) {
-  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
-  const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * kTile;
-    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
-    const int64_t idx = base + threadIdx.x;
-    const bool live = threadIdx.x < cnt;
+  // wave-private staging: every wave streams its own 64-sample tiles, no workgroup barrier
+  __shared__ __attribute__((aligned(16))) float sm[kBlock / kWave][kWave * 9];
+  float* wl = sm[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t ntiles = (n + kWave - 1) / kWave;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * kWave;
+    const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
+    const int64_t idx = base + lane;
+    const bool live = lane < cnt;
     float r[9], w[3];
-    load_rows<9>(R, base, cnt, sm, r);
     const float e = live ? eps[idx * eps_stride] : 1.0f;
+    wave_load_rows<9>(R, base, cnt, wl, r);
     log3(r, w);
-    const float ang = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);   // rmat_to_aa angle, util.py:217
-    double dlogf;
-    const float f = (float)eps_ft_and_dlog_f64((double)ang, (double)e, &dlogf);
-    if (live) logp[idx] = logf(f);
-    const float dl = (float)dlogf;
+    const float ang = fsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);   // rmat_to_aa angle, util.py:217
+    float lp, dl;
+    if (ang == 0.0f) {  // exact identity: the reference's fp64 limit expression (rare, divergent on purpose)
+      lp = logp_identity_f64(e);
+      dl = 0.0f;
+    } else {
+      lp = igso3_logf_dlog_f32(ang, e, &dl);
+    }
+    if (live) logp[idx] = lp;
     if (score_vec) {
-      float sv[3] = {dl * (w[0] / ang), dl * (w[1] / ang), dl * (w[2] / ang)};
-      store_rows<3>(score_vec, base, cnt, sm, sv);
+      const float k = dl * frcp(ang);
+      float sv[3] = {k * w[0], k * w[1], k * w[2]};
+      wave_store_rows<3>(score_vec, base, cnt, wl, sv);
     }
     if (grad_R) {
       // d omega / dR = [ c/(4s) (R - R^T) - (s/2) I ] / (s^2 + c^2)   
       float v0 = r[7] - r[5], v1 = r[2] - r[6], v2 = r[3] - r[1];
-      float s = sqrtf(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
+      float s = fsqrt(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
       float c = (r[0] + r[4] + r[8] - 1.0f) * 0.5f;
-      float inv = dl / (s * s + c * c);
-      float k = c / (4.0f * s);
+      float inv = dl * frcp(s * s + c * c);
+      float k = c * frcp(4.0f * s);
       float g[9];
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) g[3 * i + j] = (k * (r[3 * i + j] - r[3 * j + i]) - (i == j ? 0.5f * s : 0.0f)) * inv;
-      store_rows<9>(grad_R, base, cnt, sm, g);
+      wave_store_rows<9>(grad_R, base, cnt, wl, g);
     }
   }
 }

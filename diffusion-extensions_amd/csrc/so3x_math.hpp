@@ -36,6 +36,34 @@ __device__ __forceinline__ void sincos_cw(float a, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// 1-ulp hardware reciprocal / sqrt / rsqrt.  The IEEE-exact division and sqrt sequences
+// (v_div_scale/fmas/fixup, ~10 instructions each) cost more than the rest of the rotation
+// math; 1 ulp (6e-8) is far inside the 1e-5 parity gates.  Semantics at 0 / inf are the
+// IEEE ones (rcp(0) = inf), which the 0/0 -> NaN behaviours of the reference rely on.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// atan2(s, c) for s >= 0 (result in [0, pi]): odd minimax polynomial on [0, 1] with exact unit
+// slope at 0 (max abs error 1.1e-7, relative accuracy kept for small angles), octant folding.
+__device__ __forceinline__ float atan2_pos(float s, float c) {
+  const float ac = fabsf(c);
+  const float mx = fmaxf(s, ac), mn = fminf(s, ac);
+  const float a = fdiv(mn, mx);  // 0/0 -> NaN only when s == c == 0 (not a rotation)
+  const float z = a * a;
+  float q = -0x1.1d7010p-8f;
+  q = fmaf(q, z, 0x1.797dd0p-6f);
+  q = fmaf(q, z, -0x1.d9485ep-5f);
+  q = fmaf(q, z, 0x1.912c20p-4f);
+  q = fmaf(q, z, -0x1.1e3d90p-3f);
+  q = fmaf(q, z, 0x1.98d610p-3f);
+  q = fmaf(q, z, -0x1.5550f2p-2f);
+  float r = fmaf(a * z, q, a);
+  r = s > ac ? 1.57079632679489662f - r : r;
+  return c < 0.0f ? 3.14159265358979324f - r : r;
+}
+
 // vee(R - R^T)-based log, as a 3-vector.  util.py:164-192.
 //   s = |v|/2, c = (tr R - 1)/2, angle = atan2(s, c), w = v * angle/(2 s);
 //   angle == 0 -> 0 (util.py:174).  s == 0 with c < 0 (exact pi) is the reference's
@@ -43,10 +71,10 @@ __device__ __forceinline__ void sincos_cw(float a, float* sn, float* cs) {
 //   the correct axis from diag((R+I)/2) is used instead (parity unpinned there).
 __device__ __forceinline__ void log3(const float* R, float* w) {
   float v0 = R[7] - R[5], v1 = R[2] - R[6], v2 = R[3] - R[1];
-  float s = sqrtf(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
+  float s = fsqrt(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
   float c = (R[0] + R[4] + R[8] - 1.0f) * 0.5f;
-  float ang = atan2f(s, c);
-  float scale = ang / (2.0f * s);
+  float ang = atan2_pos(s, c);
+  float scale = ang * frcp(2.0f * s);
   if (ang == 0.0f) scale = 0.0f;
   w[0] = scale * v0; w[1] = scale * v1; w[2] = scale * v2;
   if (s == 0.0f && ang != 0.0f) {  // exact pi rotation: rare, divergent on purpose
@@ -64,16 +92,15 @@ __device__ __forceinline__ void log3(const float* R, float* w) {
 __device__ __forceinline__ void exp3(const float* w, float* R) {
   float x = w[0], y = w[1], z = w[2];
   float t2 = x * x + y * y + z * z;
-  float th = sqrtf(t2);
-  float A, B;
-  if (th < 1e-4f) {
+  float th = fsqrt(t2);
+  float sn, cs;
+  sincos_cw(th, &sn, &cs);
+  const float it = frcp(th);
+  float A = sn * it;
+  float B = (1.0f - cs) * it * it;
+  if (th < 1e-3f) {  // series: also covers th == 0 (rcp(0) = inf above)
     A = 1.0f - t2 * (1.0f / 6.0f);
     B = 0.5f - t2 * (1.0f / 24.0f);
-  } else {
-    float sn, cs;
-    sincos_cw(th, &sn, &cs);
-    A = sn / th;
-    B = (1.0f - cs) / t2;
   }
   R[0] = 1.0f + B * (x * x - t2); R[1] = B * x * y - A * z;       R[2] = B * x * z + A * y;
   R[3] = B * x * y + A * z;       R[4] = 1.0f + B * (y * y - t2); R[5] = B * y * z - A * x;
@@ -149,7 +176,7 @@ __device__ __forceinline__ float u01(uint32_t u) { return (float)(u >> 8) * (1.0
 // reference's normalised Gaussian 3-vector (distributions.py:35-36) at 2 draws, not 3.
 __device__ __forceinline__ void unit_axis(uint32_t a, uint32_t b, float* ax) {
   float z = 2.0f * u01(a) - 1.0f + (1.0f / 16777216.0f);  // centred: z in (-1, 1)
-  float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+  float r = fsqrt(fmaxf(0.0f, 1.0f - z * z));
   float sn, cs;
   sincos_cw(2.0f * kPi * u01(b), &sn, &cs);
   ax[0] = r * cs; ax[1] = r * sn; ax[2] = z;
@@ -169,7 +196,7 @@ __device__ __forceinline__ float igso3_angle(const float* row, const float* wrow
   int idx0 = idx1 - 1 < 0 ? 0 : idx1 - 1;
   float ts = wrow[idx0], te = wrow[idx1];
   float df = fmaxf(te - ts, 1e-6f);
-  float wt = fminf(fmaxf((u - ts) / df, 0.0f), 1.0f);
+  float wt = fminf(fmaxf((u - ts) / df, 0.0f), 1.0f);  // IEEE division: keeps the knot interpolation bit-faithful
   float a0 = knots[idx0 + 1], a1 = knots[idx1 + 1];
   float dl = a1 - a0;
   return wt < 0.5f ? a0 + wt * dl : a1 - dl * (1.0f - wt);  // torch.lerp's two-sided form

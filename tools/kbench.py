@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one MI355X (development aid; results go to stdout as JSON lines)."""
+import json
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
+    sys.path.insert(0, os.path.abspath(p))
+import torch
+from so3x import backend as B
+from so3x.so3_train import RotPredict
+from so3x.diffusion import SO3Diffusion
+
+dev = "cuda:0"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    which = set(sys.argv[1:]) or {"logprob", "rot", "chain", "train"}
+    g = torch.Generator(device=dev).manual_seed(0)
+    if "logprob" in which:
+        for lg in (20, 24):
+            n = 1 << lg
+            R = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+            eps = torch.rand(n, device=dev, generator=g) * 0.9 + 0.1
+            ms = timeit(lambda: B.igso3_logprob_score(R, eps))
+            print(json.dumps({"k": "logprob_score", "n": n, "ms": ms, "GBs": 56 * n / ms / 1e6, "frac8T": 56 * n / ms / 1e6 / 8000}))
+    if "rot" in which:
+        n = 1 << 22
+        R = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        k = torch.rand(n, device=dev, generator=g)
+        ms = timeit(lambda: B.so3_scale(R, k))
+        print(json.dumps({"k": "so3_scale", "n": n, "ms": ms, "GBs": 76 * n / ms / 1e6}))
+        ms = timeit(lambda: B.quat_to_rmat(torch.empty(0, 4, device=dev)) if False else B.log_rmat_vec(R))
+        print(json.dumps({"k": "log_rmat_vec", "n": n, "ms": ms, "GBs": 48 * n / ms / 1e6}))
+    if "chain" in which or "train" in which:
+        torch.manual_seed(0)
+        net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
+        proc = SO3Diffusion(net, timesteps=1000).to(dev)
+        _, trap_p = proc._tables()
+        params = net.flat_params_nograd()
+    if "chain" in which:
+        n = 1 << 20
+        x = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        for prec, name in ((1, "bf16"), (0, "fp32")):
+            steps = 50 if prec else 10
+            ms = timeit(lambda: B.p_sample_chain(params, proc._sched, trap_p, x, 600, steps, seed=1, precision=prec), reps=3, warm=1)
+            print(json.dumps({"k": f"chain_{name}", "n": n, "steps": steps, "ms": ms, "sample_steps_per_s": n * steps / ms * 1e3,
+                              "mfma_algo_TFLOPs": 34190 * n * steps / ms / 1e9}))
+        ms = timeit(lambda: B.p_sample_chain(params, proc._sched, trap_p, x, 600, 1, seed=1, precision=1), reps=10)
+        print(json.dumps({"k": "step_bf16", "n": n, "ms": ms, "sample_steps_per_s": n / ms * 1e3}))
+    if "train" in which:
+        n = 1 << 19
+        x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        for prec in ("bf16", "fp32"):
+            net.precision = prec
+            opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+
+            def step():
+                loss = proc(x0)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            ms = timeit(step, reps=5, warm=2)
+            print(json.dumps({"k": f"train_step_{prec}", "n": n, "ms": ms, "samples_per_s": n / ms * 1e3}))
+            t = torch.randint(0, 1000, (n,), device=dev)
+            ms = timeit(lambda: B.mlp_fwd(params, x0, t, B.PREC_BF16 if prec == "bf16" else B.PREC_F32), reps=5)
+            print(json.dumps({"k": f"mlp_fwd_{prec}", "n": n, "ms": ms, "TFLOPs": 34190 * n / ms / 1e9}))
+
+
+if __name__ == "__main__":
+    main()
