@@ -125,7 +125,7 @@ k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, co
 //  * noise: Philox keyed (seed; global sample index, rng_offset + t) or explicit draws.
 // ---------------------------------------------------------------------------------------
 template <int PREC>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, PREC == SO3X_PREC_BF16 ? 3 : 2)
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ sched, int T,
                  const float* __restrict__ trap_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                  int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
@@ -205,16 +205,20 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
                  const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                  uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
   constexpr int IMG = image_bytes<PREC, CHAIN>();
-  static int attr_set = 0;
-  if (!attr_set) {
+  static int max_blocks = 0;  // resident blocks on this device (occupancy x CUs), queried once; host-only calls, no sync
+  if (!max_blocks) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p_sample_chain<PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
     if (e != hipSuccess) return (int)e;
-    attr_set = 1;
+    int per_cu = 0, dev = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_p_sample_chain<PREC>), 256, IMG);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+    max_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
   }
   const int64_t nchunks = (n + 63) / 64;
   const int64_t want = (nchunks + 3) / 4;
-  const int max_blocks = IMG > 80 * 1024 ? 256 : 512;  // LDS-limited: 1 or 2 resident blocks per CU
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   hipLaunchKernelGGL((k_p_sample_chain<PREC>), dim3(grid), dim3(256), IMG, s, ws, beff, sched, T, trap_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);

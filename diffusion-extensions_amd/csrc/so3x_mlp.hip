@@ -44,7 +44,8 @@ template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image
 
 // ---- prep: per-timestep effective bias of layer 0 (appendix C.3) ---------------------
 //   beff[t][o] = b_0[o] + sum_e W_0[o][9+e] * emb_e(t)   (o < 65), other rows 0.
-__global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ params, Freqs fr, int T, float* __restrict__ beff) {
+__global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ params, Freqs fr, int T, float scale,
+                                                    float* __restrict__ beff) {
   __shared__ float emb[NEMB];
   const int t = blockIdx.x;
   if (threadIdx.x < NEMB) emb[threadIdx.x] = emb_value((int64_t)t, threadIdx.x, fr);
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ par
 #pragma unroll 8
       for (int e = 0; e < NEMB; e++) acc = fmaf(W[e], emb[e], acc);
     }
-    beff[(size_t)t * 96 + o] = acc;
+    beff[(size_t)t * 96 + o] = scale * acc;  // scale = -log2(e) when the SiLU scale fold is on (so3x_mlp.hpp)
   }
 }
 
@@ -94,7 +95,8 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
   hipLaunchKernelGGL((k_prep_image<PREC, VAR>), dim3(32), dim3(256), 0, s, params, ws);
   if (VAR == CHAIN && T > 0) {
     float* beff = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR));
-    hipLaunchKernelGGL(k_prep_beff, dim3(T), dim3(128), 0, s, params, host_freqs(), T, beff);
+    hipLaunchKernelGGL(k_prep_beff, dim3(T), dim3(128), 0, s, params, host_freqs(), T,
+                       fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff);
   }
   return check_launch();
 }

@@ -94,6 +94,14 @@ template <int PREC, int VAR> __host__ __device__ inline int l0_slot_to_col(int s
 }
 template <int PREC> __host__ __device__ constexpr int l0_emb_slot0() { return PREC == SO3X_PREC_F32 ? 10 : 16; }
 
+// SiLU scale fold (bf16 sampling path only): the image pre-multiplies every pre-activation by
+// s = -log2(e), so the activation is  y * rcp(1 + exp2(y)) = s * silu(z)  -- one v_exp_f32, one
+// v_add, one v_rcp_f32, one v_mul (the -log2e multiply of exp(-z) is gone); the factor s is divided
+// back out of the NEXT layer's feature columns (for hidden layers s * 1/s: unchanged weights, only
+// the bias column carries s).
+constexpr float kFoldS = -1.44269504088896341f;
+template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() { return PREC == SO3X_PREC_BF16 && VAR == CHAIN; }
+
 // weight-image element value: fragment `frag`, lane, element j (bf16 only)
 template <int PREC, int VAR>
 __device__ inline float image_value(const float* __restrict__ params, int frag, int lane, int j) {
@@ -109,10 +117,16 @@ __device__ inline float image_value(const float* __restrict__ params, int frag, 
   const float* bias = W + dout_of(l) * D;
   if (l == 0) {
     const int col = l0_slot_to_col<PREC, VAR>(l0_slot<PREC>(ks, h, j));
-    return col >= 0 ? W[o * D + col] : (col == -2 ? bias[o] : 0.0f);
+    const float sc0 = fold_scale<PREC, VAR>() ? kFoldS : 1.0f;
+    return sc0 * (col >= 0 ? W[o * D + col] : (col == -2 ? bias[o] : 0.0f));
   }
   const int f = hidden_feature<PREC>(ks, h, j);
-  return f < D ? W[o * D + f] : (f == ONE_ROW ? bias[o] : 0.0f);
+  float wsc = 1.0f, bsc = 1.0f;
+  if (fold_scale<PREC, VAR>()) {
+    if (l < 4) bsc = kFoldS;            // hidden: s * (1/s) on features, s on the bias column
+    else wsc = 1.0f / kFoldS;           // output layer: undo the s carried by its inputs
+  }
+  return f < D ? wsc * W[o * D + f] : (f == ONE_ROW ? bsc * bias[o] : 0.0f);
 }
 
 // ---- activations ------------------------------------------------------------------
@@ -141,10 +155,7 @@ template <> struct Tile<SO3X_PREC_BF16> {
 };
 
 template <int PREC> __device__ __forceinline__ f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; i++) z[i] = 0.0f;
-  return z;
+  return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // folds into the MFMA's inline-0 C operand
 }
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
@@ -155,9 +166,12 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // activation + repack of the three accumulator tiles into the next layer's operand
-template <int PREC> __device__ __forceinline__ void activate(const f32x16 (&acc)[3], Tile<PREC>& out, int h);
+template <int PREC, bool FOLD = false> __device__ __forceinline__ void activate(const f32x16 (&acc)[3], Tile<PREC>& out, int h);
 
-template <> __device__ __forceinline__ void activate<SO3X_PREC_F32>(const f32x16 (&acc)[3], Tile<SO3X_PREC_F32>& out, int h) {
+// y = s z  ->  s silu(z)
+__device__ __forceinline__ float silu_folded(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+
+template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_F32>& out, int h) {
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -165,21 +179,28 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_F32>(const f32x16
   out.h[2][0] = h ? 1.0f : silu<SO3X_PREC_F32>(acc[2][0]);  // row 64 (h=0) / the constant-one row 68 (h=1)
 }
 
-template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
+template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       bf16x8 p;
 #pragma unroll
-      for (int j = 0; j < 8; j++) p[j] = (__bf16)silu<SO3X_PREC_BF16>(acc[t][8 * s + j]);
+      for (int j = 0; j < 8; j++)
+        p[j] = (__bf16)(FOLD ? silu_folded(acc[t][8 * s + j]) : silu<SO3X_PREC_BF16>(acc[t][8 * s + j]));
       out.b[2 * t + s] = p;
     }
   bf16x8 p;
 #pragma unroll
   for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
-  p[0] = (__bf16)(h ? 1.0f : silu<SO3X_PREC_BF16>(acc[2][0]));
+  p[0] = (__bf16)(h ? 1.0f : (FOLD ? silu_folded(acc[2][0]) : silu<SO3X_PREC_BF16>(acc[2][0])));
   out.b[4] = p;
+}
+template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
+  activate_bf16<false>(acc, out, h);
+}
+template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, true>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
+  activate_bf16<true>(acc, out, h);
 }
 
 // One hidden layer (NT output tiles) from LDS-resident weight fragments.
@@ -315,11 +336,12 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
   Tile<PREC> cur;
   if constexpr (VAR == CHAIN) layer0_chain<PREC>(img, beff, x, acc, lane);
   else layer0_full<PREC>(img, x, t, *fr, acc, lane);
-  activate<PREC>(acc, cur, h);
+  constexpr bool FOLD = fold_scale<PREC, VAR>();
+  activate<PREC, FOLD>(acc, cur, h);
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     hidden_layer<PREC, 3>(img + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane);
-    activate<PREC>(acc, cur, h);
+    activate<PREC, FOLD>(acc, cur, h);
   }
   f32x16 last[1];
   hidden_layer<PREC, 1>(img + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
