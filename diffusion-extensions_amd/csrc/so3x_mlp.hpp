@@ -207,7 +207,7 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, true>(const
 template <int PREC, int NT>
 __device__ __forceinline__ void hidden_layer(const char* __restrict__ wl /*LDS, first fragment of the layer*/,
                                              const Tile<PREC>& in, f32x16 (&acc)[NT], int lane) {
-  __builtin_amdgcn_sched_barrier(0);  // keep this layer's LDS weight reads from being hoisted above the previous layer
+  __builtin_amdgcn_sched_barrier(0);  // keep this layer's LDS weight reads from being hoisted above the previous layer (else ~240 VGPR spills)
   if constexpr (PREC == SO3X_PREC_F32) {
     const float* w = reinterpret_cast<const float*>(wl);
 #pragma unroll
