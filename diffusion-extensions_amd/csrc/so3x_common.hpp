@@ -116,6 +116,22 @@ __device__ __forceinline__ void wave_store_rows(float* __restrict__ g, int64_t b
   __builtin_amdgcn_wave_barrier();
 }
 
+// A lane's whole rotation (36 contiguous bytes, 4-byte aligned) moved with three wide accesses
+// (dwordx4 + dwordx3 + dwordx2) instead of nine 4-byte ones at a 36-byte lane stride: the nine
+// partial-line stores showed up as 5.8x WRITE_SIZE inflation in the PMC pass of round 1.
+struct __attribute__((packed, aligned(4))) Rot9 { float m[9]; };
+__device__ __forceinline__ void load_rot9(const float* __restrict__ g, int64_t idx, float* r) {
+  const Rot9 v = *reinterpret_cast<const Rot9*>(g + idx * 9);
+#pragma unroll
+  for (int j = 0; j < 9; j++) r[j] = v.m[j];
+}
+__device__ __forceinline__ void store_rot9(float* __restrict__ g, int64_t idx, const float* r) {
+  Rot9 v;
+#pragma unroll
+  for (int j = 0; j < 9; j++) v.m[j] = r[j];
+  *reinterpret_cast<Rot9*>(g + idx * 9) = v;
+}
+
 // scalar-per-sample operand with stride 0 (broadcast) or 1
 __device__ __forceinline__ float load_scalar(const float* p, int64_t stride, int64_t i) { return p[i * stride]; }
 

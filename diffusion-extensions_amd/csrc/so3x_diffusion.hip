@@ -142,25 +142,17 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     const bool live = idx < n;
     const int64_t idc = live ? idx : n - 1;
     float R[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) R[j] = x_in[idc * 9 + j];
+    load_rot9(x_in, idc, R);
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
       const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t];
       const float c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
       // ---- score network: v = RotPredict(x, t)  (diffusion.py:309)
-      float xs[9], xa[9], xb[9];
-#pragma unroll
-      for (int j = 0; j < 9; j++) {
-        xs[j] = __shfl_xor(R[j], 32);
-        xa[j] = h ? xs[j] : R[j];  // tile A = samples 0..31 of the chunk: column c lives in lane c
-        xb[j] = h ? R[j] : xs[j];  // tile B = samples 32..63: column c lives in lane 32 + c
-      }
       const float* beff = beff_tab + (size_t)t * 96;
       float va[3], vb[3], v[3];
-      forward_tile<PREC, CHAIN>(lds, xa, beff, 0, nullptr, va, lane);
-      forward_tile<PREC, CHAIN>(lds, xb, beff, 0, nullptr, vb, lane);
+      forward_tile<PREC, CHAIN, 1>(lds, R, beff, 0, nullptr, va, lane);  // tile A = samples 0..31 of the chunk
+      forward_tile<PREC, CHAIN, 2>(lds, R, beff, 0, nullptr, vb, lane);  // tile B = samples 32..63
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const float o = __shfl_xor(vb[j], 32);  // tile B results sit in lanes 0..31, owners are lanes 32..63
@@ -193,10 +185,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         mul33(mean, nz, R);                            // model_mean @ sample, :326
       }
     }
-    if (live) {
-#pragma unroll
-      for (int j = 0; j < 9; j++) x_out[idx * 9 + j] = R[j];
-    }
+    if (live) store_rot9(x_out, idx, R);
   }
 }
 

@@ -82,8 +82,7 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
     const bool live = idx < n;
     if (!live) idx = n - 1;
     float x[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) x[j] = R[idx * 9 + j];
+    load_rot9(R, idx, x);
     const int64_t tt = t[idx * t_stride];
     float v[3];
     forward_tile<PREC, VAR>(lds, x, VAR == CHAIN ? beff_tab + (size_t)tt * 96 : nullptr, tt, &fr, v, lane);

@@ -224,6 +224,7 @@ __device__ __forceinline__ void hidden_layer(const char* __restrict__ wl /*LDS, 
     const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
 #pragma unroll
     for (int to = 0; to < NT; to++) {
+      if (to == 2) __builtin_amdgcn_sched_barrier(0);  // cap the weight-fragment prefetch at two output tiles (40 VGPRs)
       f32x16 a = zero16<PREC>();
 #pragma unroll
       for (int ks = 0; ks < 5; ks++) a = mfma_bf16(w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
@@ -234,11 +235,22 @@ __device__ __forceinline__ void hidden_layer(const char* __restrict__ wl /*LDS, 
 
 // Layer 0, CHAIN variant: accumulators start from the per-timestep effective bias
 // beff[96] (global/L2, identical address across a lane half -> broadcast load) and add
-// W_0[:, 0:9] . R.   x = the 9 rotation entries of this lane's sample column.
-template <int PREC>
+// W_0[:, 0:9] . R.   XSRC says where the 9 rotation entries of this lane's sample column are:
+//   0: x[] already holds the column's sample in both lanes of the column (standalone forward);
+//   1: wave64 tile A -- x[] is the lane's OWN rotation, column c lives in lane c      (lower half owns);
+//   2: wave64 tile B -- x[] is the lane's OWN rotation, column c lives in lane 32 + c (upper half owns).
+// For 1/2 only the entries the other half actually feeds to the MFMA are exchanged (ds_bpermute):
+// bf16 1 + 8 values per step, fp32 4 + 5 -- instead of mirroring all 9 twice.
+template <int PREC, int XSRC = 0>
 __device__ __forceinline__ void layer0_chain(const char* __restrict__ wl, const float* __restrict__ beff, const float* x,
                                              f32x16 (&acc)[3], int lane) {
   const int h = lane >> 5;
+  // value of entry j as seen by the lane half that feeds it: `feeder_is_upper` = the MFMA slot belongs to h == 1
+  auto entry = [&](int j, bool feeder_is_upper) -> float {
+    if (XSRC == 0) return x[j];
+    const bool owner_is_upper = (XSRC == 2);
+    return feeder_is_upper == owner_is_upper ? x[j] : __shfl_xor(x[j], 32);
+  };
 #pragma unroll
   for (int to = 0; to < 3; to++) {
     f32x16 a;
@@ -259,7 +271,7 @@ __device__ __forceinline__ void layer0_chain(const char* __restrict__ wl, const 
     float xs[5];
 #pragma unroll
     for (int m = 0; m < 5; m++) {  // slot 2m + h; slot 9 is padding
-      const float lo = x[2 * m], hi = (2 * m + 1 < 9) ? x[2 * m + 1] : 0.0f;
+      const float lo = entry(2 * m, false), hi = (2 * m + 1 < 9) ? entry((2 * m + 1) % 9, true) : 0.0f;
       xs[m] = h ? hi : lo;
     }
 #pragma unroll
@@ -269,8 +281,13 @@ __device__ __forceinline__ void layer0_chain(const char* __restrict__ wl, const 
   } else {
     const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
     bf16x8 b;
+    // the exchanges are cross-lane operations: evaluate them in uniform control flow, select afterwards
+    const float x8 = entry(8, true);
+    float xe[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x[8] : 0.0f) : x[j]);  // slot 8h + j
+    for (int j = 0; j < 8; j++) xe[j] = entry(j, false);
+#pragma unroll
+    for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : 0.0f) : xe[j]);  // slot 8h + j
 #pragma unroll
     for (int to = 0; to < 3; to++) acc[to] = mfma_bf16(w[to * 64 + lane], b, acc[to]);
   }
@@ -327,14 +344,14 @@ __device__ __forceinline__ void layer0_full(const char* __restrict__ wl, const f
 
 // The whole network on one 32-sample tile.  Returns the 3 outputs of sample column
 // (lane & 31) in v[0..2]; only lanes of the LOWER half (h == 0) hold valid values.
-template <int PREC, int VAR>
+template <int PREC, int VAR, int XSRC = 0>
 __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS weight image*/, const float* x,
                                              const float* __restrict__ beff, int64_t t, const Freqs* fr, float* v, int lane) {
   const int h = lane >> 5;
   constexpr int FB = frag_bytes<PREC>();
   f32x16 acc[3];
   Tile<PREC> cur;
-  if constexpr (VAR == CHAIN) layer0_chain<PREC>(img, beff, x, acc, lane);
+  if constexpr (VAR == CHAIN) layer0_chain<PREC, XSRC>(img, beff, x, acc, lane);
   else layer0_full<PREC>(img, x, t, *fr, acc, lane);
   constexpr bool FOLD = fold_scale<PREC, VAR>();
   activate<PREC, FOLD>(acc, cur, h);

@@ -432,6 +432,33 @@ def test_chain_fp32_vs_oracle_stepwise(mods, golden, net):
     assert maxabs(host(xd @ xd.transpose(-1, -2)), np.eye(3)[None]) < 1e-4
 
 
+@pytest.mark.parametrize("t", [5, 300, 700])
+def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
+    """bf16-operand chain step vs the fp64 oracle with the same Philox noise.  Covers both MFMA tiles of a wave
+    (lanes 0..31 / 32..63 take different operand-exchange paths) and ragged tails."""
+    B = mods["B"]
+    T = 1000
+    proc = mods["diff"].SO3Diffusion(net, timesteps=T).to(DEV)
+    _, trap_p = proc._tables()
+    sched = O.schedule_from_betas(O.cosine_beta_schedule(T))
+    params_np = O.flat_params(golden["score_mlp"])
+    n = 200
+    x0 = O.quat_to_rmat(np.random.default_rng(t).standard_normal((n, 4)).astype(np.float32))
+    out = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=1))
+    coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
+    v = O.mlp_fwd(params_np, x0, np.full(n, t), "f64")
+    _, ref = O.p_mean(x0, v, *coef, "f64")
+    _, ang, ax = B.igso3_sample(trap_p, n, row_const=t, seed=9, rng_offset=7 + t, want_angle=True, want_axis=True)
+    ref = O.rmul(ref, O.aa_to_rmat(host(ax), host(ang), "f64"), "f64")
+    err = np.abs(out - ref).reshape(n, -1).max(1)
+    # bf16 operands: ~2e-2 relative on v (|v| ~ 0.3 with the seed-0 weights) times b_t <= 7 at these t
+    assert err.max() < 2e-2 * max(1.0, coef[1]), (t, err.max())
+    assert np.median(err) < 4e-3 * max(1.0, coef[1])
+    # the two halves of a wave must agree in quality (a broken operand exchange shows up as one bad half)
+    lanes = np.arange(n) % 64
+    assert abs(np.median(err[lanes < 32]) - np.median(err[lanes >= 32])) < 2e-3 * max(1.0, coef[1])
+
+
 def test_full_size_chain_properties(mods, net):
     """BASELINE config 3 shape (2^20 rotations), a short bf16 chain: no NaN, orthonormal, det +1."""
     net.precision = "bf16"
