@@ -26,7 +26,7 @@ constexpr int HROWS = 66;                       // 65 inputs + the constant one 
 constexpr int H_BASE(int l) { return HROWS * l; }
 constexpr int DZ_BASE(int l) { return 5 * HROWS + D * l; }
 constexpr int STASH_ROWS = 5 * HROWS + 4 * D + 3;  // 593
-constexpr int CHUNK = 1 << 16;
+constexpr int CHUNK = 1 << 19;  // samples per stash chunk: 593 rows x 2^19 x 4 B = 1.24 GB of workspace (288 GB HBM)
 constexpr int DW_BLOCKS = 256;
 constexpr int NPAIRS = 39;                      // 4 layers x 3x3 tiles + last layer 1x3
 
@@ -334,13 +334,24 @@ k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs)
   }
 }
 
+// 32 parameters x 8 slab groups per block: coalesced 128-B reads, 8-way split of the slab loop, fixed
+// summation order (deterministic)
 __global__ void __launch_bounds__(256)
 k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= NPARAMS) return;
+  __shared__ float part[8][33];
+  const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + p;
   float s = 0.0f;
-  for (int b = 0; b < nslabs; b++) s += slabs[(size_t)b * NPARAMS + idx];
-  dparams[idx] = accumulate ? dparams[idx] + s : s;
+  if (idx < NPARAMS)
+    for (int b = g; b < nslabs; b += 8) s += slabs[(size_t)b * NPARAMS + idx];
+  part[g][p] = s;
+  __syncthreads();
+  if (g == 0 && idx < NPARAMS) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += part[k][p];
+    dparams[idx] = accumulate ? dparams[idx] + t : t;
+  }
 }
 
 template <int PREC>
@@ -374,7 +385,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
                        R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * 3, host_freqs(), stash, nc);
     const int g2 = (int)(ntiles < DW_BLOCKS ? ntiles : DW_BLOCKS);
     hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), STASH_ROWS * LROW * sizeof(float), s, (const float*)stash, nc, slabs);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 255) / 256), dim3(256), 0, s, (const float*)slabs, g2, dparams,
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, g2, dparams,
                        c0 > 0 ? 1 : 0);
   }
   return check_launch();

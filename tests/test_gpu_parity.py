@@ -273,6 +273,24 @@ def test_mlp_backward_ragged_vs_oracle(mods, golden, net, n):
         assert maxabs(mine, ref) < 3e-5 * np.abs(ref).max(), (n, maxabs(mine, ref), np.abs(ref).max())
 
 
+def test_mlp_backward_is_additive_across_stash_chunks(mods, golden, net):
+    """n > 2^19 crosses the backward's stash-chunk boundary: the gradient of the whole batch must equal the sum
+    of the gradients of two halves (linearity in dout) -- a size-independent property at BASELINE scale."""
+    B = mods["B"]
+    n = (1 << 19) + 999
+    g = torch.Generator(device=DEV).manual_seed(4)
+    R = B.quat_to_rmat(torch.randn(n, 4, device=DEV, generator=g))
+    t = torch.randint(0, 1000, (n,), device=DEV, generator=g)
+    dout = torch.randn(n, 3, device=DEV, generator=g) / n
+    params = net.flat_params_nograd()
+    for prec, tol in ((0, 2e-5), (1, 2e-3)):
+        full = B.mlp_bwd(params, R, t, dout, prec)
+        cut = 300000
+        parts = B.mlp_bwd(params, R[:cut], t[:cut], dout[:cut], prec) + B.mlp_bwd(params, R[cut:], t[cut:], dout[cut:], prec)
+        assert float((full - parts).abs().max()) < tol * float(full.abs().max())
+        assert torch.isfinite(full).all()
+
+
 def test_training_step_matches_reference_gradients(mods, golden, net):
     """One full SO3Diffusion training step (p_losses -> backward) with the reference's recorded draws."""
     g = golden["train_step"]
