@@ -106,8 +106,11 @@ __device__ __forceinline__ void dh_layer(const void* __restrict__ wt, const Z33&
 // Stash stores use a wave-uniform 64-bit row base (SGPRs) plus a per-lane 32-bit offset, so the 270 stores of a
 // tile cost no VGPR address pairs (per-lane 64-bit addresses made the register allocator spill ~400 VGPRs).
 //   off4 = 4 h nc + s  (rows row_of(r, h) = row_of(r, 0) + 4 h),   off1 = h nc + s  (rows base + h)
-__device__ __forceinline__ void st_row(float* __restrict__ stash, int64_t nc, int row0, unsigned off, float v) {
-  (stash + (int64_t)row0 * nc)[off] = v;
+template <int PREC> struct Stash { using T = float; };      // fp32 mode: exact hand-off
+template <> struct Stash<SO3X_PREC_BF16> { using T = __bf16; };  // bf16 mode: half the HBM round trip, bf16 MFMA in K2
+template <typename T>
+__device__ __forceinline__ void st_row(T* __restrict__ stash, int64_t nc, int row0, unsigned off, float v) {
+  (stash + (int64_t)row0 * nc)[off] = (T)v;
 }
 
 // stash row of feature-layout register q (Z33 order) for lane half h: rows 0..63 for q < 32; q == 32: feature 64 (h = 0)
@@ -145,7 +148,7 @@ template <int PREC>
 __global__ void __launch_bounds__(256, 1)
 k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ R,
             const int64_t* __restrict__ t, int64_t t_stride, const float* __restrict__ dout, Freqs fr,
-            float* __restrict__ stash, int64_t nc /*samples in this chunk*/) {
+            typename Stash<PREC>::T* __restrict__ stash, int64_t nc /*samples in this chunk*/) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool SWAP = swap_images<PREC>();
   constexpr int FB = frag_bytes<PREC>();
@@ -258,6 +261,11 @@ __device__ __forceinline__ void pair_of(int p, int* l, int* to, int* ti) {
   else { *l = 4; *to = 0; *ti = p - 36; }
 }
 
+__device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h);
+__device__ __forceinline__ void write_slab(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h) {
+  write_slab_impl(slabs, acc, wid, i, h);
+}
+
 constexpr int LROW = 33;  // padded LDS row (floats): fragment reads of stride-LROW rows are conflict-free
 
 __global__ void __launch_bounds__(512, 1)
@@ -310,7 +318,11 @@ k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs)
       }
     }
   }
-  // ---- write this block's partial dparams slab (every entry is owned by exactly one lane)
+  write_slab(slabs, acc, wid, i, h);
+}
+
+// this block's partial dparams slab (every entry is owned by exactly one lane of one wave)
+__device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h) {
   float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
 #pragma unroll
   for (int k = 0; k < 5; k++) {
@@ -332,6 +344,64 @@ k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs)
       }
     }
   }
+}
+
+// bf16 stash variant: rows of 32 bf16 (64 B) staged at an 80-B pitch (16-B aligned, ds_read_b128 conflict-free),
+// two v_mfma_f32_32x32x16_bf16 k-steps per 32-sample slice (k = sample index), fp32 accumulation.
+constexpr int LROW16 = 40;  // bf16 elements per padded LDS row
+
+__global__ void __launch_bounds__(512, 1)
+k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __bf16* sb = reinterpret_cast<__bf16*>(sm);  // [STASH_ROWS][LROW16]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  f32x16 acc[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) acc[k] = zero16<0>();
+  bf16x8 zero8;
+#pragma unroll
+  for (int j = 0; j < 8; j++) zero8[j] = (__bf16)0.0f;
+  const int64_t nsub = (nc + 31) / 32;
+  for (int64_t sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
+    const int64_t s0 = sub * 32;
+    __syncthreads();
+    for (int e = threadIdx.x; e < STASH_ROWS * 4; e += blockDim.x) {  // 4 lanes x 16 B per row
+      const int row = e >> 2, c8 = (e & 3) * 8;
+      const __bf16* src = stash + (int64_t)row * nc + s0 + c8;
+      bf16x8 v;
+      if (s0 + c8 + 7 < nc && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        v = *reinterpret_cast<const bf16x8*>(src);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (s0 + c8 + u < nc) ? src[u] : (__bf16)0.0f;
+      }
+      *reinterpret_cast<bf16x8*>(sb + row * LROW16 + c8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int p = wid + 8 * k;
+      if (p < NPAIRS) {
+        int l, to, ti;
+        pair_of(p, &l, &to, &ti);
+        const int nout = (l < 4 ? D : 3) - 32 * to;
+        const int nin = HROWS - 32 * ti;
+        const bool va = i < nout, vb = i < nin;
+        const __bf16* pa = sb + (DZ_BASE(l) + 32 * to + (va ? i : 0)) * LROW16 + 8 * h;
+        const __bf16* pb = sb + (H_BASE(l) + 32 * ti + (vb ? i : 0)) * LROW16 + 8 * h;
+        f32x16 a = acc[k];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {  // k-step m: samples 16 m + 8 h + j
+          const bf16x8 fa = va ? *reinterpret_cast<const bf16x8*>(pa + 16 * m) : zero8;
+          const bf16x8 fb = vb ? *reinterpret_cast<const bf16x8*>(pb + 16 * m) : zero8;
+          a = mfma_bf16(fa, fb, a);
+        }
+        acc[k] = a;
+      }
+    }
+  }
+  write_slab(slabs, acc, wid, i, h);
 }
 
 // 32 parameters x 8 slab groups per block: coalesced 128-B reads, 8-way split of the slab loop, fixed
@@ -362,13 +432,16 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   constexpr size_t WT_BYTES = (size_t)wt_nfrags<PREC>() * frag_bytes<PREC>();
   constexpr size_t SLAB_OFF = (WT_OFF + WT_BYTES + 255) & ~(size_t)255;
   constexpr size_t STASH_OFF = SLAB_OFF + (size_t)DW_BLOCKS * NPARAMS * sizeof(float);
+  using ST = typename Stash<PREC>::T;
+  constexpr int DW_LDS = PREC == SO3X_PREC_F32 ? STASH_ROWS * LROW * (int)sizeof(float) : STASH_ROWS * LROW16 * 2;
   static int attr_set = 0;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_stage<PREC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, stage_lds_bytes<PREC>());
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_dw), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            STASH_ROWS * LROW * (int)sizeof(float));
+    e = hipFuncSetAttribute(PREC == SO3X_PREC_F32 ? reinterpret_cast<const void*>(&k_bwd_dw)
+                                                  : reinterpret_cast<const void*>(&k_bwd_dw_bf16),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = 1;
   }
@@ -376,7 +449,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   if (rc) return rc;
   hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + WT_OFF));
   float* slabs = reinterpret_cast<float*>(ws + SLAB_OFF);
-  float* stash = reinterpret_cast<float*>(ws + STASH_OFF);
+  ST* stash = reinterpret_cast<ST*>(ws + STASH_OFF);
   for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
     const int64_t nc = (n - c0) < CHUNK ? (n - c0) : CHUNK;
     const int64_t ntiles = (nc + 31) / 32;
@@ -384,7 +457,10 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     hipLaunchKernelGGL((k_bwd_stage<PREC>), dim3(g1), dim3(256), stage_lds_bytes<PREC>(), s, (const void*)ws, (const void*)(ws + WT_OFF),
                        R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * 3, host_freqs(), stash, nc);
     const int g2 = (int)(ntiles < DW_BLOCKS ? ntiles : DW_BLOCKS);
-    hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), STASH_ROWS * LROW * sizeof(float), s, (const float*)stash, nc, slabs);
+    if constexpr (PREC == SO3X_PREC_F32)
+      hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs);
+    else
+      hipLaunchKernelGGL(k_bwd_dw_bf16, dim3(g2), dim3(512), DW_LDS, s, (const __bf16*)stash, nc, slabs);
     hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, g2, dparams,
                        c0 > 0 ? 1 : 0);
   }
