@@ -19,8 +19,8 @@ const Freqs& host_freqs() {
 }
 
 size_t image_bytes_rt(int precision, int variant) {
-  if (precision == SO3X_PREC_F32) return variant == CHAIN ? image_bytes<SO3X_PREC_F32, CHAIN>() : image_bytes<SO3X_PREC_F32, FULL>();
-  return variant == CHAIN ? image_bytes<SO3X_PREC_BF16, CHAIN>() : image_bytes<SO3X_PREC_BF16, FULL>();
+  if (precision == SO3X_PREC_F32) return chain_layout(variant) ? image_bytes<SO3X_PREC_F32, CHAIN>() : image_bytes<SO3X_PREC_F32, FULL>();
+  return chain_layout(variant) ? image_bytes<SO3X_PREC_BF16, CHAIN>() : image_bytes<SO3X_PREC_BF16, FULL>();
 }
 size_t beff_offset(int precision, int variant) { return (image_bytes_rt(precision, variant) + 255) & ~(size_t)255; }
 
@@ -45,10 +45,13 @@ template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image
 // ---- prep: per-timestep effective bias of layer 0 (appendix C.3) ---------------------
 //   beff[t][o] = b_0[o] + sum_e W_0[o][9+e] * emb_e(t)   (o < 65), other rows 0.
 __global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ params, Freqs fr, int T, float scale,
-                                                    float* __restrict__ beff) {
+                                                    float* __restrict__ beff, float* __restrict__ emb_tab) {
   __shared__ float emb[NEMB];
   const int t = blockIdx.x;
-  if (threadIdx.x < NEMB) emb[threadIdx.x] = emb_value((int64_t)t, threadIdx.x, fr);
+  if (threadIdx.x < NEMB) {
+    emb[threadIdx.x] = emb_value((int64_t)t, threadIdx.x, fr);
+    if (emb_tab) emb_tab[(size_t)t * NEMB + threadIdx.x] = emb[threadIdx.x];  // [T][56] time-embedding table
+  }
   __syncthreads();
   const int o = threadIdx.x;
   if (o < 96) {
@@ -85,17 +88,18 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
     load_rot9(R, idx, x);
     const int64_t tt = t[idx * t_stride];
     float v[3];
-    forward_tile<PREC, VAR>(lds, x, VAR == CHAIN ? beff_tab + (size_t)tt * 96 : nullptr, tt, &fr, v, lane);
+    forward_tile<PREC, VAR>(lds, x, chain_layout(VAR) ? beff_tab + (size_t)tt * 96 : nullptr, tt, &fr, v, lane);
     if (live && h == 0) { out[idx * 3] = v[0]; out[idx * 3 + 1] = v[1]; out[idx * 3 + 2] = v[2]; }
   }
 }
 
 template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws) {
   hipLaunchKernelGGL((k_prep_image<PREC, VAR>), dim3(32), dim3(256), 0, s, params, ws);
-  if (VAR == CHAIN && T > 0) {
+  if (chain_layout(VAR) && T > 0) {
     float* beff = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR));
+    float* emb = VAR == GATHER ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
     hipLaunchKernelGGL(k_prep_beff, dim3(T), dim3(128), 0, s, params, host_freqs(), T,
-                       fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff);
+                       fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb);
   }
   return check_launch();
 }
@@ -114,8 +118,9 @@ int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t
   const int64_t want = (ntiles + 3) / 4;
   const int max_blocks = IMG > 80 * 1024 ? 256 : 512;  // LDS-limited residency: 1 or 2 blocks per CU
   const int grid = (int)(want < max_blocks ? want : max_blocks);
-  hipLaunchKernelGGL((k_mlp_fwd<PREC, VAR>), dim3(grid), dim3(256), IMG, s, ws, (const float*)nullptr, R, t, t_stride,
-                     host_freqs(), out, n);
+  const float* beff = chain_layout(VAR) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + beff_offset(PREC, VAR))
+                                        : nullptr;
+  hipLaunchKernelGGL((k_mlp_fwd<PREC, VAR>), dim3(grid), dim3(256), IMG, s, ws, beff, R, t, t_stride, host_freqs(), out, n);
   return check_launch();
 }
 
@@ -124,11 +129,14 @@ int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t
 namespace so3x {
 namespace mlp {
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace) {
-  if (precision == SO3X_PREC_F32)
-    return variant == CHAIN ? launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace)
-                            : launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace);
-  return variant == CHAIN ? launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace)
-                          : launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace);
+  if (precision == SO3X_PREC_F32) {
+    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace);
+    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace);
+    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace);
+  }
+  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace);
+  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace);
+  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace);
 }
 }  // namespace mlp
 }  // namespace so3x
@@ -136,11 +144,19 @@ int launch_prep(hipStream_t s, const float* params, int precision, int variant, 
 extern "C" {
 
 int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
-                 int64_t n, int precision, void* workspace, size_t workspace_bytes) {
-  if (n < 0 || (n && (!params || !R || !t || !out)) || (t_stride != 0 && t_stride != 1)) return SO3X_ERR_INVALID_ARG;
+                 int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !out)) || (t_stride != 0 && t_stride != 1) || t_table < 0)
+    return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < image_bytes_rt(precision, FULL)) return SO3X_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < (t_table ? tables_end(precision, CHAIN, t_table) : image_bytes_rt(precision, FULL)))
+    return SO3X_ERR_WORKSPACE;
   if (n == 0) return SO3X_OK;
+  if (t_table > 0) {  // bounded timesteps: per-timestep effective-bias rows gathered per sample, no in-kernel sin/cos
+    int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, t_table, workspace);
+    if (rc) return rc;
+    if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, CHAIN>((hipStream_t)s, workspace, R, t, t_stride, out, n);
+    return launch_fwd_t<SO3X_PREC_BF16, CHAIN>((hipStream_t)s, workspace, R, t, t_stride, out, n);
+  }
   int rc = launch_prep((hipStream_t)s, params, precision, FULL, 0, workspace);
   if (rc) return rc;
   if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);

@@ -50,12 +50,17 @@ __host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 
 // variant CHAIN: layer 0 sees only the 9 rotation entries (the 56 time-embedding
 // inputs are folded into a per-timestep effective bias, appendix C.3);
 // variant FULL : layer 0 sees [R(9), 1, emb(56)] per sample (per-sample timesteps).
-enum Variant { CHAIN = 0, FULL = 1 };
+enum Variant { CHAIN = 0, FULL = 1, GATHER = 2 };
+// GATHER: the CHAIN layer-0 layout (K = 9, per-timestep effective bias) with a PER-SAMPLE bias row
+// gathered by t from the [T][96] table -- per-sample timesteps without evaluating 56 sin/cos per sample.
+// Used by the training forward/backward when the caller bounds t (t_table > 0); never scale-folded
+// (the backward needs the true pre-activations).
+__host__ __device__ constexpr bool chain_layout(int var) { return var != FULL; }
 
 // number of k-steps
 template <int PREC> __host__ __device__ constexpr int ks_hidden() { return PREC == SO3X_PREC_F32 ? 33 : 5; }
 template <int PREC, int VAR> __host__ __device__ constexpr int ks_layer0() {
-  return PREC == SO3X_PREC_F32 ? (VAR == CHAIN ? 5 : 33) : (VAR == CHAIN ? 1 : 5);
+  return PREC == SO3X_PREC_F32 ? (chain_layout(VAR) ? 5 : 33) : (chain_layout(VAR) ? 1 : 5);
 }
 // a fragment = what the 64 lanes read for one MFMA: 64 x 4 B (fp32) or 64 x 16 B (bf16)
 template <int PREC> __host__ __device__ constexpr int frag_bytes() { return PREC == SO3X_PREC_F32 ? 256 : 1024; }
@@ -86,7 +91,7 @@ template <int PREC> __host__ __device__ inline int l0_slot(int ks, int h, int j)
 //  fp32 FULL: [0..8] R, [9] one, [10..65] emb.   bf16 FULL: [0..8] R, [9] one, [16..71] emb.
 template <int PREC, int VAR> __host__ __device__ inline int l0_slot_to_col(int slot) {
   if (slot < 9) return slot;
-  if (VAR == CHAIN) return -1;
+  if (chain_layout(VAR)) return -1;
   if (slot == 9) return -2;
   const int e0 = PREC == SO3X_PREC_F32 ? 10 : 16;
   if (slot >= e0 && slot < e0 + NEMB) return 9 + (slot - e0);
@@ -351,7 +356,7 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
   constexpr int FB = frag_bytes<PREC>();
   f32x16 acc[3];
   Tile<PREC> cur;
-  if constexpr (VAR == CHAIN) layer0_chain<PREC, XSRC>(img, beff, x, acc, lane);
+  if constexpr (chain_layout(VAR)) layer0_chain<PREC, XSRC>(img, beff, x, acc, lane);
   else layer0_full<PREC>(img, x, t, *fr, acc, lane);
   constexpr bool FOLD = fold_scale<PREC, VAR>();
   activate<PREC, FOLD>(acc, cur, h);
@@ -378,6 +383,9 @@ size_t image_bytes_rt(int precision, int variant);
 // effective-bias table beff[T][96] right after it (16-B aligned).
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace);
 size_t beff_offset(int precision, int variant);
+// tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32
+inline size_t emb_offset(int precision, int variant, int T) { return beff_offset(precision, variant) + (size_t)T * 96 * sizeof(float); }
+inline size_t tables_end(int precision, int variant, int T) { return emb_offset(precision, variant, T) + (size_t)T * NEMB * sizeof(float); }
 const Freqs& host_freqs();
 
 }  // namespace mlp

@@ -124,8 +124,9 @@ __device__ __forceinline__ int z33_row0(int q) { return q < 32 ? 32 * (q >> 4) +
 // ---------------------------------------------------------------------------------------
 template <int PREC> __host__ __device__ constexpr int wt_bytes() { return wt_nfrags<PREC>() * frag_bytes<PREC>(); }
 template <int PREC> __host__ __device__ constexpr bool swap_images() { return PREC == SO3X_PREC_F32; }
-template <int PREC> __host__ __device__ constexpr int stage_lds_bytes() {
-  return swap_images<PREC>() ? image_bytes<PREC, FULL>() : image_bytes<PREC, FULL>() + wt_bytes<PREC>();
+template <int PREC, int VAR> __host__ __device__ constexpr int stage_lds_bytes() {
+  return swap_images<PREC>() ? (image_bytes<PREC, VAR>() > wt_bytes<PREC>() ? image_bytes<PREC, VAR>() : wt_bytes<PREC>())
+                             : image_bytes<PREC, VAR>() + wt_bytes<PREC>();
 }
 
 
@@ -144,15 +145,16 @@ __device__ __forceinline__ void activate_z(const Z33& z, Tile<PREC>& out, int h)
   activate<PREC>(a, out, h);
 }
 
-template <int PREC>
+template <int PREC, int VAR>
 __global__ void __launch_bounds__(256, 1)
-k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ R,
-            const int64_t* __restrict__ t, int64_t t_stride, const float* __restrict__ dout, Freqs fr,
-            typename Stash<PREC>::T* __restrict__ stash, int64_t nc /*samples in this chunk*/) {
+k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
+            const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
+            int64_t t_stride, const float* __restrict__ dout, Freqs fr, typename Stash<PREC>::T* __restrict__ stash,
+            int64_t nc /*samples in this chunk*/) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool SWAP = swap_images<PREC>();
   constexpr int FB = frag_bytes<PREC>();
-  constexpr int IMG = image_bytes<PREC, FULL>();
+  constexpr int IMG = image_bytes<PREC, VAR>();
   const char* wt_lds = SWAP ? lds : lds + IMG;
   load_image(gimg, lds, IMG);
   if (!SWAP) load_image(gwt, lds + IMG, wt_bytes<PREC>());
@@ -191,17 +193,20 @@ k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
           st_row(stash, nc, H_BASE(0) + 2 * j, off1, h ? hi : lo);
         }
 #pragma unroll 1
-        for (int e = 0; e < NEMB; e += 2) st_row(stash, nc, H_BASE(0) + 10 + e, off1, emb_value(tt, e + h, fr));
+        for (int e = 0; e < NEMB; e += 2)
+          st_row(stash, nc, H_BASE(0) + 10 + e, off1,
+                 VAR == GATHER ? emb_tab[(size_t)tt * NEMB + e + h] : emb_value(tt, e + h, fr));
       }
       // ---- forward, keeping the pre-activations
       f32x16 acc[3];
       Tile<PREC> cur;
-      layer0_full<PREC>(lds, x, tt, fr, acc, lane);
+      if constexpr (VAR == GATHER) layer0_chain<PREC, 0>(lds, beff_tab + (size_t)tt * 96, x, acc, lane);
+      else layer0_full<PREC>(lds, x, tt, fr, acc, lane);
       keep(acc, z[0]);
 #pragma unroll
       for (int l = 1; l < 4; l++) {
         activate_z<PREC>(z[l - 1], cur, h);
-        hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, FULL>(l) * FB, cur, acc, lane);
+        hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane);
         keep(acc, z[l]);
       }
     }
@@ -424,20 +429,31 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
   }
 }
 
-template <int PREC>
+// workspace layout: [weight image | (t_table: beff, emb tables)] [transposed image] [slabs] [stash]
+struct BwdLayout { size_t wt, slabs, stash, end; };
+template <int PREC> BwdLayout bwd_layout(int64_t n, int t_table) {
+  const int var = t_table > 0 ? GATHER : FULL;
+  const size_t head = t_table > 0 ? tables_end(PREC, var, t_table) : image_bytes_rt(PREC, var);
+  BwdLayout L;
+  L.wt = (head + 255) & ~(size_t)255;
+  L.slabs = (L.wt + (size_t)wt_nfrags<PREC>() * frag_bytes<PREC>() + 255) & ~(size_t)255;
+  L.stash = L.slabs + (size_t)DW_BLOCKS * NPARAMS * sizeof(float);
+  const int64_t nc = n < CHUNK ? (n < 32 ? 32 : n) : CHUNK;
+  L.end = L.stash + (size_t)STASH_ROWS * (size_t)nc * sizeof(typename Stash<PREC>::T) + 256;
+  return L;
+}
+
+template <int PREC, int VAR>
 int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
-               float* dparams, int64_t n, char* ws) {
-  constexpr int IMG = image_bytes<PREC, FULL>();
-  constexpr size_t WT_OFF = (IMG + 255) & ~(size_t)255;
-  constexpr size_t WT_BYTES = (size_t)wt_nfrags<PREC>() * frag_bytes<PREC>();
-  constexpr size_t SLAB_OFF = (WT_OFF + WT_BYTES + 255) & ~(size_t)255;
-  constexpr size_t STASH_OFF = SLAB_OFF + (size_t)DW_BLOCKS * NPARAMS * sizeof(float);
+               float* dparams, int64_t n, int t_table, char* ws) {
   using ST = typename Stash<PREC>::T;
   constexpr int DW_LDS = PREC == SO3X_PREC_F32 ? STASH_ROWS * LROW * (int)sizeof(float) : STASH_ROWS * LROW16 * 2;
+  constexpr int STAGE_LDS = stage_lds_bytes<PREC, VAR>();
+  const BwdLayout L = bwd_layout<PREC>(n, t_table);
   static int attr_set = 0;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_stage<PREC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, stage_lds_bytes<PREC>());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_stage<PREC, VAR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_LDS);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(PREC == SO3X_PREC_F32 ? reinterpret_cast<const void*>(&k_bwd_dw)
                                                   : reinterpret_cast<const void*>(&k_bwd_dw_bf16),
@@ -445,17 +461,20 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     if (e != hipSuccess) return (int)e;
     attr_set = 1;
   }
-  int rc = launch_prep(s, params, PREC, FULL, 0, ws);
+  int rc = launch_prep(s, params, PREC, VAR, t_table, ws);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + WT_OFF));
-  float* slabs = reinterpret_cast<float*>(ws + SLAB_OFF);
-  ST* stash = reinterpret_cast<ST*>(ws + STASH_OFF);
+  hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + L.wt));
+  const float* beff = VAR == GATHER ? reinterpret_cast<const float*>(ws + beff_offset(PREC, VAR)) : nullptr;
+  const float* emb = VAR == GATHER ? reinterpret_cast<const float*>(ws + emb_offset(PREC, VAR, t_table)) : nullptr;
+  float* slabs = reinterpret_cast<float*>(ws + L.slabs);
+  ST* stash = reinterpret_cast<ST*>(ws + L.stash);
   for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
     const int64_t nc = (n - c0) < CHUNK ? (n - c0) : CHUNK;
     const int64_t ntiles = (nc + 31) / 32;
     const int g1 = (int)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
-    hipLaunchKernelGGL((k_bwd_stage<PREC>), dim3(g1), dim3(256), stage_lds_bytes<PREC>(), s, (const void*)ws, (const void*)(ws + WT_OFF),
-                       R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * 3, host_freqs(), stash, nc);
+    hipLaunchKernelGGL((k_bwd_stage<PREC, VAR>), dim3(g1), dim3(256), STAGE_LDS, s, (const void*)ws,
+                       (const void*)(ws + L.wt), beff, emb, R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * 3,
+                       host_freqs(), stash, nc);
     const int g2 = (int)(ntiles < DW_BLOCKS ? ntiles : DW_BLOCKS);
     if constexpr (PREC == SO3X_PREC_F32)
       hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs);
@@ -471,28 +490,29 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
 
 extern "C" {
 
-size_t so3x_mlp_workspace_bytes(int64_t n, int precision) {
-  const int p = precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16;
-  const size_t img = (image_bytes_rt(p, FULL) + 255) & ~(size_t)255;
-  const size_t wt = ((p == SO3X_PREC_F32 ? (size_t)wt_nfrags<SO3X_PREC_F32>() * 256 : (size_t)wt_nfrags<SO3X_PREC_BF16>() * 1024) + 255) &
-                    ~(size_t)255;
-  const int64_t nc = n < CHUNK ? (n < 32 ? 32 : n) : CHUNK;
-  return img + wt + (size_t)DW_BLOCKS * NPARAMS * sizeof(float) + (size_t)STASH_ROWS * (size_t)nc * sizeof(float) + 1024;
+size_t so3x_mlp_workspace_bytes(int64_t n, int precision, int t_table) {
+  if (precision == SO3X_PREC_F32) return bwd_layout<SO3X_PREC_F32>(n, t_table).end;
+  return bwd_layout<SO3X_PREC_BF16>(n, t_table).end;
 }
 
 int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride,
-                 const float* dout, float* dparams, int64_t n, int precision, void* workspace, size_t workspace_bytes) {
-  if (n < 0 || (n && (!params || !R || !t || !dout)) || !dparams || (t_stride != 0 && t_stride != 1))
+                 const float* dout, float* dparams, int64_t n, int precision, int t_table, void* workspace,
+                 size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !dout)) || !dparams || (t_stride != 0 && t_stride != 1) || t_table < 0)
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < so3x_mlp_workspace_bytes(n, precision)) return SO3X_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < so3x_mlp_workspace_bytes(n, precision, t_table)) return SO3X_ERR_WORKSPACE;
   if (n == 0) {
     hipError_t e = hipMemsetAsync(dparams, 0, NPARAMS * sizeof(float), (hipStream_t)s);
     return e == hipSuccess ? SO3X_OK : (int)e;
   }
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)s;
   if (precision == SO3X_PREC_F32)
-    return launch_bwd<SO3X_PREC_F32>((hipStream_t)s, params, R, t, t_stride, dout, dparams, n, (char*)workspace);
-  return launch_bwd<SO3X_PREC_BF16>((hipStream_t)s, params, R, t, t_stride, dout, dparams, n, (char*)workspace);
+    return t_table > 0 ? launch_bwd<SO3X_PREC_F32, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws)
+                       : launch_bwd<SO3X_PREC_F32, FULL>(st, params, R, t, t_stride, dout, dparams, n, 0, ws);
+  return t_table > 0 ? launch_bwd<SO3X_PREC_BF16, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws)
+                     : launch_bwd<SO3X_PREC_BF16, FULL>(st, params, R, t, t_stride, dout, dparams, n, 0, ws);
 }
 
 }  // extern "C"

@@ -338,7 +338,7 @@ def _t_arg(t, n):
     raise ValueError(f"so3x: t must have 1 or {n} elements, got {t.numel()}")
 
 
-def mlp_fwd(params, R, t, precision=PREC_F32):
+def mlp_fwd(params, R, t, precision=PREC_F32, t_table=0):
     params = _dev(params, "params").reshape(-1)
     if params.numel() != N_PARAMS:
         raise ValueError(f"so3x: params must hold {N_PARAMS} values")
@@ -346,26 +346,27 @@ def mlp_fwd(params, R, t, precision=PREC_F32):
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
     out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
-    nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision))
+    nb = lib().so3x_mlp_workspace_bytes(_i64(0), C.c_int(precision), C.c_int(int(t_table)))  # forward: image + tables only
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_mlp_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n),
-                                  C.c_int(precision), _ptr(ws), C.c_size_t(ws.numel())), "mlp_fwd")
+                                  C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "mlp_fwd")
     return out
 
 
-def mlp_bwd(params, R, t, dout, precision=PREC_F32):
+def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0):
     params = _dev(params, "params").reshape(-1)
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
     dout = _dev(dout, "dout").reshape(-1, 3)
     dparams = torch.empty(N_PARAMS, dtype=torch.float32, device=R.device)
-    nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision))
+    nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision), C.c_int(int(t_table)))
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_mlp_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                  _i64(n), C.c_int(precision), _ptr(ws), C.c_size_t(ws.numel())), "mlp_bwd")
+                                  _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+               "mlp_bwd")
     return dparams
 
 

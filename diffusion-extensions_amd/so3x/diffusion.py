@@ -171,7 +171,9 @@ class SO3Diffusion(nn.Module):
                                                 axes=axes, unif=unif, seed=_rng.seed(),
                                                 rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
                                                 index_base=self.index_base)
-        x_recon = self.denoise_fn(x_noisy, t)
+        net = self._fused_net()
+        # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
+        x_recon = net(x_noisy, t, t_table=self.num_timesteps) if net is not None else self.denoise_fn(x_noisy, t)
         return F.mse_loss(x_recon, target)
 
     def forward(self, x, *args, **kwargs):

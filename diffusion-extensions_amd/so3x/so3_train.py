@@ -25,16 +25,17 @@ class _ScoreMLPFn(torch.autograd.Function):
     and targets of loss_type='skewvec' carry none."""
 
     @staticmethod
-    def forward(ctx, x, t, flat_params, precision):
+    def forward(ctx, x, t, flat_params, precision, t_table):
         ctx.save_for_backward(x, t, flat_params)
         ctx.precision = precision
-        return _b.mlp_fwd(flat_params, x, t, precision)
+        ctx.t_table = t_table
+        return _b.mlp_fwd(flat_params, x, t, precision, t_table)
 
     @staticmethod
     def backward(ctx, dout):
         x, t, flat_params = ctx.saved_tensors
-        dparams = _b.mlp_bwd(flat_params, x, t, dout.contiguous(), ctx.precision)
-        return None, None, dparams, None
+        dparams = _b.mlp_bwd(flat_params, x, t, dout.contiguous(), ctx.precision, ctx.t_table)
+        return None, None, dparams, None, None
 
 
 class RotPredict(nn.Module):
@@ -61,6 +62,11 @@ class RotPredict(nn.Module):
             nn.Linear(d_model, self.d_out),
         )
         self._flat_cache = None
+        # 0: timesteps are arbitrary (embedding evaluated per sample in-kernel).  T > 0: the caller promises
+        # 0 <= t < T; the kernels then gather per-timestep table rows instead of 56 sin/cos per sample.
+        # SO3Diffusion passes its num_timesteps per call (forward's t_table argument); this attribute is the
+        # default for direct calls and may be set by a caller that knows its timestep range.
+        self.t_table = 0
 
     def flat_params(self) -> torch.Tensor:
         """The 17,358 parameters in state_dict order; differentiable (autograd routes the
@@ -79,10 +85,11 @@ class RotPredict(nn.Module):
     def precision_code(self) -> int:
         return _PRECISIONS[self.precision]
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor):
+    def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None):
+        tt = self.t_table if t_table is None else int(t_table)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            return _ScoreMLPFn.apply(x, t, self.flat_params(), self.precision_code)
-        return _b.mlp_fwd(self.flat_params_nograd(), x, t, self.precision_code)
+            return _ScoreMLPFn.apply(x, t, self.flat_params(), self.precision_code, tt)
+        return _b.mlp_fwd(self.flat_params_nograd(), x, t, self.precision_code, tt)
 
 
 def main(argv=None):

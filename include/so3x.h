@@ -125,15 +125,19 @@ int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, 
 /* ------------------------------------------------------------------- score MLP */
 /* models.py:13-25 + so3_train.py:39-49, out_type="skewvec".  params = the 17,358
  * fp32 values in state_dict order net.{0,2,4,6,8}.{weight,bias}.  t int64, t_stride
- * 0 (one timestep for the whole batch, the (1,)-shaped t of so3_test.py:31) or 1. */
-size_t so3x_mlp_workspace_bytes(int64_t n, int precision);
+ * 0 (one timestep for the whole batch, the (1,)-shaped t of so3_test.py:31) or 1.
+ * t_table: 0 = timesteps are arbitrary, the embedding is evaluated per sample in-kernel;
+ *          T > 0 = the caller guarantees 0 <= t < T for every sample (SO3Diffusion's
+ *          num_timesteps): the call builds [T][96] effective-bias / [T][56] embedding tables
+ *          (appendix C.3 of SURVEY.md) and gathers rows by t -- no per-sample sin/cos. */
+size_t so3x_mlp_workspace_bytes(int64_t n, int precision, int t_table);
 int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                 int64_t t_stride, float* out, int64_t n, int precision, void* workspace,
-                 size_t workspace_bytes);
+                 int64_t t_stride, float* out, int64_t n, int precision, int t_table,
+                 void* workspace, size_t workspace_bytes);
 /* autograd of the above for a given dL/dout[n][3] -> dparams[17358] (overwritten). */
 int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
                  int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,
-                 void* workspace, size_t workspace_bytes);
+                 int t_table, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------- diffusion steps */
 /* SO3Diffusion.q_sample + the p_losses target (diffusion.py:339-355), fused with the

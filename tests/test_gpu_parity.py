@@ -273,6 +273,32 @@ def test_mlp_backward_ragged_vs_oracle(mods, golden, net, n):
         assert maxabs(mine, ref) < 3e-5 * np.abs(ref).max(), (n, maxabs(mine, ref), np.abs(ref).max())
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_mlp_table_path_matches_in_kernel_embedding(mods, golden, net, prec, tol):
+    """t_table > 0 (per-timestep effective-bias / embedding tables gathered by t) must agree with the
+    in-kernel embedding path and with the oracle, forward and backward."""
+    B = mods["B"]
+    code = 0 if prec == "fp32" else 1
+    params_np = O.flat_params(golden["score_mlp"])
+    params = dev(params_np)
+    rng = np.random.default_rng(12)
+    n = 3000
+    R = O.quat_to_rmat(rng.standard_normal((n, 4)).astype(np.float32))
+    t = rng.integers(0, 1000, n)
+    dout = (rng.standard_normal((n, 3)) / n).astype(np.float32)
+    ref = O.mlp_fwd(params_np, R, t, "f64")
+    for tab in (0, 1000, 1500):
+        out = host(B.mlp_fwd(params, dev(R), dev(t, torch.int64), code, t_table=tab))
+        assert maxabs(out, ref) < tol * np.abs(ref).max(), (tab, maxabs(out, ref))
+    gref = O.mlp_bwd(params_np, R, t, dout, "f64")
+    for tab in (0, 1000):
+        g = host(B.mlp_bwd(params, dev(R), dev(t, torch.int64), dev(dout), code, t_table=tab))
+        assert maxabs(g, gref) < max(tol, 3e-5) * np.abs(gref).max(), (tab, maxabs(g, gref))
+    # shared timestep ((1,)-shaped t) through the table path
+    out1 = host(B.mlp_fwd(params, dev(R), dev(t[:1], torch.int64), code, t_table=1000))
+    assert maxabs(out1, O.mlp_fwd(params_np, R, t[:1], "f64")) < tol * np.abs(ref).max()
+
+
 def test_mlp_backward_is_additive_across_stash_chunks(mods, golden, net):
     """n > 2^19 crosses the backward's stash-chunk boundary: the gradient of the whole batch must equal the sum
     of the gradients of two halves (linearity in dout) -- a size-independent property at BASELINE scale."""
