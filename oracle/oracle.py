@@ -315,3 +315,44 @@ def flat_params(state):
         parts.append(np.asarray(state[f"net_{l}_weight"], np.float32).ravel())
         parts.append(np.asarray(state[f"net_{l}_bias"], np.float32).ravel())
     return np.concatenate(parts)
+
+
+# ---------------------------------------------------------------------------------------------
+# Sample-quality statistics used by gate G3 (numpy restatement; reference util.py:128-134, 254-299)
+# ---------------------------------------------------------------------------------------------
+def pairwise_rmat_dist(X, Y):
+    """rmat_dist(x_i, y_j) for all pairs: ||log(x_i^T y_j)||_F = sqrt(2) * angle  (util.py:315-322)."""
+    X = np.asarray(X, np.float64).reshape(-1, 3, 3)
+    Y = np.asarray(Y, np.float64).reshape(-1, 3, 3)
+    # M = x^T y ; M[a][b] = sum_k x[k][a] y[k][b]
+    def M(a, b):
+        return X[:, :, a] @ Y[:, :, b].T
+    tr = M(0, 0) + M(1, 1) + M(2, 2)
+    v0 = M(2, 1) - M(1, 2)
+    v1 = M(0, 2) - M(2, 0)
+    v2 = M(1, 0) - M(0, 1)
+    s = np.sqrt(v0 * v0 + v1 * v1 + v2 * v2) / 2
+    c = (tr - 1) / 2
+    return np.sqrt(2.0) * np.arctan2(s, c)
+
+
+def rmat_gaussian_kernel_matrix(X, Y):
+    """exp(-rmat_dist) (util.py:128-134)"""
+    return np.exp(-pairwise_rmat_dist(X, Y))
+
+
+def MMD(X, Y):
+    """Maximum mean discrepancy with the reference's estimator (util.py:254-286): means over ALL pairs."""
+    lx, ly = len(X), len(Y)
+    return (rmat_gaussian_kernel_matrix(X, X).sum() / lx ** 2 + rmat_gaussian_kernel_matrix(Y, Y).sum() / ly ** 2
+            - 2 * rmat_gaussian_kernel_matrix(X, Y).sum() / (lx * ly))
+
+
+def ker_2samp_threshold(m, alpha=0.05, max_ker=1.0):
+    """acceptance bound of Ker_2samp_test (util.py:289-299)"""
+    return (2 * max_ker / m) ** 0.5 * (1 + (2 * np.log(1 / alpha)) ** 0.5)
+
+
+def Ker_2samp_test(X, Y, alpha=0.05):
+    assert len(X) == len(Y)
+    return MMD(X, Y) < ker_2samp_threshold(len(X), alpha)

@@ -503,6 +503,51 @@ def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
     assert abs(np.median(err[lanes < 32]) - np.median(err[lanes >= 32])) < 2e-3 * max(1.0, coef[1])
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("fixture", ["chain_samples_trained", "chain_samples_T1000"])
+def test_G3_full_chain_two_sample_test_vs_reference(mods, golden, net, prec, fixture):
+    """Gate G3: 4096 samples of the full 1000-step chain must be statistically
+    indistinguishable from 4096 samples of the REFERENCE's own p_sample_loop under the reference's kernel
+    two-sample test (util.MMD + rmat_gaussian_kernel + Ker_2samp_test, alpha = 0.05), stay orthonormal and finite.
+    Fixtures (tools/make_golden.py): `chain_samples_trained` = a RotPredict trained for 3000 steps BY THE
+    REFERENCE on its two-mode data (so3_train.py:65-72) -- a concentrated population, the test has power;
+    `chain_samples_T1000` = the seed-0 untrained net (near-uniform population)."""
+    import copy
+    from so3x import rng
+    g = golden[fixture]
+    ref = g["x_final"]
+    m = len(ref)
+    mynet = copy.deepcopy(net)
+    if "net_0_weight" in g:
+        mynet.load_state_dict({f"net.{l}.{k}": torch.from_numpy(g[f"net_{l}_{k}"]) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")})
+    mynet = mynet.to(DEV)
+    mynet.precision = prec
+    proc = mods["diff"].SO3Diffusion(mynet, timesteps=1000).to(DEV)
+    rng.manual_seed(2024)
+    x = proc.p_sample_loop((m,))
+    assert not torch.isnan(x).any()
+    assert float((x @ x.transpose(-1, -2) - torch.eye(3, device=DEV)).abs().max()) < 1e-5
+    mine = host(x)
+    thr = O.ker_2samp_threshold(m)
+    mmd = O.MMD(mine, ref)
+    assert mmd < thr, (mmd, thr)
+    assert mmd < 5 * max(O.MMD(ref[: m // 2], ref[m // 2:]), 1e-3)  # tighter than the reference's bound: ~ estimator noise
+    if fixture == "chain_samples_trained":
+        # power: Haar-uniform rotations are rejected against this population
+        uni = O.quat_to_rmat(np.random.default_rng(0).standard_normal((m, 4)), "f64")
+        assert O.MMD(uni, ref) > thr
+        # same concentration around the two training modes (so3_train.py:65-72) and the same mode split
+        z90 = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+        def stats(X):
+            d0 = O.rmat_dist(X, np.broadcast_to(z90, X.shape).copy(), "f64")
+            d1 = O.rmat_dist(X, np.broadcast_to(z90.T, X.shape).copy(), "f64")
+            return np.median(np.minimum(d0, d1)), np.mean(d0 < d1)
+        med_r, frac_r = stats(ref.astype(np.float64))
+        med_m, frac_m = stats(mine.astype(np.float64))
+        assert abs(med_m - med_r) < 0.25 * med_r, (med_m, med_r)
+        assert abs(frac_m - frac_r) < 4 * np.sqrt(0.25 / m) + 0.01, (frac_m, frac_r)
+
+
 def test_full_size_chain_properties(mods, net):
     """BASELINE config 3 shape (2^20 rotations), a short bf16 chain: no NaN, orthonormal, det +1."""
     net.precision = "bf16"

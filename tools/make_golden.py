@@ -416,5 +416,74 @@ def main():
     print("total KB", tot / 1024)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def chain_samples():
+    """G3 fixture: 4096 final samples of the reference's full 1000-step p_sample_loop (seed-0 RotPredict),
+    the population the build's chain is compared with by the reference's own kernel two-sample test."""
+    cosine_beta_schedule = _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import diffusion as rdiff
+    import so3_train as rtrain
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    net = rtrain.RotPredict(out_type="skewvec")
+    proc = rdiff.SO3Diffusion(net, timesteps=1000, loss_type="skewvec")
+    rdiff.tqdm = lambda it, **k: it
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        x = proc.p_sample_loop((4096,))
+    assert torch.isfinite(x).all()
+    np.savez_compressed(os.path.join(OUT, "chain_samples_T1000.npz"), x_final=npy(x).astype(np.float32))
+    print("chain_samples_T1000.npz", os.path.getsize(os.path.join(OUT, "chain_samples_T1000.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chain_samples":
+    chain_samples()
+
+
+def trained_chain_samples(steps=3000, batch=256, lr=1e-3):
+    """G3 fixture with statistical power: train the REFERENCE RotPredict briefly with the REFERENCE's own
+    SO3Diffusion loss on the two-mode data of so3_train.py:65-72, then draw 4096 samples with the reference's
+    p_sample_loop.  Stores the trained weights and the samples."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import diffusion as rdiff
+    import so3_train as rtrain
+    import util as rutil
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    net = rtrain.RotPredict(out_type="skewvec")
+    proc = rdiff.SO3Diffusion(net, timesteps=1000, loss_type="skewvec")
+    optim = torch.optim.Adam(net.parameters(), lr=lr)
+    z90 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    rotations = torch.stack((z90, z90.T), dim=0)
+    for i in range(steps):
+        idx = torch.randint(0, 2, (batch,))
+        loss = proc(rotations[idx])
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        if i % 250 == 0:
+            print(i, float(loss), flush=True)
+    rdiff.tqdm = lambda it, **k: it
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        x = proc.p_sample_loop((4096,))
+    d = torch.minimum(rutil.rmat_dist(x, rotations[0][None].expand_as(x)), rutil.rmat_dist(x, rotations[1][None].expand_as(x)))
+    print("median geodesic distance to nearest mode (x0.7071):", float(d.median()) * 0.7071)
+    out = {"x_final": npy(x).astype(np.float32)}
+    for k_, v in net.state_dict().items():
+        out[k_.replace(".", "_")] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "chain_samples_trained.npz"), **out)
+    print("chain_samples_trained.npz", os.path.getsize(os.path.join(OUT, "chain_samples_trained.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trained_chain_samples":
+    trained_chain_samples()
