@@ -116,6 +116,32 @@ __device__ __forceinline__ void wave_store_rows(float* __restrict__ g, int64_t b
   __builtin_amdgcn_wave_barrier();
 }
 
+// Split form of wave_load_rows<9> for software prefetch: issue the NEXT tile's global loads into
+// registers (9 VGPRs) before computing the current tile, land them in LDS when their turn comes.
+// Only for full, 16-B-aligned tiles (the caller falls back to wave_load_rows otherwise).
+struct Pref9 { float4 a, b, c; };
+__device__ __forceinline__ Pref9 wave_prefetch9(const float* __restrict__ g, int64_t base) {
+  const int lane = threadIdx.x & 63;
+  const float4* s4 = reinterpret_cast<const float4*>(g + base * 9);
+  Pref9 p;
+  p.a = s4[lane];
+  p.b = s4[lane + 64];
+  p.c = lane < 16 ? s4[lane + 128] : float4{0.f, 0.f, 0.f, 0.f};
+  return p;
+}
+__device__ __forceinline__ void wave_commit9(const Pref9& p, float* wlds, float* r) {
+  const int lane = threadIdx.x & 63;
+  float4* d4 = reinterpret_cast<float4*>(wlds);
+  __builtin_amdgcn_wave_barrier();
+  d4[lane] = p.a;
+  d4[lane + 64] = p.b;
+  if (lane < 16) d4[lane + 128] = p.c;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 9; j++) r[j] = wlds[lane * 9 + j];
+  __builtin_amdgcn_wave_barrier();
+}
+
 // A lane's whole rotation (36 contiguous bytes, 4-byte aligned) moved with three wide accesses
 // (dwordx4 + dwordx3 + dwordx2) instead of nine 4-byte ones at a 36-byte lane stride: the nine
 // partial-line stores showed up as 5.8x WRITE_SIZE inflation in the PMC pass of round 1.

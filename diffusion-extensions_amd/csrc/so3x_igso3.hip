@@ -133,7 +133,7 @@ __device__ __attribute__((noinline)) float logp_identity_f64(float e) {
 // by design.  The reference evaluates the density in fp64, casts to fp32 and logs in fp32
 // (distributions.py:53-77); igso3_logf_dlog_f32 reproduces that result in fp32 arithmetic
 // (so3x_igso3.hpp) -- the fp64 form was VALU-bound at 27 % of HBM peak.
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 5)
 k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int64_t eps_stride, float* __restrict__ logp,
                 float* __restrict__ score_vec, float* __restrict__ grad_R, int64_t n) {
   // wave-private staging: every wave streams its own 64-sample tiles, no workgroup barrier
@@ -143,22 +143,37 @@ k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int6
   const int64_t ntiles = (n + kWave - 1) / kWave;
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+  // software prefetch: the next tile's loads are in flight while the current tile is computed
+  const bool aligned = (reinterpret_cast<uintptr_t>(R) & 15) == 0;
+  auto full = [&](int64_t tl) { return aligned && tl < ntiles && (n - tl * kWave) >= kWave; };
+  Pref9 pf;
+  float pe = 1.0f;
+  bool have = full(wave);
+  if (have) { pf = wave_prefetch9(R, wave * kWave); pe = eps[(wave * kWave + lane) * eps_stride]; }
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kWave;
     const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
     const int64_t idx = base + lane;
     const bool live = lane < cnt;
     float r[9], w[3];
-    const float e = live ? eps[idx * eps_stride] : 1.0f;
-    wave_load_rows<9>(R, base, cnt, wl, r);
-    log3(r, w);
-    const float ang = fsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);   // rmat_to_aa angle, util.py:217
+    float e;
+    if (have) {
+      wave_commit9(pf, wl, r);
+      e = pe;
+    } else {
+      e = live ? eps[idx * eps_stride] : 1.0f;
+      wave_load_rows<9>(R, base, cnt, wl, r);
+    }
+    have = full(tile + nwaves);
+    if (have) { pf = wave_prefetch9(R, (tile + nwaves) * kWave); pe = eps[((tile + nwaves) * kWave + lane) * eps_stride]; }
+    float sn_om, cs_om;
+    const float ang = log3_sc(r, w, &sn_om, &cs_om);   // rmat_to_aa angle (util.py:217): |w| = atan2(s, c)
     float lp, dl;
     if (ang == 0.0f) {  // exact identity: the reference's fp64 limit expression (rare, divergent on purpose)
       lp = logp_identity_f64(e);
       dl = 0.0f;
     } else {
-      lp = igso3_logf_dlog_f32(ang, e, &dl);
+      lp = igso3_logf_dlog_f32(ang, e, sn_om, cs_om, &dl);
     }
     if (live) logp[idx] = lp;
     if (score_vec) {
@@ -217,7 +232,10 @@ int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, 
                              float* score_vec, float* grad_R, int64_t n) {
   if (n < 0 || (n && (!R || !eps || !logp)) || (eps_stride != 0 && eps_stride != 1)) return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
-  hipLaunchKernelGGL(k_logprob_score, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, R, eps,
+  // 4 resident blocks per CU at this kernel's register budget: one wave of blocks, every wave streams several tiles
+  const int64_t nt64 = (n + kWave - 1) / kWave;
+  const int64_t want = (nt64 + 3) / 4;
+  hipLaunchKernelGGL(k_logprob_score, dim3((unsigned)(want < 1280 ? want : 1280)), dim3(kBlock), 0, (hipStream_t)s, R, eps,
                      eps_stride, logp, score_vec, grad_R, n);
   return check_launch();
 }

@@ -58,7 +58,11 @@ __device__ __forceinline__ double eps_ft_and_dlog_f64(double t, double eps, doub
 //   * (w - 2pi) e^{pi w / v} overflows float64  <=>  x + ln(2pi - w) > ln(DBL_MAX): density zeroed -> -inf
 //   * the .float() cast: values below the fp32 normal range are rounded on the 2^-149 grid.
 // Caller handles w == 0 with the fp64 limit expression.
-__device__ __forceinline__ float igso3_logf_dlog_f32(float om, float eps, float* dlogf) {
+// sin_om >= 0 and cos_om are sin/cos of the FULL angle as read off the rotation matrix (log3_sc); the half-angle
+// pair comes from them with one sqrt and one rcp instead of a range-reduced sincos:
+//   cos(w/2) = sqrt((1+c)/2), sin(w/2) = s / (2 cos(w/2))        for c >= 0   (no cancellation in 1 + c)
+//   sin(w/2) = sqrt((1-c)/2), cos(w/2) = s / (2 sin(w/2))        for c <  0   (no cancellation in 1 - c)
+__device__ __forceinline__ float igso3_logf_dlog_f32(float om, float eps, float sin_om, float cos_om, float* dlogf) {
   const float PI = 3.14159274101257324f, PI_LO = -8.74227765734758577e-8f;
   const float v = eps * eps;
   const float inv_v = frcp(v);
@@ -83,18 +87,22 @@ __device__ __forceinline__ float igso3_logf_dlog_f32(float om, float eps, float*
   const float g = om - (2.0f * om * Ech - 4.0f * PI * Esh);
   const float N = 4.0f * PI * ES - 2.0f * om * x * Esh;
   const float r = N * frcp(g * om);
-  float sh2, ch2;
-  sincos_cw(0.5f * om, &sh2, &ch2);
+  const float big = fsqrt(0.5f * (1.0f + fabsf(cos_om)));   // the well-conditioned one of cos(w/2), sin(w/2)
+  const float small = 0.5f * sin_om * frcp(big);
+  const float sh2 = cos_om >= 0.0f ? small : big, ch2 = cos_om >= 0.0f ? big : small;
   const float o2 = om * om;
   const float c = om < 0.5f ? -om * (1.0f / 12 + o2 * (1.0f / 720 + o2 * (1.0f / 30240 + o2 * (1.0f / 1209600))))
                             : 0.5f * ch2 * frcp(sh2) - frcp(om);
   *dlogf = -om * 0.5f * inv_v + r - c;
-  float lf = 0.572364942924700087f - 1.5f * __logf(v) + 0.25f * v - 0.25f * o2 * inv_v + __logf(g) - __logf(2.0f * sh2);
+  // one logarithm for  ln g - ln(2 sin(w/2)) - 3/2 ln v  (the quotient stays far inside the fp32 range)
+  float lf = 0.572364942924700087f + 0.25f * v - 0.25f * o2 * inv_v + __logf(g * frcp(2.0f * sh2) * inv_v * frsq(v));
   if (lf < -87.33654f) {  // below the fp32 normal range: emulate the cast's rounding on the 2^-149 grid
     const float q = rintf(exp2f(lf * 1.44269504088896341f + 149.0f));
     lf = __logf(q) - 103.278929903431851f;  // log(0) = -inf when the value rounds to zero
   }
-  if (x + __logf(2.0f * PI - om) > 709.782712893384f) lf = -INFINITY;  // the reference's float64 overflow -> 0
+  if (x > 707.0f) {  // only here can (w - 2pi) e^{pi w / v} overflow float64 (ln(2pi - w) <= 1.84): rare branch
+    if (x + __logf(2.0f * PI - om) > 709.782712893384f) lf = -INFINITY;  // the reference's float64 overflow -> 0
+  }
   return lf;
 }
 

@@ -69,10 +69,12 @@ __device__ __forceinline__ float atan2_pos(float s, float c) {
 //   angle == 0 -> 0 (util.py:174).  s == 0 with c < 0 (exact pi) is the reference's
 //   eigh branch (util.py:178-191, which takes an eigenvector ROW -- a reference bug);
 //   the correct axis from diag((R+I)/2) is used instead (parity unpinned there).
-__device__ __forceinline__ void log3(const float* R, float* w) {
+// (log3_sc also returns s = sin(angle) >= 0 and c = cos(angle) as read off the matrix)
+__device__ __forceinline__ float log3_sc(const float* R, float* w, float* s_out, float* c_out) {
   float v0 = R[7] - R[5], v1 = R[2] - R[6], v2 = R[3] - R[1];
   float s = fsqrt(v0 * v0 + v1 * v1 + v2 * v2) * 0.5f;
   float c = (R[0] + R[4] + R[8] - 1.0f) * 0.5f;
+  *s_out = s; *c_out = c;
   float ang = atan2_pos(s, c);
   float scale = ang * frcp(2.0f * s);
   if (ang == 0.0f) scale = 0.0f;
@@ -85,6 +87,11 @@ __device__ __forceinline__ void log3(const float* R, float* w) {
     else                      { a2 = sqrtf(d2); a0 = (R[2] + R[6]) / (4.f * a2); a1 = (R[5] + R[7]) / (4.f * a2); }
     w[0] = ang * a0; w[1] = ang * a1; w[2] = ang * a2;
   }
+  return ang;  // the rotation angle in [0, pi] (= |w| up to rounding)
+}
+__device__ __forceinline__ void log3(const float* R, float* w) {
+  float s, c;
+  log3_sc(R, w, &s, &c);
 }
 
 // exp(hat(w)); hat per util.py:87-92.  |w| reaches ~6e4 rad at t = T-1
