@@ -78,6 +78,46 @@ def cpu_baseline(T, params_np, betas, budget_s=12.0):
             "sample": f"{n} rotations x {steps} reverse steps (t from {T // 2} down), {el:.1f} s of CPU work"}
 
 
+def pmc_traffic(kernel, **match):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json; FETCH_SIZE
+    doubled per the gfx950 rule of MI355X_MICROARCH.md, WRITE_SIZE as is).  PMC counters cannot be read from
+    inside this process; the value is reported only when the profiled configuration matches this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel)
+        if rec and all(rec.get("config", {}).get(k) == v for k, v in match.items()):
+            return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def train_step_extra(B, torch, proc, net, n=1 << 19, reps=5):
+    """BASELINE config 4 on this GPU's shard: forward noising + loss + backward + Adam at 2^19 samples (bf16 MLP)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev))
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+
+    def step():
+        loss = proc(x0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"samples_per_s": n / (ms * 1e-3), "ms_per_step": ms, "batch": n, "mlp_operands": net.precision,
+            "algorithmic_TFLOPs": 94120 * n / (ms * 1e-3) / 1e12, "optimizer": "torch Adam"}
+
+
 def igso3_eval_roofline(B, torch, n=1 << 20, reps=50):
     """BASELINE config 2: IGSO(3) log-density + score, per-sample eps, HBM-bound kernel.  The C ABI is called
     directly with preallocated outputs, captured once into a HIP graph and replayed, so the events bracket
@@ -119,7 +159,8 @@ def igso3_eval_roofline(B, torch, n=1 << 20, reps=50):
     gbs = IGSO3_BYTES_PER_EVAL * n / (ms * 1e-3) / 1e9
     return {"kernel": "k_logprob_score", "evals_per_s": n / (ms * 1e-3), "bound": "hbm", "achieved": gbs,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "n": n, "ms": ms,
-            "bytes_per_eval": IGSO3_BYTES_PER_EVAL, "launches": reps, "timing": "HIP events around a graph replay"}
+            "bytes_per_eval": IGSO3_BYTES_PER_EVAL, "launches": reps, "timing": "HIP events around a graph replay",
+            "traffic": pmc_traffic("k_logprob_score", n=n)}
 
 
 def main():
@@ -202,17 +243,26 @@ def main():
                        "parallelism": f"batch-sharded x{ctx.world_size}, no collective"},
             "finite": ok,
             "roofline": {"kernel": "k_p_sample_chain", "bound": "mfma", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=int(args.steps / launches),
+                                                precision=args.precision),
                          "launches": launches, "steps_per_launch": args.steps / launches, "ms_per_launch": ms_per_launch,
                          "flop_per_sample_step": MLP_FLOP_PER_SAMPLE,
-                         "note": "algorithmic MLP flops only; kernel also does ~600 fp32 VALU ops + 570 transcendentals "
-                                 "per sample-step (see DESIGN.md); chain HBM traffic is 72 B/sample per launch"},
+                         "note": "algorithmic MLP flops vs the dense bf16 MFMA peak; the kernel's real bound is the VALU "
+                                 "(555 transcendentals + ~2400 other instructions per 64-sample wave-step, DESIGN.md "
+                                 "section 4); algorithmic HBM traffic is 72 B/sample per launch"},
         }
         if not args.no_extras:
             try:
                 line["igso3_eval"] = igso3_eval_roofline(B, torch)
+                big = igso3_eval_roofline(B, torch, n=1 << 24, reps=10)
+                line["igso3_eval"]["at_n_2p24"] = {k: big[k] for k in ("achieved", "frac", "ms", "evals_per_s")}
             except Exception as e:  # report, never hide
                 line["igso3_eval"] = {"error": repr(e)}
+            try:
+                line["train_step"] = train_step_extra(B, torch, proc, net)
+            except Exception as e:
+                line["train_step"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, params.cpu().numpy(), B.cosine_beta_schedule(T))
         print(json.dumps(line), flush=True)
