@@ -252,7 +252,7 @@ def main():
                                  "(555 transcendentals + ~2400 other instructions per 64-sample wave-step, DESIGN.md "
                                  "section 4); algorithmic HBM traffic is 72 B/sample per launch"},
         }
-        if not args.no_extras:
+        if not args.no_extras and ctx.world_size == 1:
             try:
                 line["igso3_eval"] = igso3_eval_roofline(B, torch)
                 big = igso3_eval_roofline(B, torch, n=1 << 24, reps=10)
@@ -263,7 +263,7 @@ def main():
                 line["train_step"] = train_step_extra(B, torch, proc, net)
             except Exception as e:
                 line["train_step"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and ctx.world_size == 1:  # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(T, params.cpu().numpy(), B.cosine_beta_schedule(T))
         print(json.dumps(line), flush=True)
     parallel.finalize(ctx)
