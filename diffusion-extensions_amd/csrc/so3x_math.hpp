@@ -209,4 +209,33 @@ __device__ __forceinline__ float igso3_angle(const float* row, const float* wrow
   return wt < 0.5f ? a0 + wt * dl : a1 - dl * (1.0f - wt);  // torch.lerp's two-sided form
 }
 
+// ---------------------------------------------------------------- reverse-step mean
+// reverse mean of one sample: predict_start_from_noise (diffusion.py:291-297) then
+// q_posterior (299-302).  log(x) is evaluated once (the reference does it twice, 292 & 301).
+__device__ __forceinline__ void p_mean_one(const float* x, const float* v, float a, float b, float c1, float c2,
+                                           float* x0hat, float* mean) {
+  float w[3], wa[3], xa[9], nv[3], nt[9], wh[3], e1[9], e2[9];
+  log3(x, w);
+  wa[0] = w[0] * a; wa[1] = w[1] * a; wa[2] = w[2] * a;
+  exp3(wa, xa);
+  nv[0] = v[0] * b; nv[1] = v[1] * b; nv[2] = v[2] * b;
+  exp3(nv, nt);
+  mul33_bt(xa, nt, x0hat);
+  log3(x0hat, wh);
+  wh[0] *= c1; wh[1] *= c1; wh[2] *= c1;
+  exp3(wh, e1);
+  w[0] *= c2; w[1] *= c2; w[2] *= c2;
+  exp3(w, e2);
+  mul33(e1, e2, mean);
+}
+
+// standard normals from two uniforms (Box-Muller); u in [0,1) from u01: shift to (0,1] for the log
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float* z0, float* z1) {
+  const float u1 = u01(a) + (1.0f / 16777216.0f), u2 = u01(b);
+  const float r = fsqrt(-2.0f * __logf(u1));
+  float sn, cs;
+  sincos_cw(2.0f * kPi * u2, &sn, &cs);
+  *z0 = r * cs; *z1 = r * sn;
+}
+
 }  // namespace so3x

@@ -29,6 +29,7 @@ SYMBOLS = (
     "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_sample",
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
+    "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
 )
 
 
@@ -430,3 +431,79 @@ def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=N
                                          _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision), _ptr(ws),
                                          C.c_size_t(ws.numel())), "p_sample_chain")
     return out
+
+
+# ----------------------------------------------------------------------------- SE(3) layer
+def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_col0=True, axes=None, unif=None, znorm=None,
+                        seed=0, rng_offset=0, index_base=0, want_targets=True):
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    x0_rot = _rot_in(x0_rot, "x_start.rot")
+    n = x0_rot.numel() // 9
+    x0_shift = _dev(x0_shift, "x_start.shift").reshape(n, 3)
+    tt = _dev(t, "t", torch.int64).reshape(-1)
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    zn = _dev(znorm, "znorm").reshape(-1, 3) if znorm is not None else None
+    dev = x0_rot.device
+    xt_rot = torch.empty_like(x0_rot)
+    xt_shift = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    tg_rot = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
+    tg_shift = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
+    with _Guard(x0_rot):
+        _check(lib().so3x_se3_q_sample_target(_stream(x0_rot), _ptr(sched), C.c_int(T), _ptr(_dev(trap_q, "trap_q")),
+                                              C.c_float(float(shift_scale)), _ptr(x0_rot), _ptr(x0_shift), _ptr(tt),
+                                              C.c_int(int(quirk_col0)), _ptr(ax), _ptr(un), _ptr(zn), _u64(seed),
+                                              _u64(rng_offset), _i64(index_base), _ptr(xt_rot), _ptr(xt_shift),
+                                              _ptr(tg_rot), _ptr(tg_shift), _i64(n)), "se3_q_sample_target")
+    return xt_rot, xt_shift, tg_rot, tg_shift
+
+
+def se3_p_mean(sched, x_rot, x_shift, v_rot, v_shift, t):
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    x_rot = _rot_in(x_rot, "x.rot")
+    n = x_rot.numel() // 9
+    x_shift = _dev(x_shift, "x.shift").reshape(n, 3)
+    v_rot = _dev(v_rot, "noise.rot_g").reshape(n, 3)
+    v_shift = _dev(v_shift, "noise.shift_g").reshape(n, 3)
+    mean_rot = torch.empty_like(x_rot)
+    mean_shift = torch.empty_like(x_shift)
+    with _Guard(x_rot):
+        _check(lib().so3x_se3_p_mean(_stream(x_rot), _ptr(sched), C.c_int(T), _ptr(x_rot), _ptr(x_shift), _ptr(v_rot),
+                                     _ptr(v_shift), C.c_int(int(t)), _ptr(mean_rot), _ptr(mean_shift), _i64(n)), "se3_p_mean")
+    return mean_rot, mean_shift
+
+
+def se3_p_noise(trap_row, sigma, shift_scale, mean_rot, mean_shift, axes=None, unif=None, znorm=None, seed=0, rng_offset=0,
+                index_base=0, shared_rot=True):
+    mean_rot = _rot_in(mean_rot, "mean.rot")
+    n = mean_rot.numel() // 9
+    mean_shift = _dev(mean_shift, "mean.shift").reshape(n, 3)
+    ax = _dev(axes, "axes").reshape(-1) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    zn = _dev(znorm, "znorm").reshape(-1, 3) if znorm is not None else None
+    out_rot = torch.empty_like(mean_rot)
+    out_shift = torch.empty_like(mean_shift)
+    with _Guard(mean_rot):
+        _check(lib().so3x_se3_p_noise(_stream(mean_rot), _ptr(_dev(trap_row, "trap_row")), C.c_float(float(sigma)),
+                                      C.c_float(float(shift_scale)), _ptr(mean_rot), _ptr(mean_shift), _ptr(ax), _ptr(un),
+                                      _ptr(zn), _u64(seed), _u64(rng_offset), _i64(index_base), C.c_int(int(shared_rot)),
+                                      _ptr(out_rot), _ptr(out_shift), _i64(n)), "se3_p_noise")
+    return out_rot, out_shift
+
+
+def rigid_move(rot, shift, pos, frames=None):
+    """rot [S,3,3], shift [S,3], pos [S,L,3], frames [S,L,3,3] or None."""
+    rot = _rot_in(rot, "transf.rot")
+    S = rot.numel() // 9
+    shift = _dev(shift, "transf.shift").reshape(S, 3)
+    pos = _dev(pos, "positions")
+    L = pos.numel() // (3 * S)
+    fr = _dev(frames, "angles") if frames is not None else None
+    out_pos = torch.empty_like(pos)
+    out_fr = torch.empty_like(fr) if fr is not None else None
+    with _Guard(rot):
+        _check(lib().so3x_rigid_move(_stream(rot), _ptr(rot), _ptr(shift), _ptr(pos), _ptr(fr), _ptr(out_pos), _ptr(out_fr),
+                                     _i64(S), _i64(L)), "rigid_move")
+    return out_pos, out_fr

@@ -1,0 +1,202 @@
+"""SE(3) = SO(3) x R^3 layer with the reference's names:
+AffineT / AffineGrad / se3_scale / se3_lerp (reference util.py:10-56, 364-385),
+IGSO3xR3 (distributions.py:84-110), SE3Diffusion (diffusion.py:432-522) and
+move_prot (prot_util.py:73-81).  Rotations run on the SO(3) kernels, the fused
+SE(3) steps on so3x_se3.hip; shifts of the small helper ops are single torch
+element-wise expressions."""
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import backend as _b
+from . import rng as _rng
+from .diffusion import _SCHED_NAMES, cosine_beta_schedule, extract
+from .distributions import IsotropicGaussianSO3
+
+__all__ = ["AffineT", "AffineGrad", "ProtData", "se3_scale", "se3_lerp", "IGSO3xR3", "SE3Diffusion", "move_prot"]
+
+ProtData = namedtuple("ProtData", ["residues", "positions", "angles"])
+
+
+class AffineT(object):
+    """Rigid transform: rot [..., 3, 3] and shift [..., 3] (reference util.py:10-42)."""
+
+    def __init__(self, rot: torch.Tensor, shift: torch.Tensor):
+        self.rot = rot
+        self.shift = shift
+
+    def __len__(self):
+        return max(len(self.rot), len(self.shift))
+
+    def __getitem__(self, item):
+        return AffineT(self.rot[item], self.shift[item])
+
+    @property
+    def device(self):
+        return self.rot.device
+
+    @property
+    def shape(self):
+        return self.shift.shape
+
+    def to(self, device):
+        return AffineT(self.rot.to(device), self.shift.to(device))
+
+    def detach(self):
+        return AffineT(self.rot.detach(), self.shift.detach())
+
+
+class AffineGrad(object):
+    """Denoiser output: rot_g [..., 3] (tangent vector) and shift_g [..., 3] (reference util.py:45-56)."""
+
+    def __init__(self, rot_g, shift_g):
+        self.rot_g = rot_g
+        self.shift_g = shift_g
+
+    def __len__(self):
+        return max(len(self.rot_g), len(self.shift_g))
+
+    def __getitem__(self, item):
+        return AffineGrad(self.rot_g[item], self.shift_g[item])
+
+
+def se3_scale(transf: AffineT, scalars) -> AffineT:
+    """reference util.py:382-385"""
+    return AffineT(_b.so3_scale(transf.rot, scalars), transf.shift * scalars[..., None])
+
+
+def se3_lerp(transf_a: AffineT, transf_b: AffineT, weight: torch.Tensor) -> AffineT:
+    """reference util.py:364-379"""
+    return AffineT(_b.so3_lerp(transf_a.rot, transf_b.rot, weight), torch.lerp(transf_a.shift, transf_b.shift, weight))
+
+
+def move_prot(transf: AffineT, protein: ProtData) -> ProtData:
+    """Rigid move of residue positions [.., L, 3] and frames [.., L, 3, 3] about the residue centroid
+    (reference prot_util.py:73-81); batched over leading structure dimensions."""
+    pos, fr = protein.positions, protein.angles
+    L = pos.shape[-2]
+    rot = transf.rot.reshape(-1, 3, 3)
+    out_pos, out_fr = _b.rigid_move(rot, transf.shift.reshape(-1, 3), pos.reshape(rot.shape[0], L, 3),
+                                    fr.reshape(rot.shape[0], L, 3, 3) if fr is not None else None)
+    return ProtData(protein.residues, out_pos.reshape(pos.shape), out_fr.reshape(fr.shape) if fr is not None else None)
+
+
+class IGSO3xR3:
+    """IGSO(3) x isotropic Gaussian on R^3 (reference distributions.py:84-110)."""
+
+    def __init__(self, eps: torch.Tensor, mean: AffineT = None, shift_scale=1.0):
+        self.eps = eps
+        self.shift_scale = shift_scale
+        self._mean = mean
+        self.igso3 = IsotropicGaussianSO3(eps=eps, mean=mean.rot if (mean is not None and mean.rot.dim() == 2) else None)
+
+    @property
+    def mean(self):
+        return self._mean
+
+    def sample(self, sample_shape=torch.Size(), axes=None, unif=None, znorm=None):
+        rot = self.igso3.sample(sample_shape, axes=axes, unif=unif)
+        if self._mean is not None and self._mean.rot.dim() > 2:
+            rot = _b.rmul(self._mean.rot, rot)  # per-sample mean rotations
+        shape = tuple(sample_shape) + tuple(self.eps.shape) + (3,)
+        if znorm is None:
+            znorm = torch.randn(shape, device=self.eps.device)
+        shift = znorm.reshape(shape) * (self.eps[..., None] * self.shift_scale)
+        if self._mean is not None:
+            shift = shift + self._mean.shift
+        return AffineT(rot, shift)
+
+
+class SE3Diffusion(nn.Module):
+    """reference diffusion.py:432-522.  denoise_fn(AffineT, t) -> AffineGrad (any torch module/callable)."""
+
+    def __init__(self, denoise_fn, timesteps=1000, loss_type="grad_mse", betas=None, shift_scale=75.0, quirk_col0=True,
+                 shared_rot_noise=True):
+        super().__init__()
+        self.denoise_fn = denoise_fn
+        if betas is not None:
+            betas = betas.detach().cpu().numpy() if isinstance(betas, torch.Tensor) else np.asarray(betas)
+        else:
+            betas = cosine_beta_schedule(timesteps)
+        betas = np.ascontiguousarray(betas, np.float64)
+        self.num_timesteps = int(betas.shape[0])
+        if loss_type != "grad_mse":
+            raise NotImplementedError("so3x: SE3Diffusion implements loss_type='grad_mse' (reference diffusion.py:513)")
+        self.loss_type = loss_type
+        self.shift_scale = shift_scale
+        self.quirk_col0 = quirk_col0
+        # reference p_sample draws ONE rotation noise for the whole batch (diffusion.py:482 with scalar eps and an
+        # empty sample shape, distributions.py:98-101); kept by default, False = one draw per sample
+        self.shared_rot_noise = shared_rot_noise
+        self.index_base = 0
+        sched = _b.schedule_from_betas(betas)
+        for i, name in enumerate(_SCHED_NAMES):
+            self.register_buffer(name, torch.from_numpy(sched[i].copy()))
+        self.register_buffer("identity", torch.eye(3))
+        self.register_buffer("_sched", torch.from_numpy(sched.copy()), persistent=False)
+        self._sigma_host = sched[12].copy()
+        self._trap_q = None
+        self._trap_p = None
+
+    def _tables(self):
+        dev = self._sched.device
+        if self._trap_q is None or self._trap_q.device != dev:
+            self._trap_q = _b.igso3_build_tables(self._sched[4])
+            self._trap_p = _b.igso3_build_tables(self._sched[12])
+        return self._trap_q, self._trap_p
+
+    @staticmethod
+    def _shared_t(t):
+        return t if isinstance(t, int) else int(t.reshape(-1)[0].item())
+
+    def q_mean_variance(self, x_start, t):
+        mean = se3_scale(x_start, self.sqrt_alphas_cumprod[t])
+        return mean, extract(1.0 - self.alphas_cumprod, t, x_start.shape), \
+            extract(self.log_one_minus_alphas_cumprod, t, x_start.shape)
+
+    def p_mean_variance(self, x: AffineT, t, clip_denoised: bool = False):
+        predict = self.denoise_fn(x, t)
+        mean_rot, mean_shift = _b.se3_p_mean(self._sched, x.rot, x.shift, predict.rot_g, predict.shift_g, self._shared_t(t))
+        return AffineT(mean_rot, mean_shift), extract(self.posterior_variance, t, t.shape), \
+            extract(self.posterior_log_variance_clipped, t, t.shape)
+
+    @torch.no_grad()
+    def p_sample(self, x: AffineT, t, clip_denoised=False, repeat_noise=False, axes=None, unif=None, znorm=None):
+        t0 = self._shared_t(t)
+        mean, _, _ = self.p_mean_variance(x, t)
+        if t0 == 0:
+            return mean
+        _, trap_p = self._tables()
+        off = _rng.next_offset() if axes is None else 0
+        rot, shift = _b.se3_p_noise(trap_p[t0], float(self._sigma_host[t0]), self.shift_scale, mean.rot, mean.shift, axes=axes,
+                                    unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
+                                    shared_rot=self.shared_rot_noise)
+        return AffineT(rot, shift)
+
+    def q_sample(self, x_start: AffineT, t, noise: AffineT = None, axes=None, unif=None, znorm=None):
+        if noise is not None:
+            x_blend = se3_scale(x_start, self.sqrt_alphas_cumprod[t])
+            return AffineT(_b.rmul(x_blend.rot, noise.rot), x_blend.shift + noise.shift)
+        trap_q, _ = self._tables()
+        xt_rot, xt_shift, _, _ = _b.se3_q_sample_target(
+            self._sched, trap_q, self.shift_scale, x_start.rot, x_start.shift, t, quirk_col0=self.quirk_col0, axes=axes,
+            unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
+            index_base=self.index_base, want_targets=False)
+        return AffineT(xt_rot, xt_shift)
+
+    def p_losses(self, x_start: AffineT, t, noise=None, axes=None, unif=None, znorm=None):
+        trap_q, _ = self._tables()
+        xt_rot, xt_shift, tg_rot, tg_shift = _b.se3_q_sample_target(
+            self._sched, trap_q, self.shift_scale, x_start.rot, x_start.shift, t, quirk_col0=self.quirk_col0, axes=axes,
+            unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
+            index_base=self.index_base)
+        x_recon = self.denoise_fn(AffineT(xt_rot, xt_shift), t)
+        return F.mse_loss(x_recon.shift_g, tg_shift) + F.mse_loss(x_recon.rot_g, tg_rot)
+
+    def forward(self, x: AffineT, *args, **kwargs):
+        b = len(x)
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+        return self.p_losses(x, t, *args, **kwargs)

@@ -167,6 +167,37 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
                         uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                         void* workspace, size_t workspace_bytes);
 
+/* ------------------------------------------------------ SE(3) = SO(3) x R^3 layer */
+/* SE3Diffusion.q_sample + the two p_losses targets (diffusion.py:496-513) fused with the
+ * IGSO3xR3 noise draw (distributions.py:84-101): rotation noise as so3x_q_sample_target,
+ * shift noise = z * (eps_t * shift_scale), z ~ N(0,1)^3;
+ *   xt_rot = so3_scale(x0_rot, sqrt(abar)) @ noise_rot,  xt_shift = x0_shift*sqrt(abar) + noise_shift,
+ *   target_rot = vee(log noise_rot)/eps,  target_shift = noise_shift/(eps*shift_scale).
+ * axes/unif/znorm: explicit draws (all three or none; none = in-kernel Philox + Box-Muller). */
+int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q,
+                             float shift_scale, const float* x0_rot, const float* x0_shift,
+                             const int64_t* t, int quirk_col0, const float* axes, const float* unif,
+                             const float* znorm, uint64_t seed, uint64_t rng_offset, int64_t index_base,
+                             float* xt_rot, float* xt_shift, float* target_rot, float* target_shift,
+                             int64_t n);
+/* SE3Diffusion.predict_start_from_noise + q_posterior (diffusion.py:444-466) for one shared t:
+ * v_rot/v_shift = the denoiser's AffineGrad (rot_g [n][3], shift_g [n][3]). */
+int so3x_se3_p_mean(so3x_stream_t s, const float* sched, int T, const float* x_rot, const float* x_shift,
+                    const float* v_rot, const float* v_shift, int t, float* mean_rot, float* mean_shift,
+                    int64_t n);
+/* SE3Diffusion.p_sample noise (diffusion.py:476-483): out_rot = mean_rot @ noise, out_shift =
+ * mean_shift + sigma*shift_scale*z.  trap_row = the 999-entry CDF row of sigma.  shared_rot != 0
+ * reproduces the reference's ONE rotation noise for the whole batch (scalar eps + empty sample
+ * shape, distributions.py:98-101): axes[3]/unif[1] are then single draws; 0 = one per sample. */
+int so3x_se3_p_noise(so3x_stream_t s, const float* trap_row, float sigma, float shift_scale,
+                     const float* mean_rot, const float* mean_shift, const float* axes, const float* unif,
+                     const float* znorm, uint64_t seed, uint64_t rng_offset, int64_t index_base,
+                     int shared_rot, float* out_rot, float* out_shift, int64_t n);
+/* move_prot (prot_util.py:73-81): S rigid transforms applied to S structures of L residues:
+ * pos' = (pos - mean_L(pos)) R^T + mean + shift, frames' = frames R^T (frames may be NULL). */
+int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const float* pos,
+                    const float* frames, float* out_pos, float* out_frames, int64_t S, int64_t L);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,3 +356,40 @@ def ker_2samp_threshold(m, alpha=0.05, max_ker=1.0):
 def Ker_2samp_test(X, Y, alpha=0.05):
     assert len(X) == len(Y)
     return MMD(X, Y) < ker_2samp_threshold(len(X), alpha)
+
+
+# ---------------------------------------------------------------------------------------------
+# SE(3) layer: numpy restatement on top of the C rotation oracle
+# ---------------------------------------------------------------------------------------------
+def se3_q_sample_target(x0_rot, x0_shift, noise_rot, noise_shift, sched, t, shift_scale, prec="f32"):
+    """SE3Diffusion.q_sample (diffusion.py:496-503) and the p_losses targets (:511-512)."""
+    dt = _DT[prec]
+    t = np.asarray(t, np.int64)
+    xt_rot, tg_rot = q_sample_target(x0_rot, noise_rot, sched, t, prec)
+    k = sched[3][t].astype(dt)[:, None]
+    eps = sched[4][t].astype(dt)[:, None]
+    ns = np.asarray(noise_shift, dt)
+    xt_shift = np.asarray(x0_shift, dt) * k + ns                     # se3_scale shift (util.py:384) + noise.shift
+    tg_shift = ns * (1 / (eps * dt(shift_scale)))
+    return xt_rot, xt_shift, tg_rot, tg_shift
+
+
+def se3_p_mean(x_rot, x_shift, v_rot, v_shift, sched, t, prec="f32"):
+    """SE3Diffusion.predict_start_from_noise + q_posterior (diffusion.py:444-466), one shared t."""
+    dt = _DT[prec]
+    a, b, c1, c2 = (dt(sched[i][t]) for i in (6, 7, 10, 11))
+    _, mean_rot = p_mean(x_rot, v_rot, float(a), float(b), float(c1), float(c2), prec)
+    xs = np.asarray(x_shift, dt)
+    x0h = xs * a - np.asarray(v_shift, dt) * b
+    return mean_rot, x0h * c1 + xs * c2
+
+
+def move_prot(rot, shift, pos, frames):
+    """prot_util.py:73-81, batched over structures: pos [S,L,3], frames [S,L,3,3]."""
+    rot = np.asarray(rot, np.float64); shift = np.asarray(shift, np.float64)
+    pos = np.asarray(pos, np.float64); frames = np.asarray(frames, np.float64)
+    mean = pos.mean(axis=-2, keepdims=True)
+    RT = np.swapaxes(rot, -1, -2)[:, None]
+    out_pos = ((pos - mean)[:, :, None, :] @ RT)[:, :, 0, :] + mean + shift[:, None, :]
+    out_fr = frames @ RT
+    return out_pos, out_fr

@@ -1,0 +1,147 @@
+"""SE(3) layer: oracle pinned against fixtures generated from the reference's
+SE3Diffusion / IGSO3xR3 / se3_scale / move_prot (tools/make_golden.py se3), then the HIP kernels against both."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+@pytest.fixture(scope="module")
+def g(golden):
+    return golden["se3"]
+
+
+@pytest.fixture(scope="module")
+def sched():
+    return O.schedule_from_betas(O.cosine_beta_schedule(1000))
+
+
+# ------------------------------------------------------------------ CPU: oracle vs the reference's outputs
+def test_oracle_se3_forward_noising(g, sched):
+    t = g["t"]
+    trap_q = O.igso3_build_tables(sched[4])
+    noise_rot, _ = O.igso3_sample(trap_q, g["q_axes"], g["q_unif"], row_idx=t, weight_row=int(t[0]))
+    assert maxabs(noise_rot, g["q_noise_rot"]) < 2e-5
+    eps = sched[4][t][:, None]
+    assert maxabs(g["q_z"] * (eps * g["shift_scale"]), g["q_noise_shift"]) < 1e-4
+    xt_rot, xt_shift, tg_rot, tg_shift = O.se3_q_sample_target(g["rot0"], g["shift0"], g["q_noise_rot"], g["q_noise_shift"],
+                                                              sched, t, g["shift_scale"])
+    assert maxabs(xt_rot, g["xt_rot"]) < 2e-5 and maxabs(xt_shift, g["xt_shift"]) < 2e-4
+    assert maxabs(tg_rot, g["target_rot"]) < 1e-5 * max(1, np.abs(g["target_rot"]).max())
+    assert maxabs(tg_shift, g["target_shift"]) < 1e-5
+
+
+@pytest.mark.parametrize("tv", [0, 3, 400, 900])
+def test_oracle_se3_reverse_mean(g, sched, tv):
+    pre = f"t{tv}_"
+    mr, ms = O.se3_p_mean(g["rot0"], g["shift0"], g[pre + "pred_rot"], g[pre + "pred_shift"], sched, tv, "f64")
+    assert maxabs(mr, g[pre + "mean_rot_64"]) < 1e-6
+    assert maxabs(ms, g[pre + "mean_shift_64"]) < 1e-4 * max(1.0, np.abs(g[pre + "mean_shift_64"]).max())
+
+
+def test_oracle_se3_scale_and_move(g):
+    assert maxabs(O.so3_scale(g["rot0"], g["k"], "f64"), g["scale_rot"]) < 1e-5
+    assert maxabs(g["shift0"] * g["k"][:, None], g["scale_shift"]) < 1e-5
+    op, of = O.move_prot(g["mv_rot"], g["mv_shift"], g["mv_pos"], g["mv_frames"])
+    assert maxabs(op, g["mv_out_pos"]) < 2e-5 and maxabs(of, g["mv_out_frames"]) < 2e-6
+
+
+# ------------------------------------------------------------------ GPU: kernels vs reference fixtures and oracle
+DEV = "cuda:0"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def host(x):
+    return x.detach().cpu().numpy()
+
+
+def dummy(x, t):
+    """the stand-in denoiser of tools/make_golden.py (plain torch on the GPU: a user-supplied denoise_fn)"""
+    from so3x.se3 import AffineGrad
+    tt = t.float()[:, None] / 1000.0
+    return AffineGrad(0.3 * x.rot[..., 0] - 0.1 * x.rot[..., 2] + 0.05 * tt, 0.01 * x.shift + 0.2 * tt - 0.1)
+
+
+@pytest.mark.gpu
+def test_gpu_se3_p_losses_and_q_sample(g):
+    from so3x.se3 import SE3Diffusion, AffineT
+    proc = SE3Diffusion(dummy, timesteps=1000).to(DEV)
+    x0 = AffineT(dev(g["rot0"]), dev(g["shift0"]))
+    t = dev(g["t"], torch.int64)
+    kw = dict(axes=dev(g["q_axes"]), unif=dev(g["q_unif"]), znorm=dev(g["q_z"]))
+    xt = proc.q_sample(x0, t, **kw)
+    assert maxabs(host(xt.rot), g["xt_rot"]) < 2e-5 and maxabs(host(xt.shift), g["xt_shift"]) < 2e-4
+    xt2 = proc.q_sample(x0, t, noise=AffineT(dev(g["q_noise_rot"]), dev(g["q_noise_shift"])))
+    assert maxabs(host(xt2.rot), g["xt_rot"]) < 2e-5 and maxabs(host(xt2.shift), g["xt_shift"]) < 2e-4
+    loss = proc.p_losses(x0, t, **kw)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    from so3x import backend as B
+    trap_q, _ = proc._tables()
+    _, _, tg_rot, tg_shift = B.se3_q_sample_target(proc._sched, trap_q, proc.shift_scale, x0.rot, x0.shift, t, **kw)
+    assert maxabs(host(tg_rot), g["target_rot"]) < 1e-5 * max(1, np.abs(g["target_rot"]).max())
+    assert maxabs(host(tg_shift), g["target_shift"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tv", [0, 3, 400, 900])
+def test_gpu_se3_reverse_step(g, tv):
+    from so3x.se3 import SE3Diffusion, AffineT
+    pre = f"t{tv}_"
+    proc = SE3Diffusion(dummy, timesteps=1000).to(DEV)
+    x0 = AffineT(dev(g["rot0"]), dev(g["shift0"]))
+    t = torch.full((len(g["rot0"]),), tv, device=DEV, dtype=torch.long)
+    mean, _, _ = proc.p_mean_variance(x0, t)
+    n = len(g["rot0"])
+    err = np.linalg.norm((host(mean.rot) - g[pre + "mean_rot_64"]).reshape(n, -1), axis=1)
+    ref_err = np.linalg.norm((g[pre + "mean_rot"] - g[pre + "mean_rot_64"]).reshape(n, -1), axis=1)
+    assert err.max() <= max(2e-5, 2 * ref_err.max())
+    sscale = max(1.0, np.abs(g[pre + "mean_shift_64"]).max())
+    assert maxabs(host(mean.shift), g[pre + "mean_shift_64"]) < 2e-6 * sscale + 2 * maxabs(g[pre + "mean_shift"], g[pre + "mean_shift_64"])
+    kw = dict(axes=dev(g[pre + "ps_axes"]), unif=dev(g[pre + "ps_unif"]), znorm=dev(g[pre + "ps_z"])) if tv > 0 else {}
+    xs = proc.p_sample(x0, t, **kw)
+    assert maxabs(host(xs.rot), g[pre + "ps_rot"]) < 5e-5 + 4 * ref_err.max()       # ONE shared rotation noise, as the reference
+    assert maxabs(host(xs.shift), g[pre + "ps_shift"]) < 2e-5 * max(1.0, np.abs(g[pre + "ps_shift"]).max())
+
+
+@pytest.mark.gpu
+def test_gpu_se3_scale_move_and_philox(g):
+    from so3x.se3 import AffineT, ProtData, se3_scale, move_prot, SE3Diffusion
+    sc = se3_scale(AffineT(dev(g["rot0"]), dev(g["shift0"])), dev(g["k"]))
+    assert maxabs(host(sc.rot), g["scale_rot"]) < 1e-5 and maxabs(host(sc.shift), g["scale_shift"]) < 1e-5
+    pd = move_prot(AffineT(dev(g["mv_rot"]), dev(g["mv_shift"])), ProtData(None, dev(g["mv_pos"]), dev(g["mv_frames"])))
+    assert maxabs(host(pd.positions), g["mv_out_pos"]) < 2e-5 and maxabs(host(pd.angles), g["mv_out_frames"]) < 2e-6
+    # BASELINE config 5 shape: 4096 structures x 256 residues; rigid motion preserves pairwise distances and frames stay orthonormal
+    S, L = 4096, 256
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    from so3x import backend as B
+    rot = B.quat_to_rmat(torch.randn(S, 4, device=DEV, generator=gen))
+    shift = torch.randn(S, 3, device=DEV, generator=gen) * 5
+    pos = torch.randn(S, L, 3, device=DEV, generator=gen) * 10
+    frames = B.quat_to_rmat(torch.randn(S, L, 4, device=DEV, generator=gen))
+    out = move_prot(AffineT(rot, shift), ProtData(None, pos, frames))
+    d_in = (pos[:, :8, None] - pos[:, None, :8]).norm(dim=-1)
+    d_out = (out.positions[:, :8, None] - out.positions[:, None, :8]).norm(dim=-1)
+    assert float((d_in - d_out).abs().max()) < 1e-4
+    assert float((out.positions.mean(1) - pos.mean(1) - shift).abs().max()) < 1e-4
+    ff = out.angles @ out.angles.transpose(-1, -2)
+    assert float((ff - torch.eye(3, device=DEV)).abs().max()) < 1e-5
+    # in-kernel Philox + Box-Muller noise: shift targets are standard normal, rotation targets finite, shards consistent
+    proc = SE3Diffusion(dummy, timesteps=1000).to(DEV)
+    n = 1 << 16
+    x0 = AffineT(B.quat_to_rmat(torch.randn(n, 4, device=DEV, generator=gen)), torch.randn(n, 3, device=DEV, generator=gen))
+    t = torch.randint(0, 1000, (n,), device=DEV, generator=gen)
+    trap_q, _ = proc._tables()
+    full = B.se3_q_sample_target(proc._sched, trap_q, 75.0, x0.rot, x0.shift, t, quirk_col0=False, seed=5, rng_offset=9)
+    z = full[3]
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1) < 0.01 and torch.isfinite(full[2]).all()
+    half = B.se3_q_sample_target(proc._sched, trap_q, 75.0, x0.rot[n // 2:], x0.shift[n // 2:], t[n // 2:], quirk_col0=False,
+                                 seed=5, rng_offset=9, index_base=n // 2)
+    assert all(torch.equal(a[n // 2:], b) for a, b in zip(full, half))

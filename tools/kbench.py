@@ -29,7 +29,7 @@ def timeit(fn, reps=20, warm=3):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"logprob", "rot", "chain", "train"}
+    which = set(sys.argv[1:]) or {"logprob", "rot", "chain", "train", "se3"}
     g = torch.Generator(device=dev).manual_seed(0)
     if "logprob" in which:
         for lg in (20, 24):
@@ -46,6 +46,23 @@ def main():
         print(json.dumps({"k": "so3_scale", "n": n, "ms": ms, "GBs": 76 * n / ms / 1e6}))
         ms = timeit(lambda: B.quat_to_rmat(torch.empty(0, 4, device=dev)) if False else B.log_rmat_vec(R))
         print(json.dumps({"k": "log_rmat_vec", "n": n, "ms": ms, "GBs": 48 * n / ms / 1e6}))
+    if "se3" in which:
+        from so3x.se3 import SE3Diffusion, AffineGrad
+        S, L = 4096, 256
+        rot = B.quat_to_rmat(torch.randn(S, 4, device=dev, generator=g))
+        shift = torch.randn(S, 3, device=dev, generator=g)
+        pos = torch.randn(S, L, 3, device=dev, generator=g)
+        frames = B.quat_to_rmat(torch.randn(S, L, 4, device=dev, generator=g))
+        ms = timeit(lambda: B.rigid_move(rot, shift, pos, frames))
+        print(json.dumps({"k": "rigid_move", "residues": S * L, "ms": ms, "GBs": 96 * S * L / ms / 1e6, "frac8T": 96 * S * L / ms / 1e6 / 8000}))
+        n = 1 << 20
+        proc3 = SE3Diffusion(lambda x, t: AffineGrad(x.rot[..., 0], x.shift), timesteps=1000).to(dev)
+        tq, _ = proc3._tables()
+        xr = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        xs = torch.randn(n, 3, device=dev, generator=g)
+        tt = torch.randint(0, 1000, (n,), device=dev, generator=g)
+        ms = timeit(lambda: B.se3_q_sample_target(proc3._sched, tq, 75.0, xr, xs, tt, seed=1))
+        print(json.dumps({"k": "se3_q_sample_target", "n": n, "ms": ms, "GBs": (84 + 48 + 8) * n / ms / 1e6}))
     if "chain" in which or "train" in which:
         torch.manual_seed(0)
         net = RotPredict(out_type="skewvec", precision="bf16").to(dev)

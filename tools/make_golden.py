@@ -487,3 +487,109 @@ def trained_chain_samples(steps=3000, batch=256, lr=1e-3):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trained_chain_samples":
     trained_chain_samples()
+
+
+def se3_golden():
+    """SE(3) layer fixtures: IGSO3xR3 sampling, SE3Diffusion q_sample / p_losses targets /
+    predict_start / q_posterior / p_sample (incl. its ONE-shared-rotation-noise behaviour), se3_scale, move_prot."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import diffusion as rdiff
+    import distributions as rdist
+    import util as rutil
+    import prot_util as rprot
+    torch.set_num_threads(4)
+    out = {}
+    B, T = 48, 1000
+    g = torch.Generator().manual_seed(31)
+    rot0 = rutil.quat_to_rmat(torch.randn(B, 4, generator=g))
+    shift0 = torch.randn(B, 3, generator=g) * 20.0
+    x0 = rutil.AffineT(rot0, shift0)
+
+    def dummy(x, t):  # deterministic stand-in denoiser: AffineT, t -> AffineGrad
+        tt = t.float()[:, None] / 1000.0
+        return rutil.AffineGrad(0.3 * x.rot[..., 0] - 0.1 * x.rot[..., 2] + 0.05 * tt, 0.01 * x.shift + 0.2 * tt - 0.1)
+
+    proc = rdiff.SE3Diffusion(dummy, timesteps=T)  # shift_scale = 75.0 default
+    out["rot0"], out["shift0"] = npy(rot0), npy(shift0)
+    out["shift_scale"] = np.float32(proc.shift_scale)
+    # record torch.normal too (Normal.sample goes through it)
+    normals = []
+    orig_normal = torch.normal
+
+    def normal_spy(*a, **k):
+        o = orig_normal(*a, **k)
+        normals.append(o.detach().clone())
+        return o
+
+    torch.normal = normal_spy
+    try:
+        torch.manual_seed(77)
+        t = torch.randint(0, T, (B,))
+        out["t"] = npy(t)
+        with RNGRecorder() as rec:
+            eps = proc.sqrt_one_minus_alphas_cumprod[t]
+            noise = rdist.IGSO3xR3(eps, shift_scale=proc.shift_scale).sample()
+        assert [n for n, _ in rec.log] == ["randn", "rand"] and len(normals) == 1
+        out["q_axes"], out["q_unif"] = npy(rec.log[0][1]), npy(rec.log[1][1])
+        out["q_noise_rot"], out["q_noise_shift"] = npy(noise.rot), npy(noise.shift)
+        out["q_z"] = npy(noise.shift / (eps * proc.shift_scale)[:, None])
+        xt = proc.q_sample(x0, t, noise=noise)
+        out["xt_rot"], out["xt_shift"] = npy(xt.rot), npy(xt.shift)
+        out["target_shift"] = npy(noise.shift * (1 / (eps * proc.shift_scale))[..., None])
+        out["target_rot"] = npy(rutil.skew2vec(rutil.log_rmat(noise.rot)) * (1 / eps)[..., None])
+        pred = dummy(xt, t)
+        out["loss"] = npy(torch.nn.functional.mse_loss(pred.shift_g, torch.from_numpy(out["target_shift"]))
+                          + torch.nn.functional.mse_loss(pred.rot_g, torch.from_numpy(out["target_rot"])))
+        # se3_scale
+        k = torch.rand(B, generator=g) * 1.5
+        sc = rutil.se3_scale(x0, k)
+        out["k"], out["scale_rot"], out["scale_shift"] = npy(k), npy(sc.rot), npy(sc.shift)
+        # reverse step pieces at a few timesteps (fp32 and fp64)
+        proc64 = rdiff.SE3Diffusion(dummy, timesteps=T).double()
+        for tv in (0, 3, 400, 900):
+            tt = torch.full((B,), tv, dtype=torch.long)
+            pre = f"t{tv}_"
+            p = dummy(x0, tt)
+            out[pre + "pred_rot"], out[pre + "pred_shift"] = npy(p.rot_g), npy(p.shift_g)
+            xr = proc.predict_start_from_noise(x0, tt, p)
+            mean, _, logvar = proc.q_posterior(xr, x0, tt)
+            out[pre + "x0hat_rot"], out[pre + "x0hat_shift"] = npy(xr.rot), npy(xr.shift)
+            out[pre + "mean_rot"], out[pre + "mean_shift"] = npy(mean.rot), npy(mean.shift)
+            x064 = rutil.AffineT(rot0.double(), shift0.double())
+            p64 = rutil.AffineGrad(p.rot_g.double(), p.shift_g.double())
+            xr64 = proc64.predict_start_from_noise(x064, tt, p64)
+            mean64, _, _ = proc64.q_posterior(xr64, x064, tt)
+            out[pre + "mean_rot_64"], out[pre + "mean_shift_64"] = npy(mean64.rot), npy(mean64.shift)
+            normals.clear()
+            with RNGRecorder() as rec:
+                xs = proc.p_sample(x0, tt)
+            out[pre + "ps_rot"], out[pre + "ps_shift"] = npy(xs.rot), npy(xs.shift)
+            if tv > 0:
+                assert [n for n, _ in rec.log] == ["randn", "rand"] and rec.log[0][1].shape == (3,) and len(normals) == 1
+                sigma = (0.5 * logvar).exp()[0]
+                out[pre + "ps_axes"], out[pre + "ps_unif"] = npy(rec.log[0][1]), npy(rec.log[1][1])
+                out[pre + "ps_z"] = npy((normals[0] - mean.shift) / (sigma * proc.shift_scale))
+                out[pre + "sigma"] = npy(sigma)
+    finally:
+        torch.normal = orig_normal
+    # move_prot (prot_util.py:73-81): 6 structures x 40 residues
+    S, L = 6, 40
+    pos = torch.randn(S, L, 3, generator=g) * 10
+    frames = rutil.quat_to_rmat(torch.randn(S, L, 4, generator=g))
+    tr = rutil.AffineT(rutil.quat_to_rmat(torch.randn(S, 4, generator=g)), torch.randn(S, 3, generator=g) * 5)
+    mp, mf = [], []
+    for s_ in range(S):
+        pd = rprot.move_prot(tr[s_], rutil.ProtData(None, pos[s_], frames[s_]))
+        mp.append(pd.positions)
+        mf.append(pd.angles)
+    out.update(mv_pos=npy(pos), mv_frames=npy(frames), mv_rot=npy(tr.rot), mv_shift=npy(tr.shift),
+               mv_out_pos=npy(torch.stack(mp)), mv_out_frames=npy(torch.stack(mf)))
+    np.savez(os.path.join(OUT, "se3.npz"), **out)
+    print("se3.npz", os.path.getsize(os.path.join(OUT, "se3.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "se3":
+    se3_golden()
