@@ -30,6 +30,7 @@ SYMBOLS = (
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
+    "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum",
 )
 
 
@@ -58,6 +59,7 @@ def lib():
                 l.so3x_error_string.restype = C.c_char_p
                 l.so3x_mlp_workspace_bytes.restype = C.c_size_t
                 l.so3x_p_sample_workspace_bytes.restype = C.c_size_t
+                l.so3x_kernel_sum_workspace_bytes.restype = C.c_size_t
                 if l.so3x_abi_version() != 1:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
@@ -507,3 +509,22 @@ def rigid_move(rot, shift, pos, frames=None):
         _check(lib().so3x_rigid_move(_stream(rot), _ptr(rot), _ptr(shift), _ptr(pos), _ptr(fr), _ptr(out_pos), _ptr(out_fr),
                                      _i64(S), _i64(L)), "rigid_move")
     return out_pos, out_fr
+
+
+# ----------------------------------------------------------------------------- statistics
+KERNEL_GAUSSIAN = 0
+KERNEL_COSINE = 1
+
+
+def kernel_sum(X, Y, kind=KERNEL_GAUSSIAN, scale=1.0):
+    """scale * sum_ij k(X_i, Y_j) as a 0-d tensor (no host sync)."""
+    X = _rot_in(X, "X").reshape(-1, 3, 3)
+    Y = _rot_in(Y, "Y").reshape(-1, 3, 3)
+    nx, ny = X.shape[0], Y.shape[0]
+    out = torch.empty(1, dtype=torch.float32, device=X.device)
+    nb = lib().so3x_kernel_sum_workspace_bytes(_i64(nx), _i64(ny))
+    ws = _workspace(X.device, nb)
+    with _Guard(X):
+        _check(lib().so3x_kernel_sum(_stream(X), _ptr(X), _i64(nx), _ptr(Y), _i64(ny), C.c_int(int(kind)),
+                                     C.c_float(float(scale)), _ptr(out), _ptr(ws), C.c_size_t(ws.numel())), "kernel_sum")
+    return out[0]

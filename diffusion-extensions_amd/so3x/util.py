@@ -9,7 +9,8 @@ import torch
 from . import backend as _b
 
 __all__ = ["skew2vec", "vec2skew", "orthogonalise", "log_rmat", "aa_to_rmat", "rmat_to_aa", "quat_to_rmat",
-           "rmat_dist", "so3_lerp", "so3_scale", "cycle"]
+           "rmat_dist", "so3_lerp", "so3_scale", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
+           "MMD", "Ker_2samp_test", "Ker_2samp_log_prob"]
 
 
 def skew2vec(skew: torch.Tensor) -> torch.Tensor:
@@ -72,3 +73,57 @@ def cycle(iterable):
     while True:
         for x in iterable:
             yield x
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel two-sample statistics (reference util.py:110-151, 254-312)
+# ---------------------------------------------------------------------------------------------
+def rmat_cosine_dist(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
+    """1 - cos(angle(m2^T m1)) (reference util.py:110-125); trace of a 3x3 product: plain indexing/arithmetic."""
+    tra = (m2 * m1).sum(dim=(-1, -2))  # tr(m2^T m1) = sum_ij m2_ij m1_ij
+    return 1 - (tra - 1) / 2
+
+
+def rmat_gaussian_kernel(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
+    """exp(-rmat_dist(m1, m2)), broadcasting like the reference (util.py:128-134)."""
+    return torch.exp(-rmat_dist(m1, m2))
+
+
+def rmat_cosine_kernel(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
+    """(tr(m2^T m1) - 1)/2 (reference util.py:136-151)"""
+    return ((m2 * m1).sum(dim=(-1, -2)) - 1) / 2
+
+
+_FUSED_KERNELS = {rmat_gaussian_kernel: _b.KERNEL_GAUSSIAN, rmat_cosine_kernel: _b.KERNEL_COSINE}
+
+
+def MMD(X: torch.Tensor, Y: torch.Tensor, kernel, chunksize=None):
+    """Maximum mean discrepancy with the reference's estimator (util.py:254-286).  For the two rotation
+    kernels above, the three O(N^2) pair sums run in one fused HIP kernel each (no [N,N,3,3] intermediate, so
+    `chunksize` is unnecessary and ignored); any other kernel callable goes through the reference's broadcast."""
+    l_X, l_Y = len(X), len(Y)
+    kind = _FUSED_KERNELS.get(kernel)
+    if kind is not None:
+        return (_b.kernel_sum(X, X, kind, 1.0 / (l_X ** 2)) + _b.kernel_sum(Y, Y, kind, 1.0 / (l_Y ** 2))
+                - _b.kernel_sum(X, Y, kind, 2.0 / (l_X * l_Y)))
+    X_sum = kernel(X.unsqueeze(0), X.unsqueeze(1)).sum(dim=(0, 1))
+    Y_sum = kernel(Y.unsqueeze(0), Y.unsqueeze(1)).sum(dim=(0, 1))
+    XY_sum = kernel(X.unsqueeze(0), Y.unsqueeze(1)).sum(dim=(0, 1))
+    return (1 / (l_X ** 2)) * X_sum + (1 / (l_Y ** 2)) * Y_sum - (2 / (l_X * l_Y)) * XY_sum
+
+
+def Ker_2samp_test(X, Y, kernel, alpha=0.05, max_ker=1, chunksize=None):
+    """Kernel two-sample test (reference util.py:289-299): True = same distribution not rejected."""
+    from math import log
+    m, n = len(X), len(Y)
+    assert m == n, "Requires equal amount of samples from X and Y"
+    mmd = MMD(X, Y, kernel, chunksize=chunksize).item()
+    return mmd < (2 * max_ker / m) ** 0.5 * (1 + (2 * log(1 / alpha)) ** 0.5)
+
+
+def Ker_2samp_log_prob(X, Y, kernel, max_ker=1, chunksize=None):
+    """log p-value bound of the test (reference util.py:301-312)"""
+    m, n = len(X), len(Y)
+    assert m == n, "Requires equal amount of samples from X and Y"
+    mmd = MMD(X, Y, kernel, chunksize=chunksize).item()
+    return -((((mmd / ((2 * max_ker / m) ** 0.5)) - 1) ** 2) / 2)

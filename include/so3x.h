@@ -198,6 +198,16 @@ int so3x_se3_p_noise(so3x_stream_t s, const float* trap_row, float sigma, float 
 int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const float* pos,
                     const float* frames, float* out_pos, float* out_frames, int64_t S, int64_t L);
 
+/* ------------------------------------------------------- sample-quality statistics */
+/* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):
+ *   out[0] = scale * sum_{i < nx, j < ny} k(X_i, Y_j),
+ * kind 0: rmat_gaussian_kernel = exp(-rmat_dist)  (util.py:128-134);
+ * kind 1: rmat_cosine_kernel = (tr(Y_j^T X_i) - 1)/2  (util.py:136-151).
+ * Deterministic (per-block double partial sums, fixed-order final sum). */
+size_t so3x_kernel_sum_workspace_bytes(int64_t nx, int64_t ny);
+int so3x_kernel_sum(so3x_stream_t s, const float* X, int64_t nx, const float* Y, int64_t ny, int kind,
+                    float scale, float* out, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -561,3 +561,41 @@ def test_full_size_chain_properties(mods, net):
     assert not torch.isnan(x).any()
     assert float((x @ x.transpose(-1, -2) - torch.eye(3, device=DEV)).abs().max()) < 1e-4
     assert float((torch.linalg.det(x) - 1).abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------ statistics
+def test_mmd_kernel_sums_vs_oracle_and_reference_samples(mods, golden):
+    U = mods["util"]
+    ref = golden["chain_samples_trained"]["x_final"]
+    rng_ = np.random.default_rng(0)
+    uni = O.quat_to_rmat(rng_.standard_normal((1500, 4)).astype(np.float32))
+    X, Y = dev(ref[:2000]), dev(uni)
+    mine = float(U.MMD(X, Y, U.rmat_gaussian_kernel))
+    want = O.MMD(ref[:2000], uni)
+    assert abs(mine - want) < 2e-6 + 1e-5 * abs(want), (mine, want)
+    # the generic (broadcast) path of MMD with a user kernel agrees with the fused one
+    Xs, Ys = X[:300], Y[:257]
+    fused = float(U.MMD(Xs, Ys, U.rmat_gaussian_kernel))
+    generic = float(U.MMD(Xs, Ys, lambda a, b: U.rmat_gaussian_kernel(a, b)))
+    assert abs(fused - generic) < 1e-5
+    cos_f = float(U.MMD(Xs, Ys, U.rmat_cosine_kernel))
+    cos_g = float(U.MMD(Xs, Ys, lambda a, b: U.rmat_cosine_kernel(a, b)))
+    assert abs(cos_f - cos_g) < 1e-5
+    assert U.Ker_2samp_test(dev(ref[:2048]), dev(ref[2048:]), U.rmat_gaussian_kernel)
+    assert not U.Ker_2samp_test(dev(ref[:1500]), Y, U.rmat_gaussian_kernel)
+    # bingham_test.py-sized problem (20,000 x 20,000 pairs) in one launch: identical populations give MMD ~ 0
+    big = mods["B"].quat_to_rmat(torch.randn(20000, 4, device=DEV))
+    assert abs(float(U.MMD(big, big, U.rmat_gaussian_kernel))) < 1e-6
+
+
+def test_mmd_statistics_vs_reference_values(mods, golden):
+    U = mods["util"]
+    g = golden["stats"]
+    X, Y = dev(g["X"]), dev(g["Y"])
+    assert abs(float(U.MMD(X, Y, U.rmat_gaussian_kernel)) - float(g["mmd_gauss"])) < 5e-6
+    assert abs(float(U.MMD(X, Y, U.rmat_cosine_kernel)) - float(g["mmd_cos"])) < 2e-5
+    assert maxabs(host(U.rmat_gaussian_kernel(X[:50].unsqueeze(0), Y[:40].unsqueeze(1))), g["kern_gauss_xy"]) < 5e-6
+    assert maxabs(host(U.rmat_cosine_dist(X[:100], Y[:100])), g["cos_dist"]) < 2e-6
+    assert U.Ker_2samp_test(X[:150], X[150:], U.rmat_gaussian_kernel) == bool(g["test_same"])
+    assert U.Ker_2samp_test(X[:257], Y, U.rmat_gaussian_kernel) == bool(g["test_diff"])
+    assert abs(U.Ker_2samp_log_prob(X[:257], Y, U.rmat_gaussian_kernel) - float(g["logp_diff"])) < 1e-3

@@ -593,3 +593,30 @@ def se3_golden():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "se3":
     se3_golden()
+
+
+def stats_golden():
+    """util.MMD / kernels / Ker_2samp_test values computed by the reference (util.py:110-151, 254-312)."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import util as rutil
+    g = torch.Generator().manual_seed(8)
+    X = rutil.quat_to_rmat(torch.randn(300, 4, generator=g))
+    Y = rutil.aa_to_rmat(torch.randn(257, 3, generator=g), torch.rand(257, 1, generator=g) * 0.8)
+    out = {"X": npy(X), "Y": npy(Y)}
+    out["mmd_gauss"] = npy(rutil.MMD(X, Y, rutil.rmat_gaussian_kernel))
+    out["mmd_gauss_chunked"] = npy(rutil.MMD(X, Y, rutil.rmat_gaussian_kernel, chunksize=100))
+    out["mmd_cos"] = npy(rutil.MMD(X, Y, rutil.rmat_cosine_kernel))
+    out["kern_gauss_xy"] = npy(rutil.rmat_gaussian_kernel(X[:50].unsqueeze(0), Y[:40].unsqueeze(1)))
+    out["cos_dist"] = npy(rutil.rmat_cosine_dist(X[:100], Y[:100]))
+    out["test_same"] = np.bool_(rutil.Ker_2samp_test(X[:150], X[150:], rutil.rmat_gaussian_kernel))
+    out["test_diff"] = np.bool_(rutil.Ker_2samp_test(X[:257], Y, rutil.rmat_gaussian_kernel))
+    out["logp_diff"] = np.float64(rutil.Ker_2samp_log_prob(X[:257], Y, rutil.rmat_gaussian_kernel))
+    np.savez(os.path.join(OUT, "stats.npz"), **out)
+    print({k: (v if np.ndim(v) == 0 else v.shape) for k, v in out.items() if k not in ("X", "Y")})
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stats":
+    stats_golden()
