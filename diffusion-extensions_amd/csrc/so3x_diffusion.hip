@@ -124,12 +124,14 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     const int64_t idc = live ? idx : n - 1;
     float R[9];
     load_rot9(x_in, idc, R);
+    Quat q = quat_from_rmat(R);  // the state lives as a unit quaternion for the n_steps of this launch
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
       const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t];
       const float c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
       // ---- score network: v = RotPredict(x, t)  (diffusion.py:309)
+      if (s > 0) rmat_from_quat(q, R);
       const float* beff = beff_tab + (size_t)t * 96;
       float va[3], vb[3], v[3];
       forward_tile<PREC, CHAIN, 1>(lds, R, beff, 0, nullptr, va, lane);  // tile A = samples 0..31 of the chunk
@@ -139,33 +141,38 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         const float o = __shfl_xor(vb[j], 32);  // tile B results sit in lanes 0..31, owners are lanes 32..63
         v[j] = h ? o : va[j];
       }
-      // ---- posterior mean (diffusion.py:310-311)
-      float xh[9], mean[9];
-      p_mean_one(R, v, a, b, c1, c2, xh, mean);
-      if (t == 0) {  // diffusion.py:320-321 -- no noise at t == 0
-#pragma unroll
-        for (int j = 0; j < 9; j++) R[j] = mean[j];
-      } else {
-        float ax[3], u;
+      // ---- posterior mean (diffusion.py:291-302) in quaternion form:
+      //   x0hat = exp(a log x) exp(b v)^T,   mean = exp(c1 log x0hat) exp(c2 log x)
+      float ax[3], axh[3], vax[3];
+      const float th = quat_axis_angle(q, ax);
+      const float vn = fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      const float vinv = vn > 0.f ? frcp(vn) : 0.f;
+      vax[0] = v[0] * vinv; vax[1] = v[1] * vinv; vax[2] = v[2] * vinv;
+      const Quat qh = qmul(quat_axis_angle_exp(ax, a * th), quat_axis_angle_exp(vax, -b * vn));
+      const float thh = quat_axis_angle(qh, axh);
+      q = qmul(quat_axis_angle_exp(axh, c1 * thh), quat_axis_angle_exp(ax, c2 * th));
+      if (t != 0) {  // diffusion.py:320-326 -- no noise at t == 0
+        float nax[3], u;
         if (axes) {
           float a0 = axes[idc * 3], a1 = axes[idc * 3 + 1], a2 = axes[idc * 3 + 2];
           float nrm = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
-          ax[0] = a0 / nrm; ax[1] = a1 / nrm; ax[2] = a2 / nrm;
-          float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-          ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
+          nax[0] = a0 / nrm; nax[1] = a1 / nrm; nax[2] = a2 / nrm;
+          float n2 = sqrtf(nax[0] * nax[0] + nax[1] * nax[1] + nax[2] * nax[2]);
+          nax[0] /= n2; nax[1] /= n2; nax[2] /= n2;
           u = unif[idc];
         } else {
           Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset + (uint64_t)t);
-          unit_axis(r.x, r.y, ax);
+          unit_axis(r.x, r.y, nax);
           u = u01(r.z);
         }
         const float* row = trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
-        const float ang = igso3_angle(row, row, SO3X_KNOTS_DATA, u);
-        float nz[9];
-        exp_axis_angle(ax, ang, nz);
-        mul33(mean, nz, R);                            // model_mean @ sample, :326
+        const float ang = axes ? igso3_angle<true>(row, row, SO3X_KNOTS_DATA, u) : igso3_angle<false>(row, row, SO3X_KNOTS_DATA, u);
+        q = qmul(q, quat_axis_angle_exp(nax, ang));   // model_mean @ sample, :326
       }
+      // no per-step renormalisation: q is rebuilt from (axis, angle) pairs every step, so its norm error is
+      // three products' rounding (~3e-7) however long the chain is
     }
+    rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
   }
 }

@@ -192,6 +192,10 @@ __device__ __forceinline__ void unit_axis(uint32_t a, uint32_t b, float* ax) {
 // Inverse-CDF angle, distributions.py:39-49, on one CDF row (999 fp32, global or LDS)
 // and the 1000 knot angles.  wrow = the row the interpolation weight is gathered from
 // (== row unless the column-0 quirk is on).
+// EXACT = true keeps the reference's IEEE division in the interpolation weight (bit-identical angles on the
+// reference's own CDF rows, used by every explicit-draw / parity path); false = 1-ulp reciprocal (in-kernel
+// Philox paths, where no bitwise comparison with the reference is possible anyway).
+template <bool EXACT = true>
 __device__ __forceinline__ float igso3_angle(const float* row, const float* wrow, const float* knots, float u) {
   int lo = 0, hi = 999;  // idx1 = #{k : row[k] <= u}  (row is non-decreasing)
 #pragma unroll 1
@@ -203,10 +207,64 @@ __device__ __forceinline__ float igso3_angle(const float* row, const float* wrow
   int idx0 = idx1 - 1 < 0 ? 0 : idx1 - 1;
   float ts = wrow[idx0], te = wrow[idx1];
   float df = fmaxf(te - ts, 1e-6f);
-  float wt = fminf(fmaxf((u - ts) / df, 0.0f), 1.0f);  // IEEE division: keeps the knot interpolation bit-faithful
+  float wt = fminf(fmaxf(EXACT ? (u - ts) / df : (u - ts) * frcp(df), 0.0f), 1.0f);
   float a0 = knots[idx0 + 1], a1 = knots[idx1 + 1];
   float dl = a1 - a0;
   return wt < 0.5f ? a0 + wt * dl : a1 - dl * (1.0f - wt);  // torch.lerp's two-sided form
+}
+
+// ---------------------------------------------------------------- unit quaternions
+// The chain-resident sampler keeps its state as a unit quaternion (w, x, y, z) between the steps of one launch:
+// composition is 16 multiplies instead of 27, exp is a half-angle sincos, log is one atan2 with no 1/(pi - w)
+// conditioning problem, and the matrix is only formed as the network's input (quat_to_rmat, util.py:222-252).
+// hat() of the reference (util.py:87-92) is the standard cross-product matrix, so exp(hat(n * th)) <-> (cos th/2, n sin th/2).
+struct Quat { float w, x, y, z; };
+
+__device__ __forceinline__ Quat qmul(const Quat& a, const Quat& b) {  // R(a) R(b) = R(a (x) b)
+  return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Quat qnormalize(const Quat& q) {
+  const float r = frsq(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return Quat{q.w * r, q.x * r, q.y * r, q.z * r};
+}
+__device__ __forceinline__ void rmat_from_quat(const Quat& q, float* o) {  // unit q
+  const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z, xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+  const float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+  o[0] = 1.f - 2.f * (yy + zz); o[1] = 2.f * (xy - wz);       o[2] = 2.f * (xz + wy);
+  o[3] = 2.f * (xy + wz);       o[4] = 1.f - 2.f * (xx + zz); o[5] = 2.f * (yz - wx);
+  o[6] = 2.f * (xz - wy);       o[7] = 2.f * (yz + wx);       o[8] = 1.f - 2.f * (xx + yy);
+}
+__device__ __forceinline__ Quat quat_from_rmat(const float* R) {  // Shepperd's branch choice, then normalised
+  const float tr = R[0] + R[4] + R[8];
+  Quat q;
+  if (tr > 0.f) {
+    const float s = 2.f * sqrtf(tr + 1.f);
+    q = Quat{0.25f * s, (R[7] - R[5]) / s, (R[2] - R[6]) / s, (R[3] - R[1]) / s};
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const float s = 2.f * sqrtf(1.f + R[0] - R[4] - R[8]);
+    q = Quat{(R[7] - R[5]) / s, 0.25f * s, (R[1] + R[3]) / s, (R[2] + R[6]) / s};
+  } else if (R[4] > R[8]) {
+    const float s = 2.f * sqrtf(1.f + R[4] - R[0] - R[8]);
+    q = Quat{(R[2] - R[6]) / s, (R[1] + R[3]) / s, 0.25f * s, (R[5] + R[7]) / s};
+  } else {
+    const float s = 2.f * sqrtf(1.f + R[8] - R[0] - R[4]);
+    q = Quat{(R[3] - R[1]) / s, (R[2] + R[6]) / s, (R[5] + R[7]) / s, 0.25f * s};
+  }
+  return qnormalize(q);
+}
+// rotation angle in [0, pi] and unit axis (zero vector at the identity, where the angle is 0 anyway)
+__device__ __forceinline__ float quat_axis_angle(const Quat& q, float* ax) {
+  const float sg = q.w < 0.f ? -1.f : 1.f;  // q and -q are the same rotation: take w >= 0
+  const float n = fsqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+  const float inv = n > 0.f ? sg * frcp(n) : 0.f;
+  ax[0] = q.x * inv; ax[1] = q.y * inv; ax[2] = q.z * inv;
+  return 2.f * atan2_pos(n, sg * q.w);
+}
+__device__ __forceinline__ Quat quat_axis_angle_exp(const float* ax, float ang) {
+  float sn, cs;
+  sincos_cw(0.5f * ang, &sn, &cs);
+  return Quat{cs, sn * ax[0], sn * ax[1], sn * ax[2]};
 }
 
 // ---------------------------------------------------------------- reverse-step mean
