@@ -109,3 +109,56 @@ int so3x_kernel_sum(so3x_stream_t s, const float* X, int64_t nx, const float* Y,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// F.mse_loss of p_losses (diffusion.py:357) and its gradient: loss = mean((a - b)^2) over all elements.
+// Two-stage deterministic reduction (per-block double partials, fixed-order final sum).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                     double* __restrict__ partial) {
+  __shared__ double wsum[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    acc += (double)(d * d);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// grad_a = (a - b) * 2/n * gscale[0]   (gscale = the upstream gradient of the scalar loss, device-resident: no sync)
+__global__ void __launch_bounds__(256) k_mse_grad(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                  const float* __restrict__ gscale, float* __restrict__ ga) {
+  const float k = 2.0f / (float)n * (gscale ? gscale[0] : 1.0f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) ga[i] = (a[i] - b[i]) * k;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t so3x_mse_workspace_bytes(int64_t n) { (void)n; return 1024 * sizeof(double); }
+
+int so3x_mse_loss(so3x_stream_t s, const float* a, const float* b, int64_t n, float* loss, void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || !a || !b || !loss) return SO3X_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < so3x_mse_workspace_bytes(n)) return SO3X_ERR_WORKSPACE;
+  const int64_t want = (n + 255) / 256;
+  const int grid = (int)(want < 1024 ? want : 1024);
+  hipLaunchKernelGGL(k_mse_partial, dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, n, reinterpret_cast<double*>(workspace));
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)s, (const double*)workspace, grid, 1.0 / (double)n, loss);
+  return check_launch();
+}
+
+int so3x_mse_grad(so3x_stream_t s, const float* a, const float* b, int64_t n, const float* gscale, float* grad_a) {
+  if (n <= 0 || !a || !b || !grad_a) return SO3X_ERR_INVALID_ARG;
+  const int64_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_mse_grad, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)s, a, b, n, gscale, grad_a);
+  return check_launch();
+}
+
+}  // extern "C"

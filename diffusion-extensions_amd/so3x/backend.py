@@ -30,7 +30,7 @@ SYMBOLS = (
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
-    "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum",
+    "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
 )
 
 
@@ -60,6 +60,7 @@ def lib():
                 l.so3x_mlp_workspace_bytes.restype = C.c_size_t
                 l.so3x_p_sample_workspace_bytes.restype = C.c_size_t
                 l.so3x_kernel_sum_workspace_bytes.restype = C.c_size_t
+                l.so3x_mse_workspace_bytes.restype = C.c_size_t
                 if l.so3x_abi_version() != 1:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
@@ -528,3 +529,48 @@ def kernel_sum(X, Y, kind=KERNEL_GAUSSIAN, scale=1.0):
         _check(lib().so3x_kernel_sum(_stream(X), _ptr(X), _i64(nx), _ptr(Y), _i64(ny), C.c_int(int(kind)),
                                      C.c_float(float(scale)), _ptr(out), _ptr(ws), C.c_size_t(ws.numel())), "kernel_sum")
     return out[0]
+
+
+class _MSELoss(torch.autograd.Function):
+    """mean((a - b)^2) with the gradient wrt `a` (the network output); `b` (the target) carries none."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _dev(a, "input")
+        b = _dev(b, "target")
+        if a.shape != b.shape:
+            raise ValueError("so3x: mse_loss needs equal shapes")
+        ctx.save_for_backward(a, b)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        ws = _workspace_small(a.device, lib().so3x_mse_workspace_bytes(_i64(a.numel())))
+        with _Guard(a):
+            _check(lib().so3x_mse_loss(_stream(a), _ptr(a), _ptr(b), _i64(a.numel()), _ptr(loss), _ptr(ws),
+                                       C.c_size_t(ws.numel())), "mse_loss")
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        gs = _dev(g.reshape(1), "grad")
+        with _Guard(a):
+            _check(lib().so3x_mse_grad(_stream(a), _ptr(a), _ptr(b), _i64(a.numel()), _ptr(gs), _ptr(ga)), "mse_grad")
+        return ga, None
+
+
+_ws_small = {}
+
+
+def _workspace_small(device, nbytes):
+    """separate small scratch so the loss reduction never aliases the MLP workspace"""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_small.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_small[key] = buf
+    return buf
+
+
+def mse_loss(a, b):
+    """F.mse_loss(a, b) (reference diffusion.py:357) as a differentiable 0-d tensor."""
+    return _MSELoss.apply(a, b)

@@ -13,7 +13,6 @@ batched-eps sampler (`quirk_col0`), IGSO3(eps=1) chain initialisation.
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import backend as _b
 from . import rng as _rng
@@ -174,7 +173,7 @@ class SO3Diffusion(nn.Module):
         net = self._fused_net()
         # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
         x_recon = net(x_noisy, t, t_table=self.num_timesteps) if net is not None else self.denoise_fn(x_noisy, t)
-        return F.mse_loss(x_recon, target)
+        return _b.mse_loss(x_recon, target)
 
     def forward(self, x, *args, **kwargs):
         b = x.shape[0]

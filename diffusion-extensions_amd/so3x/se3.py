@@ -9,7 +9,6 @@ from collections import namedtuple
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import backend as _b
 from . import rng as _rng
@@ -194,7 +193,7 @@ class SE3Diffusion(nn.Module):
             unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
             index_base=self.index_base)
         x_recon = self.denoise_fn(AffineT(xt_rot, xt_shift), t)
-        return F.mse_loss(x_recon.shift_g, tg_shift) + F.mse_loss(x_recon.rot_g, tg_rot)
+        return _b.mse_loss(x_recon.shift_g, tg_shift) + _b.mse_loss(x_recon.rot_g, tg_rot)
 
     def forward(self, x: AffineT, *args, **kwargs):
         b = len(x)

@@ -208,6 +208,14 @@ size_t so3x_kernel_sum_workspace_bytes(int64_t nx, int64_t ny);
 int so3x_kernel_sum(so3x_stream_t s, const float* X, int64_t nx, const float* Y, int64_t ny, int kind,
                     float scale, float* out, void* workspace, size_t workspace_bytes);
 
+/* F.mse_loss of p_losses (diffusion.py:357): loss[0] = mean((a - b)^2) over n elements
+ * (deterministic two-stage reduction), and its gradient grad_a = (a - b) * 2/n * gscale[0]
+ * (gscale = device-resident upstream gradient of the scalar loss, NULL = 1). */
+size_t so3x_mse_workspace_bytes(int64_t n);
+int so3x_mse_loss(so3x_stream_t s, const float* a, const float* b, int64_t n, float* loss, void* workspace,
+                  size_t workspace_bytes);
+int so3x_mse_grad(so3x_stream_t s, const float* a, const float* b, int64_t n, const float* gscale, float* grad_a);
+
 #ifdef __cplusplus
 }
 #endif
