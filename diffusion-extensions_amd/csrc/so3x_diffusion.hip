@@ -19,7 +19,7 @@ enum { S_SQRT_AC = 3, S_SQRT_1MAC = 4, S_RECIP = 6, S_RECIPM1 = 7, S_COEF1 = 10,
 // A12: noise draw + forward noising + regression target, one pass, 84 B/sample algorithmic
 // (36 x0 in, 36 x_t + 12 target out; +8 for t).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 8)
 k_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q, const float* __restrict__ x0,
                   const int64_t* __restrict__ t, int quirk_col0, const float* __restrict__ noise_in,
                   const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,

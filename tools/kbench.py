@@ -63,6 +63,17 @@ def main():
         tt = torch.randint(0, 1000, (n,), device=dev, generator=g)
         ms = timeit(lambda: B.se3_q_sample_target(proc3._sched, tq, 75.0, xr, xs, tt, seed=1))
         print(json.dumps({"k": "se3_q_sample_target", "n": n, "ms": ms, "GBs": (84 + 48 + 8) * n / ms / 1e6}))
+    if "qsample" in which:
+        from so3x.so3_train import RotPredict as _RP
+        from so3x.diffusion import SO3Diffusion as _SD
+        pr = _SD(_RP(out_type="skewvec"), timesteps=1000).to(dev)
+        tq, _ = pr._tables()
+        for lg in (19, 22):
+            n = 1 << lg
+            x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+            tt = torch.randint(0, 1000, (n,), device=dev, generator=g)
+            ms = timeit(lambda: B.q_sample_target(pr._sched, tq, x0, tt, seed=1))
+            print(json.dumps({"k": "q_sample_target", "n": n, "ms": ms, "GBs": 92 * n / ms / 1e6, "frac8T": 92 * n / ms / 1e6 / 8000}))
     if "chain" in which or "train" in which:
         torch.manual_seed(0)
         net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
