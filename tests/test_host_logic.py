@@ -170,3 +170,18 @@ def test_gloo_world_size_2_gradient_allreduce(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "OK" in o
+
+
+def test_flat_name_shims_resolve_like_the_reference_layout(tmp_path):
+    """`from diffusion import SO3Diffusion` etc. (the reference's flat module names) resolve through compat/."""
+    code = ("from diffusion import SO3Diffusion, SE3Diffusion\n"
+            "from distributions import IsotropicGaussianSO3, IGSO3xR3\n"
+            "from so3_train import RotPredict\n"
+            "from models import SinusoidalPosEmb\n"
+            "from util import *\n"
+            "assert callable(quat_to_rmat) and callable(so3_scale) and callable(MMD) and AffineT is not None\n"
+            "p = SO3Diffusion(RotPredict(out_type='skewvec'), timesteps=10)\n"
+            "print('OK', p.num_timesteps)\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(PKG, "compat"), PKG]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=180)
+    assert r.returncode == 0 and "OK 10" in r.stdout, r.stderr
