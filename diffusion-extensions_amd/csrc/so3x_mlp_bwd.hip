@@ -429,6 +429,305 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused backward (bf16, bounded timesteps): K1 and K2 in ONE kernel, no HBM stash.
+//   * a block = 4 waves = 128 samples per round; every wave recomputes the forward of its 32-sample tile
+//     (pre-activations in registers) and walks the layers backwards;
+//   * per layer, each wave drops its dZ_l and H_l tiles into its own 12 KB LDS image
+//     [32 samples][192 features] with 8-byte stores straight from the accumulator layout (4 consecutive
+//     feature rows per store), the block synchronises, and the 39 dW tiles -- owned 10 / 10 / 10 / 9 by
+//     the four waves, accumulators persistent in registers for the whole launch -- are updated with
+//     v_mfma_f32_32x32x16_bf16 whose operands come from ds_read_b64_tr_b16 (hardware transposed read:
+//     the contraction index of dW = dZ H^T is the SAMPLE, which is the lane index of the producers);
+//   * the image is XOR-swizzled so that the 8-byte stores (16-lane groups, 32-dword banking) and the
+//     transposed reads (32-lane halves, 64-dword banking) are both bank-conflict free:
+//         chunk' = chunk ^ ((row & 7) | ((((row >> 1) ^ (row >> 3)) & 1) << 3)),  8-byte chunks, 384-byte rows.
+// LDS: forward image 53 KB + transposed image 48 KB + 4 x 12 KB = 149 KB (one block per CU).
+// ---------------------------------------------------------------------------------------
+constexpr int FIMG_COLS = 192;                 // dZ block [0, 96), H block [96, 192)
+constexpr int FIMG_PITCH = FIMG_COLS * 2;      // bytes per sample row
+constexpr int FIMG_BYTES = 32 * FIMG_PITCH;    // 12,288 per (wave, layer)
+
+__device__ __forceinline__ int fimg_off(int row, int col /*multiple of 4*/) {
+  int ch = col >> 2;
+  ch ^= (row & 7) | ((((row >> 1) ^ (row >> 3)) & 1) << 3);
+  return row * FIMG_PITCH + ch * 8;
+}
+// Addressing is split into a per-lane part computed once per round (a handful of VGPRs) and compile-time
+// constants that fold into the DS instructions' offset field; the round loop makes the per-lane parts opaque
+// (empty asm) so the compiler does not hoist ~800 loop-invariant address registers and spill them.
+struct FimgStoreLane { int rowbase, swz8; };  // rowbase = row * pitch; swz8 = 8 * swizzle(row)
+__device__ __forceinline__ FimgStoreLane fimg_store_lane(int row) {
+  return FimgStoreLane{row * FIMG_PITCH, 8 * ((row & 7) | ((((row >> 1) ^ (row >> 3)) & 1) << 3))};
+}
+// chunk index `ch` (= column / 4) is a compile-time constant plus the lane-half bit h in bit 0
+__device__ __forceinline__ void fimg_store4(char* img, const FimgStoreLane& L, int ch, float a, float b, float c, float d) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  *reinterpret_cast<bf16x4*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = v;
+}
+// transposed-read lane offsets: [part (rows +0 / +4)][cbit (bit 3 of the tile's first chunk)]
+struct FimgReadLane { int off[2][2]; };
+__device__ __forceinline__ FimgReadLane fimg_read_lane(int lane) {
+  const int h = lane >> 5, l32 = lane & 31, G = l32 >> 4, q = (l32 & 15) >> 2, pp = l32 & 3;
+  FimgReadLane L;
+#pragma unroll
+  for (int part = 0; part < 2; part++)
+#pragma unroll
+    for (int cbit = 0; cbit < 2; cbit++) {
+      const int row = 8 * h + q + 4 * part;                                  // row within a 16-sample k-step
+      const int sw = ((q + 4 * part) & 7) | ((((q >> 1) ^ h) & 1) << 3);       // swizzle(16 ks + row): ks drops out
+      L.off[part][cbit] = row * FIMG_PITCH + 8 * ((8 * cbit + 4 * G + pp) ^ sw);
+    }
+  return L;
+}
+// MFMA operand (8 bf16 = samples 16 ks + 8 h + 0..7 of feature cb + (lane & 31)); cb in {0,32,64,96,128,160}
+__device__ __forceinline__ bf16x8 fimg_frag(const char* img, const FimgReadLane& L, int cb, int ks) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const int chb = cb >> 2, cbit = (chb >> 3) & 1;
+  const int konst = 16 * ks * FIMG_PITCH + (chb & ~15) * 8;                  // folds into the instruction offset
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[0][cbit]));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[1][cbit]));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// pre-activations of the fused kernel are parked as packed f16 (66 -> 17 VGPRs per layer would be 33 fp32):
+// 11 significant bits on O(1..10) values, well inside the bf16 path's tolerance, and it is what lets the
+// 160 persistent dW accumulator registers + 4 layers of Z fit the 512-register budget without scratch.
+struct Z33h {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 p[17];
+  __device__ __forceinline__ float get(int q) const { return (float)p[q >> 1][q & 1]; }
+};
+__device__ __forceinline__ void keep_h(const f32x16 (&acc)[3], Z33h& z) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    z.p[r >> 1] = Z33h::h2{(_Float16)acc[0][r], (_Float16)acc[0][r + 1]};
+    z.p[8 + (r >> 1)] = Z33h::h2{(_Float16)acc[1][r], (_Float16)acc[1][r + 1]};
+  }
+  z.p[16] = Z33h::h2{(_Float16)acc[2][0], (_Float16)0.0f};
+}
+template <int PREC>
+__device__ __forceinline__ void activate_zh(const Z33h& z, Tile<PREC>& out, int h) {
+  f32x16 a[3];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { a[0][r] = z.get(r); a[1][r] = z.get(16 + r); a[2][r] = 0.0f; }
+  a[2][0] = z.get(32);
+  activate<PREC>(a, out, h);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L, int ch, uint32_t lo, uint32_t hi) {
+  *reinterpret_cast<uint2*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = uint2{lo, hi};
+}
+// one pass over a layer's pre-activations: packed H = silu(Z) * lv (with the constant-one row in the upper half of
+// tile 2) and the derivative silu'(Z) in fp32
+template <int PREC>
+__device__ __forceinline__ void silu_pass(const Z33h& z, float lv, int h, uint32_t (&ph)[17], float (&dv)[33]) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    float a0, a1;
+    silu_grad<PREC>(z.get(2 * r), &a0, &dv[2 * r]);
+    silu_grad<PREC>(z.get(2 * r + 1), &a1, &dv[2 * r + 1]);
+    ph[r] = pack_bf16x2(a0 * lv, a1 * lv);
+  }
+  float a;
+  silu_grad<PREC>(z.get(32), &a, &dv[32]);
+  ph[16] = pack_bf16x2(h ? lv : a * lv, 0.0f);
+}
+// dH = W^T dZ with dZ given as packed bf16 pairs (the MFMA operand bits as they are)
+template <int PREC, int L>
+__device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const uint32_t (&pdz)[17], f32x16 (&dh)[3], int lane) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wt);
+  constexpr int KS = L < 4 ? 5 : 1;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 b[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    const u32x4 v = ks < 4 ? u32x4{pdz[4 * ks], pdz[4 * ks + 1], pdz[4 * ks + 2], pdz[4 * ks + 3]} : u32x4{pdz[16], 0u, 0u, 0u};
+    b[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+#pragma unroll
+  for (int to = 0; to < 3; to++) {
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 a = zero16<PREC>();
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) a = mfma_bf16(w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane], b[ks], a);
+    dh[to] = a;
+  }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(512, 2)
+k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
+            const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
+            int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n) {
+  // Wave specialisation: waves 0-3 ("chain" waves) recompute the forward and run the dZ chain for one 32-sample
+  // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators) and only consume
+  // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
+  // SiLU-derivative VALU work, and neither role needs more than 256 registers.
+  static_assert(PREC == SO3X_PREC_BF16, "fused backward is the bf16 path");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int VAR = GATHER;
+  constexpr int FB = frag_bytes<PREC>();
+  constexpr int IMG = image_bytes<PREC, VAR>();
+  constexpr int WTB = wt_bytes<PREC>();
+  char* wt_lds = lds + IMG;
+  char* fimg_all = lds + IMG + WTB;
+  load_image(gimg, lds, IMG);
+  load_image(gwt, wt_lds, WTB);
+  for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (n + 31) / 32;
+  const int64_t nchain = (int64_t)gridDim.x * 4;
+  const int64_t rounds = (ntiles + nchain - 1) / nchain;  // uniform trip count: the barriers are block-wide
+  if (wid < 4) {
+    // =============================== chain waves ===============================
+    char* my_img = fimg_all + wid * FIMG_BYTES;
+    FimgStoreLane SL = fimg_store_lane(col);
+    for (int64_t rd = 0; rd < rounds; rd++) {
+      asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per round: no hoisting of the ~90 store addresses
+      const int64_t tile = rd * nchain + (int64_t)blockIdx.x * 4 + wid;
+      const bool active = tile < ntiles;
+      const int64_t s = tile * 32 + col;
+      const bool live = active && s < n;
+      const int64_t sc = live ? s : n - 1;
+      Z33h z[4];
+      f32x16 dh[3];
+      float x[9];
+      load_rot9(R, sc, x);
+      const int64_t tt = t[sc * t_stride];
+      const float lv = live ? 1.0f : 0.0f;  // dead columns contribute exact zeros to every dW sum
+      {
+        f32x16 a3[3];
+        Tile<PREC> cur;
+        layer0_chain<PREC, 0>(lds, beff_tab + (size_t)tt * 96, x, a3, lane);
+        keep_h(a3, z[0]);
+#pragma unroll
+        for (int l = 1; l < 4; l++) {
+          activate_zh<PREC>(z[l - 1], cur, h);
+          hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
+          keep_h(a3, z[l]);
+        }
+      }
+      // ---- backward, software-pipelined one layer ahead so that the chain waves work while the dW waves
+      //      consume the images:   [write images of layer l] B1 [dH_l, dZ_{l-1}, silu pass for layer l-1] B2
+      // Everything that goes into an image is kept as packed bf16 pairs (the exact MFMA operand bits).
+      uint32_t pdz[17], ph[17];
+      float dnext[33];  // silu'(Z_{l-1}) of the layer about to be differentiated
+#pragma unroll
+      for (int r = 0; r < 17; r++) pdz[r] = 0u;
+      if (h == 0) {
+        pdz[0] = pack_bf16x2(dout[sc * 3] * lv, dout[sc * 3 + 1] * lv);
+        pdz[1] = pack_bf16x2(dout[sc * 3 + 2] * lv, 0.0f);
+      }
+      silu_pass<PREC>(z[3], lv, h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
+#pragma unroll
+      for (int l = 4; l >= 0; l--) {
+        // ---- images of layer l (8-byte stores of ready-made operand bits)
+#pragma unroll
+        for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 2 * c8 + h, pdz[2 * c8], pdz[2 * c8 + 1]);
+        fimg_store_pk(my_img, SL, 16 + h, h ? 0u : pdz[16], 0u);
+        if (l > 0) {
+#pragma unroll
+          for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 24 + 2 * c8 + h, ph[2 * c8], ph[2 * c8 + 1]);
+          fimg_store_pk(my_img, SL, 24 + 16 + h, ph[16], 0u);
+        } else {  // H_0 = the network input: [0..8] R, [9] one, [10..65] emb(t), zeros; the two lanes of a column split the row
+#pragma unroll
+          for (int c4 = 0; c4 < 12; c4++) {
+            const int ch0 = 24 + 12 * h + c4;  // chunk of the 4 consecutive input slots 48 h + 4 c4 ..
+            float v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int klo = 4 * c4 + u, khi = 48 + 4 * c4 + u;  // the two candidates are compile-time, h selects
+              const float vlo = klo < 9 ? x[klo < 9 ? klo : 0] : (klo == 9 ? 1.0f : emb_tab[(size_t)tt * NEMB + (klo - 10)]);
+              const float vhi = khi < 66 ? emb_tab[(size_t)tt * NEMB + (khi < 66 ? khi - 10 : 0)] : 0.0f;
+              v4[u] = (h ? vhi : vlo) * lv;
+            }
+            fimg_store_pk(my_img, SL, ch0, pack_bf16x2(v4[0], v4[1]), pack_bf16x2(v4[2], v4[3]));
+          }
+        }
+        __syncthreads();  // B1: images of layer l complete -- the dW waves consume them while this wave goes on
+        if (l > 0) {
+          if (l == 4) dh_layer_pk<PREC, 4>(wt_lds, pdz, dh, lane);
+          if (l == 3) dh_layer_pk<PREC, 3>(wt_lds, pdz, dh, lane);
+          if (l == 2) dh_layer_pk<PREC, 2>(wt_lds, pdz, dh, lane);
+          if (l == 1) dh_layer_pk<PREC, 1>(wt_lds, pdz, dh, lane);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const float g0 = (r < 8 ? dh[0][2 * r] : dh[1][2 * r - 16]) * dnext[2 * r];
+            const float g1 = (r < 8 ? dh[0][2 * r + 1] : dh[1][2 * r - 15]) * dnext[2 * r + 1];
+            pdz[r] = pack_bf16x2(g0, g1);
+          }
+          pdz[16] = pack_bf16x2(h ? 0.0f : dh[2][0] * dnext[32], 0.0f);  // upper half of tile 2 / reg 0 = the constant-one row
+          if (l > 1) silu_pass<PREC>(z[l - 2], lv, h, ph, dnext);       // H_{l-1} = silu(Z_{l-2}), silu'(Z_{l-2})
+        }
+        __syncthreads();  // B2: the dW waves are done with the images
+      }
+    }
+  } else {
+    // ================================ dW waves =================================
+    const int dw = wid - 4;
+    f32x16 acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
+    FimgReadLane RL = fimg_read_lane(lane);
+    for (int64_t rd = 0; rd < rounds; rd++) {
+      asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
+#pragma unroll
+      for (int l = 4; l >= 0; l--) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          const int p = dw + 4 * k;  // owned pair
+          const int pl = p < 36 ? p / 9 : 4;
+          if (p < NPAIRS && pl == l) {
+            const int to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
+            f32x16 a = acc[k];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+              const char* im = fimg_all + w * FIMG_BYTES;
+#pragma unroll
+              for (int ks = 0; ks < 2; ks++) a = mfma_bf16(fimg_frag(im, RL, 32 * to, ks), fimg_frag(im, RL, 96 + 32 * ti, ks), a);
+            }
+            acc[k] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
+    float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const int p = dw + 4 * k;
+      if (p < NPAIRS) {
+        const int l = p < 36 ? p / 9 : 4, to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
+        const int in_f = 32 * ti + col;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int out = 32 * to + row_of(r, h);
+          if (out >= (l < 4 ? D : 3)) continue;
+          int pc;  // weight column, -2 = bias, -1 = padding
+          if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
+          else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
+          if (pc == -1) continue;
+          const int base = l * LAYER_STRIDE;
+          slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = acc[k][r];
+        }
+      }
+    }
+  }
+}
+
 // workspace layout: [weight image | (t_table: beff, emb tables)] [transposed image] [slabs] [stash]
 struct BwdLayout { size_t wt, slabs, stash, end; };
 template <int PREC> BwdLayout bwd_layout(int64_t n, int t_table) {
@@ -468,6 +767,23 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   const float* emb = VAR == GATHER ? reinterpret_cast<const float*>(ws + emb_offset(PREC, VAR, t_table)) : nullptr;
   float* slabs = reinterpret_cast<float*>(ws + L.slabs);
   ST* stash = reinterpret_cast<ST*>(ws + L.stash);
+  if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER) {
+    // fused path: no stash, one launch for the whole batch
+    constexpr int FUSED_LDS = image_bytes<PREC, VAR>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
+    static int fattr = 0;
+    if (!fattr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_fused<PREC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+      if (e != hipSuccess) return (int)e;
+      fattr = 1;
+    }
+    const int64_t nt = (n + 31) / 32;
+    const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
+    hipLaunchKernelGGL((k_bwd_fused<PREC>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff, emb,
+                       R, t, t_stride, dout, slabs, n);
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0);
+    return check_launch();
+  }
   for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
     const int64_t nc = (n - c0) < CHUNK ? (n - c0) : CHUNK;
     const int64_t ntiles = (nc + 31) / 32;
