@@ -1,0 +1,431 @@
+// so3x_resnet.hip -- the wide residual score network of so3_lock_train.py:11-59
+//   RotPredict(d_model = 255): x0 = [R(9), sin(123), cos(123)];  x_{l+1} = x_l + silu(W_l x_l + b_l), l = 0..5
+//   (models.py:28-34 ResLayer);  out = W_out x_6 + b_out (3 values, out_type = "skewvec"),
+// on the CDNA4 matrix cores, standalone forward and fused into the chain-resident reverse sampler.
+//
+// Shape of the problem: 392,448 parameters = 768 KiB as bf16 -- five times the LDS -- and 781,830 flop per
+// sample, 23x the 65-wide network.  So, unlike so3x_mlp.hpp (weights resident in LDS, activations flowing),
+//   * the ACTIVATIONS are stationary: a wave owns 32 samples and keeps their 256-row residual stream in
+//     128 fp32 VGPRs for the whole network (rows 0..254 features, row 255 the constant one that carries
+//     every bias as a weight column; W row 255 is zero, so silu(0) = 0 keeps it at one);
+//   * the WEIGHTS stream: one "chunk" = one 32-row output tile of one layer = the 16 (bf16) or 128 (fp32)
+//     MFMA A-fragments of its K = 256 contraction, laid out fragment-major by a prep kernel; every
+//     workgroup walks the 49 chunks of the network through a 3-slot LDS ring filled by LDS-DMA
+//     (global_load_lds_dwordx4, two chunks in flight across the per-chunk barrier; the image is
+//     L2-resident and shared by all workgroups);
+//   * operand layout as in so3x_mlp.hpp: weights = A, activations = B, an accumulator tile has the row
+//     map row(reg, h) = (reg & 3) + 8 (reg >> 2) + 4 h, and the image's K order is permuted so that the
+//     residual registers, packed to bf16 pairs, ARE the next B operand (no lane movement, no LDS);
+//   * bf16: the two waves of a SIMD run half a chunk out of phase -- wave A: MFMAs(c) then SiLU(c),
+//     wave B: SiLU(c-1) then MFMAs(c) -- so the matrix pipe and the VALU/transcendental pipe overlap
+//     across the pair (roofline: MFMA-bound, 128 MFMAs vs 128 SiLUs per lane per layer);
+//   * bf16 SiLU scale fold as in so3x_mlp.hpp: the image carries -log2(e) W, the residual update is one
+//     fma with the constant -1/log2(e).
+// fp32 (parity path): v_mfma_f32_32x32x2_f32, one wave per SIMD (the operand copy needs a second
+// 128-register set).
+#include "so3x_common.hpp"
+#include "so3x_math.hpp"
+#include "so3x_igso3.hpp"
+#include "so3x_reverse_step.hpp"
+
+using namespace so3x;
+
+namespace {
+
+constexpr int DW = SO3X_RESNET_D;  // 255
+constexpr int NBLK = 6;
+constexpr int NFREQ = 123;         // models.py:18-24 with dim = 246
+constexpr int LAYER_STRIDE = DW * DW + DW;
+constexpr int NPARAMS = NBLK * LAYER_STRIDE + 3 * DW + 3;
+static_assert(NPARAMS == SO3X_RESNET_PARAMS, "param count");
+constexpr int NCHUNK = NBLK * 8 + 1;  // (layer, output tile) in stream order, then the 3-row output layer
+constexpr int RING = 3;
+constexpr float kFoldS = -1.44269504088896341f;
+
+struct Freqs { float f[NFREQ]; };
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+
+template <int PREC> __host__ __device__ constexpr int chunk_bytes() { return PREC == SO3X_PREC_F32 ? 32768 : 16384; }
+template <int PREC> __host__ __device__ constexpr int n_waves() { return PREC == SO3X_PREC_F32 ? 4 : 8; }
+template <int PREC> __host__ __device__ constexpr size_t image_bytes() { return (size_t)NCHUNK * chunk_bytes<PREC>(); }
+__host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- prep: weight image --------------------------------------------------------------------
+// value of (chunk, output row o, input feature f): weights, the bias in column 255, zeros in the padding
+__device__ __forceinline__ float wvalue(const float* __restrict__ params, int chunk, int o, int f) {
+  if (chunk < NBLK * 8) {
+    const float* W = params + (size_t)(chunk >> 3) * LAYER_STRIDE;
+    if (o >= DW) return 0.0f;
+    return f < DW ? W[o * DW + f] : W[DW * DW + o];
+  }
+  const float* W = params + (size_t)NBLK * LAYER_STRIDE;
+  if (o >= 3) return 0.0f;
+  return f < DW ? W[o * DW + f] : W[3 * DW + o];
+}
+
+// one 16-byte piece per thread: bf16 piece = (k-step ks, lane) -> 8 elements, element j of lane half h is
+// feature 16 ks + 8 (j >> 2) + 4 h + (j & 3);  fp32 piece = (group g, lane) -> the lane's values of k-steps
+// 4g .. 4g+3, k-step k of half h is feature 32 (k >> 4) + row(k & 15, h).
+template <int PREC>
+__global__ void __launch_bounds__(256) k_resnet_image(const float* __restrict__ params, void* __restrict__ img) {
+  const int chunk = blockIdx.x;
+  constexpr int PIECES = chunk_bytes<PREC>() / 16;
+  for (int p = threadIdx.x; p < PIECES; p += blockDim.x) {
+    const int lane = p & 63, i = lane & 31, h = lane >> 5, q = p >> 6;
+    const int o = 32 * (chunk < NBLK * 8 ? (chunk & 7) : 0) + i;
+    if constexpr (PREC == SO3X_PREC_BF16) {
+      const float sc = chunk < NBLK * 8 ? kFoldS : 1.0f;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = (__bf16)(sc * wvalue(params, chunk, o, 16 * q + 8 * (j >> 2) + 4 * h + (j & 3)));
+      reinterpret_cast<bf16x8*>(img)[(size_t)chunk * PIECES + p] = v;
+    } else {
+      float4 v;
+      float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = 4 * q + u; e[u] = wvalue(params, chunk, o, 32 * (k >> 4) + row_of(k & 15, h)); }
+      reinterpret_cast<float4*>(img)[(size_t)chunk * PIECES + p] = v;
+    }
+  }
+}
+
+// ---- prep: per-timestep input rows  x0tab[t][256] = [0 x 9 (rotation slots), sin(t f), cos(t f), 1] ------
+// models.py:22-24: the angle is formed in fp32 (int64 t promoted), then sin / cos of that fp32 angle.
+__global__ void __launch_bounds__(256) k_resnet_x0tab(Freqs fr, int T, float* __restrict__ tab) {
+  const int t = blockIdx.x, r = threadIdx.x;
+  float v = 0.0f;
+  if (r >= 9 && r < 9 + 2 * NFREQ) {
+    const int e = r - 9;
+    float sn, cs;
+    sincos_cw((float)t * fr.f[e < NFREQ ? e : e - NFREQ], &sn, &cs);
+    v = e < NFREQ ? sn : cs;
+  } else if (r == 255) {
+    v = 1.0f;
+  }
+  tab[(size_t)t * 256 + r] = v;
+}
+
+// ---- the streaming forward -----------------------------------------------------------------
+template <int PREC> struct Operand;  // what the MFMAs read as B: a copy of the layer input
+template <> struct Operand<SO3X_PREC_BF16> { uint32_t hi[64]; };
+template <> struct Operand<SO3X_PREC_F32> { float x[128]; };
+
+template <int PREC> __device__ __forceinline__ void refresh(Operand<PREC>& op, const float (&xf)[128]) {
+  if constexpr (PREC == SO3X_PREC_BF16) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      bf16x2 p = {(__bf16)xf[2 * i], (__bf16)xf[2 * i + 1]};
+      op.hi[i] = __builtin_bit_cast(uint32_t, p);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 128; i++) op.x[i] = xf[i];
+  }
+}
+
+// LDS-DMA of one chunk: the block's waves split its 1 KiB fragments; lane l lands at base + 16 l.
+template <int PREC>
+__device__ __forceinline__ void issue_chunk(const char* __restrict__ gimg, char* ring, int chunk, int slot, int wave, int lane) {
+  constexpr int CB = chunk_bytes<PREC>();
+  constexpr int PER_WAVE = CB / 1024 / n_waves<PREC>();
+  const char* src = gimg + (size_t)chunk * CB + (size_t)(wave * PER_WAVE) * 1024 + lane * 16;
+  char* dst = ring + slot * CB + (wave * PER_WAVE) * 1024;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; i++)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+}
+template <int PREC> __host__ __device__ constexpr int dma_per_chunk() { return chunk_bytes<PREC>() / 1024 / n_waves<PREC>(); }
+
+// wait until at most `keep` of this wave's LDS-DMAs are outstanding, then the workgroup barrier: afterwards the
+// oldest chunk of the ring is complete for every wave and the slot freed one chunk ago may be refilled.
+// Raw s_barrier on purpose: __syncthreads() would add a vmcnt(0) fence and drain the chunks still in flight.
+template <int KEEP> __device__ __forceinline__ void ring_sync() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 chunk_mfma(const char* slotp, const Operand<PREC>& op, int lane) {
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (PREC == SO3X_PREC_BF16) {
+    const bf16x8* A = reinterpret_cast<const bf16x8*>(slotp);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      __builtin_amdgcn_sched_barrier(0);  // at most four A fragments (16 VGPRs) in flight
+#pragma unroll
+      for (int k = 4 * g; k < 4 * g + 4; k++) {
+        const u32x4 b = {op.hi[4 * k], op.hi[4 * k + 1], op.hi[4 * k + 2], op.hi[4 * k + 3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * 64 + lane], __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+      }
+    }
+  } else {
+    const float4* A = reinterpret_cast<const float4*>(slotp);
+#pragma unroll
+    for (int g = 0; g < 32; g++) {
+      if ((g & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      const float4 a = A[g * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, op.x[4 * g], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, op.x[4 * g + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, op.x[4 * g + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, op.x[4 * g + 3], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// residual update of one output tile: x += silu(z)
+template <int PREC> __device__ __forceinline__ void residual(const f32x16& acc, float (&xf)[128], int TO /* constant after unrolling */) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    if constexpr (PREC == SO3X_PREC_BF16) {
+      const float y = acc[r];  // = -log2(e) z
+      xf[16 * TO + r] = fmaf(y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)), 1.0f / kFoldS, xf[16 * TO + r]);
+    } else {
+      const float z = acc[r];
+      xf[16 * TO + r] += z / (1.0f + expf(-z));  // accurate path (parity gate G5)
+    }
+  }
+}
+
+// position in the chunk stream of a workgroup: ring slot of the next chunk to CONSUME
+struct Stream { int slot; };
+
+// first two chunks of a pass; call once before the first forward() of a workgroup
+template <int PREC>
+__device__ __forceinline__ void stream_begin(const char* __restrict__ gimg, char* ring, Stream& st, int wave, int lane) {
+  st.slot = 0;
+  issue_chunk<PREC>(gimg, ring, 0, 0, wave, lane);
+  issue_chunk<PREC>(gimg, ring, 1, 1, wave, lane);
+}
+
+// The whole network on this wave's 32 samples.  xf = the input rows on entry (destroyed); v = the three outputs of
+// sample column (lane & 31), valid in the lower lane half.  Block-collective (49 barriers).  `again` = another
+// forward() follows in this workgroup: its first two chunks are requested while this pass drains.
+template <int PREC>
+__device__ __forceinline__ void forward(const char* __restrict__ gimg, char* ring, Stream& st, float (&xf)[128], float (&v)[3],
+                                        bool again, int wave, int lane) {
+  constexpr int CB = chunk_bytes<PREC>();
+  constexpr int DMA = dma_per_chunk<PREC>();
+  const bool late = PREC == SO3X_PREC_BF16 && (wave >> 2);  // the SIMD partner that runs its SiLU half a chunk later
+  Operand<PREC> op;
+  refresh<PREC>(op, xf);
+  f32x16 acc;
+  int slot = st.slot;
+  // the counted waits below assume that this wave's only outstanding memory operations are the ring's DMAs
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+  for (int l = 0; l < NBLK; l++) {
+#pragma unroll
+    for (int to = 0; to < 8; to++) {
+      const int c = 8 * l + to;
+      ring_sync<DMA>();  // chunk c landed everywhere (chunk c+1 may still be in flight); slot of chunk c-1 is free
+      {
+        const int nslot = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3
+        if (c + 2 < NCHUNK) issue_chunk<PREC>(gimg, ring, c + 2, nslot, wave, lane);
+        else if (again) issue_chunk<PREC>(gimg, ring, c + 2 - NCHUNK, nslot, wave, lane);
+      }
+      if (late) {
+        if (to > 0) residual<PREC>(acc, xf, to - 1);
+        else if (l > 0) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); }
+      }
+      acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
+      if (!late) {
+        residual<PREC>(acc, xf, to);
+        if (to == 7) refresh<PREC>(op, xf);
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  // output layer: chunk 48.  Outstanding DMAs here: chunk 48 itself and, with `again`, chunk 0 of the next pass.
+  if (again) ring_sync<DMA>(); else ring_sync<0>();
+  if (again) issue_chunk<PREC>(gimg, ring, 1, slot == 0 ? 2 : slot - 1, wave, lane);
+  if (late) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); }
+  acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
+  v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2];  // rows 0,1,2 = regs 0,1,2 of the lower half
+  st.slot = slot == 2 ? 0 : slot + 1;
+}
+
+// input rows of a sample column: the x0tab row of its timestep with the rotation entries dropped into rows 0..8
+// (lower half: rows 0-3 and 8 = regs 0-3 and 4;  upper half: rows 4-7 = regs 0-3)
+__device__ __forceinline__ void fill_input(float (&xf)[128], const float (&R)[9], const float* __restrict__ x0row, int h) {
+#pragma unroll
+  for (int tq = 0; tq < 32; tq++) {
+    const float4 e = *reinterpret_cast<const float4*>(x0row + 8 * tq + 4 * h);  // rows 32 tin + 8 q + 4 h + (0..3), tq = 4 tin + q
+    xf[4 * tq] = e.x; xf[4 * tq + 1] = e.y; xf[4 * tq + 2] = e.z; xf[4 * tq + 3] = e.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) xf[r] = h ? R[4 + r] : R[r];
+  xf[4] = h ? xf[4] : R[8];
+}
+
+// ---- standalone forward ----------------------------------------------------------------------
+template <int PREC>
+__global__ void __launch_bounds__(64 * n_waves<PREC>(), 1)
+k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int T, const float* __restrict__ R,
+             const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int NW = n_waves<PREC>();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t ngroups = (n + 32 * NW - 1) / (32 * NW);
+  Stream st;
+  stream_begin<PREC>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    int64_t idx = (g * NW + wave) * 32 + col;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    float Rm[9];
+    load_rot9(R, idx, Rm);
+    int64_t tt = t[idx * t_stride];
+    tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+    float xf[128], v[3];
+    fill_input(xf, Rm, x0tab + tt * 256, h);
+    forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, v, g + gridDim.x < ngroups, wave, lane);
+    if (live && h == 0) {
+      out[idx * 3] = v[0]; out[idx * 3 + 1] = v[1]; out[idx * 3 + 2] = v[2];
+    }
+  }
+}
+
+// ---- chain-resident reverse sampler with this network (diffusion.py:315-337, so3_lock_test.py:24-31) ------
+// Both lanes of a sample column carry the same unit-quaternion state and do the same per-step rotation math
+// (keyed noise -> identical results); the 3 network outputs are mirrored from the lower half each step.
+template <int PREC>
+__global__ void __launch_bounds__(64 * n_waves<PREC>(), 1)
+k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, const float* __restrict__ sched, int T,
+               const float* __restrict__ trap_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
+               int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
+               int64_t index_base, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int NW = n_waves<PREC>();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t ngroups = (n + 32 * NW - 1) / (32 * NW);
+  Stream st;
+  stream_begin<PREC>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t idx = (g * NW + wave) * 32 + col;
+    const bool live = idx < n;
+    const int64_t idc = live ? idx : n - 1;
+    float Rm[9];
+    load_rot9(x_in, idc, Rm);
+    Quat q = quat_from_rmat(Rm);
+    const bool last_group = g + gridDim.x >= ngroups;
+#pragma unroll 1
+    for (int s = 0; s < n_steps; s++) {
+      const int t = t_start - s;
+      if (s > 0) rmat_from_quat(q, Rm);
+      float xf[128], vo[3], v[3];
+      fill_input(xf, Rm, x0tab + (size_t)t * 256, h);
+      forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, vo, !(last_group && s == n_steps - 1), wave, lane);
+#pragma unroll
+      for (int j = 0; j < 3; j++) v[j] = __shfl(vo[j], col);
+      q = reverse_step(q, v, sched, T, t, trap_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+    }
+    rmat_from_quat(qnormalize(q), Rm);
+    if (live && h == 0) store_rot9(x_out, idx, Rm);
+  }
+}
+
+const Freqs& host_freqs() {
+  static Freqs fr;
+  static bool init = false;
+  if (!init) { so3x_posemb_freqs(NFREQ, fr.f); init = true; }
+  return fr;
+}
+
+size_t x0tab_offset(int precision) {
+  return precision == SO3X_PREC_F32 ? image_bytes<SO3X_PREC_F32>() : image_bytes<SO3X_PREC_BF16>();
+}
+size_t ws_bytes(int precision, int T) { return x0tab_offset(precision) + (size_t)(T > 0 ? T : 0) * 256 * sizeof(float); }
+
+template <int PREC> int prep(hipStream_t s, const float* params, int T, void* ws) {
+  hipLaunchKernelGGL((k_resnet_image<PREC>), dim3(NCHUNK), dim3(256), 0, s, params, ws);
+  float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + image_bytes<PREC>());
+  hipLaunchKernelGGL(k_resnet_x0tab, dim3(T), dim3(256), 0, s, host_freqs(), T, tab);
+  return check_launch();
+}
+
+template <typename K> int grid_cap(K kernel, int threads, int lds, int* cap) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  int per_cu = 0, dev = 0, cus = 0;
+  if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), threads, lds)) != hipSuccess) return (int)e;
+  if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+  if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+  *cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+  return SO3X_OK;
+}
+
+template <int PREC>
+int launch_fwd(hipStream_t s, const void* ws, int T, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n) {
+  constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
+  static int cap = 0;  // resident workgroups on this device, queried once (idempotent)
+  if (!cap) { int rc = grid_cap(&k_resnet_fwd<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
+  const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
+  const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
+  hipLaunchKernelGGL((k_resnet_fwd<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, T, R, t,
+                     t_stride, out, n);
+  return check_launch();
+}
+
+template <int PREC>
+int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const float* trap_p, const float* x_in, float* x_out,
+                 int t_start, int n_steps, const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
+                 int64_t index_base, int64_t n) {
+  constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
+  static int cap = 0;
+  if (!cap) { int rc = grid_cap(&k_resnet_chain<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
+  const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
+  const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
+  hipLaunchKernelGGL((k_resnet_chain<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, sched, T,
+                     trap_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
+  return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t so3x_resnet_workspace_bytes(int precision, int t_table) {
+  return ws_bytes(precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16, t_table);
+}
+
+int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
+                    int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!params || !R || !t || !out)))
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ws_bytes(precision, t_table)) return SO3X_ERR_WORKSPACE;
+  if (n == 0) return SO3X_OK;
+  int rc = precision == SO3X_PREC_F32 ? prep<SO3X_PREC_F32>((hipStream_t)s, params, t_table, workspace)
+                                      : prep<SO3X_PREC_BF16>((hipStream_t)s, params, t_table, workspace);
+  if (rc) return rc;
+  return precision == SO3X_PREC_F32 ? launch_fwd<SO3X_PREC_F32>((hipStream_t)s, workspace, t_table, R, t, t_stride, out, n)
+                                    : launch_fwd<SO3X_PREC_BF16>((hipStream_t)s, workspace, t_table, R, t, t_stride, out, n);
+}
+
+int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,
+                               const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                               uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
+                               void* workspace, size_t workspace_bytes) {
+  if (n < 0 || T <= 0 || n_steps < 0 || t_start < 0 || t_start >= T || t_start - n_steps + 1 < 0 ||
+      (n && (!params || !sched || !trap_p || !x_in || !x_out)) || ((axes == nullptr) != (unif == nullptr)) ||
+      (axes && n_steps > 1))
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ws_bytes(precision, T)) return SO3X_ERR_WORKSPACE;
+  if (n == 0 || n_steps == 0) return SO3X_OK;
+  int rc = precision == SO3X_PREC_F32 ? prep<SO3X_PREC_F32>((hipStream_t)s, params, T, workspace)
+                                      : prep<SO3X_PREC_BF16>((hipStream_t)s, params, T, workspace);
+  if (rc) return rc;
+  if (precision == SO3X_PREC_F32)
+    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes, unif,
+                                       seed, rng_offset, index_base, n);
+  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes, unif,
+                                      seed, rng_offset, index_base, n);
+}
+
+}  // extern "C"

@@ -31,6 +31,7 @@ SYMBOLS = (
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
+    "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
 )
 
 
@@ -61,6 +62,7 @@ def lib():
                 l.so3x_p_sample_workspace_bytes.restype = C.c_size_t
                 l.so3x_kernel_sum_workspace_bytes.restype = C.c_size_t
                 l.so3x_mse_workspace_bytes.restype = C.c_size_t
+                l.so3x_resnet_workspace_bytes.restype = C.c_size_t
                 if l.so3x_abi_version() != 1:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
@@ -433,6 +435,50 @@ def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=N
                                          C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un), _u64(seed),
                                          _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision), _ptr(ws),
                                          C.c_size_t(ws.numel())), "p_sample_chain")
+    return out
+
+
+# ------------------------------------------------- wide residual score network (so3_lock_train.py:11-59)
+N_PARAMS_RESNET = 6 * (255 * 255 + 255) + 3 * 255 + 3
+
+
+def resnet_fwd(params, R, t, t_table, precision=PREC_F32):
+    params = _dev(params, "params").reshape(-1)
+    if params.numel() != N_PARAMS_RESNET:
+        raise ValueError(f"so3x: params must hold {N_PARAMS_RESNET} values")
+    R = _rot_in(R, "x")
+    n = R.numel() // 9
+    tt, stride = _t_arg(t, n)
+    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(int(t_table)))
+    ws = _workspace(R.device, nb)
+    with _Guard(R):
+        _check(lib().so3x_resnet_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n),
+                                     C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "resnet_fwd")
+    return out
+
+
+def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0,
+                          index_base=0, precision=PREC_BF16, out=None):
+    params = _dev(params, "params").reshape(-1)
+    if params.numel() != N_PARAMS_RESNET:
+        raise ValueError(f"so3x: params must hold {N_PARAMS_RESNET} values")
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    trap_p = _dev(trap_p, "trap_p")
+    x = _rot_in(x, "x")
+    n = x.numel() // 9
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    if out is None:
+        out = torch.empty_like(x)
+    nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(T))
+    ws = _workspace(x.device, nb)
+    with _Guard(x):
+        _check(lib().so3x_resnet_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(x),
+                                                _ptr(out), C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un),
+                                                _u64(seed), _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision),
+                                                _ptr(ws), C.c_size_t(ws.numel())), "resnet_p_sample_chain")
     return out
 
 

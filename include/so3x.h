@@ -167,6 +167,26 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
                         uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                         void* workspace, size_t workspace_bytes);
 
+/* ------------------------------------------- wide residual score network (8f row 3) */
+/* so3_lock_train.RotPredict (so3_lock_train.py:11-59), out_type="skewvec": d_model = 255, input
+ * [R(9), sin(123), cos(123)] (models.py:13-25 with dim 246), six ResLayer(Linear(255,255)+SiLU) blocks
+ * (models.py:28-34), Linear(255,3).  params = the 392,448 fp32 values in state_dict order
+ * net.{0..5}.layer.0.{weight,bias}, net.6.{weight,bias}.  t_table = T > 0 is REQUIRED: the call builds the
+ * [T][256] input-row table and gathers by t; timesteps outside [0, T) are clamped into it. */
+#define SO3X_RESNET_D 255
+#define SO3X_RESNET_PARAMS 392448
+size_t so3x_resnet_workspace_bytes(int precision, int t_table);
+int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
+                    int64_t t_stride, float* out, int64_t n, int precision, int t_table,
+                    void* workspace, size_t workspace_bytes);
+/* so3x_p_sample_chain with this network as the denoiser (so3_lock_test.py:24-31); workspace =
+ * so3x_resnet_workspace_bytes(precision, T). */
+int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T,
+                               const float* trap_p, const float* x_in, float* x_out, int t_start,
+                               int n_steps, const float* axes, const float* unif, uint64_t seed,
+                               uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
+                               void* workspace, size_t workspace_bytes);
+
 /* ------------------------------------------------------ SE(3) = SO(3) x R^3 layer */
 /* SE3Diffusion.q_sample + the two p_losses targets (diffusion.py:496-513) fused with the
  * IGSO3xR3 noise draw (distributions.py:84-101): rotation noise as so3x_q_sample_target,

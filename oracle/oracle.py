@@ -243,6 +243,34 @@ def mlp_bwd(params, R, t, dout, prec="f32"):
     return dp
 
 
+N_PARAMS_RESNET = 6 * (255 * 255 + 255) + 3 * 255 + 3
+
+
+def resnet_fwd(params, R, t, prec="f32"):
+    """so3_lock_train.RotPredict(out_type="skewvec") forward (so3_lock_train.py:11-59)."""
+    params = _arr(params, np.float32).ravel()
+    assert params.size == N_PARAMS_RESNET
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    t = _arr(t, np.int64).ravel()
+    n = R.shape[0]
+    out = np.empty((n, 3), _DT[prec])
+    fr = posemb_freqs(123)
+    _fn("resnet_fwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(out), C.c_long(n))
+    return out
+
+
+def resnet_bwd(params, R, t, dout, prec="f32"):
+    params = _arr(params, np.float32).ravel()
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    t = _arr(t, np.int64).ravel()
+    dout = _arr(dout, _DT[prec]).reshape(-1, 3)
+    dp = np.empty(N_PARAMS_RESNET, np.float64)
+    fr = posemb_freqs(123)
+    _fn("resnet_bwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(dout), _p(dp),
+                            C.c_long(R.shape[0]))
+    return dp
+
+
 def q_sample_target(x0, noise, sched, t, prec="f32"):
     """returns (x_t, target); sched = schedule_from_betas table."""
     x0 = _arr(x0, _DT[prec]).reshape(-1, 9)

@@ -371,6 +371,88 @@ void FN(domega_dR)(const REAL* R, REAL* g, long n) {
   }
 }
 
+/* ---- so3_lock_train.RotPredict (so3_lock_train.py:11-59): d_model = 255, six ResLayer(Linear+SiLU) blocks
+ * (models.py:28-34: x + layer(x)), then Linear(255, 3) for out_type="skewvec".  Input = [R(9), sin(123), cos(123)]
+ * (models.py:13-25 with dim = 246).  Params flat in state_dict order: 6 x (W[255][255], b[255]), W_out[3][255], b_out[3]. */
+#define SO3O_DW 255
+static void FN(resnet_input)(const REAL* R, long t, const float* freqs, REAL* x) {
+  for (int i = 0; i < 9; i++) x[i] = R[i];
+  for (int i = 0; i < 123; i++) {
+    float a = (float)t * freqs[i];
+    x[9 + i] = (REAL)SIN((REAL)a);
+    x[9 + 123 + i] = (REAL)COS((REAL)a);
+  }
+}
+
+void FN(resnet_fwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride, REAL* out, long n) {
+  const int D = SO3O_DW;
+#pragma omp parallel for schedule(static)
+  for (long b = 0; b < n; b++) {
+    REAL x[SO3O_DW], y[SO3O_DW];
+    FN(resnet_input)(R + 9 * b, t[b * t_stride], freqs, x);
+    const float* p = params;
+    for (int l = 0; l < 6; l++) {
+      const float* W = p; const float* bias = p + D * D; p += D * D + D;
+      for (int o = 0; o < D; o++) {
+        REAL acc = (REAL)bias[o];
+        for (int i = 0; i < D; i++) acc += (REAL)W[o * D + i] * x[i];
+        y[o] = x[o] + FN(silu)(acc);
+      }
+      for (int o = 0; o < D; o++) x[o] = y[o];
+    }
+    for (int o = 0; o < 3; o++) {
+      REAL acc = (REAL)p[3 * D + o];
+      for (int i = 0; i < D; i++) acc += (REAL)p[o * D + i] * x[i];
+      out[3 * b + o] = acc;
+    }
+  }
+}
+
+/* gradients wrt the 392,448 parameters for a given dL/dout [n,3] (autograd of so3_lock_train.py:50-59), accumulated in double */
+void FN(resnet_bwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride, const REAL* dout,
+                    double* dparams, long n) {
+  const int D = SO3O_DW;
+  const long LS = (long)D * D + D, NP = 6 * LS + 3 * D + 3;
+  for (long i = 0; i < NP; i++) dparams[i] = 0.0;
+  for (long b = 0; b < n; b++) {
+    REAL x[7][SO3O_DW], z[6][SO3O_DW], dx[SO3O_DW], dz[SO3O_DW];
+    FN(resnet_input)(R + 9 * b, t[b * t_stride], freqs, x[0]);
+    for (int l = 0; l < 6; l++) {
+      const float* W = params + l * LS; const float* bias = W + D * D;
+      for (int o = 0; o < D; o++) {
+        REAL acc = (REAL)bias[o];
+        for (int i = 0; i < D; i++) acc += (REAL)W[o * D + i] * x[l][i];
+        z[l][o] = acc; x[l + 1][o] = x[l][o] + FN(silu)(acc);
+      }
+    }
+    const long off6 = 6 * LS;
+    for (int i = 0; i < D; i++) dx[i] = 0;
+    for (int o = 0; o < 3; o++) {
+      REAL g = dout[3 * b + o];
+      dparams[off6 + 3 * D + o] += (double)g;
+      for (int i = 0; i < D; i++) {
+        dparams[off6 + o * D + i] += (double)g * (double)x[6][i];
+        dx[i] += (REAL)params[off6 + o * D + i] * g;
+      }
+    }
+    for (int l = 5; l >= 0; l--) {
+      const long off = l * LS;
+      for (int o = 0; o < D; o++) {
+        REAL sg = 1 / (1 + EXP(-z[l][o]));
+        dz[o] = dx[o] * (sg * (1 + z[l][o] * (1 - sg)));
+      }
+      for (int o = 0; o < D; o++) {  /* dx_l = dx_{l+1} + W^T dz */
+        dparams[off + D * D + o] += (double)dz[o];
+        for (int i = 0; i < D; i++) {
+          dparams[off + o * D + i] += (double)dz[o] * (double)x[l][i];
+          dx[i] += (REAL)params[off + o * D + i] * dz[o];
+        }
+      }
+    }
+  }
+}
+#undef SO3O_DW
+
 #undef SO3O_D
 #undef FN
 #undef CAT

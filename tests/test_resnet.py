@@ -1,0 +1,154 @@
+"""The wide residual score network of so3_lock_train.py:11-59: oracle vs the values captured
+from the reference (CPU), device kernels vs the oracle through the C ABI (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- CPU: oracle pinned by the reference
+def test_oracle_resnet_forward_vs_reference(golden):
+    g = golden["resnet"]
+    assert g["params"].size == O.N_PARAMS_RESNET
+    assert [str(s) for s in g["param_names"][:2]] == ["net.0.layer.0.weight", "net.0.layer.0.bias"]
+    o32 = O.resnet_fwd(g["params"], g["x"], g["t"], "f32")
+    o64 = O.resnet_fwd(g["params"], g["x"], g["t"], "f64")
+    assert np.abs(o32 - g["out"]).max() < 5e-6          # fp32 restatement vs the reference's fp32 forward
+    assert np.abs(o64 - g["out_64"]).max() < 2e-7       # fp64 vs the reference run in double (fp32 embedding angles)
+    # (1,)-shaped t broadcasts to the batch (so3_lock_train.py:52-53)
+    assert np.abs(O.resnet_fwd(g["params"], g["x"], g["t"][:1], "f32") - g["out_t1"]).max() < 5e-6
+
+
+def test_oracle_resnet_backward_vs_reference_autograd(golden):
+    g = golden["resnet"]
+    B = g["x"].shape[0]
+    out = O.resnet_fwd(g["params"], g["x"], g["t"], "f64")
+    assert abs(np.mean((out - g["target"]) ** 2) - float(g["loss"])) < 1e-6
+    dout = (2.0 / (3 * B)) * (out - g["target"])         # d mse / d out
+    dp = O.resnet_bwd(g["params"], g["x"], g["t"], dout, "f64")
+    assert np.abs(dp - g["grad"]).max() < 2e-6 * max(1.0, np.abs(g["grad"]).max())
+
+
+def test_oracle_lock_train_data_path(golden):
+    """so3_lock_train.py:76-81: the arc so3_lerp(R_1, R_2, w) between two Euler rotations."""
+    g = golden["resnet"]
+    n = g["lerp_w"].shape[0]
+    R1 = np.repeat(g["R1"], n, 0)
+    R2 = np.repeat(g["R2"], n, 0)
+    assert np.abs(O.so3_lerp(R1, R2, g["lerp_w"][:, 0], "f64") - g["lerp"]).max() < 1e-5
+
+
+# ----------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def B():
+    from so3x import backend
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return backend
+
+
+@pytest.mark.gpu
+def test_resnet_fwd_fp32_vs_reference_and_oracle(B, golden):
+    g = golden["resnet"]
+    out = host(B.resnet_fwd(dev(g["params"]), dev(g["x"]), dev(g["t"], torch.int64), 1000, precision=0))
+    assert np.abs(out - g["out_64"]).max() < 2e-5        # gate G5: fp32 MFMA path vs the reference in double
+    assert np.abs(out - g["out"]).max() < 2e-5
+    out1 = host(B.resnet_fwd(dev(g["params"]), dev(g["x"]), dev(g["t"][:1], torch.int64), 1000, precision=0))
+    assert np.abs(out1 - g["out_t1"]).max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [(0, 3e-5), (1, 4e-2)])
+@pytest.mark.parametrize("n", [1, 31, 257, 5000])
+def test_resnet_fwd_ragged_sizes_vs_oracle(B, golden, prec, tol, n):
+    """every wave slot / several workgroup passes / ragged tails; bf16 operands with an fp32 residual stream"""
+    g = golden["resnet"]
+    rs = np.random.default_rng(n)
+    x = O.quat_to_rmat(rs.standard_normal((n, 4)).astype(np.float32))
+    t = rs.integers(0, 1000, n)
+    ref = O.resnet_fwd(g["params"], x, t, "f64")
+    out = host(B.resnet_fwd(dev(g["params"]), dev(x), dev(t, torch.int64), 1000, precision=prec))
+    err = np.abs(out - ref)
+    assert err.max() < tol, (n, err.max())
+    if prec == 1 and n >= 257:
+        assert np.median(err) < 6e-3
+        col = np.arange(n) % 256 // 32                   # wave of the workgroup: early and late SIMD partners must agree in quality
+        assert abs(np.median(err[col < 4]) - np.median(err[col >= 4])) < 3e-3
+
+
+@pytest.mark.gpu
+def test_resnet_fwd_argument_errors(B, golden):
+    g = golden["resnet"]
+    x = dev(g["x"])
+    with pytest.raises(ValueError):
+        B.resnet_fwd(dev(g["params"][:-1]), x, dev(g["t"], torch.int64), 1000)
+    with pytest.raises(B.So3xError):
+        B.resnet_fwd(dev(g["params"]), x, dev(g["t"], torch.int64), 0)      # a timestep table is required
+    empty = B.resnet_fwd(dev(g["params"]), x[:0], dev(g["t"][:0], torch.int64), 10)
+    assert empty.shape == (0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+def test_resnet_chain_step_vs_oracle(B, golden, prec):
+    """one reverse step with the wide network vs the fp64 oracle fed the same Philox noise"""
+    g = golden["resnet"]
+    T = 1000
+    betas = O.cosine_beta_schedule(T)
+    sched = O.schedule_from_betas(betas)
+    sched_d = dev(B.schedule_from_betas(betas))          # [13][T]: the 12 reference buffers + sigma_t
+    trap_p = B.igso3_build_tables(sched_d[12])
+    n = 300
+    for t in (3, 400, 800):
+        x0 = O.quat_to_rmat(np.random.default_rng(t).standard_normal((n, 4)).astype(np.float32))
+        out = host(B.resnet_p_sample_chain(dev(g["params"]), sched_d, trap_p, dev(x0), t, 1, seed=4, rng_offset=20, precision=prec))
+        coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
+        v = O.resnet_fwd(g["params"], x0, np.full(n, t), "f64")
+        x0h, ref = O.p_mean(x0, v, *coef, "f64")
+        _, ang, ax = B.igso3_sample(trap_p, n, row_const=t, seed=4, rng_offset=20 + t, want_angle=True, want_axis=True)
+        ref = O.rmul(ref, O.aa_to_rmat(host(ax), host(ang), "f64"), "f64")
+        _, a1 = O.rmat_to_aa(x0, "f64")
+        _, a2 = O.rmat_to_aa(x0h, "f64")
+        cond = max(coef[0], 1.0) * (1.0 / (np.pi - a1[:, 0]) + 1.0 / (np.pi - a2[:, 0]) + 1.0)
+        err = np.abs(out - ref).reshape(n, -1).max(1)
+        if prec == 0:
+            assert (err <= 3e-5 + 4e-6 * cond).all(), (t, float(err.max()))
+        else:
+            assert np.median(err) < 1e-2 * max(1.0, coef[1]), (t, float(np.median(err)))
+        assert np.abs(out @ out.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+def test_resnet_chain_span_reproducible_and_shard_invariant(B, golden, prec):
+    g = golden["resnet"]
+    T = 40
+    sched_d = dev(B.schedule_from_betas(O.cosine_beta_schedule(T)))
+    trap_p = B.igso3_build_tables(sched_d[12])
+    n = 700
+    x0 = dev(O.quat_to_rmat(np.random.default_rng(2).standard_normal((n, 4)).astype(np.float32)))
+    p = dev(g["params"])
+    full = B.resnet_p_sample_chain(p, sched_d, trap_p, x0, T - 1, T, seed=6, rng_offset=0, precision=prec)
+    again = B.resnet_p_sample_chain(p, sched_d, trap_p, x0, T - 1, T, seed=6, rng_offset=0, precision=prec)
+    assert torch.equal(full, again)
+    a = B.resnet_p_sample_chain(p, sched_d, trap_p, x0[:300], T - 1, T, seed=6, rng_offset=0, index_base=0, precision=prec)
+    b = B.resnet_p_sample_chain(p, sched_d, trap_p, x0[300:], T - 1, T, seed=6, rng_offset=0, index_base=300, precision=prec)
+    assert torch.equal(torch.cat([a, b]), full)          # results do not depend on how the batch is sharded over GPUs
+    assert not torch.isnan(full).any()
+    assert float((full @ full.transpose(-1, -2) - torch.eye(3, device=DEV)).abs().max()) < 1e-4
+    # a span in one launch == the same steps one launch each, below the ill-conditioned head of the chain
+    span = B.resnet_p_sample_chain(p, sched_d, trap_p, x0, 20, 21, seed=6, rng_offset=0, precision=prec)
+    x = x0
+    for t in reversed(range(21)):
+        x = B.resnet_p_sample_chain(p, sched_d, trap_p, x, t, 1, seed=6, rng_offset=0, precision=prec)
+    assert float((x - span).abs().max()) < (1e-4 if prec == 0 else 3e-2)

@@ -620,3 +620,45 @@ def stats_golden():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stats":
     stats_golden()
+
+
+def resnet_golden(B=96):
+    """so3_lock_train.RotPredict (d_model 255, six residual SiLU blocks, so3_lock_train.py:11-59): forward values,
+    MSE gradients, and one skewvec training loss of the reference, CPU fp32 (+ an fp64 forward)."""
+    _install_stubs()
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import util as rutil
+    import so3_lock_train as rlock
+    torch.manual_seed(4)
+    net = rlock.RotPredict(out_type="skewvec")
+    sd = net.state_dict()
+    out = {"params": np.concatenate([npy(v).reshape(-1) for v in sd.values()]),
+           "param_names": np.array(list(sd.keys()))}
+    g = torch.Generator().manual_seed(33)
+    xin = rutil.quat_to_rmat(torch.randn(B, 4, generator=g))
+    tin = torch.randint(0, 1000, (B,), generator=g)
+    tgt = torch.randn(B, 3, generator=g)
+    y = net(xin, tin)
+    loss = torch.nn.functional.mse_loss(y, tgt)
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    out.update(x=npy(xin), t=npy(tin), target=npy(tgt), out=npy(y), loss=npy(loss),
+               grad=np.concatenate([npy(gr).reshape(-1) for gr in grads]),
+               emb=npy(net.time_embedding(tin)), out_t1=npy(net(xin, tin[:1])))
+    net64 = rlock.RotPredict(out_type="skewvec").double()
+    net64.load_state_dict({k_: v.double() for k_, v in sd.items()})
+    out["out_64"] = npy(net64(xin.double(), tin))
+    # the data path of so3_lock_train.py:76-81
+    from math import pi
+    R1 = rutil.euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None]
+    R2 = rutil.euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None]
+    w = torch.rand(32, 1, generator=g)
+    out.update(R1=npy(R1), R2=npy(R2), lerp_w=npy(w), lerp=npy(rutil.so3_lerp(R1, R2, w)))
+    np.savez(os.path.join(OUT, "resnet.npz"), **out)
+    print({k: (v if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "resnet":
+    resnet_golden()
