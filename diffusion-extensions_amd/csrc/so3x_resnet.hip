@@ -205,14 +205,47 @@ __device__ __forceinline__ void stream_begin(const char* __restrict__ gimg, char
 // The whole network on this wave's 32 samples.  xf = the input rows on entry (destroyed); v = the three outputs of
 // sample column (lane & 31), valid in the lower lane half.  Block-collective (49 barriers).  `again` = another
 // forward() follows in this workgroup: its first two chunks are requested while this pass drains.
-template <int PREC>
+// STASH (training): the layer inputs X_l (the packed bf16 operand registers, l = 0..6) and the pre-activations
+// Y_l = -log2(e) Z_l (l = 0..5) of this wave's 32 samples are dumped as they are, 32 B per lane per 32-row tile
+// ("native" layout [tile][column n][half h][16 bf16], 2 KiB per wave-tile, fully coalesced) for the backward kernels.
+struct StashPtr { char* x; char* y; size_t layer_stride; };  // this wave's 16-KiB blocks of layer 0; +layer_stride per layer
+
+__device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const uint32_t* p8) {
+  uint4* d = reinterpret_cast<uint4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 32);
+  d[0] = uint4{p8[0], p8[1], p8[2], p8[3]};
+  d[1] = uint4{p8[4], p8[5], p8[6], p8[7]};
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 p = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, p);
+}
+
+template <int PREC, bool STASH = false>
 __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* ring, Stream& st, float (&xf)[128], float (&v)[3],
-                                        bool again, int wave, int lane) {
+                                        bool again, int wave, int lane, StashPtr sp = StashPtr{nullptr, nullptr, 0}) {
+  static_assert(!STASH || PREC == SO3X_PREC_BF16, "the training stash is the bf16 path's");
   constexpr int CB = chunk_bytes<PREC>();
-  constexpr int DMA = dma_per_chunk<PREC>();
+  // with stash stores in flight the counted waits cannot tell DMAs from stores: wait for everything
+  constexpr int DMA = STASH ? 0 : dma_per_chunk<PREC>();
+  auto stash_x = [&](const Operand<PREC>& o, int l) {
+    if constexpr (STASH) {
+#pragma unroll
+      for (int to = 0; to < 8; to++) stash_tile(sp.x + l * sp.layer_stride, to, lane, &o.hi[8 * to]);
+    }
+  };
+  auto stash_y = [&](const f32x16& a, int l, int to) {
+    if constexpr (STASH) {
+      uint32_t p8[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) p8[i] = pack2(a[2 * i], a[2 * i + 1]);
+      stash_tile(sp.y + l * sp.layer_stride, to, lane, p8);
+    }
+  };
   const bool late = PREC == SO3X_PREC_BF16 && (wave >> 2);  // the SIMD partner that runs its SiLU half a chunk later
   Operand<PREC> op;
   refresh<PREC>(op, xf);
+  stash_x(op, 0);
   f32x16 acc;
   int slot = st.slot;
   // the counted waits below assume that this wave's only outstanding memory operations are the ring's DMAs
@@ -230,12 +263,13 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
       }
       if (late) {
         if (to > 0) residual<PREC>(acc, xf, to - 1);
-        else if (l > 0) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); }
+        else if (l > 0) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); stash_x(op, l); }
       }
       acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
+      stash_y(acc, l, to);
       if (!late) {
         residual<PREC>(acc, xf, to);
-        if (to == 7) refresh<PREC>(op, xf);
+        if (to == 7) { refresh<PREC>(op, xf); stash_x(op, l + 1); }
       }
       slot = slot == 2 ? 0 : slot + 1;
     }
@@ -243,7 +277,7 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
   // output layer: chunk 48.  Outstanding DMAs here: chunk 48 itself and, with `again`, chunk 0 of the next pass.
   if (again) ring_sync<DMA>(); else ring_sync<0>();
   if (again) issue_chunk<PREC>(gimg, ring, 1, slot == 0 ? 2 : slot - 1, wave, lane);
-  if (late) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); }
+  if (late) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); stash_x(op, NBLK); }
   acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
   v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2];  // rows 0,1,2 = regs 0,1,2 of the lower half
   st.slot = slot == 2 ? 0 : slot + 1;
@@ -263,10 +297,11 @@ __device__ __forceinline__ void fill_input(float (&xf)[128], const float (&R)[9]
 }
 
 // ---- standalone forward ----------------------------------------------------------------------
-template <int PREC>
+template <int PREC, bool STASH = false>
 __global__ void __launch_bounds__(64 * n_waves<PREC>(), 1)
 k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int T, const float* __restrict__ R,
-             const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, int64_t n) {
+             const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, int64_t n, char* stash_x = nullptr,
+             char* stash_y = nullptr, size_t layer_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int NW = n_waves<PREC>();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
@@ -283,8 +318,10 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
     tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
     float xf[128], v[3];
     fill_input(xf, Rm, x0tab + tt * 256, h);
-    forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, v, g + gridDim.x < ngroups, wave, lane);
-    if (live && h == 0) {
+    const size_t blk = (size_t)(g * NW + wave) * 16384;  // this wave's 32-sample block within a layer of the stash
+    forward<PREC, STASH>(reinterpret_cast<const char*>(gimg), ring, st, xf, v, g + gridDim.x < ngroups, wave, lane,
+                         StashPtr{stash_x + blk, stash_y + blk, layer_stride});
+    if (out && live && h == 0) {
       out[idx * 3] = v[0]; out[idx * 3 + 1] = v[1]; out[idx * 3 + 2] = v[2];
     }
   }
@@ -327,6 +364,223 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
     rmat_from_quat(qnormalize(q), Rm);
     if (live && h == 0) store_rot9(x_out, idx, Rm);
   }
+}
+
+// =============================================================================================
+// Backward (training), bf16 operands: gradients wrt the 392,448 parameters for a given dL/dout.
+//   so3x_resnet_bwd = [forward with stash] -> k_resnet_bwd (dX chain, writes dZ_l) -> k_resnet_dw (dW_l = dZ_l^T X_l,
+//   split over sample ranges, fp32 partials) -> k_resnet_dw_reduce (fixed-order sum into the flat gradient).
+// All three per-sample streams (X_l, Y_l, dZ_l) live in the workspace in the register-dump layout of StashPtr.
+// =============================================================================================
+constexpr int NTILE_T = NBLK * 8;  // transposed-weight tiles, stream order: layers 5..0, input-row tile 0..7
+
+// transposed image: tile (layer l, input-row tile ti): A[m][k] = W_l[o(k)][32 ti + m], k in the operand order of the packed
+// dZ registers (the same permutation as the forward image); true (unscaled) weights; the constant-one row gets no gradient.
+__global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict__ params, void* __restrict__ img) {
+  const int tile = blockIdx.x, l = NBLK - 1 - (tile >> 3), ti = tile & 7;
+  const float* W = params + (size_t)l * LAYER_STRIDE;
+  for (int p = threadIdx.x; p < 1024; p += blockDim.x) {
+    const int lane = p & 63, m = lane & 31, h = lane >> 5, ks = p >> 6;
+    const int i = 32 * ti + m;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int o = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+      v[j] = (__bf16)((o < DW && i < DW) ? W[o * DW + i] : 0.0f);
+    }
+    reinterpret_cast<bf16x8*>(img)[(size_t)tile * 1024 + p] = v;
+  }
+}
+
+__device__ __forceinline__ void load_tile(const char* blk, int to, int lane, uint32_t* p8) {
+  const uint4* s = reinterpret_cast<const uint4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 32);
+  const uint4 a = s[0], b = s[1];
+  p8[0] = a.x; p8[1] = a.y; p8[2] = a.z; p8[3] = a.w; p8[4] = b.x; p8[5] = b.y; p8[6] = b.z; p8[7] = b.w;
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// dX chain of one workgroup pass (8 waves x 32 samples):  dX_6 = W_out^T dout;  for l = 5..0:
+//   dZ_l = dX_{l+1} * silu'(Z_l)  (stored for k_resnet_dw),  dX_l = dX_{l+1} + W_l^T dZ_l  (MFMA, C = the dX tile itself).
+// The transposed weight tiles stream through the same 3-slot LDS ring as the forward's.
+__global__ void __launch_bounds__(512, 1)
+k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ params, const float* __restrict__ dout,
+             const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int PREC = SO3X_PREC_BF16, CB = chunk_bytes<PREC>();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t ngroups = (n + 255) / 256;
+  const char* gimg = reinterpret_cast<const char*>(gimg_t);
+  const float* Wout = params + (size_t)NBLK * LAYER_STRIDE;
+  int slot = 0;
+  issue_chunk<PREC>(gimg, ring, 0, 0, wave, lane);
+  issue_chunk<PREC>(gimg, ring, 1, 1, wave, lane);
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t idx = (g * 8 + wave) * 32 + col;
+    const bool live = idx < n;
+    const size_t blk = (size_t)(g * 8 + wave) * 16384;
+    const bool again_group = g + gridDim.x < ngroups;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (live) { d0 = dout[idx * 3]; d1 = dout[idx * 3 + 1]; d2 = dout[idx * 3 + 2]; }
+    f32x16 dx[8];
+    const float* Wo = Wout;
+    asm volatile("" : "+s"(Wo));  // opaque per group: else the 384 loop-invariant loads are hoisted out of the group loop and spilled
+#pragma unroll
+    for (int tq = 0; tq < 32; tq++) {  // rows 32 tin + 8 q + 4 h + (0..3) of W_out^T dout; rows >= 255 read the bias (harmless: the one-row has no gradient path)
+      const int f0 = 8 * tq + 4 * h;
+      __builtin_amdgcn_sched_barrier(0);  // keep the 384 weight loads from being hoisted together
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int f = f0 + r;
+        const float w0 = f < DW ? Wo[f] : 0.f, w1 = f < DW ? Wo[DW + f] : 0.f, w2 = f < DW ? Wo[2 * DW + f] : 0.f;
+        dx[tq >> 2][4 * (tq & 3) + r] = w0 * d0 + w1 * d1 + w2 * d2;
+      }
+    }
+    {  // dZ of the output layer = dout in rows 0..2 of tile 0 (rows 0..3 live in regs 0..3 of the lower half)
+      uint32_t p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (h == 0) { p8[0] = pack2(d0, d1); p8[1] = pack2(d2, 0.f); }
+      stash_tile(stash_dz + NBLK * layer_stride + blk, 0, lane, p8);
+    }
+#pragma unroll 1
+    for (int l = NBLK - 1; l >= 0; l--) {
+      uint32_t dzop[64];
+#pragma unroll
+      for (int to = 0; to < 8; to++) {
+        uint32_t y8[8];
+        __builtin_amdgcn_sched_barrier(0);  // one tile's loads in flight at a time
+        load_tile(stash_y + l * layer_stride + blk, to, lane, y8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          float g2[2];
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const float y = e ? bf_hi(y8[i]) : bf_lo(y8[i]);                  // = -log2(e) z
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+            const float z = y * (1.0f / kFoldS);
+            g2[e] = dx[to][2 * i + e] * (sg * fmaf(z, 1.0f - sg, 1.0f));      // silu'(z) = s (1 + z (1 - s))
+          }
+          dzop[8 * to + i] = pack2(g2[0], g2[1]);
+        }
+        stash_tile(stash_dz + l * layer_stride + blk, to, lane, &dzop[8 * to]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counted waits below see only the ring's DMAs
+#pragma unroll
+      for (int ti = 0; ti < 8; ti++) {
+        const int c = 8 * (NBLK - 1 - l) + ti;
+        ring_sync<dma_per_chunk<PREC>()>();
+        {
+          const int nslot = slot == 0 ? 2 : slot - 1;
+          if (c + 2 < NTILE_T) issue_chunk<PREC>(gimg, ring, c + 2, nslot, wave, lane);
+          else if (again_group) issue_chunk<PREC>(gimg, ring, c + 2 - NTILE_T, nslot, wave, lane);
+        }
+        const bf16x8* A = reinterpret_cast<const bf16x8*>(ring + slot * CB);
+        f32x16 a = dx[ti];
+#pragma unroll
+        for (int gk = 0; gk < 4; gk++) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 4 * gk; k < 4 * gk + 4; k++) {
+            const u32x4 b = {dzop[4 * k], dzop[4 * k + 1], dzop[4 * k + 2], dzop[4 * k + 3]};
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * 64 + lane], __builtin_bit_cast(bf16x8, b), a, 0, 0, 0);
+          }
+        }
+        dx[ti] = a;
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+    }
+  }
+}
+
+// dW_l = sum over samples dZ_l^T X_l: one workgroup = one (layer, sample range); wave w owns output rows 32w..32w+31
+// x all 256 columns (8 accumulator tiles).  Per 32-sample block the two 16-KiB register dumps are copied to LDS as they
+// are and read back as MFMA operands with ds_read_b64_tr_b16 (K = the sample index): the quad (sample s, features
+// 4 fq .. 4 fq+3) of a dump sits at  (fq >> 3) 2048 + s 64 + (fq & 1) 32 + ((fq >> 1) & 3) 8.
+struct DumpReadLane { int off[2]; };  // [part]: samples +0 / +4
+__device__ __forceinline__ DumpReadLane dump_read_lane(int lane) {
+  const int hh = lane >> 5, l32 = lane & 31, G = l32 >> 4, q = (l32 & 15) >> 2, pp = l32 & 3;
+  const int fq = 4 * G + pp;  // feature quad within the 32-feature tile
+  DumpReadLane L;
+#pragma unroll
+  for (int part = 0; part < 2; part++) L.off[part] = (8 * hh + q + 4 * part) * 64 + (fq & 1) * 32 + ((fq >> 1) & 3) * 8;
+  return L;
+}
+// operand = 8 bf16: samples 16 ks + 8 (lane >> 5) + 0..7 of feature 32 ft + (lane & 31)
+__device__ __forceinline__ bf16x8 dump_frag(const char* img, const DumpReadLane& L, int ft, int ks) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const int konst = ft * 2048 + ks * 1024;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[0]));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[1]));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int DW_SPLITS = 36;  // (6 + 1) layers x 36 sample ranges = 252 workgroups
+
+__global__ void __launch_bounds__(512, 1)
+k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz, size_t layer_stride, int64_t nblk32,
+            float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][16384];  // [buffer][X | dZ]
+  const int l = blockIdx.x / DW_SPLITS, split = blockIdx.x % DW_SPLITS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t per = (nblk32 + DW_SPLITS - 1) / DW_SPLITS;
+  const int64_t b0 = split * per, b1 = b0 + per < nblk32 ? b0 + per : nblk32;
+  const char* xs = stash_x + l * layer_stride;
+  const char* ds = stash_dz + l * layer_stride;
+  const DumpReadLane RL = dump_read_lane(lane);
+  f32x16 acc[8];
+#pragma unroll
+  for (int tj = 0; tj < 8; tj++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[tj][r] = 0.0f;
+  uint4 px[2], pd[2];  // this thread's 2 x 16 B of each dump, prefetched one block ahead
+  auto fetch = [&](int64_t b) {
+    const uint4* sx = reinterpret_cast<const uint4*>(xs + (size_t)b * 16384);
+    const uint4* sd = reinterpret_cast<const uint4*>(ds + (size_t)b * 16384);
+    px[0] = sx[threadIdx.x]; px[1] = sx[threadIdx.x + 512];
+    pd[0] = sd[threadIdx.x]; pd[1] = sd[threadIdx.x + 512];
+  };
+  if (b0 < b1) fetch(b0);
+  int buf = 0;
+  for (int64_t b = b0; b < b1; b++) {
+    uint4* dxl = reinterpret_cast<uint4*>(lds[buf][0]);
+    uint4* ddl = reinterpret_cast<uint4*>(lds[buf][1]);
+    dxl[threadIdx.x] = px[0]; dxl[threadIdx.x + 512] = px[1];
+    ddl[threadIdx.x] = pd[0]; ddl[threadIdx.x + 512] = pd[1];
+    __syncthreads();  // one barrier per block: the other buffer was last read two iterations ago
+    if (b + 1 < b1) fetch(b + 1);
+    const bool head = l == NBLK;  // output layer: only rows 0..2 (tile-row 0) carry a gradient
+    if (!head || wave == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const bf16x8 a = dump_frag(lds[buf][1], RL, wave, ks);
+#pragma unroll
+        for (int tj = 0; tj < 8; tj++) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dump_frag(lds[buf][0], RL, tj, ks), acc[tj], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+  // partial[l][split][o][f], o = 32 wave + row(reg, h), f = 32 tj + (lane & 31)
+  float* P = partial + ((size_t)l * DW_SPLITS + split) * 65536;
+  const int n32 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tj = 0; tj < 8; tj++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) P[(32 * wave + row_of(r, h)) * 256 + 32 * tj + n32] = acc[tj][r];
+}
+
+// fixed-order sum of the split partials into the flat gradient (state_dict order); column 255 = the bias
+__global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restrict__ partial, float* __restrict__ dparams) {
+  const int l = blockIdx.y, o = blockIdx.x, f = threadIdx.x;
+  const int rows = l < NBLK ? DW : 3;
+  if (o >= rows || f >= 256) return;
+  const float* P = partial + (size_t)l * DW_SPLITS * 65536 + o * 256 + f;
+  float s = 0.0f;
+  for (int k = 0; k < DW_SPLITS; k++) s += P[(size_t)k * 65536];
+  float* base = dparams + (size_t)l * LAYER_STRIDE;
+  if (f < DW) base[o * DW + f] = s;
+  else base[rows * DW + o] = s;
 }
 
 const Freqs& host_freqs() {
@@ -385,9 +639,58 @@ int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const
   return check_launch();
 }
 
+// training workspace: [forward image | x0tab | transposed image | X stash 7 layers | Y stash 6 | dZ stash 7 | dW partials]
+struct TrainLayout { size_t img_t, x, y, dz, partial, end, layer_stride; int64_t nblk32; };
+TrainLayout train_layout(int64_t n, int T) {
+  TrainLayout L;
+  L.nblk32 = ((n + 255) / 256) * 8;
+  L.layer_stride = (size_t)L.nblk32 * 16384;
+  L.img_t = (ws_bytes(SO3X_PREC_BF16, T) + 255) & ~(size_t)255;
+  L.x = L.img_t + (size_t)NTILE_T * 16384;
+  L.y = L.x + 7 * L.layer_stride;
+  L.dz = L.y + 6 * L.layer_stride;
+  L.partial = L.dz + 7 * L.layer_stride;
+  L.end = L.partial + (size_t)7 * DW_SPLITS * 65536 * sizeof(float);
+  return L;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table) {
+  (void)precision;
+  return train_layout(n > 0 ? n : 0, t_table).end;
+}
+
+int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
+                    float* dparams, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || !params || !dparams || (n && (!R || !t || !dout)))
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;  // the fp32 path of this network is forward-only
+  const TrainLayout L = train_layout(n, t_table);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)s_;
+  if (n == 0) return (int)hipMemsetAsync(dparams, 0, sizeof(float) * NPARAMS, s);
+  constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
+  char* ws = reinterpret_cast<char*>(workspace);
+  int rc = prep<PREC>(s, params, t_table, workspace);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
+  static int cap_f = 0, cap_b = 0;
+  if (!cap_f) { rc = grid_cap(&k_resnet_fwd<PREC, true>, 512, LDS, &cap_f); if (rc) return rc; }
+  if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
+  const int64_t ngroups = (n + 255) / 256;
+  const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
+  hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap_f ? ngroups : cap_f)), dim3(512), LDS, s, (const void*)ws,
+                     tab, t_table, R, t, t_stride, (float*)nullptr, n, ws + L.x, ws + L.y, L.layer_stride);
+  hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
+                     params, dout, (const char*)(ws + L.y), ws + L.dz, L.layer_stride, n);
+  hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 0, s, (const char*)(ws + L.x), (const char*)(ws + L.dz),
+                     L.layer_stride, L.nblk32, reinterpret_cast<float*>(ws + L.partial));
+  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, reinterpret_cast<const float*>(ws + L.partial), dparams);
+  return check_launch();
+}
 
 size_t so3x_resnet_workspace_bytes(int precision, int t_table) {
   return ws_bytes(precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16, t_table);

@@ -32,6 +32,7 @@ SYMBOLS = (
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
+    "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd",
 )
 
 
@@ -63,6 +64,7 @@ def lib():
                 l.so3x_kernel_sum_workspace_bytes.restype = C.c_size_t
                 l.so3x_mse_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_workspace_bytes.restype = C.c_size_t
+                l.so3x_resnet_train_workspace_bytes.restype = C.c_size_t
                 if l.so3x_abi_version() != 1:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
@@ -456,6 +458,23 @@ def resnet_fwd(params, R, t, t_table, precision=PREC_F32):
         _check(lib().so3x_resnet_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n),
                                      C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "resnet_fwd")
     return out
+
+
+def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16):
+    """dL/dparams [392448] for dL/dout [n, 3] (bf16 operands; fp32 raises So3xError 'unsupported')."""
+    params = _dev(params, "params").reshape(-1)
+    R = _rot_in(R, "x")
+    n = R.numel() // 9
+    tt, stride = _t_arg(t, n)
+    dout = _dev(dout, "dout").reshape(-1, 3)
+    dparams = torch.empty(N_PARAMS_RESNET, dtype=torch.float32, device=R.device)
+    nb = lib().so3x_resnet_train_workspace_bytes(_i64(n), C.c_int(precision), C.c_int(int(t_table)))
+    ws = _workspace(R.device, nb)
+    with _Guard(R):
+        _check(lib().so3x_resnet_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
+                                     _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+               "resnet_bwd")
+    return dparams
 
 
 def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0,

@@ -77,7 +77,13 @@ class SO3Diffusion(nn.Module):
         return self._trap_q, self._trap_p
 
     def _fused_net(self):
-        return self.denoise_fn if isinstance(self.denoise_fn, RotPredict) else None
+        """the denoiser when it is one of the two score networks with fused kernels (so3_train / so3_lock_train RotPredict)"""
+        from .so3_lock_train import RotPredict as WideRotPredict
+        return self.denoise_fn if isinstance(self.denoise_fn, (RotPredict, WideRotPredict)) else None
+
+    @staticmethod
+    def _chain_fn(net):
+        return _b.resnet_p_sample_chain if getattr(net, "kind", "") == "resnet255" else _b.p_sample_chain
 
     @staticmethod
     def _shared_t(t):
@@ -120,7 +126,7 @@ class SO3Diffusion(nn.Module):
         net = self._fused_net()
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
         if net is not None:
-            return _b.p_sample_chain(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
+            return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
                                      seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
                                      precision=net.precision_code)
         tt = t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device, dtype=torch.long)
@@ -148,7 +154,7 @@ class SO3Diffusion(nn.Module):
         if net is not None:
             _, trap_p = self._tables()
             off = _rng.next_offset(T)
-            return _b.p_sample_chain(net.flat_params_nograd(), self._sched, trap_p, x, T - 1, T, seed=_rng.seed(),
+            return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, T - 1, T, seed=_rng.seed(),
                                      rng_offset=off, index_base=self.index_base, precision=net.precision_code)
         for i in reversed(range(T)):
             x = self.p_sample(x, torch.full((b,), i, device=device, dtype=torch.long))

@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-__all__ = ["SinusoidalPosEmb"]
+__all__ = ["SinusoidalPosEmb", "ResLayer"]
 
 
 class SinusoidalPosEmb(nn.Module):
@@ -19,3 +19,15 @@ class SinusoidalPosEmb(nn.Module):
         freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
         ang = x[:, None] * freqs[None, :]
         return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+class ResLayer(nn.Module):
+    """x + layer(x) (reference models.py:28-34); the container the wide score network's state_dict keys go through
+    (`net.<i>.layer.0.weight`).  so3_lock_train.RotPredict evaluates the whole stack in the fused kernels."""
+
+    def __init__(self, layer: nn.Module):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, x):
+        return x + self.layer(x)

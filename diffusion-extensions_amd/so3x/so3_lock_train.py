@@ -1,0 +1,143 @@
+"""The wide residual score network and training script of the reference's so3_lock_train.py:
+RotPredict(d_model=255) = six ResLayer(Linear(255,255)+SiLU) blocks and a Linear(255,3) head on
+[R(9), sin(123), cos(123)], same constructor, forward signature and state_dict keys
+(reference so3_lock_train.py:11-59), evaluated by the streaming-weight MFMA kernels of libso3x
+(so3x_resnet_fwd; fused into the reverse chain by SO3Diffusion -> so3x_resnet_p_sample_chain)."""
+import argparse
+import json
+import os
+import time
+from math import pi
+
+import torch
+from torch import nn
+
+from . import backend as _b
+from .models import SinusoidalPosEmb, ResLayer
+
+__all__ = ["RotPredict", "BATCH", "main"]
+
+BATCH = 32
+_PRECISIONS = {"fp32": _b.PREC_F32, "bf16": _b.PREC_BF16}
+
+
+class _ResNetFn(torch.autograd.Function):
+    """autograd bridge: only the 392,448 parameters need gradients (loss_type='skewvec': inputs and targets carry none)"""
+
+    @staticmethod
+    def forward(ctx, x, t, flat_params, precision, t_table):
+        ctx.save_for_backward(x, t, flat_params)
+        ctx.precision = precision
+        ctx.t_table = t_table
+        return _b.resnet_fwd(flat_params, x, t, t_table, precision)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, t, flat_params = ctx.saved_tensors
+        dparams = _b.resnet_bwd(flat_params, x, t, dout.contiguous(), ctx.t_table, ctx.precision)
+        return None, None, dparams, None, None
+
+
+class RotPredict(nn.Module):
+    kind = "resnet255"  # which fused kernels SO3Diffusion dispatches to
+
+    def __init__(self, d_model=255, out_type="rotmat", in_type="rotmat", precision="fp32"):
+        super().__init__()
+        self.in_type = in_type
+        self.out_type = out_type
+        if in_type != "rotmat" or d_model != 255:
+            raise NotImplementedError("so3x: the wide score network is built for in_type='rotmat', d_model=255")
+        if out_type != "skewvec":
+            # the six2rmat head (so3_lock_train.py:57-58) is unused by every script of the reference (all pass "skewvec")
+            raise NotImplementedError("so3x: only out_type='skewvec' is implemented")
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {list(_PRECISIONS)}")
+        self.precision = precision
+        self.d_out = 3
+        self.time_embedding = SinusoidalPosEmb(d_model - 9)
+        self.net = nn.Sequential(*[ResLayer(nn.Sequential(nn.Linear(d_model, d_model), nn.SiLU())) for _ in range(6)],
+                                 nn.Linear(d_model, self.d_out))
+        self._flat_cache = None
+        # the kernels gather per-timestep input rows from a [T][256] table: T must bound every t.  SO3Diffusion passes
+        # its num_timesteps per call; this attribute is the default for direct calls.
+        self.t_table = 1000
+
+    def flat_params(self) -> torch.Tensor:
+        """The 392,448 parameters in state_dict order; differentiable (autograd routes the fused gradient back to each
+        nn.Linear through the cat)."""
+        return torch.cat([p.reshape(-1) for p in self.net.parameters()])
+
+    def flat_params_nograd(self) -> torch.Tensor:
+        key = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        if self._flat_cache is None or self._flat_cache[0] != key:
+            with torch.no_grad():
+                self._flat_cache = (key, self.flat_params().detach())
+        return self._flat_cache[1]
+
+    @property
+    def precision_code(self) -> int:
+        return _PRECISIONS[self.precision]
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None):
+        tt = self.t_table if t_table is None else int(t_table)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            return _ResNetFn.apply(x, t, self.flat_params(), self.precision_code, tt)
+        return _b.resnet_fwd(self.flat_params_nograd(), x, t, tt, self.precision_code)
+
+
+def main(argv=None):
+    """Training loop of the reference's so3_lock_train.py:64-97 (data = the so3_lerp arc between two Euler rotations,
+    Adam 3e-4), data-parallel over the GPUs of one node when launched with torchrun."""
+    from .diffusion import SO3Diffusion
+    from .util import euler_to_rmat, so3_lerp
+    from . import parallel
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=BATCH, help="global batch (reference: 32)")
+    ap.add_argument("--steps", type=int, default=100000)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--precision", default="fp32", choices=list(_PRECISIONS))
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--log-every", type=int, default=10)
+    ap.add_argument("--save-every", type=int, default=1000)
+    ap.add_argument("--weights", default="weights/weights_so3_lock.pt")
+    args = ap.parse_args(argv)
+
+    ctx = parallel.init()
+    device = ctx.device
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision=args.precision).to(device)
+    net.train()
+    parallel.broadcast_parameters(net, ctx)
+    process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
+    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr)
+    R_1 = euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None].to(device)
+    R_2 = euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None].to(device)
+    lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)
+    process.index_base = lo
+    gen = torch.Generator(device=device).manual_seed(1234 + ctx.rank)
+    t0 = time.time()
+    sumloss = 0.0
+    for i in range(1, args.steps + 1):
+        weight = torch.rand(hi - lo, 1, device=device, generator=gen)
+        truepos = so3_lerp(R_1, R_2, weight)
+        loss = process(truepos)
+        if torch.isnan(loss).any():  # so3_lock_train.py:83-84
+            continue
+        optim.zero_grad()
+        loss.backward()
+        parallel.allreduce_gradients(net, ctx)
+        optim.step()
+        sumloss += parallel.mean_scalar(loss.detach(), ctx)
+        if i % args.log_every == 0:
+            if ctx.rank == 0:
+                print(json.dumps({"step": i, "loss": sumloss / args.log_every, "elapsed_s": round(time.time() - t0, 3)}), flush=True)
+            sumloss = 0.0
+        if i % args.save_every == 0 and ctx.rank == 0:
+            os.makedirs(os.path.dirname(args.weights) or ".", exist_ok=True)
+            torch.save(net.state_dict(), args.weights)
+    parallel.finalize(ctx)
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@ import torch
 from . import backend as _b
 
 __all__ = ["skew2vec", "vec2skew", "orthogonalise", "log_rmat", "aa_to_rmat", "rmat_to_aa", "quat_to_rmat",
-           "rmat_dist", "so3_lerp", "so3_scale", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
+           "rmat_dist", "so3_lerp", "so3_scale", "euler_to_rmat", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
            "MMD", "Ker_2samp_test", "Ker_2samp_log_prob"]
 
 
@@ -66,6 +66,18 @@ def so3_lerp(rot_a: torch.Tensor, rot_b: torch.Tensor, weight: torch.Tensor) -> 
 def so3_scale(rmat: torch.Tensor, scalars: torch.Tensor) -> torch.Tensor:
     """exp(scalars * log(rmat)) (reference util.py:349-361); scalars has 1 or batch elements."""
     return _b.so3_scale(rmat, scalars)
+
+
+def euler_to_rmat(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """R_z(z) @ R_y(y) @ R_x(x) with the reference's sign convention for R_y (R_y[2,0] = +sin y, R_y[0,2] = -sin y;
+    reference util.py:396-423).  Host-side data preparation (two constant rotations in so3_lock_train.py:76-77):
+    plain tensor ops, any device."""
+    cx, sx, cy, sy, cz, sz = torch.cos(x), torch.sin(x), torch.cos(y), torch.sin(y), torch.cos(z), torch.sin(z)
+    one, zero = torch.ones_like(cx), torch.zeros_like(cx)
+    Rx = torch.stack((one, zero, zero, zero, cx, -sx, zero, sx, cx), -1).reshape(*cx.shape, 3, 3)
+    Ry = torch.stack((cy, zero, -sy, zero, one, zero, sy, zero, cy), -1).reshape(*cy.shape, 3, 3)
+    Rz = torch.stack((cz, -sz, zero, sz, cz, zero, zero, zero, one), -1).reshape(*cz.shape, 3, 3)
+    return Rz @ Ry @ Rx
 
 
 def cycle(iterable):

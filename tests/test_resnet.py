@@ -152,3 +152,70 @@ def test_resnet_chain_span_reproducible_and_shard_invariant(B, golden, prec):
     for t in reversed(range(21)):
         x = B.resnet_p_sample_chain(p, sched_d, trap_p, x, t, 1, seed=6, rng_offset=0, precision=prec)
     assert float((x - span).abs().max()) < (1e-4 if prec == 0 else 3e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [96, 700])
+def test_resnet_backward_vs_oracle(B, golden, n):
+    """fused gradient (bf16 operands, fp32 accumulation) vs the fp64 oracle; at n = 96 also vs the reference's autograd"""
+    g = golden["resnet"]
+    rs = np.random.default_rng(n)
+    if n == 96:
+        x, t, tgt = g["x"], g["t"], g["target"]
+    else:
+        x = O.quat_to_rmat(rs.standard_normal((n, 4)).astype(np.float32))
+        t = rs.integers(0, 1000, n)
+        tgt = rs.standard_normal((n, 3)).astype(np.float32)
+    out = O.resnet_fwd(g["params"], x, t, "f64")
+    dout = (2.0 / (3 * n)) * (out - tgt)
+    ref = O.resnet_bwd(g["params"], x, t, dout, "f64")
+    dp = host(B.resnet_bwd(dev(g["params"]), dev(x), dev(t, torch.int64), dev(dout), 1000, precision=1))
+    assert np.isfinite(dp).all()
+    LS = 255 * 255 + 255
+    for l in range(7):                                      # per layer: weights and biases, relative to the layer's gradient norm
+        lo, hi = l * LS, (l + 1) * LS if l < 6 else dp.size
+        err = np.linalg.norm(dp[lo:hi] - ref[lo:hi]) / np.linalg.norm(ref[lo:hi])
+        assert err < 2.5e-2, (l, err)
+    cos = float(dp @ ref / np.linalg.norm(dp) / np.linalg.norm(ref))
+    assert cos > 0.9995, cos
+    if n == 96:
+        assert np.linalg.norm(dp - g["grad"]) / np.linalg.norm(g["grad"]) < 2.5e-2
+    with pytest.raises(B.So3xError):
+        B.resnet_bwd(dev(g["params"]), dev(x), dev(t, torch.int64), dev(dout), 1000, precision=0)
+
+
+@pytest.mark.gpu
+def test_wide_rotpredict_module_and_training_step(B, golden):
+    """so3x.so3_lock_train.RotPredict: the reference's state_dict keys, forward == golden, autograd through the fused
+    backward, SO3Diffusion dispatches its sampler to the wide-network chain kernel."""
+    from so3x.so3_lock_train import RotPredict
+    from so3x.diffusion import SO3Diffusion
+    from so3x import rng
+    g = golden["resnet"]
+    net = RotPredict(out_type="skewvec", precision="bf16")
+    assert list(net.state_dict().keys()) == [str(k) for k in g["param_names"]]
+    off, sd = 0, {}
+    for k, v in net.state_dict().items():
+        sd[k] = torch.from_numpy(g["params"][off:off + v.numel()].reshape(v.shape).copy())
+        off += v.numel()
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    x, t = dev(g["x"]), dev(g["t"], torch.int64)
+    with torch.no_grad():
+        net.precision = "fp32"
+        assert float((net(x, t) - dev(g["out"])).abs().max()) < 2e-5
+        net.precision = "bf16"
+    loss = torch.nn.functional.mse_loss(net(x, t), dev(g["target"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * float(g["loss"])
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.net.parameters()])
+    ref = dev(g["grad"])
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-2
+    proc = SO3Diffusion(net, timesteps=30).to(DEV)
+    rng.manual_seed(3)
+    xs = proc.p_sample_loop((500,))
+    assert xs.shape == (500, 3, 3) and not torch.isnan(xs).any()
+    assert float((xs @ xs.transpose(-1, -2) - torch.eye(3, device=DEV)).abs().max()) < 1e-4
+    l2 = proc(proc.p_sample_loop((64,)))                     # a p_losses training step end to end
+    l2.backward()
+    assert torch.isfinite(l2)

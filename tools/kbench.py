@@ -90,6 +90,29 @@ def main():
                               "mfma_algo_TFLOPs": 34190 * n * steps / ms / 1e9}))
         ms = timeit(lambda: B.p_sample_chain(params, proc._sched, trap_p, x, 600, 1, seed=1, precision=1), reps=10)
         print(json.dumps({"k": "step_bf16", "n": n, "ms": ms, "sample_steps_per_s": n / ms * 1e3}))
+    if "resnet" in which or "resnetchain" in which:
+        FLOP = 781830  # 6 x 2 x 255 x 255 + 6 x 255 (bias adds folded: counted as mul-add) ... algorithmic, per sample
+        pw = torch.randn(B.N_PARAMS_RESNET, device=dev, generator=g) * 0.06
+        proc_t = SO3Diffusion(RotPredict(out_type="skewvec"), timesteps=1000).to(dev)
+        _, trap_p = proc_t._tables()
+        for lg in (16, 18, 20) if "resnet" in which else ():
+            n = 1 << lg
+            x = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+            t = torch.randint(0, 1000, (n,), device=dev)
+            ms = timeit(lambda: B.resnet_fwd(pw, x, t, 1000, precision=1), reps=5, warm=2)
+            print(json.dumps({"k": "resnet_fwd_bf16", "n": n, "ms": ms, "algo_TFLOPs": FLOP * n / ms / 1e9}))
+        if "resnet" in which:
+            n = 1 << 14
+            x = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+            t = torch.randint(0, 1000, (n,), device=dev)
+            ms = timeit(lambda: B.resnet_fwd(pw, x, t, 1000, precision=0), reps=3, warm=1)
+            print(json.dumps({"k": "resnet_fwd_fp32", "n": n, "ms": ms, "algo_TFLOPs": FLOP * n / ms / 1e9}))
+        for lg, steps in ((16, 100), (18, 50)) if "resnet" in which else ((18, 50),):
+            n = 1 << lg
+            x = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+            ms = timeit(lambda: B.resnet_p_sample_chain(pw, proc_t._sched, trap_p, x, 600, steps, seed=1, precision=1), reps=3, warm=1)
+            print(json.dumps({"k": "resnet_chain_bf16", "n": n, "steps": steps, "ms": ms, "sample_steps_per_s": n * steps / ms * 1e3,
+                              "algo_TFLOPs": FLOP * n * steps / ms / 1e9}))
     if "train" in which:
         n = 1 << 19
         x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
