@@ -118,6 +118,52 @@ def train_step_extra(B, torch, proc, net, n=1 << 19, reps=5):
             "algorithmic_TFLOPs": 94120 * n / (ms * 1e-3) / 1e12, "optimizer": "torch Adam"}
 
 
+def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
+    """the 255-wide residual score network of so3_lock_train.py as the chain's denoiser (the shape
+    where the matrix cores are the bound) and one full training step with it.  Algorithmic flops: 781,830 per sample."""
+    from so3x.so3_lock_train import RotPredict as WideNet
+    from so3x.diffusion import SO3Diffusion
+    dev = torch.device("cuda", torch.cuda.current_device())
+    flop = 6 * 2 * 255 * 255 + 6 * 255 + 2 * 255 * 3 + 3
+    torch.manual_seed(0)
+    wnet = WideNet(out_type="skewvec", precision="bf16").to(dev)
+    params = wnet.flat_params_nograd()
+    x = B.quat_to_rmat(torch.randn(n, 4, device=dev))
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms = timed(lambda: B.resnet_p_sample_chain(params, sched, trap_p, x, 600, steps, seed=1, precision=B.PREC_BF16), reps)
+    tf = flop * n * steps / (ms * 1e-3) / 1e12
+    out = {"chain": {"kernel": "k_resnet_chain", "batch": n, "steps_per_launch": steps, "ms_per_launch": ms,
+                     "sample_steps_per_s": n * steps / (ms * 1e-3), "bound": "mfma", "achieved": tf,
+                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_MFMA_PEAK_TFLOPS,
+                     "flop_per_sample_step": flop}}
+    nt = 1 << 19
+    proc = SO3Diffusion(wnet, timesteps=sched.shape[1]).to(dev)
+    x0 = B.quat_to_rmat(torch.randn(nt, 4, device=dev))
+    opt = torch.optim.Adam(wnet.parameters(), lr=3e-4)
+
+    def step():
+        loss = proc(x0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    ms = timed(step, 3)
+    out["train_step"] = {"batch": nt, "ms_per_step": ms, "samples_per_s": nt / (ms * 1e-3), "operands": "bf16",
+                         "algorithmic_TFLOPs": 3 * flop * nt / (ms * 1e-3) / 1e12, "optimizer": "torch Adam"}
+    return out
+
+
 def igso3_eval_roofline(B, torch, n=1 << 20, reps=50):
     """BASELINE config 2: IGSO(3) log-density + score, per-sample eps, HBM-bound kernel.  The C ABI is called
     directly with preallocated outputs, captured once into a HIP graph and replayed, so the events bracket
@@ -263,6 +309,10 @@ def main():
                 line["train_step"] = train_step_extra(B, torch, proc, net)
             except Exception as e:
                 line["train_step"] = {"error": repr(e)}
+            try:
+                line["wide_net"] = wide_net_extra(B, torch, proc._sched, trap_p)
+            except Exception as e:
+                line["wide_net"] = {"error": repr(e)}
         if not args.no_cpu_baseline and ctx.world_size == 1:  # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(T, params.cpu().numpy(), B.cosine_beta_schedule(T))
         print(json.dumps(line), flush=True)

@@ -113,6 +113,24 @@ def main():
             ms = timeit(lambda: B.resnet_p_sample_chain(pw, proc_t._sched, trap_p, x, 600, steps, seed=1, precision=1), reps=3, warm=1)
             print(json.dumps({"k": "resnet_chain_bf16", "n": n, "steps": steps, "ms": ms, "sample_steps_per_s": n * steps / ms * 1e3,
                               "algo_TFLOPs": FLOP * n * steps / ms / 1e9}))
+    if "resnettrain" in which:
+        from so3x.so3_lock_train import RotPredict as WideNet
+        torch.manual_seed(0)
+        wnet = WideNet(out_type="skewvec", precision="bf16").to(dev)
+        wproc = SO3Diffusion(wnet, timesteps=1000).to(dev)
+        opt = torch.optim.Adam(wnet.parameters(), lr=3e-4)
+        for lg in (15, 19):
+            n = 1 << lg
+            x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+
+            def wstep():
+                loss = wproc(x0)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            ms = timeit(wstep, reps=5, warm=2)
+            print(json.dumps({"k": "resnet_train_step_bf16", "n": n, "ms": ms, "samples_per_s": n / ms * 1e3,
+                              "algo_TFLOPs": 3 * 781830 * n / ms / 1e9}))
     if "train" in which:
         n = 1 << 19
         x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
