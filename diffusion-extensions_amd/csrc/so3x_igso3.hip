@@ -232,10 +232,14 @@ int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, 
                              float* score_vec, float* grad_R, int64_t n) {
   if (n < 0 || (n && (!R || !eps || !logp)) || (eps_stride != 0 && eps_stride != 1)) return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
-  // 4 resident blocks per CU at this kernel's register budget: one wave of blocks, every wave streams several tiles
+  // one 64-sample tile per wave, as many workgroups as that takes: measured against a persistent one-wave-of-blocks grid
+  // with software prefetch (1261 blocks at 2^24: 175.8 us) the plain oversubscribed launch wins (65,536 blocks: 164.8 us
+  // = 5.7 TB/s; 2^20: 12.1-12.3 us vs 12.5-12.7) -- the dispatcher rebalances the tail, five resident blocks per CU
+  // already cover the load latency.  The in-kernel tile loop remains for n beyond the cap.
   const int64_t nt64 = (n + kWave - 1) / kWave;
-  const int64_t want = (nt64 + 3) / 4;
-  hipLaunchKernelGGL(k_logprob_score, dim3((unsigned)(want < 1280 ? want : 1280)), dim3(kBlock), 0, (hipStream_t)s, R, eps,
+  int64_t want = (nt64 + 3) / 4;
+  if (want > (1 << 20)) want = 1 << 20;
+  hipLaunchKernelGGL(k_logprob_score, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, R, eps,
                      eps_stride, logp, score_vec, grad_R, n);
   return check_launch();
 }
