@@ -124,7 +124,7 @@ def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
     from so3x.so3_lock_train import RotPredict as WideNet
     from so3x.diffusion import SO3Diffusion
     dev = torch.device("cuda", torch.cuda.current_device())
-    flop = 6 * 2 * 255 * 255 + 6 * 255 + 2 * 255 * 3 + 3
+    flop = 6 * 2 * 255 * 255 + 2 * 255 * 3  # multiply-adds of the 7 linear layers, as MLP_FLOP_PER_SAMPLE counts the 65-wide net
     torch.manual_seed(0)
     wnet = WideNet(out_type="skewvec", precision="bf16").to(dev)
     params = wnet.flat_params_nograd()

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Produces the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r01      ->  gpurun_out/profile_r01/{bench_line.json, stats/, pmc_*/}
+# then `python tools/summarize_profiles.py r01` (no GPU needed) copies the summaries into profiles/.
+tag=${1:-r01}
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/profile_$tag
+mkdir -p $out
+cd $R
+python3 bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
+tail -1 $out/bench_stdout.txt > $out/bench_line.json
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o b -- python3 $R/bench.py --no-cpu-baseline > $out/stats.log 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" \
+           "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 100 > $out/pmc_$i.log 2>&1
+done
+ls $out $out/stats | head -30
+cat $out/bench_line.json | cut -c1-600

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/profile_<tag>/ (tools/profile_round.sh) into the tracked profiles/ directory:
+   <tag>_bench_line.json, <tag>_bench_kernel_stats.csv, <tag>_pmc_<counters>.csv (per-kernel averages) and
+   pmc_traffic.json (what bench.py quotes as roofline.traffic).  No GPU needed."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"profile_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line.json"))
+shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd", "k_q_sample_target",
+           "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw")
+per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
+for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
+    f = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    if not f:
+        continue
+    disp = collections.defaultdict(float)
+    meta = {}
+    for r in csv.DictReader(open(f[0])):
+        key = (r["Dispatch_Id"], r["Counter_Name"])
+        disp[key] += float(r["Counter_Value"])
+        meta[r["Dispatch_Id"]] = (r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0))
+    for (did, cname), v in disp.items():
+        kname, grid = meta[did]
+        short = next((k for k in KERNELS if k in kname), None)
+        if short:
+            per.setdefault(cname, {}).setdefault((short, grid), []).append(v)
+rows = []
+for cname, ks in sorted(per.items()):
+    for (k, grid), vals in sorted(ks.items()):
+        rows.append({"counter": cname, "kernel": k, "grid_size": grid, "dispatches": len(vals), "mean": sum(vals) / len(vals),
+                     "min": min(vals), "max": max(vals)})
+with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    w.writerows(rows)
+
+
+def mean(counter, kernel, grid=None):
+    c = [r for r in rows if r["counter"] == counter and r["kernel"] == kernel and (grid is None or r["grid_size"] == grid)]
+    if not c:
+        return None
+    return max(c, key=lambda r: r["dispatches"])["mean"] if grid is None else c[0]["mean"]
+
+
+line = json.load(open(os.path.join(src, "bench_line.json")))
+n = line["config"]["batch_per_gpu"]
+spl = int(line["roofline"]["steps_per_launch"])
+traffic = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --no-cpu-baseline --steps 300 "
+                   f"--warmup 100` ({tag}); counters are KB per dispatch; FETCH_SIZE is doubled (gfx950 reports half of wide "
+                   "streaming reads, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is"}
+fs, wsz = mean("FETCH_SIZE", "k_p_sample_chain"), mean("WRITE_SIZE", "k_p_sample_chain")
+if fs is not None and wsz is not None:
+    traffic["k_p_sample_chain"] = {"config": {"batch": n, "steps_per_launch": spl, "precision": line["dtype"]},
+                                   "fetch_size_kb": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": int((2 * fs + wsz) * 1024),
+                                   "algorithmic_bytes_per_launch": 72 * n}
+lg = [r for r in rows if r["counter"] == "FETCH_SIZE" and r["kernel"] == "k_logprob_score"]
+if lg:
+    small = min(lg, key=lambda r: r["grid_size"])
+    big = max(lg, key=lambda r: r["grid_size"])
+    def rec(r):
+        w_ = mean("WRITE_SIZE", "k_logprob_score", r["grid_size"])
+        return {"fetch_size_kb": r["mean"], "write_size_kb": w_, "hbm_bytes_per_launch": int((2 * r["mean"] + w_) * 1024)}
+    traffic["k_logprob_score"] = dict(config={"n": 1 << 20}, algorithmic_bytes_per_launch=56 << 20, **rec(small))
+    if big is not small:
+        traffic["k_logprob_score"]["at_n_2p24"] = dict(algorithmic_bytes_per_launch=56 << 24, **rec(big))
+# matrix-pipe utilisation of the two chain kernels: busy cycles are per SIMD, wave cycles are in units of 4 cycles per wave
+util = {}
+for k, waves_per_simd in (("k_p_sample_chain", 3), ("k_resnet_chain", 2)):
+    busy, wc = mean("SQ_VALU_MFMA_BUSY_CYCLES", k), mean("SQ_WAVE_CYCLES", k)
+    if busy and wc:
+        util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_WAVE_CYCLES": wc, "resident_waves_per_simd": waves_per_simd,
+                   "mfma_pipe_busy_frac": busy / (4.0 * wc / waves_per_simd),
+                   "note": "busy cycles summed over SIMDs / (4 x wave-quad-cycles / resident waves per SIMD) = fraction of SIMD-cycles "
+                           "the matrix pipe is executing, at the clock the chip actually holds under this load"}
+traffic["mfma_utilisation"] = util
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1)[:3000])
