@@ -75,15 +75,16 @@ if lg:
     traffic["k_logprob_score"] = dict(config={"n": 1 << 20}, algorithmic_bytes_per_launch=56 << 20, **rec(small))
     if big is not small:
         traffic["k_logprob_score"]["at_n_2p24"] = dict(algorithmic_bytes_per_launch=56 << 24, **rec(big))
-# matrix-pipe utilisation of the two chain kernels: busy cycles are per SIMD, wave cycles are in units of 4 cycles per wave
+# matrix-pipe utilisation of the two chain kernels.  SQ_VALU_MFMA_BUSY_CYCLES sums the cycles each SIMD's matrix pipe is
+# executing (= MFMAs x 32 for v_mfma_f32_32x32x16_bf16, checked against SQ_INSTS_VALU_MFMA_MOPS_BF16); SQ_BUSY_CYCLES is
+# the kernel's duration in shader cycles counted once per shader engine (32 on this chip: 8 XCDs x 4).
 util = {}
-for k, waves_per_simd in (("k_p_sample_chain", 3), ("k_resnet_chain", 2)):
-    busy, wc = mean("SQ_VALU_MFMA_BUSY_CYCLES", k), mean("SQ_WAVE_CYCLES", k)
-    if busy and wc:
-        util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_WAVE_CYCLES": wc, "resident_waves_per_simd": waves_per_simd,
-                   "mfma_pipe_busy_frac": busy / (4.0 * wc / waves_per_simd),
-                   "note": "busy cycles summed over SIMDs / (4 x wave-quad-cycles / resident waves per SIMD) = fraction of SIMD-cycles "
-                           "the matrix pipe is executing, at the clock the chip actually holds under this load"}
+for k in ("k_p_sample_chain", "k_resnet_chain"):
+    busy, sqb = mean("SQ_VALU_MFMA_BUSY_CYCLES", k), mean("SQ_BUSY_CYCLES", k)
+    if busy and sqb:
+        util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sqb, "simds": 1024, "shader_engines": 32,
+                   "mfma_pipe_busy_frac": busy / (1024.0 * sqb / 32.0),
+                   "note": "fraction of SIMD-cycles the matrix pipe is executing, at the clock the chip actually holds under this load"}
 traffic["mfma_utilisation"] = util
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:3000])
