@@ -215,6 +215,17 @@ __device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const ui
   d[0] = uint4{p8[0], p8[1], p8[2], p8[3]};
   d[1] = uint4{p8[4], p8[5], p8[6], p8[7]};
 }
+// fp32 training path: the same dump with 16 fp32 per lane per tile (64 B per lane, 4 KiB per wave-tile, 32 KiB per block)
+__device__ __forceinline__ void stash_tile_f32(char* blk, int to, int lane, const float* v16) {
+  float4* d = reinterpret_cast<float4*>(blk + to * 4096 + (2 * (lane & 31) + (lane >> 5)) * 64);
+#pragma unroll
+  for (int i = 0; i < 4; i++) d[i] = float4{v16[4 * i], v16[4 * i + 1], v16[4 * i + 2], v16[4 * i + 3]};
+}
+__device__ __forceinline__ void load_tile_f32(const char* blk, int to, int lane, float* v16) {
+  const float4* s4 = reinterpret_cast<const float4*>(blk + to * 4096 + (2 * (lane & 31) + (lane >> 5)) * 64);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const float4 v = s4[i]; v16[4 * i] = v.x; v16[4 * i + 1] = v.y; v16[4 * i + 2] = v.z; v16[4 * i + 3] = v.w; }
+}
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 p = {(__bf16)a, (__bf16)b};
@@ -224,22 +235,29 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 template <int PREC, bool STASH = false>
 __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* ring, Stream& st, float (&xf)[128], float (&v)[3],
                                         bool again, int wave, int lane, StashPtr sp = StashPtr{nullptr, nullptr, 0}) {
-  static_assert(!STASH || PREC == SO3X_PREC_BF16, "the training stash is the bf16 path's");
   constexpr int CB = chunk_bytes<PREC>();
   // with stash stores in flight the counted waits cannot tell DMAs from stores: wait for everything
   constexpr int DMA = STASH ? 0 : dma_per_chunk<PREC>();
   auto stash_x = [&](const Operand<PREC>& o, int l) {
-    if constexpr (STASH) {
+    if constexpr (STASH && PREC == SO3X_PREC_BF16) {
 #pragma unroll
       for (int to = 0; to < 8; to++) stash_tile(sp.x + l * sp.layer_stride, to, lane, &o.hi[8 * to]);
+    } else if constexpr (STASH) {
+#pragma unroll
+      for (int to = 0; to < 8; to++) stash_tile_f32(sp.x + l * sp.layer_stride, to, lane, &o.x[16 * to]);
     }
   };
   auto stash_y = [&](const f32x16& a, int l, int to) {
-    if constexpr (STASH) {
+    if constexpr (STASH && PREC == SO3X_PREC_BF16) {
       uint32_t p8[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) p8[i] = pack2(a[2 * i], a[2 * i + 1]);
       stash_tile(sp.y + l * sp.layer_stride, to, lane, p8);
+    } else if constexpr (STASH) {
+      float z[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) z[i] = a[i];
+      stash_tile_f32(sp.y + l * sp.layer_stride, to, lane, z);
     }
   };
   const bool late = PREC == SO3X_PREC_BF16 && (wave >> 2);  // the SIMD partner that runs its SiLU half a chunk later
@@ -318,7 +336,7 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
     tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
     float xf[128], v[3];
     fill_input(xf, Rm, x0tab + tt * 256, h);
-    const size_t blk = (size_t)(g * NW + wave) * 16384;  // this wave's 32-sample block within a layer of the stash
+    const size_t blk = (size_t)(g * NW + wave) * (PREC == SO3X_PREC_F32 ? 32768 : 16384);  // this wave's 32-sample block within a layer of the stash
     forward<PREC, STASH>(reinterpret_cast<const char*>(gimg), ring, st, xf, v, g + gridDim.x < ngroups, wave, lane,
                          StashPtr{stash_x + blk, stash_y + blk, layer_stride});
     if (out && live && h == 0) {
@@ -367,7 +385,7 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
 }
 
 // =============================================================================================
-// Backward (training), bf16 operands: gradients wrt the 392,448 parameters for a given dL/dout.
+// Backward (training): gradients wrt the 392,448 parameters for a given dL/dout; bf16 operands first, fp32 variants below.
 //   so3x_resnet_bwd = [forward with stash] -> k_resnet_bwd (dX chain, writes dZ_l) -> k_resnet_dw (dW_l = dZ_l^T X_l,
 //   split over sample ranges, fp32 partials) -> k_resnet_dw_reduce (fixed-order sum into the flat gradient).
 // All three per-sample streams (X_l, Y_l, dZ_l) live in the workspace in the register-dump layout of StashPtr.
@@ -516,6 +534,153 @@ __device__ __forceinline__ bf16x8 dump_frag(const char* img, const DumpReadLane&
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- fp32 training path (parity path: exact fp32 MFMA, fp32 dumps; one wave per SIMD in the chain kernel) ----------
+__global__ void __launch_bounds__(256) k_resnet_image_t_f32(const float* __restrict__ params, void* __restrict__ img) {
+  const int tile = blockIdx.x, l = NBLK - 1 - (tile >> 3), ti = tile & 7;
+  const float* W = params + (size_t)l * LAYER_STRIDE;
+  for (int p = threadIdx.x; p < 2048; p += blockDim.x) {  // piece = (group g of 4 k-steps, lane)
+    const int lane = p & 63, m = lane & 31, h = lane >> 5, g = p >> 6;
+    const int i = 32 * ti + m;
+    float4 v;
+    float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = 4 * g + u, o = 32 * (k >> 4) + row_of(k & 15, h);
+      e[u] = (o < DW && i < DW) ? W[o * DW + i] : 0.0f;
+    }
+    reinterpret_cast<float4*>(img)[(size_t)tile * 2048 + p] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_resnet_bwd_f32(const void* __restrict__ gimg_t, const float* __restrict__ params, const float* __restrict__ dout,
+                 const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  constexpr int PREC = SO3X_PREC_F32, CB = chunk_bytes<PREC>();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int64_t ngroups = (n + 127) / 128;
+  const char* gimg = reinterpret_cast<const char*>(gimg_t);
+  const float* Wout = params + (size_t)NBLK * LAYER_STRIDE;
+  int slot = 0;
+  issue_chunk<PREC>(gimg, ring, 0, 0, wave, lane);
+  issue_chunk<PREC>(gimg, ring, 1, 1, wave, lane);
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t idx = (g * 4 + wave) * 32 + col;
+    const bool live = idx < n;
+    const size_t blk = (size_t)(g * 4 + wave) * 32768;
+    const bool again_group = g + gridDim.x < ngroups;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (live) { d0 = dout[idx * 3]; d1 = dout[idx * 3 + 1]; d2 = dout[idx * 3 + 2]; }
+    f32x16 dx[8];
+    const float* Wo = Wout;
+    asm volatile("" : "+s"(Wo));
+#pragma unroll
+    for (int tq = 0; tq < 32; tq++) {
+      const int f0 = 8 * tq + 4 * h;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int f = f0 + r;
+        const float w0 = f < DW ? Wo[f] : 0.f, w1 = f < DW ? Wo[DW + f] : 0.f, w2 = f < DW ? Wo[2 * DW + f] : 0.f;
+        dx[tq >> 2][4 * (tq & 3) + r] = w0 * d0 + w1 * d1 + w2 * d2;
+      }
+    }
+    {
+      float z16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (h == 0) { z16[0] = d0; z16[1] = d1; z16[2] = d2; }
+      stash_tile_f32(stash_dz + NBLK * layer_stride + blk, 0, lane, z16);
+    }
+#pragma unroll 1
+    for (int l = NBLK - 1; l >= 0; l--) {
+      float dz[128];
+#pragma unroll
+      for (int to = 0; to < 8; to++) {
+        float z16[16];
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile_f32(stash_y + l * layer_stride + blk, to, lane, z16);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float z = z16[i];
+          const float sg = 1.0f / (1.0f + expf(-z));
+          dz[16 * to + i] = dx[to][i] * (sg * (1.0f + z * (1.0f - sg)));
+        }
+        stash_tile_f32(stash_dz + l * layer_stride + blk, to, lane, &dz[16 * to]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int ti = 0; ti < 8; ti++) {
+        const int c = 8 * (NBLK - 1 - l) + ti;
+        ring_sync<dma_per_chunk<PREC>()>();
+        {
+          const int nslot = slot == 0 ? 2 : slot - 1;
+          if (c + 2 < NTILE_T) issue_chunk<PREC>(gimg, ring, c + 2, nslot, wave, lane);
+          else if (again_group) issue_chunk<PREC>(gimg, ring, c + 2 - NTILE_T, nslot, wave, lane);
+        }
+        const float4* A = reinterpret_cast<const float4*>(ring + slot * CB);
+        f32x16 a = dx[ti];
+#pragma unroll
+        for (int gk = 0; gk < 32; gk++) {
+          if ((gk & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+          const float4 w = A[gk * 64 + lane];
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, dz[4 * gk], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, dz[4 * gk + 1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, dz[4 * gk + 2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, dz[4 * gk + 3], a, 0, 0, 0);
+        }
+        dx[ti] = a;
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+    }
+  }
+}
+
+// fp32 dW: the two 32-KiB dumps of a 32-sample block in LDS (single buffer), operands by ds_read_b32: the value
+// (sample s, feature 32 ft + m) of a dump sits at  ft 4096 + (2 s + ((m >> 2) & 1)) 64 + ((m & 3) + 4 (m >> 3)) 4.
+__global__ void __launch_bounds__(512, 1)
+k_resnet_dw_f32(const char* __restrict__ stash_x, const char* __restrict__ stash_dz, size_t layer_stride, int64_t nblk32,
+                float* __restrict__ partial, int splits) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [X | dZ], 2 x 32 KiB
+  const int l = blockIdx.x / splits, split = blockIdx.x % splits;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+  const int64_t per = (nblk32 + splits - 1) / splits;
+  const int64_t b0 = split * per, b1 = b0 + per < nblk32 ? b0 + per : nblk32;
+  const char* xs = stash_x + l * layer_stride;
+  const char* ds = stash_dz + l * layer_stride;
+  const int lb = (2 * h + ((m >> 2) & 1)) * 64 + ((m & 3) + 4 * (m >> 3)) * 4;  // + 256 per k-step (2 samples)
+  f32x16 acc[8];
+#pragma unroll
+  for (int tj = 0; tj < 8; tj++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[tj][r] = 0.0f;
+  const bool head = l == NBLK;
+  for (int64_t b = b0; b < b1; b++) {
+    const uint4* sx = reinterpret_cast<const uint4*>(xs + (size_t)b * 32768);
+    const uint4* sd = reinterpret_cast<const uint4*>(ds + (size_t)b * 32768);
+    uint4* dxl = reinterpret_cast<uint4*>(lds);
+    uint4* ddl = reinterpret_cast<uint4*>(lds + 32768);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dxl[threadIdx.x + 512 * i] = sx[threadIdx.x + 512 * i]; ddl[threadIdx.x + 512 * i] = sd[threadIdx.x + 512 * i]; }
+    __syncthreads();
+    if (!head || wave == 0) {
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ks++) {
+        const float a = *reinterpret_cast<const float*>(lds + 32768 + wave * 4096 + ks * 256 + lb);
+#pragma unroll
+        for (int tj = 0; tj < 8; tj++) {
+          const float bv = *reinterpret_cast<const float*>(lds + tj * 4096 + ks * 256 + lb);
+          acc[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tj], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* P = partial + ((size_t)l * splits + split) * 65536;
+#pragma unroll
+  for (int tj = 0; tj < 8; tj++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) P[(32 * wave + row_of(r, h)) * 256 + 32 * tj + m] = acc[tj][r];
+}
+
 constexpr int DW_SPLITS = 36;  // (6 + 1) layers x 36 sample ranges = 252 workgroups
 
 __global__ void __launch_bounds__(512, 1)
@@ -639,14 +804,15 @@ int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const
   return check_launch();
 }
 
-// training workspace: [forward image | x0tab | transposed image | X stash 7 layers | Y stash 6 | dZ stash 7 | dW partials]
+// training workspace: [forward image | x0tab | transposed image | X dumps 7 layers | Y dumps 6 | dZ dumps 7 | dW partials]
 struct TrainLayout { size_t img_t, x, y, dz, partial, end, layer_stride; int64_t nblk32; };
-TrainLayout train_layout(int64_t n, int T) {
+TrainLayout train_layout(int64_t n, int T, int precision) {
+  const bool f32 = precision == SO3X_PREC_F32;
   TrainLayout L;
-  L.nblk32 = ((n + 255) / 256) * 8;
-  L.layer_stride = (size_t)L.nblk32 * 16384;
-  L.img_t = (ws_bytes(SO3X_PREC_BF16, T) + 255) & ~(size_t)255;
-  L.x = L.img_t + (size_t)NTILE_T * 16384;
+  L.nblk32 = f32 ? ((n + 127) / 128) * 4 : ((n + 255) / 256) * 8;   // whole workgroup passes
+  L.layer_stride = (size_t)L.nblk32 * (f32 ? 32768 : 16384);
+  L.img_t = (ws_bytes(precision, T) + 255) & ~(size_t)255;
+  L.x = L.img_t + (size_t)NTILE_T * (f32 ? 32768 : 16384);
   L.y = L.x + 7 * L.layer_stride;
   L.dz = L.y + 6 * L.layer_stride;
   L.partial = L.dz + 7 * L.layer_stride;
@@ -659,36 +825,58 @@ TrainLayout train_layout(int64_t n, int T) {
 extern "C" {
 
 size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table) {
-  (void)precision;
-  return train_layout(n > 0 ? n : 0, t_table).end;
+  return train_layout(n > 0 ? n : 0, t_table, precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16).end;
 }
 
 int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
                     float* dparams, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
   if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || !params || !dparams || (n && (!R || !t || !dout)))
     return SO3X_ERR_INVALID_ARG;
-  if (precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;  // the fp32 path of this network is forward-only
-  const TrainLayout L = train_layout(n, t_table);
+  if (precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
+  const TrainLayout L = train_layout(n, t_table, precision);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)s_;
   if (n == 0) return (int)hipMemsetAsync(dparams, 0, sizeof(float) * NPARAMS, s);
-  constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
   char* ws = reinterpret_cast<char*>(workspace);
-  int rc = prep<PREC>(s, params, t_table, workspace);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
-  static int cap_f = 0, cap_b = 0;
-  if (!cap_f) { rc = grid_cap(&k_resnet_fwd<PREC, true>, 512, LDS, &cap_f); if (rc) return rc; }
-  if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
-  const int64_t ngroups = (n + 255) / 256;
-  const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
-  hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap_f ? ngroups : cap_f)), dim3(512), LDS, s, (const void*)ws,
-                     tab, t_table, R, t, t_stride, (float*)nullptr, n, ws + L.x, ws + L.y, L.layer_stride);
-  hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
-                     params, dout, (const char*)(ws + L.y), ws + L.dz, L.layer_stride, n);
-  hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 0, s, (const char*)(ws + L.x), (const char*)(ws + L.dz),
-                     L.layer_stride, L.nblk32, reinterpret_cast<float*>(ws + L.partial));
-  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, reinterpret_cast<const float*>(ws + L.partial), dparams);
+  float* partial = reinterpret_cast<float*>(ws + L.partial);
+  int rc;
+  if (precision == SO3X_PREC_BF16) {
+    constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
+    if ((rc = prep<PREC>(s, params, t_table, workspace))) return rc;
+    hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
+    static int cap_f = 0, cap_b = 0;
+    if (!cap_f) { rc = grid_cap(&k_resnet_fwd<PREC, true>, 512, LDS, &cap_f); if (rc) return rc; }
+    if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
+    const int64_t ngroups = (n + 255) / 256;
+    const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
+    hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap_f ? ngroups : cap_f)), dim3(512), LDS, s, (const void*)ws,
+                       tab, t_table, R, t, t_stride, (float*)nullptr, n, ws + L.x, ws + L.y, L.layer_stride);
+    hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
+                       params, dout, (const char*)(ws + L.y), ws + L.dz, L.layer_stride, n);
+    hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 0, s, (const char*)(ws + L.x), (const char*)(ws + L.dz),
+                       L.layer_stride, L.nblk32, partial);
+  } else {
+    constexpr int PREC = SO3X_PREC_F32, LDS = RING * chunk_bytes<PREC>();
+    if ((rc = prep<PREC>(s, params, t_table, workspace))) return rc;
+    hipLaunchKernelGGL(k_resnet_image_t_f32, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
+    static int cap_f = 0, cap_b = 0, dw_attr = 0;
+    if (!cap_f) { rc = grid_cap(&k_resnet_fwd<PREC, true>, 256, LDS, &cap_f); if (rc) return rc; }
+    if (!cap_b) { rc = grid_cap(&k_resnet_bwd_f32, 256, LDS, &cap_b); if (rc) return rc; }
+    if (!dw_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resnet_dw_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      if (e != hipSuccess) return (int)e;
+      dw_attr = 1;
+    }
+    const int64_t ngroups = (n + 127) / 128;
+    const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
+    hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap_f ? ngroups : cap_f)), dim3(256), LDS, s, (const void*)ws,
+                       tab, t_table, R, t, t_stride, (float*)nullptr, n, ws + L.x, ws + L.y, L.layer_stride);
+    hipLaunchKernelGGL(k_resnet_bwd_f32, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(256), LDS, s, (const void*)(ws + L.img_t),
+                       params, dout, (const char*)(ws + L.y), ws + L.dz, L.layer_stride, n);
+    hipLaunchKernelGGL(k_resnet_dw_f32, dim3(7 * DW_SPLITS), dim3(512), 65536, s, (const char*)(ws + L.x), (const char*)(ws + L.dz),
+                       L.layer_stride, L.nblk32, partial, DW_SPLITS);
+  }
+  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, (const float*)partial, dparams);
   return check_launch();
 }
 

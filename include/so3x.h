@@ -179,9 +179,9 @@ size_t so3x_resnet_workspace_bytes(int precision, int t_table);
 int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
                     int64_t t_stride, float* out, int64_t n, int precision, int t_table,
                     void* workspace, size_t workspace_bytes);
-/* autograd of so3x_resnet_fwd for a given dL/dout[n][3] -> dparams[392448] (overwritten).  bf16 operands only
- * (SO3X_ERR_UNSUPPORTED otherwise): forward recomputed with its layer inputs and pre-activations parked in the
- * workspace (~10 KB per sample), dX chain and dW GEMMs on the matrix cores, deterministic reduction. */
+/* autograd of so3x_resnet_fwd for a given dL/dout[n][3] -> dparams[392448] (overwritten): forward recomputed with
+ * its layer inputs and pre-activations parked in the workspace (~10 KB per sample with bf16 operands, ~20 KB in
+ * fp32), dX chain and dW GEMMs on the matrix cores, deterministic reduction. */
 size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table);
 int so3x_resnet_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
                     int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,

@@ -180,8 +180,15 @@ def test_resnet_backward_vs_oracle(B, golden, n):
     assert cos > 0.9995, cos
     if n == 96:
         assert np.linalg.norm(dp - g["grad"]) / np.linalg.norm(g["grad"]) < 2.5e-2
-    with pytest.raises(B.So3xError):
-        B.resnet_bwd(dev(g["params"]), dev(x), dev(t, torch.int64), dev(dout), 1000, precision=0)
+    # fp32 path (exact fp32 MFMA, fp32 dumps): the reference's own precision
+    dp32 = host(B.resnet_bwd(dev(g["params"]), dev(x), dev(t, torch.int64), dev(dout), 1000, precision=0))
+    for l in range(7):
+        lo, hi = l * LS, (l + 1) * LS if l < 6 else dp32.size
+        err = np.linalg.norm(dp32[lo:hi] - ref[lo:hi]) / np.linalg.norm(ref[lo:hi])
+        assert err < 2e-5, (l, err)
+    assert np.abs(dp32 - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    if n == 96:
+        assert np.abs(dp32 - g["grad"]).max() < 2e-5 * max(1.0, np.abs(g["grad"]).max())
 
 
 @pytest.mark.gpu
@@ -211,6 +218,15 @@ def test_wide_rotpredict_module_and_training_step(B, golden):
     got = torch.cat([p.grad.reshape(-1) for p in net.net.parameters()])
     ref = dev(g["grad"])
     assert float((got - ref).norm() / ref.norm()) < 2.5e-2
+    net.precision = "fp32"                                   # the reference's precision end to end
+    net.zero_grad()
+    loss32 = torch.nn.functional.mse_loss(net(x, t), dev(g["target"]))
+    assert abs(float(loss32.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss32.backward()
+    got32 = torch.cat([p.grad.reshape(-1) for p in net.net.parameters()])
+    assert float((got32 - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    net.precision = "bf16"
+    net.zero_grad()
     proc = SO3Diffusion(net, timesteps=30).to(DEV)
     rng.manual_seed(3)
     xs = proc.p_sample_loop((500,))
