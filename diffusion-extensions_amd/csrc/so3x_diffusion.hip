@@ -6,42 +6,48 @@
 #include "so3x_math.hpp"
 #include "so3x_igso3.hpp"
 #include "so3x_mlp.hpp"
+#include "so3x_reverse_step.hpp"
 
 using namespace so3x;
 using namespace so3x::mlp;
 
 namespace {
 
-// rows of the [13][T] schedule table (so3x_schedule_from_betas)
-enum { S_SQRT_AC = 3, S_SQRT_1MAC = 4, S_RECIP = 6, S_RECIPM1 = 7, S_COEF1 = 10, S_COEF2 = 11, S_SIGMA = 12 };
-
 // ---------------------------------------------------------------------------------------
 // A12: noise draw + forward noising + regression target, one pass, 84 B/sample algorithmic
 // (36 x0 in, 36 x_t + 12 target out; +8 for t).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock, 8)
-k_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q, const float* __restrict__ x0,
+// Wave-private staging (one 64-sample tile per wave, no workgroup barrier), launched one tile per wave on an
+// oversubscribed grid like k_logprob_score: the per-sample CDF-row search is a chain of ~10 dependent L2 loads, and
+// only other resident waves hide it.
+__global__ void __launch_bounds__(kBlock, 6)
+k_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q,
+                  const uint16_t* __restrict__ guide_q, const float* __restrict__ x0,
                   const int64_t* __restrict__ t, int quirk_col0, const float* __restrict__ noise_in,
                   const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
                   int64_t index_base, float* __restrict__ x_t, float* __restrict__ target, float* __restrict__ noise_out,
                   int64_t n) {
-  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
-  const int64_t ntiles = (n + kTile - 1) / kTile;
+  __shared__ __attribute__((aligned(16))) float sm[kBlock / kWave][kWave * 9];
+  float* wl = sm[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t ntiles = (n + kWave - 1) / kWave;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
   const int64_t wrow_t = quirk_col0 ? t[0] : -1;  // distributions.py:42-43: column 0 == sample 0's eps
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * kTile;
-    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
-    const int64_t idx = base + threadIdx.x;
-    const bool live = threadIdx.x < cnt;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * kWave;
+    const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
+    const int64_t idx = base + lane;
+    const bool live = lane < cnt;
     const int64_t tt = t[live ? idx : base];
     float nz[9];
     if (noise_in) {
-      load_rows<9>(noise_in, base, cnt, sm, nz);
+      wave_load_rows<9>(noise_in, base, cnt, wl, nz);
     } else {
       float ax[3], u;
       if (axes) {
         float a[3];
-        load_rows<3>(axes, base, cnt, sm, a);
+        wave_load_rows<3>(axes, base, cnt, wl, a);
         float nrm = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);       // distributions.py:36
         ax[0] = a[0] / nrm; ax[1] = a[1] / nrm; ax[2] = a[2] / nrm;
         float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // util.py:201
@@ -54,25 +60,25 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
       }
       const float* row = trap_q + tt * 999;
       const float* wrow = wrow_t >= 0 ? trap_q + wrow_t * 999 : row;
-      const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u);
+      const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tt * kGuidePitch : nullptr);
       exp_axis_angle(ax, ang, nz);
     }
     float x[9], w[3], xs[9], xt[9];
-    load_rows<9>(x0, base, cnt, sm, x);
+    wave_load_rows<9>(x0, base, cnt, wl, x);
     const float k = sched[S_SQRT_AC * T + tt];
     log3(x, w);
     w[0] *= k; w[1] *= k; w[2] *= k;
     exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
     mul33(xs, nz, xt);                // x_blend @ noise, :346
-    if (x_t) store_rows<9>(x_t, base, cnt, sm, xt);
+    if (x_t) wave_store_rows<9>(x_t, base, cnt, wl, xt);
     if (target) {
       float lw[3];
       log3(nz, lw);                   // skew2vec(log_rmat(noise)) * (1/eps), :355
       const float ie = 1.0f / sched[S_SQRT_1MAC * T + tt];
       float tg[3] = {lw[0] * ie, lw[1] * ie, lw[2] * ie};
-      store_rows<3>(target, base, cnt, sm, tg);
+      wave_store_rows<3>(target, base, cnt, wl, tg);
     }
-    if (noise_out) store_rows<9>(noise_out, base, cnt, sm, nz);
+    if (noise_out) wave_store_rows<9>(noise_out, base, cnt, wl, nz);
   }
 }
 
@@ -128,8 +134,6 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
-      const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t];
-      const float c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
       // ---- score network: v = RotPredict(x, t)  (diffusion.py:309)
       if (s > 0) rmat_from_quat(q, R);
       const float* beff = beff_tab + (size_t)t * 96;
@@ -141,36 +145,8 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         const float o = __shfl_xor(vb[j], 32);  // tile B results sit in lanes 0..31, owners are lanes 32..63
         v[j] = h ? o : va[j];
       }
-      // ---- posterior mean (diffusion.py:291-302) in quaternion form:
-      //   x0hat = exp(a log x) exp(b v)^T,   mean = exp(c1 log x0hat) exp(c2 log x)
-      float ax[3], axh[3], vax[3];
-      const float th = quat_axis_angle(q, ax);
-      const float vn = fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-      const float vinv = vn > 0.f ? frcp(vn) : 0.f;
-      vax[0] = v[0] * vinv; vax[1] = v[1] * vinv; vax[2] = v[2] * vinv;
-      const Quat qh = qmul(quat_axis_angle_exp(ax, a * th), quat_axis_angle_exp(vax, -b * vn));
-      const float thh = quat_axis_angle(qh, axh);
-      q = qmul(quat_axis_angle_exp(axh, c1 * thh), quat_axis_angle_exp(ax, c2 * th));
-      if (t != 0) {  // diffusion.py:320-326 -- no noise at t == 0
-        float nax[3], u;
-        if (axes) {
-          float a0 = axes[idc * 3], a1 = axes[idc * 3 + 1], a2 = axes[idc * 3 + 2];
-          float nrm = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
-          nax[0] = a0 / nrm; nax[1] = a1 / nrm; nax[2] = a2 / nrm;
-          float n2 = sqrtf(nax[0] * nax[0] + nax[1] * nax[1] + nax[2] * nax[2]);
-          nax[0] /= n2; nax[1] /= n2; nax[2] /= n2;
-          u = unif[idc];
-        } else {
-          Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset + (uint64_t)t);
-          unit_axis(r.x, r.y, nax);
-          u = u01(r.z);
-        }
-        const float* row = trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
-        const float ang = axes ? igso3_angle<true>(row, row, SO3X_KNOTS_DATA, u) : igso3_angle<false>(row, row, SO3X_KNOTS_DATA, u);
-        q = qmul(q, quat_axis_angle_exp(nax, ang));   // model_mean @ sample, :326
-      }
-      // no per-step renormalisation: q is rebuilt from (axis, angle) pairs every step, so its norm error is
-      // three products' rounding (~3e-7) however long the chain is
+      // ---- posterior mean + noise (diffusion.py:291-326), so3x_reverse_step.hpp
+      q = reverse_step(q, v, sched, T, t, trap_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
     }
     rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
@@ -206,15 +182,19 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
 
 extern "C" {
 
-int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const float* x0, const int64_t* t,
+int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                         const float* x0, const int64_t* t,
                          int quirk_col0, const float* noise_in, const float* axes, const float* unif, uint64_t seed,
                          uint64_t rng_offset, int64_t index_base, float* x_t, float* target, float* noise_out, int64_t n) {
   if (n < 0 || T <= 0 || (n && (!sched || !x0 || !t)) || (n && !noise_in && !trap_q) ||
       ((axes == nullptr) != (unif == nullptr)))
     return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
-  hipLaunchKernelGGL(k_q_sample_target, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, sched,
-                     T, trap_q, x0, t, quirk_col0, noise_in, axes, unif, seed, rng_offset, index_base, x_t, target, noise_out, n);
+  const int64_t nt64 = (n + kWave - 1) / kWave;
+  int64_t want = (nt64 + 3) / 4;   // one tile per wave
+  if (want > (1 << 20)) want = 1 << 20;
+  hipLaunchKernelGGL(k_q_sample_target, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, sched,
+                     T, trap_q, guide_q, x0, t, quirk_col0, noise_in, axes, unif, seed, rng_offset, index_base, x_t, target, noise_out, n);
   return check_launch();
 }
 

@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(kBlock) k_build_tables(const float* __restrict
 
 // ------------------------------------------------------------------ A2 sampling
 __global__ void __launch_bounds__(kBlock)
-k_igso3_sample(const float* __restrict__ trap, const int64_t* __restrict__ row_idx, int64_t row_const, int quirk_col0,
+k_igso3_sample(const float* __restrict__ trap, const uint16_t* __restrict__ guide, const int64_t* __restrict__ row_idx,
+               int64_t row_const, int quirk_col0,
                const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
                int64_t index_base, const float* __restrict__ mean, float* __restrict__ out, float* __restrict__ angle_out,
                float* __restrict__ axis_out, int64_t n) {
@@ -103,7 +104,7 @@ k_igso3_sample(const float* __restrict__ trap, const int64_t* __restrict__ row_i
     const int64_t ri = live ? (row_idx ? row_idx[idx] : row_const) : (row_idx ? row_idx[base] : row_const);
     const float* row = trap + ri * 999;
     const float* wrow = wrow_i >= 0 ? trap + wrow_i * 999 : row;
-    float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u);
+    float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, guide ? guide + ri * kGuidePitch : nullptr);
     float r9[9], o[9];
     exp_axis_angle(ax, ang, r9);
     if (mean) {
@@ -119,6 +120,21 @@ k_igso3_sample(const float* __restrict__ trap, const int64_t* __restrict__ row_i
     if (axis_out) store_rows<3>(axis_out, base, cnt, sm, ax);
     store_rows<9>(out, base, cnt, sm, o);
   }
+}
+
+// search guide of a CDF row: guide[b] = #{k : row[k] <= b / 256}, by the same bisection the samplers use
+static_assert(kGuideBins == SO3X_GUIDE_BINS && kGuidePitch == SO3X_GUIDE_PITCH, "guide geometry");
+__global__ void __launch_bounds__(kGuidePitch + 62) k_build_guide(const float* __restrict__ trap, uint16_t* __restrict__ guide) {
+  const float* row = trap + (int64_t)blockIdx.x * 999;
+  const int b = threadIdx.x;
+  if (b >= kGuidePitch) return;
+  const float u = (float)b * (1.0f / (float)kGuideBins);
+  int lo = 0, hi = 999;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (row[mid] <= u) lo = mid + 1; else hi = mid;
+  }
+  guide[(int64_t)blockIdx.x * kGuidePitch + b] = (uint16_t)(b <= kGuideBins ? lo : 999);
 }
 
 // exact-identity input: the reference's fp64 limit expression; out of line so the fp64 code does not
@@ -217,14 +233,22 @@ int so3x_igso3_build_tables(so3x_stream_t s, const float* eps, int64_t n_rows, f
   return check_launch();
 }
 
-int so3x_igso3_sample(so3x_stream_t s, const float* trap, const int64_t* row_idx, int64_t row_const, int quirk_col0,
+int so3x_igso3_build_guide(so3x_stream_t s, const float* trap, int64_t n_rows, uint16_t* guide) {
+  if (n_rows < 0 || n_rows > 0x7fffffff || (n_rows && (!trap || !guide))) return SO3X_ERR_INVALID_ARG;
+  if (n_rows == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_build_guide, dim3((unsigned)n_rows), dim3(kGuidePitch + 62), 0, (hipStream_t)s, trap, guide);
+  return check_launch();
+}
+
+int so3x_igso3_sample(so3x_stream_t s, const float* trap, const uint16_t* guide, const int64_t* row_idx, int64_t row_const,
+                      int quirk_col0,
                       const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset, int64_t index_base,
                       const float* mean, float* out, float* angle_out, float* axis_out, int64_t n) {
   if (n < 0 || (n && (!trap || !out)) || ((axes == nullptr) != (unif == nullptr)) || row_const < 0)
     return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
   hipLaunchKernelGGL(k_igso3_sample, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, trap,
-                     row_idx, row_const, quirk_col0, axes, unif, seed, rng_offset, index_base, mean, out, angle_out, axis_out, n);
+                     guide, row_idx, row_const, quirk_col0, axes, unif, seed, rng_offset, index_base, mean, out, angle_out, axis_out, n);
   return check_launch();
 }
 

@@ -195,9 +195,22 @@ __device__ __forceinline__ void unit_axis(uint32_t a, uint32_t b, float* ax) {
 // EXACT = true keeps the reference's IEEE division in the interpolation weight (bit-identical angles on the
 // reference's own CDF rows, used by every explicit-draw / parity path); false = 1-ulp reciprocal (in-kernel
 // Philox paths, where no bitwise comparison with the reference is possible anyway).
+// guide (optional, so3x_igso3_build_guide): guide[b] = #{k : row[k] <= b / 256}, b = 0..256, brackets the answer for every
+// u of bin b, so the bisection starts ~4 knots wide instead of 999: with per-sample rows (training: t differs per lane)
+// every probe is its own 128-byte L2 line, and 10 of them per sample made the search L2-bandwidth-bound.
+constexpr int kGuideBins = 256, kGuidePitch = 258;  // = SO3X_GUIDE_BINS / SO3X_GUIDE_PITCH (checked in so3x_igso3.hip)
 template <bool EXACT = true>
-__device__ __forceinline__ float igso3_angle(const float* row, const float* wrow, const float* knots, float u) {
+__device__ __forceinline__ float igso3_angle(const float* row, const float* wrow, const float* knots, float u,
+                                             const uint16_t* guide = nullptr) {
   int lo = 0, hi = 999;  // idx1 = #{k : row[k] <= u}  (row is non-decreasing)
+  if (guide) {
+    int b = (int)(u * (float)kGuideBins);  // exact: power-of-two scale
+    b = b < 0 ? 0 : (b > kGuideBins - 1 ? kGuideBins - 1 : b);
+    const uint32_t g2 = *reinterpret_cast<const uint32_t*>(guide + (b & ~1));  // guide[b & ~1], guide[(b & ~1) + 1] in one load
+    const uint32_t g3 = guide[b + 1];
+    lo = (b & 1) ? (int)(g2 >> 16) : (int)(g2 & 0xffffu);
+    hi = (b & 1) ? (int)g3 : (int)(g2 >> 16);
+  }
 #pragma unroll 1
   while (lo < hi) {
     int mid = (lo + hi) >> 1;

@@ -22,7 +22,8 @@ __device__ __forceinline__ void unit_axis_from(const float* a, float* ax) {  // 
 
 // q_sample + p_losses targets: 84 B (rotation) + 24 B in / 24 B out (shift) per sample
 __global__ void __launch_bounds__(kBlock)
-k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q, float shift_scale,
+k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q,
+                      const uint16_t* __restrict__ guide_q, float shift_scale,
                       const float* __restrict__ x0_rot, const float* __restrict__ x0_shift, const int64_t* __restrict__ t,
                       int quirk_col0, const float* __restrict__ axes, const float* __restrict__ unif,
                       const float* __restrict__ znorm, uint64_t seed, uint64_t rng_offset, int64_t index_base,
@@ -55,7 +56,7 @@ k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __res
     }
     const float* row = trap_q + tt * 999;
     const float* wrow = wrow_t >= 0 ? trap_q + wrow_t * 999 : row;
-    const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u);
+    const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tt * kGuidePitch : nullptr);
     float nz[9], x[9], w[3], xs[9], xt[9], sh[3];
     exp_axis_angle(ax, ang, nz);
     load_rows<9>(x0_rot, base, cnt, sm, x);
@@ -202,7 +203,8 @@ k_rigid_move(const float* __restrict__ rot, const float* __restrict__ shift, con
 
 extern "C" {
 
-int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, float shift_scale,
+int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                             float shift_scale,
                              const float* x0_rot, const float* x0_shift, const int64_t* t, int quirk_col0, const float* axes,
                              const float* unif, const float* znorm, uint64_t seed, uint64_t rng_offset, int64_t index_base,
                              float* xt_rot, float* xt_shift, float* target_rot, float* target_shift, int64_t n) {
@@ -211,7 +213,7 @@ int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const f
     return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
   hipLaunchKernelGGL(k_se3_q_sample_target, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s,
-                     sched, T, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_col0, axes, unif, znorm, seed, rng_offset,
+                     sched, T, trap_q, guide_q, shift_scale, x0_rot, x0_shift, t, quirk_col0, axes, unif, znorm, seed, rng_offset,
                      index_base, xt_rot, xt_shift, target_rot, target_shift, n);
   return check_launch();
 }

@@ -26,7 +26,7 @@ SYMBOLS = (
     "so3x_abi_version", "so3x_error_string", "so3x_schedule_from_betas", "so3x_cosine_beta_schedule",
     "so3x_igso3_knots", "so3x_posemb_freqs", "so3x_quat_to_rmat", "so3x_log_rmat", "so3x_log_rmat_vec",
     "so3x_exp_skewvec", "so3x_so3_scale", "so3x_aa_to_rmat", "so3x_rmat_to_aa", "so3x_so3_lerp",
-    "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_sample",
+    "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_build_guide", "so3x_igso3_sample",
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
@@ -65,7 +65,7 @@ def lib():
                 l.so3x_mse_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_train_workspace_bytes.restype = C.c_size_t
-                if l.so3x_abi_version() != 1:
+                if l.so3x_abi_version() != 2:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -305,8 +305,21 @@ def igso3_build_tables(eps):
     return trap
 
 
+GUIDE_PITCH = 258
+
+
+def igso3_build_guide(trap):
+    """uint16 [rows, 258] search guide of CDF rows (so3x_igso3_build_guide): pass it wherever rows are looked up per sample."""
+    trap = _dev(trap, "trap")
+    rows = trap.numel() // TRAP
+    guide = torch.empty((rows, GUIDE_PITCH), dtype=torch.int16, device=trap.device)
+    with _Guard(trap):
+        _check(lib().so3x_igso3_build_guide(_stream(trap), _ptr(trap), _i64(rows), _ptr(guide)), "igso3_build_guide")
+    return guide
+
+
 def igso3_sample(trap, n, row_idx=None, row_const=0, quirk_col0=False, axes=None, unif=None, seed=0, rng_offset=0,
-                 index_base=0, mean=None, want_angle=False, want_axis=False):
+                 index_base=0, mean=None, want_angle=False, want_axis=False, guide=None):
     trap = _dev(trap, "trap")
     dev = trap.device
     ri = _dev(row_idx, "row_idx", torch.int64).reshape(-1) if row_idx is not None else None
@@ -317,7 +330,7 @@ def igso3_sample(trap, n, row_idx=None, row_const=0, quirk_col0=False, axes=None
     ang = torch.empty(n, dtype=torch.float32, device=dev) if want_angle else None
     axo = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_axis else None
     with _Guard(trap):
-        _check(lib().so3x_igso3_sample(_stream(trap), _ptr(trap), _ptr(ri), _i64(row_const), C.c_int(int(quirk_col0)),
+        _check(lib().so3x_igso3_sample(_stream(trap), _ptr(trap), _ptr(guide), _ptr(ri), _i64(row_const), C.c_int(int(quirk_col0)),
                                        _ptr(ax), _ptr(un), _u64(seed), _u64(rng_offset), _i64(index_base), _ptr(mn),
                                        _ptr(out), _ptr(ang), _ptr(axo), _i64(n)), "igso3_sample")
     return out, ang, axo
@@ -380,7 +393,7 @@ def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0):
 
 # ----------------------------------------------------------------------------- diffusion
 def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None, unif=None, seed=0, rng_offset=0,
-                    index_base=0, want_x_t=True, want_target=True, want_noise=False):
+                    index_base=0, want_x_t=True, want_target=True, want_noise=False, guide_q=None):
     sched = _dev(sched, "sched")
     T = sched.shape[1]
     x0 = _rot_in(x0, "x_start")
@@ -397,7 +410,7 @@ def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None
     tg = torch.empty(x0.shape[:-2] + (3,), dtype=torch.float32, device=dev) if want_target else None
     nzo = torch.empty_like(x0) if want_noise else None
     with _Guard(x0):
-        _check(lib().so3x_q_sample_target(_stream(x0), _ptr(sched), C.c_int(T), _ptr(tq), _ptr(x0), _ptr(tt),
+        _check(lib().so3x_q_sample_target(_stream(x0), _ptr(sched), C.c_int(T), _ptr(tq), _ptr(guide_q), _ptr(x0), _ptr(tt),
                                           C.c_int(int(quirk_col0)), _ptr(nz), _ptr(ax), _ptr(un), _u64(seed),
                                           _u64(rng_offset), _i64(index_base), _ptr(x_t), _ptr(tg), _ptr(nzo), _i64(n)),
                "q_sample_target")
@@ -503,7 +516,7 @@ def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None,
 
 # ----------------------------------------------------------------------------- SE(3) layer
 def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_col0=True, axes=None, unif=None, znorm=None,
-                        seed=0, rng_offset=0, index_base=0, want_targets=True):
+                        seed=0, rng_offset=0, index_base=0, want_targets=True, guide_q=None):
     sched = _dev(sched, "sched")
     T = sched.shape[1]
     x0_rot = _rot_in(x0_rot, "x_start.rot")
@@ -519,7 +532,7 @@ def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_c
     tg_rot = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
     tg_shift = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
     with _Guard(x0_rot):
-        _check(lib().so3x_se3_q_sample_target(_stream(x0_rot), _ptr(sched), C.c_int(T), _ptr(_dev(trap_q, "trap_q")),
+        _check(lib().so3x_se3_q_sample_target(_stream(x0_rot), _ptr(sched), C.c_int(T), _ptr(_dev(trap_q, "trap_q")), _ptr(guide_q),
                                               C.c_float(float(shift_scale)), _ptr(x0_rot), _ptr(x0_shift), _ptr(tt),
                                               C.c_int(int(quirk_col0)), _ptr(ax), _ptr(un), _ptr(zn), _u64(seed),
                                               _u64(rng_offset), _i64(index_base), _ptr(xt_rot), _ptr(xt_shift),

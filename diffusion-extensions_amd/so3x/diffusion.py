@@ -67,6 +67,7 @@ class SO3Diffusion(nn.Module):
         self.register_buffer("_sched", torch.from_numpy(sched.copy()), persistent=False)
         self._trap_q = None  # rows for eps_t = sqrt(1 - abar_t)          (p_losses / q_sample)
         self._trap_p = None  # rows for sigma_t = exp(0.5 * logvar_t)     (p_sample)
+        self._guide_q = None  # search guide of the q rows (looked up per sample: t differs across the batch)
 
     # ------------------------------------------------------------------ tables
     def _tables(self):
@@ -74,6 +75,7 @@ class SO3Diffusion(nn.Module):
         if self._trap_q is None or self._trap_q.device != dev:
             self._trap_q = _b.igso3_build_tables(self._sched[4])
             self._trap_p = _b.igso3_build_tables(self._sched[12])
+            self._guide_q = _b.igso3_build_guide(self._trap_q)
         return self._trap_q, self._trap_p
 
     def _fused_net(self):
@@ -166,7 +168,7 @@ class SO3Diffusion(nn.Module):
         x_t, _, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
                                        axes=axes, unif=unif, seed=_rng.seed(),
                                        rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
-                                       index_base=self.index_base, want_target=False)
+                                       index_base=self.index_base, want_target=False, guide_q=self._guide_q)
         return x_t
 
     def p_losses(self, x_start, t, noise=None, axes=None, unif=None):
@@ -175,7 +177,7 @@ class SO3Diffusion(nn.Module):
         x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
                                                 axes=axes, unif=unif, seed=_rng.seed(),
                                                 rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
-                                                index_base=self.index_base)
+                                                index_base=self.index_base, guide_q=self._guide_q)
         net = self._fused_net()
         # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
         x_recon = net(x_noisy, t, t_table=self.num_timesteps) if net is not None else self.denoise_fn(x_noisy, t)

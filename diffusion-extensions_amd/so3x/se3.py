@@ -139,12 +139,14 @@ class SE3Diffusion(nn.Module):
         self._sigma_host = sched[12].copy()
         self._trap_q = None
         self._trap_p = None
+        self._guide_q = None
 
     def _tables(self):
         dev = self._sched.device
         if self._trap_q is None or self._trap_q.device != dev:
             self._trap_q = _b.igso3_build_tables(self._sched[4])
             self._trap_p = _b.igso3_build_tables(self._sched[12])
+            self._guide_q = _b.igso3_build_guide(self._trap_q)
         return self._trap_q, self._trap_p
 
     @staticmethod
@@ -183,7 +185,7 @@ class SE3Diffusion(nn.Module):
         xt_rot, xt_shift, _, _ = _b.se3_q_sample_target(
             self._sched, trap_q, self.shift_scale, x_start.rot, x_start.shift, t, quirk_col0=self.quirk_col0, axes=axes,
             unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
-            index_base=self.index_base, want_targets=False)
+            index_base=self.index_base, want_targets=False, guide_q=self._guide_q)
         return AffineT(xt_rot, xt_shift)
 
     def p_losses(self, x_start: AffineT, t, noise=None, axes=None, unif=None, znorm=None):
@@ -191,7 +193,7 @@ class SE3Diffusion(nn.Module):
         xt_rot, xt_shift, tg_rot, tg_shift = _b.se3_q_sample_target(
             self._sched, trap_q, self.shift_scale, x_start.rot, x_start.shift, t, quirk_col0=self.quirk_col0, axes=axes,
             unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
-            index_base=self.index_base)
+            index_base=self.index_base, guide_q=self._guide_q)
         x_recon = self.denoise_fn(AffineT(xt_rot, xt_shift), t)
         return _b.mse_loss(x_recon.shift_g, tg_shift) + _b.mse_loss(x_recon.rot_g, tg_rot)
 

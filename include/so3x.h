@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 1
+#define SO3X_ABI_VERSION 2
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -104,6 +104,13 @@ int so3x_igso3_eps_ft(so3x_stream_t s, const float* omega, const float* eps, int
                       float* out, int64_t n);
 /* distributions.py:15-30  CDF table rows: eps[n_rows] -> trap[n_rows][999] */
 int so3x_igso3_build_tables(so3x_stream_t s, const float* eps, int64_t n_rows, float* trap);
+/* Search guide for rows that are looked up per sample (not in the reference: a lookup accelerator with bit-identical
+ * results): guide[n_rows][SO3X_GUIDE_PITCH] uint16, guide[r][b] = #{k : trap[r][k] <= b / SO3X_GUIDE_BINS} for
+ * b = 0..SO3X_GUIDE_BINS (one pad entry keeps rows 4-byte aligned).  Every `guide` argument below is optional
+ * (NULL = full bisection). */
+#define SO3X_GUIDE_BINS 256
+#define SO3X_GUIDE_PITCH 258
+int so3x_igso3_build_guide(so3x_stream_t s, const float* trap, int64_t n_rows, uint16_t* guide);
 /* distributions.py:33-51  inverse-CDF sampling.
  *  trap [n_rows][999]; row_idx int64[n] or NULL (then every sample uses row `row_const`);
  *  quirk_col0 != 0: the interpolation weight is gathered from the row of sample 0
@@ -112,7 +119,7 @@ int so3x_igso3_build_tables(so3x_stream_t s, const float* eps, int64_t n_rows, f
  *      keyed by seed, counter = (index_base + i, rng_offset) so results do not depend on
  *      launch geometry or GPU count.
  *  mean: 9 floats or NULL (identity).  angle_out[n], axis_out[n][3] optional. */
-int so3x_igso3_sample(so3x_stream_t s, const float* trap, const int64_t* row_idx, int64_t row_const,
+int so3x_igso3_sample(so3x_stream_t s, const float* trap, const uint16_t* guide, const int64_t* row_idx, int64_t row_const,
                       int quirk_col0, const float* axes, const float* unif, uint64_t seed,
                       uint64_t rng_offset, int64_t index_base, const float* mean, float* out,
                       float* angle_out, float* axis_out, int64_t n);
@@ -145,7 +152,7 @@ int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int
  * x_t = so3_scale(x0, sqrt(abar_t)) @ noise; target = vee(log noise)/eps_t.
  * sched = device copy of the [13][T] table.  noise_in != NULL teacher-forces the noise
  * (then trap_q/axes/unif are ignored).  x_t, target, noise_out optional outputs. */
-int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q,
+int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                          const float* x0, const int64_t* t, int quirk_col0, const float* noise_in,
                          const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
                          int64_t index_base, float* x_t, float* target, float* noise_out, int64_t n);
@@ -201,7 +208,7 @@ int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float
  *   xt_rot = so3_scale(x0_rot, sqrt(abar)) @ noise_rot,  xt_shift = x0_shift*sqrt(abar) + noise_shift,
  *   target_rot = vee(log noise_rot)/eps,  target_shift = noise_shift/(eps*shift_scale).
  * axes/unif/znorm: explicit draws (all three or none; none = in-kernel Philox + Box-Muller). */
-int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q,
+int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                              float shift_scale, const float* x0_rot, const float* x0_shift,
                              const int64_t* t, int quirk_col0, const float* axes, const float* unif,
                              const float* znorm, uint64_t seed, uint64_t rng_offset, int64_t index_base,

@@ -606,3 +606,36 @@ def test_mmd_statistics_vs_reference_values(mods, golden):
     assert U.Ker_2samp_test(X[:150], X[150:], U.rmat_gaussian_kernel) == bool(g["test_same"])
     assert U.Ker_2samp_test(X[:257], Y, U.rmat_gaussian_kernel) == bool(g["test_diff"])
     assert abs(U.Ker_2samp_log_prob(X[:257], Y, U.rmat_gaussian_kernel) - float(g["logp_diff"])) < 1e-3
+
+
+def test_search_guide_is_bit_identical(mods):
+    """the [rows][258] guide only narrows the bisection's starting bracket: angles, rotations and targets are bitwise the
+    same with and without it, for explicit draws (incl. u = 0 and u just below 1) and Philox draws, per-sample rows"""
+    B = mods["B"]
+    T = 1000
+    sched = dev(B.schedule_from_betas(O.cosine_beta_schedule(T)))
+    for row in (4, 12):
+        trap = B.igso3_build_tables(sched[row])
+        guide = B.igso3_build_guide(trap)
+        gh = host(guide).astype(np.int64) & 0xffff
+        th = host(trap)
+        for r in (0, 1, 500, 999):                       # guide[b] = #{k : row[k] <= b/256}
+            cnt = (th[r][None, :] <= (np.arange(257, dtype=np.float32) / np.float32(256))[:, None]).sum(1)
+            assert (gh[r, :257] == cnt).all()
+        n = 5000
+        gen = torch.Generator(device=DEV).manual_seed(row)
+        ri = torch.randint(0, T, (n,), device=DEV, generator=gen)
+        unif = torch.rand(n, device=DEV, generator=gen)
+        unif[:4] = torch.tensor([0.0, 1.0 - 2.0 ** -24, 0.5, 2.0 ** -30], device=DEV)
+        axes = torch.randn(n, 3, device=DEV, generator=gen)
+        for kw in (dict(axes=axes, unif=unif), dict(seed=3, rng_offset=9)):
+            a = B.igso3_sample(trap, n, row_idx=ri, quirk_col0=True, want_angle=True, **kw)
+            b = B.igso3_sample(trap, n, row_idx=ri, quirk_col0=True, want_angle=True, guide=guide, **kw)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    trap_q = B.igso3_build_tables(sched[4])
+    guide_q = B.igso3_build_guide(trap_q)
+    x0 = mods["util"].quat_to_rmat(torch.randn(3000, 4, device=DEV))
+    t = torch.randint(0, T, (3000,), device=DEV)
+    a = B.q_sample_target(sched, trap_q, x0, t, seed=5, rng_offset=1)
+    b = B.q_sample_target(sched, trap_q, x0, t, seed=5, rng_offset=1, guide_q=guide_q)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

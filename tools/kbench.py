@@ -74,6 +74,8 @@ def main():
             tt = torch.randint(0, 1000, (n,), device=dev, generator=g)
             ms = timeit(lambda: B.q_sample_target(pr._sched, tq, x0, tt, seed=1))
             print(json.dumps({"k": "q_sample_target", "n": n, "ms": ms, "GBs": 92 * n / ms / 1e6, "frac8T": 92 * n / ms / 1e6 / 8000}))
+            ms = timeit(lambda: B.q_sample_target(pr._sched, tq, x0, tt, seed=1, guide_q=pr._guide_q))
+            print(json.dumps({"k": "q_sample_target_guided", "n": n, "ms": ms, "GBs": 92 * n / ms / 1e6, "frac8T": 92 * n / ms / 1e6 / 8000}))
     if "chain" in which or "train" in which:
         torch.manual_seed(0)
         net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
