@@ -152,16 +152,35 @@ template <int PREC>
 __device__ __forceinline__ f32x16 chunk_mfma(const char* slotp, const Operand<PREC>& op, int lane) {
   f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (PREC == SO3X_PREC_BF16) {
-    const bf16x8* A = reinterpret_cast<const bf16x8*>(slotp);
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      __builtin_amdgcn_sched_barrier(0);  // at most four A fragments (16 VGPRs) in flight
-#pragma unroll
-      for (int k = 4 * g; k < 4 * g + 4; k++) {
-        const u32x4 b = {op.hi[4 * k], op.hi[4 * k + 1], op.hi[4 * k + 2], op.hi[4 * k + 3]};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * 64 + lane], __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-      }
-    }
+    // The A fragments are read PF MFMAs (PF x 32 cycles > the LDS latency under 8 reading waves) ahead of their use, with
+    // explicit reads and counted waits: hipcc's own pipeline of this loop waits lgkmcnt(0) before every PF-th MFMA, i.e.
+    // for the read it issued one instruction earlier (+3.5 % on the chain kernel).
+    constexpr int PF = 6;
+    const uint32_t a0 = (uint32_t)(uintptr_t)slotp + lane * 16;  // LDS byte address (low 32 bits of the generic pointer)
+    u32x4 a[16];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the counted waits below assume nothing else is outstanding
+#define SO3X_RD(K) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[K]) : "v"(a0), "n"((K) * 1024))
+#define SO3X_MM(K, LEFT)                                                                                             \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[K]) : "n"(LEFT));                                                  \
+    const u32x4 b = {op.hi[4 * (K)], op.hi[4 * (K) + 1], op.hi[4 * (K) + 2], op.hi[4 * (K) + 3]};                     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[K]), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0); \
+  }
+    SO3X_RD(0); SO3X_RD(1); SO3X_RD(2); SO3X_RD(3); SO3X_RD(4); SO3X_RD(5);
+    SO3X_MM(0, 5) SO3X_RD(6);
+    SO3X_MM(1, 5) SO3X_RD(7);
+    SO3X_MM(2, 5) SO3X_RD(8);
+    SO3X_MM(3, 5) SO3X_RD(9);
+    SO3X_MM(4, 5) SO3X_RD(10);
+    SO3X_MM(5, 5) SO3X_RD(11);
+    SO3X_MM(6, 5) SO3X_RD(12);
+    SO3X_MM(7, 5) SO3X_RD(13);
+    SO3X_MM(8, 5) SO3X_RD(14);
+    SO3X_MM(9, 5) SO3X_RD(15);
+    SO3X_MM(10, 5) SO3X_MM(11, 4) SO3X_MM(12, 3) SO3X_MM(13, 2) SO3X_MM(14, 1) SO3X_MM(15, 0)
+#undef SO3X_RD
+#undef SO3X_MM
+    static_assert(PF == 6, "the schedule above is written out for PF = 6");
   } else {
     const float4* A = reinterpret_cast<const float4*>(slotp);
 #pragma unroll
