@@ -4,5 +4,5 @@ from so3x.diffusion import *  # noqa: F401,F403
 from so3x import diffusion as _impl
 
 __all__ = list(getattr(_impl, "__all__", [n for n in dir(_impl) if not n.startswith("_")]))
-from so3x.se3 import SE3Diffusion  # noqa: E402,F401  (reference diffusion.py:432)
-__all__ = __all__ + ["SE3Diffusion"]
+from so3x.se3 import SE3Diffusion, ProjectedSE3Diffusion  # noqa: E402,F401  (reference diffusion.py:432, 525)
+__all__ = __all__ + ["SE3Diffusion", "ProjectedSE3Diffusion"]

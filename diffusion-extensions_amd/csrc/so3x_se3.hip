@@ -199,9 +199,43 @@ k_rigid_move(const float* __restrict__ rot, const float* __restrict__ shift, con
   }
 }
 
+// PointCloudProj (models.py:75-91, so3 branch): out[b][p] = data[p] @ R_b^T -- one cloud shared by the whole batch,
+// 12 B written per (rotation, point), the cloud and the rotation stay in registers / L1.  One workgroup per rotation
+// and 768-point slab; consecutive threads write consecutive floats.
+__global__ void __launch_bounds__(kBlock)
+k_rotate_cloud(const float* __restrict__ rot, const float* __restrict__ cloud, float* __restrict__ out, int64_t P) {
+  const int64_t b = blockIdx.y;
+  float R[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) R[j] = rot[b * 9 + j];
+  const int64_t f0 = (int64_t)blockIdx.x * (3 * kBlock);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int64_t f = f0 + k * kBlock + threadIdx.x;  // flat index into [P][3]
+    if (f < 3 * P) {
+      const int64_t pt = f / 3;
+      const int j = (int)(f - 3 * pt);
+      const float d0 = cloud[pt * 3], d1 = cloud[pt * 3 + 1], d2 = cloud[pt * 3 + 2];
+      out[b * 3 * P + f] = d0 * R[3 * j] + d1 * R[3 * j + 1] + d2 * R[3 * j + 2];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, float* out, int64_t n, int64_t P) {
+  if (n < 0 || P < 0 || n > 65535 * (int64_t)65535 || ((n && P) && (!rot || !cloud || !out))) return SO3X_ERR_INVALID_ARG;
+  if (n == 0 || P == 0) return SO3X_OK;
+  const unsigned gx = (unsigned)((3 * P + 3 * kBlock - 1) / (3 * kBlock));
+  for (int64_t b0 = 0; b0 < n; b0 += 65535) {  // grid.y limit
+    const int64_t nb = n - b0 < 65535 ? n - b0 : 65535;
+    hipLaunchKernelGGL(k_rotate_cloud, dim3(gx, (unsigned)nb), dim3(kBlock), 0, (hipStream_t)s, rot + b0 * 9, cloud,
+                       out + b0 * 3 * P, P);
+  }
+  return check_launch();
+}
 
 int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                              float shift_scale,

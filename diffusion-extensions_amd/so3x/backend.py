@@ -29,7 +29,7 @@ SYMBOLS = (
     "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_build_guide", "so3x_igso3_sample",
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
-    "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move",
+    "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move", "so3x_rotate_cloud",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
     "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd",
@@ -450,6 +450,17 @@ def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=N
                                          C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un), _u64(seed),
                                          _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision), _ptr(ws),
                                          C.c_size_t(ws.numel())), "p_sample_chain")
+    return out
+
+
+def rotate_cloud(rot, cloud):
+    """cloud [P, 3] @ rot[..., 3, 3]^T -> [..., P, 3]  (PointCloudProj, reference models.py:75-91)"""
+    rot = _rot_in(rot, "x")
+    cloud = _dev(cloud, "data").reshape(-1, 3)
+    n, P = rot.numel() // 9, cloud.shape[0]
+    out = torch.empty(rot.shape[:-2] + (P, 3), dtype=torch.float32, device=rot.device)
+    with _Guard(rot):
+        _check(lib().so3x_rotate_cloud(_stream(rot), _ptr(rot), _ptr(cloud), _ptr(out), _i64(n), _i64(P)), "rotate_cloud")
     return out
 
 

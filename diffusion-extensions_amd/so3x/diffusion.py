@@ -19,7 +19,7 @@ from . import rng as _rng
 from .distributions import IsotropicGaussianSO3
 from .so3_train import RotPredict
 
-__all__ = ["SO3Diffusion", "cosine_beta_schedule", "extract"]
+__all__ = ["SO3Diffusion", "ProjectedSO3Diffusion", "cosine_beta_schedule", "extract"]
 
 _SCHED_NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
                 "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
@@ -184,6 +184,57 @@ class SO3Diffusion(nn.Module):
         return _b.mse_loss(x_recon, target)
 
     def forward(self, x, *args, **kwargs):
+        b = x.shape[0]
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+        return self.p_losses(x, t, *args, **kwargs)
+
+
+class ProjectedSO3Diffusion(SO3Diffusion):
+    """SO3Diffusion whose denoiser sees `projection(x)` instead of the rotation itself (reference diffusion.py:377-429;
+    the projection is any callable, e.g. models.PointCloudProj).  Noising, targets, posterior mean and noise are the fused
+    kernels of the base class; the denoiser and the projection are the caller's."""
+
+    def p_mean_variance(self, x, t, clip_denoised: bool = False):
+        predict = self.denoise_fn(self.projection(x), t)
+        _, model_mean = _b.p_mean(self._sched, x, predict, self._shared_t(t))
+        return model_mean, extract(self.posterior_variance, t, t.shape), \
+            extract(self.posterior_log_variance_clipped, t, t.shape)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, clip_denoised=False, repeat_noise=False, axes=None, unif=None):
+        t0 = self._shared_t(t)
+        mean, _, _ = self.p_mean_variance(x, t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device,
+                                                                                            dtype=torch.long))
+        if t0 == 0:
+            return mean
+        _, trap_p = self._tables()
+        off = _rng.next_offset(self.num_timesteps) if axes is None else 0
+        smp, _, _ = _b.igso3_sample(trap_p, x.numel() // 9, row_const=t0, axes=axes, unif=unif, seed=_rng.seed(),
+                                    rng_offset=off + t0, index_base=self.index_base)
+        return _b.rmul(mean, smp.reshape(x.shape))
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, projection, x_init=None):
+        """reference diffusion.py:391-401: starts from the Q factor of a Gaussian matrix (which may have det -1, as there)"""
+        self.projection = projection
+        device = self.betas.device
+        b = shape[0]
+        x = torch.linalg.qr(torch.randn((b, 3, 3), device=device))[0] if x_init is None else x_init
+        for i in reversed(range(self.num_timesteps)):
+            x = self.p_sample(x, torch.full((b,), i, device=device, dtype=torch.long))
+        return x
+
+    def p_losses(self, x_start, t, noise=None, axes=None, unif=None):
+        trap_q, _ = self._tables()
+        x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
+                                                axes=axes, unif=unif, seed=_rng.seed(),
+                                                rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
+                                                index_base=self.index_base, guide_q=self._guide_q)
+        x_recon = self.denoise_fn(self.projection(x_noisy), t)
+        return _b.mse_loss(x_recon, target)
+
+    def forward(self, x, projection, *args, **kwargs):
+        self.projection = projection
         b = x.shape[0]
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
         return self.p_losses(x, t, *args, **kwargs)

@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-__all__ = ["SinusoidalPosEmb", "ResLayer"]
+__all__ = ["SinusoidalPosEmb", "ResLayer", "PointCloudProj"]
 
 
 class SinusoidalPosEmb(nn.Module):
@@ -31,3 +31,21 @@ class ResLayer(nn.Module):
 
     def forward(self, x):
         return x + self.layer(x)
+
+
+class PointCloudProj(nn.Module):
+    """data @ R^T for a batch of rotations R (reference models.py:75-91): the `projection` callable handed to
+    ProjectedSO3Diffusion / ProjectedSE3Diffusion.  so3=False (Euler-angle input of the Euclidean baselines) converts with
+    util.euler_to_rmat first."""
+
+    def __init__(self, data, so3=True):
+        super().__init__()
+        self.data = data
+        self.so3 = so3
+
+    def forward(self, x):
+        from . import backend as _b
+        if not self.so3:
+            from .util import euler_to_rmat
+            x = euler_to_rmat(*torch.unbind(x, -1))
+        return _b.rotate_cloud(x, self.data)

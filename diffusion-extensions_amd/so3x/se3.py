@@ -15,7 +15,8 @@ from . import rng as _rng
 from .diffusion import _SCHED_NAMES, cosine_beta_schedule, extract
 from .distributions import IsotropicGaussianSO3
 
-__all__ = ["AffineT", "AffineGrad", "ProtData", "se3_scale", "se3_lerp", "IGSO3xR3", "SE3Diffusion", "move_prot"]
+__all__ = ["AffineT", "AffineGrad", "ProtData", "se3_scale", "se3_lerp", "IGSO3xR3", "SE3Diffusion", "ProjectedSE3Diffusion",
+           "move_prot"]
 
 ProtData = namedtuple("ProtData", ["residues", "positions", "angles"])
 
@@ -198,6 +199,46 @@ class SE3Diffusion(nn.Module):
         return _b.mse_loss(x_recon.shift_g, tg_shift) + _b.mse_loss(x_recon.rot_g, tg_rot)
 
     def forward(self, x: AffineT, *args, **kwargs):
+        b = len(x)
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+        return self.p_losses(x, t, *args, **kwargs)
+
+
+class ProjectedSE3Diffusion(SE3Diffusion):
+    """SE3Diffusion whose denoiser sees `projection(x)` (reference diffusion.py:525-573).  The reference's constructor does
+    not forward `shift_scale` to its base class and then sets the attribute itself (527-529); the effect -- the given
+    shift_scale is used everywhere -- is what this class does."""
+
+    def p_mean_variance(self, x: AffineT, t, clip_denoised: bool = False):
+        predict = self.denoise_fn(self.projection(x), t)
+        mean_rot, mean_shift = _b.se3_p_mean(self._sched, x.rot, x.shift, predict.rot_g, predict.shift_g, self._shared_t(t))
+        return AffineT(mean_rot, mean_shift), extract(self.posterior_variance, t, t.shape), \
+            extract(self.posterior_log_variance_clipped, t, t.shape)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, projection, x_init: AffineT = None):
+        """reference diffusion.py:539-550: Q factor of a Gaussian matrix and a unit Gaussian shift as the initial state"""
+        self.projection = projection
+        device = self.betas.device
+        b = shape[0]
+        if x_init is None:
+            x_init = AffineT(torch.linalg.qr(torch.randn((b, 3, 3), device=device))[0], torch.randn((b, 3), device=device))
+        x = x_init
+        for i in reversed(range(self.num_timesteps)):
+            x = self.p_sample(x, torch.full((b,), i, device=device, dtype=torch.long))
+        return x
+
+    def p_losses(self, x_start: AffineT, t, noise=None, axes=None, unif=None, znorm=None):
+        trap_q, _ = self._tables()
+        xt_rot, xt_shift, tg_rot, tg_shift = _b.se3_q_sample_target(
+            self._sched, trap_q, self.shift_scale, x_start.rot, x_start.shift, t, quirk_col0=self.quirk_col0, axes=axes,
+            unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
+            index_base=self.index_base, guide_q=self._guide_q)
+        x_recon = self.denoise_fn(self.projection(AffineT(xt_rot, xt_shift)), t)
+        return _b.mse_loss(x_recon.shift_g, tg_shift) + _b.mse_loss(x_recon.rot_g, tg_rot)
+
+    def forward(self, x: AffineT, projection, *args, **kwargs):
+        self.projection = projection
         b = len(x)
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
         return self.p_losses(x, t, *args, **kwargs)

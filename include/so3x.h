@@ -232,6 +232,10 @@ int so3x_se3_p_noise(so3x_stream_t s, const float* trap_row, float sigma, float 
 int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const float* pos,
                     const float* frames, float* out_pos, float* out_frames, int64_t S, int64_t L);
 
+/* PointCloudProj (models.py:75-91, so3 = True): the projection the Projected*Diffusion variants (diffusion.py:377-429,
+ * 525-573) feed their denoisers with: out[n][P][3] = cloud[P][3] @ rot[n]^T. */
+int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, float* out, int64_t n, int64_t P);
+
 /* ------------------------------------------------------- sample-quality statistics */
 /* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):
  *   out[0] = scale * sum_{i < nx, j < ny} k(X_i, Y_j),

@@ -662,3 +662,26 @@ def resnet_golden(B=96):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "resnet":
     resnet_golden()
+
+
+def projection_golden():
+    """models.PointCloudProj (models.py:75-91) on a random cloud and batch of rotations, so3 = True and False."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import util as rutil
+    import models as rmodels
+    g = torch.Generator().manual_seed(17)
+    data = torch.randn(301, 3, generator=g)
+    R = rutil.quat_to_rmat(torch.randn(37, 4, generator=g))
+    eul = torch.rand(5, 3, generator=g) * 6.0 - 3.0
+    out = {"data": npy(data), "R": npy(R), "proj": npy(rmodels.PointCloudProj(data)(R)), "euler": npy(eul),
+           "proj_euler": npy(rmodels.PointCloudProj(data, so3=False)(eul)),
+           "euler_rmat": npy(rutil.euler_to_rmat(*torch.unbind(eul, -1)))}
+    np.savez(os.path.join(OUT, "projection.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "projection":
+    projection_golden()
