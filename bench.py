@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0                # spec, same table
 IGSO3_BYTES_PER_EVAL = 56            # 36 R + 4 eps in, 4 logp + 12 score out, SURVEY.md 8d
 
 
-def run_steps(B, params, sched, trap_p, x, T, nsteps, seed, index_base, precision, rng_offset=0, per_launch=100):
+def run_steps(B, params, sched, trap_p, x, T, nsteps, seed, index_base, precision, rng_offset=0, per_launch=100, guide_p=None):
     """nsteps consecutive reverse steps starting at t = T-1, wrapping; `per_launch` steps per kernel launch so
     that every launch (warmup and timed alike) does the same work and rocprof's per-kernel average duration is
     directly comparable with the number reported here."""
@@ -43,7 +43,7 @@ def run_steps(B, params, sched, trap_p, x, T, nsteps, seed, index_base, precisio
     while done < nsteps:
         seg = min(nsteps - done, t + 1, per_launch)
         B.p_sample_chain(params, sched, trap_p, x, t, seg, seed=seed, rng_offset=rng_offset + done, index_base=index_base,
-                         precision=precision, out=x)
+                         precision=precision, out=x, guide_p=guide_p)
         done += seg
         launches += 1
         t = t - seg
@@ -141,7 +141,9 @@ def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    ms = timed(lambda: B.resnet_p_sample_chain(params, sched, trap_p, x, 600, steps, seed=1, precision=B.PREC_BF16), reps)
+    guide_p = B.igso3_build_guide(trap_p)
+    ms = timed(lambda: B.resnet_p_sample_chain(params, sched, trap_p, x, 600, steps, seed=1, precision=B.PREC_BF16,
+                                               guide_p=guide_p), reps)
     tf = flop * n * steps / (ms * 1e-3) / 1e12
     out = {"chain": {"kernel": "k_resnet_chain", "batch": n, "steps_per_launch": steps, "ms_per_launch": ms,
                      "sample_steps_per_s": n * steps / (ms * 1e-3), "bound": "mfma", "achieved": tf,
@@ -255,13 +257,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run_steps(B, params, proc._sched, trap_p, x, T, args.warmup, 0, index_base, prec, per_launch=args.steps_per_launch)
+    run_steps(B, params, proc._sched, trap_p, x, T, args.warmup, 0, index_base, prec, per_launch=args.steps_per_launch,
+              guide_p=proc._guide_p)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                        # same (current) stream the C ABI launches on
     launches = run_steps(B, params, proc._sched, trap_p, x, T, args.steps, 0, index_base, prec, rng_offset=args.warmup,
-                         per_launch=args.steps_per_launch)
+                         per_launch=args.steps_per_launch, guide_p=proc._guide_p)
     ev1.record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0

@@ -113,8 +113,9 @@ k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, co
 // ---------------------------------------------------------------------------------------
 template <int PREC>
 __global__ void __launch_bounds__(256, PREC == SO3X_PREC_BF16 ? 3 : 2)
-k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ sched, int T,
-                 const float* __restrict__ trap_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
+k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
+                 const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
+                 const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                  int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
                  uint64_t rng_offset, int64_t index_base, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -138,15 +139,21 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       if (s > 0) rmat_from_quat(q, R);
       const float* beff = beff_tab + (size_t)t * 96;
       float va[3], vb[3], v[3];
-      forward_tile<PREC, CHAIN, 1>(lds, R, beff, 0, nullptr, va, lane);  // tile A = samples 0..31 of the chunk
-      forward_tile<PREC, CHAIN, 2>(lds, R, beff, 0, nullptr, vb, lane);  // tile B = samples 32..63
+      if constexpr (PREC == SO3X_PREC_BF16) {  // layer 0 from this timestep's fragments (bias in the K dimension)
+        const bf16x8* l0t = l0t_tab + (size_t)t * 192;
+        forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);
+        forward_tile<PREC, CHAIN, 2, true>(lds, R, nullptr, 0, nullptr, vb, lane, l0t);
+      } else {
+        forward_tile<PREC, CHAIN, 1>(lds, R, beff, 0, nullptr, va, lane);  // tile A = samples 0..31 of the chunk
+        forward_tile<PREC, CHAIN, 2>(lds, R, beff, 0, nullptr, vb, lane);  // tile B = samples 32..63
+      }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const float o = __shfl_xor(vb[j], 32);  // tile B results sit in lanes 0..31, owners are lanes 32..63
         v[j] = h ? o : va[j];
       }
       // ---- posterior mean + noise (diffusion.py:291-326), so3x_reverse_step.hpp
-      q = reverse_step(q, v, sched, T, t, trap_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+      q = reverse_step(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
     }
     rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
@@ -155,7 +162,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 
 template <int PREC>
 int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
-                 const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                 const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                  uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
   constexpr int IMG = image_bytes<PREC, CHAIN>();
   static int max_blocks = 0;  // resident blocks on this device (occupancy x CUs), queried once; host-only calls, no sync
@@ -173,7 +180,8 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
   const int64_t nchunks = (n + 63) / 64;
   const int64_t want = (nchunks + 3) / 4;
   const int grid = (int)(want < max_blocks ? want : max_blocks);
-  hipLaunchKernelGGL((k_p_sample_chain<PREC>), dim3(grid), dim3(256), IMG, s, ws, beff, sched, T, trap_p, x_in, x_out,
+  const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
+  hipLaunchKernelGGL((k_p_sample_chain<PREC>), dim3(grid), dim3(256), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
   return check_launch();
 }
@@ -209,11 +217,12 @@ int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, cons
 
 size_t so3x_p_sample_workspace_bytes(int T, int precision) {
   const int p = precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16;
-  return beff_offset(p, CHAIN) + (size_t)(T > 0 ? T : 0) * 96 * sizeof(float);
+  const int Tn = T > 0 ? T : 0;
+  return p == SO3X_PREC_BF16 ? l0t_end(Tn) : beff_offset(p, CHAIN) + (size_t)Tn * 96 * sizeof(float);
 }
 
 int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,
-                        const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                        const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                         uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, int precision, void* workspace,
                         size_t workspace_bytes) {
   if (n < 0 || T <= 0 || n_steps < 0 || t_start < 0 || t_start >= T || t_start - n_steps + 1 < 0 ||
@@ -225,11 +234,12 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
   if (n == 0 || n_steps == 0) return SO3X_OK;
   int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace);
   if (rc) return rc;
+  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace))) return rc;
   const float* beff = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + beff_offset(precision, CHAIN));
   if (precision == SO3X_PREC_F32)
-    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes,
+    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,
                                        unif, seed, rng_offset, index_base, n);
-  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, beff, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes,
+  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,
                                       unif, seed, rng_offset, index_base, n);
 }
 

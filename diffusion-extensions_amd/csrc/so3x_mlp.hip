@@ -66,6 +66,27 @@ __global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ par
   }
 }
 
+// ---- prep: per-timestep layer-0 fragments of the bf16 chain (layer0_chain_t) ------------------------------
+// element j of lane (i, h) of tile `to` feeds K slot 8h + j:  slots 0..8 = -log2(e) W_0[o][slot], 9 / 10 = bf16 halves
+// of beff[t][o] (already scaled by k_prep_beff), o = 32 to + i.
+__global__ void __launch_bounds__(192) k_prep_l0t(const float* __restrict__ params, const float* __restrict__ beff, void* __restrict__ l0t) {
+  const int t = blockIdx.x, to = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int o = 32 * to + i;
+  const float be = beff[(size_t)t * 96 + o];
+  const __bf16 hi = (__bf16)be;
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int slot = 8 * h + j;
+    float val = 0.0f;
+    if (slot < 9) val = o < D ? kFoldS * params[o * D + slot] : 0.0f;
+    else if (slot == 9) val = (float)hi;
+    else if (slot == 10) val = be - (float)hi;
+    v[j] = (__bf16)val;
+  }
+  reinterpret_cast<bf16x8*>(l0t)[((size_t)t * 3 + to) * 64 + lane] = v;
+}
+
 // ---- standalone forward ---------------------------------------------------------------
 // 4 waves per block; each wave walks 32-sample tiles.  Both lanes of a sample column read
 // the sample's 9 rotation entries straight from global (36-B stride; compute-bound kernel).
@@ -128,6 +149,13 @@ int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t
 
 namespace so3x {
 namespace mlp {
+// after launch_prep(bf16, CHAIN, T): the per-timestep layer-0 fragments of the chain kernel, workspace >= l0t_end(T)
+int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace) {
+  char* ws = reinterpret_cast<char*>(workspace);
+  hipLaunchKernelGGL(k_prep_l0t, dim3(T), dim3(192), 0, s, params,
+                     reinterpret_cast<const float*>(ws + beff_offset(SO3X_PREC_BF16, CHAIN)), (void*)(ws + l0t_offset(T)));
+  return check_launch();
+}
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace) {
   if (precision == SO3X_PREC_F32) {
     if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace);

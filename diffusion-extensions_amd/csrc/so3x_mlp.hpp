@@ -298,6 +298,31 @@ __device__ __forceinline__ void layer0_chain(const char* __restrict__ wl, const 
   }
 }
 
+// Layer 0 of the bf16 chain kernel with PER-TIMESTEP A fragments: the effective bias of timestep t rides in two extra K
+// slots of the layer's single k-step (slot 9 = bf16(beff), slot 10 = bf16 of the remainder: 16 significant bits) against
+// a constant 1 in the B operand, so the accumulators start from the MFMA's inline zero instead of 96 loaded bias values
+// per tile (-18 broadcast loads and ~100 register moves per wave-step).  l0t = this timestep's [3][64] fragments,
+// written by k_prep_l0t, read with one coalesced 16-byte load per lane and tile.
+template <int XSRC>
+__device__ __forceinline__ void layer0_chain_t(const bf16x8* __restrict__ l0t, const float* x, f32x16 (&acc)[3], int lane) {
+  const int h = lane >> 5;
+  auto entry = [&](int j, bool feeder_is_upper) -> float {
+    const bool owner_is_upper = (XSRC == 2);
+    return feeder_is_upper == owner_is_upper ? x[j] : __shfl_xor(x[j], 32);
+  };
+  const bf16x8 w0 = l0t[lane], w1 = l0t[64 + lane], w2 = l0t[128 + lane];
+  const float x8 = entry(8, true);
+  float xe[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) xe[j] = entry(j, false);
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : (j < 3 ? 1.0f : 0.0f)) : xe[j]);  // slot 8h + j
+  acc[0] = mfma_bf16(w0, b, zero16<SO3X_PREC_BF16>());
+  acc[1] = mfma_bf16(w1, b, zero16<SO3X_PREC_BF16>());
+  acc[2] = mfma_bf16(w2, b, zero16<SO3X_PREC_BF16>());
+}
+
 // Layer 0, FULL variant: per-sample timestep; every lane evaluates the embedding
 // entries of its own k-slots (the two lanes of a sample split the 56 sin/cos).
 // The embedding k-steps are a real loop (not unrolled): 56 inlined sincos would
@@ -349,14 +374,16 @@ __device__ __forceinline__ void layer0_full(const char* __restrict__ wl, const f
 
 // The whole network on one 32-sample tile.  Returns the 3 outputs of sample column
 // (lane & 31) in v[0..2]; only lanes of the LOWER half (h == 0) hold valid values.
-template <int PREC, int VAR, int XSRC = 0>
+template <int PREC, int VAR, int XSRC = 0, bool L0T = false>
 __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS weight image*/, const float* x,
-                                             const float* __restrict__ beff, int64_t t, const Freqs* fr, float* v, int lane) {
+                                             const float* __restrict__ beff, int64_t t, const Freqs* fr, float* v, int lane,
+                                             const bf16x8* __restrict__ l0t = nullptr) {
   const int h = lane >> 5;
   constexpr int FB = frag_bytes<PREC>();
   f32x16 acc[3];
   Tile<PREC> cur;
-  if constexpr (chain_layout(VAR)) layer0_chain<PREC, XSRC>(img, beff, x, acc, lane);
+  if constexpr (L0T) layer0_chain_t<XSRC>(l0t, x, acc, lane);
+  else if constexpr (chain_layout(VAR)) layer0_chain<PREC, XSRC>(img, beff, x, acc, lane);
   else layer0_full<PREC>(img, x, t, *fr, acc, lane);
   constexpr bool FOLD = fold_scale<PREC, VAR>();
   activate<PREC, FOLD>(acc, cur, h);
@@ -382,9 +409,13 @@ size_t image_bytes_rt(int precision, int variant);
 // writes the weight image at workspace[0 .. image) and, for CHAIN with T > 0, the
 // effective-bias table beff[T][96] right after it (16-B aligned).
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace);
+int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace);
 size_t beff_offset(int precision, int variant);
 // tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32
 inline size_t emb_offset(int precision, int variant, int T) { return beff_offset(precision, variant) + (size_t)T * 96 * sizeof(float); }
+// bf16 CHAIN only: per-timestep layer-0 fragments [T][3][64][8 bf16] after the beff table (16-byte aligned: 384 B rows)
+inline size_t l0t_offset(int T) { return emb_offset(SO3X_PREC_BF16, CHAIN, T); }
+inline size_t l0t_end(int T) { return l0t_offset(T) + (size_t)T * 3 * 1024; }
 inline size_t tables_end(int precision, int variant, int T) { return emb_offset(precision, variant, T) + (size_t)T * NEMB * sizeof(float); }
 const Freqs& host_freqs();
 

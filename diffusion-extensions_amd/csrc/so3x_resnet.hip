@@ -370,7 +370,7 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
 template <int PREC>
 __global__ void __launch_bounds__(64 * n_waves<PREC>(), 1)
 k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, const float* __restrict__ sched, int T,
-               const float* __restrict__ trap_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
+               const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
                int64_t index_base, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -396,7 +396,7 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
       forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, vo, !(last_group && s == n_steps - 1), wave, lane);
 #pragma unroll
       for (int j = 0; j < 3; j++) v[j] = __shfl(vo[j], col);
-      q = reverse_step(q, v, sched, T, t, trap_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+      q = reverse_step(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
     }
     rmat_from_quat(qnormalize(q), Rm);
     if (live && h == 0) store_rot9(x_out, idx, Rm);
@@ -810,7 +810,8 @@ int launch_fwd(hipStream_t s, const void* ws, int T, const float* R, const int64
 }
 
 template <int PREC>
-int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const float* trap_p, const float* x_in, float* x_out,
+int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const float* trap_p, const uint16_t* guide_p,
+                 const float* x_in, float* x_out,
                  int t_start, int n_steps, const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
                  int64_t index_base, int64_t n) {
   constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
@@ -819,7 +820,7 @@ int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_chain<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, sched, T,
-                     trap_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
+                     trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
   return check_launch();
 }
 
@@ -918,7 +919,7 @@ int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const 
 }
 
 int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,
-                               const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                               const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                                uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                                void* workspace, size_t workspace_bytes) {
   if (n < 0 || T <= 0 || n_steps < 0 || t_start < 0 || t_start >= T || t_start - n_steps + 1 < 0 ||
@@ -932,9 +933,9 @@ int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float
                                       : prep<SO3X_PREC_BF16>((hipStream_t)s, params, T, workspace);
   if (rc) return rc;
   if (precision == SO3X_PREC_F32)
-    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes, unif,
+    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif,
                                        seed, rng_offset, index_base, n);
-  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, sched, T, trap_p, x_in, x_out, t_start, n_steps, axes, unif,
+  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif,
                                       seed, rng_offset, index_base, n);
 }
 

@@ -13,7 +13,8 @@ enum { S_SQRT_AC = 3, S_SQRT_1MAC = 4, S_RECIP = 6, S_RECIPM1 = 7, S_COEF1 = 10,
 //   x0hat = exp(a log x) exp(b v)^T,   mean = exp(c1 log x0hat) exp(c2 log x),   x' = mean @ IGSO3(sigma_t) (t > 0).
 // idc = clamped sample index for the explicit-draw arrays, gidx = global index keying the Philox counter.
 __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const float* __restrict__ sched, int T, int t,
-                                             const float* __restrict__ trap_p, const float* __restrict__ axes,
+                                             const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p,
+                                             const float* __restrict__ axes,
                                              const float* __restrict__ unif, int64_t idc, uint64_t seed, uint64_t rng_offset,
                                              uint64_t gidx) {
   const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t];
@@ -41,7 +42,8 @@ __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const 
       u = u01(r.z);
     }
     const float* row = trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
-    const float ang = axes ? igso3_angle<true>(row, row, SO3X_KNOTS_DATA, u) : igso3_angle<false>(row, row, SO3X_KNOTS_DATA, u);
+    const uint16_t* grow = guide_p ? guide_p + (size_t)t * kGuidePitch : nullptr;  // optional search guide (bit-identical)
+    const float ang = axes ? igso3_angle<true>(row, row, SO3X_KNOTS_DATA, u, grow) : igso3_angle<false>(row, row, SO3X_KNOTS_DATA, u, grow);
     q = qmul(q, quat_axis_angle_exp(nax, ang));   // model_mean @ sample, :326
   }
   // no per-step renormalisation: q is rebuilt from (axis, angle) pairs every step, so its norm error is

@@ -432,7 +432,7 @@ def p_mean(sched, x, v, t, want_x0hat=False):
 
 
 def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0, index_base=0,
-                   precision=PREC_BF16, out=None):
+                   precision=PREC_BF16, out=None, guide_p=None):
     params = _dev(params, "params").reshape(-1)
     sched = _dev(sched, "sched")
     T = sched.shape[1]
@@ -446,7 +446,7 @@ def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=N
     nb = lib().so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(precision))
     ws = _workspace(x.device, nb)
     with _Guard(x):
-        _check(lib().so3x_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(x), _ptr(out),
+        _check(lib().so3x_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(guide_p), _ptr(x), _ptr(out),
                                          C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un), _u64(seed),
                                          _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision), _ptr(ws),
                                          C.c_size_t(ws.numel())), "p_sample_chain")
@@ -502,7 +502,7 @@ def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16):
 
 
 def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0,
-                          index_base=0, precision=PREC_BF16, out=None):
+                          index_base=0, precision=PREC_BF16, out=None, guide_p=None):
     params = _dev(params, "params").reshape(-1)
     if params.numel() != N_PARAMS_RESNET:
         raise ValueError(f"so3x: params must hold {N_PARAMS_RESNET} values")
@@ -518,7 +518,7 @@ def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None,
     nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(T))
     ws = _workspace(x.device, nb)
     with _Guard(x):
-        _check(lib().so3x_resnet_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(x),
+        _check(lib().so3x_resnet_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(guide_p), _ptr(x),
                                                 _ptr(out), C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un),
                                                 _u64(seed), _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision),
                                                 _ptr(ws), C.c_size_t(ws.numel())), "resnet_p_sample_chain")

@@ -166,10 +166,10 @@ int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, cons
  * network fused in: applies n_steps reverse steps t_start, t_start-1, ... to x in place
  * (x_out may alias x_in).  trap_p = CDF rows of the posterior sigma [T][999].
  * axes/unif: explicit draws for ONE step (n_steps must be 1), else in-kernel Philox with
- * counter (index_base + i, rng_offset + t). */
+ * counter (index_base + i, rng_offset + t).  guide_p: optional search guide of trap_p (so3x_igso3_build_guide). */
 size_t so3x_p_sample_workspace_bytes(int T, int precision);
 int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T,
-                        const float* trap_p, const float* x_in, float* x_out, int t_start,
+                        const float* trap_p, const uint16_t* guide_p, const float* x_in, float* x_out, int t_start,
                         int n_steps, const float* axes, const float* unif, uint64_t seed,
                         uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                         void* workspace, size_t workspace_bytes);
@@ -196,7 +196,7 @@ int so3x_resnet_bwd(so3x_stream_t s, const float* params, const float* R, const 
 /* so3x_p_sample_chain with this network as the denoiser (so3_lock_test.py:24-31); workspace =
  * so3x_resnet_workspace_bytes(precision, T). */
 int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T,
-                               const float* trap_p, const float* x_in, float* x_out, int t_start,
+                               const float* trap_p, const uint16_t* guide_p, const float* x_in, float* x_out, int t_start,
                                int n_steps, const float* axes, const float* unif, uint64_t seed,
                                uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                                void* workspace, size_t workspace_bytes);

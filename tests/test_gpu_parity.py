@@ -632,6 +632,17 @@ def test_search_guide_is_bit_identical(mods):
             a = B.igso3_sample(trap, n, row_idx=ri, quirk_col0=True, want_angle=True, **kw)
             b = B.igso3_sample(trap, n, row_idx=ri, quirk_col0=True, want_angle=True, guide=guide, **kw)
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # the chain kernels with the guide of the p rows: same samples, bit for bit
+    trap_p = B.igso3_build_tables(sched[12])
+    guide_p = B.igso3_build_guide(trap_p)
+    from so3x.so3_train import RotPredict
+    torch.manual_seed(0)
+    pnet = RotPredict(out_type="skewvec").to(DEV).flat_params_nograd()
+    xc = mods["util"].quat_to_rmat(torch.randn(777, 4, device=DEV))
+    for prec in (0, 1):
+        a = B.p_sample_chain(pnet, sched, trap_p, xc, 700, 40, seed=2, precision=prec)
+        b = B.p_sample_chain(pnet, sched, trap_p, xc, 700, 40, seed=2, precision=prec, guide_p=guide_p)
+        assert torch.equal(a, b)
     trap_q = B.igso3_build_tables(sched[4])
     guide_q = B.igso3_build_guide(trap_q)
     x0 = mods["util"].quat_to_rmat(torch.randn(3000, 4, device=DEV))

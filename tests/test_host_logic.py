@@ -68,12 +68,15 @@ def test_error_paths_return_codes_not_crashes():
     lib = B.lib()
     assert lib.so3x_so3_scale(None, None, None, C.c_int64(1), None, C.c_int64(4)) == -1
     assert lib.so3x_quat_to_rmat(None, None, None, C.c_int64(0)) == 0
-    assert lib.so3x_p_sample_chain(None, None, None, C.c_int(10), None, None, None, C.c_int(3), C.c_int(5), None, None,
+    assert lib.so3x_p_sample_chain(None, None, None, C.c_int(10), None, None, None, None, C.c_int(3), C.c_int(5), None, None,
                                    C.c_uint64(0), C.c_uint64(0), C.c_int64(0), C.c_int64(8), C.c_int(1), None,
                                    C.c_size_t(0)) == -1  # t_start - n_steps + 1 < 0
     assert b"workspace" in lib.so3x_error_string(-2)
     ws = lib.so3x_p_sample_workspace_bytes(C.c_int(1000), C.c_int(1))
-    assert 53 * 1024 + 1000 * 96 * 4 <= ws <= 60 * 1024 + 1000 * 96 * 4
+    # bf16: weight image + [T][96] effective-bias table + [T][3 KB] per-timestep layer-0 fragments
+    assert 53 * 1024 + 1000 * (96 * 4 + 3072) <= ws <= 60 * 1024 + 1000 * (96 * 4 + 3072)
+    ws32 = lib.so3x_p_sample_workspace_bytes(C.c_int(1000), C.c_int(0))
+    assert 1000 * 96 * 4 < ws32 < 200 * 1024 + 1000 * 96 * 4
 
 
 def test_cpu_tensors_are_refused_loudly():
