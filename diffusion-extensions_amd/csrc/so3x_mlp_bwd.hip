@@ -519,6 +519,73 @@ __device__ __forceinline__ void activate_zh(const Z33h& z, Tile<PREC>& out, int 
   activate<PREC>(a, out, h);
 }
 
+// Pre-activation stash between the training forward (k_mlp_fwd_stash) and k_bwd_fused: the four Z33h of a wave's
+// 32-sample tile as they sit in registers, 68 dwords per lane = 17 chunks of 16 B, chunk-major so that every store /
+// load is a fully coalesced 1 KiB per wave.  17 KiB per tile = 544 B per sample.
+constexpr size_t ZSTASH_TILE = 17 * 1024;
+__device__ __forceinline__ void zstash_store(char* tile_base, int lane, const Z33h (&z)[4]) {
+  uint32_t d[68];
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int i = 0; i < 17; i++) d[17 * l + i] = __builtin_bit_cast(uint32_t, z[l].p[i]);
+  uint4* o = reinterpret_cast<uint4*>(tile_base) + lane;
+#pragma unroll
+  for (int c = 0; c < 17; c++) o[c * 64] = uint4{d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]};
+}
+__device__ __forceinline__ void zstash_load(const char* tile_base, int lane, Z33h (&z)[4]) {
+  const uint4* in = reinterpret_cast<const uint4*>(tile_base) + lane;
+  uint32_t d[68];
+#pragma unroll
+  for (int c = 0; c < 17; c++) { const uint4 v = in[c * 64]; d[4 * c] = v.x; d[4 * c + 1] = v.y; d[4 * c + 2] = v.z; d[4 * c + 3] = v.w; }
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int i = 0; i < 17; i++) z[l].p[i] = __builtin_bit_cast(Z33h::h2, d[17 * l + i]);
+}
+
+// Training forward (bf16 operands, per-timestep tables): the network output AND the stash above, so that the backward
+// does not run the forward again (that recompute was half of k_bwd_fused's time).  Same arithmetic as the recompute it
+// replaces: GATHER image (true pre-activations, no scale fold), pre-activations rounded to f16 before the activation.
+template <int PREC>
+__global__ void __launch_bounds__(256, 2)
+k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
+                const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int VAR = GATHER;
+  constexpr int FB = frag_bytes<PREC>();
+  load_image(gimg, lds, image_bytes<PREC, VAR>());
+  __syncthreads();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    int64_t idx = tile * 32 + col;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    float x[9];
+    load_rot9(R, idx, x);
+    const int64_t tt = t[idx * t_stride];
+    Z33h z[4];
+    f32x16 a3[3];
+    Tile<PREC> cur;
+    layer0_chain<PREC, 0>(lds, beff_tab + (size_t)tt * 96, x, a3, lane);
+    keep_h(a3, z[0]);
+#pragma unroll
+    for (int l = 1; l < 4; l++) {
+      activate_zh<PREC>(z[l - 1], cur, h);
+      hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
+      keep_h(a3, z[l]);
+    }
+    activate_zh<PREC>(z[3], cur, h);
+    f32x16 last[1];
+    hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
+    if (live && h == 0) { out[idx * 3] = last[0][0]; out[idx * 3 + 1] = last[0][1]; out[idx * 3 + 2] = last[0][2]; }
+    zstash_store(zstash + (size_t)tile * ZSTASH_TILE, lane, z);
+  }
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -564,11 +631,12 @@ __device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const u
   }
 }
 
-template <int PREC>
+template <int PREC, bool STASHED>
 __global__ void __launch_bounds__(512, 2)
 k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
-            int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n) {
+            int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n,
+            const char* __restrict__ zstash) {
   // Wave specialisation: waves 0-3 ("chain" waves) recompute the forward and run the dZ chain for one 32-sample
   // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators) and only consume
   // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
@@ -606,7 +674,9 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       load_rot9(R, sc, x);
       const int64_t tt = t[sc * t_stride];
       const float lv = live ? 1.0f : 0.0f;  // dead columns contribute exact zeros to every dW sum
-      {
+      if constexpr (STASHED) {  // pre-activations parked by the training forward (k_mlp_fwd_stash)
+        zstash_load(zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE, lane, z);
+      } else {
         f32x16 a3[3];
         Tile<PREC> cur;
         layer0_chain<PREC, 0>(lds, beff_tab + (size_t)tt * 96, x, a3, lane);
@@ -744,7 +814,7 @@ template <int PREC> BwdLayout bwd_layout(int64_t n, int t_table) {
 
 template <int PREC, int VAR>
 int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
-               float* dparams, int64_t n, int t_table, char* ws) {
+               float* dparams, int64_t n, int t_table, char* ws, const char* zstash = nullptr) {
   using ST = typename Stash<PREC>::T;
   constexpr int DW_LDS = PREC == SO3X_PREC_F32 ? STASH_ROWS * LROW * (int)sizeof(float) : STASH_ROWS * LROW16 * 2;
   constexpr int STAGE_LDS = stage_lds_bytes<PREC, VAR>();
@@ -772,15 +842,22 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     constexpr int FUSED_LDS = image_bytes<PREC, VAR>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
     static int fattr = 0;
     if (!fattr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_fused<PREC>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_fused<PREC, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+      if (e != hipSuccess) return (int)e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_fused<PREC, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
       if (e != hipSuccess) return (int)e;
       fattr = 1;
     }
     const int64_t nt = (n + 31) / 32;
     const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
-    hipLaunchKernelGGL((k_bwd_fused<PREC>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff, emb,
-                       R, t, t_stride, dout, slabs, n);
+    if (zstash)
+      hipLaunchKernelGGL((k_bwd_fused<PREC, true>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
+                         emb, R, t, t_stride, dout, slabs, n, zstash);
+    else
+      hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
+                         emb, R, t, t_stride, dout, slabs, n, zstash);
     hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0);
     return check_launch();
   }
@@ -811,10 +888,37 @@ size_t so3x_mlp_workspace_bytes(int64_t n, int precision, int t_table) {
   return bwd_layout<SO3X_PREC_BF16>(n, t_table).end;
 }
 
+size_t so3x_mlp_stash_bytes(int64_t n) { return (size_t)((n > 0 ? n : 0) + 31) / 32 * ZSTASH_TILE; }
+
+int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
+                       void* zstash, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !out || !zstash)) || (t_stride != 0 && t_stride != 1) || t_table < 0)
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_BF16 || t_table <= 0) return SO3X_ERR_UNSUPPORTED;  // the stash is the fused backward's
+  if (!workspace || workspace_bytes < tables_end(precision, GATHER, t_table)) return SO3X_ERR_WORKSPACE;
+  if (n == 0) return SO3X_OK;
+  constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER>();
+  char* ws = (char*)workspace;
+  int rc = launch_prep((hipStream_t)s, params, PREC, GATHER, t_table, ws);
+  if (rc) return rc;
+  static int attr = 0;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
+    if (e != hipSuccess) return (int)e;
+    attr = 1;
+  }
+  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
+  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, (hipStream_t)s, (const void*)ws,
+                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n);
+  return check_launch();
+}
+
 int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride,
-                 const float* dout, float* dparams, int64_t n, int precision, int t_table, void* workspace,
-                 size_t workspace_bytes) {
-  if (n < 0 || (n && (!params || !R || !t || !dout)) || !dparams || (t_stride != 0 && t_stride != 1) || t_table < 0)
+                 const float* dout, float* dparams, int64_t n, int precision, int t_table, const void* zstash,
+                 void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !dout)) || !dparams || (t_stride != 0 && t_stride != 1) || t_table < 0 ||
+      (zstash && (precision != SO3X_PREC_BF16 || t_table <= 0)))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < so3x_mlp_workspace_bytes(n, precision, t_table)) return SO3X_ERR_WORKSPACE;
@@ -827,7 +931,7 @@ int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int
   if (precision == SO3X_PREC_F32)
     return t_table > 0 ? launch_bwd<SO3X_PREC_F32, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws)
                        : launch_bwd<SO3X_PREC_F32, FULL>(st, params, R, t, t_stride, dout, dparams, n, 0, ws);
-  return t_table > 0 ? launch_bwd<SO3X_PREC_BF16, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws)
+  return t_table > 0 ? launch_bwd<SO3X_PREC_BF16, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws, (const char*)zstash)
                      : launch_bwd<SO3X_PREC_BF16, FULL>(st, params, R, t, t_stride, dout, dparams, n, 0, ws);
 }
 

@@ -27,7 +27,8 @@ SYMBOLS = (
     "so3x_igso3_knots", "so3x_posemb_freqs", "so3x_quat_to_rmat", "so3x_log_rmat", "so3x_log_rmat_vec",
     "so3x_exp_skewvec", "so3x_so3_scale", "so3x_aa_to_rmat", "so3x_rmat_to_aa", "so3x_so3_lerp",
     "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_build_guide", "so3x_igso3_sample",
-    "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd",
+    "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd", "so3x_mlp_stash_bytes",
+    "so3x_mlp_fwd_stash",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move", "so3x_rotate_cloud",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
@@ -60,6 +61,7 @@ def lib():
                     raise So3xError(f"so3x: {LIB_PATH} lacks symbols {missing}")
                 l.so3x_error_string.restype = C.c_char_p
                 l.so3x_mlp_workspace_bytes.restype = C.c_size_t
+                l.so3x_mlp_stash_bytes.restype = C.c_size_t
                 l.so3x_p_sample_workspace_bytes.restype = C.c_size_t
                 l.so3x_kernel_sum_workspace_bytes.restype = C.c_size_t
                 l.so3x_mse_workspace_bytes.restype = C.c_size_t
@@ -84,7 +86,7 @@ def _dev(x, name, dtype=torch.float32):
                         "(move the tensor/module to a 'cuda' device)")
     if x.dtype != dtype:
         x = x.to(dtype)
-    return x.contiguous()
+    return x if x.is_contiguous() else x.contiguous()
 
 
 def _ptr(x):
@@ -104,14 +106,22 @@ def _u64(v):
 
 
 class _Guard:
+    """Makes the tensor's GPU the current HIP device for the launch.  When it already is (the one-process-per-GPU
+    layout always), entering costs two integer reads instead of a torch.cuda.device context (~10 us per call, a
+    measurable share of a host-bound training step)."""
+    __slots__ = ("g",)
+
     def __init__(self, x):
-        self.g = torch.cuda.device(x.device)
+        idx = x.device.index
+        self.g = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(x.device)
 
     def __enter__(self):
-        self.g.__enter__()
+        if self.g is not None:
+            self.g.__enter__()
 
     def __exit__(self, *a):
-        self.g.__exit__(*a)
+        if self.g is not None:
+            self.g.__exit__(*a)
 
 
 # ----------------------------------------------------------------------------- host-side
@@ -375,7 +385,24 @@ def mlp_fwd(params, R, t, precision=PREC_F32, t_table=0):
     return out
 
 
-def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0):
+def mlp_fwd_stash(params, R, t, t_table):
+    """training forward (bf16 operands, bounded timesteps): (out, zstash) -- zstash goes to mlp_bwd(..., zstash=)"""
+    params = _dev(params, "params").reshape(-1)
+    R = _rot_in(R, "x")
+    n = R.numel() // 9
+    tt, stride = _t_arg(t, n)
+    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    zstash = torch.empty(lib().so3x_mlp_stash_bytes(_i64(n)), dtype=torch.uint8, device=R.device)
+    nb = lib().so3x_mlp_workspace_bytes(_i64(0), C.c_int(PREC_BF16), C.c_int(int(t_table)))
+    ws = _workspace(R.device, nb)
+    with _Guard(R):
+        _check(lib().so3x_mlp_fwd_stash(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _ptr(zstash),
+                                        _i64(n), C.c_int(PREC_BF16), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+               "mlp_fwd_stash")
+    return out, zstash
+
+
+def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0, zstash=None):
     params = _dev(params, "params").reshape(-1)
     R = _rot_in(R, "x")
     n = R.numel() // 9
@@ -386,7 +413,8 @@ def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0):
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_mlp_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                  _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+                                  _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(zstash), _ptr(ws),
+                                  C.c_size_t(ws.numel())),
                "mlp_bwd")
     return dparams
 

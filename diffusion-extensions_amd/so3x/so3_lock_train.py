@@ -110,7 +110,7 @@ def main(argv=None):
     net.train()
     parallel.broadcast_parameters(net, ctx)
     process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
-    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr)
+    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True)
     R_1 = euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None].to(device)
     R_2 = euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None].to(device)
     lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)

@@ -141,10 +141,17 @@ size_t so3x_mlp_workspace_bytes(int64_t n, int precision, int t_table);
 int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
                  int64_t t_stride, float* out, int64_t n, int precision, int t_table,
                  void* workspace, size_t workspace_bytes);
-/* autograd of the above for a given dL/dout[n][3] -> dparams[17358] (overwritten). */
+/* Training forward (bf16 operands and t_table > 0 only, else SO3X_ERR_UNSUPPORTED): the same output plus the four
+ * layers' pre-activations parked in `zstash` (so3x_mlp_stash_bytes(n) = 544 B per sample, f16) for so3x_mlp_bwd. */
+size_t so3x_mlp_stash_bytes(int64_t n);
+int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
+                       int64_t t_stride, float* out, void* zstash, int64_t n, int precision, int t_table,
+                       void* workspace, size_t workspace_bytes);
+/* autograd of the above for a given dL/dout[n][3] -> dparams[17358] (overwritten).  zstash: NULL (the forward is
+ * recomputed inside) or the stash written by so3x_mlp_fwd_stash for the SAME params, R, t (bf16, t_table > 0). */
 int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
                  int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,
-                 int t_table, void* workspace, size_t workspace_bytes);
+                 int t_table, const void* zstash, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------- diffusion steps */
 /* SO3Diffusion.q_sample + the p_losses target (diffusion.py:339-355), fused with the

@@ -650,3 +650,24 @@ def test_search_guide_is_bit_identical(mods):
     a = B.q_sample_target(sched, trap_q, x0, t, seed=5, rng_offset=1)
     b = B.q_sample_target(sched, trap_q, x0, t, seed=5, rng_offset=1, guide_q=guide_q)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_training_forward_stash_equals_recompute(mods, golden, net):
+    """so3x_mlp_fwd_stash + so3x_mlp_bwd(zstash) == so3x_mlp_bwd with the forward recomputed inside: the parked
+    pre-activations are the recomputed ones bit for bit, so the gradients are too; the output matches the plain forward."""
+    B = mods["B"]
+    params = net.flat_params_nograd()
+    for n in (1, 77, 4100):
+        gen = torch.Generator(device=DEV).manual_seed(n)
+        x = mods["util"].quat_to_rmat(torch.randn(n, 4, device=DEV, generator=gen))
+        t = torch.randint(0, 300, (n,), device=DEV, generator=gen)
+        dout = torch.randn(n, 3, device=DEV, generator=gen)
+        out, zs = B.mlp_fwd_stash(params, x, t, 300)
+        assert zs.numel() == (n + 31) // 32 * 17 * 1024
+        ref_out = B.mlp_fwd(params, x, t, B.PREC_BF16, 300)
+        assert float((out - ref_out).abs().max()) < 3e-2          # same operands; the plain forward folds the SiLU scale
+        g_stash = B.mlp_bwd(params, x, t, dout, B.PREC_BF16, 300, zstash=zs)
+        g_rec = B.mlp_bwd(params, x, t, dout, B.PREC_BF16, 300)
+        assert torch.equal(g_stash, g_rec)
+    with pytest.raises(B.So3xError):
+        B.mlp_bwd(params, x, t, dout, B.PREC_F32, 300, zstash=zs)    # the stash belongs to the bf16 fused path

@@ -120,7 +120,7 @@ def main():
         torch.manual_seed(0)
         wnet = WideNet(out_type="skewvec", precision="bf16").to(dev)
         wproc = SO3Diffusion(wnet, timesteps=1000).to(dev)
-        opt = torch.optim.Adam(wnet.parameters(), lr=3e-4)
+        opt = torch.optim.Adam(wnet.parameters(), lr=3e-4, fused=True)
         for lg in (15, 19):
             n = 1 << lg
             x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
@@ -138,7 +138,7 @@ def main():
         x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
         for prec in ("bf16", "fp32"):
             net.precision = prec
-            opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+            opt = torch.optim.Adam(net.parameters(), lr=3e-4, fused=True)
 
             def step():
                 loss = proc(x0)
