@@ -840,6 +840,22 @@ TrainLayout train_layout(int64_t n, int T, int precision) {
   return L;
 }
 
+// the forward-with-dumps launch shared by so3x_resnet_fwd_stash and (when the caller brings no stash) so3x_resnet_bwd
+template <int PREC>
+int launch_fwd_stash(hipStream_t s, char* ws, int T, const float* params, const float* R, const int64_t* t, int64_t t_stride,
+                     float* out, int64_t n, char* x_dump, char* y_dump, size_t layer_stride) {
+  constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
+  int rc = prep<PREC>(s, params, T, ws);
+  if (rc) return rc;
+  static int cap = 0;
+  if (!cap) { rc = grid_cap(&k_resnet_fwd<PREC, true>, THREADS, LDS, &cap); if (rc) return rc; }
+  const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
+  const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
+  hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, (const void*)ws, tab,
+                     T, R, t, t_stride, out, n, x_dump, y_dump, layer_stride);
+  return check_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -848,8 +864,28 @@ size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table) 
   return train_layout(n > 0 ? n : 0, t_table, precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16).end;
 }
 
+size_t so3x_resnet_stash_bytes(int64_t n, int precision) {
+  return 13 * train_layout(n > 0 ? n : 0, 1, precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16).layer_stride;
+}
+
+int so3x_resnet_fwd_stash(so3x_stream_t s_, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
+                          void* stash, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!params || !R || !t || !out || !stash)))
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ws_bytes(precision, t_table)) return SO3X_ERR_WORKSPACE;
+  if (n == 0) return SO3X_OK;
+  const TrainLayout L = train_layout(n, t_table, precision);
+  char* st = reinterpret_cast<char*>(stash);
+  char* ws = reinterpret_cast<char*>(workspace);
+  return precision == SO3X_PREC_BF16
+             ? launch_fwd_stash<SO3X_PREC_BF16>((hipStream_t)s_, ws, t_table, params, R, t, t_stride, out, n, st, st + 7 * L.layer_stride, L.layer_stride)
+             : launch_fwd_stash<SO3X_PREC_F32>((hipStream_t)s_, ws, t_table, params, R, t, t_stride, out, n, st, st + 7 * L.layer_stride, L.layer_stride);
+}
+
 int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
-                    float* dparams, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+                    float* dparams, int64_t n, int precision, int t_table, const void* stash, void* workspace,
+                    size_t workspace_bytes) {
   if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || !params || !dparams || (n && (!R || !t || !dout)))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
@@ -859,28 +895,26 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
   if (n == 0) return (int)hipMemsetAsync(dparams, 0, sizeof(float) * NPARAMS, s);
   char* ws = reinterpret_cast<char*>(workspace);
   float* partial = reinterpret_cast<float*>(ws + L.partial);
+  // layer inputs / pre-activations: the caller's stash (so3x_resnet_fwd_stash) or a forward run here into the workspace
+  const char* xd = stash ? reinterpret_cast<const char*>(stash) : ws + L.x;
+  const char* yd = stash ? xd + 7 * L.layer_stride : ws + L.y;
   int rc;
   if (precision == SO3X_PREC_BF16) {
     constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
-    if ((rc = prep<PREC>(s, params, t_table, workspace))) return rc;
+    if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, ws + L.x, ws + L.y, L.layer_stride))) return rc;
     hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
-    static int cap_f = 0, cap_b = 0;
-    if (!cap_f) { rc = grid_cap(&k_resnet_fwd<PREC, true>, 512, LDS, &cap_f); if (rc) return rc; }
+    static int cap_b = 0;
     if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
     const int64_t ngroups = (n + 255) / 256;
-    const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
-    hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap_f ? ngroups : cap_f)), dim3(512), LDS, s, (const void*)ws,
-                       tab, t_table, R, t, t_stride, (float*)nullptr, n, ws + L.x, ws + L.y, L.layer_stride);
     hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
-                       params, dout, (const char*)(ws + L.y), ws + L.dz, L.layer_stride, n);
-    hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 0, s, (const char*)(ws + L.x), (const char*)(ws + L.dz),
-                       L.layer_stride, L.nblk32, partial);
+                       params, dout, yd, ws + L.dz, L.layer_stride, n);
+    hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 0, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
+                       partial);
   } else {
     constexpr int PREC = SO3X_PREC_F32, LDS = RING * chunk_bytes<PREC>();
-    if ((rc = prep<PREC>(s, params, t_table, workspace))) return rc;
+    if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, ws + L.x, ws + L.y, L.layer_stride))) return rc;
     hipLaunchKernelGGL(k_resnet_image_t_f32, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
-    static int cap_f = 0, cap_b = 0, dw_attr = 0;
-    if (!cap_f) { rc = grid_cap(&k_resnet_fwd<PREC, true>, 256, LDS, &cap_f); if (rc) return rc; }
+    static int cap_b = 0, dw_attr = 0;
     if (!cap_b) { rc = grid_cap(&k_resnet_bwd_f32, 256, LDS, &cap_b); if (rc) return rc; }
     if (!dw_attr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resnet_dw_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -888,13 +922,10 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
       dw_attr = 1;
     }
     const int64_t ngroups = (n + 127) / 128;
-    const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
-    hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap_f ? ngroups : cap_f)), dim3(256), LDS, s, (const void*)ws,
-                       tab, t_table, R, t, t_stride, (float*)nullptr, n, ws + L.x, ws + L.y, L.layer_stride);
     hipLaunchKernelGGL(k_resnet_bwd_f32, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(256), LDS, s, (const void*)(ws + L.img_t),
-                       params, dout, (const char*)(ws + L.y), ws + L.dz, L.layer_stride, n);
-    hipLaunchKernelGGL(k_resnet_dw_f32, dim3(7 * DW_SPLITS), dim3(512), 65536, s, (const char*)(ws + L.x), (const char*)(ws + L.dz),
-                       L.layer_stride, L.nblk32, partial, DW_SPLITS);
+                       params, dout, yd, ws + L.dz, L.layer_stride, n);
+    hipLaunchKernelGGL(k_resnet_dw_f32, dim3(7 * DW_SPLITS), dim3(512), 65536, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
+                       partial, DW_SPLITS);
   }
   hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, (const float*)partial, dparams);
   return check_launch();

@@ -33,7 +33,7 @@ SYMBOLS = (
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move", "so3x_rotate_cloud",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
-    "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd",
+    "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd", "so3x_resnet_stash_bytes", "so3x_resnet_fwd_stash",
 )
 
 
@@ -67,6 +67,7 @@ def lib():
                 l.so3x_mse_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_train_workspace_bytes.restype = C.c_size_t
+                l.so3x_resnet_stash_bytes.restype = C.c_size_t
                 if l.so3x_abi_version() != 2:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
@@ -512,8 +513,25 @@ def resnet_fwd(params, R, t, t_table, precision=PREC_F32):
     return out
 
 
-def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16):
-    """dL/dparams [392448] for dL/dout [n, 3] (bf16 operands; fp32 raises So3xError 'unsupported')."""
+def resnet_fwd_stash(params, R, t, t_table, precision=PREC_BF16):
+    """training forward: (out, stash) -- stash goes to resnet_bwd(..., stash=) instead of a second forward there"""
+    params = _dev(params, "params").reshape(-1)
+    R = _rot_in(R, "x")
+    n = R.numel() // 9
+    tt, stride = _t_arg(t, n)
+    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    stash = torch.empty(lib().so3x_resnet_stash_bytes(_i64(n), C.c_int(precision)), dtype=torch.uint8, device=R.device)
+    nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(int(t_table)))
+    ws = _workspace(R.device, nb)
+    with _Guard(R):
+        _check(lib().so3x_resnet_fwd_stash(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _ptr(stash),
+                                           _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+               "resnet_fwd_stash")
+    return out, stash
+
+
+def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16, stash=None):
+    """dL/dparams [392448] for dL/dout [n, 3]; stash = what resnet_fwd_stash returned for the same inputs, or None."""
     params = _dev(params, "params").reshape(-1)
     R = _rot_in(R, "x")
     n = R.numel() // 9
@@ -524,7 +542,8 @@ def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16):
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_resnet_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                     _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+                                     _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(stash), _ptr(ws),
+                                     C.c_size_t(ws.numel())),
                "resnet_bwd")
     return dparams
 

@@ -26,15 +26,16 @@ class _ResNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, t, flat_params, precision, t_table):
-        ctx.save_for_backward(x, t, flat_params)
         ctx.precision = precision
         ctx.t_table = t_table
-        return _b.resnet_fwd(flat_params, x, t, t_table, precision)
+        out, stash = _b.resnet_fwd_stash(flat_params, x, t, t_table, precision)  # layer inputs + pre-activations for the backward
+        ctx.save_for_backward(x, t, flat_params, stash)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, t, flat_params = ctx.saved_tensors
-        dparams = _b.resnet_bwd(flat_params, x, t, dout.contiguous(), ctx.t_table, ctx.precision)
+        x, t, flat_params, stash = ctx.saved_tensors
+        dparams = _b.resnet_bwd(flat_params, x, t, dout.contiguous(), ctx.t_table, ctx.precision, stash=stash)
         return None, None, dparams, None, None
 
 

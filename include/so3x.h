@@ -197,9 +197,16 @@ int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const 
  * its layer inputs and pre-activations parked in the workspace (~10 KB per sample with bf16 operands, ~20 KB in
  * fp32), dX chain and dW GEMMs on the matrix cores, deterministic reduction. */
 size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table);
+/* Training forward: the output plus the layer inputs / pre-activations in `stash` (so3x_resnet_stash_bytes: 6.5 KB per
+ * sample with bf16 operands, 13 KB in fp32) for so3x_resnet_bwd; workspace = so3x_resnet_workspace_bytes. */
+size_t so3x_resnet_stash_bytes(int64_t n, int precision);
+int so3x_resnet_fwd_stash(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
+                          int64_t t_stride, float* out, void* stash, int64_t n, int precision, int t_table,
+                          void* workspace, size_t workspace_bytes);
+/* stash: NULL (the forward is run again inside) or what so3x_resnet_fwd_stash wrote for the SAME params, R, t, precision */
 int so3x_resnet_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
                     int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,
-                    int t_table, void* workspace, size_t workspace_bytes);
+                    int t_table, const void* stash, void* workspace, size_t workspace_bytes);
 /* so3x_p_sample_chain with this network as the denoiser (so3_lock_test.py:24-31); workspace =
  * so3x_resnet_workspace_bytes(precision, T). */
 int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T,

@@ -176,6 +176,11 @@ def test_resnet_backward_vs_oracle(B, golden, n):
         lo, hi = l * LS, (l + 1) * LS if l < 6 else dp.size
         err = np.linalg.norm(dp[lo:hi] - ref[lo:hi]) / np.linalg.norm(ref[lo:hi])
         assert err < 2.5e-2, (l, err)
+    # the stash handed over from the training forward gives the same gradient bit for bit, and the same output
+    o2, st = B.resnet_fwd_stash(dev(g["params"]), dev(x), dev(t, torch.int64), 1000, precision=1)
+    assert torch.equal(o2, B.resnet_fwd(dev(g["params"]), dev(x), dev(t, torch.int64), 1000, precision=1))
+    dp2 = B.resnet_bwd(dev(g["params"]), dev(x), dev(t, torch.int64), dev(dout), 1000, precision=1, stash=st)
+    assert np.array_equal(host(dp2), dp)
     cos = float(dp @ ref / np.linalg.norm(dp) / np.linalg.norm(ref))
     assert cos > 0.9995, cos
     if n == 96:
