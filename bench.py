@@ -92,10 +92,27 @@ def pmc_traffic(kernel, **match):
     return None
 
 
-def train_step_extra(B, torch, proc, net, n=1 << 19, reps=5):
-    """BASELINE config 4 on this GPU's shard: forward noising + loss + backward + Adam at 2^19 samples (bf16 MLP)."""
+def train_step_extra(B, torch, proc, net, n=1 << 19, reps=10):
+    """BASELINE config 4 on this GPU's shard: forward noising + loss + backward + Adam at 2^19 samples (bf16 MLP), the
+    whole step replayed as one captured hipGraph (so3x.graphs.TrainStepGraph); the eager Python loop is timed beside it."""
+    import copy
+    from so3x.graphs import TrainStepGraph
+    from so3x.diffusion import SO3Diffusion
     dev = torch.device("cuda", torch.cuda.current_device())
     x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev))
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     opt = torch.optim.Adam(net.parameters(), lr=3e-4, fused=True)  # same update, one multi-tensor launch
 
     def step():
@@ -104,18 +121,15 @@ def train_step_extra(B, torch, proc, net, n=1 << 19, reps=5):
         loss.backward()
         opt.step()
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    eager_ms = timed(step, reps)
+    gnet = copy.deepcopy(net)
+    gproc = SO3Diffusion(gnet, timesteps=proc.num_timesteps).to(dev)
+    gopt = torch.optim.Adam(gnet.parameters(), lr=3e-4, fused=True, capturable=True)
+    tg = TrainStepGraph(gproc, gopt, x0.shape)
+    ms = timed(tg.graph.replay, reps)
     return {"samples_per_s": n / (ms * 1e-3), "ms_per_step": ms, "batch": n, "mlp_operands": net.precision,
-            "algorithmic_TFLOPs": 94120 * n / (ms * 1e-3) / 1e12, "optimizer": "torch Adam (fused=True)"}
+            "algorithmic_TFLOPs": 94120 * n / (ms * 1e-3) / 1e12, "optimizer": "torch Adam (fused=True, capturable=True)",
+            "mode": "one captured hipGraph per step", "eager_python_loop_ms_per_step": eager_ms}
 
 
 def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):

@@ -25,9 +25,10 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
                   const uint16_t* __restrict__ guide_q, const float* __restrict__ x0,
                   const int64_t* __restrict__ t, int quirk_col0, const float* __restrict__ noise_in,
                   const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
-                  int64_t index_base, float* __restrict__ x_t, float* __restrict__ target, float* __restrict__ noise_out,
-                  int64_t n) {
+                  const int64_t* __restrict__ rng_offset_dev, int64_t index_base, float* __restrict__ x_t,
+                  float* __restrict__ target, float* __restrict__ noise_out, int64_t n) {
   __shared__ __attribute__((aligned(16))) float sm[kBlock / kWave][kWave * 9];
+  if (rng_offset_dev) rng_offset += (uint64_t)rng_offset_dev[0];  // device-resident part of the counter (hipGraph replays)
   float* wl = sm[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   const int64_t ntiles = (n + kWave - 1) / kWave;
@@ -193,7 +194,8 @@ extern "C" {
 int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                          const float* x0, const int64_t* t,
                          int quirk_col0, const float* noise_in, const float* axes, const float* unif, uint64_t seed,
-                         uint64_t rng_offset, int64_t index_base, float* x_t, float* target, float* noise_out, int64_t n) {
+                         uint64_t rng_offset, const int64_t* rng_offset_dev, int64_t index_base, float* x_t, float* target,
+                         float* noise_out, int64_t n) {
   if (n < 0 || T <= 0 || (n && (!sched || !x0 || !t)) || (n && !noise_in && !trap_q) ||
       ((axes == nullptr) != (unif == nullptr)))
     return SO3X_ERR_INVALID_ARG;
@@ -202,7 +204,8 @@ int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float
   int64_t want = (nt64 + 3) / 4;   // one tile per wave
   if (want > (1 << 20)) want = 1 << 20;
   hipLaunchKernelGGL(k_q_sample_target, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, sched,
-                     T, trap_q, guide_q, x0, t, quirk_col0, noise_in, axes, unif, seed, rng_offset, index_base, x_t, target, noise_out, n);
+                     T, trap_q, guide_q, x0, t, quirk_col0, noise_in, axes, unif, seed, rng_offset, rng_offset_dev, index_base, x_t,
+                     target, noise_out, n);
   return check_launch();
 }
 

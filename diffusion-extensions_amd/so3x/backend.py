@@ -422,7 +422,7 @@ def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0, zstash=None):
 
 # ----------------------------------------------------------------------------- diffusion
 def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None, unif=None, seed=0, rng_offset=0,
-                    index_base=0, want_x_t=True, want_target=True, want_noise=False, guide_q=None):
+                    index_base=0, want_x_t=True, want_target=True, want_noise=False, guide_q=None, rng_offset_dev=None):
     sched = _dev(sched, "sched")
     T = sched.shape[1]
     x0 = _rot_in(x0, "x_start")
@@ -441,7 +441,8 @@ def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None
     with _Guard(x0):
         _check(lib().so3x_q_sample_target(_stream(x0), _ptr(sched), C.c_int(T), _ptr(tq), _ptr(guide_q), _ptr(x0), _ptr(tt),
                                           C.c_int(int(quirk_col0)), _ptr(nz), _ptr(ax), _ptr(un), _u64(seed),
-                                          _u64(rng_offset), _i64(index_base), _ptr(x_t), _ptr(tg), _ptr(nzo), _i64(n)),
+                                          _u64(rng_offset), _ptr(rng_offset_dev), _i64(index_base), _ptr(x_t), _ptr(tg),
+                                          _ptr(nzo), _i64(n)),
                "q_sample_target")
     return x_t, tg, nzo
 

@@ -58,6 +58,10 @@ class SO3Diffusion(nn.Module):
             raise NotImplementedError("so3x: only loss_type='skewvec' (reference so3_train.py:63) is implemented")
         self.quirk_col0 = quirk_col0
         self.index_base = 0  # global index of this process's first sample (data-parallel shards)
+        # None: the Philox offset of each p_losses call is a host counter (so3x.rng).  A device int64 tensor (see
+        # so3x.graphs.TrainStepGraph): the offset is read from it by the kernel and incremented on the device after the
+        # call, which is what a captured hipGraph of the training step needs to draw fresh noise on every replay.
+        self.rng_counter = None
 
         sched = _b.schedule_from_betas(betas)  # float64 math, fp32 storage, as diffusion.py:62-92
         for i, name in enumerate(_SCHED_NAMES):
@@ -177,10 +181,14 @@ class SO3Diffusion(nn.Module):
     def p_losses(self, x_start, t, noise=None, axes=None, unif=None):
         """MSE between the network output and vee(log noise)/eps_t (reference diffusion.py:348-369)."""
         trap_q, _ = self._tables()
+        dev_rng = self.rng_counter is not None and noise is None and axes is None
         x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
                                                 axes=axes, unif=unif, seed=_rng.seed(),
-                                                rng_offset=_rng.next_offset() if (noise is None and axes is None) else 0,
-                                                index_base=self.index_base, guide_q=self._guide_q)
+                                                rng_offset=0 if (dev_rng or noise is not None or axes is not None) else _rng.next_offset(),
+                                                index_base=self.index_base, guide_q=self._guide_q,
+                                                rng_offset_dev=self.rng_counter if dev_rng else None)
+        if dev_rng:
+            self.rng_counter += 1
         net = self._fused_net()
         # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
         x_recon = net(x_noisy, t, t_table=self.num_timesteps) if net is not None else self.denoise_fn(x_noisy, t)

@@ -158,10 +158,12 @@ int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int
  * noise draw: noise ~ IGSO3(sqrt(1-abar_t)) from trap_q rows [T][999];
  * x_t = so3_scale(x0, sqrt(abar_t)) @ noise; target = vee(log noise)/eps_t.
  * sched = device copy of the [13][T] table.  noise_in != NULL teacher-forces the noise
- * (then trap_q/axes/unif are ignored).  x_t, target, noise_out optional outputs. */
+ * (then trap_q/axes/unif are ignored).  x_t, target, noise_out optional outputs.
+ * rng_offset_dev (optional): a device-resident int64 added to rng_offset at run time, so that a captured hipGraph of a
+ * training step draws fresh noise on every replay (the caller increments it inside the graph). */
 int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                          const float* x0, const int64_t* t, int quirk_col0, const float* noise_in,
-                         const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
+                         const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset, const int64_t* rng_offset_dev,
                          int64_t index_base, float* x_t, float* target, float* noise_out, int64_t n);
 
 /* Reverse mean for a given network output v (diffusion.py:291-313): x0hat (optional) and

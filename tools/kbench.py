@@ -133,6 +133,23 @@ def main():
             ms = timeit(wstep, reps=5, warm=2)
             print(json.dumps({"k": "resnet_train_step_bf16", "n": n, "ms": ms, "samples_per_s": n / ms * 1e3,
                               "algo_TFLOPs": 3 * 781830 * n / ms / 1e9}))
+    if "traingraph" in which:
+        from so3x.graphs import TrainStepGraph
+        for wide in (False, True):
+            torch.manual_seed(0)
+            if wide:
+                from so3x.so3_lock_train import RotPredict as Net
+            else:
+                Net = RotPredict
+            gnet = Net(out_type="skewvec", precision="bf16").to(dev)
+            gproc = SO3Diffusion(gnet, timesteps=1000).to(dev)
+            gopt = torch.optim.Adam(gnet.parameters(), lr=3e-4, fused=True, capturable=True)
+            n = 1 << 19
+            x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+            tg = TrainStepGraph(gproc, gopt, x0.shape)
+            ms = timeit(lambda: tg.graph.replay(), reps=10, warm=3)
+            print(json.dumps({"k": "train_step_graph_" + ("wide" if wide else "mlp65"), "n": n, "ms": ms, "samples_per_s": n / ms * 1e3,
+                              "loss": float(tg.loss)}))
     if "train" in which:
         n = 1 << 19
         x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
