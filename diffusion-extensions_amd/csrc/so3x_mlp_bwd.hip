@@ -631,6 +631,62 @@ __device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const u
   }
 }
 
+// The dW role of k_bwd_fused for dW wave DWI (0..3): owns pairs p = DWI + 4k of the 39 (dZ tile, H tile) pairs.
+template <int PREC, int DWI>
+__device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, float* __restrict__ slabs, int lane) {
+  constexpr int dw = DWI;
+  const int col = lane & 31, h = lane >> 5;
+    f32x16 acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
+    FimgReadLane RL = fimg_read_lane(lane);
+    for (int64_t rd = 0; rd < rounds; rd++) {
+      asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
+#pragma unroll
+      for (int l = 4; l >= 0; l--) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          const int p = dw + 4 * k;  // owned pair
+          const int pl = p < 36 ? p / 9 : 4;
+          if (p < NPAIRS && pl == l) {
+            const int to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
+            f32x16 a = acc[k];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+              const char* im = fimg_all + w * FIMG_BYTES;
+#pragma unroll
+              for (int ks = 0; ks < 2; ks++) a = mfma_bf16(fimg_frag(im, RL, 32 * to, ks), fimg_frag(im, RL, 96 + 32 * ti, ks), a);
+            }
+            acc[k] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
+    float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const int p = dw + 4 * k;
+      if (p < NPAIRS) {
+        const int l = p < 36 ? p / 9 : 4, to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
+        const int in_f = 32 * ti + col;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int out = 32 * to + row_of(r, h);
+          if (out >= (l < 4 ? D : 3)) continue;
+          int pc;  // weight column, -2 = bias, -1 = padding
+          if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
+          else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
+          if (pc == -1) continue;
+          const int base = l * LAYER_STRIDE;
+          slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = acc[k][r];
+        }
+      }
+    }
+}
+
 template <int PREC, bool STASHED>
 __global__ void __launch_bounds__(512, 2)
 k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
@@ -745,55 +801,13 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
     }
   } else {
     // ================================ dW waves =================================
-    const int dw = wid - 4;
-    f32x16 acc[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
-    FimgReadLane RL = fimg_read_lane(lane);
-    for (int64_t rd = 0; rd < rounds; rd++) {
-      asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
-#pragma unroll
-      for (int l = 4; l >= 0; l--) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-          const int p = dw + 4 * k;  // owned pair
-          const int pl = p < 36 ? p / 9 : 4;
-          if (p < NPAIRS && pl == l) {
-            const int to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
-            f32x16 a = acc[k];
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-              const char* im = fimg_all + w * FIMG_BYTES;
-#pragma unroll
-              for (int ks = 0; ks < 2; ks++) a = mfma_bf16(fimg_frag(im, RL, 32 * to, ks), fimg_frag(im, RL, 96 + 32 * ti, ks), a);
-            }
-            acc[k] = a;
-          }
-        }
-        __syncthreads();
-      }
-    }
-    // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
-    float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-      const int p = dw + 4 * k;
-      if (p < NPAIRS) {
-        const int l = p < 36 ? p / 9 : 4, to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
-        const int in_f = 32 * ti + col;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int out = 32 * to + row_of(r, h);
-          if (out >= (l < 4 ? D : 3)) continue;
-          int pc;  // weight column, -2 = bias, -1 = padding
-          if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
-          else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
-          if (pc == -1) continue;
-          const int base = l * LAYER_STRIDE;
-          slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = acc[k][r];
-        }
-      }
+    // one instantiation per dW wave: with the wave's index a compile-time constant its pairs, their layers and every LDS
+    // offset fold into the instruction stream
+    switch (wid - 4) {
+      case 0: dw_role<PREC, 0>(fimg_all, rounds, slabs, lane); break;
+      case 1: dw_role<PREC, 1>(fimg_all, rounds, slabs, lane); break;
+      case 2: dw_role<PREC, 2>(fimg_all, rounds, slabs, lane); break;
+      default: dw_role<PREC, 3>(fimg_all, rounds, slabs, lane); break;
     }
   }
 }
