@@ -632,59 +632,81 @@ __device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const u
 }
 
 // The dW role of k_bwd_fused for dW wave DWI (0..3): owns pairs p = DWI + 4k of the 39 (dZ tile, H tile) pairs.
+// Ownership of the 39 dW tiles by the four dW waves.  In the hidden layers (3 x 3 tiles each) a wave owns a whole ROW
+// of tiles -- the three pairs that share the dZ tile `to` -- so the A fragments are read once per row instead of once per
+// pair (64 transposed reads per layer instead of 96); the wave that gets no row in layer l is (l + 3) & 3, so every
+// wave works in three of the four layers, and the three tiles of the output layer go one each to waves 0..2: 10/10/10/9
+// persistent accumulators.  Everything here is compile-time per DWI.
+__host__ __device__ constexpr int dw_row(int dwi, int l) { return (dwi - l) & 3; }              // 0..2 = the row, 3 = idle in layer l
+__host__ __device__ constexpr int dw_slot(int dwi, int l) {                                       // index of layer l among the wave's active layers
+  int c = 0;
+  for (int q = 0; q < l; q++) c += dw_row(dwi, q) != 3;
+  return c;
+}
+
+// The dW role of k_bwd_fused for dW wave DWI (0..3).
 template <int PREC, int DWI>
 __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, float* __restrict__ slabs, int lane) {
-  constexpr int dw = DWI;
   const int col = lane & 31, h = lane >> 5;
-    f32x16 acc[10];
+  f32x16 acc[10];  // [3 slot + ti] for the hidden layers, [9] = the wave's tile of the output layer
 #pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
-    FimgReadLane RL = fimg_read_lane(lane);
-    for (int64_t rd = 0; rd < rounds; rd++) {
-      asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
+  for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
+  FimgReadLane RL = fimg_read_lane(lane);
+  for (int64_t rd = 0; rd < rounds; rd++) {
+    asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
 #pragma unroll
-      for (int l = 4; l >= 0; l--) {
-        __syncthreads();
+    for (int l = 4; l >= 0; l--) {
+      __syncthreads();
+      if (l == 4) {
+        if (DWI < 3) {
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
-          const int p = dw + 4 * k;  // owned pair
-          const int pl = p < 36 ? p / 9 : 4;
-          if (p < NPAIRS && pl == l) {
-            const int to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
-            f32x16 a = acc[k];
+          for (int w = 0; w < 4; w++) {
+            const char* im = fimg_all + w * FIMG_BYTES;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-              const char* im = fimg_all + w * FIMG_BYTES;
-#pragma unroll
-              for (int ks = 0; ks < 2; ks++) a = mfma_bf16(fimg_frag(im, RL, 32 * to, ks), fimg_frag(im, RL, 96 + 32 * ti, ks), a);
-            }
-            acc[k] = a;
+            for (int ks = 0; ks < 2; ks++) acc[9] = mfma_bf16(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
           }
         }
-        __syncthreads();
-      }
-    }
-    // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
-    float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
+      } else if (dw_row(DWI, l) != 3) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int to = dw_row(DWI, l), sl = dw_slot(DWI, l);
 #pragma unroll
-    for (int k = 0; k < 10; k++) {
-      const int p = dw + 4 * k;
-      if (p < NPAIRS) {
-        const int l = p < 36 ? p / 9 : 4, to = p < 36 ? (p % 9) / 3 : 0, ti = p < 36 ? p % 3 : p - 36;
-        const int in_f = 32 * ti + col;
+        for (int w = 0; w < 4; w++) {
+          const char* im = fimg_all + w * FIMG_BYTES;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int out = 32 * to + row_of(r, h);
-          if (out >= (l < 4 ? D : 3)) continue;
-          int pc;  // weight column, -2 = bias, -1 = padding
-          if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
-          else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
-          if (pc == -1) continue;
-          const int base = l * LAYER_STRIDE;
-          slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = acc[k][r];
+          for (int ks = 0; ks < 2; ks++) {
+            const bf16x8 a = fimg_frag(im, RL, 32 * to, ks);
+#pragma unroll
+            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
+          }
         }
       }
+      __syncthreads();
     }
+  }
+  // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
+  float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
+  auto write_tile = [&](const f32x16& a, int l, int to, int ti) {
+    const int in_f = 32 * ti + col;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int out = 32 * to + row_of(r, h);
+      if (out >= (l < 4 ? D : 3)) continue;
+      int pc;  // weight column, -2 = bias, -1 = padding
+      if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
+      else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
+      if (pc == -1) continue;
+      const int base = l * LAYER_STRIDE;
+      slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = a[r];
+    }
+  };
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    if (dw_row(DWI, l) == 3) continue;
+#pragma unroll
+    for (int ti = 0; ti < 3; ti++) write_tile(acc[3 * dw_slot(DWI, l) + ti], l, dw_row(DWI, l), ti);
+  }
+  if (DWI < 3) write_tile(acc[9], 4, 0, DWI);
 }
 
 template <int PREC, bool STASHED>
@@ -694,7 +716,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
             int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n,
             const char* __restrict__ zstash) {
   // Wave specialisation: waves 0-3 ("chain" waves) recompute the forward and run the dZ chain for one 32-sample
-  // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators) and only consume
+  // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators; dw_row) and only consume
   // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
   // SiLU-derivative VALU work, and neither role needs more than 256 registers.
   static_assert(PREC == SO3X_PREC_BF16, "fused backward is the bf16 path");
