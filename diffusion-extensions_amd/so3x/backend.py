@@ -255,6 +255,9 @@ def rmat_to_aa(R):
 
 def so3_lerp(a, b, w):
     b = _rot_in(b, "rot_b")
+    if b.numel() == 9 and isinstance(w, torch.Tensor) and w.numel() > 1:
+        # one end point, many weights (so3_lock_train.py:76-81: the arc between two fixed rotations): broadcast rot_b
+        b = b.reshape(1, 3, 3).expand(w.numel(), 3, 3).contiguous()
     n = b.numel() // 9
     a = _rot_in(a, "rot_a")
     if a.numel() == 9:

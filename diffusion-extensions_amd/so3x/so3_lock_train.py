@@ -101,6 +101,8 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--save-every", type=int, default=1000)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one captured hipGraph (so3x.graphs.TrainStepGraph; single process only)")
     ap.add_argument("--weights", default="weights/weights_so3_lock.pt")
     args = ap.parse_args(argv)
 
@@ -111,7 +113,8 @@ def main(argv=None):
     net.train()
     parallel.broadcast_parameters(net, ctx)
     process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
-    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True)
+    use_graph = args.graph and ctx.world_size == 1
+    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True, capturable=use_graph)
     R_1 = euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None].to(device)
     R_2 = euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None].to(device)
     lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)
@@ -119,16 +122,23 @@ def main(argv=None):
     gen = torch.Generator(device=device).manual_seed(1234 + ctx.rank)
     t0 = time.time()
     sumloss = 0.0
+    graph = None
+    if use_graph:
+        from .graphs import TrainStepGraph
+        graph = TrainStepGraph(process, optim, (hi - lo, 3, 3))
     for i in range(1, args.steps + 1):
         weight = torch.rand(hi - lo, 1, device=device, generator=gen)
         truepos = so3_lerp(R_1, R_2, weight)
-        loss = process(truepos)
-        if torch.isnan(loss).any():  # so3_lock_train.py:83-84
-            continue
-        optim.zero_grad()
-        loss.backward()
-        parallel.allreduce_gradients(net, ctx)
-        optim.step()
+        if graph is not None:
+            loss = graph.step(truepos)  # (the reference's skip-on-NaN needs the loss on the host before the update: eager mode only)
+        else:
+            loss = process(truepos)
+            if torch.isnan(loss).any():  # so3_lock_train.py:83-84
+                continue
+            optim.zero_grad()
+            loss.backward()
+            parallel.allreduce_gradients(net, ctx)
+            optim.step()
         sumloss += parallel.mean_scalar(loss.detach(), ctx)
         if i % args.log_every == 0:
             if ctx.rank == 0:

@@ -112,6 +112,8 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--save-every", type=int, default=1000)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one captured hipGraph (so3x.graphs.TrainStepGraph; single process only)")
     ap.add_argument("--weights", default="weights/weights_so3.pt")
     args = ap.parse_args(argv)
 
@@ -122,21 +124,29 @@ def main(argv=None):
     net.train()
     parallel.broadcast_parameters(net, ctx)
     process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
-    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True)  # the reference's Adam, one launch
+    use_graph = args.graph and ctx.world_size == 1
+    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True, capturable=use_graph)  # the reference's Adam, one launch
     z90 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
     rotations = torch.stack((z90, z90.T), dim=0).to(device)
     lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)
     process.index_base = lo
     gen = torch.Generator(device=device).manual_seed(1234 + ctx.rank)
     t0 = time.time()
+    graph = None
+    if use_graph:
+        from .graphs import TrainStepGraph
+        graph = TrainStepGraph(process, optim, (hi - lo, 3, 3))
     for i in range(1, args.steps + 1):
         idx = torch.randint(0, 2, (hi - lo,), device=device, generator=gen)
         truepos = rotations[idx]
-        loss = process(truepos)
-        optim.zero_grad()
-        loss.backward()
-        parallel.allreduce_gradients(net, ctx)
-        optim.step()
+        if graph is not None:
+            loss = graph.step(truepos)
+        else:
+            loss = process(truepos)
+            optim.zero_grad()
+            loss.backward()
+            parallel.allreduce_gradients(net, ctx)
+            optim.step()
         if i % args.log_every == 0:
             lval = parallel.mean_scalar(loss.detach(), ctx)
             if ctx.rank == 0:

@@ -58,6 +58,20 @@ def B():
 
 
 @pytest.mark.gpu
+def test_lock_train_data_path_on_device(B, golden):
+    """so3_lock_train.py:76-81 as the script calls it: euler_to_rmat end points of shape [1,3,3], weights [B,1]"""
+    from so3x.util import so3_lerp, euler_to_rmat
+    from math import pi
+    g = golden["resnet"]
+    R1 = euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None].to(DEV)
+    R2 = euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None].to(DEV)
+    assert float((R1 - dev(g["R1"])).abs().max()) < 1e-6 and float((R2 - dev(g["R2"])).abs().max()) < 1e-6
+    out = so3_lerp(R1, R2, dev(g["lerp_w"]))
+    assert out.shape == (32, 3, 3)
+    assert float((out - dev(g["lerp"])).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
 def test_resnet_fwd_fp32_vs_reference_and_oracle(B, golden):
     g = golden["resnet"]
     out = host(B.resnet_fwd(dev(g["params"]), dev(g["x"]), dev(g["t"], torch.int64), 1000, precision=0))
