@@ -50,6 +50,11 @@ using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
 
 template <int PREC> __host__ __device__ constexpr int chunk_bytes() { return PREC == SO3X_PREC_F32 ? 32768 : 16384; }
 template <int PREC> __host__ __device__ constexpr int n_waves() { return PREC == SO3X_PREC_F32 ? 4 : 8; }
+// The first NRES tiles of the stream stay in LDS for the whole launch (behind the ring) instead of being DMA'd on every
+// pass: LDS-DMA issue is ~19 % of the bf16 kernel's time, 6 of 49 tiles is what fits beside the ring with
+// room to spare (3 x 16 KiB + 6 x 16 KiB = 144 KiB).  Sampling kernels only (bf16, no stash).
+template <int PREC, bool STASH> __host__ __device__ constexpr int n_resident() { return (PREC == SO3X_PREC_BF16 && !STASH) ? 6 : 0; }
+template <int PREC, bool STASH> __host__ __device__ constexpr int lds_bytes() { return (3 + n_resident<PREC, STASH>()) * chunk_bytes<PREC>(); }
 template <int PREC> __host__ __device__ constexpr size_t image_bytes() { return (size_t)NCHUNK * chunk_bytes<PREC>(); }
 __host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -214,11 +219,17 @@ template <int PREC> __device__ __forceinline__ void residual(const f32x16& acc, 
 struct Stream { int slot; };
 
 // first two chunks of a pass; call once before the first forward() of a workgroup
-template <int PREC>
+template <int PREC, int NRES = 0>
 __device__ __forceinline__ void stream_begin(const char* __restrict__ gimg, char* ring, Stream& st, int wave, int lane) {
   st.slot = 0;
-  issue_chunk<PREC>(gimg, ring, 0, 0, wave, lane);
-  issue_chunk<PREC>(gimg, ring, 1, 1, wave, lane);
+  issue_chunk<PREC>(gimg, ring, NRES, 0, wave, lane);
+  issue_chunk<PREC>(gimg, ring, NRES + 1, 1, wave, lane);
+  if constexpr (NRES > 0) {  // resident tiles 0 .. NRES-1 behind the ring
+    const float4* src = reinterpret_cast<const float4*>(gimg);
+    float4* dst = reinterpret_cast<float4*>(ring + RING * chunk_bytes<PREC>());
+    for (int i = threadIdx.x; i < NRES * chunk_bytes<PREC>() / 16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
 }
 
 // The whole network on this wave's 32 samples.  xf = the input rows on entry (destroyed); v = the three outputs of
@@ -255,6 +266,7 @@ template <int PREC, bool STASH = false>
 __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* ring, Stream& st, float (&xf)[128], float (&v)[3],
                                         bool again, int wave, int lane, StashPtr sp = StashPtr{nullptr, nullptr, 0}) {
   constexpr int CB = chunk_bytes<PREC>();
+  constexpr int NRES = n_resident<PREC, STASH>();
   // with stash stores in flight the counted waits cannot tell DMAs from stores: wait for everything
   constexpr int DMA = STASH ? 0 : dma_per_chunk<PREC>();
   auto stash_x = [&](const Operand<PREC>& o, int l) {
@@ -292,28 +304,29 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
 #pragma unroll
     for (int to = 0; to < 8; to++) {
       const int c = 8 * l + to;
-      ring_sync<DMA>();  // chunk c landed everywhere (chunk c+1 may still be in flight); slot of chunk c-1 is free
-      {
+      const bool res = to < NRES && l == 0;  // an LDS-resident tile: no DMA, no barrier, no ring slot
+      if (!res) {
+        ring_sync<DMA>();  // chunk c landed everywhere (chunk c+1 may still be in flight); slot of chunk c-1 is free
         const int nslot = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3
         if (c + 2 < NCHUNK) issue_chunk<PREC>(gimg, ring, c + 2, nslot, wave, lane);
-        else if (again) issue_chunk<PREC>(gimg, ring, c + 2 - NCHUNK, nslot, wave, lane);
+        else if (again) issue_chunk<PREC>(gimg, ring, c + 2 - NCHUNK + NRES, nslot, wave, lane);
       }
       if (late) {
         if (to > 0) residual<PREC>(acc, xf, to - 1);
         else if (l > 0) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); stash_x(op, l); }
       }
-      acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
+      acc = chunk_mfma<PREC>(res ? ring + (RING + c) * CB : ring + slot * CB, op, lane);
       stash_y(acc, l, to);
       if (!late) {
         residual<PREC>(acc, xf, to);
         if (to == 7) { refresh<PREC>(op, xf); stash_x(op, l + 1); }
       }
-      slot = slot == 2 ? 0 : slot + 1;
+      if (!res) slot = slot == 2 ? 0 : slot + 1;
     }
   }
   // output layer: chunk 48.  Outstanding DMAs here: chunk 48 itself and, with `again`, chunk 0 of the next pass.
   if (again) ring_sync<DMA>(); else ring_sync<0>();
-  if (again) issue_chunk<PREC>(gimg, ring, 1, slot == 0 ? 2 : slot - 1, wave, lane);
+  if (again) issue_chunk<PREC>(gimg, ring, NRES + 1, slot == 0 ? 2 : slot - 1, wave, lane);
   if (late) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); stash_x(op, NBLK); }
   acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
   v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2];  // rows 0,1,2 = regs 0,1,2 of the lower half
@@ -344,7 +357,7 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const int64_t ngroups = (n + 32 * NW - 1) / (32 * NW);
   Stream st;
-  stream_begin<PREC>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
+  stream_begin<PREC, n_resident<PREC, STASH>()>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     int64_t idx = (g * NW + wave) * 32 + col;
     const bool live = idx < n;
@@ -378,7 +391,7 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const int64_t ngroups = (n + 32 * NW - 1) / (32 * NW);
   Stream st;
-  stream_begin<PREC>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
+  stream_begin<PREC, n_resident<PREC, false>()>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t idx = (g * NW + wave) * 32 + col;
     const bool live = idx < n;
@@ -799,7 +812,7 @@ template <typename K> int grid_cap(K kernel, int threads, int lds, int* cap) {
 
 template <int PREC>
 int launch_fwd(hipStream_t s, const void* ws, int T, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n) {
-  constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
+  constexpr int LDS = lds_bytes<PREC, false>(), THREADS = 64 * n_waves<PREC>();
   static int cap = 0;  // resident workgroups on this device, queried once (idempotent)
   if (!cap) { int rc = grid_cap(&k_resnet_fwd<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
@@ -814,7 +827,7 @@ int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const
                  const float* x_in, float* x_out,
                  int t_start, int n_steps, const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
                  int64_t index_base, int64_t n) {
-  constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
+  constexpr int LDS = lds_bytes<PREC, false>(), THREADS = 64 * n_waves<PREC>();
   static int cap = 0;
   if (!cap) { int rc = grid_cap(&k_resnet_chain<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
