@@ -1,8 +1,13 @@
 // so3x_mlp_bwd.hip -- backward of the RotPredict score network (autograd of
 // so3_train.py:39-49; only the 17,358 parameters need gradients).
 //
-// Three kernels per chunk of <= 65,536 samples (activations are recomputed, never saved
-// by the forward op):
+// Two paths.
+// (A) bf16 operands + bounded timesteps (what SO3Diffusion.p_losses runs): ONE kernel, k_bwd_fused -- chain waves and dW
+//     waves of a workgroup hand dZ_l / H_l over through LDS images, nothing per-sample returns to HBM; the forward's
+//     pre-activations come from the training forward's stash (k_mlp_fwd_stash, 544 B/sample) or are recomputed.
+//     Described at the kernel and in DESIGN.md section 4.
+// (B) every other case (fp32; unbounded timesteps): three kernels per chunk of <= 2^19 samples (activations are
+//     recomputed, never saved by the forward op):
 //   K1 k_bwd_stage : per 32-sample tile, recompute the forward keeping the pre-activations
 //                    Z_l in registers, then run the dZ chain  dH_{l-1} = W_l^T dZ_l  on the
 //                    matrix cores (transposed-weight fragments, same accumulator-as-operand
@@ -13,7 +18,7 @@
 //                    fragments, and its 8 waves own the 39 output tiles; partial sums go to
 //                    one slab per block (deterministic, no float atomics);
 //   K3 k_bwd_reduce: sums the slabs into dparams.
-// The stash is fp32 in both precisions; K2/K3 always run exact-fp32 MFMA.
+// The stash is fp32 / bf16 with the operand precision; K2 runs exact-fp32 or bf16 MFMA accordingly.
 #include "so3x_common.hpp"
 #include "so3x_mlp.hpp"
 
@@ -715,7 +720,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
             int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n,
             const char* __restrict__ zstash) {
-  // Wave specialisation: waves 0-3 ("chain" waves) recompute the forward and run the dZ chain for one 32-sample
+  // Wave specialisation: waves 0-3 ("chain" waves) load (STASHED) or recompute the forward's pre-activations and run the dZ chain for one 32-sample
   // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators; dw_row) and only consume
   // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
   // SiLU-derivative VALU work, and neither role needs more than 256 registers.
@@ -874,7 +879,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   float* slabs = reinterpret_cast<float*>(ws + L.slabs);
   ST* stash = reinterpret_cast<ST*>(ws + L.stash);
   if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER) {
-    // fused path: no stash, one launch for the whole batch
+    // fused path: no dZ/H stash, one launch for the whole batch
     constexpr int FUSED_LDS = image_bytes<PREC, VAR>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
     static int fattr = 0;
     if (!fattr) {
