@@ -254,3 +254,36 @@ def test_wide_rotpredict_module_and_training_step(B, golden):
     l2 = proc(proc.p_sample_loop((64,)))                     # a p_losses training step end to end
     l2.backward()
     assert torch.isfinite(l2)
+
+
+@pytest.mark.gpu
+def test_resnet_chain_explicit_draws_and_edge_sizes(B, golden):
+    """explicit (axes, unif) draws for one step reproduce the oracle's p_sample with the same draws; gradients at the
+    workgroup-pass boundaries (n = 1, 257) and with one shared timestep"""
+    g = golden["resnet"]
+    T = 1000
+    betas = O.cosine_beta_schedule(T)
+    sched = O.schedule_from_betas(betas)
+    sched_d = dev(B.schedule_from_betas(betas))
+    trap_p = B.igso3_build_tables(sched_d[12])
+    rs = np.random.default_rng(9)
+    n, t = 130, 321
+    x0 = O.quat_to_rmat(rs.standard_normal((n, 4)).astype(np.float32))
+    axes = rs.standard_normal((n, 3)).astype(np.float32)
+    unif = rs.random(n).astype(np.float32)
+    out = host(B.resnet_p_sample_chain(dev(g["params"]), sched_d, trap_p, dev(x0), t, 1, axes=dev(axes), unif=dev(unif), precision=0))
+    coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
+    v = O.resnet_fwd(g["params"], x0, np.full(n, t), "f64")
+    _, mean = O.p_mean(x0, v, *coef, "f64")
+    smp, _ = O.igso3_sample(host(trap_p)[t:t + 1], axes, unif, prec="f64")
+    ref = O.rmul(mean, smp, "f64")
+    assert np.abs(out - ref).max() < 5e-5
+    with pytest.raises(B.So3xError):          # explicit draws are for a single step
+        B.resnet_p_sample_chain(dev(g["params"]), sched_d, trap_p, dev(x0), t, 2, axes=dev(axes), unif=dev(unif), precision=0)
+    for m in (1, 257):
+        xm = O.quat_to_rmat(rs.standard_normal((m, 4)).astype(np.float32))
+        dout = rs.standard_normal((m, 3)).astype(np.float32) / m
+        for tt in (rs.integers(0, T, m), np.array([77])):          # per-sample and (1,)-shaped t
+            refg = O.resnet_bwd(g["params"], xm, tt, dout, "f64")
+            got = host(B.resnet_bwd(dev(g["params"]), dev(xm), dev(tt, torch.int64), dev(dout), T, precision=0))
+            assert np.abs(got - refg).max() < 3e-5 * max(1.0, np.abs(refg).max())
