@@ -92,6 +92,15 @@ def pmc_traffic(kernel, **match):
     return None
 
 
+def pmc_mfma_busy(kernel):
+    """matrix-pipe busy fraction of `kernel` from the committed PMC pass (profiles/pmc_traffic.json), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["mfma_utilisation"][kernel]["mfma_pipe_busy_frac"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def train_step_extra(B, torch, proc, net, n=1 << 19, reps=10):
     """BASELINE config 4 on this GPU's shard: forward noising + loss + backward + Adam at 2^19 samples (bf16 MLP), the
     whole step replayed as one captured hipGraph (so3x.graphs.TrainStepGraph); the eager Python loop is timed beside it."""
@@ -162,7 +171,7 @@ def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
     out = {"chain": {"kernel": "k_resnet_chain", "batch": n, "steps_per_launch": steps, "ms_per_launch": ms,
                      "sample_steps_per_s": n * steps / (ms * 1e-3), "bound": "mfma", "achieved": tf,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_MFMA_PEAK_TFLOPS,
-                     "flop_per_sample_step": flop}}
+                     "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_resnet_chain"), "flop_per_sample_step": flop}}
     nt = 1 << 19
     proc = SO3Diffusion(wnet, timesteps=sched.shape[1]).to(dev)
     x0 = B.quat_to_rmat(torch.randn(nt, 4, device=dev))
@@ -309,11 +318,12 @@ def main():
                          "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=int(args.steps / launches),
                                                 precision=args.precision),
+                         "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_p_sample_chain"),
                          "launches": launches, "steps_per_launch": args.steps / launches, "ms_per_launch": ms_per_launch,
                          "flop_per_sample_step": MLP_FLOP_PER_SAMPLE,
-                         "note": "algorithmic MLP flops vs the dense bf16 MFMA peak; the kernel's real bound is the VALU "
-                                 "(555 transcendentals + ~2400 other instructions per 64-sample wave-step, DESIGN.md "
-                                 "section 4); algorithmic HBM traffic is 72 B/sample per launch"},
+                         "note": "algorithmic MLP flops vs the dense bf16 MFMA peak; the kernel's real bound is the VALU issue "
+                                 "port (546 transcendentals + ~1,300 other vector instructions per 64-sample wave-step, "
+                                 "~96 % of that floor, DESIGN.md section 4); algorithmic HBM traffic is 72 B/sample per launch"},
         }
         if not args.no_extras and ctx.world_size == 1:
             try:
