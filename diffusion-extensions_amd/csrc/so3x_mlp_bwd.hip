@@ -525,28 +525,30 @@ __device__ __forceinline__ void activate_zh(const Z33h& z, Tile<PREC>& out, int 
 }
 
 // Pre-activation stash between the training forward (k_mlp_fwd_stash) and k_bwd_fused: the four Z33h of a wave's
-// 32-sample tile as they sit in registers, 68 dwords per lane = 17 chunks of 16 B, chunk-major so that every store /
-// load is a fully coalesced 1 KiB per wave.  17 KiB per tile = 544 B per sample.
+// 32-sample tile as they sit in registers, 17 dwords per lane and layer = four fully coalesced 1-KiB chunks and one
+// 256-B row per layer, layer after layer, so that the backward can fetch them one layer ahead of their use.
+// 17 KiB per tile = 544 B per sample.
 constexpr size_t ZSTASH_TILE = 17 * 1024;
-__device__ __forceinline__ void zstash_store(char* tile_base, int lane, const Z33h (&z)[4]) {
-  uint32_t d[68];
+constexpr size_t ZSTASH_LAYER = 17 * 256;  // one layer of a tile: 4 chunks of [lane][16 B], then [lane][4 B]
+__device__ __forceinline__ void zstash_store_layer(char* tile_base, int lane, int l, const Z33h& z) {
+  char* lb = tile_base + l * ZSTASH_LAYER;
+  uint4* o = reinterpret_cast<uint4*>(lb) + lane;
 #pragma unroll
-  for (int l = 0; l < 4; l++)
-#pragma unroll
-    for (int i = 0; i < 17; i++) d[17 * l + i] = __builtin_bit_cast(uint32_t, z[l].p[i]);
-  uint4* o = reinterpret_cast<uint4*>(tile_base) + lane;
-#pragma unroll
-  for (int c = 0; c < 17; c++) o[c * 64] = uint4{d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]};
+  for (int c = 0; c < 4; c++)
+    o[c * 64] = uint4{__builtin_bit_cast(uint32_t, z.p[4 * c]), __builtin_bit_cast(uint32_t, z.p[4 * c + 1]),
+                      __builtin_bit_cast(uint32_t, z.p[4 * c + 2]), __builtin_bit_cast(uint32_t, z.p[4 * c + 3])};
+  reinterpret_cast<uint32_t*>(lb + 4096)[lane] = __builtin_bit_cast(uint32_t, z.p[16]);
 }
-__device__ __forceinline__ void zstash_load(const char* tile_base, int lane, Z33h (&z)[4]) {
-  const uint4* in = reinterpret_cast<const uint4*>(tile_base) + lane;
-  uint32_t d[68];
+__device__ __forceinline__ void zstash_load_layer(const char* tile_base, int lane, int l, Z33h& z) {
+  const char* lb = tile_base + l * ZSTASH_LAYER;
+  const uint4* in = reinterpret_cast<const uint4*>(lb) + lane;
 #pragma unroll
-  for (int c = 0; c < 17; c++) { const uint4 v = in[c * 64]; d[4 * c] = v.x; d[4 * c + 1] = v.y; d[4 * c + 2] = v.z; d[4 * c + 3] = v.w; }
-#pragma unroll
-  for (int l = 0; l < 4; l++)
-#pragma unroll
-    for (int i = 0; i < 17; i++) z[l].p[i] = __builtin_bit_cast(Z33h::h2, d[17 * l + i]);
+  for (int c = 0; c < 4; c++) {
+    const uint4 v = in[c * 64];
+    z.p[4 * c] = __builtin_bit_cast(Z33h::h2, v.x); z.p[4 * c + 1] = __builtin_bit_cast(Z33h::h2, v.y);
+    z.p[4 * c + 2] = __builtin_bit_cast(Z33h::h2, v.z); z.p[4 * c + 3] = __builtin_bit_cast(Z33h::h2, v.w);
+  }
+  z.p[16] = __builtin_bit_cast(Z33h::h2, reinterpret_cast<const uint32_t*>(lb + 4096)[lane]);
 }
 
 // Training forward (bf16 operands, per-timestep tables): the network output AND the stash above, so that the backward
@@ -587,7 +589,8 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     f32x16 last[1];
     hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
     if (live && h == 0) { out[idx * 3] = last[0][0]; out[idx * 3 + 1] = last[0][1]; out[idx * 3 + 2] = last[0][2]; }
-    zstash_store(zstash + (size_t)tile * ZSTASH_TILE, lane, z);
+#pragma unroll
+    for (int l = 0; l < 4; l++) zstash_store_layer(zstash + (size_t)tile * ZSTASH_TILE, lane, l, z[l]);
   }
 }
 
@@ -744,6 +747,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
     // =============================== chain waves ===============================
     char* my_img = fimg_all + wid * FIMG_BYTES;
     FimgStoreLane SL = fimg_store_lane(col);
+    Z33h zb[2];  // STASHED: the two rolling pre-activation buffers
     for (int64_t rd = 0; rd < rounds; rd++) {
       asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per round: no hoisting of the ~90 store addresses
       const int64_t tile = rd * nchain + (int64_t)blockIdx.x * 4 + wid;
@@ -751,14 +755,18 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       const int64_t s = tile * 32 + col;
       const bool live = active && s < n;
       const int64_t sc = live ? s : n - 1;
-      Z33h z[4];
+      // STASHED: the pre-activations parked by the training forward (k_mlp_fwd_stash) arrive one layer ahead of their
+      // use through two 17-register buffers, each fetch issued two uses before its SiLU pass (z3 and z2 of a round during
+      // the previous round's last layers), so no HBM latency is exposed and the four layers never sit in registers together.  Not STASHED: all four are recomputed here.
+      Z33h z[STASHED ? 1 : 4];
       f32x16 dh[3];
       float x[9];
       load_rot9(R, sc, x);
       const int64_t tt = t[sc * t_stride];
       const float lv = live ? 1.0f : 0.0f;  // dead columns contribute exact zeros to every dW sum
-      if constexpr (STASHED) {  // pre-activations parked by the training forward (k_mlp_fwd_stash)
-        zstash_load(zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE, lane, z);
+      const char* ztile = STASHED ? zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE : nullptr;
+      if constexpr (STASHED) {
+        if (rd == 0) { zstash_load_layer(ztile, lane, 3, zb[0]); zstash_load_layer(ztile, lane, 2, zb[1]); }
       } else {
         f32x16 a3[3];
         Tile<PREC> cur;
@@ -782,7 +790,12 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
         pdz[0] = pack_bf16x2(dout[sc * 3] * lv, dout[sc * 3 + 1] * lv);
         pdz[1] = pack_bf16x2(dout[sc * 3 + 2] * lv, 0.0f);
       }
-      silu_pass<PREC>(z[3], lv, h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
+      if constexpr (STASHED) {
+        silu_pass<PREC>(zb[0], lv, h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
+        zstash_load_layer(ztile, lane, 1, zb[0]);   // z1: used two layers from now
+      } else {
+        silu_pass<PREC>(z[3], lv, h, ph, dnext);
+      }
 #pragma unroll
       for (int l = 4; l >= 0; l--) {
         // ---- images of layer l (8-byte stores of ready-made operand bits)
@@ -821,7 +834,19 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
             pdz[r] = pack_bf16x2(g0, g1);
           }
           pdz[16] = pack_bf16x2(h ? 0.0f : dh[2][0] * dnext[32], 0.0f);  // upper half of tile 2 / reg 0 = the constant-one row
-          if (l > 1) silu_pass<PREC>(z[l - 2], lv, h, ph, dnext);       // H_{l-1} = silu(Z_{l-2}), silu'(Z_{l-2})
+          if constexpr (STASHED) {
+            // every fetch is issued two uses (~two layers, more than an HBM round trip) ahead:  l = 4 uses z2 (buffer 1)
+            // and fetches z0 into it;  l = 3 uses z1 (buffer 0, fetched at the top of the round) and fetches the NEXT
+            // round's z3;  l = 2 uses z0 and fetches the next round's z2
+            if (l > 1) silu_pass<PREC>(zb[l & 1 ? 0 : 1], lv, h, ph, dnext);
+            const int64_t ntile = (rd + 1) * nchain + (int64_t)blockIdx.x * 4 + wid;
+            const char* nz = zstash + (size_t)(ntile < ntiles ? ntile : ntiles - 1) * ZSTASH_TILE;
+            if (l == 4) zstash_load_layer(ztile, lane, 0, zb[1]);
+            if (l == 3) zstash_load_layer(nz, lane, 3, zb[0]);
+            if (l == 2) zstash_load_layer(nz, lane, 2, zb[1]);
+          } else {
+            if (l > 1) silu_pass<PREC>(z[l - 2], lv, h, ph, dnext);     // H_{l-1} = silu(Z_{l-2}), silu'(Z_{l-2})
+          }
         }
         __syncthreads();  // B2: the dW waves are done with the images
       }
