@@ -45,7 +45,8 @@ template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image
 // ---- prep: per-timestep effective bias of layer 0 (appendix C.3) ---------------------
 //   beff[t][o] = b_0[o] + sum_e W_0[o][9+e] * emb_e(t)   (o < 65), other rows 0.
 __global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ params, Freqs fr, int T, float scale,
-                                                    float* __restrict__ beff, float* __restrict__ emb_tab) {
+                                                    float* __restrict__ beff, float* __restrict__ emb_tab,
+                                                    __bf16* __restrict__ h0_tab) {
   __shared__ float emb[NEMB];
   const int t = blockIdx.x;
   if (threadIdx.x < NEMB) {
@@ -53,6 +54,8 @@ __global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ par
     if (emb_tab) emb_tab[(size_t)t * NEMB + threadIdx.x] = emb[threadIdx.x];  // [T][56] time-embedding table
   }
   __syncthreads();
+  if (h0_tab && threadIdx.x < 96)  // [T][96] bf16 input-slot row (embedding at slots 10..65)
+    h0_tab[(size_t)t * 96 + threadIdx.x] = (__bf16)((threadIdx.x >= 10 && threadIdx.x < 10 + NEMB) ? emb[threadIdx.x - 10] : 0.0f);
   const int o = threadIdx.x;
   if (o < 96) {
     float acc = 0.0f;
@@ -119,8 +122,9 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
   if (chain_layout(VAR) && T > 0) {
     float* beff = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR));
     float* emb = VAR == GATHER ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
+    __bf16* h0 = VAR == GATHER ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
     hipLaunchKernelGGL(k_prep_beff, dim3(T), dim3(128), 0, s, params, host_freqs(), T,
-                       fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb);
+                       fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb, h0);
   }
   return check_launch();
 }

@@ -416,7 +416,10 @@ inline size_t emb_offset(int precision, int variant, int T) { return beff_offset
 // bf16 CHAIN only: per-timestep layer-0 fragments [T][3][64][8 bf16] after the beff table (16-byte aligned: 384 B rows)
 inline size_t l0t_offset(int T) { return emb_offset(SO3X_PREC_BF16, CHAIN, T); }
 inline size_t l0t_end(int T) { return l0t_offset(T) + (size_t)T * 3 * 1024; }
-inline size_t tables_end(int precision, int variant, int T) { return emb_offset(precision, variant, T) + (size_t)T * NEMB * sizeof(float); }
+// ... then h0 [T][96] bf16: the layer-0 input row of timestep t as the backward's LDS image wants it (slot s of the 96 =
+// input slot s: 10..65 the embedding, zeros elsewhere), so a lane fetches its 48 slots with six 16-byte loads
+inline size_t h0_offset(int precision, int variant, int T) { return emb_offset(precision, variant, T) + (size_t)T * NEMB * sizeof(float); }
+inline size_t tables_end(int precision, int variant, int T) { return h0_offset(precision, variant, T) + (size_t)T * 96 * 2; }
 const Freqs& host_freqs();
 
 }  // namespace mlp

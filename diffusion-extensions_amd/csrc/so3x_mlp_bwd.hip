@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(512, 2)
 k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
             int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n,
-            const char* __restrict__ zstash) {
+            const char* __restrict__ zstash, const uint4* __restrict__ h0_tab) {
   // Wave specialisation: waves 0-3 ("chain" waves) load (STASHED) or recompute the forward's pre-activations and run the dZ chain for one 32-sample
   // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators; dw_row) and only consume
   // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
@@ -765,6 +765,11 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       const int64_t tt = t[sc * t_stride];
       const float lv = live ? 1.0f : 0.0f;  // dead columns contribute exact zeros to every dW sum
       const char* ztile = STASHED ? zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE : nullptr;
+      // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them), fetched now, stored five layers
+      // later: six 16-byte loads instead of 56 four-byte gathers waited for on the spot
+      uint4 hq[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) hq[i] = h0_tab[(size_t)tt * 12 + 6 * h + i];
       if constexpr (STASHED) {
         if (rd == 0) { zstash_load_layer(ztile, lane, 3, zb[0]); zstash_load_layer(ztile, lane, 2, zb[1]); }
       } else {
@@ -807,18 +812,19 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
           for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 24 + 2 * c8 + h, ph[2 * c8], ph[2 * c8 + 1]);
           fimg_store_pk(my_img, SL, 24 + 16 + h, ph[16], 0u);
         } else {  // H_0 = the network input: [0..8] R, [9] one, [10..65] emb(t), zeros; the two lanes of a column split the row
+          const uint32_t hd[24] = {hq[0].x, hq[0].y, hq[0].z, hq[0].w, hq[1].x, hq[1].y, hq[1].z, hq[1].w, hq[2].x, hq[2].y, hq[2].z, hq[2].w,
+                                   hq[3].x, hq[3].y, hq[3].z, hq[3].w, hq[4].x, hq[4].y, hq[4].z, hq[4].w, hq[5].x, hq[5].y, hq[5].z, hq[5].w};
 #pragma unroll
           for (int c4 = 0; c4 < 12; c4++) {
             const int ch0 = 24 + 12 * h + c4;  // chunk of the 4 consecutive input slots 48 h + 4 c4 ..
-            float v4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int klo = 4 * c4 + u, khi = 48 + 4 * c4 + u;  // the two candidates are compile-time, h selects
-              const float vlo = klo < 9 ? x[klo < 9 ? klo : 0] : (klo == 9 ? 1.0f : emb_tab[(size_t)tt * NEMB + (klo - 10)]);
-              const float vhi = khi < 66 ? emb_tab[(size_t)tt * NEMB + (khi < 66 ? khi - 10 : 0)] : 0.0f;
-              v4[u] = (h ? vhi : vlo) * lv;
+            uint32_t lo = hd[2 * c4], hi = hd[2 * c4 + 1];
+            if (c4 < 3) {  // the lower half's first three chunks carry the rotation entries and the constant one
+              const uint32_t plo = c4 == 0 ? pack_bf16x2(x[0], x[1]) : (c4 == 1 ? pack_bf16x2(x[4], x[5]) : pack_bf16x2(x[8], 1.0f));
+              const uint32_t phi = c4 == 0 ? pack_bf16x2(x[2], x[3]) : (c4 == 1 ? pack_bf16x2(x[6], x[7]) : hi);
+              lo = h ? lo : plo;
+              hi = h ? hi : phi;
             }
-            fimg_store_pk(my_img, SL, ch0, pack_bf16x2(v4[0], v4[1]), pack_bf16x2(v4[2], v4[3]));
+            fimg_store_pk(my_img, SL, ch0, live ? lo : 0u, live ? hi : 0u);
           }
         }
         __syncthreads();  // B1: images of layer l complete -- the dW waves consume them while this wave goes on
@@ -901,6 +907,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + L.wt));
   const float* beff = VAR == GATHER ? reinterpret_cast<const float*>(ws + beff_offset(PREC, VAR)) : nullptr;
   const float* emb = VAR == GATHER ? reinterpret_cast<const float*>(ws + emb_offset(PREC, VAR, t_table)) : nullptr;
+  const uint4* h0 = VAR == GATHER ? reinterpret_cast<const uint4*>(ws + h0_offset(PREC, VAR, t_table)) : nullptr;
   float* slabs = reinterpret_cast<float*>(ws + L.slabs);
   ST* stash = reinterpret_cast<ST*>(ws + L.stash);
   if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER) {
@@ -920,10 +927,10 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
     if (zstash)
       hipLaunchKernelGGL((k_bwd_fused<PREC, true>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
-                         emb, R, t, t_stride, dout, slabs, n, zstash);
+                         emb, R, t, t_stride, dout, slabs, n, zstash, h0);
     else
       hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
-                         emb, R, t, t_stride, dout, slabs, n, zstash);
+                         emb, R, t, t_stride, dout, slabs, n, zstash, h0);
     hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0);
     return check_launch();
   }
