@@ -426,8 +426,22 @@ constexpr int NTILE_T = NBLK * 8;  // transposed-weight tiles, stream order: lay
 
 // transposed image: tile (layer l, input-row tile ti): A[m][k] = W_l[o(k)][32 ti + m], k in the operand order of the packed
 // dZ registers (the same permutation as the forward image); true (unscaled) weights; the constant-one row gets no gradient.
+// Tiles NTILE_T .. NTILE_T + 7 (one k-step each, at 16-KiB pitch like the rest): the output layer transposed,
+// A[m][k] = W_out[k][32 ti + m] for k < 3 -- dX_6 = W_out^T dout as eight MFMAs instead of 384 loads and FMAs per lane.
 __global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict__ params, void* __restrict__ img) {
-  const int tile = blockIdx.x, l = NBLK - 1 - (tile >> 3), ti = tile & 7;
+  const int tile = blockIdx.x, ti = tile & 7;
+  if (tile >= NTILE_T) {
+    const float* Wo = params + (size_t)NBLK * LAYER_STRIDE;
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x, m = lane & 31, h = lane >> 5, i = 32 * ti + m;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = (__bf16)((h == 0 && j < 3 && i < DW) ? Wo[j * DW + i] : 0.0f);
+      reinterpret_cast<bf16x8*>(img)[(size_t)tile * 1024 + lane] = v;
+    }
+    return;
+  }
+  const int l = NBLK - 1 - (tile >> 3);
   const float* W = params + (size_t)l * LAYER_STRIDE;
   for (int p = threadIdx.x; p < 1024; p += blockDim.x) {
     const int lane = p & 63, m = lane & 31, h = lane >> 5, ks = p >> 6;
@@ -461,7 +475,6 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ params, 
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const int64_t ngroups = (n + 255) / 256;
   const char* gimg = reinterpret_cast<const char*>(gimg_t);
-  const float* Wout = params + (size_t)NBLK * LAYER_STRIDE;
   int slot = 0;
   issue_chunk<PREC>(gimg, ring, 0, 0, wave, lane);
   issue_chunk<PREC>(gimg, ring, 1, 1, wave, lane);
@@ -473,18 +486,15 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ params, 
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
     if (live) { d0 = dout[idx * 3]; d1 = dout[idx * 3 + 1]; d2 = dout[idx * 3 + 2]; }
     f32x16 dx[8];
-    const float* Wo = Wout;
-    asm volatile("" : "+s"(Wo));  // opaque per group: else the 384 loop-invariant loads are hoisted out of the group loop and spilled
+    {  // dX_6 = W_out^T dout on the matrix cores: K slots 0..2 of one k-step carry dout (lower lane half), A from the image tail
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const bf16x2 p01 = {(__bf16)d0, (__bf16)d1}, p2 = {(__bf16)d2, (__bf16)0.0f};
+      const u32x4 bq = {h ? 0u : __builtin_bit_cast(uint32_t, p01), h ? 0u : __builtin_bit_cast(uint32_t, p2), 0u, 0u};
+      const bf16x8 bop = __builtin_bit_cast(bf16x8, bq);
+      const bf16x8* Ah = reinterpret_cast<const bf16x8*>(gimg + (size_t)NTILE_T * 16384);
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tq = 0; tq < 32; tq++) {  // rows 32 tin + 8 q + 4 h + (0..3) of W_out^T dout; rows >= 255 read the bias (harmless: the one-row has no gradient path)
-      const int f0 = 8 * tq + 4 * h;
-      __builtin_amdgcn_sched_barrier(0);  // keep the 384 weight loads from being hoisted together
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int f = f0 + r;
-        const float w0 = f < DW ? Wo[f] : 0.f, w1 = f < DW ? Wo[DW + f] : 0.f, w2 = f < DW ? Wo[2 * DW + f] : 0.f;
-        dx[tq >> 2][4 * (tq & 3) + r] = w0 * d0 + w1 * d1 + w2 * d2;
-      }
+      for (int ti = 0; ti < 8; ti++) dx[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[(size_t)ti * 1024 + lane], bop, zero, 0, 0, 0);
     }
     {  // dZ of the output layer = dout in rows 0..2 of tile 0 (rows 0..3 live in regs 0..3 of the lower half)
       uint32_t p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -854,7 +864,7 @@ TrainLayout train_layout(int64_t n, int T, int precision) {
   L.nblk32 = f32 ? ((n + 127) / 128) * 4 : ((n + 255) / 256) * 8;   // whole workgroup passes
   L.layer_stride = (size_t)L.nblk32 * (f32 ? 32768 : 16384);
   L.img_t = (ws_bytes(precision, T) + 255) & ~(size_t)255;
-  L.x = L.img_t + (size_t)NTILE_T * (f32 ? 32768 : 16384);
+  L.x = L.img_t + (size_t)(NTILE_T + 8) * (f32 ? 32768 : 16384);  // + the transposed output layer (bf16 path)
   L.y = L.x + 7 * L.layer_stride;
   L.dz = L.y + 6 * L.layer_stride;
   L.partial = L.dz + 7 * L.layer_stride;
@@ -924,7 +934,7 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
   if (precision == SO3X_PREC_BF16) {
     constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
     if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, ws + L.x, ws + L.y, L.layer_stride))) return rc;
-    hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
+    hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T + 8), dim3(256), 0, s, params, (void*)(ws + L.img_t));
     static int cap_b = 0;
     if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
     const int64_t ngroups = (n + 255) / 256;
