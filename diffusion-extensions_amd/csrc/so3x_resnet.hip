@@ -468,8 +468,7 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(f
 //   dZ_l = dX_{l+1} * silu'(Z_l)  (stored for k_resnet_dw),  dX_l = dX_{l+1} + W_l^T dZ_l  (MFMA, C = the dX tile itself).
 // The transposed weight tiles stream through the same 3-slot LDS ring as the forward's.
 __global__ void __launch_bounds__(512, 1)
-k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ params, const float* __restrict__ dout,
-             const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n) {
+k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int PREC = SO3X_PREC_BF16, CB = chunk_bytes<PREC>();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
@@ -939,7 +938,7 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
     if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
     const int64_t ngroups = (n + 255) / 256;
     hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
-                       params, dout, yd, ws + L.dz, L.layer_stride, n);
+                       dout, yd, ws + L.dz, L.layer_stride, n);
     static int dwb_attr = 0;
     if (!dwb_attr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resnet_dw), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
