@@ -1,0 +1,28 @@
+import sys, os, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
+    sys.path.insert(0, os.path.abspath(p))
+import torch
+from so3x import backend as B
+from so3x.so3_train import RotPredict
+from so3x.diffusion import SO3Diffusion
+dev = "cuda:0"
+fused = len(sys.argv) > 1
+torch.manual_seed(0)
+net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
+proc = SO3Diffusion(net, timesteps=1000).to(dev)
+opt = torch.optim.Adam(net.parameters(), lr=3e-4, fused=fused)
+for lg in (12, 19):
+    n = 1 << lg
+    x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev))
+    def step():
+        loss = proc(x0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100): step()
+    torch.cuda.synchronize()
+    print("fused" if fused else "foreach", "n=2^%d step: %.1f us" % (lg, (time.perf_counter() - t0) / 100 * 1e6))
