@@ -287,3 +287,23 @@ def test_resnet_chain_explicit_draws_and_edge_sizes(B, golden):
             refg = O.resnet_bwd(g["params"], xm, tt, dout, "f64")
             got = host(B.resnet_bwd(dev(g["params"]), dev(xm), dev(tt, torch.int64), dev(dout), T, precision=0))
             assert np.abs(got - refg).max() < 3e-5 * max(1.0, np.abs(refg).max())
+
+
+@pytest.mark.gpu
+def test_wide_net_training_step_as_a_captured_graph(B):
+    """the wide network's whole training step (stash forward, dX chain, dW GEMM, reduce, fused Adam) replays as one hipGraph"""
+    from so3x.so3_lock_train import RotPredict
+    from so3x.diffusion import SO3Diffusion
+    from so3x.graphs import TrainStepGraph
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = SO3Diffusion(net, timesteps=200).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)
+    x = B.quat_to_rmat(torch.randn(600, 4, device=DEV))
+    before = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    g = TrainStepGraph(proc, opt, x.shape, warmup=2)
+    losses = [float(g.step(x)) for _ in range(5)]
+    after = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert all(np.isfinite(losses)) and len(set(losses)) == 5
+    assert float((after - before).abs().max()) > 1e-4 and torch.isfinite(after).all()
+    assert int(proc.rng_counter) == 2 + 5              # warm-up + replays (capture records, it does not execute)
