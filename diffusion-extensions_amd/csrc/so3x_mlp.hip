@@ -30,13 +30,13 @@ size_t beff_offset(int precision, int variant) { return (image_bytes_rt(precisio
 namespace {
 
 // ---- prep: flat state_dict parameters -> permuted/padded weight image ----------------
-template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image(const float* __restrict__ params, void* __restrict__ img) {
+template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image(const float* __restrict__ params, void* __restrict__ img, int nout) {
   constexpr int NF = n_frags<PREC, VAR>();
   constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;  // elements per lane per fragment
   const int total = NF * 64 * EPL;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
-    const float v = image_value<PREC, VAR>(params, frag, lane, j);
+    const float v = image_value<PREC, VAR>(params, frag, lane, j, nout);
     if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
     else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
   }
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(192) k_prep_l0t(const float* __restrict__ para
 template <int PREC, int VAR>
 __global__ void __launch_bounds__(256, 2)
 k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
-          const int64_t* __restrict__ t, int64_t t_stride, Freqs fr, float* __restrict__ out, int64_t n) {
+          const int64_t* __restrict__ t, int64_t t_stride, Freqs fr, float* __restrict__ out, int64_t n, int nout) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   load_image(gimg, lds, image_bytes<PREC, VAR>());
   __syncthreads();
@@ -111,14 +111,17 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
     float x[9];
     load_rot9(R, idx, x);
     const int64_t tt = t[idx * t_stride];
-    float v[3];
-    forward_tile<PREC, VAR>(lds, x, chain_layout(VAR) ? beff_tab + (size_t)tt * 96 : nullptr, tt, &fr, v, lane);
-    if (live && h == 0) { out[idx * 3] = v[0]; out[idx * 3 + 1] = v[1]; out[idx * 3 + 2] = v[2]; }
+    float v[NOUT_MAX];
+    forward_tile<PREC, VAR, 0, false, NOUT_MAX>(lds, x, chain_layout(VAR) ? beff_tab + (size_t)tt * 96 : nullptr, tt, &fr, v, lane);
+    if (live && h == 0) {
+      out[idx * nout] = v[0]; out[idx * nout + 1] = v[1]; out[idx * nout + 2] = v[2];
+      if (nout == 6) { out[idx * 6 + 3] = v[3]; out[idx * 6 + 4] = v[4]; out[idx * 6 + 5] = v[5]; }
+    }
   }
 }
 
-template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws) {
-  hipLaunchKernelGGL((k_prep_image<PREC, VAR>), dim3(32), dim3(256), 0, s, params, ws);
+template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws, int nout) {
+  hipLaunchKernelGGL((k_prep_image<PREC, VAR>), dim3(32), dim3(256), 0, s, params, ws, nout);
   if (chain_layout(VAR) && T > 0) {
     float* beff = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR));
     float* emb = VAR == GATHER ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
@@ -130,7 +133,7 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
 }
 
 template <int PREC, int VAR>
-int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n) {
+int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n, int nout) {
   constexpr int IMG = image_bytes<PREC, VAR>();
   static int attr_set = 0;  // idempotent: raising the dynamic-LDS cap of this kernel
   if (!attr_set) {
@@ -145,7 +148,7 @@ int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   const float* beff = chain_layout(VAR) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + beff_offset(PREC, VAR))
                                         : nullptr;
-  hipLaunchKernelGGL((k_mlp_fwd<PREC, VAR>), dim3(grid), dim3(256), IMG, s, ws, beff, R, t, t_stride, host_freqs(), out, n);
+  hipLaunchKernelGGL((k_mlp_fwd<PREC, VAR>), dim3(grid), dim3(256), IMG, s, ws, beff, R, t, t_stride, host_freqs(), out, n, nout);
   return check_launch();
 }
 
@@ -160,15 +163,15 @@ int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace) 
                      reinterpret_cast<const float*>(ws + beff_offset(SO3X_PREC_BF16, CHAIN)), (void*)(ws + l0t_offset(T)));
   return check_launch();
 }
-int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace) {
+int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout) {
   if (precision == SO3X_PREC_F32) {
-    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace);
-    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace);
-    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace);
+    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace, nout);
+    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace, nout);
+    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace, nout);
   }
-  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace);
-  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace);
-  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace);
+  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout);
+  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout);
+  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout);
 }
 }  // namespace mlp
 }  // namespace so3x
@@ -176,23 +179,24 @@ int launch_prep(hipStream_t s, const float* params, int precision, int variant, 
 extern "C" {
 
 int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
-                 int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
-  if (n < 0 || (n && (!params || !R || !t || !out)) || (t_stride != 0 && t_stride != 1) || t_table < 0)
+                 int64_t n, int n_out, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !out)) || (t_stride != 0 && t_stride != 1) || t_table < 0 ||
+      (n_out != 3 && n_out != 6))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < (t_table ? tables_end(precision, CHAIN, t_table) : image_bytes_rt(precision, FULL)))
     return SO3X_ERR_WORKSPACE;
   if (n == 0) return SO3X_OK;
   if (t_table > 0) {  // bounded timesteps: per-timestep effective-bias rows gathered per sample, no in-kernel sin/cos
-    int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, t_table, workspace);
+    int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, t_table, workspace, n_out);
     if (rc) return rc;
-    if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, CHAIN>((hipStream_t)s, workspace, R, t, t_stride, out, n);
-    return launch_fwd_t<SO3X_PREC_BF16, CHAIN>((hipStream_t)s, workspace, R, t, t_stride, out, n);
+    if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, CHAIN>((hipStream_t)s, workspace, R, t, t_stride, out, n, n_out);
+    return launch_fwd_t<SO3X_PREC_BF16, CHAIN>((hipStream_t)s, workspace, R, t, t_stride, out, n, n_out);
   }
-  int rc = launch_prep((hipStream_t)s, params, precision, FULL, 0, workspace);
+  int rc = launch_prep((hipStream_t)s, params, precision, FULL, 0, workspace, n_out);
   if (rc) return rc;
-  if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);
-  return launch_fwd_t<SO3X_PREC_BF16, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n);
+  if (precision == SO3X_PREC_F32) return launch_fwd_t<SO3X_PREC_F32, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n, n_out);
+  return launch_fwd_t<SO3X_PREC_BF16, FULL>((hipStream_t)s, workspace, R, t, t_stride, out, n, n_out);
 }
 
 }  // extern "C"

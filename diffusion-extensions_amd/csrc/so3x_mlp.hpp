@@ -37,13 +37,21 @@ constexpr int ONE_ROW = 68;  // hidden-feature row that carries the constant 1
 constexpr int LAYER_STRIDE = D * D + D;
 constexpr int NPARAMS = 4 * LAYER_STRIDE + 3 * D + 3;
 static_assert(NPARAMS == SO3X_MLP_PARAMS, "param count");
+// The output layer is 3 wide (out_type "skewvec") or 6 wide ("rotmat", so3_train.py:19-22); n_out is a run-time argument.
+// Head output o sits in row o (o < 4) or o + 4 of the layer's single 32-row tile: rows 0..3, 8, 9 are accumulator
+// registers 0..5 of the LOWER lane half, so one lane holds all of a sample's outputs, and -- read as a contraction index
+// (dH_4 = W_4^T dout) -- K slots 0..5 of that half.
+constexpr int NOUT_MAX = 6;
+constexpr int NPARAMS_MAX = 4 * LAYER_STRIDE + NOUT_MAX * D + NOUT_MAX;  // slab stride of the dW partials
+static_assert(NPARAMS_MAX == SO3X_MLP_PARAMS_ROTMAT, "param count");
+__host__ __device__ constexpr int nparams(int nout) { return 4 * LAYER_STRIDE + nout * (D + 1); }
+__host__ __device__ constexpr int head_of_row(int row) { return row < 4 ? row : ((row == 8 || row == 9) ? row - 4 : -1); }
 
 struct Freqs { float f[NFREQ]; };  // passed by value as a kernel argument
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
 
-__host__ __device__ constexpr int dout_of(int l) { return l < 4 ? D : 3; }
 __host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 // ---- image geometry -------------------------------------------------------------
@@ -109,17 +117,17 @@ template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() { r
 
 // weight-image element value: fragment `frag`, lane, element j (bf16 only)
 template <int PREC, int VAR>
-__device__ inline float image_value(const float* __restrict__ params, int frag, int lane, int j) {
+__device__ inline float image_value(const float* __restrict__ params, int frag, int lane, int j, int nout) {
   const int i = lane & 31, h = lane >> 5;
   int l, tout, ks;
   constexpr int K0 = ks_layer0<PREC, VAR>(), KH = ks_hidden<PREC>();
   if (frag < 3 * K0) { l = 0; tout = frag / K0; ks = frag % K0; }
   else if (frag < frag_last<PREC, VAR>()) { int f = frag - 3 * K0; l = 1 + f / (3 * KH); f %= 3 * KH; tout = f / KH; ks = f % KH; }
   else { l = 4; tout = 0; ks = frag - frag_last<PREC, VAR>(); }
-  const int o = 32 * tout + i;
-  if (o >= dout_of(l)) return 0.0f;
+  const int o = l < 4 ? 32 * tout + i : head_of_row(i);
+  if (o < 0 || o >= (l < 4 ? D : nout)) return 0.0f;
   const float* W = params + l * LAYER_STRIDE;
-  const float* bias = W + dout_of(l) * D;
+  const float* bias = W + (l < 4 ? D : nout) * D;
   if (l == 0) {
     const int col = l0_slot_to_col<PREC, VAR>(l0_slot<PREC>(ks, h, j));
     const float sc0 = fold_scale<PREC, VAR>() ? kFoldS : 1.0f;
@@ -372,9 +380,9 @@ __device__ __forceinline__ void layer0_full(const char* __restrict__ wl, const f
   }
 }
 
-// The whole network on one 32-sample tile.  Returns the 3 outputs of sample column
-// (lane & 31) in v[0..2]; only lanes of the LOWER half (h == 0) hold valid values.
-template <int PREC, int VAR, int XSRC = 0, bool L0T = false>
+// The whole network on one 32-sample tile.  Returns the outputs of sample column
+// (lane & 31) in v[0..NV-1]; only lanes of the LOWER half (h == 0) hold valid values.
+template <int PREC, int VAR, int XSRC = 0, bool L0T = false, int NV = 3>
 __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS weight image*/, const float* x,
                                              const float* __restrict__ beff, int64_t t, const Freqs* fr, float* v, int lane,
                                              const bf16x8* __restrict__ l0t = nullptr) {
@@ -394,7 +402,8 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
   }
   f32x16 last[1];
   hidden_layer<PREC, 1>(img + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
-  v[0] = last[0][0]; v[1] = last[0][1]; v[2] = last[0][2];  // rows 0,1,2 = regs 0,1,2 of the lower half
+#pragma unroll
+  for (int k = 0; k < NV; k++) v[k] = last[0][k];  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
 }
 
 // cooperative copy of the weight image (global workspace -> LDS), 16 B per lane
@@ -408,7 +417,7 @@ __device__ __forceinline__ void load_image(const void* __restrict__ gimg, char* 
 size_t image_bytes_rt(int precision, int variant);
 // writes the weight image at workspace[0 .. image) and, for CHAIN with T > 0, the
 // effective-bias table beff[T][96] right after it (16-B aligned).
-int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace);
+int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout = 3);
 int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace);
 size_t beff_offset(int precision, int variant);
 // tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32

@@ -30,20 +30,20 @@ namespace {
 constexpr int HROWS = 66;                       // 65 inputs + the constant one (bias carrier)
 constexpr int H_BASE(int l) { return HROWS * l; }
 constexpr int DZ_BASE(int l) { return 5 * HROWS + D * l; }
-constexpr int STASH_ROWS = 5 * HROWS + 4 * D + 3;  // 593
-constexpr int CHUNK = 1 << 19;  // samples per stash chunk: 593 rows x 2^19 x 4 B = 1.24 GB of workspace (288 GB HBM)
+constexpr int STASH_ROWS = 5 * HROWS + 4 * D + NOUT_MAX;  // 596 (the dZ_4 rows beyond n_out hold zeros)
+constexpr int CHUNK = 1 << 19;  // samples per stash chunk: 596 rows x 2^19 x 4 B = 1.24 GB of workspace (288 GB HBM)
 constexpr int DW_BLOCKS = 256;
 constexpr int NPAIRS = 39;                      // 4 layers x 3x3 tiles + last layer 1x3
 
 // ---- transposed-weight image (A operand of dH = W^T dZ), global/L2-resident -----------
 // fragment order: layers 1..3: [l-1][To(in-feature tile) 3][ks over out-features KH], then layer 4: [To 3][K4]
-template <int PREC> __host__ __device__ constexpr int k4() { return PREC == SO3X_PREC_F32 ? 3 : 1; }
+template <int PREC> __host__ __device__ constexpr int k4() { return PREC == SO3X_PREC_F32 ? NOUT_MAX : 1; }  // k-steps covering head slots 0..5
 template <int PREC> __host__ __device__ constexpr int wt_frag(int l, int to, int ks) {
   return l < 4 ? ((l - 1) * 3 + to) * ks_hidden<PREC>() + ks : 9 * ks_hidden<PREC>() + to * k4<PREC>() + ks;
 }
 template <int PREC> __host__ __device__ constexpr int wt_nfrags() { return 9 * ks_hidden<PREC>() + 3 * k4<PREC>(); }
 
-template <int PREC> __global__ void __launch_bounds__(256) k_prep_wt(const float* __restrict__ params, void* __restrict__ img) {
+template <int PREC> __global__ void __launch_bounds__(256) k_prep_wt(const float* __restrict__ params, void* __restrict__ img, int nout) {
   constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;
   constexpr int KH = ks_hidden<PREC>();
   const int total = wt_nfrags<PREC>() * 64 * EPL;
@@ -54,9 +54,10 @@ template <int PREC> __global__ void __launch_bounds__(256) k_prep_wt(const float
     if (frag < 9 * KH) { l = 1 + frag / (3 * KH); to = (frag % (3 * KH)) / KH; ks = frag % KH; }
     else { const int f = frag - 9 * KH; l = 4; to = f / k4<PREC>(); ks = f % k4<PREC>(); }
     const int in = 32 * to + i;                       // row of W^T = input feature of layer l
-    const int out = hidden_feature<PREC>(ks, h, j);   // k index = output feature of layer l
+    int out = hidden_feature<PREC>(ks, h, j);         // k index = output feature of layer l (layer 4: its tile row)
+    if (l == 4) out = head_of_row(out);
     float v = 0.0f;
-    if (in < D && out < dout_of(l)) v = params[l * LAYER_STRIDE + out * D + in];
+    if (in < D && out >= 0 && out < (l < 4 ? D : nout)) v = params[l * LAYER_STRIDE + out * D + in];
     if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
     else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
   }
@@ -74,12 +75,12 @@ template <int PREC> __device__ __forceinline__ void silu_grad(float z, float* hv
   *dval = sg + hv * (1.0f - sg);  // sigma (1 + z (1 - sigma))
 }
 
-// dH = W^T dZ for one layer; dz in the 33-register layout of Z33 (layer-4: only v[0..2] of the lower half)
+// dH = W^T dZ for one layer; dz in the 33-register layout of Z33 (layer-4: only v[0..5] of the lower half)
 template <int PREC, int L>
 __device__ __forceinline__ void dh_layer(const void* __restrict__ wt, const Z33& dz, f32x16 (&dh)[3], int lane) {
   if constexpr (PREC == SO3X_PREC_F32) {
     const float* w = reinterpret_cast<const float*>(wt);
-    constexpr int KS = L < 4 ? 33 : 3;
+    constexpr int KS = L < 4 ? 33 : k4<PREC>();
 #pragma unroll
     for (int to = 0; to < 3; to++) {
       __builtin_amdgcn_sched_barrier(0);  // bound the LDS-read hoisting to one output tile
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256, 1)
 k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
             int64_t t_stride, const float* __restrict__ dout, Freqs fr, typename Stash<PREC>::T* __restrict__ stash,
-            int64_t nc /*samples in this chunk*/) {
+            int64_t nc /*samples in this chunk*/, int nout) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool SWAP = swap_images<PREC>();
   constexpr int FB = frag_bytes<PREC>();
@@ -182,13 +183,14 @@ k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
     const int64_t sc = live ? s : nc - 1;
     const unsigned off1 = (unsigned)(h * nc + s), off4 = (unsigned)(4 * h * nc + s);
     Z33 z[4];
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    float dd[NOUT_MAX] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
       float x[9];
 #pragma unroll
       for (int j = 0; j < 9; j++) x[j] = R[sc * 9 + j];
       const int64_t tt = t[sc * t_stride];
-      d0 = dout[sc * 3]; d1 = dout[sc * 3 + 1]; d2 = dout[sc * 3 + 2];
+#pragma unroll
+      for (int k = 0; k < NOUT_MAX; k++) dd[k] = k < nout ? dout[sc * nout + k] : 0.0f;
       // ---- layer-0 input rows of the stash: [0..8] R, [9] one, [10..65] emb (canonical order);
       //      the two lanes of a sample split the rows: lane half h writes rows 2 j + h
       if (live) {
@@ -227,11 +229,10 @@ k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
 #pragma unroll
       for (int q = 0; q < 33; q++) dz.v[q] = 0.0f;
       if (h == 0) {
-        dz.v[0] = d0; dz.v[1] = d1; dz.v[2] = d2;
-        if (live) {
-          st_row(stash, nc, DZ_BASE(4) + 0, off1, d0);  // h == 0 here: off1 == s
-          st_row(stash, nc, DZ_BASE(4) + 1, off1, d1);
-          st_row(stash, nc, DZ_BASE(4) + 2, off1, d2);
+#pragma unroll
+        for (int k = 0; k < NOUT_MAX; k++) {
+          dz.v[k] = dd[k];                                          // K slots 0..5 of the lower half (head_of_row)
+          if (live) st_row(stash, nc, DZ_BASE(4) + k, off1, dd[k]);  // h == 0 here: off1 == s
         }
       }
       dh_layer<PREC, 4>(wt_lds, dz, dh, lane);
@@ -271,15 +272,15 @@ __device__ __forceinline__ void pair_of(int p, int* l, int* to, int* ti) {
   else { *l = 4; *to = 0; *ti = p - 36; }
 }
 
-__device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h);
-__device__ __forceinline__ void write_slab(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h) {
-  write_slab_impl(slabs, acc, wid, i, h);
+__device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h, int nout);
+__device__ __forceinline__ void write_slab(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h, int nout) {
+  write_slab_impl(slabs, acc, wid, i, h, nout);
 }
 
 constexpr int LROW = 33;  // padded LDS row (floats): fragment reads of stride-LROW rows are conflict-free
 
 __global__ void __launch_bounds__(512, 1)
-k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs) {
+k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs, int n_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [STASH_ROWS][LROW]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -312,7 +313,7 @@ k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs)
       if (p < NPAIRS) {
         int l, to, ti;
         pair_of(p, &l, &to, &ti);
-        const int nout = (l < 4 ? D : 3) - 32 * to;   // valid dZ rows in this tile
+        const int nout = (l < 4 ? D : NOUT_MAX) - 32 * to;   // valid dZ rows in this tile
         const int nin = HROWS - 32 * ti;              // valid H rows in this tile
         const bool va = i < nout, vb = i < nin;
         const float* pa = sm + (DZ_BASE(l) + 32 * to + (va ? i : 0)) * LROW + h;
@@ -328,12 +329,12 @@ k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs)
       }
     }
   }
-  write_slab(slabs, acc, wid, i, h);
+  write_slab(slabs, acc, wid, i, h, n_out);
 }
 
 // this block's partial dparams slab (every entry is owned by exactly one lane of one wave)
-__device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h) {
-  float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
+__device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const f32x16 (&acc)[5], int wid, int i, int h, int nout) {
+  float* slab = slabs + (size_t)blockIdx.x * NPARAMS_MAX;
 #pragma unroll
   for (int k = 0; k < 5; k++) {
     const int p = wid + 8 * k;
@@ -344,12 +345,12 @@ __device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int out = 32 * to + row_of(r, h);
-        if (out >= (l < 4 ? D : 3) || in_ext >= HROWS) continue;
+        if (out >= (l < 4 ? D : nout) || in_ext >= HROWS) continue;
         int col;  // column of the layer's weight, or -2 = bias
         if (l == 0) col = in_ext < 9 ? in_ext : (in_ext == 9 ? -2 : in_ext - 1);  // [R(9), one, emb(56)] -> cols 0..8, bias, 9..64
         else col = in_ext < D ? in_ext : -2;
         const int base = l * LAYER_STRIDE;
-        const int idx = col >= 0 ? base + out * D + col : base + (l < 4 ? D : 3) * D + out;
+        const int idx = col >= 0 ? base + out * D + col : base + (l < 4 ? D : nout) * D + out;
         slab[idx] = acc[k][r];
       }
     }
@@ -361,7 +362,7 @@ __device__ __forceinline__ void write_slab_impl(float* __restrict__ slabs, const
 constexpr int LROW16 = 40;  // bf16 elements per padded LDS row
 
 __global__ void __launch_bounds__(512, 1)
-k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ slabs) {
+k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ slabs, int n_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __bf16* sb = reinterpret_cast<__bf16*>(sm);  // [STASH_ROWS][LROW16]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -395,7 +396,7 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
       if (p < NPAIRS) {
         int l, to, ti;
         pair_of(p, &l, &to, &ti);
-        const int nout = (l < 4 ? D : 3) - 32 * to;
+        const int nout = (l < 4 ? D : NOUT_MAX) - 32 * to;
         const int nin = HROWS - 32 * ti;
         const bool va = i < nout, vb = i < nin;
         const __bf16* pa = sb + (DZ_BASE(l) + 32 * to + (va ? i : 0)) * LROW16 + 8 * h;
@@ -411,22 +412,22 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
       }
     }
   }
-  write_slab(slabs, acc, wid, i, h);
+  write_slab(slabs, acc, wid, i, h, n_out);
 }
 
 // 32 parameters x 8 slab groups per block: coalesced 128-B reads, 8-way split of the slab loop, fixed
 // summation order (deterministic)
 __global__ void __launch_bounds__(256)
-k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate) {
+k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np) {
   __shared__ float part[8][33];
   const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + p;
   float s = 0.0f;
-  if (idx < NPARAMS)
-    for (int b = g; b < nslabs; b += 8) s += slabs[(size_t)b * NPARAMS + idx];
+  if (idx < np)
+    for (int b = g; b < nslabs; b += 8) s += slabs[(size_t)b * NPARAMS_MAX + idx];
   part[g][p] = s;
   __syncthreads();
-  if (g == 0 && idx < NPARAMS) {
+  if (g == 0 && idx < np) {
     float t = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) t += part[k][p];
@@ -557,7 +558,7 @@ __device__ __forceinline__ void zstash_load_layer(const char* tile_base, int lan
 template <int PREC>
 __global__ void __launch_bounds__(256, 2)
 k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
-                const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n) {
+                const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n, int nout) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int VAR = GATHER;
   constexpr int FB = frag_bytes<PREC>();
@@ -588,7 +589,10 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     activate_zh<PREC>(z[3], cur, h);
     f32x16 last[1];
     hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
-    if (live && h == 0) { out[idx * 3] = last[0][0]; out[idx * 3 + 1] = last[0][1]; out[idx * 3 + 2] = last[0][2]; }
+    if (live && h == 0) {  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
+      out[idx * nout] = last[0][0]; out[idx * nout + 1] = last[0][1]; out[idx * nout + 2] = last[0][2];
+      if (nout == 6) { out[idx * 6 + 3] = last[0][3]; out[idx * 6 + 4] = last[0][4]; out[idx * 6 + 5] = last[0][5]; }
+    }
 #pragma unroll
     for (int l = 0; l < 4; l++) zstash_store_layer(zstash + (size_t)tile * ZSTASH_TILE, lane, l, z[l]);
   }
@@ -654,7 +658,7 @@ __host__ __device__ constexpr int dw_slot(int dwi, int l) {                     
 
 // The dW role of k_bwd_fused for dW wave DWI (0..3).
 template <int PREC, int DWI>
-__device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, float* __restrict__ slabs, int lane) {
+__device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, float* __restrict__ slabs, int lane, int nout) {
   const int col = lane & 31, h = lane >> 5;
   f32x16 acc[10];  // [3 slot + ti] for the hidden layers, [9] = the wave's tile of the output layer
 #pragma unroll
@@ -693,19 +697,19 @@ __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, fl
     }
   }
   // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
-  float* slab = slabs + (size_t)blockIdx.x * NPARAMS;
+  float* slab = slabs + (size_t)blockIdx.x * NPARAMS_MAX;
   auto write_tile = [&](const f32x16& a, int l, int to, int ti) {
     const int in_f = 32 * ti + col;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const int out = 32 * to + row_of(r, h);
-      if (out >= (l < 4 ? D : 3)) continue;
+      const int out = l < 4 ? 32 * to + row_of(r, h) : head_of_row(row_of(r, h));
+      if (out < 0 || out >= (l < 4 ? D : nout)) continue;
       int pc;  // weight column, -2 = bias, -1 = padding
       if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
       else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
       if (pc == -1) continue;
       const int base = l * LAYER_STRIDE;
-      slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = a[r];
+      slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : nout) * D + out] = a[r];
     }
   };
 #pragma unroll
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(512, 2)
 k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
             int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n,
-            const char* __restrict__ zstash, const uint4* __restrict__ h0_tab) {
+            const char* __restrict__ zstash, const uint4* __restrict__ h0_tab, int nout) {
   // Wave specialisation: waves 0-3 ("chain" waves) load (STASHED) or recompute the forward's pre-activations and run the dZ chain for one 32-sample
   // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators; dw_row) and only consume
   // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
@@ -791,9 +795,11 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       float dnext[33];  // silu'(Z_{l-1}) of the layer about to be differentiated
 #pragma unroll
       for (int r = 0; r < 17; r++) pdz[r] = 0u;
-      if (h == 0) {
-        pdz[0] = pack_bf16x2(dout[sc * 3] * lv, dout[sc * 3 + 1] * lv);
-        pdz[1] = pack_bf16x2(dout[sc * 3 + 2] * lv, 0.0f);
+      if (h == 0) {  // dZ_4 = dout in K slots / image columns 0..5 of the lower half (head_of_row)
+        const float* dp = dout + sc * nout;
+        pdz[0] = pack_bf16x2(dp[0] * lv, dp[1] * lv);
+        pdz[1] = pack_bf16x2(dp[2] * lv, nout == 6 ? dp[3] * lv : 0.0f);
+        if (nout == 6) pdz[2] = pack_bf16x2(dp[4] * lv, dp[5] * lv);
       }
       if constexpr (STASHED) {
         silu_pass<PREC>(zb[0], lv, h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
@@ -862,10 +868,10 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
     // one instantiation per dW wave: with the wave's index a compile-time constant its pairs, their layers and every LDS
     // offset fold into the instruction stream
     switch (wid - 4) {
-      case 0: dw_role<PREC, 0>(fimg_all, rounds, slabs, lane); break;
-      case 1: dw_role<PREC, 1>(fimg_all, rounds, slabs, lane); break;
-      case 2: dw_role<PREC, 2>(fimg_all, rounds, slabs, lane); break;
-      default: dw_role<PREC, 3>(fimg_all, rounds, slabs, lane); break;
+      case 0: dw_role<PREC, 0>(fimg_all, rounds, slabs, lane, nout); break;
+      case 1: dw_role<PREC, 1>(fimg_all, rounds, slabs, lane, nout); break;
+      case 2: dw_role<PREC, 2>(fimg_all, rounds, slabs, lane, nout); break;
+      default: dw_role<PREC, 3>(fimg_all, rounds, slabs, lane, nout); break;
     }
   }
 }
@@ -878,7 +884,7 @@ template <int PREC> BwdLayout bwd_layout(int64_t n, int t_table) {
   BwdLayout L;
   L.wt = (head + 255) & ~(size_t)255;
   L.slabs = (L.wt + (size_t)wt_nfrags<PREC>() * frag_bytes<PREC>() + 255) & ~(size_t)255;
-  L.stash = L.slabs + (size_t)DW_BLOCKS * NPARAMS * sizeof(float);
+  L.stash = L.slabs + (size_t)DW_BLOCKS * NPARAMS_MAX * sizeof(float);
   const int64_t nc = n < CHUNK ? (n < 32 ? 32 : n) : CHUNK;
   L.end = L.stash + (size_t)STASH_ROWS * (size_t)nc * sizeof(typename Stash<PREC>::T) + 256;
   return L;
@@ -886,7 +892,7 @@ template <int PREC> BwdLayout bwd_layout(int64_t n, int t_table) {
 
 template <int PREC, int VAR>
 int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
-               float* dparams, int64_t n, int t_table, char* ws, const char* zstash = nullptr) {
+               float* dparams, int64_t n, int nout, int t_table, char* ws, const char* zstash = nullptr) {
   using ST = typename Stash<PREC>::T;
   constexpr int DW_LDS = PREC == SO3X_PREC_F32 ? STASH_ROWS * LROW * (int)sizeof(float) : STASH_ROWS * LROW16 * 2;
   constexpr int STAGE_LDS = stage_lds_bytes<PREC, VAR>();
@@ -902,9 +908,9 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     if (e != hipSuccess) return (int)e;
     attr_set = 1;
   }
-  int rc = launch_prep(s, params, PREC, VAR, t_table, ws);
+  int rc = launch_prep(s, params, PREC, VAR, t_table, ws, nout);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + L.wt));
+  hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + L.wt), nout);
   const float* beff = VAR == GATHER ? reinterpret_cast<const float*>(ws + beff_offset(PREC, VAR)) : nullptr;
   const float* emb = VAR == GATHER ? reinterpret_cast<const float*>(ws + emb_offset(PREC, VAR, t_table)) : nullptr;
   const uint4* h0 = VAR == GATHER ? reinterpret_cast<const uint4*>(ws + h0_offset(PREC, VAR, t_table)) : nullptr;
@@ -927,11 +933,11 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
     if (zstash)
       hipLaunchKernelGGL((k_bwd_fused<PREC, true>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
-                         emb, R, t, t_stride, dout, slabs, n, zstash, h0);
+                         emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
     else
       hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
-                         emb, R, t, t_stride, dout, slabs, n, zstash, h0);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0);
+                         emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout));
     return check_launch();
   }
   for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
@@ -939,15 +945,15 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
     const int64_t ntiles = (nc + 31) / 32;
     const int g1 = (int)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
     hipLaunchKernelGGL((k_bwd_stage<PREC, VAR>), dim3(g1), dim3(256), STAGE_LDS, s, (const void*)ws,
-                       (const void*)(ws + L.wt), beff, emb, R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * 3,
-                       host_freqs(), stash, nc);
+                       (const void*)(ws + L.wt), beff, emb, R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * nout,
+                       host_freqs(), stash, nc, nout);
     const int g2 = (int)(ntiles < DW_BLOCKS ? ntiles : DW_BLOCKS);
     if constexpr (PREC == SO3X_PREC_F32)
-      hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs);
+      hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs, nout);
     else
-      hipLaunchKernelGGL(k_bwd_dw_bf16, dim3(g2), dim3(512), DW_LDS, s, (const __bf16*)stash, nc, slabs);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((NPARAMS + 31) / 32), dim3(256), 0, s, (const float*)slabs, g2, dparams,
-                       c0 > 0 ? 1 : 0);
+      hipLaunchKernelGGL(k_bwd_dw_bf16, dim3(g2), dim3(512), DW_LDS, s, (const __bf16*)stash, nc, slabs, nout);
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(256), 0, s, (const float*)slabs, g2, dparams,
+                       c0 > 0 ? 1 : 0, nparams(nout));
   }
   return check_launch();
 }
@@ -964,15 +970,16 @@ size_t so3x_mlp_workspace_bytes(int64_t n, int precision, int t_table) {
 size_t so3x_mlp_stash_bytes(int64_t n) { return (size_t)((n > 0 ? n : 0) + 31) / 32 * ZSTASH_TILE; }
 
 int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
-                       void* zstash, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
-  if (n < 0 || (n && (!params || !R || !t || !out || !zstash)) || (t_stride != 0 && t_stride != 1) || t_table < 0)
+                       void* zstash, int64_t n, int n_out, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n && (!params || !R || !t || !out || !zstash)) || (t_stride != 0 && t_stride != 1) || t_table < 0 ||
+      (n_out != 3 && n_out != 6))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_BF16 || t_table <= 0) return SO3X_ERR_UNSUPPORTED;  // the stash is the fused backward's
   if (!workspace || workspace_bytes < tables_end(precision, GATHER, t_table)) return SO3X_ERR_WORKSPACE;
   if (n == 0) return SO3X_OK;
   constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER>();
   char* ws = (char*)workspace;
-  int rc = launch_prep((hipStream_t)s, params, PREC, GATHER, t_table, ws);
+  int rc = launch_prep((hipStream_t)s, params, PREC, GATHER, t_table, ws, n_out);
   if (rc) return rc;
   static int attr = 0;
   if (!attr) {
@@ -983,29 +990,29 @@ int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, con
   }
   const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
   hipLaunchKernelGGL((k_mlp_fwd_stash<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, (hipStream_t)s, (const void*)ws,
-                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n);
+                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out);
   return check_launch();
 }
 
 int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride,
-                 const float* dout, float* dparams, int64_t n, int precision, int t_table, const void* zstash,
+                 const float* dout, float* dparams, int64_t n, int n_out, int precision, int t_table, const void* zstash,
                  void* workspace, size_t workspace_bytes) {
   if (n < 0 || (n && (!params || !R || !t || !dout)) || !dparams || (t_stride != 0 && t_stride != 1) || t_table < 0 ||
-      (zstash && (precision != SO3X_PREC_BF16 || t_table <= 0)))
+      (zstash && (precision != SO3X_PREC_BF16 || t_table <= 0)) || (n_out != 3 && n_out != 6))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < so3x_mlp_workspace_bytes(n, precision, t_table)) return SO3X_ERR_WORKSPACE;
   if (n == 0) {
-    hipError_t e = hipMemsetAsync(dparams, 0, NPARAMS * sizeof(float), (hipStream_t)s);
+    hipError_t e = hipMemsetAsync(dparams, 0, nparams(n_out) * sizeof(float), (hipStream_t)s);
     return e == hipSuccess ? SO3X_OK : (int)e;
   }
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)s;
   if (precision == SO3X_PREC_F32)
-    return t_table > 0 ? launch_bwd<SO3X_PREC_F32, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws)
-                       : launch_bwd<SO3X_PREC_F32, FULL>(st, params, R, t, t_stride, dout, dparams, n, 0, ws);
-  return t_table > 0 ? launch_bwd<SO3X_PREC_BF16, GATHER>(st, params, R, t, t_stride, dout, dparams, n, t_table, ws, (const char*)zstash)
-                     : launch_bwd<SO3X_PREC_BF16, FULL>(st, params, R, t, t_stride, dout, dparams, n, 0, ws);
+    return t_table > 0 ? launch_bwd<SO3X_PREC_F32, GATHER>(st, params, R, t, t_stride, dout, dparams, n, n_out, t_table, ws)
+                       : launch_bwd<SO3X_PREC_F32, FULL>(st, params, R, t, t_stride, dout, dparams, n, n_out, 0, ws);
+  return t_table > 0 ? launch_bwd<SO3X_PREC_BF16, GATHER>(st, params, R, t, t_stride, dout, dparams, n, n_out, t_table, ws, (const char*)zstash)
+                     : launch_bwd<SO3X_PREC_BF16, FULL>(st, params, R, t, t_stride, dout, dparams, n, n_out, 0, ws);
 }
 
 }  // extern "C"

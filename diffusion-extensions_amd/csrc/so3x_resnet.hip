@@ -1,6 +1,6 @@
 // so3x_resnet.hip -- the wide residual score network of so3_lock_train.py:11-59
 //   RotPredict(d_model = 255): x0 = [R(9), sin(123), cos(123)];  x_{l+1} = x_l + silu(W_l x_l + b_l), l = 0..5
-//   (models.py:28-34 ResLayer);  out = W_out x_6 + b_out (3 values, out_type = "skewvec"),
+//   (models.py:28-34 ResLayer);  out = W_out x_6 + b_out (3 values for out_type = "skewvec", 6 for "rotmat"),
 // on the CDNA4 matrix cores, standalone forward and fused into the chain-resident reverse sampler.
 //
 // Shape of the problem: 392,448 parameters = 768 KiB as bf16 -- five times the LDS -- and 781,830 flop per
@@ -38,6 +38,14 @@ constexpr int NFREQ = 123;         // models.py:18-24 with dim = 246
 constexpr int LAYER_STRIDE = DW * DW + DW;
 constexpr int NPARAMS = NBLK * LAYER_STRIDE + 3 * DW + 3;
 static_assert(NPARAMS == SO3X_RESNET_PARAMS, "param count");
+// The output layer is 3 or 6 rows (n_out, a run-time argument).  Head output o sits in row o (o < 4) or o + 4 of the output
+// tile: rows 0..3, 8, 9 = accumulator registers 0..5 of the LOWER lane half (one lane holds all of a sample's outputs),
+// and K slots 0..5 of that half when dout is the B operand of dX_6 = W_out^T dout.
+constexpr int NOUT_MAX = 6;
+__host__ __device__ constexpr int nparams(int nout) { return NBLK * LAYER_STRIDE + nout * (DW + 1); }
+static_assert(nparams(6) == SO3X_RESNET_PARAMS_ROTMAT, "param count");
+__host__ __device__ constexpr int head_of_row(int row) { return row < 4 ? row : ((row == 8 || row == 9) ? row - 4 : -1); }
+__host__ __device__ constexpr int row_of_head(int o) { return o < 4 ? o : o + 4; }
 constexpr int NCHUNK = NBLK * 8 + 1;  // (layer, output tile) in stream order, then the 3-row output layer
 constexpr int RING = 3;
 constexpr float kFoldS = -1.44269504088896341f;
@@ -60,22 +68,23 @@ __host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 
 
 // ---- prep: weight image --------------------------------------------------------------------
 // value of (chunk, output row o, input feature f): weights, the bias in column 255, zeros in the padding
-__device__ __forceinline__ float wvalue(const float* __restrict__ params, int chunk, int o, int f) {
+__device__ __forceinline__ float wvalue(const float* __restrict__ params, int chunk, int o, int f, int nout) {
   if (chunk < NBLK * 8) {
     const float* W = params + (size_t)(chunk >> 3) * LAYER_STRIDE;
     if (o >= DW) return 0.0f;
     return f < DW ? W[o * DW + f] : W[DW * DW + o];
   }
   const float* W = params + (size_t)NBLK * LAYER_STRIDE;
-  if (o >= 3) return 0.0f;
-  return f < DW ? W[o * DW + f] : W[3 * DW + o];
+  o = o < 32 ? head_of_row(o) : -1;
+  if (o < 0 || o >= nout) return 0.0f;
+  return f < DW ? W[o * DW + f] : W[nout * DW + o];
 }
 
 // one 16-byte piece per thread: bf16 piece = (k-step ks, lane) -> 8 elements, element j of lane half h is
 // feature 16 ks + 8 (j >> 2) + 4 h + (j & 3);  fp32 piece = (group g, lane) -> the lane's values of k-steps
 // 4g .. 4g+3, k-step k of half h is feature 32 (k >> 4) + row(k & 15, h).
 template <int PREC>
-__global__ void __launch_bounds__(256) k_resnet_image(const float* __restrict__ params, void* __restrict__ img) {
+__global__ void __launch_bounds__(256) k_resnet_image(const float* __restrict__ params, void* __restrict__ img, int nout) {
   const int chunk = blockIdx.x;
   constexpr int PIECES = chunk_bytes<PREC>() / 16;
   for (int p = threadIdx.x; p < PIECES; p += blockDim.x) {
@@ -85,13 +94,13 @@ __global__ void __launch_bounds__(256) k_resnet_image(const float* __restrict__ 
       const float sc = chunk < NBLK * 8 ? kFoldS : 1.0f;
       bf16x8 v;
 #pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = (__bf16)(sc * wvalue(params, chunk, o, 16 * q + 8 * (j >> 2) + 4 * h + (j & 3)));
+      for (int j = 0; j < 8; j++) v[j] = (__bf16)(sc * wvalue(params, chunk, o, 16 * q + 8 * (j >> 2) + 4 * h + (j & 3), nout));
       reinterpret_cast<bf16x8*>(img)[(size_t)chunk * PIECES + p] = v;
     } else {
       float4 v;
       float* e = reinterpret_cast<float*>(&v);
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int k = 4 * q + u; e[u] = wvalue(params, chunk, o, 32 * (k >> 4) + row_of(k & 15, h)); }
+      for (int u = 0; u < 4; u++) { const int k = 4 * q + u; e[u] = wvalue(params, chunk, o, 32 * (k >> 4) + row_of(k & 15, h), nout); }
       reinterpret_cast<float4*>(img)[(size_t)chunk * PIECES + p] = v;
     }
   }
@@ -263,7 +272,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 
 template <int PREC, bool STASH = false>
-__device__ __forceinline__ void forward(const char* __restrict__ gimg, char* ring, Stream& st, float (&xf)[128], float (&v)[3],
+__device__ __forceinline__ void forward(const char* __restrict__ gimg, char* ring, Stream& st, float (&xf)[128], float (&v)[NOUT_MAX],
                                         bool again, int wave, int lane, StashPtr sp = StashPtr{nullptr, nullptr, 0}) {
   constexpr int CB = chunk_bytes<PREC>();
   constexpr int NRES = n_resident<PREC, STASH>();
@@ -329,7 +338,8 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
   if (again) issue_chunk<PREC>(gimg, ring, NRES + 1, slot == 0 ? 2 : slot - 1, wave, lane);
   if (late) { residual<PREC>(acc, xf, 7); refresh<PREC>(op, xf); stash_x(op, NBLK); }
   acc = chunk_mfma<PREC>(ring + slot * CB, op, lane);
-  v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2];  // rows 0,1,2 = regs 0,1,2 of the lower half
+#pragma unroll
+  for (int k = 0; k < NOUT_MAX; k++) v[k] = acc[k];  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
   st.slot = slot == 2 ? 0 : slot + 1;
 }
 
@@ -350,7 +360,7 @@ __device__ __forceinline__ void fill_input(float (&xf)[128], const float (&R)[9]
 template <int PREC, bool STASH = false>
 __global__ void __launch_bounds__(64 * n_waves<PREC>(), 1)
 k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int T, const float* __restrict__ R,
-             const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, int64_t n, char* stash_x = nullptr,
+             const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, int64_t n, int nout, char* stash_x = nullptr,
              char* stash_y = nullptr, size_t layer_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int NW = n_waves<PREC>();
@@ -366,13 +376,14 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
     load_rot9(R, idx, Rm);
     int64_t tt = t[idx * t_stride];
     tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-    float xf[128], v[3];
+    float xf[128], v[NOUT_MAX];
     fill_input(xf, Rm, x0tab + tt * 256, h);
     const size_t blk = (size_t)(g * NW + wave) * (PREC == SO3X_PREC_F32 ? 32768 : 16384);  // this wave's 32-sample block within a layer of the stash
     forward<PREC, STASH>(reinterpret_cast<const char*>(gimg), ring, st, xf, v, g + gridDim.x < ngroups, wave, lane,
                          StashPtr{stash_x + blk, stash_y + blk, layer_stride});
     if (out && live && h == 0) {
-      out[idx * 3] = v[0]; out[idx * 3 + 1] = v[1]; out[idx * 3 + 2] = v[2];
+      out[idx * nout] = v[0]; out[idx * nout + 1] = v[1]; out[idx * nout + 2] = v[2];
+      if (nout == 6) { out[idx * 6 + 3] = v[3]; out[idx * 6 + 4] = v[4]; out[idx * 6 + 5] = v[5]; }
     }
   }
 }
@@ -404,7 +415,7 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
       if (s > 0) rmat_from_quat(q, Rm);
-      float xf[128], vo[3], v[3];
+      float xf[128], vo[NOUT_MAX], v[3];
       fill_input(xf, Rm, x0tab + (size_t)t * 256, h);
       forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, vo, !(last_group && s == n_steps - 1), wave, lane);
 #pragma unroll
@@ -427,8 +438,9 @@ constexpr int NTILE_T = NBLK * 8;  // transposed-weight tiles, stream order: lay
 // transposed image: tile (layer l, input-row tile ti): A[m][k] = W_l[o(k)][32 ti + m], k in the operand order of the packed
 // dZ registers (the same permutation as the forward image); true (unscaled) weights; the constant-one row gets no gradient.
 // Tiles NTILE_T .. NTILE_T + 7 (one k-step each, at 16-KiB pitch like the rest): the output layer transposed,
-// A[m][k] = W_out[k][32 ti + m] for k < 3 -- dX_6 = W_out^T dout as eight MFMAs instead of 384 loads and FMAs per lane.
-__global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict__ params, void* __restrict__ img) {
+// A[m][k] = W_out[k][32 ti + m] for k < n_out (K slot k of the lower half = head output k) -- dX_6 = W_out^T dout as eight
+// MFMAs instead of 384 loads and FMAs per lane.
+__global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict__ params, void* __restrict__ img, int nout) {
   const int tile = blockIdx.x, ti = tile & 7;
   if (tile >= NTILE_T) {
     const float* Wo = params + (size_t)NBLK * LAYER_STRIDE;
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict_
       const int lane = threadIdx.x, m = lane & 31, h = lane >> 5, i = 32 * ti + m;
       bf16x8 v;
 #pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = (__bf16)((h == 0 && j < 3 && i < DW) ? Wo[j * DW + i] : 0.0f);
+      for (int j = 0; j < 8; j++) v[j] = (__bf16)((h == 0 && j < nout && i < DW) ? Wo[j * DW + i] : 0.0f);
       reinterpret_cast<bf16x8*>(img)[(size_t)tile * 1024 + lane] = v;
     }
     return;
@@ -468,7 +480,7 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(f
 //   dZ_l = dX_{l+1} * silu'(Z_l)  (stored for k_resnet_dw),  dX_l = dX_{l+1} + W_l^T dZ_l  (MFMA, C = the dX tile itself).
 // The transposed weight tiles stream through the same 3-slot LDS ring as the forward's.
 __global__ void __launch_bounds__(512, 1)
-k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n) {
+k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n, int nout) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int PREC = SO3X_PREC_BF16, CB = chunk_bytes<PREC>();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
@@ -482,22 +494,23 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
     const bool live = idx < n;
     const size_t blk = (size_t)(g * 8 + wave) * 16384;
     const bool again_group = g + gridDim.x < ngroups;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    if (live) { d0 = dout[idx * 3]; d1 = dout[idx * 3 + 1]; d2 = dout[idx * 3 + 2]; }
+    float dd[NOUT_MAX] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < NOUT_MAX; k++) dd[k] = k < nout ? dout[idx * nout + k] : 0.0f;
+    }
+    const uint32_t dpk[3] = {h ? 0u : pack2(dd[0], dd[1]), h ? 0u : pack2(dd[2], dd[3]), h ? 0u : pack2(dd[4], dd[5])};
     f32x16 dx[8];
-    {  // dX_6 = W_out^T dout on the matrix cores: K slots 0..2 of one k-step carry dout (lower lane half), A from the image tail
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      const bf16x2 p01 = {(__bf16)d0, (__bf16)d1}, p2 = {(__bf16)d2, (__bf16)0.0f};
-      const u32x4 bq = {h ? 0u : __builtin_bit_cast(uint32_t, p01), h ? 0u : __builtin_bit_cast(uint32_t, p2), 0u, 0u};
+    {  // dX_6 = W_out^T dout on the matrix cores: K slots 0..5 of one k-step carry dout (lower lane half), A from the image tail
+      const u32x4 bq = {dpk[0], dpk[1], dpk[2], 0u};
       const bf16x8 bop = __builtin_bit_cast(bf16x8, bq);
       const bf16x8* Ah = reinterpret_cast<const bf16x8*>(gimg + (size_t)NTILE_T * 16384);
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ti = 0; ti < 8; ti++) dx[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[(size_t)ti * 1024 + lane], bop, zero, 0, 0, 0);
     }
-    {  // dZ of the output layer = dout in rows 0..2 of tile 0 (rows 0..3 live in regs 0..3 of the lower half)
-      uint32_t p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (h == 0) { p8[0] = pack2(d0, d1); p8[1] = pack2(d2, 0.f); }
+    {  // dZ of the output layer = dout in tile rows 0..3, 8, 9 (regs 0..5 of the lower half)
+      uint32_t p8[8] = {dpk[0], dpk[1], dpk[2], 0, 0, 0, 0, 0};
       stash_tile(stash_dz + NBLK * layer_stride + blk, 0, lane, p8);
     }
 #pragma unroll 1
@@ -595,7 +608,7 @@ __global__ void __launch_bounds__(256) k_resnet_image_t_f32(const float* __restr
 
 __global__ void __launch_bounds__(256, 1)
 k_resnet_bwd_f32(const void* __restrict__ gimg_t, const float* __restrict__ params, const float* __restrict__ dout,
-                 const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n) {
+                 const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n, int nout) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int PREC = SO3X_PREC_F32, CB = chunk_bytes<PREC>();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
@@ -610,8 +623,11 @@ k_resnet_bwd_f32(const void* __restrict__ gimg_t, const float* __restrict__ para
     const bool live = idx < n;
     const size_t blk = (size_t)(g * 4 + wave) * 32768;
     const bool again_group = g + gridDim.x < ngroups;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    if (live) { d0 = dout[idx * 3]; d1 = dout[idx * 3 + 1]; d2 = dout[idx * 3 + 2]; }
+    float dd[NOUT_MAX] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < NOUT_MAX; k++) dd[k] = k < nout ? dout[idx * nout + k] : 0.0f;
+    }
     f32x16 dx[8];
     const float* Wo = Wout;
     asm volatile("" : "+s"(Wo));
@@ -623,12 +639,20 @@ k_resnet_bwd_f32(const void* __restrict__ gimg_t, const float* __restrict__ para
       for (int r = 0; r < 4; r++) {
         const int f = f0 + r;
         const float w0 = f < DW ? Wo[f] : 0.f, w1 = f < DW ? Wo[DW + f] : 0.f, w2 = f < DW ? Wo[2 * DW + f] : 0.f;
-        dx[tq >> 2][4 * (tq & 3) + r] = w0 * d0 + w1 * d1 + w2 * d2;
+        float a = w0 * dd[0] + w1 * dd[1] + w2 * dd[2];
+        if (nout == 6) {
+          const float w3 = f < DW ? Wo[3 * DW + f] : 0.f, w4 = f < DW ? Wo[4 * DW + f] : 0.f, w5 = f < DW ? Wo[5 * DW + f] : 0.f;
+          a += w3 * dd[3] + w4 * dd[4] + w5 * dd[5];
+        }
+        dx[tq >> 2][4 * (tq & 3) + r] = a;
       }
     }
     {
       float z16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (h == 0) { z16[0] = d0; z16[1] = d1; z16[2] = d2; }
+      if (h == 0) {
+#pragma unroll
+        for (int k = 0; k < NOUT_MAX; k++) z16[k] = dd[k];  // tile rows 0..3, 8, 9
+      }
       stash_tile_f32(stash_dz + NBLK * layer_stride + blk, 0, lane, z16);
     }
 #pragma unroll 1
@@ -758,7 +782,7 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
   };
   for (int u = 0; u < 3; u++)
     if (b0 + u < b1) issue(b0 + u, u);
-  const bool head = l == NBLK;  // output layer: only rows 0..2 (tile-row 0) carry a gradient
+  const bool head = l == NBLK;  // output layer: only tile-row 0 carries a gradient
   int slot = 0;
   for (int64_t blk = b0; blk < b1; blk++) {
     // blocks younger than `blk` already requested: min(2, b1 - 1 - blk) -> that many x 4 DMAs may stay in flight
@@ -786,11 +810,12 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
 }
 
 // fixed-order sum of the split partials into the flat gradient (state_dict order); column 255 = the bias
-__global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restrict__ partial, float* __restrict__ dparams) {
+__global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restrict__ partial, float* __restrict__ dparams, int nout) {
   const int l = blockIdx.y, o = blockIdx.x, f = threadIdx.x;
-  const int rows = l < NBLK ? DW : 3;
+  const int rows = l < NBLK ? DW : nout;
   if (o >= rows || f >= 256) return;
-  const float* P = partial + (size_t)l * DW_SPLITS * 65536 + o * 256 + f;
+  const int prow = l < NBLK ? o : row_of_head(o);  // the head's outputs sit in tile rows 0..3, 8, 9
+  const float* P = partial + (size_t)l * DW_SPLITS * 65536 + prow * 256 + f;
   float s = 0.0f;
   for (int k = 0; k < DW_SPLITS; k++) s += P[(size_t)k * 65536];
   float* base = dparams + (size_t)l * LAYER_STRIDE;
@@ -810,8 +835,8 @@ size_t x0tab_offset(int precision) {
 }
 size_t ws_bytes(int precision, int T) { return x0tab_offset(precision) + (size_t)(T > 0 ? T : 0) * 256 * sizeof(float); }
 
-template <int PREC> int prep(hipStream_t s, const float* params, int T, void* ws) {
-  hipLaunchKernelGGL((k_resnet_image<PREC>), dim3(NCHUNK), dim3(256), 0, s, params, ws);
+template <int PREC> int prep(hipStream_t s, const float* params, int T, void* ws, int nout = 3) {
+  hipLaunchKernelGGL((k_resnet_image<PREC>), dim3(NCHUNK), dim3(256), 0, s, params, ws, nout);
   float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + image_bytes<PREC>());
   hipLaunchKernelGGL(k_resnet_x0tab, dim3(T), dim3(256), 0, s, host_freqs(), T, tab);
   return check_launch();
@@ -829,14 +854,14 @@ template <typename K> int grid_cap(K kernel, int threads, int lds, int* cap) {
 }
 
 template <int PREC>
-int launch_fwd(hipStream_t s, const void* ws, int T, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n) {
+int launch_fwd(hipStream_t s, const void* ws, int T, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n, int nout) {
   constexpr int LDS = lds_bytes<PREC, false>(), THREADS = 64 * n_waves<PREC>();
   static int cap = 0;  // resident workgroups on this device, queried once (idempotent)
   if (!cap) { int rc = grid_cap(&k_resnet_fwd<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_fwd<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, T, R, t,
-                     t_stride, out, n);
+                     t_stride, out, n, nout);
   return check_launch();
 }
 
@@ -874,16 +899,16 @@ TrainLayout train_layout(int64_t n, int T, int precision) {
 // the forward-with-dumps launch shared by so3x_resnet_fwd_stash and (when the caller brings no stash) so3x_resnet_bwd
 template <int PREC>
 int launch_fwd_stash(hipStream_t s, char* ws, int T, const float* params, const float* R, const int64_t* t, int64_t t_stride,
-                     float* out, int64_t n, char* x_dump, char* y_dump, size_t layer_stride) {
+                     float* out, int64_t n, int nout, char* x_dump, char* y_dump, size_t layer_stride) {
   constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
-  int rc = prep<PREC>(s, params, T, ws);
+  int rc = prep<PREC>(s, params, T, ws, nout);
   if (rc) return rc;
   static int cap = 0;
   if (!cap) { rc = grid_cap(&k_resnet_fwd<PREC, true>, THREADS, LDS, &cap); if (rc) return rc; }
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, (const void*)ws, tab,
-                     T, R, t, t_stride, out, n, x_dump, y_dump, layer_stride);
+                     T, R, t, t_stride, out, n, nout, x_dump, y_dump, layer_stride);
   return check_launch();
 }
 
@@ -900,8 +925,9 @@ size_t so3x_resnet_stash_bytes(int64_t n, int precision) {
 }
 
 int so3x_resnet_fwd_stash(so3x_stream_t s_, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
-                          void* stash, int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
-  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!params || !R || !t || !out || !stash)))
+                          void* stash, int64_t n, int n_out, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!params || !R || !t || !out || !stash)) ||
+      (n_out != 3 && n_out != 6))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < ws_bytes(precision, t_table)) return SO3X_ERR_WORKSPACE;
@@ -910,20 +936,21 @@ int so3x_resnet_fwd_stash(so3x_stream_t s_, const float* params, const float* R,
   char* st = reinterpret_cast<char*>(stash);
   char* ws = reinterpret_cast<char*>(workspace);
   return precision == SO3X_PREC_BF16
-             ? launch_fwd_stash<SO3X_PREC_BF16>((hipStream_t)s_, ws, t_table, params, R, t, t_stride, out, n, st, st + 7 * L.layer_stride, L.layer_stride)
-             : launch_fwd_stash<SO3X_PREC_F32>((hipStream_t)s_, ws, t_table, params, R, t, t_stride, out, n, st, st + 7 * L.layer_stride, L.layer_stride);
+             ? launch_fwd_stash<SO3X_PREC_BF16>((hipStream_t)s_, ws, t_table, params, R, t, t_stride, out, n, n_out, st, st + 7 * L.layer_stride, L.layer_stride)
+             : launch_fwd_stash<SO3X_PREC_F32>((hipStream_t)s_, ws, t_table, params, R, t, t_stride, out, n, n_out, st, st + 7 * L.layer_stride, L.layer_stride);
 }
 
 int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const int64_t* t, int64_t t_stride, const float* dout,
-                    float* dparams, int64_t n, int precision, int t_table, const void* stash, void* workspace,
+                    float* dparams, int64_t n, int n_out, int precision, int t_table, const void* stash, void* workspace,
                     size_t workspace_bytes) {
-  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || !params || !dparams || (n && (!R || !t || !dout)))
+  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || !params || !dparams || (n && (!R || !t || !dout)) ||
+      (n_out != 3 && n_out != 6))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   const TrainLayout L = train_layout(n, t_table, precision);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)s_;
-  if (n == 0) return (int)hipMemsetAsync(dparams, 0, sizeof(float) * NPARAMS, s);
+  if (n == 0) return (int)hipMemsetAsync(dparams, 0, sizeof(float) * nparams(n_out), s);
   char* ws = reinterpret_cast<char*>(workspace);
   float* partial = reinterpret_cast<float*>(ws + L.partial);
   // layer inputs / pre-activations: the caller's stash (so3x_resnet_fwd_stash) or a forward run here into the workspace
@@ -932,13 +959,13 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
   int rc;
   if (precision == SO3X_PREC_BF16) {
     constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
-    if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, ws + L.x, ws + L.y, L.layer_stride))) return rc;
-    hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T + 8), dim3(256), 0, s, params, (void*)(ws + L.img_t));
+    if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, n_out, ws + L.x, ws + L.y, L.layer_stride))) return rc;
+    hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T + 8), dim3(256), 0, s, params, (void*)(ws + L.img_t), n_out);
     static int cap_b = 0;
     if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
     const int64_t ngroups = (n + 255) / 256;
     hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
-                       dout, yd, ws + L.dz, L.layer_stride, n);
+                       dout, yd, ws + L.dz, L.layer_stride, n, n_out);
     static int dwb_attr = 0;
     if (!dwb_attr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resnet_dw), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -949,7 +976,7 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
                        partial);
   } else {
     constexpr int PREC = SO3X_PREC_F32, LDS = RING * chunk_bytes<PREC>();
-    if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, ws + L.x, ws + L.y, L.layer_stride))) return rc;
+    if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, n_out, ws + L.x, ws + L.y, L.layer_stride))) return rc;
     hipLaunchKernelGGL(k_resnet_image_t_f32, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
     static int cap_b = 0, dw_attr = 0;
     if (!cap_b) { rc = grid_cap(&k_resnet_bwd_f32, 256, LDS, &cap_b); if (rc) return rc; }
@@ -960,11 +987,11 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
     }
     const int64_t ngroups = (n + 127) / 128;
     hipLaunchKernelGGL(k_resnet_bwd_f32, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(256), LDS, s, (const void*)(ws + L.img_t),
-                       params, dout, yd, ws + L.dz, L.layer_stride, n);
+                       params, dout, yd, ws + L.dz, L.layer_stride, n, n_out);
     hipLaunchKernelGGL(k_resnet_dw_f32, dim3(7 * DW_SPLITS), dim3(512), 65536, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
                        partial, DW_SPLITS);
   }
-  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, (const float*)partial, dparams);
+  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, (const float*)partial, dparams, n_out);
   return check_launch();
 }
 
@@ -973,17 +1000,18 @@ size_t so3x_resnet_workspace_bytes(int precision, int t_table) {
 }
 
 int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t, int64_t t_stride, float* out,
-                    int64_t n, int precision, int t_table, void* workspace, size_t workspace_bytes) {
-  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!params || !R || !t || !out)))
+                    int64_t n, int n_out, int precision, int t_table, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || t_table <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!params || !R || !t || !out)) ||
+      (n_out != 3 && n_out != 6))
     return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < ws_bytes(precision, t_table)) return SO3X_ERR_WORKSPACE;
   if (n == 0) return SO3X_OK;
-  int rc = precision == SO3X_PREC_F32 ? prep<SO3X_PREC_F32>((hipStream_t)s, params, t_table, workspace)
-                                      : prep<SO3X_PREC_BF16>((hipStream_t)s, params, t_table, workspace);
+  int rc = precision == SO3X_PREC_F32 ? prep<SO3X_PREC_F32>((hipStream_t)s, params, t_table, workspace, n_out)
+                                      : prep<SO3X_PREC_BF16>((hipStream_t)s, params, t_table, workspace, n_out);
   if (rc) return rc;
-  return precision == SO3X_PREC_F32 ? launch_fwd<SO3X_PREC_F32>((hipStream_t)s, workspace, t_table, R, t, t_stride, out, n)
-                                    : launch_fwd<SO3X_PREC_BF16>((hipStream_t)s, workspace, t_table, R, t, t_stride, out, n);
+  return precision == SO3X_PREC_F32 ? launch_fwd<SO3X_PREC_F32>((hipStream_t)s, workspace, t_table, R, t, t_stride, out, n, n_out)
+                                    : launch_fwd<SO3X_PREC_BF16>((hipStream_t)s, workspace, t_table, R, t, t_stride, out, n, n_out);
 }
 
 int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,

@@ -18,6 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "so3x.h")
 PREC_F32 = 0
 PREC_BF16 = 1
 N_PARAMS = 17358
+N_PARAMS_ROTMAT = 17556  # out_type="rotmat": Linear(65, 6) head (reference so3_train.py:21-22)
 SCHED_ROWS = 13
 TRAP = 999
 
@@ -34,6 +35,8 @@ SYMBOLS = (
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
     "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd", "so3x_resnet_stash_bytes", "so3x_resnet_fwd_stash",
+    "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
+    "so3x_prevstep_loss",
 )
 
 
@@ -68,7 +71,8 @@ def lib():
                 l.so3x_resnet_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_train_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_stash_bytes.restype = C.c_size_t
-                if l.so3x_abi_version() != 2:
+                l.so3x_prevstep_workspace_bytes.restype = C.c_size_t
+                if l.so3x_abi_version() != 3:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -373,18 +377,26 @@ def _t_arg(t, n):
     raise ValueError(f"so3x: t must have 1 or {n} elements, got {t.numel()}")
 
 
+def _head_width(numel, trunk, d, what):
+    """3 (out_type "skewvec") or 6 ("rotmat") network outputs, read off the flat parameter count"""
+    for k in (3, 6):
+        if numel == trunk + k * (d + 1):
+            return k
+    raise ValueError(f"so3x: {what} params must hold {trunk + 3 * (d + 1)} (skewvec) or {trunk + 6 * (d + 1)} (rotmat) values")
+
+
 def mlp_fwd(params, R, t, precision=PREC_F32, t_table=0):
+    """RotPredict forward; returns the RAW network outputs [.., 3] or [.., 6] (six2rmat is a separate op)"""
     params = _dev(params, "params").reshape(-1)
-    if params.numel() != N_PARAMS:
-        raise ValueError(f"so3x: params must hold {N_PARAMS} values")
+    n_out = _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
     nb = lib().so3x_mlp_workspace_bytes(_i64(0), C.c_int(precision), C.c_int(int(t_table)))  # forward: image + tables only
     ws = _workspace(R.device, nb)
     with _Guard(R):
-        _check(lib().so3x_mlp_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n),
+        _check(lib().so3x_mlp_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n), C.c_int(n_out),
                                   C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "mlp_fwd")
     return out
 
@@ -392,16 +404,18 @@ def mlp_fwd(params, R, t, precision=PREC_F32, t_table=0):
 def mlp_fwd_stash(params, R, t, t_table):
     """training forward (bf16 operands, bounded timesteps): (out, zstash) -- zstash goes to mlp_bwd(..., zstash=)"""
     params = _dev(params, "params").reshape(-1)
+    n_out = _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
     zstash = torch.empty(lib().so3x_mlp_stash_bytes(_i64(n)), dtype=torch.uint8, device=R.device)
     nb = lib().so3x_mlp_workspace_bytes(_i64(0), C.c_int(PREC_BF16), C.c_int(int(t_table)))
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_mlp_fwd_stash(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _ptr(zstash),
-                                        _i64(n), C.c_int(PREC_BF16), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+                                        _i64(n), C.c_int(n_out), C.c_int(PREC_BF16), C.c_int(int(t_table)), _ptr(ws),
+                                        C.c_size_t(ws.numel())),
                "mlp_fwd_stash")
     return out, zstash
 
@@ -411,13 +425,14 @@ def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0, zstash=None):
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
-    dout = _dev(dout, "dout").reshape(-1, 3)
-    dparams = torch.empty(N_PARAMS, dtype=torch.float32, device=R.device)
+    n_out = _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
+    dout = _dev(dout, "dout").reshape(-1, n_out)
+    dparams = torch.empty(params.numel(), dtype=torch.float32, device=R.device)
     nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision), C.c_int(int(t_table)))
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_mlp_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                  _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(zstash), _ptr(ws),
+                                  _i64(n), C.c_int(n_out), C.c_int(precision), C.c_int(int(t_table)), _ptr(zstash), _ptr(ws),
                                   C.c_size_t(ws.numel())),
                "mlp_bwd")
     return dparams
@@ -499,20 +514,21 @@ def rotate_cloud(rot, cloud):
 
 # ------------------------------------------------- wide residual score network (so3_lock_train.py:11-59)
 N_PARAMS_RESNET = 6 * (255 * 255 + 255) + 3 * 255 + 3
+N_PARAMS_RESNET_ROTMAT = 6 * (255 * 255 + 255) + 6 * 255 + 6
+_RESNET_TRUNK = 6 * (255 * 255 + 255)
 
 
 def resnet_fwd(params, R, t, t_table, precision=PREC_F32):
     params = _dev(params, "params").reshape(-1)
-    if params.numel() != N_PARAMS_RESNET:
-        raise ValueError(f"so3x: params must hold {N_PARAMS_RESNET} values")
+    n_out = _head_width(params.numel(), _RESNET_TRUNK, 255, "wide-net")
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
     nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(int(t_table)))
     ws = _workspace(R.device, nb)
     with _Guard(R):
-        _check(lib().so3x_resnet_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n),
+        _check(lib().so3x_resnet_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n), C.c_int(n_out),
                                      C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "resnet_fwd")
     return out
 
@@ -520,33 +536,36 @@ def resnet_fwd(params, R, t, t_table, precision=PREC_F32):
 def resnet_fwd_stash(params, R, t, t_table, precision=PREC_BF16):
     """training forward: (out, stash) -- stash goes to resnet_bwd(..., stash=) instead of a second forward there"""
     params = _dev(params, "params").reshape(-1)
+    n_out = _head_width(params.numel(), _RESNET_TRUNK, 255, "wide-net")
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
+    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
     stash = torch.empty(lib().so3x_resnet_stash_bytes(_i64(n), C.c_int(precision)), dtype=torch.uint8, device=R.device)
     nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(int(t_table)))
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_resnet_fwd_stash(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _ptr(stash),
-                                           _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())),
+                                           _i64(n), C.c_int(n_out), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws),
+                                           C.c_size_t(ws.numel())),
                "resnet_fwd_stash")
     return out, stash
 
 
 def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16, stash=None):
-    """dL/dparams [392448] for dL/dout [n, 3]; stash = what resnet_fwd_stash returned for the same inputs, or None."""
+    """dL/dparams for dL/dout [n, 3 | 6]; stash = what resnet_fwd_stash returned for the same inputs, or None."""
     params = _dev(params, "params").reshape(-1)
+    n_out = _head_width(params.numel(), _RESNET_TRUNK, 255, "wide-net")
     R = _rot_in(R, "x")
     n = R.numel() // 9
     tt, stride = _t_arg(t, n)
-    dout = _dev(dout, "dout").reshape(-1, 3)
-    dparams = torch.empty(N_PARAMS_RESNET, dtype=torch.float32, device=R.device)
+    dout = _dev(dout, "dout").reshape(-1, n_out)
+    dparams = torch.empty(params.numel(), dtype=torch.float32, device=R.device)
     nb = lib().so3x_resnet_train_workspace_bytes(_i64(n), C.c_int(precision), C.c_int(int(t_table)))
     ws = _workspace(R.device, nb)
     with _Guard(R):
         _check(lib().so3x_resnet_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                     _i64(n), C.c_int(precision), C.c_int(int(t_table)), _ptr(stash), _ptr(ws),
+                                     _i64(n), C.c_int(n_out), C.c_int(precision), C.c_int(int(t_table)), _ptr(stash), _ptr(ws),
                                      C.c_size_t(ws.numel())),
                "resnet_bwd")
     return dparams
@@ -669,6 +688,143 @@ def kernel_sum(X, Y, kind=KERNEL_GAUSSIAN, scale=1.0):
         _check(lib().so3x_kernel_sum(_stream(X), _ptr(X), _i64(nx), _ptr(Y), _i64(ny), C.c_int(int(kind)),
                                      C.c_float(float(scale)), _ptr(out), _ptr(ws), C.c_size_t(ws.numel())), "kernel_sum")
     return out[0]
+
+
+# ------------------------------------------ rotation-matrix head + "prevstep" objective (8f row 3)
+class _Six2Rmat(torch.autograd.Function):
+    """six2rmat (reference util.py:67-76) with its closed-form backward"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, "x")
+        if x.shape[-1] != 6:
+            raise ValueError("so3x: six2rmat needs [..., 6]")
+        ctx.save_for_backward(x)
+        out = torch.empty(x.shape[:-1] + (3, 3), dtype=torch.float32, device=x.device)
+        with _Guard(x):
+            _check(lib().so3x_six2rmat(_stream(x), _ptr(x), _ptr(out), _i64(x.numel() // 6)), "six2rmat")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _dev(g, "grad")
+        dx = torch.empty_like(x)
+        with _Guard(x):
+            _check(lib().so3x_six2rmat_bwd(_stream(x), _ptr(x), _ptr(g), _ptr(dx), _i64(x.numel() // 6)), "six2rmat_bwd")
+        return dx
+
+
+def six2rmat(x):
+    return _Six2Rmat.apply(x)
+
+
+def log_rmat_bwd(R, dlog):
+    """autograd of log_rmat: dL/dlog [.., 3, 3] -> dL/dR"""
+    R = _rot_in(R, "r_mat")
+    dlog = _rot_in(dlog, "grad")
+    dR = torch.empty_like(R)
+    with _Guard(R):
+        _check(lib().so3x_log_rmat_bwd(_stream(R), _ptr(R), _ptr(dlog), _ptr(dR), _i64(R.numel() // 9)), "log_rmat_bwd")
+    return dR
+
+
+def rmat_dist_bwd(a, b, ddist):
+    """autograd of rmat_dist: dL/ddist [..] -> (dL/da, dL/db)"""
+    a = _rot_in(a, "input")
+    b = _rot_in(b, "target")
+    g = _dev(ddist, "grad").reshape(-1)
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    with _Guard(a):
+        _check(lib().so3x_rmat_dist_bwd(_stream(a), _ptr(a), _ptr(b), _ptr(g), _ptr(da), _ptr(db), _i64(a.numel() // 9)),
+               "rmat_dist_bwd")
+    return da, db
+
+
+class _LogRmat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R):
+        ctx.save_for_backward(R)
+        return log_rmat(R)
+
+    @staticmethod
+    def backward(ctx, g):
+        return log_rmat_bwd(ctx.saved_tensors[0], g)
+
+
+class _RmatDist(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _rot_in(a, "input")
+        b = _rot_in(b, "target")
+        if a.shape != b.shape:
+            raise ValueError("so3x: differentiable rmat_dist needs equal shapes")
+        ctx.save_for_backward(a, b)
+        return rmat_dist(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da, db = rmat_dist_bwd(a, b, g.contiguous())
+        return da, db
+
+
+def log_rmat_ad(R):
+    """log_rmat that autograd can differentiate (reference util.py:164-192 under torch autograd)"""
+    return _LogRmat.apply(R)
+
+
+def rmat_dist_ad(a, b):
+    """rmat_dist that autograd can differentiate (reference util.py:315-322 under torch autograd)"""
+    return _RmatDist.apply(a, b)
+
+
+class _PrevstepLoss(torch.autograd.Function):
+    """mean_i rmat_dist(x_recon_i, x_noisy_i^T q_posterior_mean_i)^2 (reference diffusion.py:358-365), one fused kernel
+    that also leaves d loss / d x_recon for the backward; x_start, x_noisy, t carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, sched, x_recon, x_start, x_noisy, t):
+        x_recon = _rot_in(x_recon, "x_recon")
+        x_start = _rot_in(x_start, "x_start")
+        x_noisy = _rot_in(x_noisy, "x_noisy")
+        n = x_recon.numel() // 9
+        tt, stride = _t_arg(t, n)
+        T = sched.shape[1]
+        loss = torch.empty(1, dtype=torch.float32, device=x_recon.device)
+        dx = torch.empty_like(x_recon)
+        ws = _workspace_small(x_recon.device, lib().so3x_prevstep_workspace_bytes(_i64(n)))
+        with _Guard(x_recon):
+            _check(lib().so3x_prevstep_loss(_stream(x_recon), _ptr(sched), C.c_int(T), _ptr(x_recon), _ptr(x_start), _ptr(x_noisy),
+                                            _ptr(tt), _i64(stride), _i64(n), _ptr(loss), _ptr(dx), None, _ptr(ws),
+                                            C.c_size_t(ws.numel())), "prevstep_loss")
+        ctx.save_for_backward(dx)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return None, dx * g, None, None, None
+
+
+def prevstep_loss(sched, x_recon, x_start, x_noisy, t):
+    return _PrevstepLoss.apply(sched, x_recon, x_start, x_noisy, t)
+
+
+def prevstep_step(sched, x_start, x_noisy, t):
+    """the rotation from x_noisy to the posterior mean of the previous step (reference diffusion.py:360-364)"""
+    x_start = _rot_in(x_start, "x_start")
+    x_noisy = _rot_in(x_noisy, "x_noisy")
+    n = x_start.numel() // 9
+    tt, stride = _t_arg(t, n)
+    loss = torch.empty(1, dtype=torch.float32, device=x_start.device)
+    step = torch.empty_like(x_start)
+    ws = _workspace_small(x_start.device, lib().so3x_prevstep_workspace_bytes(_i64(n)))
+    with _Guard(x_start):
+        _check(lib().so3x_prevstep_loss(_stream(x_start), _ptr(sched), C.c_int(sched.shape[1]), _ptr(x_noisy), _ptr(x_start),
+                                        _ptr(x_noisy), _ptr(tt), _i64(stride), _i64(n), _ptr(loss), None, _ptr(step), _ptr(ws),
+                                        C.c_size_t(ws.numel())), "prevstep_step")
+    return step
 
 
 class _MSELoss(torch.autograd.Function):

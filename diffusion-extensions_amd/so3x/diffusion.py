@@ -54,8 +54,9 @@ class SO3Diffusion(nn.Module):
         (timesteps,) = betas.shape
         self.num_timesteps = int(timesteps)
         self.loss_type = loss_type
-        if loss_type != "skewvec":
-            raise NotImplementedError("so3x: only loss_type='skewvec' (reference so3_train.py:63) is implemented")
+        if loss_type not in ("skewvec", "prevstep"):
+            # the reference builds this error without raising it (diffusion.py:367) and then fails on an unbound `loss`
+            raise ValueError(f"Unexpected loss_type: {loss_type}")
         self.quirk_col0 = quirk_col0
         self.index_base = 0  # global index of this process's first sample (data-parallel shards)
         # None: the Philox offset of each p_losses call is a host counter (so3x.rng).  A device int64 tensor (see
@@ -84,10 +85,15 @@ class SO3Diffusion(nn.Module):
             self._guide_p = _b.igso3_build_guide(self._trap_p)
         return self._trap_q, self._trap_p
 
-    def _fused_net(self):
+    def _fused_net(self, sampling=False):
         """the denoiser when it is one of the two score networks with fused kernels (so3_train / so3_lock_train RotPredict)"""
         from .so3_lock_train import RotPredict as WideRotPredict
-        return self.denoise_fn if isinstance(self.denoise_fn, (RotPredict, WideRotPredict)) else None
+        net = self.denoise_fn if isinstance(self.denoise_fn, (RotPredict, WideRotPredict)) else None
+        if sampling and net is not None and net.out_type != "skewvec":
+            # predict_start_from_noise scales the network output as a [B, 3] skew vector (reference diffusion.py:293-294);
+            # with a rotation-matrix head the reference fails there on a shape mismatch
+            raise ValueError("so3x: reverse sampling needs a denoiser with out_type='skewvec'")
+        return net
 
     @staticmethod
     def _chain_fn(net):
@@ -131,7 +137,7 @@ class SO3Diffusion(nn.Module):
         """One reverse step (reference diffusion.py:315-326).  t: int64 tensor [B] or [1] (all equal) or int."""
         t0 = self._shared_t(t)
         _, trap_p = self._tables()
-        net = self._fused_net()
+        net = self._fused_net(sampling=True)
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
         if net is not None:
             return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
@@ -158,7 +164,7 @@ class SO3Diffusion(nn.Module):
         else:
             x = x_init
         T = self.num_timesteps
-        net = self._fused_net()
+        net = self._fused_net(sampling=True)
         if net is not None:
             _, trap_p = self._tables()
             off = _rng.next_offset(T)
@@ -179,19 +185,26 @@ class SO3Diffusion(nn.Module):
         return x_t
 
     def p_losses(self, x_start, t, noise=None, axes=None, unif=None):
-        """MSE between the network output and vee(log noise)/eps_t (reference diffusion.py:348-369)."""
+        """loss_type "skewvec": MSE between the network output and vee(log noise)/eps_t; "prevstep": squared geodesic
+        distance between the network's rotation and the step from x_noisy to the posterior mean of the previous timestep
+        (reference diffusion.py:348-369)."""
         trap_q, _ = self._tables()
         dev_rng = self.rng_counter is not None and noise is None and axes is None
+        prevstep = self.loss_type == "prevstep"
         x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
                                                 axes=axes, unif=unif, seed=_rng.seed(),
                                                 rng_offset=0 if (dev_rng or noise is not None or axes is not None) else _rng.next_offset(),
                                                 index_base=self.index_base, guide_q=self._guide_q,
-                                                rng_offset_dev=self.rng_counter if dev_rng else None)
+                                                rng_offset_dev=self.rng_counter if dev_rng else None,
+                                                want_target=not prevstep)
         if dev_rng:
             self.rng_counter += 1
         net = self._fused_net()
         # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
         x_recon = net(x_noisy, t, t_table=self.num_timesteps) if net is not None else self.denoise_fn(x_noisy, t)
+        if prevstep:
+            # posterior mean (q_posterior), step = x_noisy^T @ mean, rmat_dist(x_recon, step)^2 and its gradient: one kernel
+            return _b.prevstep_loss(self._sched, x_recon, x_start, x_noisy, t)
         return _b.mse_loss(x_recon, target)
 
     def forward(self, x, *args, **kwargs):

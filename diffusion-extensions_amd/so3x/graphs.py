@@ -16,6 +16,9 @@ class TrainStepGraph:
 
         g = TrainStepGraph(process, optim, x.shape)
         for x in data: loss = g.step(x)          # loss: 0-d device tensor, overwritten by the next replay
+
+    If eager training steps ran before, drop every reference to their losses first (`del loss`): a live loss keeps the
+    parameters' AccumulateGrad nodes bound to the stream of that earlier backward, and torch cannot capture across it.
     """
 
     def __init__(self, process, optimizer, batch_shape, warmup=3):

@@ -48,13 +48,12 @@ class RotPredict(nn.Module):
         self.out_type = out_type
         if in_type != "rotmat" or d_model != 255:
             raise NotImplementedError("so3x: the wide score network is built for in_type='rotmat', d_model=255")
-        if out_type != "skewvec":
-            # the six2rmat head (so3_lock_train.py:57-58) is unused by every script of the reference (all pass "skewvec")
-            raise NotImplementedError("so3x: only out_type='skewvec' is implemented")
+        if out_type not in ("skewvec", "rotmat"):
+            raise ValueError(f"Unexpected out_type: {out_type}")  # the reference builds this error without raising it (so3_lock_train.py:24)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {list(_PRECISIONS)}")
         self.precision = precision
-        self.d_out = 3
+        self.d_out = 3 if out_type == "skewvec" else 6  # "rotmat": six2rmat of a 6-wide head (so3_lock_train.py:19-22, 57-58)
         self.time_embedding = SinusoidalPosEmb(d_model - 9)
         self.net = nn.Sequential(*[ResLayer(nn.Sequential(nn.Linear(d_model, d_model), nn.SiLU())) for _ in range(6)],
                                  nn.Linear(d_model, self.d_out))
@@ -64,7 +63,7 @@ class RotPredict(nn.Module):
         self.t_table = 1000
 
     def flat_params(self) -> torch.Tensor:
-        """The 392,448 parameters in state_dict order; differentiable (autograd routes the fused gradient back to each
+        """The 392,448 (skewvec) / 393,216 (rotmat) parameters in state_dict order; differentiable (autograd routes the fused gradient back to each
         nn.Linear through the cat)."""
         return torch.cat([p.reshape(-1) for p in self.net.parameters()])
 
@@ -82,8 +81,10 @@ class RotPredict(nn.Module):
     def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None):
         tt = self.t_table if t_table is None else int(t_table)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            return _ResNetFn.apply(x, t, self.flat_params(), self.precision_code, tt)
-        return _b.resnet_fwd(self.flat_params_nograd(), x, t, tt, self.precision_code)
+            out = _ResNetFn.apply(x, t, self.flat_params(), self.precision_code, tt)
+        else:
+            out = _b.resnet_fwd(self.flat_params_nograd(), x, t, tt, self.precision_code)
+        return _b.six2rmat(out) if self.out_type == "rotmat" else out
 
 
 def main(argv=None):

@@ -51,14 +51,12 @@ class RotPredict(nn.Module):
         self.out_type = out_type
         if in_type != "rotmat" or d_model != 65:
             raise NotImplementedError("so3x: the fused score network is built for in_type='rotmat', d_model=65")
-        if out_type != "skewvec":
-            # the reference's 'rotmat' head (six2rmat, so3_train.py:47-48) is off the SO3Diffusion
-            # 'skewvec' path (so3_train.py:60,63) and is not part of this backend
-            raise NotImplementedError("so3x: only out_type='skewvec' is implemented")
+        if out_type not in ("skewvec", "rotmat"):
+            raise ValueError(f"Unexpected out_type: {out_type}")  # the reference builds this error without raising it (so3_train.py:24)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {list(_PRECISIONS)}")
         self.precision = precision
-        self.d_out = 3
+        self.d_out = 3 if out_type == "skewvec" else 6  # "rotmat": six2rmat of a 6-wide head (so3_train.py:19-22, 47-48)
         self.time_embedding = SinusoidalPosEmb(d_model - 9)
         self.net = nn.Sequential(
             nn.Linear(d_model, d_model), nn.SiLU(),
@@ -75,7 +73,7 @@ class RotPredict(nn.Module):
         self.t_table = 0
 
     def flat_params(self) -> torch.Tensor:
-        """The 17,358 parameters in state_dict order; differentiable (autograd routes the
+        """The 17,358 (skewvec) / 17,556 (rotmat) parameters in state_dict order; differentiable (autograd routes the
         fused gradient back to each nn.Linear through the cat)."""
         return torch.cat([p.reshape(-1) for p in self.net.parameters()])
 
@@ -94,8 +92,10 @@ class RotPredict(nn.Module):
     def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None):
         tt = self.t_table if t_table is None else int(t_table)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            return _ScoreMLPFn.apply(x, t, self.flat_params(), self.precision_code, tt)
-        return _b.mlp_fwd(self.flat_params_nograd(), x, t, self.precision_code, tt)
+            out = _ScoreMLPFn.apply(x, t, self.flat_params(), self.precision_code, tt)
+        else:
+            out = _b.mlp_fwd(self.flat_params_nograd(), x, t, self.precision_code, tt)
+        return _b.six2rmat(out) if self.out_type == "rotmat" else out
 
 
 def main(argv=None):

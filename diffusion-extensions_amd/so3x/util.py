@@ -8,7 +8,7 @@ import torch
 
 from . import backend as _b
 
-__all__ = ["skew2vec", "vec2skew", "orthogonalise", "log_rmat", "aa_to_rmat", "rmat_to_aa", "quat_to_rmat",
+__all__ = ["skew2vec", "vec2skew", "orthogonalise", "rmat2six", "six2rmat", "log_rmat", "aa_to_rmat", "rmat_to_aa", "quat_to_rmat",
            "rmat_dist", "so3_lerp", "so3_scale", "euler_to_rmat", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
            "MMD", "Ker_2samp_test", "Ker_2samp_log_prob"]
 
@@ -33,9 +33,24 @@ def orthogonalise(mat: torch.Tensor) -> torch.Tensor:
     return mat
 
 
+def rmat2six(x: torch.Tensor) -> torch.Tensor:
+    """First two rows of a rotation, flattened (reference util.py:60-64).  Pure indexing: stays in torch."""
+    return torch.flatten(x[..., :2, :], -2, -1)
+
+
+def six2rmat(x: torch.Tensor) -> torch.Tensor:
+    """Gram-Schmidt of two 3-vectors -> rotation with rows b1, b2, b1 x b2 (reference util.py:67-76); differentiable
+    (closed-form backward kernel), it is the head of RotPredict(out_type="rotmat")."""
+    return _b.six2rmat(x)
+
+
+def _needs_grad(*xs):
+    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
+
+
 def log_rmat(r_mat: torch.Tensor) -> torch.Tensor:
-    """Matrix log as a skew-symmetric matrix (reference util.py:164-192)."""
-    return _b.log_rmat(r_mat)
+    """Matrix log as a skew-symmetric matrix (reference util.py:164-192); differentiable like the reference's."""
+    return _b.log_rmat_ad(r_mat) if _needs_grad(r_mat) else _b.log_rmat(r_mat)
 
 
 def aa_to_rmat(rot_axis: torch.Tensor, ang: torch.Tensor) -> torch.Tensor:
@@ -54,7 +69,11 @@ def quat_to_rmat(quaternions: torch.Tensor) -> torch.Tensor:
 
 
 def rmat_dist(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-    """Geodesic distance ||log(input^T target)||_F (reference util.py:315-322)."""
+    """Geodesic distance ||log(input^T target)||_F (reference util.py:315-322); differentiable like the reference's."""
+    if _needs_grad(input, target):
+        if input.shape != target.shape:
+            input, target = torch.broadcast_tensors(input, target)  # autograd sums the expanded gradient back
+        return _b.rmat_dist_ad(input.contiguous(), target.contiguous())
     return _b.rmat_dist(input, target)
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 2
+#define SO3X_ABI_VERSION 3
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -45,6 +45,7 @@ extern "C" {
 #define SO3X_KNOTS 1000      /* CDF knots, distributions.py:15                    */
 #define SO3X_TRAP 999        /* CDF row length, distributions.py:26-30            */
 #define SO3X_MLP_PARAMS 17358 /* RotPredict(d_model=65, skewvec), so3_train.py:26-36 */
+#define SO3X_MLP_PARAMS_ROTMAT 17556 /* out_type="rotmat": Linear(65, 6) head */
 #define SO3X_SCHED_ROWS 13
 
 typedef void* so3x_stream_t; /* hipStream_t */
@@ -94,6 +95,14 @@ int so3x_so3_lerp(so3x_stream_t s, const float* a, int64_t a_stride, const float
                   int64_t w_stride, float* out, int64_t n);
 /* util.py:315-322  rmat_dist: ||log(a^T b)||_F -> [n] */
 int so3x_rmat_dist(so3x_stream_t s, const float* a, const float* b, float* out, int64_t n);
+/* util.py:67-76  six2rmat: x6[n][6] -> R[n][3][3] (rows b1, b2, b1 x b2 of the Gram-Schmidt of the two 3-vectors), and its
+ * autograd: dR = dL/dR[n][3][3] -> dx6[n][6] (the reference differentiates it with torch autograd, so3_train.py:47-48) */
+int so3x_six2rmat(so3x_stream_t s, const float* x6, float* R, int64_t n);
+int so3x_six2rmat_bwd(so3x_stream_t s, const float* x6, const float* dR, float* dx6, int64_t n);
+/* autograd of log_rmat (util.py:164-175, generic branch) and of rmat_dist (util.py:315-322), needed by
+ * loss_type="prevstep" (diffusion.py:358-365): dlog[n][3][3] -> dR;  ddist[n] -> (da, db) */
+int so3x_log_rmat_bwd(so3x_stream_t s, const float* R, const float* dlog, float* dR, int64_t n);
+int so3x_rmat_dist_bwd(so3x_stream_t s, const float* a, const float* b, const float* ddist, float* da, float* db, int64_t n);
 /* batched a @ b and a @ b^T (diffusion.py:297,302,326,346); strides 0 (broadcast) or 9 */
 int so3x_rmul(so3x_stream_t s, const float* a, int64_t a_stride, const float* b, int64_t b_stride,
               int transpose_b, float* out, int64_t n);
@@ -130,8 +139,9 @@ int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, 
                              float* logp, float* score_vec, float* grad_R, int64_t n);
 
 /* ------------------------------------------------------------------- score MLP */
-/* models.py:13-25 + so3_train.py:39-49, out_type="skewvec".  params = the 17,358
- * fp32 values in state_dict order net.{0,2,4,6,8}.{weight,bias}.  t int64, t_stride
+/* models.py:13-25 + so3_train.py:11-49.  n_out = 3 (out_type="skewvec": params = the 17,358 fp32 values in
+ * state_dict order net.{0,2,4,6,8}.{weight,bias}) or 6 (out_type="rotmat", so3_train.py:21-22: net.8 is
+ * Linear(65, 6), 17,556 values; the op returns the RAW 6 outputs, six2rmat is so3x_six2rmat).  t int64, t_stride
  * 0 (one timestep for the whole batch, the (1,)-shaped t of so3_test.py:31) or 1.
  * t_table: 0 = timesteps are arbitrary, the embedding is evaluated per sample in-kernel;
  *          T > 0 = the caller guarantees 0 <= t < T for every sample (SO3Diffusion's
@@ -139,18 +149,18 @@ int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, 
  *          (appendix C.3 of SURVEY.md) and gathers rows by t -- no per-sample sin/cos. */
 size_t so3x_mlp_workspace_bytes(int64_t n, int precision, int t_table);
 int so3x_mlp_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                 int64_t t_stride, float* out, int64_t n, int precision, int t_table,
+                 int64_t t_stride, float* out, int64_t n, int n_out, int precision, int t_table,
                  void* workspace, size_t workspace_bytes);
 /* Training forward (bf16 operands and t_table > 0 only, else SO3X_ERR_UNSUPPORTED): the same output plus the four
  * layers' pre-activations parked in `zstash` (so3x_mlp_stash_bytes(n) = 544 B per sample, f16) for so3x_mlp_bwd. */
 size_t so3x_mlp_stash_bytes(int64_t n);
 int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                       int64_t t_stride, float* out, void* zstash, int64_t n, int precision, int t_table,
+                       int64_t t_stride, float* out, void* zstash, int64_t n, int n_out, int precision, int t_table,
                        void* workspace, size_t workspace_bytes);
-/* autograd of the above for a given dL/dout[n][3] -> dparams[17358] (overwritten).  zstash: NULL (the forward is
+/* autograd of the above for a given dL/dout[n][n_out] -> dparams[17358 | 17556] (overwritten).  zstash: NULL (the forward is
  * recomputed inside) or the stash written by so3x_mlp_fwd_stash for the SAME params, R, t (bf16, t_table > 0). */
 int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                 int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,
+                 int64_t t_stride, const float* dout, float* dparams, int64_t n, int n_out, int precision,
                  int t_table, const void* zstash, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------- diffusion steps */
@@ -184,18 +194,19 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
                         void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------- wide residual score network (8f row 3) */
-/* so3_lock_train.RotPredict (so3_lock_train.py:11-59), out_type="skewvec": d_model = 255, input
+/* so3_lock_train.RotPredict (so3_lock_train.py:11-59): d_model = 255, input
  * [R(9), sin(123), cos(123)] (models.py:13-25 with dim 246), six ResLayer(Linear(255,255)+SiLU) blocks
- * (models.py:28-34), Linear(255,3).  params = the 392,448 fp32 values in state_dict order
- * net.{0..5}.layer.0.{weight,bias}, net.6.{weight,bias}.  t_table = T > 0 is REQUIRED: the call builds the
+ * (models.py:28-34), Linear(255, n_out).  n_out = 3 (out_type="skewvec": params = the 392,448 fp32 values in state_dict
+ * order net.{0..5}.layer.0.{weight,bias}, net.6.{weight,bias}) or 6 (out_type="rotmat": 393,216 values, raw outputs).  t_table = T > 0 is REQUIRED: the call builds the
  * [T][256] input-row table and gathers by t; timesteps outside [0, T) are clamped into it. */
 #define SO3X_RESNET_D 255
 #define SO3X_RESNET_PARAMS 392448
+#define SO3X_RESNET_PARAMS_ROTMAT 393216
 size_t so3x_resnet_workspace_bytes(int precision, int t_table);
 int so3x_resnet_fwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                    int64_t t_stride, float* out, int64_t n, int precision, int t_table,
+                    int64_t t_stride, float* out, int64_t n, int n_out, int precision, int t_table,
                     void* workspace, size_t workspace_bytes);
-/* autograd of so3x_resnet_fwd for a given dL/dout[n][3] -> dparams[392448] (overwritten): forward recomputed with
+/* autograd of so3x_resnet_fwd for a given dL/dout[n][n_out] -> dparams[392448 | 393216] (overwritten): forward recomputed with
  * its layer inputs and pre-activations parked in the workspace (~10 KB per sample with bf16 operands, ~20 KB in
  * fp32), dX chain and dW GEMMs on the matrix cores, deterministic reduction. */
 size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table);
@@ -203,11 +214,11 @@ size_t so3x_resnet_train_workspace_bytes(int64_t n, int precision, int t_table);
  * sample with bf16 operands, 13 KB in fp32) for so3x_resnet_bwd; workspace = so3x_resnet_workspace_bytes. */
 size_t so3x_resnet_stash_bytes(int64_t n, int precision);
 int so3x_resnet_fwd_stash(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                          int64_t t_stride, float* out, void* stash, int64_t n, int precision, int t_table,
+                          int64_t t_stride, float* out, void* stash, int64_t n, int n_out, int precision, int t_table,
                           void* workspace, size_t workspace_bytes);
 /* stash: NULL (the forward is run again inside) or what so3x_resnet_fwd_stash wrote for the SAME params, R, t, precision */
 int so3x_resnet_bwd(so3x_stream_t s, const float* params, const float* R, const int64_t* t,
-                    int64_t t_stride, const float* dout, float* dparams, int64_t n, int precision,
+                    int64_t t_stride, const float* dout, float* dparams, int64_t n, int n_out, int precision,
                     int t_table, const void* stash, void* workspace, size_t workspace_bytes);
 /* so3x_p_sample_chain with this network as the denoiser (so3_lock_test.py:24-31); workspace =
  * so3x_resnet_workspace_bytes(precision, T). */
@@ -269,6 +280,15 @@ size_t so3x_mse_workspace_bytes(int64_t n);
 int so3x_mse_loss(so3x_stream_t s, const float* a, const float* b, int64_t n, float* loss, void* workspace,
                   size_t workspace_bytes);
 int so3x_mse_grad(so3x_stream_t s, const float* a, const float* b, int64_t n, const float* gscale, float* grad_a);
+
+
+/* loss_type="prevstep" of SO3Diffusion.p_losses (diffusion.py:358-365), fused: step = x_noisy^T q_posterior_mean(x_start,
+ * x_noisy, t) (299-302), loss[0] = mean_i rmat_dist(x_recon_i, step_i)^2, and (dx_recon != NULL) its gradient
+ * d loss / d x_recon [n][3][3].  step_out (optional) receives the step rotations.  sched = device [13][T] table. */
+size_t so3x_prevstep_workspace_bytes(int64_t n);
+int so3x_prevstep_loss(so3x_stream_t s, const float* sched, int T, const float* x_recon, const float* x_start,
+                       const float* x_noisy, const int64_t* t, int64_t t_stride, int64_t n, float* loss, float* dx_recon,
+                       float* step_out, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

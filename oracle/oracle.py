@@ -214,19 +214,28 @@ def igso3_sample(trap, axes, unif, row_idx=None, weight_row=-1, mean=None, prec=
 
 
 N_PARAMS = 4 * (65 * 65 + 65) + 3 * 65 + 3
+N_PARAMS_ROTMAT = 4 * (65 * 65 + 65) + 6 * 65 + 6   # out_type="rotmat": a 6-wide head (so3_train.py:19-22)
+
+
+def _head_width(n_params, trunk):
+    """3 ("skewvec") or 6 ("rotmat") outputs, read off the flat parameter count"""
+    for k in (3, 6):
+        if n_params == trunk + k * (1 + (65 if trunk == 4 * (65 * 65 + 65) else 255)):
+            return k
+    raise ValueError(f"unexpected parameter count {n_params}")
 
 
 def mlp_fwd(params, R, t, prec="f32", return_acts=False):
     params = _arr(params, np.float32).ravel()
-    assert params.size == N_PARAMS
+    nout = _head_width(params.size, 4 * (65 * 65 + 65))
     R = _arr(R, _DT[prec]).reshape(-1, 9)
     t = _arr(t, np.int64).ravel()
     n = R.shape[0]
-    out = np.empty((n, 3), _DT[prec])
+    out = np.empty((n, nout), _DT[prec])
     acts = np.empty((n, 5, 65), _DT[prec]) if return_acts else None
     fr = posemb_freqs()
     _fn("mlp_fwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(out),
-                         _p(acts), C.c_long(n))
+                         _p(acts), C.c_long(n), C.c_long(nout))
     return (out, acts) if return_acts else out
 
 
@@ -234,12 +243,13 @@ def mlp_bwd(params, R, t, dout, prec="f32"):
     params = _arr(params, np.float32).ravel()
     R = _arr(R, _DT[prec]).reshape(-1, 9)
     t = _arr(t, np.int64).ravel()
-    dout = _arr(dout, _DT[prec]).reshape(-1, 3)
+    nout = _head_width(params.size, 4 * (65 * 65 + 65))
+    dout = _arr(dout, _DT[prec]).reshape(-1, nout)
     n = R.shape[0]
-    dp = np.empty(N_PARAMS, np.float64)
+    dp = np.empty(params.size, np.float64)
     fr = posemb_freqs()
     _fn("mlp_bwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(dout),
-                         _p(dp), C.c_long(n))
+                         _p(dp), C.c_long(n), C.c_long(nout))
     return dp
 
 
@@ -249,13 +259,14 @@ N_PARAMS_RESNET = 6 * (255 * 255 + 255) + 3 * 255 + 3
 def resnet_fwd(params, R, t, prec="f32"):
     """so3_lock_train.RotPredict(out_type="skewvec") forward (so3_lock_train.py:11-59)."""
     params = _arr(params, np.float32).ravel()
-    assert params.size == N_PARAMS_RESNET
+    nout = _head_width(params.size, 6 * (255 * 255 + 255))
     R = _arr(R, _DT[prec]).reshape(-1, 9)
     t = _arr(t, np.int64).ravel()
     n = R.shape[0]
-    out = np.empty((n, 3), _DT[prec])
+    out = np.empty((n, nout), _DT[prec])
     fr = posemb_freqs(123)
-    _fn("resnet_fwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(out), C.c_long(n))
+    _fn("resnet_fwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(out), C.c_long(n),
+                            C.c_long(nout))
     return out
 
 
@@ -263,12 +274,66 @@ def resnet_bwd(params, R, t, dout, prec="f32"):
     params = _arr(params, np.float32).ravel()
     R = _arr(R, _DT[prec]).reshape(-1, 9)
     t = _arr(t, np.int64).ravel()
-    dout = _arr(dout, _DT[prec]).reshape(-1, 3)
-    dp = np.empty(N_PARAMS_RESNET, np.float64)
+    nout = _head_width(params.size, 6 * (255 * 255 + 255))
+    dout = _arr(dout, _DT[prec]).reshape(-1, nout)
+    dp = np.empty(params.size, np.float64)
     fr = posemb_freqs(123)
     _fn("resnet_bwd", prec)(_p(params), _p(fr), _p(R), _p(t), C.c_long(0 if t.size == 1 else 1), _p(dout), _p(dp),
-                            C.c_long(R.shape[0]))
+                            C.c_long(R.shape[0]), C.c_long(nout))
     return dp
+
+
+N_PARAMS_RESNET_ROTMAT = 6 * (255 * 255 + 255) + 6 * 255 + 6
+
+
+def six2rmat(x, prec="f32"):
+    """util.py:67-76"""
+    x = _arr(x, _DT[prec]).reshape(-1, 6)
+    out = np.empty((x.shape[0], 3, 3), _DT[prec])
+    _fn("six2rmat", prec)(_p(x), _p(out), C.c_long(x.shape[0]))
+    return out
+
+
+def six2rmat_bwd(x, G, prec="f32"):
+    """autograd of six2rmat: dL/dout [n,3,3] -> dL/dx [n,6]"""
+    x = _arr(x, _DT[prec]).reshape(-1, 6)
+    G = _arr(G, _DT[prec]).reshape(-1, 9)
+    dx = np.empty_like(x)
+    _fn("six2rmat_bwd", prec)(_p(x), _p(G), _p(dx), C.c_long(x.shape[0]))
+    return dx
+
+
+def log_rmat_bwd(R, G, prec="f32"):
+    """autograd of log_rmat (util.py:164-175): dL/dlog [n,3,3] -> dL/dR"""
+    R = _arr(R, _DT[prec]).reshape(-1, 9)
+    G = _arr(G, _DT[prec]).reshape(-1, 9)
+    dR = np.empty_like(R)
+    _fn("log_rmat_bwd", prec)(_p(R), _p(G), _p(dR), C.c_long(R.shape[0]))
+    return dR.reshape(-1, 3, 3)
+
+
+def rmat_dist_bwd(a, b, g, prec="f32"):
+    """autograd of rmat_dist (util.py:315-322): dL/ddist [n] -> (dL/da, dL/db)"""
+    a = _arr(a, _DT[prec]).reshape(-1, 9)
+    b = _arr(b, _DT[prec]).reshape(-1, 9)
+    g = _arr(g, _DT[prec]).ravel()
+    da, db = np.empty_like(a), np.empty_like(b)
+    _fn("rmat_dist_bwd", prec)(_p(a), _p(b), _p(g), _p(da), _p(db), C.c_long(a.shape[0]))
+    return da.reshape(-1, 3, 3), db.reshape(-1, 3, 3)
+
+
+def prevstep_loss(x_recon, x_start, x_noisy, sched, t, prec="f32"):
+    """loss_type="prevstep" (diffusion.py:358-365): returns (step [n,3,3], dist2 [n], d(sum dist2)/dx_recon [n,3,3]);
+    the loss is dist2.mean().  sched = schedule_from_betas table (rows 10/11 = posterior_mean_coef1/2)."""
+    xr = _arr(x_recon, _DT[prec]).reshape(-1, 9)
+    xs = _arr(x_start, _DT[prec]).reshape(-1, 9)
+    xn = _arr(x_noisy, _DT[prec]).reshape(-1, 9)
+    t = _arr(t, np.int64).ravel()
+    n = xr.shape[0]
+    c1, c2 = np.ascontiguousarray(sched[10], np.float32), np.ascontiguousarray(sched[11], np.float32)
+    step, d2, dx = np.empty_like(xr), np.empty(n, _DT[prec]), np.empty_like(xr)
+    _fn("prevstep_loss", prec)(_p(xr), _p(xs), _p(xn), _p(c1), _p(c2), _p(t), _p(step), _p(d2), _p(dx), C.c_long(n))
+    return step.reshape(-1, 3, 3), d2, dx.reshape(-1, 3, 3)
 
 
 def q_sample_target(x0, noise, sched, t, prec="f32"):

@@ -217,7 +217,7 @@ void so3o_p_sample_step_f32(const float* params, const float* freqs, const float
   for (long b = 0; b < n; b++) {
     float v[3], mean[9];
     long tt = t;
-    so3o_mlp_fwd_one_f32(params, freqs, x + 9 * b, tt, v, NULL);
+    so3o_mlp_fwd_one_f32(params, freqs, x + 9 * b, tt, v, NULL, 3);
     so3o_p_mean_one_f32(x + 9 * b, v, a, bc, c1, c2, NULL, mean);
     if (t == 0) { memcpy(out + 9 * b, mean, sizeof(mean)); continue; }
     float smp[9];

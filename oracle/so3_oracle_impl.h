@@ -217,7 +217,7 @@ static void FN(mlp_input)(const REAL* R, long t, const float* freqs, REAL* x) {
 }
 
 static inline void FN(mlp_fwd_one)(const float* params, const float* freqs, const REAL* R, long t,
-                                   REAL* out, REAL* acts) {
+                                   REAL* out, REAL* acts, int nout) {
   const int D = SO3O_D;
   REAL h[2][SO3O_D];
   FN(mlp_input)(R, t, freqs, h[0]);
@@ -234,8 +234,8 @@ static inline void FN(mlp_fwd_one)(const float* params, const float* freqs, cons
     cur = 1 - cur;
     if (acts) for (int i = 0; i < D; i++) acts[(l + 1) * D + i] = h[cur][i];
   }
-  const float* W = p; const float* bias = p + 3 * D;
-  for (int o = 0; o < 3; o++) {
+  const float* W = p; const float* bias = p + nout * D;  /* nout = 3 ("skewvec") or 6 ("rotmat", so3_train.py:19-22) */
+  for (int o = 0; o < nout; o++) {
     REAL acc = (REAL)bias[o];
     for (int i = 0; i < D; i++) acc += (REAL)W[o * D + i] * h[cur][i];
     out[o] = acc;
@@ -243,10 +243,10 @@ static inline void FN(mlp_fwd_one)(const float* params, const float* freqs, cons
 }
 
 void FN(mlp_fwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride,
-                 REAL* out, REAL* acts, long n) {
+                 REAL* out, REAL* acts, long n, long nout) {
 #pragma omp parallel for schedule(static)
   for (long b = 0; b < n; b++)
-    FN(mlp_fwd_one)(params, freqs, R + 9 * b, t[b * t_stride], out + 3 * b, acts ? acts + b * 5 * SO3O_D : 0);
+    FN(mlp_fwd_one)(params, freqs, R + 9 * b, t[b * t_stride], out + nout * b, acts ? acts + b * 5 * SO3O_D : 0, (int)nout);
 }
 
 /* Backward of RotPredict for a given dL/dout [n,3]: gradients wrt the 17,358
@@ -254,9 +254,9 @@ void FN(mlp_fwd)(const float* params, const float* freqs, const REAL* R, const l
  * rotation inputs carry no grad for loss_type="skewvec").
  * Accumulates in double regardless of REAL so the oracle is the better-conditioned side. */
 void FN(mlp_bwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride,
-                 const REAL* dout, double* dparams, long n) {
+                 const REAL* dout, double* dparams, long n, long nout) {
   const int D = SO3O_D;
-  const long NP = 4 * (D * D + D) + 3 * D + 3;
+  const long NP = 4 * (D * D + D) + nout * D + nout;
   for (long i = 0; i < NP; i++) dparams[i] = 0.0;
   for (long b = 0; b < n; b++) {
     REAL h[5][SO3O_D], z[4][SO3O_D];
@@ -274,9 +274,9 @@ void FN(mlp_bwd)(const float* params, const float* freqs, const REAL* R, const l
     long off5 = 4 * (D * D + D);
     REAL dh[SO3O_D], dz[SO3O_D];
     for (int i = 0; i < D; i++) dh[i] = 0;
-    for (int o = 0; o < 3; o++) {
-      REAL g = dout[3 * b + o];
-      dparams[off5 + 3 * D + o] += (double)g;
+    for (int o = 0; o < nout; o++) {
+      REAL g = dout[nout * b + o];
+      dparams[off5 + nout * D + o] += (double)g;
       for (int i = 0; i < D; i++) {
         dparams[off5 + o * D + i] += (double)g * (double)h[4][i];
         dh[i] += (REAL)params[off5 + o * D + i] * g;
@@ -384,7 +384,8 @@ static void FN(resnet_input)(const REAL* R, long t, const float* freqs, REAL* x)
   }
 }
 
-void FN(resnet_fwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride, REAL* out, long n) {
+void FN(resnet_fwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride, REAL* out, long n,
+                    long nout) {
   const int D = SO3O_DW;
 #pragma omp parallel for schedule(static)
   for (long b = 0; b < n; b++) {
@@ -400,19 +401,19 @@ void FN(resnet_fwd)(const float* params, const float* freqs, const REAL* R, cons
       }
       for (int o = 0; o < D; o++) x[o] = y[o];
     }
-    for (int o = 0; o < 3; o++) {
-      REAL acc = (REAL)p[3 * D + o];
+    for (int o = 0; o < nout; o++) {
+      REAL acc = (REAL)p[nout * D + o];
       for (int i = 0; i < D; i++) acc += (REAL)p[o * D + i] * x[i];
-      out[3 * b + o] = acc;
+      out[nout * b + o] = acc;
     }
   }
 }
 
 /* gradients wrt the 392,448 parameters for a given dL/dout [n,3] (autograd of so3_lock_train.py:50-59), accumulated in double */
 void FN(resnet_bwd)(const float* params, const float* freqs, const REAL* R, const long* t, long t_stride, const REAL* dout,
-                    double* dparams, long n) {
+                    double* dparams, long n, long nout) {
   const int D = SO3O_DW;
-  const long LS = (long)D * D + D, NP = 6 * LS + 3 * D + 3;
+  const long LS = (long)D * D + D, NP = 6 * LS + nout * D + nout;
   for (long i = 0; i < NP; i++) dparams[i] = 0.0;
   for (long b = 0; b < n; b++) {
     REAL x[7][SO3O_DW], z[6][SO3O_DW], dx[SO3O_DW], dz[SO3O_DW];
@@ -427,9 +428,9 @@ void FN(resnet_bwd)(const float* params, const float* freqs, const REAL* R, cons
     }
     const long off6 = 6 * LS;
     for (int i = 0; i < D; i++) dx[i] = 0;
-    for (int o = 0; o < 3; o++) {
-      REAL g = dout[3 * b + o];
-      dparams[off6 + 3 * D + o] += (double)g;
+    for (int o = 0; o < nout; o++) {
+      REAL g = dout[nout * b + o];
+      dparams[off6 + nout * D + o] += (double)g;
       for (int i = 0; i < D; i++) {
         dparams[off6 + o * D + i] += (double)g * (double)x[6][i];
         dx[i] += (REAL)params[off6 + o * D + i] * g;
@@ -452,6 +453,115 @@ void FN(resnet_bwd)(const float* params, const float* freqs, const REAL* R, cons
   }
 }
 #undef SO3O_DW
+
+/* ---- rotation-matrix head and the "prevstep" loss ---------------------------------------------
+ * six2rmat (util.py:67-76): Gram-Schmidt of two 3-vectors, rows b1, b2, b1 x b2. */
+void FN(six2rmat)(const REAL* x, REAL* out, long n) {
+  for (long b = 0; b < n; b++) {
+    const REAL* a1 = x + 6 * b; const REAL* a2 = a1 + 3; REAL* o = out + 9 * b;
+    REAL n1 = SQRT(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    REAL b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    REAL d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    REAL u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    REAL n2 = SQRT(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    REAL b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    o[0] = b1[0]; o[1] = b1[1]; o[2] = b1[2]; o[3] = b2[0]; o[4] = b2[1]; o[5] = b2[2];
+    o[6] = b1[1] * b2[2] - b1[2] * b2[1]; o[7] = b1[2] * b2[0] - b1[0] * b2[2]; o[8] = b1[0] * b2[1] - b1[1] * b2[0];
+  }
+}
+/* autograd of six2rmat: G = dL/dout [n,3,3] -> dL/dx [n,6] */
+void FN(six2rmat_bwd)(const REAL* x, const REAL* G, REAL* dx, long n) {
+  for (long b = 0; b < n; b++) {
+    const REAL* a1 = x + 6 * b; const REAL* a2 = a1 + 3; const REAL* g = G + 9 * b;
+    REAL n1 = SQRT(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    REAL b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    REAL d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    REAL u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    REAL n2 = SQRT(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    REAL b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    const REAL* g1 = g; const REAL* g2 = g + 3; const REAL* g3 = g + 6;
+    /* b3 = b1 x b2:  db1 += b2 x g3,  db2 += g3 x b1 */
+    REAL gb1[3] = {g1[0] + b2[1] * g3[2] - b2[2] * g3[1], g1[1] + b2[2] * g3[0] - b2[0] * g3[2], g1[2] + b2[0] * g3[1] - b2[1] * g3[0]};
+    REAL gb2[3] = {g2[0] + g3[1] * b1[2] - g3[2] * b1[1], g2[1] + g3[2] * b1[0] - g3[0] * b1[2], g2[2] + g3[0] * b1[1] - g3[1] * b1[0]};
+    REAL p2 = gb2[0] * b2[0] + gb2[1] * b2[1] + gb2[2] * b2[2];
+    REAL du[3] = {(gb2[0] - p2 * b2[0]) / n2, (gb2[1] - p2 * b2[1]) / n2, (gb2[2] - p2 * b2[2]) / n2};
+    REAL q = b1[0] * du[0] + b1[1] * du[1] + b1[2] * du[2];
+    for (int k = 0; k < 3; k++) {
+      dx[6 * b + 3 + k] = du[k] - q * b1[k];        /* u = a2 - (b1.a2) b1 */
+      gb1[k] += -d * du[k] - q * a2[k];
+    }
+    REAL p1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
+    for (int k = 0; k < 3; k++) dx[6 * b + k] = (gb1[k] - p1 * b1[k]) / n1;
+  }
+}
+
+/* d omega / dM and (s, c, omega) of a matrix, util.py:165-169 */
+static inline REAL FN(domega)(const REAL* r, REAL* g, REAL* s_out) {
+  REAL v0 = r[7] - r[5], v1 = -(r[6] - r[2]), v2 = r[3] - r[1];
+  REAL s = SQRT(v0 * v0 + v1 * v1 + v2 * v2) / 2;
+  REAL c = (r[0] + r[4] + r[8] - 1) / 2;
+  REAL den = s * s + c * c, k = c / (4 * s);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) g[3 * i + j] = (k * (r[3 * i + j] - r[3 * j + i]) - (i == j ? s / 2 : 0)) / den;
+  *s_out = s;
+  return ATAN2(s, c);
+}
+
+/* autograd of log_rmat (util.py:164-175, generic branch): log = scale (R - R^T), scale = omega / (2 s);
+ * G = dL/dlog [n,3,3] -> dL/dR.  d scale = d omega / (2 s) - omega / (2 s^2) ds,  ds/dR = (R - R^T) / (4 s). */
+void FN(log_rmat_bwd)(const REAL* R, const REAL* G, REAL* dR, long n) {
+  for (long b = 0; b < n; b++) {
+    const REAL* r = R + 9 * b; const REAL* g = G + 9 * b;
+    REAL dom[9], s;
+    REAL om = FN(domega)(r, dom, &s);
+    REAL scale = om / (2 * s), gs = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) gs += g[3 * i + j] * (r[3 * i + j] - r[3 * j + i]);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        REAL S = r[3 * i + j] - r[3 * j + i];
+        dR[9 * b + 3 * i + j] = scale * (g[3 * i + j] - g[3 * j + i]) + gs * (dom[3 * i + j] / (2 * s) - om / (2 * s * s) * S / (4 * s));
+      }
+  }
+}
+
+/* autograd of rmat_dist (util.py:315-322): dist = |log(a^T b)|_F = sqrt(2) omega(a^T b);  g = dL/ddist [n] */
+void FN(rmat_dist_bwd)(const REAL* A, const REAL* Bm, const REAL* g, REAL* dA, REAL* dB, long n) {
+  for (long b = 0; b < n; b++) {
+    REAL M[9], dom[9], s;
+    FN(mul33_at)(A + 9 * b, Bm + 9 * b, M);
+    FN(domega)(M, dom, &s);
+    const REAL k = SQRT((REAL)2) * g[b];
+    for (int i = 0; i < 9; i++) dom[i] *= k;
+    FN(mul33_bt)(Bm + 9 * b, dom, dA + 9 * b);  /* M = a^T b: dL/da = b dM^T */
+    FN(mul33)(A + 9 * b, dom, dB + 9 * b);      /*            dL/db = a dM   */
+  }
+}
+
+/* loss_type = "prevstep" (diffusion.py:358-365): posterior mean (299-302) relative to x_noisy, squared geodesic distance to
+ * the network's rotation.  dist2[n] = rmat_dist(x_recon, step)^2 (the loss is its mean); dx = d(sum dist2)/dx_recon. */
+void FN(prevstep_loss)(const REAL* x_recon, const REAL* x_start, const REAL* x_noisy, const float* coef1, const float* coef2,
+                       const long* t, REAL* step_out, REAL* dist2, REAL* dx, long n) {
+  for (long b = 0; b < n; b++) {
+    REAL w[3], c1m[9], c2m[9], pm[9], step[9], M[9], dom[9], s;
+    FN(log3)(x_start + 9 * b, w);
+    for (int k = 0; k < 3; k++) w[k] *= (REAL)coef1[t[b]];
+    FN(exp3)(w, c1m);
+    FN(log3)(x_noisy + 9 * b, w);
+    for (int k = 0; k < 3; k++) w[k] *= (REAL)coef2[t[b]];
+    FN(exp3)(w, c2m);
+    FN(mul33)(c1m, c2m, pm);
+    FN(mul33_at)(x_noisy + 9 * b, pm, step);
+    if (step_out) for (int k = 0; k < 9; k++) step_out[9 * b + k] = step[k];
+    FN(mul33_at)(x_recon + 9 * b, step, M);
+    REAL om = FN(domega)(M, dom, &s);
+    dist2[b] = 2 * om * om;
+    if (dx) {
+      for (int k = 0; k < 9; k++) dom[k] *= 4 * om;
+      FN(mul33_bt)(step, dom, dx + 9 * b);
+    }
+  }
+}
 
 #undef SO3O_D
 #undef FN

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/so3x.h but not exported"
     assert declared == set(B.SYMBOLS)
-    assert B.lib().so3x_abi_version() == 2
+    assert B.lib().so3x_abi_version() == 3
 
 
 def test_no_oracle_or_cpu_fallback_in_product():
@@ -116,8 +116,16 @@ def test_reference_interface_is_kept(golden):
     assert torch.equal(S, -S.transpose(-1, -2)) and torch.equal(S[:, 2, 1], v[:, 0]) and torch.equal(S[:, 2, 0], -v[:, 1])
     explicit = SO3Diffusion(net, betas=torch.linspace(1e-4, 0.02, 50))
     assert explicit.num_timesteps == 50
-    with pytest.raises(NotImplementedError):
-        RotPredict(out_type="rotmat")
+    rot = RotPredict()                      # the reference's default head: out_type="rotmat", Linear(65, 6) + six2rmat
+    assert rot.out_type == "rotmat" and rot.net[8].out_features == 6 and rot.flat_params().numel() == 17556
+    with pytest.raises(ValueError):
+        RotPredict(out_type="quat")
+    assert SO3Diffusion(rot, timesteps=10, loss_type="prevstep").loss_type == "prevstep"
+    with pytest.raises(ValueError):
+        SO3Diffusion(net, timesteps=10, loss_type="l2")
+    for f in ("six2rmat", "rmat2six"):
+        assert callable(getattr(util, f))
+    assert torch.equal(util.rmat2six(torch.arange(18.).reshape(2, 3, 3)), torch.tensor([[0., 1, 2, 3, 4, 5], [9, 10, 11, 12, 13, 14]]))
     assert hasattr(distributions.IsotropicGaussianSO3, "sample") and hasattr(distributions.IsotropicGaussianSO3, "log_prob")
 
 

@@ -685,3 +685,92 @@ def projection_golden():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "projection":
     projection_golden()
+
+
+def prevstep_golden(B=64):
+    """The rotation-matrix head and the "prevstep" loss (so3_train.py:19-22,47-48, util.py:67-76, diffusion.py:358-365):
+    six2rmat / log_rmat / rmat_dist values with the reference's AUTOGRAD gradients, and one prevstep training step of the
+    reference for the 65-wide and the 255-wide RotPredict(out_type="rotmat") (recorded draws, loss, parameter gradients)."""
+    _install_stubs()
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import util as rutil
+    import diffusion as rdiff
+    import so3_train as rtrain
+    import so3_lock_train as rlock
+    out = {}
+    g = torch.Generator().manual_seed(91)
+    # ---- six2rmat
+    x6 = torch.randn(B, 6, generator=g, requires_grad=True)
+    G = torch.randn(B, 3, 3, generator=g)
+    R6 = rutil.six2rmat(x6)
+    (gx6,) = torch.autograd.grad((R6 * G).sum(), x6)
+    out.update(six_x=npy(x6), six_G=npy(G), six_R=npy(R6), six_grad=npy(gx6))
+    # ---- log_rmat (matrix output) and rmat_dist, generic rotations plus small-angle and near-pi cases
+    q = torch.randn(B, 4, generator=g)
+    R = rutil.quat_to_rmat(q)
+    ang = torch.cat([torch.full((8,), 1e-3), torch.full((8,), 3.0), torch.rand(B - 16, generator=g) * 3.0])
+    ax = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    Rb = R @ rutil.aa_to_rmat(ax, ang[:, None])          # b = a . exp(angle axis): dist = sqrt(2) angle
+    Ra = R.clone().requires_grad_(True)
+    Rbg = Rb.clone().requires_grad_(True)
+    L = rutil.log_rmat(Ra)
+    (gL,) = torch.autograd.grad((L * G).sum(), Ra)
+    out.update(log_R=npy(R), log_G=npy(G), log_out=npy(L), log_grad=npy(gL))
+    Ra2 = R.clone().requires_grad_(True)
+    d = rutil.rmat_dist(Ra2, Rbg)
+    gd = torch.randn(B, generator=g)
+    ga, gb = torch.autograd.grad((d * gd).sum(), [Ra2, Rbg])
+    out.update(dist_a=npy(R), dist_b=npy(Rb), dist_g=npy(gd), dist=npy(d), dist_grad_a=npy(ga), dist_grad_b=npy(gb))
+    # ---- one prevstep training step, both networks
+    for name, mod, seed in (("mlp", rtrain, 5), ("resnet", rlock, 6)):
+        torch.manual_seed(seed)
+        net = mod.RotPredict(out_type="rotmat")
+        sd = net.state_dict()
+        out[name + "_params"] = np.concatenate([npy(v).reshape(-1) for v in sd.values()])
+        out[name + "_param_names"] = np.array(list(sd.keys()))
+        for T in (100,):
+            torch.manual_seed(200 + seed)
+            x0 = rutil.quat_to_rmat(torch.randn(B, 4))
+            proc = rdiff.SO3Diffusion(net, timesteps=T, loss_type="prevstep")
+            cap = {}
+            orig_q, orig_post = proc.q_sample, proc.q_posterior
+
+            def q_spy(x_start, t, noise=None, _o=orig_q, _c=cap):
+                _c["noise"] = noise.detach().clone()
+                r = _o(x_start=x_start, t=t, noise=noise)
+                _c["x_t"] = r.detach().clone()
+                return r
+
+            def post_spy(x_start, x_t, t, _o=orig_post, _c=cap):
+                r = _o(x_start, x_t, t)
+                _c["post_mean"] = r[0].detach().clone()
+                return r
+
+            proc.q_sample, proc.q_posterior = q_spy, post_spy
+            with RNGRecorder() as rec:
+                loss = proc(x0)
+            grads = torch.autograd.grad(loss, list(net.parameters()))
+            assert [n for n, _ in rec.log] == ["randint", "randn", "rand"]
+            t = rec.log[0][1]
+            pre = f"{name}_T{T}_"
+            raw = net.net(torch.cat((torch.flatten(cap["x_t"], start_dim=-2), net.time_embedding(t)), dim=-1))
+            out[pre + "x0"] = npy(x0)
+            out[pre + "t"] = npy(t)
+            out[pre + "axes"] = npy(rec.log[1][1])
+            out[pre + "unif"] = npy(rec.log[2][1])
+            out[pre + "x_t"] = npy(cap["x_t"])
+            out[pre + "post_mean"] = npy(cap["post_mean"])
+            out[pre + "step"] = npy(cap["x_t"].transpose(-1, -2) @ cap["post_mean"])
+            out[pre + "out6"] = npy(raw)
+            out[pre + "x_recon"] = npy(net(cap["x_t"], t))
+            out[pre + "loss"] = npy(loss)
+            out[pre + "grad"] = np.concatenate([npy(g_).reshape(-1) for g_ in grads])
+    np.savez(os.path.join(OUT, "prevstep.npz"), **out)
+    print({k: (v if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "prevstep":
+    prevstep_golden()
