@@ -12,6 +12,8 @@ from so3x import backend as B
 from so3x.so3_train import RotPredict
 from so3x.diffusion import SO3Diffusion
 
+if os.environ.get("SO3X_LIB"):  # A/B: an alternative build of the same ABI
+    B.LIB_PATH = os.path.abspath(os.environ["SO3X_LIB"])
 dev = "cuda:0"
 
 
