@@ -9,7 +9,7 @@ import torch
 from . import backend as _b
 from . import rng as _rng
 
-__all__ = ["IsotropicGaussianSO3"]
+__all__ = ["IsotropicGaussianSO3", "Bingham"]
 
 
 class IsotropicGaussianSO3:
@@ -66,3 +66,16 @@ class IsotropicGaussianSO3:
         (reference distributions.py:189-190)."""
         logp, score, grad = _b.igso3_logprob_score(rotations, self.eps, want_score=not dense_grad, want_grad=dense_grad)
         return logp, (grad if dense_grad else score)
+
+
+class Bingham(torch.distributions.MultivariateNormal):
+    """Antipodally symmetric distribution on unit quaternions: a zero-mean Gaussian 4-vector, normalised
+    (reference distributions.py:113-127).  It is the DATA source of bingham_train / bingham_test (samples go through
+    quat_to_rmat), not part of the diffusion hot path: plain torch on whatever device `loc` lives on."""
+
+    def __init__(self, loc, covariance_matrix=None, precision_matrix=None, scale_tril=None, validate_args=None):
+        super().__init__(torch.zeros_like(loc), covariance_matrix, precision_matrix, scale_tril, validate_args)  # location is always 0
+
+    def rsample(self, sample_shape=torch.Size()):
+        vals = super().rsample(sample_shape)
+        return vals / vals.norm(dim=-1, keepdim=True)
