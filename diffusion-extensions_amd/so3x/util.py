@@ -9,7 +9,7 @@ import torch
 from . import backend as _b
 
 __all__ = ["skew2vec", "vec2skew", "orthogonalise", "rmat2six", "six2rmat", "log_rmat", "aa_to_rmat", "rmat_to_aa", "quat_to_rmat",
-           "rmat_dist", "so3_lerp", "so3_scale", "euler_to_rmat", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
+           "rmat_dist", "so3_lerp", "so3_scale", "rmat_to_euler", "euler_to_rmat", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
            "MMD", "Ker_2samp_test", "Ker_2samp_log_prob"]
 
 
@@ -85,6 +85,14 @@ def so3_lerp(rot_a: torch.Tensor, rot_b: torch.Tensor, weight: torch.Tensor) -> 
 def so3_scale(rmat: torch.Tensor, scalars: torch.Tensor) -> torch.Tensor:
     """exp(scalars * log(rmat)) (reference util.py:349-361); scalars has 1 or batch elements."""
     return _b.so3_scale(rmat, scalars)
+
+
+def rmat_to_euler(rmat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(x, y, z) Euler angles of a rotation, the reference's plotting decomposition (util.py:388-393: y from
+    atan2(R20, sqrt(R00^2 + R10^2)), i.e. its own sign convention for R_y).  Analysis helper: plain tensor ops."""
+    sy = torch.sqrt(rmat[..., 0, 0] * rmat[..., 0, 0] + rmat[..., 1, 0] * rmat[..., 1, 0])
+    return (torch.atan2(rmat[..., 2, 1], rmat[..., 2, 2]), torch.atan2(rmat[..., 2, 0], sy),
+            torch.atan2(rmat[..., 1, 0], rmat[..., 0, 0]))
 
 
 def euler_to_rmat(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor) -> torch.Tensor:

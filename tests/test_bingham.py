@@ -85,3 +85,51 @@ def test_bingham_train_then_evaluate_pipeline(tmp_path):
     untrained = bingham_test.calc_step("sur", cov, 0, **kw)
     assert np.isfinite(trained) and np.isfinite(untrained)
     assert trained < 0.25 * untrained
+
+
+# ----------------------------------------------------------------------------- the sampling scripts (so3_test.py, so3_lock_test.py)
+def test_rmat_to_euler_inverts_euler_to_rmat():
+    from so3x import util
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(200, generator=g) - 0.5) * 6.0
+    y = (torch.rand(200, generator=g) - 0.5) * 3.0          # |y| < pi/2: the decomposition's principal range
+    z = (torch.rand(200, generator=g) - 0.5) * 6.0
+    xr, yr, zr = util.rmat_to_euler(util.euler_to_rmat(x, y, z))
+    for a, b in ((x, xr), (y, yr), (z, zr)):
+        assert float((a - b).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wide", [False, True])
+def test_sampling_script_trajectory(tmp_path, wide):
+    """so3_test.py / so3_lock_test.py: weights file -> external per-step loop with the whole trajectory kept"""
+    import so3x
+    from so3x import so3_test, so3_lock_test, util
+    from so3x.diffusion import SO3Diffusion
+    if wide:
+        from so3x.so3_lock_train import RotPredict
+    else:
+        from so3x.so3_train import RotPredict
+    torch.manual_seed(1)
+    net = RotPredict(out_type="skewvec")
+    wpath = str(tmp_path / "w.pt")
+    torch.save(net.state_dict(), wpath)
+    proc = SO3Diffusion(net.to(DEV), timesteps=50).to(DEV)
+    R0 = util.quat_to_rmat(torch.randn(96, 4, device=DEV))
+    so3x.manual_seed(11)
+    res, final = so3_test.sample_trajectory(proc, R0)
+    assert res.shape == (50, 96, 3, 3) and torch.equal(res[49], R0)
+    eye = torch.eye(3, device=DEV)
+    assert float((res @ res.transpose(-1, -2) - eye).abs().max()) < 2e-5 and torch.isfinite(final).all()
+    so3x.manual_seed(11)                                    # same seed, same launch sequence: identical trajectory
+    res2, final2 = so3_test.sample_trajectory(proc, R0)
+    assert torch.equal(res, res2) and torch.equal(final, final2)
+    d = so3_test.mode_distance(res)
+    assert d.shape == (50, 96) and float(d.min()) >= 0 and float(d.max()) <= np.pi + 1e-4
+    z90 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]], device=DEV)
+    both = torch.stack([z90, z90.T])[None].repeat(3, 1, 1, 1)
+    assert float(so3_test.mode_distance(both).abs().max()) < 1e-3   # the two modes themselves are at distance 0
+    main = so3_lock_test.main if wide else so3_test.main
+    out = str(tmp_path / "traj.pt")
+    s = main(["--weights", wpath, "--timesteps", "20", "--batch", "40", "--out", out])
+    assert s["timesteps"] == 20 and torch.load(out)["trajectory"].shape == (20, 40, 3, 3)
