@@ -19,7 +19,7 @@ from . import rng as _rng
 from .distributions import IsotropicGaussianSO3
 from .so3_train import RotPredict
 
-__all__ = ["SO3Diffusion", "ProjectedSO3Diffusion", "cosine_beta_schedule", "extract"]
+__all__ = ["SO3Diffusion", "ProjectedSO3Diffusion", "cosine_beta_schedule", "extract", "noise_like"]
 
 _SCHED_NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
                 "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
@@ -40,6 +40,13 @@ def extract(a, t, x_shape):
     """a[t] reshaped to broadcast against x_shape (the lucidrains helper)."""
     b = t.shape[0]
     return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def noise_like(shape, device, repeat=False):
+    """Gaussian noise of a shape, optionally one draw repeated along the batch (reference diffusion.py:19-22)"""
+    if repeat:
+        return torch.randn((1, *shape[1:]), device=device).repeat(shape[0], *((1,) * (len(shape) - 1)))
+    return torch.randn(shape, device=device)
 
 
 class SO3Diffusion(nn.Module):

@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-__all__ = ["SinusoidalPosEmb", "ResLayer", "PointCloudProj"]
+__all__ = ["SinusoidalPosEmb", "Siren", "ResLayer", "PointCloudProj"]
 
 
 class SinusoidalPosEmb(nn.Module):
@@ -19,6 +19,26 @@ class SinusoidalPosEmb(nn.Module):
         freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
         ang = x[:, None] * freqs[None, :]
         return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+class Siren(nn.Module):
+    """Sine-activated positional encoding layer (reference models.py:37-72; imported by so3_train.py:6 and unused on the
+    SO(3) path): sin(Linear(x)) with the SIREN initialisation, optionally followed by a Linear.  Plain torch."""
+
+    def __init__(self, in_channels, out_channels, scale=1, optimize=True, post_scale=True):
+        super().__init__()
+        self.positional = nn.Linear(in_features=in_channels, out_features=out_channels)
+        bound = (6 / in_channels) ** 0.5
+        nn.init.uniform_(self.positional.weight, -bound, bound)
+        self.positional.weight.data *= scale
+        nn.init.uniform_(self.positional.bias, -3.14159, 3.14159)  # biases cover +-pi
+        self.post_scale = nn.Linear(out_channels, out_channels) if post_scale else None
+        for param in self.parameters():
+            param.requires_grad = optimize
+
+    def forward(self, x):
+        res = torch.sin(self.positional(x))
+        return self.post_scale(res) if self.post_scale is not None else res
 
 
 class ResLayer(nn.Module):

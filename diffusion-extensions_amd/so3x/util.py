@@ -9,7 +9,7 @@ import torch
 from . import backend as _b
 
 __all__ = ["skew2vec", "vec2skew", "orthogonalise", "rmat2six", "six2rmat", "log_rmat", "aa_to_rmat", "rmat_to_aa", "quat_to_rmat",
-           "rmat_dist", "so3_lerp", "so3_scale", "rmat_to_euler", "euler_to_rmat", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
+           "rmat_dist", "so3_lerp", "so3_bezier", "so3_scale", "rmat_to_euler", "euler_to_rmat", "to_device", "init_from_dict", "identity", "masked_mean", "cycle", "rmat_cosine_dist", "rmat_gaussian_kernel", "rmat_cosine_kernel",
            "MMD", "Ker_2samp_test", "Ker_2samp_log_prob"]
 
 
@@ -105,6 +105,55 @@ def euler_to_rmat(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor) -> torch.Te
     Ry = torch.stack((cy, zero, -sy, zero, one, zero, sy, zero, cy), -1).reshape(*cy.shape, 3, 3)
     Rz = torch.stack((cz, -sz, zero, sz, cz, zero, zero, zero, one), -1).reshape(*cz.shape, 3, 3)
     return Rz @ Ry @ Rx
+
+
+def so3_bezier(*rots: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """De Casteljau curve through rotations by repeated geodesic interpolation (reference util.py:340-346, whose recursion
+    passes the tuples un-splatted and cannot run; this is the evidently intended recursion)."""
+    if len(rots) < 2:
+        raise ValueError("so3_bezier needs at least two rotations")
+    if len(rots) == 2:
+        return so3_lerp(rots[0], rots[1], weight)
+    return so3_lerp(so3_bezier(*rots[:-1], weight=weight), so3_bezier(*rots[1:], weight=weight), weight)
+
+
+def to_device(device, *objects, non_blocking=False):
+    """Move tensors, and (nested) iterables of tensors, to a device (reference util.py:426-437, minus its protein record type)."""
+    moved = []
+    for obj in objects:
+        if isinstance(obj, torch.Tensor):
+            moved.append(obj.to(device, non_blocking=non_blocking))
+        elif isinstance(obj, (list, tuple)) or hasattr(obj, "__iter__"):
+            moved.append(to_device(device, *obj, non_blocking=non_blocking))
+        else:
+            raise RuntimeError(f"Cannot move object of type {type(obj)} to {device}")
+    return moved
+
+
+def init_from_dict(argdict, *classes):
+    """Construct each class from the entries of one dict that its signature names; other entries are ignored
+    (reference util.py:440-460)."""
+    import inspect
+    objs = []
+    for cls in classes:
+        names = [k for k, v in inspect.signature(cls).parameters.items() if v.kind == inspect.Parameter.POSITIONAL_OR_KEYWORD]
+        objs.append(cls(**{k: v for k, v in argdict.items() if k in names}))
+    return objs
+
+
+def identity(x):
+    return x
+
+
+def masked_mean(tensor: torch.Tensor, mask: torch.Tensor, dim=-1) -> torch.Tensor:
+    """Mean over `dim` of the entries selected by a boolean mask, 0 where nothing is selected; zeroes the masked-out
+    entries of `tensor` IN PLACE, as the reference does (util.py:467-475)."""
+    mask = mask[(..., *((None,) * (tensor.dim() - mask.dim())))]
+    tensor.masked_fill_(~mask, 0.0)
+    count = mask.sum(dim=dim)
+    mean = tensor.sum(dim=dim) / count.clamp(min=1.0)
+    mean.masked_fill_(count == 0, 0.0)
+    return mean
 
 
 def cycle(iterable):

@@ -719,3 +719,25 @@ def test_training_step_as_a_captured_graph(mods, golden):
     # offset bookkeeping differs from the eager one, so compare statistically: same loss scale, parameters moved alike
     assert abs(np.mean(lg) - np.mean(le)) < 0.5 * max(np.mean(le), 1e-3)
     assert float((pg - pe).abs().max()) < 2e-2
+
+
+@pytest.mark.gpu
+def test_so3_bezier_de_casteljau(mods):
+    """util.so3_bezier (reference util.py:340-346): two control points = so3_lerp; end points are interpolated; control
+    points on one geodesic give the point of the same geodesic"""
+    from so3x import util
+    n = 500
+    g = torch.Generator(device=DEV).manual_seed(9)
+    a, b, c = (util.quat_to_rmat(torch.randn(n, 4, device=DEV, generator=g)) for _ in range(3))
+    w = torch.rand(n, 1, device=DEV, generator=g)
+    assert torch.equal(util.so3_bezier(a, b, weight=w), util.so3_lerp(a, b, w))
+    zero, one = torch.zeros(n, 1, device=DEV), torch.ones(n, 1, device=DEV)
+    assert float((util.so3_bezier(a, b, c, weight=zero) - a).abs().max()) < 2e-5
+    assert float((util.so3_bezier(a, b, c, weight=one) - c).abs().max()) < 1e-3   # a exp(log(a^T c)): 1e-7 / (pi - angle) conditioning
+    mid = util.so3_lerp(a, c, torch.full((n, 1), 0.5, device=DEV))        # a, mid, c on one geodesic
+    out = util.so3_bezier(a, mid, c, weight=w)
+    # (1-w)^2 * 0 + 2 w (1-w) * 1/2 + w^2 * 1 = w along that geodesic
+    # (a^T c has an angle < pi almost surely, so the geodesic and its midpoint are unique)
+    assert float((out - util.so3_lerp(a, c, w)).abs().max()) < 2e-3 and float((out - util.so3_lerp(a, c, w)).abs().median()) < 1e-6
+    with pytest.raises(ValueError):
+        util.so3_bezier(a, weight=w)

@@ -196,3 +196,24 @@ def test_flat_name_shims_resolve_like_the_reference_layout(tmp_path):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(PKG, "compat"), PKG]))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=180)
     assert r.returncode == 0 and "OK 10" in r.stdout, r.stderr
+
+
+def test_small_helpers_of_the_reference_namespace():
+    """util.{identity, masked_mean, init_from_dict, to_device}, diffusion.noise_like, models.Siren (reference util.py:426-475,
+    diffusion.py:19-22, models.py:37-72): host-side helpers, plain torch"""
+    from so3x import util, models
+    from so3x.diffusion import noise_like
+    assert util.identity(3) == 3
+    x = torch.arange(12.).reshape(3, 4)
+    m = torch.tensor([[True, True, False, False], [False] * 4, [True] * 4])
+    assert torch.equal(util.masked_mean(x.clone(), m), torch.tensor([0.5, 0.0, 9.5]))
+    lin, act = util.init_from_dict({"in_features": 4, "out_features": 2, "negative_slope": 0.3, "unused": 1},
+                                   torch.nn.Linear, torch.nn.LeakyReLU)
+    assert lin.weight.shape == (2, 4) and act.negative_slope == 0.3
+    a, (b, c) = util.to_device("cpu", torch.ones(2), (torch.zeros(1), torch.zeros(3)))
+    assert a.shape == (2,) and b.shape == (1,) and c.shape == (3,)
+    n = noise_like((5, 3, 3), "cpu", repeat=True)
+    assert n.shape == (5, 3, 3) and torch.equal(n[0], n[4]) and not torch.equal(noise_like((5, 3), "cpu")[0], noise_like((5, 3), "cpu")[1])
+    s = models.Siren(3, 8, scale=30)
+    assert s(torch.randn(7, 3)).shape == (7, 8) and float(s.positional.weight.abs().max()) <= 30 * (6 / 3) ** 0.5 + 1e-6
+    assert all(not p.requires_grad for p in models.Siren(3, 8, optimize=False, post_scale=False).parameters())
