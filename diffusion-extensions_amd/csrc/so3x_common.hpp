@@ -17,6 +17,48 @@ inline int check_launch() {
   return e == hipSuccess ? SO3X_OK : (int)e;
 }
 
+// Launch facts that have to be established once PER DEVICE (hipFuncSetAttribute and occupancy are per device, and one
+// process may drive several GPUs): a static table at each use site, indexed by the current device's ordinal.
+// Host-only HIP calls (no sync, legal outside and -- after the first call -- never made during stream capture).
+struct PerDevice { int v[64]; };
+inline int per_device_slot(PerDevice& st, int** slot) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  *slot = &st.v[dev & 63];
+  return SO3X_OK;
+}
+// raise the dynamic-LDS cap of `kernel` on the current device (once)
+inline int ensure_dyn_lds(PerDevice& st, const void* kernel, int bytes) {
+  int* slot;
+  int rc = per_device_slot(st, &slot);
+  if (rc) return rc;
+  if (__atomic_load_n(slot, __ATOMIC_ACQUIRE)) return SO3X_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_store_n(slot, 1, __ATOMIC_RELEASE);
+  return SO3X_OK;
+}
+// ... and the number of workgroups of `kernel` the current device keeps resident (occupancy x CUs), for persistent grids
+inline int resident_blocks(PerDevice& st, const void* kernel, int threads, int lds_bytes, int* cap) {
+  int* slot;
+  int rc = per_device_slot(st, &slot);
+  if (rc) return rc;
+  int c = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+  if (!c) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    int per_cu = 0, dev = 0, cus = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes)) != hipSuccess) return (int)e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+    c = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    __atomic_store_n(slot, c, __ATOMIC_RELEASE);
+  }
+  *cap = c;
+  return SO3X_OK;
+}
+
 // The reference's tensors are AoS [n][W] fp32 (W = 9 rotations, 3 vectors, 4 quats):
 // a lane-per-sample access would be a 36-B-strided gather.  Instead the block moves
 // the tile's W*256 contiguous floats with 16-B-per-lane coalesced loads into LDS and

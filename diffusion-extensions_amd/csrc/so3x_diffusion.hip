@@ -166,18 +166,9 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
                  const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                  uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
   constexpr int IMG = image_bytes<PREC, CHAIN>();
-  static int max_blocks = 0;  // resident blocks on this device (occupancy x CUs), queried once; host-only calls, no sync
-  if (!max_blocks) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p_sample_chain<PREC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
-    if (e != hipSuccess) return (int)e;
-    int per_cu = 0, dev = 0, cus = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_p_sample_chain<PREC>), 256, IMG);
-    if (e != hipSuccess) return (int)e;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-    max_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
-  }
+  static PerDevice resident;  // resident blocks per device (occupancy x CUs), queried once each
+  int max_blocks = 0;
+  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC>), 256, IMG, &max_blocks)) return rc;
   const int64_t nchunks = (n + 63) / 64;
   const int64_t want = (nchunks + 3) / 4;
   const int grid = (int)(want < max_blocks ? want : max_blocks);

@@ -135,13 +135,8 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
 template <int PREC, int VAR>
 int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n, int nout) {
   constexpr int IMG = image_bytes<PREC, VAR>();
-  static int attr_set = 0;  // idempotent: raising the dynamic-LDS cap of this kernel
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<PREC, VAR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
-    if (e != hipSuccess) return (int)e;
-    attr_set = 1;
-  }
+  static PerDevice attr;
+  if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd<PREC, VAR>), IMG)) return rc;
   const int64_t ntiles = (n + 31) / 32;
   const int64_t want = (ntiles + 3) / 4;
   const int max_blocks = IMG > 80 * 1024 ? 256 : 512;  // LDS-limited residency: 1 or 2 blocks per CU

@@ -897,17 +897,10 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   constexpr int DW_LDS = PREC == SO3X_PREC_F32 ? STASH_ROWS * LROW * (int)sizeof(float) : STASH_ROWS * LROW16 * 2;
   constexpr int STAGE_LDS = stage_lds_bytes<PREC, VAR>();
   const BwdLayout L = bwd_layout<PREC>(n, t_table);
-  static int attr_set = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_stage<PREC, VAR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_LDS);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(PREC == SO3X_PREC_F32 ? reinterpret_cast<const void*>(&k_bwd_dw)
-                                                  : reinterpret_cast<const void*>(&k_bwd_dw_bf16),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = 1;
-  }
+  static PerDevice attr_stage, attr_dw;
+  if (int rc = ensure_dyn_lds(attr_stage, reinterpret_cast<const void*>(&k_bwd_stage<PREC, VAR>), STAGE_LDS)) return rc;
+  if (int rc = ensure_dyn_lds(attr_dw, PREC == SO3X_PREC_F32 ? reinterpret_cast<const void*>(&k_bwd_dw)
+                                                             : reinterpret_cast<const void*>(&k_bwd_dw_bf16), DW_LDS)) return rc;
   int rc = launch_prep(s, params, PREC, VAR, t_table, ws, nout);
   if (rc) return rc;
   hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + L.wt), nout);
@@ -919,16 +912,9 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER) {
     // fused path: no dZ/H stash, one launch for the whole batch
     constexpr int FUSED_LDS = image_bytes<PREC, VAR>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
-    static int fattr = 0;
-    if (!fattr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_fused<PREC, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-      if (e != hipSuccess) return (int)e;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_fused<PREC, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-      if (e != hipSuccess) return (int)e;
-      fattr = 1;
-    }
+    static PerDevice attr_f0, attr_f1;
+    if (int rc2 = ensure_dyn_lds(attr_f0, reinterpret_cast<const void*>(&k_bwd_fused<PREC, false>), FUSED_LDS)) return rc2;
+    if (int rc2 = ensure_dyn_lds(attr_f1, reinterpret_cast<const void*>(&k_bwd_fused<PREC, true>), FUSED_LDS)) return rc2;
     const int64_t nt = (n + 31) / 32;
     const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
     if (zstash)
@@ -981,13 +967,8 @@ int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, con
   char* ws = (char*)workspace;
   int rc = launch_prep((hipStream_t)s, params, PREC, GATHER, t_table, ws, n_out);
   if (rc) return rc;
-  static int attr = 0;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, IMG);
-    if (e != hipSuccess) return (int)e;
-    attr = 1;
-  }
+  static PerDevice attr;
+  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC>), IMG))) return rc;
   const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
   hipLaunchKernelGGL((k_mlp_fwd_stash<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, (hipStream_t)s, (const void*)ws,
                      reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out);

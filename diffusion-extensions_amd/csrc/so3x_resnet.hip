@@ -864,22 +864,16 @@ template <int PREC> int prep(hipStream_t s, const float* params, int T, void* ws
   return check_launch();
 }
 
-template <typename K> int grid_cap(K kernel, int threads, int lds, int* cap) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return (int)e;
-  int per_cu = 0, dev = 0, cus = 0;
-  if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), threads, lds)) != hipSuccess) return (int)e;
-  if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-  if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
-  *cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
-  return SO3X_OK;
+template <typename K> int grid_cap(PerDevice& st, K kernel, int threads, int lds, int* cap) {
+  return resident_blocks(st, reinterpret_cast<const void*>(kernel), threads, lds, cap);
 }
 
 template <int PREC>
 int launch_fwd(hipStream_t s, const void* ws, int T, const float* R, const int64_t* t, int64_t t_stride, float* out, int64_t n, int nout) {
   constexpr int LDS = lds_bytes<PREC, false>(), THREADS = 64 * n_waves<PREC>();
-  static int cap = 0;  // resident workgroups on this device, queried once (idempotent)
-  if (!cap) { int rc = grid_cap(&k_resnet_fwd<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
+  static PerDevice caps;  // resident workgroups per device, queried once each
+  int cap = 0;
+  if (int rc = grid_cap(caps, &k_resnet_fwd<PREC>, THREADS, LDS, &cap)) return rc;
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_fwd<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, T, R, t,
@@ -893,8 +887,9 @@ int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const
                  int t_start, int n_steps, const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
                  int64_t index_base, int64_t n) {
   constexpr int LDS = lds_bytes<PREC, false>(), THREADS = 64 * n_waves<PREC>();
-  static int cap = 0;
-  if (!cap) { int rc = grid_cap(&k_resnet_chain<PREC>, THREADS, LDS, &cap); if (rc) return rc; }
+  static PerDevice caps;
+  int cap = 0;
+  if (int rc = grid_cap(caps, &k_resnet_chain<PREC>, THREADS, LDS, &cap)) return rc;
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_chain<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, sched, T,
@@ -925,8 +920,9 @@ int launch_fwd_stash(hipStream_t s, char* ws, int T, const float* params, const 
   constexpr int LDS = RING * chunk_bytes<PREC>(), THREADS = 64 * n_waves<PREC>();
   int rc = prep<PREC>(s, params, T, ws, nout);
   if (rc) return rc;
-  static int cap = 0;
-  if (!cap) { rc = grid_cap(&k_resnet_fwd<PREC, true>, THREADS, LDS, &cap); if (rc) return rc; }
+  static PerDevice caps;
+  int cap = 0;
+  if ((rc = grid_cap(caps, &k_resnet_fwd<PREC, true>, THREADS, LDS, &cap))) return rc;
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(ws + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_fwd<PREC, true>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, (const void*)ws, tab,
@@ -983,30 +979,23 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
     constexpr int PREC = SO3X_PREC_BF16, LDS = RING * chunk_bytes<PREC>();
     if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, n_out, ws + L.x, ws + L.y, L.layer_stride))) return rc;
     hipLaunchKernelGGL(k_resnet_image_t, dim3(NTILE_T + 8), dim3(256), 0, s, params, (void*)(ws + L.img_t), n_out);
-    static int cap_b = 0;
-    if (!cap_b) { rc = grid_cap(&k_resnet_bwd, 512, LDS, &cap_b); if (rc) return rc; }
+    static PerDevice caps_b, attr_dw;
+    int cap_b = 0;
+    if ((rc = grid_cap(caps_b, &k_resnet_bwd, 512, LDS, &cap_b))) return rc;
     const int64_t ngroups = (n + 255) / 256;
     hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
                        dout, yd, ws + L.dz, L.layer_stride, n, n_out);
-    static int dwb_attr = 0;
-    if (!dwb_attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resnet_dw), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      if (e != hipSuccess) return (int)e;
-      dwb_attr = 1;
-    }
+    if ((rc = ensure_dyn_lds(attr_dw, reinterpret_cast<const void*>(&k_resnet_dw), 131072))) return rc;
     hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 131072, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
                        partial);
   } else {
     constexpr int PREC = SO3X_PREC_F32, LDS = RING * chunk_bytes<PREC>();
     if (!stash && (rc = launch_fwd_stash<PREC>(s, ws, t_table, params, R, t, t_stride, nullptr, n, n_out, ws + L.x, ws + L.y, L.layer_stride))) return rc;
     hipLaunchKernelGGL(k_resnet_image_t_f32, dim3(NTILE_T), dim3(256), 0, s, params, (void*)(ws + L.img_t));
-    static int cap_b = 0, dw_attr = 0;
-    if (!cap_b) { rc = grid_cap(&k_resnet_bwd_f32, 256, LDS, &cap_b); if (rc) return rc; }
-    if (!dw_attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resnet_dw_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      if (e != hipSuccess) return (int)e;
-      dw_attr = 1;
-    }
+    static PerDevice caps_b, attr_dw;
+    int cap_b = 0;
+    if ((rc = grid_cap(caps_b, &k_resnet_bwd_f32, 256, LDS, &cap_b))) return rc;
+    if ((rc = ensure_dyn_lds(attr_dw, reinterpret_cast<const void*>(&k_resnet_dw_f32), 65536))) return rc;
     const int64_t ngroups = (n + 127) / 128;
     hipLaunchKernelGGL(k_resnet_bwd_f32, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(256), LDS, s, (const void*)(ws + L.img_t),
                        params, dout, yd, ws + L.dz, L.layer_stride, n, n_out);
