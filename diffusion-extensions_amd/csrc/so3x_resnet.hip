@@ -249,12 +249,11 @@ __device__ __forceinline__ void stream_begin(const char* __restrict__ gimg, char
 // ("native" layout [tile][column n][half h][16 bf16], 2 KiB per wave-tile, fully coalesced) for the backward kernels.
 struct StashPtr { char* x; char* y; size_t layer_stride; };  // this wave's 16-KiB blocks of layer 0; +layer_stride per layer
 
-template <bool NT = true> __device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const uint32_t* p8) {
+template <bool NT = false> __device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const uint32_t* p8) {
   u32x4* d = reinterpret_cast<u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 32);
-  // non-temporal: the dumps are written once and read once by a later kernel; as ordinary stores they stream ~50 MB per
-  // pass through each XCD's 4 MB L2 and keep evicting the weight image that every workgroup re-reads (measured: the
-  // training forward 1.11 -> 0.95 ms at 2^19 samples with this hint alone)
-  // (the backward's dZ dumps keep ordinary stores: k_resnet_dw reads them right afterwards)
+  // NT = non-temporal stores.  Measured both ways: they keep the dumps from evicting the L2-resident weight image (training
+  // forward alone 1.11 -> 0.97 ms at 2^19 samples), but the backward kernels that read the dumps next then find nothing
+  // in the memory-side cache and the whole step got SLOWER (2.94 -> 3.2 ms, same box) -- off.
   if constexpr (NT) {
     __builtin_nontemporal_store(u32x4{p8[0], p8[1], p8[2], p8[3]}, d);
     __builtin_nontemporal_store(u32x4{p8[4], p8[5], p8[6], p8[7]}, d + 1);
@@ -268,13 +267,13 @@ __device__ __forceinline__ void stash_tile_f32(char* blk, int to, int lane, cons
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4* d = reinterpret_cast<f32x4*>(blk + to * 4096 + (2 * (lane & 31) + (lane >> 5)) * 64);
 #pragma unroll
-  for (int i = 0; i < 4; i++) __builtin_nontemporal_store(f32x4{v16[4 * i], v16[4 * i + 1], v16[4 * i + 2], v16[4 * i + 3]}, d + i);
+  for (int i = 0; i < 4; i++) d[i] = f32x4{v16[4 * i], v16[4 * i + 1], v16[4 * i + 2], v16[4 * i + 3]};
 }
 __device__ __forceinline__ void load_tile_f32(const char* blk, int to, int lane, float* v16) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const f32x4* s4 = reinterpret_cast<const f32x4*>(blk + to * 4096 + (2 * (lane & 31) + (lane >> 5)) * 64);
 #pragma unroll
-  for (int i = 0; i < 4; i++) { const f32x4 v = __builtin_nontemporal_load(s4 + i); v16[4 * i] = v.x; v16[4 * i + 1] = v.y; v16[4 * i + 2] = v.z; v16[4 * i + 3] = v.w; }
+  for (int i = 0; i < 4; i++) { const f32x4 v = s4[i]; v16[4 * i] = v.x; v16[4 * i + 1] = v.y; v16[4 * i + 2] = v.z; v16[4 * i + 3] = v.w; }
 }
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -532,7 +531,7 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
     }
     {  // dZ of the output layer = dout in tile rows 0..3, 8, 9 (regs 0..5 of the lower half)
       uint32_t p8[8] = {dpk[0], dpk[1], dpk[2], 0, 0, 0, 0, 0};
-      stash_tile<false>(stash_dz + NBLK * layer_stride + blk, 0, lane, p8);
+      stash_tile(stash_dz + NBLK * layer_stride + blk, 0, lane, p8);
     }
 #pragma unroll 1
     for (int l = NBLK - 1; l >= 0; l--) {
@@ -554,7 +553,7 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
           }
           dzop[8 * to + i] = pack2(g2[0], g2[1]);
         }
-        stash_tile<false>(stash_dz + l * layer_stride + blk, to, lane, &dzop[8 * to]);
+        stash_tile(stash_dz + l * layer_stride + blk, to, lane, &dzop[8 * to]);
       }
       // no drain here: vmcnt is in issue order, so the waits for this layer's Y loads have already retired every older DMA,
       // and the only operations still in flight are the last tile's two dZ stores -- the counted waits below absorb them
