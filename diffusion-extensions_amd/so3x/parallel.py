@@ -42,7 +42,10 @@ def init(backend: str = None, device: str = None) -> Ctx:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if dev.type == "cuda" else "gloo"), rank=rank, world_size=world)
+        # SO3X_DIST_BACKEND: override for exercising the multi-rank plumbing where RCCL cannot run (e.g. two ranks sharing the
+        # one GPU of a test box, LOCAL_RANK=0 for both, over gloo)
+        backend = backend or os.environ.get("SO3X_DIST_BACKEND") or ("nccl" if dev.type == "cuda" else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
         owns = True
     return Ctx(rank, world, local, dev, owns)
 
