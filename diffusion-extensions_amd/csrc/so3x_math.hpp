@@ -45,6 +45,13 @@ __device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_a
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// logistic function for the fp32 network paths from the hardware exp2 / rcp (1 ulp each; the -log2(e) x product adds
+// |x| 2^-24 relative error to the exponential: ~1e-6 at |x| = 20, where the sigmoid has long saturated; parity gate G5 is
+// 1e-5).  ocml's expf plus an IEEE division is ~30 instructions per element and made the fp32 network kernels VALU-bound.
+__device__ __forceinline__ float sigmoid_f32(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+
 // atan2(s, c) for s >= 0 (result in [0, pi]): odd minimax polynomial on [0, 1] with exact unit
 // slope at 0 (max abs error 1.1e-7, relative accuracy kept for small angles), octant folding.
 __device__ __forceinline__ float atan2_pos(float s, float c) {

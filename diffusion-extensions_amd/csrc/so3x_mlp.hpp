@@ -144,7 +144,7 @@ __device__ inline float image_value(const float* __restrict__ params, int frag, 
 
 // ---- activations ------------------------------------------------------------------
 template <int PREC> __device__ __forceinline__ float silu(float x) {
-  if (PREC == SO3X_PREC_F32) return x / (1.0f + expf(-x));                 // accurate path (parity gate G5)
+  if (PREC == SO3X_PREC_F32) return x * sigmoid_f32(x);                     // fp32 path (parity gate G5)
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));                      // v_exp_f32 + v_rcp_f32
 }
 

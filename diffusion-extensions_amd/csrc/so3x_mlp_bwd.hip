@@ -68,7 +68,7 @@ struct Z33 { float v[33]; };  // [0..15] tile 0, [16..31] tile 1, [32] = tile 2 
 // silu and its derivative from the pre-activation
 template <int PREC> __device__ __forceinline__ void silu_grad(float z, float* hval, float* dval) {
   float sg;
-  if (PREC == SO3X_PREC_F32) sg = 1.0f / (1.0f + expf(-z));
+  if (PREC == SO3X_PREC_F32) sg = sigmoid_f32(z);
   else sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
   const float hv = z * sg;
   *hval = hv;

@@ -219,7 +219,7 @@ template <int PREC> __device__ __forceinline__ void residual(const f32x16& acc, 
       xf[16 * TO + r] = fmaf(y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)), 1.0f / kFoldS, xf[16 * TO + r]);
     } else {
       const float z = acc[r];
-      xf[16 * TO + r] += z / (1.0f + expf(-z));  // accurate path (parity gate G5)
+      xf[16 * TO + r] = fmaf(z, sigmoid_f32(z), xf[16 * TO + r]);  // fp32 path (parity gate G5)
     }
   }
 }
@@ -687,7 +687,7 @@ k_resnet_bwd_f32(const void* __restrict__ gimg_t, const float* __restrict__ para
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const float z = z16[i];
-          const float sg = 1.0f / (1.0f + expf(-z));
+          const float sg = sigmoid_f32(z);
           dz[16 * to + i] = dx[to][i] * (sg * (1.0f + z * (1.0f - sg)));
         }
         stash_tile_f32(stash_dz + l * layer_stride + blk, to, lane, &dz[16 * to]);
