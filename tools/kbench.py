@@ -48,6 +48,23 @@ def main():
         print(json.dumps({"k": "so3_scale", "n": n, "ms": ms, "GBs": 76 * n / ms / 1e6}))
         ms = timeit(lambda: B.quat_to_rmat(torch.empty(0, 4, device=dev)) if False else B.log_rmat_vec(R))
         print(json.dumps({"k": "log_rmat_vec", "n": n, "ms": ms, "GBs": 48 * n / ms / 1e6}))
+    if "rotgrad" in which:
+        n = 1 << 22
+        x6 = torch.randn(n, 6, device=dev, generator=g)
+        G = torch.randn(n, 3, 3, device=dev, generator=g)
+        R = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        R2 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        R3 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        t = torch.randint(0, 1000, (n,), device=dev)
+        sched = torch.from_numpy(B.schedule_from_betas(B.cosine_beta_schedule(1000))).to(dev)
+        gd = torch.randn(n, device=dev, generator=g)
+        for name, fn, nbytes in (("six2rmat", lambda: B.six2rmat(x6), 24 + 36),
+                                 ("six2rmat_bwd", lambda: B._Six2Rmat.backward(type("c", (), {"saved_tensors": (x6,)})(), G), 24 + 36 + 24),
+                                 ("log_rmat_bwd", lambda: B.log_rmat_bwd(R, G), 36 * 3),
+                                 ("rmat_dist_bwd", lambda: B.rmat_dist_bwd(R, R2, gd), 36 * 4 + 4),
+                                 ("prevstep_loss+grad", lambda: B.prevstep_loss(sched, R, R2, R3, t), 36 * 4 + 8)):
+            ms = timeit(fn)
+            print(json.dumps({"k": name, "n": n, "ms": ms, "GBs": nbytes * n / ms / 1e6, "frac8T": nbytes * n / ms / 1e6 / 8000}))
     if "se3" in which:
         from so3x.se3 import SE3Diffusion, AffineGrad
         S, L = 4096, 256
