@@ -22,6 +22,7 @@ class IsotropicGaussianSO3:
         # column 0 of the table for every sample; reproduced by default, quirk_col0=False fixes it.
         self.quirk_col0 = quirk_col0
         self.trap = _b.igso3_build_tables(eps.reshape(-1))  # [numel(eps), 999]; reference keeps [999, *eps.shape]
+        self._guide = None  # search guide of the rows (bit-identical angles, 2-3 probes instead of 10), built on first sample()
 
     @property
     def mean(self):
@@ -42,7 +43,9 @@ class IsotropicGaussianSO3:
         if batched:
             row_idx = torch.arange(n_eps, device=self.eps.device).repeat(n_rep) if n_rep > 1 else \
                 torch.arange(n_eps, device=self.eps.device)
-        out, _, _ = _b.igso3_sample(self.trap, n, row_idx=row_idx, row_const=0,
+        if self._guide is None:
+            self._guide = _b.igso3_build_guide(self.trap)
+        out, _, _ = _b.igso3_sample(self.trap, n, row_idx=row_idx, row_const=0, guide=self._guide,
                                     quirk_col0=bool(batched and self.quirk_col0), axes=axes, unif=unif,
                                     seed=_rng.seed(), rng_offset=_rng.next_offset() if axes is None else 0,
                                     index_base=index_base, mean=self._mean)

@@ -48,6 +48,21 @@ def main():
         print(json.dumps({"k": "so3_scale", "n": n, "ms": ms, "GBs": 76 * n / ms / 1e6}))
         ms = timeit(lambda: B.quat_to_rmat(torch.empty(0, 4, device=dev)) if False else B.log_rmat_vec(R))
         print(json.dumps({"k": "log_rmat_vec", "n": n, "ms": ms, "GBs": 48 * n / ms / 1e6}))
+    if "igsample" in which:
+        from so3x.distributions import IsotropicGaussianSO3
+        for lg in (20, 22):
+            n = 1 << lg
+            d1 = IsotropicGaussianSO3(torch.tensor(0.5, device=dev))                      # one shared CDF row (p_sample's case)
+            ms = timeit(lambda: d1.sample((n,)))
+            print(json.dumps({"k": "igso3_sample_scalar_eps", "n": n, "ms": ms, "samples_per_s": n / ms * 1e3, "GBs": 36 * n / ms / 1e6}))
+        n = 1 << 20
+        sched = torch.from_numpy(B.schedule_from_betas(B.cosine_beta_schedule(1000))).to(dev)
+        trap = B.igso3_build_tables(sched[4])
+        guide = B.igso3_build_guide(trap)
+        t = torch.randint(0, 1000, (n,), device=dev)
+        for gname, gd in (("noguide", None), ("guide", guide)):
+            ms = timeit(lambda: B.igso3_sample(trap, n, row_idx=t, seed=1, guide=gd) if gd is not None else B.igso3_sample(trap, n, row_idx=t, seed=1))
+            print(json.dumps({"k": "igso3_sample_per_sample_eps_" + gname, "n": n, "ms": ms, "samples_per_s": n / ms * 1e3, "GBs": 44 * n / ms / 1e6}))
     if "rotgrad" in which:
         n = 1 << 22
         x6 = torch.randn(n, 6, device=dev, generator=g)
