@@ -157,7 +157,7 @@ class SO3Diffusion(nn.Module):
             return mean
         n = x.numel() // 9
         smp, _, _ = _b.igso3_sample(trap_p, n, row_const=t0, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off + t0,
-                                    index_base=self.index_base)
+                                    index_base=self.index_base, guide=self._guide_p)
         return _b.rmul(mean, smp.reshape(x.shape))
 
     @torch.no_grad()
@@ -241,7 +241,7 @@ class ProjectedSO3Diffusion(SO3Diffusion):
         _, trap_p = self._tables()
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
         smp, _, _ = _b.igso3_sample(trap_p, x.numel() // 9, row_const=t0, axes=axes, unif=unif, seed=_rng.seed(),
-                                    rng_offset=off + t0, index_base=self.index_base)
+                                    rng_offset=off + t0, index_base=self.index_base, guide=self._guide_p)
         return _b.rmul(mean, smp.reshape(x.shape))
 
     @torch.no_grad()
