@@ -29,26 +29,39 @@ size_t beff_offset(int precision, int variant) { return (image_bytes_rt(precisio
 
 namespace {
 
-// ---- prep: flat state_dict parameters -> permuted/padded weight image ----------------
-template <int PREC, int VAR> __global__ void __launch_bounds__(256) k_prep_image(const float* __restrict__ params, void* __restrict__ img, int nout) {
-  constexpr int NF = n_frags<PREC, VAR>();
+// ---- prep (one launch): blocks [0, 32) the permuted/padded weight image, [32, 64) the transposed image of the backward,
+//      [64, 64 + T) the per-timestep rows:  beff[t][o] = b_0[o] + sum_e W_0[o][9+e] * emb_e(t)  (o < 65, other rows 0;
+//      appendix C.3), emb[t][56] and the bf16 input-slot row h0[t][96] (embedding at slots 10..65).
+constexpr int PREP_IMG_BLOCKS = 32, PREP_WT_BLOCKS = 32;
+template <int PREC, int VAR>
+__global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, void* __restrict__ img, void* __restrict__ wt, int nout,
+                                              Freqs fr, int T, float scale, float* __restrict__ beff, float* __restrict__ emb_tab,
+                                              __bf16* __restrict__ h0_tab) {
   constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;  // elements per lane per fragment
-  const int total = NF * 64 * EPL;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
-    const float v = image_value<PREC, VAR>(params, frag, lane, j, nout);
-    if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
-    else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
+  if (blockIdx.x < PREP_IMG_BLOCKS) {
+    if (!img) return;
+    const int total = n_frags<PREC, VAR>() * 64 * EPL;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += PREP_IMG_BLOCKS * 256) {
+      const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
+      const float v = image_value<PREC, VAR>(params, frag, lane, j, nout);
+      if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
+      else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
+    }
+    return;
   }
-}
-
-// ---- prep: per-timestep effective bias of layer 0 (appendix C.3) ---------------------
-//   beff[t][o] = b_0[o] + sum_e W_0[o][9+e] * emb_e(t)   (o < 65), other rows 0.
-__global__ void __launch_bounds__(128) k_prep_beff(const float* __restrict__ params, Freqs fr, int T, float scale,
-                                                    float* __restrict__ beff, float* __restrict__ emb_tab,
-                                                    __bf16* __restrict__ h0_tab) {
+  if (blockIdx.x < PREP_IMG_BLOCKS + PREP_WT_BLOCKS) {
+    if (!wt) return;
+    const int total = wt_nfrags<PREC>() * 64 * EPL;
+    for (int e = (blockIdx.x - PREP_IMG_BLOCKS) * 256 + threadIdx.x; e < total; e += PREP_WT_BLOCKS * 256) {
+      const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
+      const float v = wt_value<PREC>(params, frag, lane, j, nout);
+      if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(wt)[e] = v;
+      else reinterpret_cast<__bf16*>(wt)[e] = (__bf16)v;
+    }
+    return;
+  }
   __shared__ float emb[NEMB];
-  const int t = blockIdx.x;
+  const int t = blockIdx.x - PREP_IMG_BLOCKS - PREP_WT_BLOCKS;
   if (threadIdx.x < NEMB) {
     emb[threadIdx.x] = emb_value((int64_t)t, threadIdx.x, fr);
     if (emb_tab) emb_tab[(size_t)t * NEMB + threadIdx.x] = emb[threadIdx.x];  // [T][56] time-embedding table
@@ -120,15 +133,13 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
   }
 }
 
-template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws, int nout) {
-  hipLaunchKernelGGL((k_prep_image<PREC, VAR>), dim3(32), dim3(256), 0, s, params, ws, nout);
-  if (chain_layout(VAR) && T > 0) {
-    float* beff = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR));
-    float* emb = VAR == GATHER ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
-    __bf16* h0 = VAR == GATHER ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
-    hipLaunchKernelGGL(k_prep_beff, dim3(T), dim3(128), 0, s, params, host_freqs(), T,
-                       fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb, h0);
-  }
+template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws, int nout, void* wt, bool want_image) {
+  const bool tables = chain_layout(VAR) && T > 0;
+  float* beff = tables ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR)) : nullptr;
+  float* emb = (tables && VAR == GATHER) ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
+  __bf16* h0 = (tables && VAR == GATHER) ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
+  hipLaunchKernelGGL((k_prep<PREC, VAR>), dim3(PREP_IMG_BLOCKS + PREP_WT_BLOCKS + (tables ? T : 0)), dim3(256), 0, s, params,
+                     want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb, h0);
   return check_launch();
 }
 
@@ -158,15 +169,16 @@ int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace) 
                      reinterpret_cast<const float*>(ws + beff_offset(SO3X_PREC_BF16, CHAIN)), (void*)(ws + l0t_offset(T)));
   return check_launch();
 }
-int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout) {
+int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout, void* wt,
+                bool want_image) {
   if (precision == SO3X_PREC_F32) {
-    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace, nout);
-    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace, nout);
-    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace, nout);
+    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace, nout, wt, want_image);
+    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace, nout, wt, want_image);
+    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace, nout, wt, want_image);
   }
-  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout);
-  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout);
-  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout);
+  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image);
+  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout, wt, want_image);
+  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout, wt, want_image);
 }
 }  // namespace mlp
 }  // namespace so3x

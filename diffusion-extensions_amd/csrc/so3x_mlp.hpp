@@ -142,6 +142,25 @@ __device__ inline float image_value(const float* __restrict__ params, int frag, 
   return f < D ? wsc * W[o * D + f] : (f == ONE_ROW ? bsc * bias[o] : 0.0f);
 }
 
+// ---- transposed-weight image (A operand of dH = W^T dZ in the backward), global/L2-resident -----------
+// fragment order: layers 1..3: [l-1][To(in-feature tile) 3][ks over out-features KH], then layer 4: [To 3][K4]
+template <int PREC> __host__ __device__ constexpr int k4() { return PREC == SO3X_PREC_F32 ? NOUT_MAX : 1; }  // k-steps covering head slots 0..5
+template <int PREC> __host__ __device__ constexpr int wt_frag(int l, int to, int ks) {
+  return l < 4 ? ((l - 1) * 3 + to) * ks_hidden<PREC>() + ks : 9 * ks_hidden<PREC>() + to * k4<PREC>() + ks;
+}
+template <int PREC> __host__ __device__ constexpr int wt_nfrags() { return 9 * ks_hidden<PREC>() + 3 * k4<PREC>(); }
+template <int PREC> __device__ inline float wt_value(const float* __restrict__ params, int frag, int lane, int j, int nout) {
+  constexpr int KH = ks_hidden<PREC>();
+  const int i = lane & 31, h = lane >> 5;
+  int l, to, ks;
+  if (frag < 9 * KH) { l = 1 + frag / (3 * KH); to = (frag % (3 * KH)) / KH; ks = frag % KH; }
+  else { const int f = frag - 9 * KH; l = 4; to = f / k4<PREC>(); ks = f % k4<PREC>(); }
+  const int in = 32 * to + i;                       // row of W^T = input feature of layer l
+  int out = hidden_feature<PREC>(ks, h, j);         // k index = output feature of layer l (layer 4: its tile row)
+  if (l == 4) out = head_of_row(out);
+  return (in < D && out >= 0 && out < (l < 4 ? D : nout)) ? params[l * LAYER_STRIDE + out * D + in] : 0.0f;
+}
+
 // ---- activations ------------------------------------------------------------------
 template <int PREC> __device__ __forceinline__ float silu(float x) {
   if (PREC == SO3X_PREC_F32) return x * sigmoid_f32(x);                     // fp32 path (parity gate G5)
@@ -417,7 +436,10 @@ __device__ __forceinline__ void load_image(const void* __restrict__ gimg, char* 
 size_t image_bytes_rt(int precision, int variant);
 // writes the weight image at workspace[0 .. image) and, for CHAIN with T > 0, the
 // effective-bias table beff[T][96] right after it (16-B aligned).
-int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout = 3);
+// One launch: [the weight image] [the transposed image -> wt, optional] [the per-timestep tables when T > 0].
+// want_image = false skips the forward image (the backward with a stash never reads it).
+int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout = 3,
+                void* wt = nullptr, bool want_image = true);
 int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace);
 size_t beff_offset(int precision, int variant);
 // tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32

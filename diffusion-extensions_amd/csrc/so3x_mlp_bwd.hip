@@ -35,34 +35,6 @@ constexpr int CHUNK = 1 << 19;  // samples per stash chunk: 596 rows x 2^19 x 4 
 constexpr int DW_BLOCKS = 256;
 constexpr int NPAIRS = 39;                      // 4 layers x 3x3 tiles + last layer 1x3
 
-// ---- transposed-weight image (A operand of dH = W^T dZ), global/L2-resident -----------
-// fragment order: layers 1..3: [l-1][To(in-feature tile) 3][ks over out-features KH], then layer 4: [To 3][K4]
-template <int PREC> __host__ __device__ constexpr int k4() { return PREC == SO3X_PREC_F32 ? NOUT_MAX : 1; }  // k-steps covering head slots 0..5
-template <int PREC> __host__ __device__ constexpr int wt_frag(int l, int to, int ks) {
-  return l < 4 ? ((l - 1) * 3 + to) * ks_hidden<PREC>() + ks : 9 * ks_hidden<PREC>() + to * k4<PREC>() + ks;
-}
-template <int PREC> __host__ __device__ constexpr int wt_nfrags() { return 9 * ks_hidden<PREC>() + 3 * k4<PREC>(); }
-
-template <int PREC> __global__ void __launch_bounds__(256) k_prep_wt(const float* __restrict__ params, void* __restrict__ img, int nout) {
-  constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;
-  constexpr int KH = ks_hidden<PREC>();
-  const int total = wt_nfrags<PREC>() * 64 * EPL;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
-    const int i = lane & 31, h = lane >> 5;
-    int l, to, ks;
-    if (frag < 9 * KH) { l = 1 + frag / (3 * KH); to = (frag % (3 * KH)) / KH; ks = frag % KH; }
-    else { const int f = frag - 9 * KH; l = 4; to = f / k4<PREC>(); ks = f % k4<PREC>(); }
-    const int in = 32 * to + i;                       // row of W^T = input feature of layer l
-    int out = hidden_feature<PREC>(ks, h, j);         // k index = output feature of layer l (layer 4: its tile row)
-    if (l == 4) out = head_of_row(out);
-    float v = 0.0f;
-    if (in < D && out >= 0 && out < (l < 4 ? D : nout)) v = params[l * LAYER_STRIDE + out * D + in];
-    if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
-    else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
-  }
-}
-
 struct Z33 { float v[33]; };  // [0..15] tile 0, [16..31] tile 1, [32] = tile 2 reg 0 (feature 64 in the lower half)
 
 // silu and its derivative from the pre-activation
@@ -775,7 +747,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
   constexpr int WTB = wt_bytes<PREC>();
   char* wt_lds = lds + IMG;
   char* fimg_all = lds + IMG + WTB;
-  load_image(gimg, lds, IMG);
+  if constexpr (!STASHED) load_image(gimg, lds, IMG);  // the forward image is only for the recompute
   load_image(gwt, wt_lds, WTB);
   for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -937,9 +909,9 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   if (int rc = ensure_dyn_lds(attr_stage, reinterpret_cast<const void*>(&k_bwd_stage<PREC, VAR>), STAGE_LDS)) return rc;
   if (int rc = ensure_dyn_lds(attr_dw, PREC == SO3X_PREC_F32 ? reinterpret_cast<const void*>(&k_bwd_dw)
                                                              : reinterpret_cast<const void*>(&k_bwd_dw_bf16), DW_LDS)) return rc;
-  int rc = launch_prep(s, params, PREC, VAR, t_table, ws, nout);
+  // one prep launch: forward image (not needed when the pre-activations come from a stash), transposed image, tables
+  int rc = launch_prep(s, params, PREC, VAR, t_table, ws, nout, (void*)(ws + L.wt), zstash == nullptr);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_prep_wt<PREC>), dim3(32), dim3(256), 0, s, params, (void*)(ws + L.wt), nout);
   const float* beff = VAR == GATHER ? reinterpret_cast<const float*>(ws + beff_offset(PREC, VAR)) : nullptr;
   const float* emb = VAR == GATHER ? reinterpret_cast<const float*>(ws + emb_offset(PREC, VAR, t_table)) : nullptr;
   const uint4* h0 = VAR == GATHER ? reinterpret_cast<const uint4*>(ws + h0_offset(PREC, VAR, t_table)) : nullptr;
