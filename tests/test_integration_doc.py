@@ -1,0 +1,61 @@
+"""The binding stubs printed in INTEGRATION.md are executed as they stand against libso3x.so and compared with the
+repository's own binding: documentation of a C ABI that is not run goes stale."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+DEV = "cuda:0"
+
+
+def _blocks():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    # the ctypes stubs (the first python block of the document is the import example for the Python layer)
+    return [b for b in re.findall(r"```python\n(.*?)```", md, flags=re.S) if "_lib" in b]
+
+
+def test_integration_md_has_the_stubs():
+    src = "\n".join(_blocks())
+    for name in ("def so3_scale", "def p_sample_loop", "def mlp_forward_for_training", "def mlp_backward"):
+        assert name in src
+    compile(src.replace('ctypes.CDLL("diffusion-extensions_amd/libso3x.so")', "None"), "INTEGRATION.md", "exec")
+
+
+@pytest.mark.gpu
+def test_integration_md_stubs_run_and_agree_with_the_binding():
+    from so3x import backend as B
+    from so3x.so3_train import RotPredict
+    from so3x.diffusion import SO3Diffusion
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)  # the stubs load the library by its path relative to the repository root
+    try:
+        for b in _blocks():
+            exec(b, ns)
+    finally:
+        os.chdir(cwd)
+    lib = ns["_lib"]
+    for f in ("so3x_mlp_stash_bytes", "so3x_mlp_workspace_bytes", "so3x_p_sample_workspace_bytes"):
+        getattr(lib, f).restype = ctypes.c_size_t
+    lib.so3x_error_string.restype = ctypes.c_char_p
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = SO3Diffusion(net, timesteps=100).to(DEV)
+    params = net.flat_params_nograd()
+    n = 1000
+    x = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
+    t = torch.randint(0, 100, (n,), device=DEV)
+    out, stash, ws = ns["mlp_forward_for_training"](params, x, t, 100)
+    ref, zs = B.mlp_fwd_stash(params, x, t, 100)
+    assert torch.equal(out, ref)
+    dout = torch.randn(n, 3, device=DEV)
+    assert torch.equal(ns["mlp_backward"](params, x, t, 100, dout, stash, ws), B.mlp_bwd(params, x, t, dout, 1, 100, zstash=zs))
+    k = torch.rand(n, device=DEV)
+    assert torch.equal(ns["so3_scale"](x, k), B.so3_scale(x, k))
+    _, trap_p = proc._tables()
+    xs = ns["p_sample_loop"](params, proc._sched, trap_p, x.clone(), 100, 5)
+    eye = torch.eye(3, device=DEV)
+    assert torch.isfinite(xs).all() and float((xs @ xs.transpose(-1, -2) - eye).abs().max()) < 1e-5
