@@ -12,6 +12,22 @@ from . import rng as _rng
 __all__ = ["IsotropicGaussianSO3", "Bingham"]
 
 
+class _LogProb(torch.autograd.Function):
+    """log_prob with the gradient wrt the rotations the reference gets from torch autograd (distributions.py:74-77 and its
+    use at 189-190): the dense d logp / dR comes out of the same kernel launch as the value."""
+
+    @staticmethod
+    def forward(ctx, rotations, eps):
+        logp, _, grad = _b.igso3_logprob_score(rotations, eps, want_score=False, want_grad=True)
+        ctx.save_for_backward(grad)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g[..., None], None
+
+
 class IsotropicGaussianSO3:
     def __init__(self, eps: torch.Tensor, mean: torch.Tensor = None, quirk_col0: bool = True):
         if not isinstance(eps, torch.Tensor):
@@ -60,6 +76,8 @@ class IsotropicGaussianSO3:
 
     def log_prob(self, rotations: torch.Tensor) -> torch.Tensor:
         """log f(angle(R)), shape [..., 1] (reference distributions.py:74-77)."""
+        if torch.is_grad_enabled() and rotations.requires_grad:
+            return _LogProb.apply(rotations, self.eps)  # differentiable wrt the rotations, as under the reference's autograd
         logp, _, _ = _b.igso3_logprob_score(rotations, self.eps, want_score=False)
         return logp
 

@@ -193,6 +193,13 @@ def test_logprob_and_score_vs_golden(mods, golden):
         gr = g[f"grad_{i}"]
         scale = np.abs(gr).reshape(len(gr), -1).max(1)[:, None, None] + 1e-3
         assert np.max(np.abs(host(grad) - gr) / scale) < 5e-4
+        # ... and the way the reference gets it (distributions.py:189-190): torch.autograd.grad of log_prob wrt the rotations
+        Rg = dev(g["R"]).requires_grad_(True)
+        (ag,) = torch.autograd.grad(d.log_prob(Rg).sum(), Rg)
+        assert np.max(np.abs(host(ag) - gr) / scale) < 5e-4
+        wts = torch.linspace(0.5, 2.0, len(gr), device=DEV)[:, None]
+        (ag2,) = torch.autograd.grad((d.log_prob(Rg) * wts).sum(), Rg)
+        assert torch.allclose(ag2, ag * wts[..., None], rtol=1e-6, atol=0)
         _, sv = d.log_prob_and_score(R)
         ax, ang = O.rmat_to_aa(g["R"], "f64")
         ref_sv = O.igso3_dlogf(ang[:, 0].astype(np.float32), g[f"eps_{i}"])[:, None] * ax
