@@ -109,6 +109,16 @@ class IGSO3xR3:
             shift = shift + self._mean.shift
         return AffineT(rot, shift)
 
+    def log_prob(self, value: AffineT) -> torch.Tensor:
+        """log density of an affine transform (reference distributions.py:103-106): the IGSO(3) log-density of the rotation
+        ([..., 1], which like the reference's ignores the mean rotation) plus the per-coordinate Normal log-density of the
+        shift ([..., 3]); the sum broadcasts to [..., 3] exactly as the reference's does."""
+        rot_prob = self.igso3.log_prob(value.rot)
+        loc = self._mean.shift if self._mean is not None else torch.zeros_like(value.shift)
+        scale = self.eps[..., None] * self.shift_scale
+        shift_prob = torch.distributions.Normal(loc=loc, scale=scale).log_prob(value.shift)
+        return rot_prob + shift_prob
+
 
 class SE3Diffusion(nn.Module):
     """reference diffusion.py:432-522.  denoise_fn(AffineT, t) -> AffineGrad (any torch module/callable)."""

@@ -145,3 +145,34 @@ def test_gpu_se3_scale_move_and_philox(g):
     half = B.se3_q_sample_target(proc._sched, trap_q, 75.0, x0.rot[n // 2:], x0.shift[n // 2:], t[n // 2:], quirk_col0=False,
                                  seed=5, rng_offset=9, index_base=n // 2)
     assert all(torch.equal(a[n // 2:], b) for a, b in zip(full, half))
+
+
+@pytest.mark.gpu
+def test_gpu_igso3xr3_log_prob():
+    """IGSO3xR3.log_prob (reference distributions.py:103-106) = IGSO(3) log-density of the rotation (pinned oracle) + the
+    Normal log-density of the shift, broadcast to [n, 3]"""
+    from so3x.se3 import IGSO3xR3, AffineT
+    from so3x import backend as B
+    rng = np.random.default_rng(4)
+    n = 257
+    R = B.quat_to_rmat(dev(rng.standard_normal((n, 4)).astype(np.float32)))
+    shift = rng.standard_normal((n, 3)).astype(np.float32) * 20.0
+    mean_shift = rng.standard_normal((n, 3)).astype(np.float32)
+    eps = rng.uniform(0.1, 1.0, n).astype(np.float32)
+    for scale in (1.0, 75.0):
+        d = IGSO3xR3(dev(eps), mean=AffineT(torch.eye(3, device=DEV), dev(mean_shift)), shift_scale=scale)
+        lp = d.log_prob(AffineT(R, dev(shift))).cpu().numpy()
+        assert lp.shape == (n, 3)
+        sig = eps[:, None].astype(np.float64) * scale
+        ref = O.igso3_log_prob(R.cpu().numpy(), eps) .reshape(n, 1) - 0.5 * ((shift - mean_shift) / sig) ** 2 - np.log(sig) - 0.5 * np.log(2 * np.pi)
+        fin = np.isfinite(ref)   # small eps at large angles: the reference zeroes the density there, log = -inf on both sides
+        assert np.array_equal(fin, np.isfinite(lp)) and fin.mean() > 0.8
+        assert np.max(np.abs(lp[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) < 2e-5
+    # no mean given: zero shift mean, identity rotation mean
+    d0 = IGSO3xR3(dev(eps), shift_scale=2.0)
+    lp0 = d0.log_prob(AffineT(R, dev(shift))).cpu().numpy()
+    sig = eps[:, None].astype(np.float64) * 2.0
+    ref0 = O.igso3_log_prob(R.cpu().numpy(), eps).reshape(n, 1) - 0.5 * (shift / sig) ** 2 - np.log(sig) - 0.5 * np.log(2 * np.pi)
+    fin = np.isfinite(ref0)
+    assert np.array_equal(fin, np.isfinite(lp0))
+    assert np.max(np.abs(lp0[fin] - ref0[fin]) / np.maximum(1.0, np.abs(ref0[fin]))) < 2e-5
