@@ -48,6 +48,12 @@ class AffineT(object):
     def detach(self):
         return AffineT(self.rot.detach(), self.shift.detach())
 
+    @classmethod
+    def from_euler(cls, euls: torch.Tensor, shift: torch.Tensor):
+        """reference util.py:35-38"""
+        from .util import euler_to_rmat
+        return cls(euler_to_rmat(*torch.unbind(euls, dim=-1)), shift)
+
 
 class AffineGrad(object):
     """Denoiser output: rot_g [..., 3] (tangent vector) and shift_g [..., 3] (reference util.py:45-56)."""
@@ -169,6 +175,22 @@ class SE3Diffusion(nn.Module):
         return mean, extract(1.0 - self.alphas_cumprod, t, x_start.shape), \
             extract(self.log_one_minus_alphas_cumprod, t, x_start.shape)
 
+    def predict_start_from_noise(self, x_t: AffineT, t, noise: AffineGrad) -> AffineT:
+        """x_0 estimate from a predicted noise (reference diffusion.py:444-455): rotation = so3_scale(x_t, sqrt(1/abar))
+        @ exp(hat(rot_g * sqrt(1/abar - 1)))^T, shift = x_t.shift * sqrt(1/abar) - shift_g * sqrt(1/abar - 1)"""
+        k = self.sqrt_recip_alphas_cumprod[t]
+        ns = self.sqrt_recipm1_alphas_cumprod[t][..., None]
+        x_t_term = se3_scale(x_t, k)
+        noise_rot = _b.exp_skewvec((noise.rot_g * ns).contiguous())
+        return AffineT(_b.rmul(x_t_term.rot, noise_rot, transpose_b=True), x_t_term.shift - noise.shift_g * ns)
+
+    def q_posterior(self, x_start: AffineT, x_t: AffineT, t):
+        """reference diffusion.py:457-464"""
+        c_1 = se3_scale(x_start, self.posterior_mean_coef1[t])
+        c_2 = se3_scale(x_t, self.posterior_mean_coef2[t])
+        return AffineT(_b.rmul(c_1.rot, c_2.rot), c_1.shift + c_2.shift), extract(self.posterior_variance, t, t.shape), \
+            extract(self.posterior_log_variance_clipped, t, t.shape)
+
     def p_mean_variance(self, x: AffineT, t, clip_denoised: bool = False):
         predict = self.denoise_fn(x, t)
         mean_rot, mean_shift = _b.se3_p_mean(self._sched, x.rot, x.shift, predict.rot_g, predict.shift_g, self._shared_t(t))
@@ -187,6 +209,20 @@ class SE3Diffusion(nn.Module):
                                     unif=unif, znorm=znorm, seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
                                     shared_rot=self.shared_rot_noise)
         return AffineT(rot, shift)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, x_init: AffineT = None):
+        """Full reverse chain (reference diffusion.py:486-495, which starts from the Q factor of a Gaussian matrix as a bare
+        tensor and so cannot run as written; here the start is that rotation with a zero shift, or `x_init`)."""
+        device = self.betas.device
+        b = shape[0]
+        if x_init is None:
+            rot, _ = torch.linalg.qr(torch.randn((b, 3, 3), device=device))
+            x_init = AffineT(rot.contiguous(), torch.zeros(b, 3, device=device))
+        x = x_init
+        for i in reversed(range(self.num_timesteps)):
+            x = self.p_sample(x, torch.full((b,), i, device=device, dtype=torch.long))
+        return x
 
     def q_sample(self, x_start: AffineT, t, noise: AffineT = None, axes=None, unif=None, znorm=None):
         if noise is not None:

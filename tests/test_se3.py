@@ -176,3 +176,40 @@ def test_gpu_igso3xr3_log_prob():
     fin = np.isfinite(ref0)
     assert np.array_equal(fin, np.isfinite(lp0))
     assert np.max(np.abs(lp0[fin] - ref0[fin]) / np.maximum(1.0, np.abs(ref0[fin]))) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tv", [0, 3, 400, 900])
+def test_gpu_se3_reference_style_pieces_equal_the_fused_mean(g, tv):
+    """predict_start_from_noise + q_posterior (reference diffusion.py:444-464), composed from the standalone ops, against
+    the fused so3x_se3_p_mean that p_mean_variance uses; plus AffineT.from_euler and p_sample_loop"""
+    from so3x.se3 import SE3Diffusion, AffineT, AffineGrad
+    from so3x import util
+    rng = np.random.default_rng(tv)
+    n = 130
+    proc = SE3Diffusion(lambda x, t: None, timesteps=1000).to(DEV)
+    from so3x import backend as B
+    x = AffineT(B.quat_to_rmat(dev(rng.standard_normal((n, 4)).astype(np.float32))), dev(rng.standard_normal((n, 3)).astype(np.float32) * 5))
+    pred = AffineGrad(dev(rng.standard_normal((n, 3)).astype(np.float32)), dev(rng.standard_normal((n, 3)).astype(np.float32)))
+    t = torch.full((n,), tv, device=DEV, dtype=torch.long)
+    x0 = proc.predict_start_from_noise(x, t, pred)
+    mean, var, logvar = proc.q_posterior(x0, x, t)
+    mr, ms = B.se3_p_mean(proc._sched, x.rot, x.shift, pred.rot_g, pred.shift_g, tv)
+    # large scales (sqrt(1/abar) reaches 2e4 at t = 999) amplify fp32 rounding of the log: compare at matching conditioning
+    tol = 2e-4 if tv < 900 else 2e-2
+    assert float((mean.rot - mr).abs().max()) < tol
+    assert float((mean.shift - ms).abs().max()) < 1e-3 * max(1.0, float(ms.abs().max()))
+    assert var.shape == (n,) or var.shape == (n, 1) or var.numel() == n
+    eul = dev(rng.uniform(-1, 1, (5, 3)).astype(np.float32))
+    a = AffineT.from_euler(eul, torch.zeros(5, 3, device=DEV))
+    assert torch.equal(a.rot, util.euler_to_rmat(*torch.unbind(eul, -1)))
+
+
+@pytest.mark.gpu
+def test_gpu_se3_p_sample_loop_runs():
+    from so3x.se3 import SE3Diffusion, AffineT, AffineGrad
+    proc = SE3Diffusion(lambda x, t: AffineGrad(torch.zeros_like(x.shift), torch.zeros_like(x.shift)), timesteps=20).to(DEV)
+    out = proc.p_sample_loop((64,))
+    eye = torch.eye(3, device=DEV)
+    assert out.rot.shape == (64, 3, 3) and out.shift.shape == (64, 3) and torch.isfinite(out.shift).all()
+    assert float((out.rot @ out.rot.transpose(-1, -2) - eye).abs().max()) < 1e-4
