@@ -16,7 +16,7 @@ from .diffusion import _SCHED_NAMES, cosine_beta_schedule, extract
 from .distributions import IsotropicGaussianSO3
 
 __all__ = ["AffineT", "AffineGrad", "ProtData", "se3_scale", "se3_lerp", "IGSO3xR3", "SE3Diffusion", "ProjectedSE3Diffusion",
-           "move_prot"]
+           "move_prot", "move_prots", "ProtProjection"]
 
 ProtData = namedtuple("ProtData", ["residues", "positions", "angles"])
 
@@ -88,6 +88,38 @@ def move_prot(transf: AffineT, protein: ProtData) -> ProtData:
     out_pos, out_fr = _b.rigid_move(rot, transf.shift.reshape(-1, 3), pos.reshape(rot.shape[0], L, 3),
                                     fr.reshape(rot.shape[0], L, 3, 3) if fr is not None else None)
     return ProtData(protein.residues, out_pos.reshape(pos.shape), out_fr.reshape(fr.shape) if fr is not None else None)
+
+
+def move_prots(transf: AffineT, proteins) -> list:
+    """Move a collection of structures about their SHARED centroid (reference prot_util.py:61-70): one transform, several
+    proteins of possibly different lengths.  The structures are concatenated along the residue axis, moved by the rigid-move
+    kernel in one launch (its centroid is then the shared one), and split again."""
+    proteins = list(proteins)
+    lens = [p.positions.shape[-2] for p in proteins]
+    both = ProtData(None, torch.cat([p.positions for p in proteins], dim=-2), torch.cat([p.angles for p in proteins], dim=-3))
+    moved = move_prot(transf, both)
+    pos = torch.split(moved.positions, lens, dim=-2)
+    ang = torch.split(moved.angles, lens, dim=-3)
+    return [ProtData(p.residues, a, b) for p, a, b in zip(proteins, pos, ang)]
+
+
+class ProtProjection(nn.Module):
+    """Projection of ProjectedSE3Diffusion for docking data (reference prot_util.py:102-117): `data` is a sequence of
+    (receptor, ligand) ProtData pairs; the i-th transform moves the i-th ligand, the receptor stays.  se3=False takes
+    [n, 6] = (Euler angles, shift) instead of an AffineT."""
+
+    def __init__(self, data, se3=True):
+        super().__init__()
+        self.data = data
+        self.se3 = se3
+
+    def forward(self, transforms):
+        if self.se3:
+            tfs = transforms
+        else:
+            from .util import euler_to_rmat
+            tfs = AffineT(euler_to_rmat(*torch.unbind(transforms[..., :3], -1)), transforms[..., 3:])
+        return [(pair[0], move_prot(tfs[i], pair[1])) for i, pair in enumerate(self.data)]
 
 
 class IGSO3xR3:

@@ -213,3 +213,37 @@ def test_gpu_se3_p_sample_loop_runs():
     eye = torch.eye(3, device=DEV)
     assert out.rot.shape == (64, 3, 3) and out.shift.shape == (64, 3) and torch.isfinite(out.shift).all()
     assert float((out.rot @ out.rot.transpose(-1, -2) - eye).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_gpu_move_prots_and_prot_projection():
+    """prot_util.move_prots (shared centroid) and ProtProjection (per-pair ligand moves), against the plain formulas"""
+    from so3x.se3 import AffineT, ProtData, move_prots, move_prot, ProtProjection
+    from so3x import backend as B
+    rng = np.random.default_rng(12)
+
+    def prot(L):
+        return ProtData(torch.zeros(L, 21, device=DEV), dev(rng.standard_normal((L, 3)).astype(np.float32) * 10),
+                        B.quat_to_rmat(dev(rng.standard_normal((L, 4)).astype(np.float32))))
+
+    prots = [prot(37), prot(120), prot(5)]
+    tf = AffineT(B.quat_to_rmat(dev(rng.standard_normal((1, 4)).astype(np.float32)))[0], dev(rng.standard_normal(3).astype(np.float32)))
+    moved = move_prots(tf, prots)
+    allpos = torch.cat([p.positions for p in prots], 0)
+    mean = allpos.mean(0, keepdim=True)
+    for p, m in zip(prots, moved):
+        ref_pos = (p.positions - mean) @ tf.rot.T + mean + tf.shift
+        assert m.positions.shape == p.positions.shape and float((m.positions - ref_pos).abs().max()) < 2e-5
+        assert float((m.angles - p.angles @ tf.rot.T).abs().max()) < 2e-6 and m.residues is p.residues
+    pairs = [(prot(11), prot(23)), (prot(7), prot(64))]
+    tfs = AffineT(B.quat_to_rmat(dev(rng.standard_normal((2, 4)).astype(np.float32))), dev(rng.standard_normal((2, 3)).astype(np.float32)))
+    out = ProtProjection(pairs)(tfs)
+    for i, ((rec, lig), (orec, olig)) in enumerate(zip(pairs, out)):
+        assert orec is rec
+        ref = move_prot(tfs[i], lig)
+        assert torch.equal(olig.positions, ref.positions) and torch.equal(olig.angles, ref.angles)
+        c = lig.positions.mean(0, keepdim=True)
+        assert float((olig.positions - ((lig.positions - c) @ tfs.rot[i].T + c + tfs.shift[i])).abs().max()) < 2e-5
+    eul = dev(rng.uniform(-1, 1, (2, 6)).astype(np.float32))
+    out6 = ProtProjection(pairs, se3=False)(eul)
+    assert out6[1][1].positions.shape == (64, 3)
