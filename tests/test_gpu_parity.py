@@ -562,6 +562,59 @@ def test_G3_full_chain_two_sample_test_vs_reference(mods, golden, net, prec, fix
         assert abs(frac_m - frac_r) < 4 * np.sqrt(0.25 / m) + 0.01, (frac_m, frac_r)
 
 
+@pytest.mark.parametrize("prec,graph", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_training_with_this_stack_reaches_the_reference_trained_population(mods, golden, prec, graph):
+    """End-to-end training parity: the recipe that made `chain_samples_trained` (tools/make_golden.py: the REFERENCE trained
+    with its own loss for 3000 steps of batch 256, Adam 1e-3, on the two-mode data of so3_train.py:65-72, then sampled
+    with its own p_sample_loop) is run here with THIS stack's noising, loss, backward and sampler -- a different
+    initialisation and different noise, so the learned populations can only agree statistically: the reference's kernel
+    two-sample test must not tell them apart, and the concentration around the modes and the mode split must match."""
+    from so3x import rng
+    from so3x.so3_train import RotPredict
+    from so3x.graphs import TrainStepGraph
+    ref = golden["chain_samples_trained"]["x_final"]
+    m = len(ref)
+    torch.manual_seed(0)
+    rng.manual_seed(77)
+    mynet = RotPredict(out_type="skewvec", precision=prec).to(DEV)
+    proc = mods["diff"].SO3Diffusion(mynet, timesteps=1000).to(DEV)
+    opt = torch.optim.Adam(mynet.parameters(), lr=1e-3, fused=True, capturable=graph)
+    z90 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]], device=DEV)
+    rotations = torch.stack((z90, z90.T), dim=0)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    stepper = TrainStepGraph(proc, opt, (256, 3, 3)) if graph else None
+    for i in range(3000):
+        x0 = rotations[torch.randint(0, 2, (256,), device=DEV, generator=gen)]
+        if graph:
+            loss = stepper.step(x0)
+        else:
+            loss = proc(x0)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    assert float(loss.detach()) < 1.0
+    proc.rng_counter = None
+    x = proc.p_sample_loop((m,))
+    assert not torch.isnan(x).any()
+    mine = host(x)
+    thr = O.ker_2samp_threshold(m)
+    mmd = O.MMD(mine, ref)
+    assert mmd < thr, (mmd, thr)
+    z = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+
+    def stats(X):
+        d0 = O.rmat_dist(X, np.broadcast_to(z, X.shape).copy(), "f64")
+        d1 = O.rmat_dist(X, np.broadcast_to(z.T, X.shape).copy(), "f64")
+        return np.median(np.minimum(d0, d1)), np.mean(d0 < d1)
+    med_r, frac_r = stats(ref.astype(np.float64))
+    med_m, frac_m = stats(mine.astype(np.float64))
+    print(f"[{prec}{' graph' if graph else ''}] MMD {mmd:.2e} (bound {thr:.2e}); median mode distance {med_m:.4f} vs reference {med_r:.4f}; split {frac_m:.3f} vs {frac_r:.3f}")
+    assert med_m < 2.0 * med_r and med_m > 0.4 * med_r, (med_m, med_r)   # two short trainings: same scale of spread
+    assert abs(frac_m - 0.5) < 0.1 and abs(frac_r - 0.5) < 0.1, (frac_m, frac_r)
+    uni = O.quat_to_rmat(np.random.default_rng(0).standard_normal((m, 4)), "f64")
+    assert O.MMD(uni, mine) > thr                                             # and it is nothing like Haar-uniform
+
+
 def test_full_size_chain_properties(mods, net):
     """BASELINE config 3 shape (2^20 rotations), a short bf16 chain: no NaN, orthonormal, det +1."""
     net.precision = "bf16"
