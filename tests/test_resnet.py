@@ -307,3 +307,84 @@ def test_wide_net_training_step_as_a_captured_graph(B):
     assert all(np.isfinite(losses)) and len(set(losses)) == 5
     assert float((after - before).abs().max()) > 1e-4 and torch.isfinite(after).all()
     assert int(proc.rng_counter) == 2 + 5              # warm-up + replays (capture records, it does not execute)
+
+
+def _wide_from_flat(flat, precision):
+    from so3x.so3_lock_train import RotPredict
+    net = RotPredict(out_type="skewvec", precision=precision)
+    sd, off = {}, 0
+    for k, v in net.state_dict().items():
+        sd[k] = torch.from_numpy(flat[off:off + v.numel()].reshape(v.shape).copy())
+        off += v.numel()
+    assert off == flat.size
+    net.load_state_dict(sd)
+    return net.to(DEV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_G3_wide_net_chain_vs_reference_trained_population(B, golden, prec):
+    """Gate G3 for the 255-wide network: weights the REFERENCE trained with its so3_lock_train recipe (the so3_lerp arc
+    between two Euler rotations; tools/make_golden.py trained_chain_samples_wide), 2048 samples of this stack's 1000-step
+    chain against 2048 samples of the reference's own p_sample_loop under the reference's kernel two-sample test."""
+    import so3x
+    from so3x.diffusion import SO3Diffusion
+    g = golden["chain_samples_trained_wide"]
+    ref = g["x_final"]
+    m = len(ref)
+    net = _wide_from_flat(g["params_f16"].astype(np.float32), prec)
+    proc = SO3Diffusion(net, timesteps=1000).to(DEV)
+    so3x.manual_seed(99)
+    x = proc.p_sample_loop((m,))
+    assert not torch.isnan(x).any()
+    assert float((x @ x.transpose(-1, -2) - torch.eye(3, device=DEV)).abs().max()) < 1e-5
+    mine = host(x)
+    thr = O.ker_2samp_threshold(m)
+    mmd = O.MMD(mine, ref)
+    print(f"[wide {prec}] MMD {mmd:.2e} (bound {thr:.2e}; reference split halves {O.MMD(ref[:m // 2], ref[m // 2:]):.2e})")
+    assert mmd < thr, (mmd, thr)
+    assert mmd < 5 * max(O.MMD(ref[: m // 2], ref[m // 2:]), 1e-3)  # far tighter than the reference's bound: ~ estimator noise
+    uni = O.quat_to_rmat(np.random.default_rng(0).standard_normal((m, 4)), "f64")
+    assert O.MMD(uni, ref) > thr                      # the test has power against this population
+    # the population lies along the training arc: same distance-to-arc statistics (arc = so3_lerp(R1, R2, w))
+    w = np.linspace(0, 1, 201)
+    arc = O.so3_lerp(np.repeat(g["R1"], 201, 0), np.repeat(g["R2"], 201, 0), w, "f64")
+
+    def dist_to_arc(X):
+        d = np.stack([O.rmat_dist(X.astype(np.float64), np.broadcast_to(a, X.shape).copy(), "f64") for a in arc[::10]], 0)
+        return np.median(d.min(0))
+    dm, dr = dist_to_arc(mine), dist_to_arc(ref)
+    assert abs(dm - dr) < 0.3 * dr + 0.01, (dm, dr)
+
+
+@pytest.mark.gpu
+def test_wide_net_training_with_this_stack_reaches_the_reference_trained_population(B, golden):
+    """the so3_lock_train recipe behind that fixture (1500 Adam steps of batch 128 at 3e-4 on the arc data) with THIS stack's
+    kernels (bf16 operands), then the chain: statistically the same population as the reference's training + sampling"""
+    import so3x
+    from so3x.diffusion import SO3Diffusion
+    from so3x.so3_lock_train import RotPredict
+    from so3x import util
+    g = golden["chain_samples_trained_wide"]
+    ref = g["x_final"]
+    m = len(ref)
+    torch.manual_seed(0)
+    so3x.manual_seed(5)
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = SO3Diffusion(net, timesteps=1000).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4, fused=True)
+    R1, R2 = dev(g["R1"]), dev(g["R2"])
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for i in range(1500):
+        x0 = util.so3_lerp(R1, R2, torch.rand(128, 1, device=DEV, generator=gen))
+        loss = proc(x0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    assert float(loss.detach()) < 1.5
+    x = proc.p_sample_loop((m,))
+    mine = host(x)
+    thr = O.ker_2samp_threshold(m)
+    mmd = O.MMD(mine, ref)
+    print(f"[wide trained here] MMD {mmd:.2e} (bound {thr:.2e})")
+    assert not np.isnan(mine).any() and mmd < thr, (mmd, thr)

@@ -774,3 +774,51 @@ def prevstep_golden(B=64):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "prevstep":
     prevstep_golden()
+
+
+def trained_chain_samples_wide(steps=1500, batch=128, lr=3e-4, m=2048):
+    """G3 fixture for the 255-wide residual network: the REFERENCE's so3_lock_train recipe (so3_lock_train.py:64-97: the
+    so3_lerp arc between two Euler rotations, Adam) for a short run, then `m` samples of the reference's own p_sample_loop.
+    Stores the trained weights (fp16-rounded to halve the fixture: the samples are drawn WITH the rounded weights) and the
+    samples."""
+    _install_stubs()
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import diffusion as rdiff
+    import so3_lock_train as rlock
+    import util as rutil
+    from math import pi
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    net = rlock.RotPredict(out_type="skewvec")
+    proc = rdiff.SO3Diffusion(net, timesteps=1000, loss_type="skewvec")
+    optim = torch.optim.Adam(net.parameters(), lr=lr)
+    R_1 = rutil.euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None]
+    R_2 = rutil.euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None]
+    for i in range(steps):
+        truepos = rutil.so3_lerp(R_1, R_2, torch.rand(batch, 1))
+        loss = proc(truepos)
+        if torch.isnan(loss).any():
+            continue
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        if i % 100 == 0:
+            print(i, float(loss), flush=True)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(p.half().float())
+    rdiff.tqdm = lambda it, **k: it
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        x = proc.p_sample_loop((m,))
+    out = {"x_final": npy(x).astype(np.float32), "R1": npy(R_1), "R2": npy(R_2),
+           "params_f16": np.concatenate([npy(v).reshape(-1) for v in net.state_dict().values()]).astype(np.float16)}
+    np.savez_compressed(os.path.join(OUT, "chain_samples_trained_wide.npz"), **out)
+    print("chain_samples_trained_wide.npz", os.path.getsize(os.path.join(OUT, "chain_samples_trained_wide.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trained_chain_samples_wide":
+    trained_chain_samples_wide()
