@@ -845,9 +845,11 @@ __global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restric
 }
 
 const Freqs& host_freqs() {
-  static Freqs fr;
-  static bool init = false;
-  if (!init) { so3x_posemb_freqs(NFREQ, fr.f); init = true; }
+  static const Freqs fr = [] {  // initialised once, thread-safely
+    Freqs f;
+    so3x_posemb_freqs(NFREQ, f.f);
+    return f;
+  }();
   return fr;
 }
 

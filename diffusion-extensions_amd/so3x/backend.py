@@ -166,8 +166,16 @@ def posemb_freqs(half_dim=28):
 _ws = {}
 
 
+def _ws_key(device):
+    """one scratch buffer per (device, stream): calls on different streams may run concurrently, and a buffer first
+    requested while a hipGraph is being captured is allocated from that graph's private pool -- it stays valid for the
+    graph's lifetime whatever eager calls on other streams request later"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, torch.cuda.current_stream(idx).cuda_stream)
+
+
 def _workspace(device, nbytes):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = _ws_key(device)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -859,7 +867,7 @@ _ws_small = {}
 
 def _workspace_small(device, nbytes):
     """separate small scratch so the loss reduction never aliases the MLP workspace"""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = _ws_key(device)
     buf = _ws_small.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
