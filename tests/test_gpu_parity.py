@@ -853,3 +853,37 @@ def test_data_parallel_training_two_ranks_on_one_gpu(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+@pytest.mark.gpu
+def test_captured_graph_survives_bigger_eager_calls_on_other_streams(mods):
+    """the binding's scratch buffers are per (device, stream) and a graph's buffer comes from the graph's own pool: eager
+    calls that grow the scratch elsewhere between replays must not disturb the captured training step"""
+    from so3x import rng
+    from so3x.so3_train import RotPredict
+    from so3x.graphs import TrainStepGraph
+    B = mods["B"]
+    x = B.quat_to_rmat(torch.randn(512, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)))
+    big_x = B.quat_to_rmat(torch.randn(1 << 17, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)))
+    big_t = torch.randint(0, 100, (1 << 17,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    big_d = torch.ones(1 << 17, 3, device=DEV)
+
+    def run(disturb):
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        rng.manual_seed(9)
+        net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+        proc = mods["diff"].SO3Diffusion(net, timesteps=100).to(DEV)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)
+        g = TrainStepGraph(proc, opt, x.shape, warmup=2)
+        losses = []
+        for i in range(4):
+            if disturb:  # fp32 staged backward at 2^17 samples: a scratch request hundreds of times the graph's
+                B.mlp_bwd(net.flat_params_nograd(), big_x, big_t, big_d, B.PREC_F32, 100)
+                B.mlp_fwd(net.flat_params_nograd(), big_x, big_t, B.PREC_BF16, 100)
+            losses.append(float(g.step(x)))
+        return losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
