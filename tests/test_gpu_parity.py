@@ -887,3 +887,71 @@ def test_captured_graph_survives_bigger_eager_calls_on_other_streams(mods):
     l0, p0 = run(False)
     l1, p1 = run(True)
     assert l0 == l1 and torch.equal(p0, p1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 65, 255, 257, 1000])
+@pytest.mark.parametrize("pad", [64, 3])   # 64 floats: outputs stay 16-byte aligned; 3: deliberately misaligned
+def test_outputs_stay_inside_their_buffers(mods, n, pad):
+    """no GPU AddressSanitizer on this pool: instead every output of the tile-staged kernels is placed between two guard
+    bands of sentinels (through the raw C ABI) and the bands must come back untouched, for ragged sizes around the tile and
+    wave boundaries and for aligned and misaligned buffers"""
+    import ctypes as C
+    B = mods["B"]
+    lib = B.lib()
+    G = 256
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    SENT = 12345.0
+
+    def guarded(count):
+        buf = torch.full((count + 2 * G + pad,), SENT, device=DEV)
+        return buf, buf[G + pad: G + pad + count]
+
+    def check(buf, count, what):
+        torch.cuda.synchronize()
+        assert bool((buf[:G + pad] == SENT).all()) and bool((buf[G + pad + count:] == SENT).all()), f"{what}: wrote outside its output"
+        assert not bool((buf[G + pad: G + pad + count] == SENT).any()), f"{what}: left output unwritten"
+
+    p = lambda t: C.c_void_p(t.data_ptr())
+    q = torch.randn(n, 4, device=DEV)
+    R = B.quat_to_rmat(q)
+    R2 = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
+    k = torch.rand(n, device=DEV)
+    x6 = torch.randn(n, 6, device=DEV)
+    Gm = torch.randn(n, 3, 3, device=DEV)
+    cases = [
+        ("quat_to_rmat", 9, lambda o: lib.so3x_quat_to_rmat(st, p(q), p(o), C.c_int64(n))),
+        ("so3_scale", 9, lambda o: lib.so3x_so3_scale(st, p(R), p(k), C.c_int64(1), p(o), C.c_int64(n))),
+        ("log_rmat_vec", 3, lambda o: lib.so3x_log_rmat_vec(st, p(R), p(o), C.c_int64(n))),
+        ("log_rmat", 9, lambda o: lib.so3x_log_rmat(st, p(R), p(o), C.c_int64(n))),
+        ("rmat_dist", 1, lambda o: lib.so3x_rmat_dist(st, p(R), p(R2), p(o), C.c_int64(n))),
+        ("rmul", 9, lambda o: lib.so3x_rmul(st, p(R), C.c_int64(9), p(R2), C.c_int64(9), C.c_int(1), p(o), C.c_int64(n))),
+        ("six2rmat", 9, lambda o: lib.so3x_six2rmat(st, p(x6), p(o), C.c_int64(n))),
+        ("six2rmat_bwd", 6, lambda o: lib.so3x_six2rmat_bwd(st, p(x6), p(Gm), p(o), C.c_int64(n))),
+        ("log_rmat_bwd", 9, lambda o: lib.so3x_log_rmat_bwd(st, p(R), p(Gm), p(o), C.c_int64(n))),
+    ]
+    for name, w, call in cases:
+        buf, out = guarded(n * w)
+        assert call(out) == 0, name
+        check(buf, n * w, name)
+    # two outputs at once
+    bufa, oa = guarded(n * 9)
+    bufb, ob = guarded(n * 9)
+    assert lib.so3x_rmat_dist_bwd(st, p(R), p(R2), p(k), p(oa), p(ob), C.c_int64(n)) == 0
+    check(bufa, n * 9, "rmat_dist_bwd.da"); check(bufb, n * 9, "rmat_dist_bwd.db")
+    bufl, ol = guarded(n)
+    bufs, os_ = guarded(n * 3)
+    assert lib.so3x_igso3_logprob_score(st, p(R), p(k * 0.8 + 0.2), C.c_int64(1), p(ol), p(os_), None, C.c_int64(n)) == 0
+    check(bufl, n, "logprob"); check(bufs, n * 3, "score")
+    # the network forward (n_out = 3 and 6) and the chain's x_out
+    net3 = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    net6 = mods["train"].RotPredict(out_type="rotmat", precision="bf16").to(DEV)
+    t = torch.randint(0, 50, (n,), device=DEV)
+    for net_, no in ((net3, 3), (net6, 6)):
+        prm = net_.flat_params_nograd()
+        nb = lib.so3x_mlp_workspace_bytes(C.c_int64(0), C.c_int(1), C.c_int(50))
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        buf, out = guarded(n * no)
+        assert lib.so3x_mlp_fwd(st, p(prm), p(R), p(t), C.c_int64(1), p(out), C.c_int64(n), C.c_int(no), C.c_int(1), C.c_int(50),
+                                p(ws), C.c_size_t(nb)) == 0
+        check(buf, n * no, f"mlp_fwd n_out={no}")
