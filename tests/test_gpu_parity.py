@@ -955,3 +955,64 @@ def test_outputs_stay_inside_their_buffers(mods, n, pad):
         assert lib.so3x_mlp_fwd(st, p(prm), p(R), p(t), C.c_int64(1), p(out), C.c_int64(n), C.c_int(no), C.c_int(1), C.c_int(50),
                                 p(ws), C.c_size_t(nb)) == 0
         check(buf, n * no, f"mlp_fwd n_out={no}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 33, 257, 1000])
+def test_network_and_diffusion_outputs_stay_inside_their_buffers(mods, n):
+    """guard bands (see above) around the outputs of the fused kernels: noising, both chains, both networks' gradients"""
+    import ctypes as C
+    from so3x.so3_lock_train import RotPredict as Wide
+    B = mods["B"]
+    lib = B.lib()
+    G, SENT = 256, 12345.0
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def guarded(count):
+        buf = torch.full((count + 2 * G,), SENT, device=DEV)
+        return buf, buf[G: G + count]
+
+    def check(buf, count, what):
+        torch.cuda.synchronize()
+        assert bool((buf[:G] == SENT).all()) and bool((buf[G + count:] == SENT).all()), f"{what}: wrote outside its output"
+        assert not bool((buf[G: G + count] == SENT).any()), f"{what}: left output unwritten"
+
+    T = 50
+    net = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = mods["diff"].SO3Diffusion(net, timesteps=T).to(DEV)
+    trap_q, trap_p = proc._tables()
+    R = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
+    t = torch.randint(0, T, (n,), device=DEV)
+    bx, ox = guarded(n * 9)
+    bt, ot = guarded(n * 3)
+    assert lib.so3x_q_sample_target(st, p(proc._sched), C.c_int(T), p(trap_q), p(proc._guide_q), p(R), p(t), C.c_int(1), None, None,
+                                    None, C.c_uint64(1), C.c_uint64(0), None, C.c_int64(0), p(ox), p(ot), None, C.c_int64(n)) == 0
+    check(bx, n * 9, "q_sample x_t"); check(bt, n * 3, "q_sample target")
+    for wide in (False, True):
+        nt = Wide(out_type="skewvec", precision="bf16").to(DEV) if wide else net
+        prm = nt.flat_params_nograd()
+        fn = lib.so3x_resnet_p_sample_chain if wide else lib.so3x_p_sample_chain
+        nb = lib.so3x_resnet_workspace_bytes(C.c_int(1), C.c_int(T)) if wide else lib.so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(1))
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        bo, oo = guarded(n * 9)
+        assert fn(st, p(prm), p(proc._sched), C.c_int(T), p(trap_p), p(proc._guide_p), p(R), p(oo), C.c_int(T - 1), C.c_int(3), None, None,
+                  C.c_uint64(1), C.c_uint64(0), C.c_int64(0), C.c_int64(n), C.c_int(1), p(ws), C.c_size_t(nb)) == 0
+        check(bo, n * 9, "wide chain x_out" if wide else "chain x_out")
+        # gradients: exactly nparams floats
+        for prec in ((1, 0) if not wide else (1,)):
+            dout = torch.randn(n, 3, device=DEV)
+            npar = prm.numel()
+            bg, og = guarded(npar)
+            if wide:
+                nbw = lib.so3x_resnet_train_workspace_bytes(C.c_int64(n), C.c_int(prec), C.c_int(T))
+                wsb = torch.empty(nbw, dtype=torch.uint8, device=DEV)
+                rc = lib.so3x_resnet_bwd(st, p(prm), p(R), p(t), C.c_int64(1), p(dout), p(og), C.c_int64(n), C.c_int(3), C.c_int(prec),
+                                         C.c_int(T), None, p(wsb), C.c_size_t(nbw))
+            else:
+                nbw = lib.so3x_mlp_workspace_bytes(C.c_int64(n), C.c_int(prec), C.c_int(T))
+                wsb = torch.empty(nbw, dtype=torch.uint8, device=DEV)
+                rc = lib.so3x_mlp_bwd(st, p(prm), p(R), p(t), C.c_int64(1), p(dout), p(og), C.c_int64(n), C.c_int(3), C.c_int(prec),
+                                      C.c_int(T), None, p(wsb), C.c_size_t(nbw))
+            assert rc == 0
+            check(bg, npar, f"{'wide' if wide else 'mlp'} bwd dparams prec={prec}")
