@@ -1016,3 +1016,75 @@ def test_network_and_diffusion_outputs_stay_inside_their_buffers(mods, n):
                                       C.c_int(T), None, p(wsb), C.c_size_t(nbw))
             assert rc == 0
             check(bg, npar, f"{'wide' if wide else 'mlp'} bwd dparams prec={prec}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [33, 1000, 70001])
+def test_workspaces_are_big_enough_as_advertised(mods, n):
+    """every *_workspace_bytes / *_stash_bytes figure is an upper bound on what the kernels touch: the scratch is placed
+    between guard bands at exactly the advertised size"""
+    import ctypes as C
+    from so3x.so3_lock_train import RotPredict as Wide
+    B = mods["B"]
+    lib = B.lib()
+    GB = 4096
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def guarded(nbytes):
+        buf = torch.full((nbytes + 2 * GB,), 0xA5, dtype=torch.uint8, device=DEV)
+        return buf, buf[GB: GB + nbytes]
+
+    def check(buf, nbytes, what):
+        torch.cuda.synchronize()
+        assert bool((buf[:GB] == 0xA5).all()) and bool((buf[GB + nbytes:] == 0xA5).all()), f"{what}: wrote outside its scratch"
+
+    T = 50
+    R = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
+    t = torch.randint(0, T, (n,), device=DEV)
+    dout = torch.randn(n, 3, device=DEV)
+    out = torch.empty(n, 3, device=DEV)
+    net = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    prm = net.flat_params_nograd()
+    dprm = torch.empty_like(prm)
+    for prec in (1, 0):
+        for tt in (T, 0):
+            nb = lib.so3x_mlp_workspace_bytes(C.c_int64(n), C.c_int(prec), C.c_int(tt))
+            buf, ws = guarded(nb)
+            assert lib.so3x_mlp_bwd(st, p(prm), p(R), p(t), C.c_int64(1), p(dout), p(dprm), C.c_int64(n), C.c_int(3), C.c_int(prec), C.c_int(tt),
+                                    None, p(ws), C.c_size_t(nb)) == 0
+            check(buf, nb, f"mlp_bwd prec={prec} t_table={tt}")
+            nbf = lib.so3x_mlp_workspace_bytes(C.c_int64(0), C.c_int(prec), C.c_int(tt))
+            buf, ws = guarded(nbf)
+            assert lib.so3x_mlp_fwd(st, p(prm), p(R), p(t), C.c_int64(1), p(out), C.c_int64(n), C.c_int(3), C.c_int(prec), C.c_int(tt),
+                                    p(ws), C.c_size_t(nbf)) == 0
+            check(buf, nbf, f"mlp_fwd prec={prec} t_table={tt}")
+    # stash forward: both the scratch and the stash itself
+    nbf = lib.so3x_mlp_workspace_bytes(C.c_int64(0), C.c_int(1), C.c_int(T))
+    nbs = lib.so3x_mlp_stash_bytes(C.c_int64(n))
+    bufw, ws = guarded(nbf)
+    bufs, zs = guarded(nbs)
+    assert lib.so3x_mlp_fwd_stash(st, p(prm), p(R), p(t), C.c_int64(1), p(out), p(zs), C.c_int64(n), C.c_int(3), C.c_int(1), C.c_int(T),
+                                  p(ws), C.c_size_t(nbf)) == 0
+    check(bufw, nbf, "mlp_fwd_stash scratch"); check(bufs, nbs, "mlp_fwd_stash stash")
+    # the wide network: forward scratch, training scratch, stash
+    wide = Wide(out_type="skewvec", precision="bf16").to(DEV)
+    wprm = wide.flat_params_nograd()
+    wd = torch.empty_like(wprm)
+    for prec in (1, 0):
+        nbw = lib.so3x_resnet_workspace_bytes(C.c_int(prec), C.c_int(T))
+        nbst = lib.so3x_resnet_stash_bytes(C.c_int64(n), C.c_int(prec))
+        bufw, ws = guarded(nbw)
+        bufs, stash = guarded(nbst)
+        assert lib.so3x_resnet_fwd_stash(st, p(wprm), p(R), p(t), C.c_int64(1), p(out), p(stash), C.c_int64(n), C.c_int(3), C.c_int(prec),
+                                         C.c_int(T), p(ws), C.c_size_t(nbw)) == 0
+        check(bufw, nbw, f"resnet_fwd_stash scratch prec={prec}"); check(bufs, nbst, f"resnet stash prec={prec}")
+        nbt = lib.so3x_resnet_train_workspace_bytes(C.c_int64(n), C.c_int(prec), C.c_int(T))
+        buft, wst = guarded(nbt)
+        assert lib.so3x_resnet_bwd(st, p(wprm), p(R), p(t), C.c_int64(1), p(dout), p(wd), C.c_int64(n), C.c_int(3), C.c_int(prec), C.c_int(T),
+                                   p(stash), p(wst), C.c_size_t(nbt)) == 0
+        check(buft, nbt, f"resnet_bwd scratch (with stash) prec={prec}")
+        buft, wst = guarded(nbt)
+        assert lib.so3x_resnet_bwd(st, p(wprm), p(R), p(t), C.c_int64(1), p(dout), p(wd), C.c_int64(n), C.c_int(3), C.c_int(prec), C.c_int(T),
+                                   None, p(wst), C.c_size_t(nbt)) == 0
+        check(buft, nbt, f"resnet_bwd scratch (recompute) prec={prec}")
