@@ -1067,6 +1067,17 @@ def test_workspaces_are_big_enough_as_advertised(mods, n):
     assert lib.so3x_mlp_fwd_stash(st, p(prm), p(R), p(t), C.c_int64(1), p(out), p(zs), C.c_int64(n), C.c_int(3), C.c_int(1), C.c_int(T),
                                   p(ws), C.c_size_t(nbf)) == 0
     check(bufw, nbf, "mlp_fwd_stash scratch"); check(bufs, nbs, "mlp_fwd_stash stash")
+    # the chain's scratch (weight image + per-timestep tables), both networks
+    proc = mods["diff"].SO3Diffusion(net, timesteps=T).to(DEV)
+    _, trap_p = proc._tables()
+    xo = torch.empty_like(R)
+    for prec in (1, 0):
+        nbc = lib.so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(prec))
+        buf, ws = guarded(nbc)
+        assert lib.so3x_p_sample_chain(st, p(prm), p(proc._sched), C.c_int(T), p(trap_p), p(proc._guide_p), p(R), p(xo), C.c_int(T - 1),
+                                       C.c_int(2), None, None, C.c_uint64(1), C.c_uint64(0), C.c_int64(0), C.c_int64(n), C.c_int(prec),
+                                       p(ws), C.c_size_t(nbc)) == 0
+        check(buf, nbc, f"p_sample_chain scratch prec={prec}")
     # the wide network: forward scratch, training scratch, stash
     wide = Wide(out_type="skewvec", precision="bf16").to(DEV)
     wprm = wide.flat_params_nograd()
@@ -1088,3 +1099,9 @@ def test_workspaces_are_big_enough_as_advertised(mods, n):
         assert lib.so3x_resnet_bwd(st, p(wprm), p(R), p(t), C.c_int64(1), p(dout), p(wd), C.c_int64(n), C.c_int(3), C.c_int(prec), C.c_int(T),
                                    None, p(wst), C.c_size_t(nbt)) == 0
         check(buft, nbt, f"resnet_bwd scratch (recompute) prec={prec}")
+        nbw = lib.so3x_resnet_workspace_bytes(C.c_int(prec), C.c_int(T))
+        buf, ws = guarded(nbw)
+        assert lib.so3x_resnet_p_sample_chain(st, p(wprm), p(proc._sched), C.c_int(T), p(trap_p), p(proc._guide_p), p(R), p(xo),
+                                              C.c_int(T - 1), C.c_int(2), None, None, C.c_uint64(1), C.c_uint64(0), C.c_int64(0),
+                                              C.c_int64(n), C.c_int(prec), p(ws), C.c_size_t(nbw)) == 0
+        check(buf, nbw, f"resnet chain scratch prec={prec}")
