@@ -89,3 +89,27 @@ def mean_scalar(x: torch.Tensor, ctx: Ctx) -> float:
         dist.all_reduce(x, op=dist.ReduceOp.SUM)
         x = x / ctx.world_size
     return float(x.item())
+
+
+@torch.no_grad()
+def sharded_p_sample_loop(process, n_global: int, ctx: Ctx, gather: bool = False, x_init: torch.Tensor = None):
+    """The full reverse chain for `n_global` rotations, batch-sharded over the ranks: rank r runs samples
+    [lo, hi) with the Philox counters keyed by the GLOBAL sample index, so the assembled result is the same tensor for any
+    number of ranks; no collective inside the chain.  Returns this rank's shard, or (gather=True) the whole [n_global, 3, 3]
+    tensor on every rank via one all_gather.  x_init: optional [n_global, 3, 3] start (each rank takes its rows)."""
+    lo, hi = shard_range(n_global, ctx.rank, ctx.world_size)
+    saved = process.index_base
+    process.index_base = lo
+    try:
+        x = process.p_sample_loop((hi - lo,), x_init=None if x_init is None else x_init[lo:hi].contiguous())
+    finally:
+        process.index_base = saved
+    if not gather or ctx.world_size == 1:
+        return x
+    sizes = [shard_range(n_global, r, ctx.world_size) for r in range(ctx.world_size)]
+    width = max(b - a for a, b in sizes)
+    pad = torch.zeros((width, 3, 3), dtype=x.dtype, device=x.device)
+    pad[: hi - lo] = x
+    parts = [torch.empty_like(pad) for _ in range(ctx.world_size)]
+    dist.all_gather(parts, pad)
+    return torch.cat([parts[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0)

@@ -1105,3 +1105,53 @@ def test_workspaces_are_big_enough_as_advertised(mods, n):
                                               C.c_int(T - 1), C.c_int(2), None, None, C.c_uint64(1), C.c_uint64(0), C.c_int64(0),
                                               C.c_int64(n), C.c_int(prec), p(ws), C.c_size_t(nbw)) == 0
         check(buf, nbw, f"resnet chain scratch prec={prec}")
+
+
+_SHARD_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import so3x
+from so3x import parallel
+from so3x.so3_train import RotPredict
+from so3x.diffusion import SO3Diffusion
+ctx = parallel.init()
+torch.manual_seed(3)
+net = RotPredict(out_type="skewvec", precision="bf16").to(ctx.device)
+proc = SO3Diffusion(net, timesteps=30).to(ctx.device)
+so3x.manual_seed(5)
+x = parallel.sharded_p_sample_loop(proc, 1001, ctx, gather=True)
+assert x.shape == (1001, 3, 3)
+if ctx.rank == 0:
+    torch.save(x.cpu(), sys.argv[2])
+parallel.finalize(ctx)
+print("OK", ctx.rank)
+'''
+
+
+@pytest.mark.gpu
+def test_sharded_sampling_is_invariant_to_the_number_of_ranks(tmp_path):
+    """parallel.sharded_p_sample_loop: two ranks (sharing cuda:0, gloo) assemble bit for bit the tensor one rank produces --
+    Philox counters are keyed by the global sample index, the chain has no collective (SURVEY.md 8e)"""
+    import os, subprocess, sys
+    import so3x
+    from conftest import PKG
+    from so3x import parallel
+    from so3x.so3_train import RotPredict
+    from so3x.diffusion import SO3Diffusion
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    outp = str(tmp_path / "two_ranks.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", LOCAL_RANK="0", SO3X_DIST_BACKEND="gloo")
+    procs = [subprocess.Popen([sys.executable, str(script), PKG, outp], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o
+    two = torch.load(outp)
+    torch.manual_seed(3)
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = SO3Diffusion(net, timesteps=30).to(DEV)
+    so3x.manual_seed(5)
+    one = parallel.sharded_p_sample_loop(proc, 1001, parallel.Ctx(0, 1, 0, torch.device(DEV), False))
+    assert torch.equal(one.cpu(), two)
+    assert proc.index_base == 0
