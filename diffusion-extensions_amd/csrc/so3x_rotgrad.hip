@@ -163,6 +163,8 @@ k_rmat_dist_bwd(const float* __restrict__ A, const float* __restrict__ Bm, const
 // "prevstep" objective: step = x_noisy^T (so3_scale(x_start, c1_t) so3_scale(x_noisy, c2_t)) (diffusion.py:299-302, 360-364),
 // dist2 = rmat_dist(x_recon, step)^2 = 2 omega(x_recon^T step)^2; per-block double partial sums of dist2, and
 // dx = gscale / n * d dist2 / d x_recon = gscale / n * step (4 omega d omega/dM)^T.
+// SIX: x_recon is given as the network's raw 6 outputs; six2rmat and its backward are applied here (dx = d loss / d out6).
+template <bool SIX>
 __global__ void __launch_bounds__(kBlock)
 k_prevstep(const float* __restrict__ sched, int T, const float* __restrict__ xr, const float* __restrict__ xs,
            const float* __restrict__ xn, const int64_t* __restrict__ t, int64_t t_stride, int64_t n, float gk,
@@ -173,7 +175,13 @@ k_prevstep(const float* __restrict__ sched, int T, const float* __restrict__ xr,
   SO3X_TILE_LOOP(n) {
     SO3X_TILE_VARS(n)
     float r[9], x0[9], xt[9], w[3], e1[9], e2[9], pm[9], st[9], M[9], dom[9], o[9], s;
-    load_rows<9>(xr, base, cnt, sm, r);
+    float v6[6];
+    if constexpr (SIX) {
+      load_rows<6>(xr, base, cnt, sm, v6);
+      six2rmat_one(v6, r);
+    } else {
+      load_rows<9>(xr, base, cnt, sm, r);
+    }
     load_rows<9>(xs, base, cnt, sm, x0);
     load_rows<9>(xn, base, cnt, sm, xt);
     int64_t tt = live ? t[idx * t_stride] : 0;
@@ -196,7 +204,13 @@ k_prevstep(const float* __restrict__ sched, int T, const float* __restrict__ xr,
 #pragma unroll
       for (int i = 0; i < 9; i++) dom[i] *= k;
       mul33_bt(st, dom, o);
-      store_rows<9>(dx, base, cnt, sm, o);
+      if constexpr (SIX) {
+        float d6[6];
+        six2rmat_bwd_one(v6, o, d6);
+        store_rows<6>(dx, base, cnt, sm, d6);
+      } else {
+        store_rows<9>(dx, base, cnt, sm, o);
+      }
     }
   }
 #pragma unroll
@@ -258,8 +272,21 @@ int so3x_prevstep_loss(so3x_stream_t s, const float* sched, int T, const float* 
     return SO3X_ERR_INVALID_ARG;
   if (!workspace || workspace_bytes < so3x_prevstep_workspace_bytes(n)) return SO3X_ERR_WORKSPACE;
   const int grid = grid_for_tiles((n + kTile - 1) / kTile);
-  hipLaunchKernelGGL(k_prevstep, dim3(grid), dim3(kBlock), 0, (hipStream_t)s, sched, T, x_recon, x_start, x_noisy, t, t_stride, n,
+  hipLaunchKernelGGL(k_prevstep<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)s, sched, T, x_recon, x_start, x_noisy, t, t_stride, n,
                      1.0f / (float)n, reinterpret_cast<double*>(workspace), dx_recon, step_out);
+  hipLaunchKernelGGL(k_sum_partials_f, dim3(1), dim3(256), 0, (hipStream_t)s, (const double*)workspace, grid, 1.0 / (double)n, loss);
+  return check_launch();
+}
+
+int so3x_prevstep_loss6(so3x_stream_t s, const float* sched, int T, const float* out6, const float* x_start,
+                        const float* x_noisy, const int64_t* t, int64_t t_stride, int64_t n, float* loss, float* dout6,
+                        void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !sched || !out6 || !x_start || !x_noisy || !t || !loss || (t_stride != 0 && t_stride != 1))
+    return SO3X_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < so3x_prevstep_workspace_bytes(n)) return SO3X_ERR_WORKSPACE;
+  const int grid = grid_for_tiles((n + kTile - 1) / kTile);
+  hipLaunchKernelGGL(k_prevstep<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)s, sched, T, out6, x_start, x_noisy, t, t_stride, n,
+                     1.0f / (float)n, reinterpret_cast<double*>(workspace), dout6, (float*)nullptr);
   hipLaunchKernelGGL(k_sum_partials_f, dim3(1), dim3(256), 0, (hipStream_t)s, (const double*)workspace, grid, 1.0 / (double)n, loss);
   return check_launch();
 }

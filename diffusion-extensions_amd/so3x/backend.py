@@ -36,7 +36,7 @@ SYMBOLS = (
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
     "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd", "so3x_resnet_stash_bytes", "so3x_resnet_fwd_stash",
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
-    "so3x_prevstep_loss",
+    "so3x_prevstep_loss", "so3x_prevstep_loss6",
 )
 
 
@@ -817,6 +817,36 @@ class _PrevstepLoss(torch.autograd.Function):
 
 def prevstep_loss(sched, x_recon, x_start, x_noisy, t):
     return _PrevstepLoss.apply(sched, x_recon, x_start, x_noisy, t)
+
+
+class _PrevstepLoss6(torch.autograd.Function):
+    """_PrevstepLoss with x_recon = six2rmat(out6) applied inside: six2rmat, the loss and six2rmat's backward in one kernel"""
+
+    @staticmethod
+    def forward(ctx, sched, out6, x_start, x_noisy, t):
+        out6 = _dev(out6, "out6").reshape(-1, 6)
+        x_start = _rot_in(x_start, "x_start")
+        x_noisy = _rot_in(x_noisy, "x_noisy")
+        n = out6.shape[0]
+        tt, stride = _t_arg(t, n)
+        loss = torch.empty(1, dtype=torch.float32, device=out6.device)
+        d6 = torch.empty_like(out6)
+        ws = _workspace_small(out6.device, lib().so3x_prevstep_workspace_bytes(_i64(n)))
+        with _Guard(out6):
+            _check(lib().so3x_prevstep_loss6(_stream(out6), _ptr(sched), C.c_int(sched.shape[1]), _ptr(out6), _ptr(x_start),
+                                             _ptr(x_noisy), _ptr(tt), _i64(stride), _i64(n), _ptr(loss), _ptr(d6), _ptr(ws),
+                                             C.c_size_t(ws.numel())), "prevstep_loss6")
+        ctx.save_for_backward(d6)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d6,) = ctx.saved_tensors
+        return None, d6 * g, None, None, None
+
+
+def prevstep_loss6(sched, out6, x_start, x_noisy, t):
+    return _PrevstepLoss6.apply(sched, out6, x_start, x_noisy, t)
 
 
 def prevstep_step(sched, x_start, x_noisy, t):

@@ -208,9 +208,14 @@ class SO3Diffusion(nn.Module):
             self.rng_counter += 1
         net = self._fused_net()
         # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
+        if prevstep and net is not None and net.out_type == "rotmat":
+            # the fused networks hand over their raw 6 outputs: six2rmat, posterior mean, step = x_noisy^T @ mean,
+            # rmat_dist(x_recon, step)^2 and the gradient back through six2rmat are one kernel
+            out6 = net(x_noisy, t, t_table=self.num_timesteps, raw=True)
+            return _b.prevstep_loss6(self._sched, out6, x_start, x_noisy, t)
         x_recon = net(x_noisy, t, t_table=self.num_timesteps) if net is not None else self.denoise_fn(x_noisy, t)
         if prevstep:
-            # posterior mean (q_posterior), step = x_noisy^T @ mean, rmat_dist(x_recon, step)^2 and its gradient: one kernel
+            # any other denoiser returns rotations: posterior mean, step, distance^2 and its gradient wrt x_recon in one kernel
             return _b.prevstep_loss(self._sched, x_recon, x_start, x_noisy, t)
         return _b.mse_loss(x_recon, target)
 

@@ -89,13 +89,15 @@ class RotPredict(nn.Module):
     def precision_code(self) -> int:
         return _PRECISIONS[self.precision]
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None):
+    def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None, raw: bool = False):
+        """raw=True returns the network's [.., d_out] outputs without the six2rmat of out_type="rotmat" (SO3Diffusion's
+        prevstep loss applies it inside its own fused kernel)"""
         tt = self.t_table if t_table is None else int(t_table)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
             out = _ScoreMLPFn.apply(x, t, self.flat_params(), self.precision_code, tt)
         else:
             out = _b.mlp_fwd(self.flat_params_nograd(), x, t, self.precision_code, tt)
-        return _b.six2rmat(out) if self.out_type == "rotmat" else out
+        return _b.six2rmat(out) if (self.out_type == "rotmat" and not raw) else out
 
 
 def main(argv=None):

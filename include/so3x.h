@@ -289,6 +289,12 @@ size_t so3x_prevstep_workspace_bytes(int64_t n);
 int so3x_prevstep_loss(so3x_stream_t s, const float* sched, int T, const float* x_recon, const float* x_start,
                        const float* x_noisy, const int64_t* t, int64_t t_stride, int64_t n, float* loss, float* dx_recon,
                        float* step_out, void* workspace, size_t workspace_bytes);
+/* The same with x_recon = six2rmat(out6) applied inside (RotPredict(out_type="rotmat") under loss_type="prevstep"):
+ * out6[n][6] = the network's raw outputs, dout6 (optional) = d loss / d out6 -- six2rmat, the loss and six2rmat's backward
+ * in one pass instead of three kernels. */
+int so3x_prevstep_loss6(so3x_stream_t s, const float* sched, int T, const float* out6, const float* x_start,
+                        const float* x_noisy, const int64_t* t, int64_t t_stride, int64_t n, float* loss, float* dout6,
+                        void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

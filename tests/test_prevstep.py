@@ -260,3 +260,23 @@ def test_prevstep_training_reduces_the_loss_and_runs_as_a_graph(B):
     later = [float(g.step(x)) for _ in range(150)]
     assert all(np.isfinite(first + later))
     assert np.mean(later[-20:]) < 0.8 * np.mean(first)
+
+
+@pytest.mark.gpu
+def test_fused_prevstep_with_six2rmat_inside_equals_the_composition(B):
+    """so3x_prevstep_loss6 (six2rmat + loss + six2rmat backward in one kernel) against six2rmat -> so3x_prevstep_loss"""
+    sched = dev(B.schedule_from_betas(B.cosine_beta_schedule(200)))
+    for n in (1, 255, 3000):
+        rng = np.random.default_rng(n)
+        out6 = dev(rng.standard_normal((n, 6)).astype(np.float32))
+        xs = B.quat_to_rmat(dev(rng.standard_normal((n, 4)).astype(np.float32)))
+        xn = B.quat_to_rmat(dev(rng.standard_normal((n, 4)).astype(np.float32)))
+        t = dev(rng.integers(0, 200, n), torch.int64)
+        a = out6.clone().requires_grad_(True)
+        la = B.prevstep_loss6(sched, a, xs, xn, t)
+        la.backward()
+        b = out6.clone().requires_grad_(True)
+        lb = B.prevstep_loss(sched, B.six2rmat(b), xs, xn, t)
+        lb.backward()
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+        assert float((a.grad - b.grad).abs().max()) <= 1e-6 * max(1.0, float(b.grad.abs().max()))

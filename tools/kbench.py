@@ -184,6 +184,17 @@ def main():
             ms = timeit(lambda: tg.graph.replay(), reps=10, warm=3)
             print(json.dumps({"k": "train_step_graph_" + ("wide" if wide else "mlp65"), "n": n, "ms": ms, "samples_per_s": n / ms * 1e3,
                               "loss": float(tg.loss)}))
+    if "prevstep" in which:
+        from so3x.graphs import TrainStepGraph
+        torch.manual_seed(0)
+        pnet = RotPredict(out_type="rotmat", precision="bf16").to(dev)
+        pproc = SO3Diffusion(pnet, timesteps=1000, loss_type="prevstep").to(dev)
+        popt = torch.optim.Adam(pnet.parameters(), lr=3e-4, fused=True, capturable=True)
+        n = 1 << 19
+        x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+        tg = TrainStepGraph(pproc, popt, x0.shape)
+        ms = timeit(lambda: tg.graph.replay(), reps=10, warm=3)
+        print(json.dumps({"k": "train_step_graph_prevstep_rotmat", "n": n, "ms": ms, "samples_per_s": n / ms * 1e3, "loss": float(tg.loss)}))
     if "train" in which:
         n = 1 << 19
         x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
