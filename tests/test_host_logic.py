@@ -79,6 +79,31 @@ def test_error_paths_return_codes_not_crashes():
     assert 1000 * 96 * 4 < ws32 < 200 * 1024 + 1000 * 96 * 4
 
 
+def test_error_paths_of_the_round_1_additions():
+    """argument validation returns codes before anything touches a device (no GPU needed)"""
+    lib = B.lib()
+    i64, ci = C.c_int64, C.c_int
+    assert lib.so3x_six2rmat(None, None, None, i64(-1)) == -1 and lib.so3x_six2rmat(None, None, None, i64(0)) == 0
+    assert lib.so3x_six2rmat(None, None, None, i64(5)) == -1                      # null buffers with n > 0
+    assert lib.so3x_six2rmat_bwd(None, None, None, None, i64(0)) == 0 and lib.so3x_six2rmat_bwd(None, None, None, None, i64(3)) == -1
+    assert lib.so3x_log_rmat_bwd(None, None, None, None, i64(-2)) == -1
+    assert lib.so3x_rmat_dist_bwd(None, None, None, None, None, None, i64(4)) == -1
+    assert lib.so3x_prevstep_loss(None, None, ci(10), None, None, None, None, i64(1), i64(0), None, None, None, None, C.c_size_t(0)) == -1
+    assert lib.so3x_prevstep_loss6(None, None, ci(10), None, None, None, None, i64(1), i64(4), None, None, None, C.c_size_t(0)) == -1
+    lib.so3x_prevstep_workspace_bytes.restype = C.c_size_t
+    assert 0 < lib.so3x_prevstep_workspace_bytes(i64(1 << 20)) <= 1 << 20
+    # n_out must be 3 or 6 on the six network entry points
+    for bad in (0, 4, 7):
+        assert lib.so3x_mlp_fwd(None, None, None, None, i64(1), None, i64(0), ci(bad), ci(1), ci(10), None, C.c_size_t(0)) == -1
+        assert lib.so3x_resnet_fwd(None, None, None, None, i64(1), None, i64(0), ci(bad), ci(1), ci(10), None, C.c_size_t(0)) == -1
+        assert lib.so3x_mlp_bwd(None, None, None, None, i64(1), None, None, i64(0), ci(bad), ci(1), ci(10), None, None, C.c_size_t(0)) == -1
+    # workspace too small -> -2 (before any launch)
+    one = C.c_void_p(1)  # never dereferenced: the size check comes first
+    assert lib.so3x_mlp_fwd(None, one, one, one, i64(1), one, i64(8), ci(3), ci(1), ci(10), one, C.c_size_t(16)) == -2
+    assert lib.so3x_resnet_fwd(None, one, one, one, i64(1), one, i64(8), ci(3), ci(1), ci(10), one, C.c_size_t(16)) == -2
+    assert b"argument" in lib.so3x_error_string(-1).lower() or b"invalid" in lib.so3x_error_string(-1).lower()
+
+
 def test_cpu_tensors_are_refused_loudly():
     from so3x import util
     with pytest.raises(B.So3xError, match="no CPU path"):
@@ -215,5 +240,5 @@ def test_small_helpers_of_the_reference_namespace():
     n = noise_like((5, 3, 3), "cpu", repeat=True)
     assert n.shape == (5, 3, 3) and torch.equal(n[0], n[4]) and not torch.equal(noise_like((5, 3), "cpu")[0], noise_like((5, 3), "cpu")[1])
     s = models.Siren(3, 8, scale=30)
-    assert s(torch.randn(7, 3)).shape == (7, 8) and float(s.positional.weight.abs().max()) <= 30 * (6 / 3) ** 0.5 + 1e-6
+    assert s(torch.randn(7, 3)).shape == (7, 8) and float(s.positional.weight.detach().abs().max()) <= 30 * (6 / 3) ** 0.5 + 1e-6
     assert all(not p.requires_grad for p in models.Siren(3, 8, optimize=False, post_scale=False).parameters())
