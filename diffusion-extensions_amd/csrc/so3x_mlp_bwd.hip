@@ -429,8 +429,20 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
   const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + p;
   float s = 0.0f;
-  if (idx < np)
-    for (int b = g; b < nslabs; b += 8) s += slabs[(size_t)b * NPARAMS_MAX + idx];
+  if (idx < np) {
+    // four independent partial sums: the loads of a group's slabs are in flight together instead of one dependent
+    // add per ~1 us round trip (fixed order, so still deterministic)
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = g;
+    for (; b + 24 < nslabs; b += 32) {
+      s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
+      s1 += slabs[(size_t)(b + 8) * NPARAMS_MAX + idx];
+      s2 += slabs[(size_t)(b + 16) * NPARAMS_MAX + idx];
+      s3 += slabs[(size_t)(b + 24) * NPARAMS_MAX + idx];
+    }
+    for (; b < nslabs; b += 8) s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
+    s = (s0 + s1) + (s2 + s3);
+  }
   part[g][p] = s;
   __syncthreads();
   if (g == 0 && idx < np) {

@@ -837,8 +837,12 @@ __global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restric
   if (o >= rows || f >= 256) return;
   const int prow = l < NBLK ? o : row_of_head(o);  // the head's outputs sit in tile rows 0..3, 8, 9
   const float* P = partial + (size_t)l * DW_SPLITS * 65536 + prow * 256 + f;
-  float s = 0.0f;
-  for (int k = 0; k < DW_SPLITS; k++) s += P[(size_t)k * 65536];
+  static_assert(DW_SPLITS % 4 == 0, "four interleaved partial sums");
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // independent chains: the 36 loads overlap (fixed order: deterministic)
+  for (int k = 0; k < DW_SPLITS; k += 4) {
+    s0 += P[(size_t)k * 65536]; s1 += P[(size_t)(k + 1) * 65536]; s2 += P[(size_t)(k + 2) * 65536]; s3 += P[(size_t)(k + 3) * 65536];
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   float* base = dparams + (size_t)l * LAYER_STRIDE;
   if (f < DW) base[o * DW + f] = s;
   else base[rows * DW + o] = s;
