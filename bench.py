@@ -101,44 +101,84 @@ def pmc_mfma_busy(kernel):
         return None
 
 
-def train_step_extra(B, torch, proc, net, n=1 << 19, reps=10):
-    """BASELINE config 4 on this GPU's shard: forward noising + loss + backward + Adam at 2^19 samples (bf16 MLP), the
-    whole step replayed as one captured hipGraph (so3x.graphs.TrainStepGraph); the eager Python loop is timed beside it."""
-    import copy
+def pmc_valu_busy(kernel):
+    """vector-ALU busy fraction of `kernel` (SQ_ACTIVE_INST_VALU over SIMD-cycles) from the committed PMC pass, or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["mfma_utilisation"][kernel]["valu_busy_frac"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def train_leg(B, torch, ctx, T, n=1 << 19, reps=20, warm=5):
+    """BASELINE config 4 on every rank: one training step of so3_train.py (noising + RotPredict + MSE + backward + gradient
+    all-reduce + Adam) on this GPU's shard of 2^19 rotations (global batch 2^19 x N; 2^22 at N = 8), bf16 MLP operands,
+    replayed as a captured hipGraph (so3x.graphs.TrainStepGraph: the RCCL all-reduce of the flat 69 KB gradient inside the
+    graph, or between two graphs where the stack cannot capture it).  Timed like the headline: barrier, `reps` replays,
+    synchronize, max over ranks.  `allreduce_us` = the collective alone, timed on the same flat buffer."""
+    import torch.distributed as dist
+    from so3x import optim as so3x_optim
     from so3x.graphs import TrainStepGraph
     from so3x.diffusion import SO3Diffusion
-    dev = torch.device("cuda", torch.cuda.current_device())
-    x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev))
+    from so3x.so3_train import RotPredict
+    from so3x import parallel
+    dev = ctx.device
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
+    parallel.broadcast_parameters(net, ctx)
+    proc = SO3Diffusion(net, timesteps=T).to(dev)
+    proc.index_base = ctx.rank * n
+    opt = so3x_optim.Adam(net, lr=3e-4)
+    x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + ctx.rank)))
 
-    def timed(fn, reps):
-        for _ in range(3):
-            fn()
+    def barrier():
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        if ctx.world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def wall(fn, reps):
+        barrier()
+        t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        el = time.perf_counter() - t0
+        barrier()
+        tm = torch.tensor([el], device=dev, dtype=torch.float64)
+        if ctx.world_size > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item()) / reps
 
-    opt = torch.optim.Adam(net.parameters(), lr=3e-4, fused=True)  # same update, one multi-tensor launch
-
-    def step():
-        loss = proc(x0)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-
-    eager_ms = timed(step, reps)
-    gnet = copy.deepcopy(net)
-    gproc = SO3Diffusion(gnet, timesteps=proc.num_timesteps).to(dev)
-    gopt = torch.optim.Adam(gnet.parameters(), lr=3e-4, fused=True, capturable=True)
-    tg = TrainStepGraph(gproc, gopt, x0.shape)
-    ms = timed(tg.graph.replay, reps)
-    return {"samples_per_s": n / (ms * 1e-3), "ms_per_step": ms, "batch": n, "mlp_operands": net.precision,
-            "algorithmic_TFLOPs": 94120 * n / (ms * 1e-3) / 1e12, "optimizer": "torch Adam (fused=True, capturable=True)",
-            "mode": "one captured hipGraph per step", "eager_python_loop_ms_per_step": eager_ms}
+    out = {"batch_per_gpu": n, "global_batch": n * ctx.world_size, "ranks": ctx.world_size, "mlp_operands": "bf16",
+           "optimizer": "so3x.optim.Adam (one launch on the flat buffers; torch.optim.Adam's update rule)",
+           "collective": None if ctx.world_size == 1 else f"{dist.get_backend()} all_reduce of {net.flat_data().numel()} fp32, once per step"}
+    if ctx.world_size == 1:  # the eager Python loop beside it (host-bound)
+        def eager():
+            loss = proc(x0)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        for _ in range(3):
+            eager()
+        out["eager_python_loop_ms_per_step"] = wall(eager, 10) * 1e3
+    tg = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size)
+    for _ in range(warm):
+        tg.replay()
+    sec = wall(tg.replay, reps)
+    loss = parallel.mean_scalar(tg.loss.clone(), ctx)
+    out.update({"ms_per_step": sec * 1e3, "samples_per_s": n * ctx.world_size / sec, "mode": {
+        "in_graph": "one captured hipGraph per step" + ("" if ctx.world_size == 1 else ", all-reduce inside"),
+        "split": "two captured hipGraphs per step with the all-reduce between them"}[tg.mode],
+        "algorithmic_TFLOPs_per_gpu": 94120 * n / sec / 1e12, "loss": loss, "finite": bool(loss == loss), "steps_timed": reps})
+    if ctx.world_size > 1:
+        flat = net.gather_flat_grad()
+        def ar():
+            parallel.allreduce_flat(flat, ctx)
+        for _ in range(5):
+            ar()
+        out["allreduce_us"] = wall(ar, 50) * 1e6
+    return out
 
 
 def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
@@ -280,30 +320,60 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run_steps(B, params, proc._sched, trap_p, x, T, args.warmup, 0, index_base, prec, per_launch=args.steps_per_launch,
+    RAMP = 200  # untimed clock ramp before anything is timed, whatever --warmup says: the chip needs ~20 ms under load
+    run_steps(B, params, proc._sched, trap_p, x, T, RAMP, 0, index_base, prec, per_launch=100, guide_p=proc._guide_p)
+    run_steps(B, params, proc._sched, trap_p, x, T, args.warmup, 0, index_base, prec, rng_offset=RAMP, per_launch=args.steps_per_launch,
               guide_p=proc._guide_p)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()                        # same (current) stream the C ABI launches on
-    launches = run_steps(B, params, proc._sched, trap_p, x, T, args.steps, 0, index_base, prec, rng_offset=args.warmup,
+    launches = run_steps(B, params, proc._sched, trap_p, x, T, args.steps, 0, index_base, prec, rng_offset=RAMP + args.warmup,
                          per_launch=args.steps_per_launch, guide_p=proc._guide_p)
-    ev1.record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
-    dev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([el], device=dev, dtype=torch.float64)
     if ctx.world_size > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     el = float(tmax.item())
     ok = bool(torch.isfinite(x).all().item())
 
+    # ---- roofline of the dominant kernel on a FIXED shape (100 steps per launch, 5 launches, HIP events on the launch
+    #      stream): the shape the rocprofv3 summaries under profiles/ were taken on, whatever --steps was
+    RL_STEPS, RL_LAUNCHES = 100, 5
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()                        # same (current) stream the C ABI launches on
+    for i in range(RL_LAUNCHES):
+        B.p_sample_chain(params, proc._sched, trap_p, x, T - 1 - 100 * i, RL_STEPS, seed=1, rng_offset=10_000 + 100 * i,
+                         index_base=index_base, precision=prec, out=x, guide_p=proc._guide_p)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms_per_launch = ev0.elapsed_time(ev1) / RL_LAUNCHES
+    flop_per_launch = MLP_FLOP_PER_SAMPLE * n * RL_STEPS
+    tflops = flop_per_launch / (ms_per_launch * 1e-3) / 1e12
+
+    # ---- the metric verbatim: one complete p_sample_loop, B rotations through all T reverse steps (diffusion.py:328-337)
+    barrier()
+    t1 = time.perf_counter()
+    xf = proc.p_sample_loop((n,))
+    torch.cuda.synchronize()
+    full_s = time.perf_counter() - t1
+    tfull = torch.tensor([full_s], device=dev, dtype=torch.float64)
+    if ctx.world_size > 1:
+        torch.distributed.all_reduce(tfull, op=torch.distributed.ReduceOp.MAX)
+    full_s = float(tfull.item())
+    full_ok = bool(torch.isfinite(xf).all().item())
+    del xf
+
+    # ---- BASELINE config 4: the training step, on every rank (gradient all-reduce when N > 1)
+    train = None
+    if not args.no_extras:
+        try:
+            train = train_leg(B, torch, ctx, T)
+        except Exception as e:  # report, never hide
+            train = {"error": repr(e)}
+
     if ctx.rank == 0:
         total = ctx.world_size * n * args.steps
-        flop_per_launch = MLP_FLOP_PER_SAMPLE * n * args.steps / launches
-        ms_per_launch = dev_ms / launches
-        tflops = flop_per_launch / (ms_per_launch * 1e-3) / 1e12
         line = {
             "metric": "SO(3) sample-steps/sec, reverse p_sample chain with score MLP", "value": total / el,
             "unit": "sample-steps/s", "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
@@ -312,19 +382,25 @@ def main():
             "config": {"workload": "BASELINE config 3: full reverse p_sample chain with RotPredict score MLP",
                        "batch_per_gpu": n, "global_batch": ctx.world_size * n, "timesteps": T,
                        "mlp_operands": args.precision, "rotation_state": "fp32", "noise": "in-kernel Philox4x32-10",
-                       "parallelism": f"batch-sharded x{ctx.world_size}, no collective"},
+                       "parallelism": f"batch-sharded x{ctx.world_size}, no collective",
+                       "launches_timed": launches, "clock_ramp_steps_untimed": RAMP},
             "finite": ok,
+            "full_chain": {"what": "one complete p_sample_loop: IGSO3(1) start, T reverse steps, ONE kernel launch", "batch_per_gpu": n,
+                           "timesteps": T, "seconds": full_s, "sample_steps_per_s": ctx.world_size * n * T / full_s, "finite": full_ok},
             "roofline": {"kernel": "k_p_sample_chain", "bound": "mfma", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=int(args.steps / launches),
-                                                precision=args.precision),
+                         "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=RL_STEPS, precision=args.precision),
                          "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_p_sample_chain"),
-                         "launches": launches, "steps_per_launch": args.steps / launches, "ms_per_launch": ms_per_launch,
+                         "valu_busy_frac_pmc": pmc_valu_busy("k_p_sample_chain"),
+                         "launches": RL_LAUNCHES, "steps_per_launch": RL_STEPS, "ms_per_launch": ms_per_launch,
+                         "sample_steps_per_s": n * RL_STEPS / (ms_per_launch * 1e-3),
                          "flop_per_sample_step": MLP_FLOP_PER_SAMPLE,
-                         "note": "algorithmic MLP flops vs the dense bf16 MFMA peak; the kernel's real bound is the VALU issue "
-                                 "port (546 transcendentals + ~1,300 other vector instructions per 64-sample wave-step, "
-                                 "~96 % of that floor, DESIGN.md section 4); algorithmic HBM traffic is 72 B/sample per launch"},
+                         "note": "algorithmic MLP flops vs the dense bf16 MFMA peak, on a fixed 100-step launch timed with HIP events "
+                                 "(the shape profiled under profiles/); the kernel's real bound is the VALU issue port "
+                                 "(valu_busy_frac_pmc; DESIGN.md section 4); algorithmic HBM traffic is 72 B/sample per launch"},
         }
+        if train is not None:
+            line["train_step"] = train
         if not args.no_extras and ctx.world_size == 1:
             try:
                 line["igso3_eval"] = igso3_eval_roofline(B, torch)
@@ -332,10 +408,6 @@ def main():
                 line["igso3_eval"]["at_n_2p24"] = {k: big[k] for k in ("achieved", "frac", "ms", "evals_per_s")}
             except Exception as e:  # report, never hide
                 line["igso3_eval"] = {"error": repr(e)}
-            try:
-                line["train_step"] = train_step_extra(B, torch, proc, net)
-            except Exception as e:
-                line["train_step"] = {"error": repr(e)}
             try:
                 line["wide_net"] = wide_net_extra(B, torch, proc._sched, trap_p)
             except Exception as e:

@@ -203,4 +203,10 @@ __device__ __forceinline__ void store_rot9(float* __restrict__ g, int64_t idx, c
 // scalar-per-sample operand with stride 0 (broadcast) or 1
 __device__ __forceinline__ float load_scalar(const float* p, int64_t stride, int64_t i) { return p[i * stride]; }
 
+// so3x_diffusion.hip: so3x_q_sample_target with the option of drawing the timesteps in the kernel (used by so3x_train_fwd)
+int launch_q_sample_target(hipStream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q, const float* x0,
+                           const int64_t* t, int64_t* t_draw, int quirk_col0, const float* noise_in, const float* axes,
+                           const float* unif, uint64_t seed, uint64_t rng_offset, const int64_t* rng_offset_dev, int64_t index_base,
+                           float* x_t, float* target, float* noise_out, int64_t n);
+
 }  // namespace so3x

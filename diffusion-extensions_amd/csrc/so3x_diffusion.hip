@@ -20,10 +20,13 @@ namespace {
 // Wave-private staging (one 64-sample tile per wave, no workgroup barrier), launched one tile per wave on an
 // oversubscribed grid like k_logprob_score: the per-sample CDF-row search is a chain of ~10 dependent L2 loads, and
 // only other resident waves hide it.
+// t_draw != nullptr: the timesteps are not given but drawn here -- t_i = floor(T * w_i / 2^32) from the fourth word of the
+// sample's Philox block (the other three feed the noise), written to t_draw for the kernels that follow; SO3Diffusion.forward's
+// `t = randint(0, T, (b,))` (diffusion.py:373) keyed, like the noise, by the global sample index.
 __global__ void __launch_bounds__(kBlock, 6)
 k_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q,
                   const uint16_t* __restrict__ guide_q, const float* __restrict__ x0,
-                  const int64_t* __restrict__ t, int quirk_col0, const float* __restrict__ noise_in,
+                  const int64_t* __restrict__ t, int64_t* __restrict__ t_draw, int quirk_col0, const float* __restrict__ noise_in,
                   const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
                   const int64_t* __restrict__ rng_offset_dev, int64_t index_base, float* __restrict__ x_t,
                   float* __restrict__ target, float* __restrict__ noise_out, int64_t n) {
@@ -34,13 +37,23 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
   const int64_t ntiles = (n + kWave - 1) / kWave;
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
-  const int64_t wrow_t = quirk_col0 ? t[0] : -1;  // distributions.py:42-43: column 0 == sample 0's eps
+  auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
+  // distributions.py:42-43: column 0 == sample 0's eps
+  const int64_t wrow_t = !quirk_col0 ? -1 : (t_draw ? drawn_t(philox4x32_10(seed, (uint64_t)index_base, rng_offset).w) : t[0]);
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kWave;
     const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
     const int64_t idx = base + lane;
     const bool live = lane < cnt;
-    const int64_t tt = t[live ? idx : base];
+    Philox4 r;
+    if (t_draw || (!noise_in && !axes)) r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
+    int64_t tt;
+    if (t_draw) {
+      tt = drawn_t(r.w);
+      if (live) t_draw[idx] = tt;
+    } else {
+      tt = t[live ? idx : base];
+    }
     float nz[9];
     if (noise_in) {
       wave_load_rows<9>(noise_in, base, cnt, wl, nz);
@@ -55,7 +68,6 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
         ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
         u = live ? unif[idx] : 0.5f;
       } else {
-        Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
         unit_axis(r.x, r.y, ax);
         u = u01(r.z);
       }
@@ -83,15 +95,23 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
   }
 }
 
+// tvec == nullptr: one shared timestep t (p_sample, diffusion.py:315-326); else per-sample timesteps tvec[i * t_stride], as the
+// reference's extract(coef, t, shape) gathers them (diffusion.py:291-306)
 __global__ void __launch_bounds__(kBlock)
 k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, const float* __restrict__ v, int t,
-         float* __restrict__ x0hat, float* __restrict__ mean, int64_t n) {
+         const int64_t* __restrict__ tvec, int64_t t_stride, float* __restrict__ x0hat, float* __restrict__ mean, int64_t n) {
   __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
-  const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t], c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
   const int64_t ntiles = (n + kTile - 1) / kTile;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * kTile;
     const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
+    int ts = t;
+    if (tvec) {
+      const int64_t i = base + ((int)threadIdx.x < cnt ? threadIdx.x : 0);
+      const int64_t tv = tvec[i * t_stride];
+      ts = (int)(tv < 0 ? 0 : (tv >= T ? T - 1 : tv));
+    }
+    const float a = sched[S_RECIP * T + ts], b = sched[S_RECIPM1 * T + ts], c1 = sched[S_COEF1 * T + ts], c2 = sched[S_COEF2 * T + ts];
     float xx[9], vv[3], xh[9], mm[9];
     load_rows<9>(x, base, cnt, sm, xx);
     load_rows<3>(v, base, cnt, sm, vv);
@@ -180,6 +200,25 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
 
 }  // namespace
 
+namespace so3x {
+// so3x_q_sample_target with the option of drawing the timesteps in the kernel (t == nullptr, t_draw = where they go)
+int launch_q_sample_target(hipStream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q, const float* x0,
+                           const int64_t* t, int64_t* t_draw, int quirk_col0, const float* noise_in, const float* axes,
+                           const float* unif, uint64_t seed, uint64_t rng_offset, const int64_t* rng_offset_dev, int64_t index_base,
+                           float* x_t, float* target, float* noise_out, int64_t n) {
+  if (n < 0 || T <= 0 || (n && (!sched || !x0 || ((t == nullptr) == (t_draw == nullptr)))) || (n && !noise_in && !trap_q) ||
+      ((axes == nullptr) != (unif == nullptr)))
+    return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  const int64_t nt64 = (n + kWave - 1) / kWave;
+  int64_t want = (nt64 + 3) / 4;   // one tile per wave
+  if (want > (1 << 20)) want = 1 << 20;
+  hipLaunchKernelGGL(k_q_sample_target, dim3((unsigned)want), dim3(kBlock), 0, s, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0,
+                     noise_in, axes, unif, seed, rng_offset, rng_offset_dev, index_base, x_t, target, noise_out, n);
+  return check_launch();
+}
+}  // namespace so3x
+
 extern "C" {
 
 int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
@@ -187,17 +226,9 @@ int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float
                          int quirk_col0, const float* noise_in, const float* axes, const float* unif, uint64_t seed,
                          uint64_t rng_offset, const int64_t* rng_offset_dev, int64_t index_base, float* x_t, float* target,
                          float* noise_out, int64_t n) {
-  if (n < 0 || T <= 0 || (n && (!sched || !x0 || !t)) || (n && !noise_in && !trap_q) ||
-      ((axes == nullptr) != (unif == nullptr)))
-    return SO3X_ERR_INVALID_ARG;
-  if (n == 0) return SO3X_OK;
-  const int64_t nt64 = (n + kWave - 1) / kWave;
-  int64_t want = (nt64 + 3) / 4;   // one tile per wave
-  if (want > (1 << 20)) want = 1 << 20;
-  hipLaunchKernelGGL(k_q_sample_target, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, sched,
-                     T, trap_q, guide_q, x0, t, quirk_col0, noise_in, axes, unif, seed, rng_offset, rng_offset_dev, index_base, x_t,
-                     target, noise_out, n);
-  return check_launch();
+  if (n && !t) return SO3X_ERR_INVALID_ARG;
+  return so3x::launch_q_sample_target((hipStream_t)s, sched, T, trap_q, guide_q, x0, t, nullptr, quirk_col0, noise_in, axes, unif, seed,
+                                      rng_offset, rng_offset_dev, index_base, x_t, target, noise_out, n);
 }
 
 int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, const float* v, int t, float* x0hat,
@@ -205,7 +236,16 @@ int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, cons
   if (n < 0 || T <= 0 || t < 0 || t >= T || (n && (!sched || !x || !v || !mean))) return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
   hipLaunchKernelGGL(k_p_mean, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, sched, T, x, v,
-                     t, x0hat, mean, n);
+                     t, (const int64_t*)nullptr, (int64_t)0, x0hat, mean, n);
+  return check_launch();
+}
+
+int so3x_p_mean_t(so3x_stream_t s, const float* sched, int T, const float* x, const float* v, const int64_t* t, int64_t t_stride,
+                  float* x0hat, float* mean, int64_t n) {
+  if (n < 0 || T <= 0 || (t_stride != 0 && t_stride != 1) || (n && (!sched || !x || !v || !mean || !t))) return SO3X_ERR_INVALID_ARG;
+  if (n == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_p_mean, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s, sched, T, x, v,
+                     0, t, t_stride, x0hat, mean, n);
   return check_launch();
 }
 

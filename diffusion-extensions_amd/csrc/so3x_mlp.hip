@@ -36,8 +36,9 @@ constexpr int PREP_IMG_BLOCKS = 32, PREP_WT_BLOCKS = 32;
 template <int PREC, int VAR>
 __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, void* __restrict__ img, void* __restrict__ wt, int nout,
                                               Freqs fr, int T, float scale, float* __restrict__ beff, float* __restrict__ emb_tab,
-                                              __bf16* __restrict__ h0_tab) {
+                                              __bf16* __restrict__ h0_tab, unsigned* __restrict__ zero_word) {
   constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;  // elements per lane per fragment
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // arrival ticket of the launch that follows
   if (blockIdx.x < PREP_IMG_BLOCKS) {
     if (!img) return;
     const int total = n_frags<PREC, VAR>() * 64 * EPL;
@@ -133,13 +134,14 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
   }
 }
 
-template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws, int nout, void* wt, bool want_image) {
+template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws, int nout, void* wt, bool want_image,
+                                               unsigned* zero_word) {
   const bool tables = chain_layout(VAR) && T > 0;
   float* beff = tables ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR)) : nullptr;
   float* emb = (tables && VAR == GATHER) ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
   __bf16* h0 = (tables && VAR == GATHER) ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
   hipLaunchKernelGGL((k_prep<PREC, VAR>), dim3(PREP_IMG_BLOCKS + PREP_WT_BLOCKS + (tables ? T : 0)), dim3(256), 0, s, params,
-                     want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb, h0);
+                     want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb, h0, zero_word);
   return check_launch();
 }
 
@@ -170,15 +172,15 @@ int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace) 
   return check_launch();
 }
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout, void* wt,
-                bool want_image) {
+                bool want_image, unsigned* zero_word) {
   if (precision == SO3X_PREC_F32) {
-    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace, nout, wt, want_image);
-    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace, nout, wt, want_image);
-    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace, nout, wt, want_image);
+    if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word);
+    if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace, nout, wt, want_image, zero_word);
+    return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace, nout, wt, want_image, zero_word);
   }
-  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image);
-  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout, wt, want_image);
-  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout, wt, want_image);
+  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word);
+  if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout, wt, want_image, zero_word);
+  return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout, wt, want_image, zero_word);
 }
 }  // namespace mlp
 }  // namespace so3x

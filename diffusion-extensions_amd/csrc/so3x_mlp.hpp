@@ -438,8 +438,9 @@ size_t image_bytes_rt(int precision, int variant);
 // effective-bias table beff[T][96] right after it (16-B aligned).
 // One launch: [the weight image] [the transposed image -> wt, optional] [the per-timestep tables when T > 0].
 // want_image = false skips the forward image (the backward with a stash never reads it).
+// zero_word (optional): a device word the launch clears (the arrival ticket of a kernel that follows in the stream).
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout = 3,
-                void* wt = nullptr, bool want_image = true);
+                void* wt = nullptr, bool want_image = true, unsigned* zero_word = nullptr);
 int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace);
 size_t beff_offset(int precision, int variant);
 // tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32

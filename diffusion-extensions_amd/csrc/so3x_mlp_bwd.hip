@@ -424,7 +424,8 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
 // 32 parameters x 8 slab groups per block: coalesced 128-B reads, 8-way split of the slab loop, fixed
 // summation order (deterministic)
 __global__ void __launch_bounds__(256)
-k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np) {
+k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
+             const float* __restrict__ gscale = nullptr) {
   __shared__ float part[8][33];
   const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + p;
@@ -449,6 +450,7 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
     float t = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) t += part[k][p];
+    if (gscale) t *= gscale[0];
     dparams[idx] = accumulate ? dparams[idx] + t : t;
   }
 }
@@ -572,13 +574,42 @@ __device__ __forceinline__ void zstash_load_layer(const char* tile_base, int lan
   z.p[16] = __builtin_bit_cast(Z33h::h2, reinterpret_cast<const uint32_t*>(lb + 4096)[lane]);
 }
 
+// Arrival ticket of a grid (MI355X_MICROARCH.md, hand-off table row 1): the calling thread has stored this block's
+// contribution with agent-scope (sc1) stores; it drains them, takes a ticket, and the block whose ticket is the last one
+// may read every block's contribution with agent-scope loads.  The last arriver resets the ticket, so the word is zero
+// again when the launch ends; the prep launch of the step clears it anyway (a fresh workspace holds garbage).  One
+// calling thread per block.
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (mine != gridDim.x - 1) return false;
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// What the fused MSE epilogue of the training forward needs (diffusion.py:357: F.mse_loss over the n x 3 outputs).
+struct LossArgs {
+  const float* target;   // [n][3] regression targets
+  float* dout;           // [n][3] d loss / d out = 2 (out - target) / (3 n)
+  float* loss;           // [1]
+  double* partial;       // [gridDim.x] per-block sums of squared differences
+  unsigned* ticket;      // arrival ticket, zero between launches
+  int64_t* rng_counter;  // optional: device-resident Philox offset of the noise draw, incremented once per step
+  float dscale;          // 2 / (3 n)
+  double inv_count;      // 1 / (3 n)
+};
+
 // Training forward (bf16 operands, per-timestep tables): the network output AND the stash above, so that the backward
 // does not run the forward again (that recompute was half of k_bwd_fused's time).  Same arithmetic as the recompute it
 // replaces: GATHER image (true pre-activations, no scale fold), pre-activations rounded to f16 before the activation.
-template <int PREC>
+// LOSS: the MSE of p_losses rides in the epilogue -- the lane that holds a sample's three outputs reads its target, writes
+// d loss / d out and adds to a running sum of squares; per-block sums are combined by the last block to arrive, in block
+// order (deterministic) -- so the loss, its gradient and the step's counter increment cost no launch of their own.
+template <int PREC, bool LOSS>
 __global__ void __launch_bounds__(256, 2)
 k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
-                const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n, int nout) {
+                const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n, int nout,
+                LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int VAR = GATHER;
   constexpr int FB = frag_bytes<PREC>();
@@ -588,6 +619,7 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
   const int64_t ntiles = (n + 31) / 32;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float sq = 0.0f;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     int64_t idx = tile * 32 + col;
     const bool live = idx < n;
@@ -610,11 +642,47 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     f32x16 last[1];
     hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
     if (live && h == 0) {  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
-      out[idx * nout] = last[0][0]; out[idx * nout + 1] = last[0][1]; out[idx * nout + 2] = last[0][2];
-      if (nout == 6) { out[idx * 6 + 3] = last[0][3]; out[idx * 6 + 4] = last[0][4]; out[idx * 6 + 5] = last[0][5]; }
+      if (out) {
+        out[idx * nout] = last[0][0]; out[idx * nout + 1] = last[0][1]; out[idx * nout + 2] = last[0][2];
+        if (nout == 6) { out[idx * 6 + 3] = last[0][3]; out[idx * 6 + 4] = last[0][4]; out[idx * 6 + 5] = last[0][5]; }
+      }
+      if constexpr (LOSS) {
+        const float d0 = last[0][0] - la.target[idx * 3], d1 = last[0][1] - la.target[idx * 3 + 1], d2 = last[0][2] - la.target[idx * 3 + 2];
+        la.dout[idx * 3] = d0 * la.dscale; la.dout[idx * 3 + 1] = d1 * la.dscale; la.dout[idx * 3 + 2] = d2 * la.dscale;
+        sq += d0 * d0 + d1 * d1 + d2 * d2;
+      }
     }
 #pragma unroll
     for (int l = 0; l < 4; l++) zstash_store_layer(zstash + (size_t)tile * ZSTASH_TILE, lane, l, z[l]);
+  }
+  if constexpr (LOSS) {
+    __shared__ double wsum[4];
+    __shared__ int is_last;
+    double v = (double)sq;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (lane == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double bs = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = last_block_arrives(la.ticket) ? 1 : 0;
+    }
+    __syncthreads();  // the other waves of the last block read the partials only behind this barrier
+    if (is_last) {
+      // every block's partial, two per thread (the grid has at most 512 blocks), summed in a fixed tree: deterministic
+      // whichever block arrives last, and 2 loads deep instead of a 512-long chain of L2 round trips
+      double a = 0.0;
+      for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+      if (lane == 0) wsum[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        la.loss[0] = (float)(((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * la.inv_count);
+        if (la.rng_counter) la.rng_counter[0] += 1;  // every reader of this step's offset ran in an earlier launch
+      }
+    }
   }
 }
 
@@ -896,6 +964,43 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
   }
 }
 
+// k_bwd_fused + the slab reduction for the whole batch; the images and tables are where launch_prep left them.
+inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, const float* beff, const float* emb, const uint4* h0,
+                            const float* R, const int64_t* t, int64_t t_stride, const float* dout, float* slabs, int64_t n,
+                            const char* zstash, int nout, float* dparams, const float* gscale) {
+  constexpr int PREC = SO3X_PREC_BF16;
+  constexpr int FUSED_LDS = image_bytes<PREC, GATHER>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
+  static PerDevice attr_f0, attr_f1;
+  if (int rc2 = ensure_dyn_lds(attr_f0, reinterpret_cast<const void*>(&k_bwd_fused<PREC, false>), FUSED_LDS)) return rc2;
+  if (int rc2 = ensure_dyn_lds(attr_f1, reinterpret_cast<const void*>(&k_bwd_fused<PREC, true>), FUSED_LDS)) return rc2;
+  const int64_t nt = (n + 31) / 32;
+  const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
+  if (zstash)
+    hipLaunchKernelGGL((k_bwd_fused<PREC, true>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
+                       emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
+  else
+    hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
+                       emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
+                     gscale);
+  return check_launch();
+}
+
+// Training-step workspace (so3x_train_fwd / so3x_train_bwd): what ONE prep launch builds for both halves of the step,
+// the dW partial slabs, the regression targets and the loss bookkeeping.
+struct TrainLayout { size_t wt, slabs, target, partial, ticket, end; };
+inline TrainLayout train_layout(int64_t n, int T) {
+  constexpr int PREC = SO3X_PREC_BF16;
+  TrainLayout L;
+  L.wt = (tables_end(PREC, GATHER, T) + 255) & ~(size_t)255;
+  L.slabs = (L.wt + (size_t)wt_nfrags<PREC>() * frag_bytes<PREC>() + 255) & ~(size_t)255;
+  L.target = L.slabs + (size_t)DW_BLOCKS * NPARAMS_MAX * sizeof(float);
+  L.partial = (L.target + (size_t)(n > 0 ? n : 0) * 3 * sizeof(float) + 255) & ~(size_t)255;
+  L.ticket = L.partial + 512 * sizeof(double);
+  L.end = L.ticket + 256;
+  return L;
+}
+
 // workspace layout: [weight image | (t_table: beff, emb tables)] [transposed image] [slabs] [stash]
 struct BwdLayout { size_t wt, slabs, stash, end; };
 template <int PREC> BwdLayout bwd_layout(int64_t n, int t_table) {
@@ -929,23 +1034,8 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   const uint4* h0 = VAR == GATHER ? reinterpret_cast<const uint4*>(ws + h0_offset(PREC, VAR, t_table)) : nullptr;
   float* slabs = reinterpret_cast<float*>(ws + L.slabs);
   ST* stash = reinterpret_cast<ST*>(ws + L.stash);
-  if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER) {
-    // fused path: no dZ/H stash, one launch for the whole batch
-    constexpr int FUSED_LDS = image_bytes<PREC, VAR>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
-    static PerDevice attr_f0, attr_f1;
-    if (int rc2 = ensure_dyn_lds(attr_f0, reinterpret_cast<const void*>(&k_bwd_fused<PREC, false>), FUSED_LDS)) return rc2;
-    if (int rc2 = ensure_dyn_lds(attr_f1, reinterpret_cast<const void*>(&k_bwd_fused<PREC, true>), FUSED_LDS)) return rc2;
-    const int64_t nt = (n + 31) / 32;
-    const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
-    if (zstash)
-      hipLaunchKernelGGL((k_bwd_fused<PREC, true>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
-                         emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
-    else
-      hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)ws, (const void*)(ws + L.wt), beff,
-                         emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout));
-    return check_launch();
-  }
+  if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER)  // fused path: no dZ/H stash, one launch for the whole batch
+    return launch_fused_bwd(s, ws, ws + L.wt, beff, emb, h0, R, t, t_stride, dout, slabs, n, zstash, nout, dparams, nullptr);
   for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
     const int64_t nc = (n - c0) < CHUNK ? (n - c0) : CHUNK;
     const int64_t ntiles = (nc + 31) / 32;
@@ -988,10 +1078,10 @@ int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, con
   int rc = launch_prep((hipStream_t)s, params, PREC, GATHER, t_table, ws, n_out);
   if (rc) return rc;
   static PerDevice attr;
-  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC>), IMG))) return rc;
+  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, false>), IMG))) return rc;
   const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
-  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, (hipStream_t)s, (const void*)ws,
-                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out);
+  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, false>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, (hipStream_t)s, (const void*)ws,
+                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out, LossArgs{});
   return check_launch();
 }
 
@@ -1014,6 +1104,59 @@ int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int
                        : launch_bwd<SO3X_PREC_F32, FULL>(st, params, R, t, t_stride, dout, dparams, n, n_out, 0, ws);
   return t_table > 0 ? launch_bwd<SO3X_PREC_BF16, GATHER>(st, params, R, t, t_stride, dout, dparams, n, n_out, t_table, ws, (const char*)zstash)
                      : launch_bwd<SO3X_PREC_BF16, FULL>(st, params, R, t, t_stride, dout, dparams, n, n_out, 0, ws);
+}
+
+// ---- one training step of SO3Diffusion(RotPredict(out_type="skewvec")) under loss_type="skewvec", bf16 MLP operands ----
+size_t so3x_train_workspace_bytes(int64_t n, int T) { return train_layout(n, T > 0 ? T : 0).end; }
+
+int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                   const float* x0, const int64_t* t, int64_t* t_draw, int quirk_col0, const float* axes, const float* unif, uint64_t seed,
+                   uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, float* dout, void* zstash,
+                   float* loss, float* out, void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !params || !sched || !trap_q || !x0 || ((t == nullptr) == (t_draw == nullptr)) || !x_t || !dout ||
+      !zstash || !loss || ((axes == nullptr) != (unif == nullptr)))
+    return SO3X_ERR_INVALID_ARG;
+  const TrainLayout L = train_layout(n, T);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER>();
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)s;
+  // one prep launch for the whole step: forward image, transposed image of the backward, per-timestep tables
+  int rc = launch_prep(st, params, PREC, GATHER, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
+  if (rc) return rc;
+  float* target = reinterpret_cast<float*>(ws + L.target);
+  // noise draw + forward noising + regression target (diffusion.py:349-355)
+  rc = launch_q_sample_target(st, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0, nullptr, axes, unif, seed, rng_offset,
+                              rng_counter, index_base, x_t, target, nullptr, n);
+  if (rc) return rc;
+  const int64_t* tt = t ? t : t_draw;  // the drawn timesteps are in place when the next launch starts
+  static PerDevice attr;
+  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
+  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
+  LossArgs la;
+  la.target = target; la.dout = dout; la.loss = loss;
+  la.partial = reinterpret_cast<double*>(ws + L.partial);
+  la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
+  la.rng_counter = (axes == nullptr || t_draw) ? rng_counter : nullptr;
+  la.dscale = (float)(2.0 / (3.0 * (double)n));
+  la.inv_count = 1.0 / (3.0 * (double)n);
+  // network forward + stash + MSE and its gradient (so3_train.py:39-49, diffusion.py:353-357)
+  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, st, (const void*)ws,
+                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), x_t, tt, (int64_t)1, out, (char*)zstash, n, 3, la);
+  return check_launch();
+}
+
+int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
+                   const float* gscale, float* grad, void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !x_t || !t || !dout || !zstash || !grad) return SO3X_ERR_INVALID_ARG;
+  const TrainLayout L = train_layout(n, T);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  constexpr int PREC = SO3X_PREC_BF16;
+  const char* ws = (const char*)workspace;
+  return launch_fused_bwd((hipStream_t)s, ws, ws + L.wt, reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)),
+                          reinterpret_cast<const float*>(ws + emb_offset(PREC, GATHER, T)),
+                          reinterpret_cast<const uint4*>(ws + h0_offset(PREC, GATHER, T)), x_t, t, 1, dout,
+                          reinterpret_cast<float*>(const_cast<char*>(ws) + L.slabs), n, (const char*)zstash, 3, grad, gscale);
 }
 
 }  // extern "C"

@@ -52,6 +52,68 @@ __global__ void __launch_bounds__(kBlock) k_log_rmat(const float* __restrict__ R
   }
 }
 
+// util.py:95-107  orthogonalise: U round(S) V^T of the SVD M = U S V^T, evaluated as  M V diag(round(s_i) / s_i) V^T  with
+// V, s^2 from a cyclic Jacobi eigen-decomposition of the symmetric M^T M (fp32, 6 sweeps; a singular value that rounds to 0
+// drops its term, so no left vector is ever formed from a vanishing s).  Invariant to the choice of V inside a repeated
+// singular value, and the identity map (to rounding) on a rotation.
+__device__ __forceinline__ void jacobi_rot(float (&a)[3][3], float (&v)[3][3], int p, int q) {
+  const float apq = a[p][q];
+  if (fabsf(apq) < 1e-30f) return;
+  const float tau = (a[q][q] - a[p][p]) / (2.0f * apq);
+  const float t = (tau >= 0.f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
+  const float c = 1.0f / sqrtf(1.0f + t * t), sn = t * c;
+  const int r = 3 - p - q;
+  const float app = a[p][p], aqq = a[q][q], arp = a[r][p], arq = a[r][q];
+  a[p][p] = app - t * apq;
+  a[q][q] = aqq + t * apq;
+  a[p][q] = a[q][p] = 0.0f;
+  a[r][p] = a[p][r] = c * arp - sn * arq;
+  a[r][q] = a[q][r] = sn * arp + c * arq;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float vkp = v[k][p], vkq = v[k][q];
+    v[k][p] = c * vkp - sn * vkq;
+    v[k][q] = sn * vkp + c * vkq;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_orthogonalise(const float* __restrict__ M, float* __restrict__ out, int64_t n) {
+  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
+  SO3X_TILE_LOOP(n) {
+    SO3X_TILE_VARS(n)
+    float m[9], o[9];
+    load_rows<9>(M, base, cnt, sm, m);
+    float a[3][3], v[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) a[i][j] = m[i] * m[j] + m[3 + i] * m[3 + j] + m[6 + i] * m[6 + j];  // (M^T M)_ij
+#pragma unroll 1
+    for (int sweep = 0; sweep < 6; sweep++) {
+      jacobi_rot(a, v, 0, 1);
+      jacobi_rot(a, v, 0, 2);
+      jacobi_rot(a, v, 1, 2);
+    }
+    float w[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float sv = sqrtf(fmaxf(a[i][i], 0.0f));
+      const float r = rintf(sv);  // torch.round: half to even
+      w[i] = r > 0.0f ? r / sv : 0.0f;
+    }
+    float g[3][3];  // V diag(w) V^T
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) g[i][j] = v[i][0] * w[0] * v[j][0] + v[i][1] * w[1] * v[j][1] + v[i][2] * w[2] * v[j][2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) o[3 * i + j] = m[3 * i] * g[0][j] + m[3 * i + 1] * g[1][j] + m[3 * i + 2] * g[2][j];
+    store_rows<9>(out, base, cnt, sm, o);
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) k_exp_skewvec(const float* __restrict__ v, float* __restrict__ R, int64_t n) {
   __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
   SO3X_TILE_LOOP(n) {
@@ -198,6 +260,10 @@ int so3x_log_rmat(so3x_stream_t s, const float* R, float* log_out, int64_t n) {
 int so3x_log_rmat_vec(so3x_stream_t s, const float* R, float* vec_out, int64_t n) {
   if (bad(n) || (n && (!R || !vec_out))) return SO3X_ERR_INVALID_ARG;
   SO3X_LAUNCH(k_log_rmat<1>, n, s, R, vec_out, n);
+}
+int so3x_orthogonalise(so3x_stream_t s, const float* M, float* out, int64_t n) {
+  if (bad(n) || (n && (!M || !out))) return SO3X_ERR_INVALID_ARG;
+  SO3X_LAUNCH(k_orthogonalise, n, s, M, out, n);
 }
 int so3x_exp_skewvec(so3x_stream_t s, const float* v, float* R, int64_t n) {
   if (bad(n) || (n && (!v || !R))) return SO3X_ERR_INVALID_ARG;

@@ -21,22 +21,24 @@ N_PARAMS = 17358
 N_PARAMS_ROTMAT = 17556  # out_type="rotmat": Linear(65, 6) head (reference so3_train.py:21-22)
 SCHED_ROWS = 13
 TRAP = 999
+GUIDE_PITCH = 258
 
 # every entry point declared in include/so3x.h (checked against the header by the tests)
 SYMBOLS = (
     "so3x_abi_version", "so3x_error_string", "so3x_schedule_from_betas", "so3x_cosine_beta_schedule",
     "so3x_igso3_knots", "so3x_posemb_freqs", "so3x_quat_to_rmat", "so3x_log_rmat", "so3x_log_rmat_vec",
-    "so3x_exp_skewvec", "so3x_so3_scale", "so3x_aa_to_rmat", "so3x_rmat_to_aa", "so3x_so3_lerp",
+    "so3x_exp_skewvec", "so3x_orthogonalise", "so3x_so3_scale", "so3x_aa_to_rmat", "so3x_rmat_to_aa", "so3x_so3_lerp",
     "so3x_rmat_dist", "so3x_rmul", "so3x_igso3_eps_ft", "so3x_igso3_build_tables", "so3x_igso3_build_guide", "so3x_igso3_sample",
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd", "so3x_mlp_stash_bytes",
     "so3x_mlp_fwd_stash",
-    "so3x_q_sample_target", "so3x_p_mean", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
+    "so3x_q_sample_target", "so3x_p_mean", "so3x_p_mean_t", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
     "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move", "so3x_rotate_cloud",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
     "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd", "so3x_resnet_stash_bytes", "so3x_resnet_fwd_stash",
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
+    "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
 )
 
 
@@ -72,7 +74,8 @@ def lib():
                 l.so3x_resnet_train_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_stash_bytes.restype = C.c_size_t
                 l.so3x_prevstep_workspace_bytes.restype = C.c_size_t
-                if l.so3x_abi_version() != 3:
+                l.so3x_train_workspace_bytes.restype = C.c_size_t
+                if l.so3x_abi_version() != 4:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -96,6 +99,22 @@ def _dev(x, name, dtype=torch.float32):
 
 def _ptr(x):
     return C.c_void_p(x.data_ptr()) if x is not None else None
+
+
+def _guide(g, trap, name="guide"):
+    """optional uint16 search guide of `trap` (igso3_build_guide): same device, one 258-entry row per CDF row"""
+    if g is None:
+        return None
+    g = _dev(g, name, torch.int16)
+    if g.device != trap.device or g.numel() != (trap.numel() // TRAP) * GUIDE_PITCH:
+        raise ValueError(f"so3x: {name} does not belong to this CDF table (build it with igso3_build_guide)")
+    return g
+
+
+def _out_like(out, x, name="out"):
+    if out.dtype != torch.float32 or not out.is_cuda or out.device != x.device or not out.is_contiguous() or out.numel() != x.numel():
+        raise ValueError(f"so3x: {name} must be a contiguous fp32 tensor of {x.numel()} elements on {x.device}")
+    return out
 
 
 def _stream(x):
@@ -174,7 +193,16 @@ def _ws_key(device):
     return (idx, torch.cuda.current_stream(idx).cuda_stream)
 
 
+def _capturing():
+    return torch.cuda.is_current_stream_capturing()
+
+
 def _workspace(device, nbytes):
+    if _capturing():
+        # every capture shares torch's one capture stream: a cached per-stream buffer would be handed from one graph's
+        # private pool to the next graph.  A buffer allocated here belongs to the graph being captured and lives as long
+        # as it does; stream order makes its reuse by later allocations of the same capture safe.
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     key = _ws_key(device)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -212,6 +240,15 @@ def log_rmat_vec(R):
     out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
     with _Guard(R):
         _check(lib().so3x_log_rmat_vec(_stream(R), _ptr(R), _ptr(out), _i64(R.numel() // 9)), "log_rmat_vec")
+    return out
+
+
+def orthogonalise(M):
+    """U round(S) V^T of each 3x3 matrix (reference util.py:95-107)"""
+    M = _rot_in(M, "mat")
+    out = torch.empty_like(M)
+    with _Guard(M):
+        _check(lib().so3x_orthogonalise(_stream(M), _ptr(M), _ptr(out), _i64(M.numel() // 9)), "orthogonalise")
     return out
 
 
@@ -302,6 +339,8 @@ def rmul(a, b, transpose_b=False):
     a = _rot_in(a, "a")
     b = _rot_in(b, "b")
     n = max(a.numel(), b.numel()) // 9
+    if a.numel() != b.numel() and min(a.numel(), b.numel()) != 9:
+        raise ValueError(f"so3x: rmul operands must match or one must be a single (3, 3) matrix, got {tuple(a.shape)} and {tuple(b.shape)}")
     sa = 0 if (a.numel() == 9 and n > 1) else 9
     sb = 0 if (b.numel() == 9 and n > 1) else 9
     shape = a.shape if a.numel() >= b.numel() else b.shape
@@ -331,9 +370,6 @@ def igso3_build_tables(eps):
     return trap
 
 
-GUIDE_PITCH = 258
-
-
 def igso3_build_guide(trap):
     """uint16 [rows, 258] search guide of CDF rows (so3x_igso3_build_guide): pass it wherever rows are looked up per sample."""
     trap = _dev(trap, "trap")
@@ -348,6 +384,7 @@ def igso3_sample(trap, n, row_idx=None, row_const=0, quirk_col0=False, axes=None
                  index_base=0, mean=None, want_angle=False, want_axis=False, guide=None):
     trap = _dev(trap, "trap")
     dev = trap.device
+    guide = _guide(guide, trap)
     ri = _dev(row_idx, "row_idx", torch.int64).reshape(-1) if row_idx is not None else None
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
@@ -457,6 +494,9 @@ def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None
     if tt.numel() != n:
         raise ValueError("so3x: t must have one entry per sample")
     tq = _dev(trap_q, "trap_q") if trap_q is not None else None
+    guide_q = _guide(guide_q, tq, "guide_q") if tq is not None else None
+    if rng_offset_dev is not None:
+        rng_offset_dev = _dev(rng_offset_dev, "rng_offset_dev", torch.int64)
     nz = _rot_in(noise, "noise") if noise is not None else None
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
@@ -473,17 +513,101 @@ def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None
     return x_t, tg, nzo
 
 
+# ------------------------------------------------------------------ one training step (so3_train.py:73-76)
+def train_fwd(params, sched, trap_q, x0, t, quirk_col0=True, axes=None, unif=None, seed=0, rng_offset=0, rng_counter=None,
+              index_base=0, guide_q=None, want_out=False):
+    """SO3Diffusion.p_losses for RotPredict(65, "skewvec") with bf16 operands in three launches (so3x_train_fwd): returns
+    (loss [0-d], carry) where carry = (x_t, t, dout, zstash, workspace) is what train_bwd needs, plus the network output
+    when want_out.  t = None: the timesteps are drawn in the kernel from the samples' Philox blocks (and returned in the
+    carry).  rng_counter: device int64 [1], read as an addend of rng_offset and incremented on the device."""
+    params = _dev(params, "params").reshape(-1)
+    if params.numel() != N_PARAMS:
+        raise ValueError(f"so3x: the fused training step is built for the {N_PARAMS}-parameter skew-vector network")
+    sched = _dev(sched, "sched")
+    T = sched.shape[1]
+    trap_q = _dev(trap_q, "trap_q")
+    guide_q = _guide(guide_q, trap_q, "guide_q")
+    x0 = _rot_in(x0, "x_start")
+    n = x0.numel() // 9
+    if n == 0:
+        raise ValueError("so3x: empty batch")
+    dev = x0.device
+    if t is None:  # drawn in the kernel (SO3Diffusion.forward), returned in the carry
+        tt, t_in, t_draw = torch.empty(n, dtype=torch.int64, device=dev), None, True
+    else:
+        tt = _dev(t, "t", torch.int64).reshape(-1)
+        if tt.numel() != n:
+            raise ValueError("so3x: t must have one entry per sample")
+        t_in, t_draw = tt, False
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    if (ax is None) != (un is None) or (ax is not None and (ax.shape[0] != n or un.numel() != n)):
+        raise ValueError("so3x: axes [n, 3] and unif [n] go together")
+    if rng_counter is not None:
+        rng_counter = _dev(rng_counter, "rng_counter", torch.int64)
+    x_t = torch.empty_like(x0)
+    dout = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_out else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    zstash = torch.empty(lib().so3x_mlp_stash_bytes(_i64(n)), dtype=torch.uint8, device=dev)
+    # the workspace travels to train_bwd with the images and tables the forward's prep launch built: owned by this step
+    ws = torch.empty(lib().so3x_train_workspace_bytes(_i64(n), C.c_int(T)), dtype=torch.uint8, device=dev)
+    with _Guard(x0):
+        _check(lib().so3x_train_fwd(_stream(x0), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_q), _ptr(guide_q), _ptr(x0),
+                                    _ptr(t_in), _ptr(tt if t_draw else None), C.c_int(int(quirk_col0)), _ptr(ax), _ptr(un), _u64(seed),
+                                    _u64(rng_offset),
+                                    _ptr(rng_counter), _i64(index_base), _i64(n), _ptr(x_t), _ptr(dout), _ptr(zstash), _ptr(loss),
+                                    _ptr(out), _ptr(ws), C.c_size_t(ws.numel())), "train_fwd")
+    return loss[0], (x_t, tt, dout, zstash, ws), out
+
+
+def train_bwd(carry, n_params=N_PARAMS, T=None, gscale=None):
+    """flat gradient [17358] of the loss train_fwd returned (so3x_train_bwd); gscale: 0-d / [1] device tensor or None"""
+    x_t, tt, dout, zstash, ws = carry
+    n = x_t.numel() // 9
+    grad = torch.empty(n_params, dtype=torch.float32, device=x_t.device)
+    gs = _dev(gscale, "grad_output").reshape(1) if gscale is not None else None
+    with _Guard(x_t):
+        _check(lib().so3x_train_bwd(_stream(x_t), _ptr(x_t), _ptr(tt), _ptr(dout), _ptr(zstash), _i64(n), C.c_int(int(T)), _ptr(gs),
+                                    _ptr(grad), _ptr(ws), C.c_size_t(ws.numel())), "train_bwd")
+    return grad
+
+
+def adam_step(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0):
+    """torch.optim.Adam.step() on flat fp32 buffers, in place (so3x_adam_step); step: device float32 [2] = [count, scratch]"""
+    for name, x in (("params", params), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq), ("step", step)):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+            raise So3xError(f"so3x: adam_step needs contiguous fp32 device tensors ({name})")
+    n = params.numel()
+    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or step.numel() < 2:
+        raise ValueError("so3x: adam_step buffer sizes differ")
+    with _Guard(params):
+        _check(lib().so3x_adam_step(_stream(params), _ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(step), _i64(n),
+                                    C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
+                                    C.c_float(grad_scale)), "adam_step")
+
+
 def p_mean(sched, x, v, t, want_x0hat=False):
+    """x0hat (optional) and posterior mean for network output v (diffusion.py:291-313).  t: an int (one shared timestep), or
+    an int64 tensor with one element (shared, read on the device: no host sync) or one per sample (the reference's
+    extract(coef, t, ...))."""
     sched = _dev(sched, "sched")
     T = sched.shape[1]
     x = _rot_in(x, "x")
     v = _dev(v, "noise").reshape(-1, 3)
     n = x.numel() // 9
+    if v.shape[0] != n:
+        raise ValueError(f"so3x: the network output must be [{n}, 3], got {tuple(v.shape)}")
     x0h = torch.empty_like(x) if want_x0hat else None
     mean = torch.empty_like(x)
     with _Guard(x):
-        _check(lib().so3x_p_mean(_stream(x), _ptr(sched), C.c_int(T), _ptr(x), _ptr(v), C.c_int(int(t)), _ptr(x0h),
-                                 _ptr(mean), _i64(n)), "p_mean")
+        if isinstance(t, torch.Tensor):
+            tt, stride = _t_arg(t, n)
+            _check(lib().so3x_p_mean_t(_stream(x), _ptr(sched), C.c_int(T), _ptr(x), _ptr(v), _ptr(tt), _i64(stride), _ptr(x0h),
+                                       _ptr(mean), _i64(n)), "p_mean")
+        else:
+            _check(lib().so3x_p_mean(_stream(x), _ptr(sched), C.c_int(T), _ptr(x), _ptr(v), C.c_int(int(t)), _ptr(x0h),
+                                     _ptr(mean), _i64(n)), "p_mean")
     return x0h, mean
 
 
@@ -497,8 +621,8 @@ def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=N
     n = x.numel() // 9
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
-    if out is None:
-        out = torch.empty_like(x)
+    guide_p = _guide(guide_p, trap_p, "guide_p")
+    out = torch.empty_like(x) if out is None else _out_like(out, x)
     nb = lib().so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(precision))
     ws = _workspace(x.device, nb)
     with _Guard(x):
@@ -591,8 +715,8 @@ def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None,
     n = x.numel() // 9
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
-    if out is None:
-        out = torch.empty_like(x)
+    guide_p = _guide(guide_p, trap_p, "guide_p")
+    out = torch.empty_like(x) if out is None else _out_like(out, x)
     nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(T))
     ws = _workspace(x.device, nb)
     with _Guard(x):
@@ -611,6 +735,8 @@ def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_c
     x0_rot = _rot_in(x0_rot, "x_start.rot")
     n = x0_rot.numel() // 9
     x0_shift = _dev(x0_shift, "x_start.shift").reshape(n, 3)
+    trap_q = _dev(trap_q, "trap_q")
+    guide_q = _guide(guide_q, trap_q, "guide_q")
     tt = _dev(t, "t", torch.int64).reshape(-1)
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
@@ -621,7 +747,7 @@ def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_c
     tg_rot = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
     tg_shift = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
     with _Guard(x0_rot):
-        _check(lib().so3x_se3_q_sample_target(_stream(x0_rot), _ptr(sched), C.c_int(T), _ptr(_dev(trap_q, "trap_q")), _ptr(guide_q),
+        _check(lib().so3x_se3_q_sample_target(_stream(x0_rot), _ptr(sched), C.c_int(T), _ptr(trap_q), _ptr(guide_q),
                                               C.c_float(float(shift_scale)), _ptr(x0_rot), _ptr(x0_shift), _ptr(tt),
                                               C.c_int(int(quirk_col0)), _ptr(ax), _ptr(un), _ptr(zn), _u64(seed),
                                               _u64(rng_offset), _i64(index_base), _ptr(xt_rot), _ptr(xt_shift),
@@ -897,6 +1023,8 @@ _ws_small = {}
 
 def _workspace_small(device, nbytes):
     """separate small scratch so the loss reduction never aliases the MLP workspace"""
+    if _capturing():
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     key = _ws_key(device)
     buf = _ws_small.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -30,10 +30,16 @@ _SCHED_NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_c
 def cosine_beta_schedule(timesteps, s=0.008):
     """float64 betas of the un-vendored denoising_diffusion_pytorch helper the reference imports
     (reference diffusion.py:8-14, 60).  Parity with the reference's fork is unpinned; pass
-    `betas=` explicitly to remove the doubt."""
-    if s != 0.008:
-        raise NotImplementedError("only the default s=0.008 is provided")
-    return _b.cosine_beta_schedule(int(timesteps))
+    `betas=` explicitly to remove the doubt.  The reference only ever calls it with the default offset s (diffusion.py:60):
+    that case runs in libso3x (so3x_cosine_beta_schedule); any other s evaluates the same published formula in numpy
+    float64 -- init-time host arithmetic, as in the reference."""
+    if s == 0.008:
+        return _b.cosine_beta_schedule(int(timesteps))
+    steps = int(timesteps) + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
 
 
 def extract(a, t, x_shape):
@@ -47,6 +53,31 @@ def noise_like(shape, device, repeat=False):
     if repeat:
         return torch.randn((1, *shape[1:]), device=device).repeat(shape[0], *((1,) * (len(shape) - 1)))
     return torch.randn(shape, device=device)
+
+
+class _FusedSkewvecLoss(torch.autograd.Function):
+    """p_losses of loss_type="skewvec" for the 65-wide RotPredict with bf16 operands (reference diffusion.py:348-357) as
+    the two C-ABI calls of a training step: forward = so3x_train_fwd (noise draw, q_sample, target, network with its
+    pre-activations parked, MSE and its gradient: three launches), backward = so3x_train_bwd (fused backward + reduction:
+    two launches) returning the FLAT parameter gradient.  Only the parameters carry gradients."""
+
+    @staticmethod
+    def forward(ctx, flat, proc, x_start, t, axes, unif):
+        trap_q, _ = proc._tables()
+        dev_rng = proc.rng_counter is not None and (axes is None or t is None)
+        loss, carry, _ = _b.train_fwd(flat, proc._sched, trap_q, x_start, t, quirk_col0=proc.quirk_col0, axes=axes, unif=unif,
+                                      seed=_rng.seed(),
+                                      rng_offset=0 if (dev_rng or (axes is not None and t is not None)) else _rng.next_offset(),
+                                      rng_counter=proc.rng_counter if dev_rng else None, index_base=proc.index_base,
+                                      guide_q=proc._guide_q)
+        ctx.carry, ctx.T, ctx.n_params = carry, proc.num_timesteps, flat.numel()
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = _b.train_bwd(ctx.carry, ctx.n_params, ctx.T, gscale=g)
+        ctx.carry = None
+        return grad, None, None, None, None, None
 
 
 class SO3Diffusion(nn.Module):
@@ -70,6 +101,7 @@ class SO3Diffusion(nn.Module):
         # so3x.graphs.TrainStepGraph): the offset is read from it by the kernel and incremented on the device after the
         # call, which is what a captured hipGraph of the training step needs to draw fresh noise on every replay.
         self.rng_counter = None
+        self.draw_t_in_kernel = True  # forward(): timesteps from the samples' Philox blocks on the training fast path
 
         sched = _b.schedule_from_betas(betas)  # float64 math, fp32 storage, as diffusion.py:62-92
         for i, name in enumerate(_SCHED_NAMES):
@@ -108,10 +140,15 @@ class SO3Diffusion(nn.Module):
 
     @staticmethod
     def _shared_t(t):
-        """p_sample draws its noise from model_stdev[0] (reference diffusion.py:325): one timestep per call."""
+        """p_sample draws its noise from model_stdev[0] and skips it when (t == 0).all() (reference diffusion.py:320-325).
+        Returns (t[0], every entry equals t[0]); a tensor t costs one host read."""
         if isinstance(t, int):
-            return t
-        return int(t.reshape(-1)[0].item())
+            return t, True
+        tf = t.reshape(-1)
+        if tf.numel() == 1:
+            return int(tf.item()), True
+        t0, same = torch.stack((tf[0], (tf == tf[0]).all().to(tf.dtype))).tolist()
+        return int(t0), bool(same)
 
     # ------------------------------------------------------------------ reference API
     def q_mean_variance(self, x_start, t):
@@ -122,8 +159,9 @@ class SO3Diffusion(nn.Module):
         return mean, variance, log_variance
 
     def predict_start_from_noise(self, x_t, t, noise):
-        """so3_scale(x_t, sqrt(1/abar)) @ exp(hat(noise * sqrt(1/abar - 1)))^T  (reference diffusion.py:291-297)"""
-        x0hat, _ = _b.p_mean(self._sched, x_t, noise, self._shared_t(t), want_x0hat=True)
+        """so3_scale(x_t, sqrt(1/abar)) @ exp(hat(noise * sqrt(1/abar - 1)))^T  (reference diffusion.py:291-297); t per
+        sample ([B]) or shared ([1]), gathered on the device as the reference's extract() does"""
+        x0hat, _ = _b.p_mean(self._sched, x_t, noise, t, want_x0hat=True)
         return x0hat
 
     def q_posterior(self, x_start, x_t, t):
@@ -135,25 +173,28 @@ class SO3Diffusion(nn.Module):
 
     def p_mean_variance(self, x, t, clip_denoised: bool = False):
         predict = self.denoise_fn(x, t)
-        _, model_mean = _b.p_mean(self._sched, x, predict, self._shared_t(t))
+        _, model_mean = _b.p_mean(self._sched, x, predict, t)
         return model_mean, extract(self.posterior_variance, t, t.shape), \
             extract(self.posterior_log_variance_clipped, t, t.shape)
 
     @torch.no_grad()
     def p_sample(self, x, t, clip_denoised=False, repeat_noise=False, axes=None, unif=None):
-        """One reverse step (reference diffusion.py:315-326).  t: int64 tensor [B] or [1] (all equal) or int."""
-        t0 = self._shared_t(t)
+        """One reverse step (reference diffusion.py:315-326).  t: int64 tensor [B] or [1], or an int.  As in the reference
+        the noise scale is model_stdev[0] (t[0]'s) and the noise is skipped only when every t is 0; with all entries
+        equal (the only way the reference's own loops call it) the step is ONE fused launch, with mixed entries the mean
+        uses each sample's own coefficients (extract(), diffusion.py:291-306)."""
+        t0, same = self._shared_t(t)
         _, trap_p = self._tables()
         net = self._fused_net(sampling=True)
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
-        if net is not None:
+        if net is not None and same:
             return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
                                      seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
                                      precision=net.precision_code, guide_p=self._guide_p)
         tt = t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device, dtype=torch.long)
         predict = self.denoise_fn(x, tt)
-        _, mean = _b.p_mean(self._sched, x, predict, t0)
-        if t0 == 0:
+        _, mean = _b.p_mean(self._sched, x, predict, tt if not same else t0)
+        if same and t0 == 0:
             return mean
         n = x.numel() // 9
         smp, _, _ = _b.igso3_sample(trap_p, n, row_const=t0, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off + t0,
@@ -196,6 +237,9 @@ class SO3Diffusion(nn.Module):
         distance between the network's rotation and the step from x_noisy to the posterior mean of the previous timestep
         (reference diffusion.py:348-369)."""
         trap_q, _ = self._tables()
+        net = self._fused_net()
+        if x_start.numel() > 0 and self._lean(noise):
+            return _FusedSkewvecLoss.apply(net.flat_params(), self, x_start, t, axes, unif)  # the training step's fast path
         dev_rng = self.rng_counter is not None and noise is None and axes is None
         prevstep = self.loss_type == "prevstep"
         x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
@@ -206,7 +250,6 @@ class SO3Diffusion(nn.Module):
                                                 want_target=not prevstep)
         if dev_rng:
             self.rng_counter += 1
-        net = self._fused_net()
         # every t of this process is < num_timesteps: let the fused network gather per-timestep table rows
         if prevstep and net is not None and net.out_type == "rotmat":
             # the fused networks hand over their raw 6 outputs: six2rmat, posterior mean, step = x_noisy^T @ mean,
@@ -219,8 +262,21 @@ class SO3Diffusion(nn.Module):
             return _b.prevstep_loss(self._sched, x_recon, x_start, x_noisy, t)
         return _b.mse_loss(x_recon, target)
 
+    def _lean(self, noise):
+        """the training step's fast path applies: 65-wide skew-vector RotPredict with bf16 operands under the skewvec loss"""
+        net = self._fused_net()
+        return (self.loss_type == "skewvec" and noise is None and type(self) is SO3Diffusion and isinstance(net, RotPredict)
+                and net.out_type == "skewvec" and net.precision == "bf16" and torch.is_grad_enabled()
+                and any(p.requires_grad for p in net.net.parameters()))
+
     def forward(self, x, *args, **kwargs):
+        """loss for a batch of rotations at random timesteps (reference diffusion.py:371-374).  On the training fast path
+        the timesteps are drawn inside the noising kernel -- uniform on {0..T-1} as the reference's randint, but keyed by
+        (seed, global sample index, offset) like the noise, so a sharded run draws what the single-process run draws and a
+        replayed hipGraph what the eager loop draws; set `draw_t_in_kernel = False` for torch.randint."""
         b = x.shape[0]
+        if self.draw_t_in_kernel and b > 0 and not args and self._lean(kwargs.get("noise")) and set(kwargs) <= {"axes", "unif", "noise"}:
+            return _FusedSkewvecLoss.apply(self.denoise_fn.flat_params(), self, x, None, kwargs.get("axes"), kwargs.get("unif"))
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
         return self.p_losses(x, t, *args, **kwargs)
 
@@ -232,16 +288,16 @@ class ProjectedSO3Diffusion(SO3Diffusion):
 
     def p_mean_variance(self, x, t, clip_denoised: bool = False):
         predict = self.denoise_fn(self.projection(x), t)
-        _, model_mean = _b.p_mean(self._sched, x, predict, self._shared_t(t))
+        _, model_mean = _b.p_mean(self._sched, x, predict, t)
         return model_mean, extract(self.posterior_variance, t, t.shape), \
             extract(self.posterior_log_variance_clipped, t, t.shape)
 
     @torch.no_grad()
     def p_sample(self, x, t, clip_denoised=False, repeat_noise=False, axes=None, unif=None):
-        t0 = self._shared_t(t)
+        t0, same = self._shared_t(t)
         mean, _, _ = self.p_mean_variance(x, t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device,
                                                                                             dtype=torch.long))
-        if t0 == 0:
+        if same and t0 == 0:
             return mean
         _, trap_p = self._tables()
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0

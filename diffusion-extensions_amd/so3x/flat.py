@@ -1,0 +1,120 @@
+"""Flat parameter / gradient storage for the fused score networks.
+
+The kernels of libso3x take the network's parameters as ONE contiguous fp32 buffer in state_dict order and return the
+gradient the same way.  The two RotPredict modules therefore keep every nn.Linear parameter as a VIEW into one flat
+tensor (state_dict keys, shapes and nn.Module behaviour are unchanged), and hand autograd's flat gradient back to the
+parameters as views of one flat gradient tensor:
+
+  * sampling always sees the current weights (no cached copy that an in-place optimizer update could leave stale);
+  * a data-parallel step all-reduces `flat_grad()` in one call, with no cat / split / copy kernels;
+  * `so3x.optim.Adam` updates `flat_data()` from `flat_grad()` in one launch."""
+import torch
+
+__all__ = ["FlatParamsMixin"]
+
+
+class _FlatView(torch.autograd.Function):
+    """The flat buffer as a differentiable function of the individual parameters (what torch.cat(params) would be, with
+    no copy either way).  backward: in the usual loop (`zero_grad(); loss.backward()`: every p.grad is None) the flat
+    gradient is installed as the parameters' .grad views directly; if gradients are being accumulated it is split into
+    views and autograd adds them."""
+
+    @staticmethod
+    def forward(ctx, net, *params):
+        ctx.net = net
+        return net._flat.detach()
+
+    @staticmethod
+    def backward(ctx, dflat):
+        net = ctx.net
+        params = net._flat_params
+        if dflat.is_contiguous() and all(p.grad is None for p in params):
+            net._install_flat_grad(dflat)
+            return (None,) * (1 + len(params))
+        off, out = 0, []
+        for p in params:
+            out.append(dflat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return (None, *out)
+
+
+class FlatParamsMixin:
+    """Mixed into an nn.Module whose parameters of `self.net` live in one flat buffer."""
+
+    def _init_flat(self):
+        self._flat = None          # the flat parameter buffer the nn.Parameters are views of
+        self._flat_grad = None     # the flat gradient tensor the .grad attributes are views of (None until a backward)
+        self._flat_params = []
+        self._flatten()
+
+    def _flatten(self):
+        params = list(self.net.parameters())
+        if not params:
+            return
+        dev, dt = params[0].device, params[0].dtype
+        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=dt)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+        self._flat, self._flat_params, self._flat_grad = flat, params, None
+
+    def _flat_ok(self):
+        f, ps = self._flat, self._flat_params
+        if f is None or len(ps) == 0:
+            return False
+        last = ps[-1]
+        return (ps[0].data_ptr() == f.data_ptr() and ps[0].device == f.device
+                and last.data_ptr() == f.data_ptr() + 4 * (f.numel() - last.numel()))
+
+    def _ensure_flat(self):
+        # .to(device) / deepcopy / a caller assigning p.data re-home the parameters: adopt them again
+        if not self._flat_ok():
+            self._flatten()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    def flat_data(self) -> torch.Tensor:
+        """all parameters, flat, in state_dict order (no copy; always current)"""
+        self._ensure_flat()
+        return self._flat
+
+    def flat_params_nograd(self) -> torch.Tensor:
+        return self.flat_data()
+
+    def flat_params(self) -> torch.Tensor:
+        """the same buffer, differentiable: its gradient is routed to the nn.Linear parameters as views (no copy)"""
+        self._ensure_flat()
+        return _FlatView.apply(self, *self._flat_params)
+
+    def _install_flat_grad(self, dflat):
+        off = 0
+        for p in self._flat_params:
+            p.grad = dflat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self._flat_grad = dflat
+
+    def flat_grad(self):
+        """the flat gradient if every parameter's .grad currently is a view of one flat tensor, else None"""
+        g, ps = self._flat_grad, self._flat_params
+        if g is None or not ps or ps[0].grad is None or ps[-1].grad is None:
+            return None
+        last = ps[-1]
+        if ps[0].grad.data_ptr() != g.data_ptr() or last.grad.data_ptr() != g.data_ptr() + 4 * (g.numel() - last.numel()):
+            return None
+        return g
+
+    def gather_flat_grad(self):
+        """flat_grad(), or (gradients that arrived some other way) a flat copy installed as the .grad views"""
+        g = self.flat_grad()
+        if g is None:
+            self._ensure_flat()
+            g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._flat_params])
+            self._install_flat_grad(g)
+        return g

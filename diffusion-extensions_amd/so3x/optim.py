@@ -1,0 +1,67 @@
+"""The optimizer of the reference's training loops -- torch.optim.Adam(net.parameters(), lr=3e-4) (reference
+so3_train.py:64, so3_lock_train.py:70) -- as ONE launch on the score network's flat parameter / gradient buffers
+(so3x_adam_step), with the step count on the device so that a captured hipGraph of the training step advances it itself.
+
+Same hyper-parameters, defaults and update rule as torch.optim.Adam (amsgrad and maximize are not provided); pinned
+against torch's own results in tests/golden/adam.npz."""
+import torch
+
+from . import backend as _b
+from .flat import FlatParamsMixin
+
+__all__ = ["Adam"]
+
+
+class Adam(torch.optim.Optimizer):
+    """Adam over a so3x score network (so3_train.RotPredict / so3_lock_train.RotPredict).
+
+        optim = so3x.optim.Adam(net, lr=3e-4)
+        loss = process(x); optim.zero_grad(); loss.backward(); optim.step()
+
+    grad_scale multiplies the gradient inside the update (1/world_size after a summed all-reduce costs no launch)."""
+
+    def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if not isinstance(net, FlatParamsMixin):
+            raise TypeError("so3x.optim.Adam takes a so3x score network (flat parameter storage); use torch.optim.Adam otherwise")
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(list(net.net.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.net = net
+        self.grad_scale = 1.0
+        self._m = self._v = self._step = None
+
+    def _state(self, flat):
+        if self._m is None or self._m.device != flat.device or self._m.numel() != flat.numel():
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+            self._step = torch.zeros(2, dtype=torch.float32, device=flat.device)  # [count, scratch]
+        return self._m, self._v, self._step
+
+    @property
+    def step_count(self) -> int:
+        return 0 if self._step is None else int(self._step[0].item())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        flat = self.net.flat_data()
+        grad = self.net.gather_flat_grad()
+        m, v, step = self._state(flat)
+        g = self.param_groups[0]
+        _b.adam_step(flat, grad, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
+        return loss
+
+    def state_dict(self):
+        return {"exp_avg": self._m, "exp_avg_sq": self._v, "step": self._step, "param_groups": [dict((k, v) for k, v in g.items() if k != "params")
+                                                                                                for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        flat = self.net.flat_data()
+        m, v, step = self._state(flat)
+        if sd.get("exp_avg") is not None:
+            m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"]); step.copy_(sd["step"])
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(s)

@@ -200,7 +200,17 @@ class SE3Diffusion(nn.Module):
 
     @staticmethod
     def _shared_t(t):
-        return t if isinstance(t, int) else int(t.reshape(-1)[0].item())
+        """the fused SE(3) mean kernel takes ONE timestep per call (how the reference's own loops call p_sample,
+        diffusion.py:485-494); a batch of differing timesteps is refused rather than silently given sample 0's"""
+        if isinstance(t, int):
+            return t
+        tf = t.reshape(-1)
+        if tf.numel() == 1:
+            return int(tf.item())
+        t0, same = torch.stack((tf[0], (tf == tf[0]).all().to(tf.dtype))).tolist()
+        if not same:
+            raise ValueError("so3x: SE3Diffusion.p_mean_variance / p_sample need one shared timestep per call")
+        return int(t0)
 
     def q_mean_variance(self, x_start, t):
         mean = se3_scale(x_start, self.sqrt_alphas_cumprod[t])

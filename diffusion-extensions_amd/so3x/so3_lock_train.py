@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from . import backend as _b
+from .flat import FlatParamsMixin
 from .models import SinusoidalPosEmb, ResLayer
 
 __all__ = ["RotPredict", "BATCH", "main"]
@@ -39,7 +40,7 @@ class _ResNetFn(torch.autograd.Function):
         return None, None, dparams, None, None
 
 
-class RotPredict(nn.Module):
+class RotPredict(FlatParamsMixin, nn.Module):
     kind = "resnet255"  # which fused kernels SO3Diffusion dispatches to
 
     def __init__(self, d_model=255, out_type="rotmat", in_type="rotmat", precision="fp32"):
@@ -57,22 +58,11 @@ class RotPredict(nn.Module):
         self.time_embedding = SinusoidalPosEmb(d_model - 9)
         self.net = nn.Sequential(*[ResLayer(nn.Sequential(nn.Linear(d_model, d_model), nn.SiLU())) for _ in range(6)],
                                  nn.Linear(d_model, self.d_out))
-        self._flat_cache = None
         # the kernels gather per-timestep input rows from a [T][256] table: T must bound every t.  SO3Diffusion passes
         # its num_timesteps per call; this attribute is the default for direct calls.
         self.t_table = 1000
-
-    def flat_params(self) -> torch.Tensor:
-        """The 392,448 (skewvec) / 393,216 (rotmat) parameters in state_dict order; differentiable (autograd routes the fused gradient back to each
-        nn.Linear through the cat)."""
-        return torch.cat([p.reshape(-1) for p in self.net.parameters()])
-
-    def flat_params_nograd(self) -> torch.Tensor:
-        key = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
-        if self._flat_cache is None or self._flat_cache[0] != key:
-            with torch.no_grad():
-                self._flat_cache = (key, self.flat_params().detach())
-        return self._flat_cache[1]
+        # the 392,448 (skewvec) / 393,216 (rotmat) parameters live in ONE flat buffer in state_dict order (so3x.flat)
+        self._init_flat()
 
     @property
     def precision_code(self) -> int:
@@ -95,6 +85,7 @@ def main(argv=None):
     from .diffusion import SO3Diffusion
     from .util import euler_to_rmat, so3_lerp
     from . import parallel
+    from . import optim as so3x_optim
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=BATCH, help="global batch (reference: 32)")
@@ -104,20 +95,24 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--save-every", type=int, default=1000)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step as one captured hipGraph (so3x.graphs.TrainStepGraph; single process only)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as a captured hipGraph (so3x.graphs.TrainStepGraph)")
+    ap.add_argument("--optimizer", default="so3x", choices=["so3x", "torch"])
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--weights", default="weights/weights_so3_lock.pt")
     args = ap.parse_args(argv)
 
     ctx = parallel.init()
     device = ctx.device
-    torch.manual_seed(0)
+    torch.manual_seed(args.seed)
     net = RotPredict(out_type="skewvec", precision=args.precision).to(device)
     net.train()
     parallel.broadcast_parameters(net, ctx)
+    torch.cuda.manual_seed(args.seed + 7919 * (ctx.rank + 1))  # per-rank timesteps (diffusion.py:373 draws them on the device)
     process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
-    use_graph = args.graph and ctx.world_size == 1
-    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True, capturable=use_graph)
+    if args.optimizer == "so3x":
+        optim = so3x_optim.Adam(net, lr=args.lr)
+    else:
+        optim = torch.optim.Adam(net.parameters(), lr=args.lr, fused=True, capturable=args.graph)
     R_1 = euler_to_rmat(torch.tensor(0.0), torch.tensor(pi / 3), torch.tensor(0.0))[None].to(device)
     R_2 = euler_to_rmat(torch.tensor(0.0), torch.tensor(2 * pi / 3), torch.tensor(0.0))[None].to(device)
     lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)
@@ -126,9 +121,9 @@ def main(argv=None):
     t0 = time.time()
     sumloss = 0.0
     graph = None
-    if use_graph:
+    if args.graph:
         from .graphs import TrainStepGraph
-        graph = TrainStepGraph(process, optim, (hi - lo, 3, 3))
+        graph = TrainStepGraph(process, optim, (hi - lo, 3, 3), ctx=ctx, n_global=args.batch)
     for i in range(1, args.steps + 1):
         weight = torch.rand(hi - lo, 1, device=device, generator=gen)
         truepos = so3_lerp(R_1, R_2, weight)
@@ -136,11 +131,13 @@ def main(argv=None):
             loss = graph.step(truepos)  # (the reference's skip-on-NaN needs the loss on the host before the update: eager mode only)
         else:
             loss = process(truepos)
-            if torch.isnan(loss).any():  # so3_lock_train.py:83-84
+            # so3_lock_train.py:83-84 skips the update on a NaN loss.  The decision is made for ALL ranks together (a rank
+            # that skipped alone would miss the collectives the others enter and pair its next all-reduce with theirs)
+            if parallel.any_rank_true(torch.isnan(loss).any(), ctx):
                 continue
             optim.zero_grad()
             loss.backward()
-            parallel.allreduce_gradients(net, ctx)
+            parallel.allreduce_gradients(net, ctx, n_local=hi - lo, n_global=args.batch, optimizer=optim)
             optim.step()
         sumloss += parallel.mean_scalar(loss.detach(), ctx)
         if i % args.log_every == 0:
@@ -151,6 +148,7 @@ def main(argv=None):
             os.makedirs(os.path.dirname(args.weights) or ".", exist_ok=True)
             torch.save(net.state_dict(), args.weights)
     parallel.finalize(ctx)
+    return net
 
 
 if __name__ == "__main__":

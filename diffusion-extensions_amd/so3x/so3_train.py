@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from . import backend as _b
+from .flat import FlatParamsMixin
 from .models import SinusoidalPosEmb
 
 __all__ = ["RotPredict", "BATCH", "main"]
@@ -44,7 +45,7 @@ class _ScoreMLPFn(torch.autograd.Function):
         return None, None, dparams, None, None
 
 
-class RotPredict(nn.Module):
+class RotPredict(FlatParamsMixin, nn.Module):
     def __init__(self, d_model=65, out_type="rotmat", in_type="rotmat", precision="fp32"):
         super().__init__()
         self.in_type = in_type
@@ -65,25 +66,14 @@ class RotPredict(nn.Module):
             nn.Linear(d_model, d_model), nn.SiLU(),
             nn.Linear(d_model, self.d_out),
         )
-        self._flat_cache = None
         # 0: timesteps are arbitrary (embedding evaluated per sample in-kernel).  T > 0: the caller promises
         # 0 <= t < T; the kernels then gather per-timestep table rows instead of 56 sin/cos per sample.
         # SO3Diffusion passes its num_timesteps per call (forward's t_table argument); this attribute is the
         # default for direct calls and may be set by a caller that knows its timestep range.
         self.t_table = 0
-
-    def flat_params(self) -> torch.Tensor:
-        """The 17,358 (skewvec) / 17,556 (rotmat) parameters in state_dict order; differentiable (autograd routes the
-        fused gradient back to each nn.Linear through the cat)."""
-        return torch.cat([p.reshape(-1) for p in self.net.parameters()])
-
-    def flat_params_nograd(self) -> torch.Tensor:
-        """Cached flat copy for sampling; rebuilt when any parameter changed."""
-        key = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
-        if self._flat_cache is None or self._flat_cache[0] != key:
-            with torch.no_grad():
-                self._flat_cache = (key, self.flat_params().detach())
-        return self._flat_cache[1]
+        # the 17,358 (skewvec) / 17,556 (rotmat) parameters live in ONE flat buffer in state_dict order; the nn.Linear
+        # parameters are views of it (so3x.flat): flat_data() / flat_params() / flat_grad()
+        self._init_flat()
 
     @property
     def precision_code(self) -> int:
@@ -101,10 +91,13 @@ class RotPredict(nn.Module):
 
 
 def main(argv=None):
-    """Training loop of the reference's so3_train.py:54-81 (two-mode toy data, Adam 3e-4),
-    data-parallel over the GPUs of one node when launched with torchrun."""
+    """Training loop of the reference's so3_train.py:54-81 (two-mode toy data, Adam 3e-4), data-parallel over the GPUs of
+    one node when launched with torchrun: the batch axis is sharded, the flat gradient is all-reduced once per step (RCCL)
+    and, with --graph, the whole step -- noising, network, loss, backward, all-reduce, Adam -- replays as a captured
+    hipGraph (so3x.graphs.TrainStepGraph)."""
     from .diffusion import SO3Diffusion
     from . import parallel
+    from . import optim as so3x_optim
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=BATCH, help="global batch (reference: 64)")
@@ -114,20 +107,26 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--save-every", type=int, default=1000)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step as one captured hipGraph (so3x.graphs.TrainStepGraph; single process only)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as a captured hipGraph")
+    ap.add_argument("--optimizer", default="so3x", choices=["so3x", "torch"],
+                    help="so3x: Adam as one launch on the flat buffers (so3x.optim.Adam); torch: torch.optim.Adam(fused=True)")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--weights", default="weights/weights_so3.pt")
     args = ap.parse_args(argv)
 
     ctx = parallel.init()
     device = ctx.device
-    torch.manual_seed(0)
+    torch.manual_seed(args.seed)  # same initial weights on every rank (and broadcast below)
     net = RotPredict(out_type="skewvec", precision=args.precision).to(device)
     net.train()
     parallel.broadcast_parameters(net, ctx)
+    # the timesteps of p_losses come from torch's device generator (diffusion.py:373): decorrelate the ranks
+    torch.cuda.manual_seed(args.seed + 7919 * (ctx.rank + 1))
     process = SO3Diffusion(net, timesteps=args.timesteps, loss_type="skewvec").to(device)
-    use_graph = args.graph and ctx.world_size == 1
-    optim = torch.optim.Adam(process.denoise_fn.parameters(), lr=args.lr, fused=True, capturable=use_graph)  # the reference's Adam, one launch
+    if args.optimizer == "so3x":
+        optim = so3x_optim.Adam(net, lr=args.lr)  # the reference's Adam (so3_train.py:64), one launch
+    else:
+        optim = torch.optim.Adam(net.parameters(), lr=args.lr, fused=True, capturable=args.graph)
     z90 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
     rotations = torch.stack((z90, z90.T), dim=0).to(device)
     lo, hi = parallel.shard_range(args.batch, ctx.rank, ctx.world_size)
@@ -135,9 +134,9 @@ def main(argv=None):
     gen = torch.Generator(device=device).manual_seed(1234 + ctx.rank)
     t0 = time.time()
     graph = None
-    if use_graph:
+    if args.graph:
         from .graphs import TrainStepGraph
-        graph = TrainStepGraph(process, optim, (hi - lo, 3, 3))
+        graph = TrainStepGraph(process, optim, (hi - lo, 3, 3), ctx=ctx, n_global=args.batch)
     for i in range(1, args.steps + 1):
         idx = torch.randint(0, 2, (hi - lo,), device=device, generator=gen)
         truepos = rotations[idx]
@@ -147,7 +146,7 @@ def main(argv=None):
             loss = process(truepos)
             optim.zero_grad()
             loss.backward()
-            parallel.allreduce_gradients(net, ctx)
+            parallel.allreduce_gradients(net, ctx, n_local=hi - lo, n_global=args.batch, optimizer=optim)
             optim.step()
         if i % args.log_every == 0:
             lval = parallel.mean_scalar(loss.detach(), ctx)
@@ -157,6 +156,7 @@ def main(argv=None):
             os.makedirs(os.path.dirname(args.weights) or ".", exist_ok=True)
             torch.save(net.state_dict(), args.weights)
     parallel.finalize(ctx)
+    return net
 
 
 if __name__ == "__main__":

@@ -26,11 +26,15 @@ def vec2skew(vec: torch.Tensor) -> torch.Tensor:
 
 
 def orthogonalise(mat: torch.Tensor) -> torch.Tensor:
-    """Reference util.py:95-107 snaps the singular values of the 3x3 block to {-1,0,1}.
-    Every rotation produced by this backend comes out of a closed-form Rodrigues formula
-    and is orthogonal to fp32 rounding, where that SVD round trip is the identity map
-    (SURVEY.md 2.3 K4); kept for API compatibility."""
-    return mat
+    """Reference util.py:95-107: the leading 3x3 block of every matrix is replaced by U round(S) V^T of its SVD (singular
+    values snapped to integers); one HIP kernel (so3x_orthogonalise).  The rotations this backend produces come out of
+    closed-form Rodrigues formulas and are orthogonal to fp32 rounding, so the kernels that build them skip this step
+    (there it is the identity map); called directly it does what the reference's does."""
+    if mat.shape[-2:] == (3, 3):
+        return _b.orthogonalise(mat)
+    out = mat.clone()
+    out[..., :3, :3] = _b.orthogonalise(mat[..., :3, :3].contiguous())
+    return out
 
 
 def rmat2six(x: torch.Tensor) -> torch.Tensor:

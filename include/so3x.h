@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 3
+#define SO3X_ABI_VERSION 4
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -82,6 +82,8 @@ int so3x_quat_to_rmat(so3x_stream_t s, const float* q, float* R, int64_t n);
 int so3x_log_rmat(so3x_stream_t s, const float* R, float* log_out, int64_t n);
 /* util.py:164-192 + 79-84  skew2vec(log_rmat(R)): R -> [n][3] */
 int so3x_log_rmat_vec(so3x_stream_t s, const float* R, float* vec_out, int64_t n);
+/* util.py:95-107  orthogonalise: M[n][3][3] (any matrix) -> U round(S) V^T of its SVD (singular values snapped to integers) */
+int so3x_orthogonalise(so3x_stream_t s, const float* M, float* out, int64_t n);
 /* torch.matrix_exp(vec2skew(v)) (diffusion.py:294; util.py:87-92): v[n][3] -> R */
 int so3x_exp_skewvec(so3x_stream_t s, const float* v, float* R, int64_t n);
 /* util.py:349-361  so3_scale: exp(k log R); k_stride 0 = one scalar for all, 1 = per sample */
@@ -180,6 +182,11 @@ int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float
  * posterior mean, one shared timestep t. */
 int so3x_p_mean(so3x_stream_t s, const float* sched, int T, const float* x, const float* v, int t,
                 float* x0hat, float* mean, int64_t n);
+/* The same with the timestep read on the device, per sample (t_stride 1: the reference's extract(coef, t, shape) of
+ * predict_start_from_noise / q_posterior, diffusion.py:291-306) or one for all (t_stride 0: no host copy of t needed);
+ * values outside [0, T) are clamped. */
+int so3x_p_mean_t(so3x_stream_t s, const float* sched, int T, const float* x, const float* v, const int64_t* t, int64_t t_stride,
+                  float* x0hat, float* mean, int64_t n);
 
 /* SO3Diffusion.p_sample / p_sample_loop (diffusion.py:315-337) with the RotPredict score
  * network fused in: applies n_steps reverse steps t_start, t_start-1, ... to x in place
@@ -295,6 +302,41 @@ int so3x_prevstep_loss(so3x_stream_t s, const float* sched, int T, const float* 
 int so3x_prevstep_loss6(so3x_stream_t s, const float* sched, int T, const float* out6, const float* x_start,
                         const float* x_noisy, const int64_t* t, int64_t t_stride, int64_t n, float* loss, float* dout6,
                         void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------ one training step
+ * The device work of one iteration of the reference's training loop (so3_train.py:73-76: loss = process(truepos);
+ * loss.backward(); optim.step()) for SO3Diffusion(RotPredict(d_model=65, out_type="skewvec"), loss_type="skewvec") with
+ * bf16 MLP operands, as three calls so that a data-parallel caller can put its gradient all-reduce between the second
+ * and the third.  Five kernel launches in all (prep, noising, forward + loss, backward, reduce) + the optimizer's one.
+ *
+ * so3x_train_fwd   SO3Diffusion.p_losses (diffusion.py:348-357): noise ~ IGSO3(sqrt(1 - abar_t)) (axes/unif: explicit
+ *                  draws, else in-kernel Philox with counter (index_base + i, rng_offset + *rng_counter)), x_t =
+ *                  q_sample(x0, t, noise), target = vee(log noise)/eps_t, out = RotPredict(x_t, t),
+ *                  loss[0] = mean((out - target)^2), dout = d loss / d out.  zstash (so3x_mlp_stash_bytes(n)) and the
+ *                  workspace carry the forward's pre-activations, weight images and tables over to so3x_train_bwd:
+ *                  pass the SAME workspace, untouched, and do not change params in between.  rng_counter (optional,
+ *                  device int64): read as an addend of rng_offset and incremented by one by this call, so that a
+ *                  captured hipGraph of the step draws fresh noise on every replay.  out (optional): the network output.
+ *                  Exactly one of t / t_draw is given.  t: the timesteps, int64 [n] (p_losses(x, t)).  t_draw: int64 [n]
+ *                  OUTPUT -- the timesteps are drawn in the kernel (SO3Diffusion.forward's randint(0, T, (b,)),
+ *                  diffusion.py:373), t_i = floor(T w_i / 2^32) with w_i the spare fourth word of sample i's Philox block,
+ *                  so that they are, like the noise, a function of (seed, global sample index, offset) alone; pass the
+ *                  buffer to so3x_train_bwd as its t.
+ * so3x_train_bwd   autograd of the above wrt the 17,358 parameters (so3_train.py:75): grad[17358] = gscale[0] *
+ *                  d loss / d params (gscale: device-resident upstream gradient of the scalar loss, NULL = 1).
+ * so3x_adam_step   torch.optim.Adam.step() (so3_train.py:64,76; amsgrad = maximize = False) on flat buffers of n
+ *                  floats: the gradient is multiplied by grad_scale first (1/world_size after a summed all-reduce).
+ *                  step: TWO device floats, zero-initialised once by the caller: [0] = the step count, advanced by this
+ *                  call (torch's state['step']), [1] = scratch. */
+size_t so3x_train_workspace_bytes(int64_t n, int T);
+int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                   const float* x0, const int64_t* t, int64_t* t_draw, int quirk_col0, const float* axes, const float* unif,
+                   uint64_t seed, uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, float* dout,
+                   void* zstash, float* loss, float* out, void* workspace, size_t workspace_bytes);
+int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
+                   const float* gscale, float* grad, void* workspace, size_t workspace_bytes);
+int so3x_adam_step(so3x_stream_t s, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale);
 
 #ifdef __cplusplus
 }

@@ -486,3 +486,24 @@ def move_prot(rot, shift, pos, frames):
     out_pos = ((pos - mean)[:, :, None, :] @ RT)[:, :, 0, :] + mean + shift[:, None, :]
     out_fr = frames @ RT
     return out_pos, out_fr
+
+
+# ---------------------------------------------------------------------------------------------
+# the optimizer update of the training loop (so3_train.py:64,76)
+# ---------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """torch.optim.Adam.step() on flat fp32 arrays; returns the new (p, m, v).  `step` = the count before the call."""
+    p, m, v = (_arr(a, np.float32).copy() for a in (p, m, v))
+    g = _arr(g, np.float32)
+    lib().so3o_adam_step(_p(p), _p(g), _p(m), _p(v), C.c_long(p.size), C.c_double(step), C.c_double(lr), C.c_double(betas[0]),
+                         C.c_double(betas[1]), C.c_double(eps), C.c_double(weight_decay), C.c_double(grad_scale))
+    return p, m, v
+
+
+def orthogonalise(mat):
+    """util.py:95-107: U round(S) V^T of the SVD of the leading 3x3 block (numpy float64 SVD; torch.round = half to even)"""
+    mat = np.asarray(mat)
+    out = mat.astype(np.float64).copy()
+    u, s, vt = np.linalg.svd(out[..., :3, :3])
+    out[..., :3, :3] = (u * np.rint(s)[..., None, :]) @ vt
+    return out.astype(mat.dtype)

@@ -226,6 +226,26 @@ void so3o_p_sample_step_f32(const float* params, const float* freqs, const float
   }
 }
 
+/* torch.optim.Adam.step() as the reference's training loops call it (so3_train.py:64,76: Adam(net.parameters(), lr=3e-4),
+ * defaults betas (0.9, 0.999), eps 1e-8, weight_decay 0, amsgrad False).  The arithmetic is torch's (third-party: torch 1.8
+ * per requirements.txt:2; _single_tensor_adam in torch/optim/adam.py), restated: scalars in double as torch forms them in
+ * Python floats, element updates in fp32.  `step` is the count BEFORE this call (torch increments first).  Pinned by
+ * tests/golden/adam.npz, produced by torch.optim.Adam itself (tools/make_golden.py adam). */
+void so3o_adam_step(float* p, const float* g, float* m, float* v, long n, double step, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, double grad_scale) {
+  const double k = step + 1.0;
+  const double bc1 = 1.0 - pow(beta1, k), bc2 = 1.0 - pow(beta2, k);
+  const float neg_step_size = (float)(-lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const float b1 = (float)beta1, b2 = (float)beta2, e = (float)eps, wd = (float)weight_decay, gs = (float)grad_scale;
+  for (long i = 0; i < n; i++) {
+    float gi = g[i] * gs;
+    if (wd != 0.0f) gi = gi + wd * p[i];
+    m[i] = m[i] + (1.0f - b1) * (gi - m[i]);
+    v[i] = v[i] * b2 + (1.0f - b2) * gi * gi;
+    p[i] = p[i] + neg_step_size * (m[i] / (sqrtf(v[i]) / bc2_sqrt + e));
+  }
+}
+
 int so3o_omp_threads(void) {
 #ifdef _OPENMP
   extern int omp_get_max_threads(void);

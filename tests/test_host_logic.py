@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/so3x.h but not exported"
     assert declared == set(B.SYMBOLS)
-    assert B.lib().so3x_abi_version() == 3
+    assert B.lib().so3x_abi_version() == 4
 
 
 def test_no_oracle_or_cpu_fallback_in_product():
@@ -184,6 +184,25 @@ for i, p in enumerate(net.parameters()):
 parallel.allreduce_gradients(net, ctx)
 for i, p in enumerate(net.parameters()):
     assert torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))), "gradient mean wrong"
+# the flat path: the score network's gradient as ONE tensor (what the fused backward returns), .grad = views of it
+net.zero_grad(set_to_none=True)
+flat_g = torch.full((17358,), float(ctx.rank + 1))
+net._install_flat_grad(flat_g)
+assert net.flat_grad() is flat_g
+class _Opt:  # an optimizer that folds the 1/world into its update (so3x.optim.Adam does)
+    grad_scale = 1.0
+opt = _Opt()
+parallel.allreduce_gradients(net, ctx, n_local=5, n_global=10, optimizer=opt)
+assert net.flat_grad() is flat_g, "the all-reduce must run in place on the flat gradient"
+assert torch.allclose(flat_g * opt.grad_scale, torch.full_like(flat_g, 1.5)) and opt.grad_scale == 0.5
+assert all(p.grad.data_ptr() >= flat_g.data_ptr() for p in net.parameters())
+# unequal shards: weighted by n_local / n_global (3 + 7 samples)
+g2 = torch.full((8,), float(ctx.rank + 1))
+parallel.allreduce_flat(g2, ctx, n_local=3 if ctx.rank == 0 else 7, n_global=10)
+assert torch.allclose(g2, torch.full_like(g2, 0.3 * 1 + 0.7 * 2))
+# a decision every rank must take together (so3_lock_train's skip-on-NaN)
+assert parallel.any_rank_true(torch.tensor(ctx.rank == 1), ctx) is True
+assert parallel.any_rank_true(torch.tensor(False), ctx) is False
 m = parallel.mean_scalar(torch.tensor(float(ctx.rank)), ctx)
 assert abs(m - 0.5) < 1e-7
 lo, hi = parallel.shard_range(10, ctx.rank, ctx.world_size)
@@ -242,3 +261,50 @@ def test_small_helpers_of_the_reference_namespace():
     s = models.Siren(3, 8, scale=30)
     assert s(torch.randn(7, 3)).shape == (7, 8) and float(s.positional.weight.detach().abs().max()) <= 30 * (6 / 3) ** 0.5 + 1e-6
     assert all(not p.requires_grad for p in models.Siren(3, 8, optimize=False, post_scale=False).parameters())
+
+
+def test_score_network_parameters_live_in_one_flat_buffer(golden):
+    """so3x.flat: the nn.Linear parameters are views of one flat tensor in state_dict order, and stay so through
+    load_state_dict / in-place updates / deepcopy; the flat gradient comes back as .grad views without copies"""
+    import copy
+    from so3x.so3_train import RotPredict
+    from so3x.so3_lock_train import RotPredict as Wide
+    for cls, n in ((RotPredict, 17358), (Wide, 392448)):
+        torch.manual_seed(0)
+        net = cls(out_type="skewvec")
+        flat = net.flat_data()
+        assert flat.numel() == n and net._flat_ok()
+        assert torch.equal(flat, torch.cat([p.detach().reshape(-1) for p in net.state_dict().values()]))
+        with torch.no_grad():
+            next(net.net.parameters()).add_(1.0)                  # an optimizer's in-place update is seen at once
+        assert torch.equal(net.flat_data(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+        sd = {k: torch.randn_like(v) for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
+        assert net._flat_ok() and torch.equal(net.flat_data(), torch.cat([v.reshape(-1) for v in sd.values()]))
+        twin = copy.deepcopy(net)
+        assert torch.equal(twin.flat_data(), net.flat_data()) and twin.flat_data().data_ptr() != net.flat_data().data_ptr()
+        with torch.no_grad():
+            twin.flat_data().zero_()
+        assert float(next(twin.net.parameters()).detach().abs().sum()) == 0.0 and float(net.flat_data().abs().sum()) > 0
+        net = net.double().float()                                   # _apply re-homes the parameters: adopted again
+        assert net._flat_ok()
+        # autograd: the flat gradient is installed as views, and accumulates when asked to
+        fp = net.flat_params()
+        w = torch.arange(n, dtype=torch.float32)
+        (fp * w).sum().backward()
+        g = net.flat_grad()
+        assert g is not None and torch.equal(g, w)
+        assert all(p.grad.data_ptr() == g.data_ptr() + 4 * off for p, off in
+                   zip(net.net.parameters(), np.cumsum([0] + [q.numel() for q in net.net.parameters()])[:-1]))
+        (net.flat_params() * w).sum().backward()                     # second backward without zero_grad: accumulate
+        assert torch.equal(torch.cat([p.grad.reshape(-1) for p in net.net.parameters()]), 2 * w)
+
+
+def test_gradients_from_a_plain_torch_path_are_gathered():
+    from so3x.so3_train import RotPredict
+    net = RotPredict(out_type="skewvec")
+    for i, p in enumerate(net.net.parameters()):
+        p.grad = torch.full_like(p, float(i))
+    assert net.flat_grad() is None
+    g = net.gather_flat_grad()
+    assert g.numel() == 17358 and net.flat_grad() is g and float(g[0]) == 0.0 and float(g[-1]) == 9.0

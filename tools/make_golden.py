@@ -822,3 +822,58 @@ def trained_chain_samples_wide(steps=1500, batch=128, lr=3e-4, m=2048):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trained_chain_samples_wide":
     trained_chain_samples_wide()
+
+
+def adam_golden(n=1000, steps=25, lr=3e-4):
+    """The optimizer of the reference's training loops (so3_train.py:64: torch.optim.Adam(net.parameters(), lr=3e-4)) run by
+    torch itself on recorded gradients: parameters after every step."""
+    torch.manual_seed(11)
+    p = torch.nn.Parameter(torch.randn(n) * 0.1)
+    opt = torch.optim.Adam([p], lr=lr)
+    out = {"p0": npy(p).copy(), "lr": np.float64(lr)}
+    grads, ps = [], []
+    for i in range(steps):
+        g = torch.randn(n) * (10.0 ** torch.randint(-4, 2, (n,)).float())  # gradients over six decades
+        p.grad = g.clone()
+        opt.step()
+        grads.append(npy(g))
+        ps.append(npy(p).copy())
+    out["grads"] = np.stack(grads).astype(np.float32)
+    out["params"] = np.stack(ps).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "adam.npz"), **out)
+    print("adam.npz", os.path.getsize(os.path.join(OUT, "adam.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "adam":
+    adam_golden()
+
+
+def orthogonalise_golden(n=96):
+    """util.orthogonalise (util.py:95-107) run by the reference on (i) slightly perturbed rotations, (ii) general matrices
+    whose singular values sit away from the rounding boundaries k + 1/2, (iii) 4x4 affine matrices."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import util as rutil
+    torch.manual_seed(5)
+    rot = rutil.quat_to_rmat(torch.randn(n, 4))
+    pert = rot + 0.02 * torch.randn(n, 3, 3)
+    u = rutil.quat_to_rmat(torch.randn(n, 4))
+    v = rutil.quat_to_rmat(torch.randn(n, 4))
+    sv = torch.randint(0, 3, (n, 3)).float() + (torch.rand(n, 3) * 0.5 - 0.25)  # k +- 0.25, k in {0, 1, 2}
+    sv = sv.abs()
+    general = u @ torch.diag_embed(sv) @ v.transpose(-1, -2)
+    affine = torch.eye(4).repeat(n, 1, 1)
+    affine[:, :3, :3] = pert
+    affine[:, :3, 3] = torch.randn(n, 3)
+    out = {}
+    for name, m in (("pert", pert), ("general", general), ("affine", affine)):
+        out[name + "_in"] = npy(m)
+        out[name + "_out"] = npy(rutil.orthogonalise(m))
+    np.savez_compressed(os.path.join(OUT, "orthogonalise.npz"), **out)
+    print("orthogonalise.npz", os.path.getsize(os.path.join(OUT, "orthogonalise.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "orthogonalise":
+    orthogonalise_golden()
