@@ -2,6 +2,8 @@
 //   q_sample + training target (diffusion.py:339-355), reverse mean (291-313) and the
 //   chain-resident reverse sampler p_sample / p_sample_loop (315-337) with the score
 //   network on the matrix cores.
+#include <stdlib.h>
+#include <string.h>
 #include "so3x_common.hpp"
 #include "so3x_math.hpp"
 #include "so3x_igso3.hpp"
@@ -132,8 +134,15 @@ k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, co
 //  * waves never synchronise with each other after the weight image is loaded;
 //  * noise: Philox keyed (seed; global sample index, rng_offset + t) or explicit draws.
 // ---------------------------------------------------------------------------------------
-template <int PREC>
-__global__ void __launch_bounds__(256, PREC == SO3X_PREC_BF16 ? 3 : 2)
+// FAST: hardware sine / cosine in the reverse step (bf16 default; so3x_math.hpp).
+// bf16: ONE workgroup of 8 waves per CU (the image with its SiLU table is 55 KB: at most two workgroups fit a CU's LDS
+// whatever their size).  Measured at B = 2^20 (profiles/r02_ab_chain_blocks.json): 8 waves 6.96 ms per 100 steps, 12 waves
+// 7.04, two workgroups of 4 waves 7.21, 6-wave workgroups 8.7 (they do not spread evenly over the four SIMDs).
+// fp32: 4 waves, two workgroups per CU.
+template <int PREC> constexpr int chain_threads() { return PREC == SO3X_PREC_BF16 ? 768 : 256; }       // launch bound
+template <int PREC> constexpr int chain_threads_default() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }
+template <int PREC, bool FAST>
+__global__ void __launch_bounds__(chain_threads<PREC>(), PREC == SO3X_PREC_BF16 ? 3 : 2)
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
@@ -174,28 +183,55 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         v[j] = h ? o : va[j];
       }
       // ---- posterior mean + noise (diffusion.py:291-326), so3x_reverse_step.hpp
-      q = reverse_step(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+      q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
     }
     rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
   }
 }
 
+// A/B switches of the chain kernel, read once from the environment by the launcher (tools/ab/ab_chain.py interleaves the
+// variants in one process; not part of the ABI): SO3X_AB_TRIG=cw forces the Cody-Waite sine / cosine in the bf16 kernel,
+// SO3X_AB_BLOCK=<threads> the workgroup size (bf16 kernel, multiple of 64 up to 768).
+inline int ab_env(const char* name, const char* value) {
+  const char* e = getenv(name);
+  return e && !strcmp(e, value);
+}
+
+template <int PREC, bool FAST>
+int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
+                   const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
+                   uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
+  constexpr int IMG = image_bytes<PREC, CHAIN>();
+  int max_blocks = 0;
+  int threads = chain_threads_default<PREC>();
+  if (PREC == SO3X_PREC_BF16 && getenv("SO3X_AB_BLOCK")) threads = atoi(getenv("SO3X_AB_BLOCK"));
+  if (threads < 64 || threads > chain_threads<PREC>() || threads % 64) return SO3X_ERR_INVALID_ARG;
+  static PerDevice residents[13];  // one cache per workgroup size (A/B)
+  PerDevice& resident = residents[threads / 64];
+  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST>), threads, IMG, &max_blocks)) return rc;
+  const int64_t nchunks = (n + 63) / 64;
+  const int wpb = threads / 64;
+  const int64_t want = (nchunks + wpb - 1) / wpb;
+  const int grid = (int)(want < max_blocks ? want : max_blocks);
+  const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
+  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
+                     t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
+  return check_launch();
+}
+
 template <int PREC>
 int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
                  const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                  uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
-  constexpr int IMG = image_bytes<PREC, CHAIN>();
-  static PerDevice resident;  // resident blocks per device (occupancy x CUs), queried once each
-  int max_blocks = 0;
-  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC>), 256, IMG, &max_blocks)) return rc;
-  const int64_t nchunks = (n + 63) / 64;
-  const int64_t want = (nchunks + 3) / 4;
-  const int grid = (int)(want < max_blocks ? want : max_blocks);
-  const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
-  hipLaunchKernelGGL((k_p_sample_chain<PREC>), dim3(grid), dim3(256), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
-                     t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
-  return check_launch();
+#define SO3X_CHAIN_ARGS s, ws, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n
+  if constexpr (PREC == SO3X_PREC_BF16) {
+    if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false>(SO3X_CHAIN_ARGS);
+    return launch_chain_v<PREC, true>(SO3X_CHAIN_ARGS);
+  } else {
+    return launch_chain_v<PREC, false>(SO3X_CHAIN_ARGS);
+  }
+#undef SO3X_CHAIN_ARGS
 }
 
 }  // namespace

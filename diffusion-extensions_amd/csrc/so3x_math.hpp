@@ -36,6 +36,23 @@ __device__ __forceinline__ void sincos_cw(float a, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// Hardware sine / cosine (v_sin_f32 / v_cos_f32: argument in REVOLUTIONS, 8 issue cycles each, against ~25 instructions
+// = ~110 cycles for sincos_cw).  Measured absolute error <= 2e-6 on [0, 1) revolutions (tests/test_gpu_parity.py), so:
+//  * used where 1e-6 is invisible -- the direction of a Philox noise axis (unit_axis, all kernels alike), and the five
+//    exponentials of a reverse step in the bf16 chain kernels, whose step error is the bf16 network's 1e-3;
+//  * NOT used on the fp32 parity paths (gates G1 / G2 are 1e-5 with a 1e-6 median).
+// Large arguments (a * theta reaches 6.4e4 rad = 1e4 revolutions at t = T-1) are reduced with v_fract_f32: the product in
+// revolutions carries half an ulp = the error the fp32 angle a * theta has already.
+__device__ __forceinline__ void sincos_rev(float rev, float* sn, float* cs) {
+  *sn = __builtin_amdgcn_sinf(rev);
+  *cs = __builtin_amdgcn_cosf(rev);
+}
+template <bool FAST> __device__ __forceinline__ void sincos_sel(float a, float* sn, float* cs);
+template <> __device__ __forceinline__ void sincos_sel<false>(float a, float* sn, float* cs) { sincos_cw(a, sn, cs); }
+template <> __device__ __forceinline__ void sincos_sel<true>(float a, float* sn, float* cs) {
+  sincos_rev(__builtin_amdgcn_fractf(a * 0.15915494309189535f), sn, cs);
+}
+
 // 1-ulp hardware reciprocal / sqrt / rsqrt.  The IEEE-exact division and sqrt sequences
 // (v_div_scale/fmas/fixup, ~10 instructions each) cost more than the rest of the rotation
 // math; 1 ulp (6e-8) is far inside the 1e-5 parity gates.  Semantics at 0 / inf are the
@@ -192,7 +209,7 @@ __device__ __forceinline__ void unit_axis(uint32_t a, uint32_t b, float* ax) {
   float z = 2.0f * u01(a) - 1.0f + (1.0f / 16777216.0f);  // centred: z in (-1, 1)
   float r = fsqrt(fmaxf(0.0f, 1.0f - z * z));
   float sn, cs;
-  sincos_cw(2.0f * kPi * u01(b), &sn, &cs);
+  sincos_rev(u01(b), &sn, &cs);  // azimuth 2 pi u: the uniform IS the angle in revolutions
   ax[0] = r * cs; ax[1] = r * sn; ax[2] = z;
 }
 
@@ -281,9 +298,10 @@ __device__ __forceinline__ float quat_axis_angle(const Quat& q, float* ax) {
   ax[0] = q.x * inv; ax[1] = q.y * inv; ax[2] = q.z * inv;
   return 2.f * atan2_pos(n, sg * q.w);
 }
+template <bool FAST = false>
 __device__ __forceinline__ Quat quat_axis_angle_exp(const float* ax, float ang) {
   float sn, cs;
-  sincos_cw(0.5f * ang, &sn, &cs);
+  sincos_sel<FAST>(0.5f * ang, &sn, &cs);
   return Quat{cs, sn * ax[0], sn * ax[1], sn * ax[2]};
 }
 

@@ -35,7 +35,7 @@ namespace {
 constexpr int PREP_IMG_BLOCKS = 32, PREP_WT_BLOCKS = 32;
 template <int PREC, int VAR>
 __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, void* __restrict__ img, void* __restrict__ wt, int nout,
-                                              Freqs fr, int T, float scale, float* __restrict__ beff, float* __restrict__ emb_tab,
+                                              Freqs fr, int T, float scale, float offset, float* __restrict__ beff, float* __restrict__ emb_tab,
                                               __bf16* __restrict__ h0_tab, unsigned* __restrict__ zero_word) {
   constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;  // elements per lane per fragment
   if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // arrival ticket of the launch that follows
@@ -48,6 +48,9 @@ __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, 
       if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
       else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
     }
+    if (fold_scale<PREC, VAR>() && blockIdx.x == PREP_IMG_BLOCKS - 1)  // the SiLU table behind the fragments
+      reinterpret_cast<float2*>(reinterpret_cast<char*>(img) + (size_t)n_frags<PREC, VAR>() * frag_bytes<PREC>())[threadIdx.x] =
+          silu_table_entry(threadIdx.x);
     return;
   }
   if (blockIdx.x < PREP_IMG_BLOCKS + PREP_WT_BLOCKS) {
@@ -79,26 +82,27 @@ __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, 
 #pragma unroll 8
       for (int e = 0; e < NEMB; e++) acc = fmaf(W[e], emb[e], acc);
     }
-    beff[(size_t)t * 96 + o] = scale * acc;  // scale = -log2(e) when the SiLU scale fold is on (so3x_mlp.hpp)
+    beff[(size_t)t * 96 + o] = fmaf(scale, acc, offset);  // the table coordinate 16 z + 127.5 when the SiLU table is on (so3x_mlp.hpp)
   }
 }
 
 // ---- prep: per-timestep layer-0 fragments of the bf16 chain (layer0_chain_t) ------------------------------
-// element j of lane (i, h) of tile `to` feeds K slot 8h + j:  slots 0..8 = -log2(e) W_0[o][slot], 9 / 10 = bf16 halves
-// of beff[t][o] (already scaled by k_prep_beff), o = 32 to + i.
+// element j of lane (i, h) of tile `to` feeds K slot 8h + j:  slots 0..8 = 16 W_0[o][slot], 9 / 10 = bf16 halves of
+// 16 beff[t][o], 11 = the table offset 127.5 (k_prep wrote beff as 16 beff + 127.5), o = 32 to + i.
 __global__ void __launch_bounds__(192) k_prep_l0t(const float* __restrict__ params, const float* __restrict__ beff, void* __restrict__ l0t) {
   const int t = blockIdx.x, to = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int o = 32 * to + i;
-  const float be = beff[(size_t)t * 96 + o];
+  const float be = beff[(size_t)t * 96 + o] - kTabD;
   const __bf16 hi = (__bf16)be;
   bf16x8 v;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int slot = 8 * h + j;
     float val = 0.0f;
-    if (slot < 9) val = o < D ? kFoldS * params[o * D + slot] : 0.0f;
+    if (slot < 9) val = o < D ? kTabC * params[o * D + slot] : 0.0f;
     else if (slot == 9) val = (float)hi;
     else if (slot == 10) val = be - (float)hi;
+    else if (slot == 11) val = kTabD;
     v[j] = (__bf16)val;
   }
   reinterpret_cast<bf16x8*>(l0t)[((size_t)t * 3 + to) * 64 + lane] = v;
@@ -141,7 +145,8 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
   float* emb = (tables && VAR == GATHER) ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
   __bf16* h0 = (tables && VAR == GATHER) ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
   hipLaunchKernelGGL((k_prep<PREC, VAR>), dim3(PREP_IMG_BLOCKS + PREP_WT_BLOCKS + (tables ? T : 0)), dim3(256), 0, s, params,
-                     want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kFoldS : 1.0f, beff, emb, h0, zero_word);
+                     want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kTabC : 1.0f,
+                     fold_scale<PREC, VAR>() ? kTabD : 0.0f, beff, emb, h0, zero_word);
   return check_launch();
 }
 

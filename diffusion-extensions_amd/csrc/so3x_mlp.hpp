@@ -78,7 +78,10 @@ template <int PREC, int VAR> __host__ __device__ constexpr int frag_hidden(int l
 }
 template <int PREC, int VAR> __host__ __device__ constexpr int frag_last() { return frag_hidden<PREC, VAR>(4); }
 template <int PREC, int VAR> __host__ __device__ constexpr int n_frags() { return frag_last<PREC, VAR>() + ks_hidden<PREC>(); }
-template <int PREC, int VAR> __host__ __device__ constexpr int image_bytes() { return n_frags<PREC, VAR>() * frag_bytes<PREC>(); }
+// (the SiLU table of the folded bf16 CHAIN variant rides behind the fragments: see fold_scale below)
+template <int PREC, int VAR> __host__ __device__ constexpr int image_bytes() {
+  return n_frags<PREC, VAR>() * frag_bytes<PREC>() + ((PREC == SO3X_PREC_BF16 && VAR == 0 /*CHAIN*/) ? 2048 : 0);
+}
 
 // hidden feature index fed by (k-step ks, lane half h, element j)
 template <int PREC> __host__ __device__ inline int hidden_feature(int ks, int h, int j) {
@@ -107,12 +110,21 @@ template <int PREC, int VAR> __host__ __device__ inline int l0_slot_to_col(int s
 }
 template <int PREC> __host__ __device__ constexpr int l0_emb_slot0() { return PREC == SO3X_PREC_F32 ? 10 : 16; }
 
-// SiLU scale fold (bf16 sampling path only): the image pre-multiplies every pre-activation by
-// s = -log2(e), so the activation is  y * rcp(1 + exp2(y)) = s * silu(z)  -- one v_exp_f32, one
-// v_add, one v_rcp_f32, one v_mul (the -log2e multiply of exp(-z) is gone); the factor s is divided
-// back out of the NEXT layer's feature columns (for hidden layers s * 1/s: unchanged weights, only
-// the bias column carries s).
-constexpr float kFoldS = -1.44269504088896341f;
+// SiLU from an LDS table (bf16 sampling / inference path: CHAIN variant).  A SiLU as exp2, add, rcp, mul costs 24 cycles of
+// the SIMD's vector issue port per value and there are 264 values per lane per reverse step: two thirds of the chain
+// kernel.  Instead the weight image makes every hidden layer's MFMAs emit the table coordinate directly,
+//       u = 16 z + 127.5        (weights x 16; the bias column carries 16 b; a second constant-one row, 69, carries 127.5),
+// and the activation is   h = alpha_i + beta_i u,   i = sat_u8(rne(u))   -- one v_cvt_pk_u8_f32 (saturating on both sides), one
+// shift-add for the byte address, one ds_read_b64 of (alpha_i, beta_i), one v_fma: THREE vector instructions and no
+// transcendental.  Entry i holds the line through silu over z in [(i - 128)/16, (i - 127)/16), shifted to halve its one-sided
+// error (max |error| 1.3e-4, a tenth of a bf16 ulp at 0.25; the end entries continue silu's asymptotes 0 and z).  h is the
+// TRUE activation, so the next layer's weights are the plain ones (x 16 again for its own table coordinate).  The 2 KB table
+// rides at the end of the weight image and reaches LDS with it.  Measured on the chain kernel (profiles/r02_ab_chain_*.json):
+// -11 % time with a 4-instruction form of this, against +3 % LDS-port pressure feared; the LDS port has the room.
+constexpr float kTabC = 16.0f, kTabD = 127.5f;
+constexpr int kSiluTabEntries = 256, kSiluTabBytes = kSiluTabEntries * 8;
+constexpr int ONE_ROW2 = 69;  // second constant-one hidden row (tile 2, reg 1 of the upper lane half): carries kTabD
+static_assert(CHAIN == 0 && kSiluTabBytes == 2048, "image_bytes() above spells these out");
 template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() { return PREC == SO3X_PREC_BF16 && VAR == CHAIN; }
 
 // weight-image element value: fragment `frag`, lane, element j (bf16 only)
@@ -130,17 +142,30 @@ __device__ inline float image_value(const float* __restrict__ params, int frag, 
   const float* bias = W + (l < 4 ? D : nout) * D;
   if (l == 0) {
     const int col = l0_slot_to_col<PREC, VAR>(l0_slot<PREC>(ks, h, j));
-    const float sc0 = fold_scale<PREC, VAR>() ? kFoldS : 1.0f;
+    const float sc0 = fold_scale<PREC, VAR>() ? kTabC : 1.0f;
     return sc0 * (col >= 0 ? W[o * D + col] : (col == -2 ? bias[o] : 0.0f));
   }
   const int f = hidden_feature<PREC>(ks, h, j);
-  float wsc = 1.0f, bsc = 1.0f;
-  if (fold_scale<PREC, VAR>()) {
-    if (l < 4) bsc = kFoldS;            // hidden: s * (1/s) on features, s on the bias column
-    else wsc = 1.0f / kFoldS;           // output layer: undo the s carried by its inputs
-  }
-  return f < D ? wsc * W[o * D + f] : (f == ONE_ROW ? bsc * bias[o] : 0.0f);
+  const float sc = (fold_scale<PREC, VAR>() && l < 4) ? kTabC : 1.0f;  // hidden layers emit u = 16 z + 127.5; the head emits its outputs
+  if (f == ONE_ROW2) return (fold_scale<PREC, VAR>() && l < 4) ? kTabD : 0.0f;
+  return f < D ? sc * W[o * D + f] : (f == ONE_ROW ? sc * bias[o] : 0.0f);
 }
+
+// entry i of the SiLU table (alpha, beta): h = alpha + beta u on u in [i - 0.5, i + 0.5)
+__device__ inline float2 silu_table_entry(int i) {
+  const float h = 1.0f / kTabC, z0 = ((float)i - 128.0f) * h, z1 = z0 + h, zm = z0 + 0.5f * h;
+  auto f = [](float z) { return z / (1.0f + expf(-z)); };
+  float bz, az;
+  if (i == 0) { bz = 0.0f; az = f(zm); }                                   // z < -7.94: silu -> 0
+  else if (i == kSiluTabEntries - 1) { bz = 1.0f; az = f(z0) - z0; }        // z >= 7.94: silu -> z
+  else {
+    bz = (f(z1) - f(z0)) * kTabC;
+    az = f(z0) - bz * z0;
+    az += 0.5f * (f(zm) - (az + bz * zm));                                  // centre the secant's one-sided error
+  }
+  return float2{az - bz * kTabD / kTabC, bz / kTabC};                        // in terms of u = 16 z + 127.5
+}
+
 
 // ---- transposed-weight image (A operand of dH = W^T dZ in the backward), global/L2-resident -----------
 // fragment order: layers 1..3: [l-1][To(in-feature tile) 3][ks over out-features KH], then layer 4: [To 3][K4]
@@ -198,12 +223,17 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // activation + repack of the three accumulator tiles into the next layer's operand
-template <int PREC, bool FOLD = false> __device__ __forceinline__ void activate(const f32x16 (&acc)[3], Tile<PREC>& out, int h);
+template <int PREC, bool FOLD = false> __device__ __forceinline__ void activate(const f32x16 (&acc)[3], Tile<PREC>& out, int h,
+                                                                                const char* tab = nullptr);
 
-// y = s z  ->  s silu(z)
-__device__ __forceinline__ float silu_folded(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+// u = 16 z + 127.5  ->  silu(z) from the (alpha, beta) table at `tab` (LDS)
+__device__ __forceinline__ float silu_tab(float u, const char* tab) {
+  const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u, 0u, 0u);  // round to nearest, saturated to 0..255
+  const float2 e = *reinterpret_cast<const float2*>(tab + idx * 8);
+  return fmaf(e.y, u, e.x);
+}
 
-template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_F32>& out, int h) {
+template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_F32>& out, int h, const char*) {
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -211,28 +241,32 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const
   out.h[2][0] = h ? 1.0f : silu<SO3X_PREC_F32>(acc[2][0]);  // row 64 (h=0) / the constant-one row 68 (h=1)
 }
 
-template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
+template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab) {
+  auto act = [&](float y) -> float {
+    if constexpr (FOLD) return silu_tab(y, tab);
+    else return silu<SO3X_PREC_BF16>(y);
+  };
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       bf16x8 p;
 #pragma unroll
-      for (int j = 0; j < 8; j++)
-        p[j] = (__bf16)(FOLD ? silu_folded(acc[t][8 * s + j]) : silu<SO3X_PREC_BF16>(acc[t][8 * s + j]));
+      for (int j = 0; j < 8; j++) p[j] = (__bf16)act(acc[t][8 * s + j]);
       out.b[2 * t + s] = p;
     }
   bf16x8 p;
 #pragma unroll
   for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
-  p[0] = (__bf16)(h ? 1.0f : (FOLD ? silu_folded(acc[2][0]) : silu<SO3X_PREC_BF16>(acc[2][0])));
+  p[0] = (__bf16)(h ? 1.0f : act(acc[2][0]));     // row 64 | the constant-one row 68
+  if constexpr (FOLD) p[1] = (__bf16)(h ? 1.0f : 0.0f);  // row 69: the second constant one (carries the table offset)
   out.b[4] = p;
 }
-template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
-  activate_bf16<false>(acc, out, h);
+template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab) {
+  activate_bf16<false>(acc, out, h, tab);
 }
-template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, true>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h) {
-  activate_bf16<true>(acc, out, h);
+template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, true>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab) {
+  activate_bf16<true>(acc, out, h, tab);
 }
 
 // One hidden layer (NT output tiles) from LDS-resident weight fragments.
@@ -325,9 +359,9 @@ __device__ __forceinline__ void layer0_chain(const char* __restrict__ wl, const 
   }
 }
 
-// Layer 0 of the bf16 chain kernel with PER-TIMESTEP A fragments: the effective bias of timestep t rides in two extra K
-// slots of the layer's single k-step (slot 9 = bf16(beff), slot 10 = bf16 of the remainder: 16 significant bits) against
-// a constant 1 in the B operand, so the accumulators start from the MFMA's inline zero instead of 96 loaded bias values
+// Layer 0 of the bf16 chain kernel with PER-TIMESTEP A fragments: the effective bias of timestep t rides in three extra K
+// slots of the layer's single k-step (slot 9 = bf16(16 beff), slot 10 = bf16 of the remainder: 16 significant bits; slot 11 =
+// the table offset 127.5, exact in bf16) against constant ones in the B operand, so the accumulators start from the MFMA's inline zero instead of 96 loaded bias values
 // per tile (-18 broadcast loads and ~100 register moves per wave-step).  l0t = this timestep's [3][64] fragments,
 // written by k_prep_l0t, read with one coalesced 16-byte load per lane and tile.
 template <int XSRC>
@@ -344,7 +378,7 @@ __device__ __forceinline__ void layer0_chain_t(const bf16x8* __restrict__ l0t, c
   for (int j = 0; j < 8; j++) xe[j] = entry(j, false);
   bf16x8 b;
 #pragma unroll
-  for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : (j < 3 ? 1.0f : 0.0f)) : xe[j]);  // slot 8h + j
+  for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : (j < 4 ? 1.0f : 0.0f)) : xe[j]);  // slot 8h + j; 9..11 = ones
   acc[0] = mfma_bf16(w0, b, zero16<SO3X_PREC_BF16>());
   acc[1] = mfma_bf16(w1, b, zero16<SO3X_PREC_BF16>());
   acc[2] = mfma_bf16(w2, b, zero16<SO3X_PREC_BF16>());
@@ -413,11 +447,12 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
   else if constexpr (chain_layout(VAR)) layer0_chain<PREC, XSRC>(img, beff, x, acc, lane);
   else layer0_full<PREC>(img, x, t, *fr, acc, lane);
   constexpr bool FOLD = fold_scale<PREC, VAR>();
-  activate<PREC, FOLD>(acc, cur, h);
+  const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;  // the SiLU table behind the fragments (FOLD only)
+  activate<PREC, FOLD>(acc, cur, h, tab);
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     hidden_layer<PREC, 3>(img + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane);
-    activate<PREC, FOLD>(acc, cur, h);
+    activate<PREC, FOLD>(acc, cur, h, tab);
   }
   f32x16 last[1];
   hidden_layer<PREC, 1>(img + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);

@@ -440,7 +440,8 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
       forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, vo, !(last_group && s == n_steps - 1), wave, lane);
 #pragma unroll
       for (int j = 0; j < 3; j++) v[j] = __shfl(vo[j], col);
-      q = reverse_step(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+      q = reverse_step<PREC == SO3X_PREC_BF16>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset,
+                                               (uint64_t)(index_base + idx));  // bf16: hardware sine / cosine (so3x_math.hpp)
     }
     rmat_from_quat(qnormalize(q), Rm);
     if (live && h == 0) store_rot9(x_out, idx, Rm);

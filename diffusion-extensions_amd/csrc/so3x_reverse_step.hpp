@@ -12,6 +12,8 @@ enum { S_SQRT_AC = 3, S_SQRT_1MAC = 4, S_RECIP = 6, S_RECIPM1 = 7, S_COEF1 = 10,
 // SO3Diffusion.p_sample for one sample given the network output v (diffusion.py:291-326), in quaternion form:
 //   x0hat = exp(a log x) exp(b v)^T,   mean = exp(c1 log x0hat) exp(c2 log x),   x' = mean @ IGSO3(sigma_t) (t > 0).
 // idc = clamped sample index for the explicit-draw arrays, gidx = global index keying the Philox counter.
+// FAST: hardware sine / cosine for the five exponentials (so3x_math.hpp sincos_sel; the bf16 chain kernels).
+template <bool FAST = false>
 __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const float* __restrict__ sched, int T, int t,
                                              const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p,
                                              const float* __restrict__ axes,
@@ -24,9 +26,9 @@ __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const 
   const float vn = fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   const float vinv = vn > 0.f ? frcp(vn) : 0.f;
   vax[0] = v[0] * vinv; vax[1] = v[1] * vinv; vax[2] = v[2] * vinv;
-  const Quat qh = qmul(quat_axis_angle_exp(ax, a * th), quat_axis_angle_exp(vax, -b * vn));
+  const Quat qh = qmul(quat_axis_angle_exp<FAST>(ax, a * th), quat_axis_angle_exp<FAST>(vax, -b * vn));
   const float thh = quat_axis_angle(qh, axh);
-  q = qmul(quat_axis_angle_exp(axh, c1 * thh), quat_axis_angle_exp(ax, c2 * th));
+  q = qmul(quat_axis_angle_exp<FAST>(axh, c1 * thh), quat_axis_angle_exp<FAST>(ax, c2 * th));
   if (t != 0) {  // diffusion.py:320-326 -- no noise at t == 0
     float nax[3], u;
     if (axes) {
@@ -44,7 +46,7 @@ __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const 
     const float* row = trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
     const uint16_t* grow = guide_p ? guide_p + (size_t)t * kGuidePitch : nullptr;  // optional search guide (bit-identical)
     const float ang = axes ? igso3_angle<true>(row, row, SO3X_KNOTS_DATA, u, grow) : igso3_angle<false>(row, row, SO3X_KNOTS_DATA, u, grow);
-    q = qmul(q, quat_axis_angle_exp(nax, ang));   // model_mean @ sample, :326
+    q = qmul(q, quat_axis_angle_exp<FAST>(nax, ang));   // model_mean @ sample, :326
   }
   // no per-step renormalisation: q is rebuilt from (axis, angle) pairs every step, so its norm error is
   // three products' rounding (~3e-7) however long the chain is

@@ -1,29 +1,82 @@
-import sys, os, json
+"""A/B of the headline kernel's variants, interleaved in ONE process (cdna_hip_programming.md 5.4 rule 24):
+   python tools/ab/ab_chain.py [rounds=7] [out.json]
+Variants are selected per launch through the launcher's environment switches (csrc/so3x_diffusion.hip) or by swapping in an
+older build of the library (build/libso3x_r02a.so, if present):
+   base      bf16 chain kernel as shipped: 3-instruction LDS-table SiLU, hardware sine / cosine, 8-wave workgroups
+   cw        SO3X_AB_TRIG=cw     Cody-Waite sincos_cw in the reverse step (round 1's trigonometry)
+   blockNNN  SO3X_AB_BLOCK=NNN   other workgroup sizes (256: two per CU; 384 / 512 / 768: one per CU)
+   r02a_*    the build before the table became the product path: exp2 + rcp SiLU, and its 4-instruction table variant
+For each: ms per 100-step launch at B = 2^20 (median and min over the rounds), sample-steps/s, and max |x - x_fp32| after
+ONE reverse step from the same state with the same Philox noise (the fp32 kernel is the parity path pinned to the oracle)."""
+import sys, os, json, statistics
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
     sys.path.insert(0, os.path.abspath(p))
 import torch
 from so3x import backend as B
-GUIDE = True
-if len(sys.argv) > 1:
-    B.LIB_PATH = os.path.abspath(sys.argv[1])
 from so3x.so3_train import RotPredict
 from so3x.diffusion import SO3Diffusion
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 dev = "cuda:0"
 torch.manual_seed(0)
 net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
 proc = SO3Diffusion(net, timesteps=1000).to(dev)
 _, trap_p = proc._tables()
-params = net.flat_params_nograd()
+params = net.flat_data()
 n = 1 << 20
 x = B.quat_to_rmat(torch.randn(n, 4, device=dev))
-def run():
-    return B.p_sample_chain(params, proc._sched, trap_p, x, 600, 100, seed=1, precision=1, guide_p=(proc._guide_p if GUIDE else None))
-for _ in range(2): run()
+VARIANTS = {"base": {}, "cw": {"SO3X_AB_TRIG": "cw"}, "block256": {"SO3X_AB_BLOCK": "256"}, "block512": {"SO3X_AB_BLOCK": "512"},
+            "block384": {"SO3X_AB_BLOCK": "384"}, "block768": {"SO3X_AB_BLOCK": "768"}}
+# builds of earlier states of the kernel (same ABI), if present: "LIB" = path of the alternative libso3x.so
+OLD = os.path.join(ROOT, "build", "libso3x_r02a.so")
+if os.path.exists(OLD):
+    VARIANTS["r02a_exp2_rcp_silu"] = {"LIB": OLD}
+    VARIANTS["r02a_table_4instr"] = {"LIB": OLD, "SO3X_AB_SILU": "table"}
+_libs = {None: B.lib()}
+
+
+def setenv(env):
+    for k in ("SO3X_AB_TRIG", "SO3X_AB_SILU", "SO3X_AB_BLOCK"):
+        os.environ.pop(k, None)
+    os.environ.update({k: v for k, v in env.items() if k != "LIB"})
+    path = env.get("LIB")
+    if path not in _libs:
+        B._lib, B.LIB_PATH = None, path
+        _libs[path] = B.lib()
+    B._lib = _libs[path]
+
+
+def run(steps=100, t0=600, prec=1, xin=None):
+    return B.p_sample_chain(params, proc._sched, trap_p, x if xin is None else xin, t0, steps, seed=1, precision=prec, guide_p=proc._guide_p)
+
+
+for env in VARIANTS.values():  # warm every variant (attribute queries, code load) and ramp the clock
+    setenv(env)
+    for _ in range(3):
+        run()
 torch.cuda.synchronize()
-best = 1e9
-for rep in range(5):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); run(); e1.record(); torch.cuda.synchronize()
-    best = min(best, e0.elapsed_time(e1))
-print(sys.argv[1:] or "new", "ms", round(best, 4), "sample-steps/s %.4g" % (n * 100 / best * 1e3))
+times = {k: [] for k in VARIANTS}
+for r in range(rounds):
+    for name, env in VARIANTS.items():
+        setenv(env)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        times[name].append(e0.elapsed_time(e1))
+setenv({})
+xs = x[:65536].contiguous()
+ref_s = run(1, 600, prec=0, xin=xs)
+rows = []
+for name, env in VARIANTS.items():
+    setenv(env)
+    d = (run(1, 600, prec=1, xin=xs) - ref_s).abs().reshape(-1, 9).max(1).values
+    med, mn = statistics.median(times[name]), min(times[name])
+    rows.append({"variant": name, "env": env, "ms_per_100_step_launch_median": round(med, 4), "ms_min": round(mn, 4),
+                 "sample_steps_per_s_median": n * 100 / med * 1e3,
+                 "one_step_abs_dx_vs_fp32_kernel": {"median": float(d.median()), "p99": float(d.quantile(0.99)), "max": float(d.max())}})
+    print(f"{name:20s} median {med:8.4f} ms  min {mn:8.4f} ms  {n * 100 / med * 1e3:.4g} sample-steps/s   |dx| vs fp32: median "
+          f"{float(d.median()):.2e} p99 {float(d.quantile(0.99)):.2e} max {float(d.max()):.2e}")
+setenv({})
+if len(sys.argv) > 2:
+    json.dump({"what": "k_p_sample_chain<bf16> variants, B = 2^20, 100 steps per launch, t = 600..501, interleaved rounds in one process",
+               "rounds": rounds, "rows": rows}, open(sys.argv[2], "w"), indent=1)
