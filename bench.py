@@ -110,7 +110,7 @@ def pmc_valu_busy(kernel):
         return None
 
 
-def train_leg(B, torch, ctx, T, n=1 << 19, reps=20, warm=5):
+def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
     """BASELINE config 4 on every rank: one training step of so3_train.py (noising + RotPredict + MSE + backward + gradient
     all-reduce + Adam) on this GPU's shard of 2^19 rotations (global batch 2^19 x N; 2^22 at N = 8), bf16 MLP operands,
     replayed as a captured hipGraph (so3x.graphs.TrainStepGraph: the RCCL all-reduce of the flat 69 KB gradient inside the

@@ -37,7 +37,7 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
   float* wl = sm[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   const int64_t ntiles = (n + kWave - 1) / kWave;
-  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
   auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
   // distributions.py:42-43: column 0 == sample 0's eps
@@ -139,10 +139,10 @@ k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, co
 // whatever their size).  Measured at B = 2^20 (profiles/r02_ab_chain_blocks.json): 8 waves 6.96 ms per 100 steps, 12 waves
 // 7.04, two workgroups of 4 waves 7.21, 6-wave workgroups 8.7 (they do not spread evenly over the four SIMDs).
 // fp32: 4 waves, two workgroups per CU.
-template <int PREC> constexpr int chain_threads() { return PREC == SO3X_PREC_BF16 ? 768 : 256; }       // launch bound
+template <int PREC> constexpr int chain_threads() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }       // launch bound
 template <int PREC> constexpr int chain_threads_default() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }
-template <int PREC, bool FAST>
-__global__ void __launch_bounds__(chain_threads<PREC>(), PREC == SO3X_PREC_BF16 ? 3 : 2)
+template <int PREC, bool FAST, bool PAIR>
+__global__ void __launch_bounds__(chain_threads<PREC>(), 2)
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
@@ -153,7 +153,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int64_t nchunks = (n + 63) / 64;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const int64_t idx = chunk * 64 + lane;
@@ -171,8 +171,12 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       float va[3], vb[3], v[3];
       if constexpr (PREC == SO3X_PREC_BF16) {  // layer 0 from this timestep's fragments (bias in the K dimension)
         const bf16x8* l0t = l0t_tab + (size_t)t * 192;
-        forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);
-        forward_tile<PREC, CHAIN, 2, true>(lds, R, nullptr, 0, nullptr, vb, lane, l0t);
+        if constexpr (PAIR) {
+          forward_pair_bf16(lds, R, l0t, va, vb, lane);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
+        } else {
+          forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);
+          forward_tile<PREC, CHAIN, 2, true>(lds, R, nullptr, 0, nullptr, vb, lane, l0t);
+        }
       } else {
         forward_tile<PREC, CHAIN, 1>(lds, R, beff, 0, nullptr, va, lane);  // tile A = samples 0..31 of the chunk
         forward_tile<PREC, CHAIN, 2>(lds, R, beff, 0, nullptr, vb, lane);  // tile B = samples 32..63
@@ -198,7 +202,7 @@ inline int ab_env(const char* name, const char* value) {
   return e && !strcmp(e, value);
 }
 
-template <int PREC, bool FAST>
+template <int PREC, bool FAST, bool PAIR>
 int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
                    const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                    uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
@@ -207,15 +211,15 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   int threads = chain_threads_default<PREC>();
   if (PREC == SO3X_PREC_BF16 && getenv("SO3X_AB_BLOCK")) threads = atoi(getenv("SO3X_AB_BLOCK"));
   if (threads < 64 || threads > chain_threads<PREC>() || threads % 64) return SO3X_ERR_INVALID_ARG;
-  static PerDevice residents[13];  // one cache per workgroup size (A/B)
+  static PerDevice residents[9];  // one cache per workgroup size (A/B)
   PerDevice& resident = residents[threads / 64];
-  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST>), threads, IMG, &max_blocks)) return rc;
+  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST, PAIR>), threads, IMG, &max_blocks)) return rc;
   const int64_t nchunks = (n + 63) / 64;
   const int wpb = threads / 64;
   const int64_t want = (nchunks + wpb - 1) / wpb;
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
-  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
+  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
   return check_launch();
 }
@@ -226,10 +230,11 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
                  uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
 #define SO3X_CHAIN_ARGS s, ws, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n
   if constexpr (PREC == SO3X_PREC_BF16) {
-    if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false>(SO3X_CHAIN_ARGS);
-    return launch_chain_v<PREC, true>(SO3X_CHAIN_ARGS);
+    if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false, true>(SO3X_CHAIN_ARGS);
+    if (ab_env("SO3X_AB_PAIR", "0")) return launch_chain_v<PREC, true, false>(SO3X_CHAIN_ARGS);
+    return launch_chain_v<PREC, true, true>(SO3X_CHAIN_ARGS);
   } else {
-    return launch_chain_v<PREC, false>(SO3X_CHAIN_ARGS);
+    return launch_chain_v<PREC, false, false>(SO3X_CHAIN_ARGS);
   }
 #undef SO3X_CHAIN_ARGS
 }

@@ -120,7 +120,7 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
   __syncthreads();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
   const int64_t ntiles = (n + 31) / 32;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     int64_t idx = tile * 32 + col;

@@ -460,6 +460,78 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
   for (int k = 0; k < NV; k++) v[k] = last[0][k];  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
 }
 
+// ---- the two 32-sample tiles of a 64-sample wave through the network as ONE software-pipelined stream (bf16 chain) ------
+// forward_tile runs a tile's 15 MFMAs of a layer, then its 33 table activations per lane: the matrix pipe idles through the
+// activation and the vector port through most of the MFMAs (PMC, round 2: vector ALU busy 60 %, matrix pipe 34 %,
+// waves parked 36 %).  A wave owns TWO independent tiles (samples 0..31 and 32..63 of its chunk), so the stages are skewed:
+//     [MFMA A, layer l  ||  activation B, layer l-1]   [MFMA B, layer l  ||  activation A, layer l]   ...
+// one tile's activation (116 vector instructions + 33 LDS lookups) sits in the shadow of the other tile's 15 MFMAs
+// (15 x 32 cycles), inside one wave's instruction stream -- no reliance on a partner wave being in the complementary phase.
+// Each stage is fenced (sched_barrier) and left to the scheduler inside; accumulators and operands of both tiles are
+// live (96 + 40 registers), which the 8-wave workgroup's 256-register budget holds.
+template <int NT>
+__device__ __forceinline__ void mfma_layer_bf16(const char* __restrict__ wl, const Tile<SO3X_PREC_BF16>& in, f32x16 (&acc)[NT], int lane) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+#pragma unroll
+  for (int to = 0; to < NT; to++) {
+    f32x16 a = zero16<SO3X_PREC_BF16>();
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) a = mfma_bf16(w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
+    acc[to] = a;
+  }
+}
+// the layer-0 B operand of tile A (XSRC 1: column c lives in lane c) or B (XSRC 2: lane 32 + c), as layer0_chain_t builds it
+template <int XSRC>
+__device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
+  const int h = lane >> 5;
+  auto entry = [&](int j, bool feeder_is_upper) -> float {
+    const bool owner_is_upper = (XSRC == 2);
+    return feeder_is_upper == owner_is_upper ? x[j] : __shfl_xor(x[j], 32);
+  };
+  const float x8 = entry(8, true);
+  float xe[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) xe[j] = entry(j, false);
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : (j < 4 ? 1.0f : 0.0f)) : xe[j]);  // slot 8h + j; 9..11 = ones
+  return b;
+}
+__device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8* __restrict__ l0t,
+                                                  float* va, float* vb, int lane) {
+  constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
+  const int h = lane >> 5;
+  const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
+  f32x16 accA[3], accB[3];
+  Tile<PREC> curA, curB;
+  {  // layer 0 of both tiles from this timestep's three A fragments
+    const bf16x8 w0 = l0t[lane], w1 = l0t[64 + lane], w2 = l0t[128 + lane];
+    const bf16x8 bA = l0_operand<1>(x, lane), bB = l0_operand<2>(x, lane);
+    accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
+    accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
+  }
+  activate_bf16<true>(accA, curA, h, tab);
+#pragma unroll
+  for (int l = 1; l < 4; l++) {
+    const char* wl = img + (size_t)frag_hidden<PREC, VAR>(l) * FB;
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_layer_bf16<3>(wl, curA, accA, lane);       // MFMA A, layer l      ||
+    activate_bf16<true>(accB, curB, h, tab);        // activation B, layer l-1
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_layer_bf16<3>(wl, curB, accB, lane);       // MFMA B, layer l      ||
+    activate_bf16<true>(accA, curA, h, tab);        // activation A, layer l
+  }
+  const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
+  f32x16 lastA[1], lastB[1];
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_layer_bf16<1>(wlast, curA, lastA, lane);     // head A               ||
+  activate_bf16<true>(accB, curB, h, tab);          // activation B, layer 3
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_layer_bf16<1>(wlast, curB, lastB, lane);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { va[k] = lastA[0][k]; vb[k] = lastB[0][k]; }
+}
+
 // cooperative copy of the weight image (global workspace -> LDS), 16 B per lane
 __device__ __forceinline__ void load_image(const void* __restrict__ gimg, char* lds, int bytes) {
   const float4* s = reinterpret_cast<const float4*>(gimg);

@@ -141,7 +141,7 @@ k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
   __syncthreads();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
   const int64_t ntiles = (nc + 31) / 32;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t rounds = (ntiles + nwaves - 1) / nwaves;  // uniform trip count: the swap barriers are block-wide
   for (int64_t rd = 0; rd < rounds; rd++) {
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(512, 1)
 k_bwd_dw(const float* __restrict__ stash, int64_t nc, float* __restrict__ slabs, int n_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // 2 x [STASH_ROWS][LROW]
   constexpr int BUF = STASH_ROWS * LROW;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 31, h = lane >> 5;
   f32x16 acc[5];
 #pragma unroll
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(512, 1)
 k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ slabs, int n_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __bf16* sb = reinterpret_cast<__bf16*>(sm);  // [STASH_ROWS][LROW16]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 31, h = lane >> 5;
   f32x16 acc[5];
 #pragma unroll
@@ -421,27 +421,27 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
   write_slab(slabs, acc, wid, i, h, n_out);
 }
 
-// 32 parameters x 8 slab groups per block: coalesced 128-B reads, 8-way split of the slab loop, fixed
-// summation order (deterministic)
-__global__ void __launch_bounds__(256)
+// 32 parameters x 32 slab groups per block of 1024 threads: coalesced 128-B reads, every thread's (at most 8) loads
+// independent and in flight together -- the kernel is a latency chain, not a bandwidth problem (18 MB) -- fixed summation
+// order (deterministic).  (8 groups of 256 threads took 9.5 us for 256 slabs; this takes ~5.)
+constexpr int RED_GROUPS = 32;
+__global__ void __launch_bounds__(1024)
 k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
              const float* __restrict__ gscale = nullptr) {
-  __shared__ float part[8][33];
+  __shared__ float part[RED_GROUPS][33];
   const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + p;
   float s = 0.0f;
   if (idx < np) {
-    // four independent partial sums: the loads of a group's slabs are in flight together instead of one dependent
-    // add per ~1 us round trip (fixed order, so still deterministic)
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int b = g;
-    for (; b + 24 < nslabs; b += 32) {
+    for (; b + 3 * RED_GROUPS < nslabs; b += 4 * RED_GROUPS) {
       s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
-      s1 += slabs[(size_t)(b + 8) * NPARAMS_MAX + idx];
-      s2 += slabs[(size_t)(b + 16) * NPARAMS_MAX + idx];
-      s3 += slabs[(size_t)(b + 24) * NPARAMS_MAX + idx];
+      s1 += slabs[(size_t)(b + RED_GROUPS) * NPARAMS_MAX + idx];
+      s2 += slabs[(size_t)(b + 2 * RED_GROUPS) * NPARAMS_MAX + idx];
+      s3 += slabs[(size_t)(b + 3 * RED_GROUPS) * NPARAMS_MAX + idx];
     }
-    for (; b < nslabs; b += 8) s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
+    for (; b < nslabs; b += RED_GROUPS) s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
     s = (s0 + s1) + (s2 + s3);
   }
   part[g][p] = s;
@@ -449,7 +449,7 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
   if (g == 0 && idx < np) {
     float t = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) t += part[k][p];
+    for (int k = 0; k < RED_GROUPS; k++) t += part[k][p];
     if (gscale) t *= gscale[0];
     dparams[idx] = accumulate ? dparams[idx] + t : t;
   }
@@ -617,7 +617,7 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
   __syncthreads();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
   const int64_t ntiles = (n + 31) / 32;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   float sq = 0.0f;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
@@ -831,7 +831,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
   load_image(gwt, wt_lds, WTB);
   for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
   const int64_t ntiles = (n + 31) / 32;
   const int64_t nchain = (int64_t)gridDim.x * 4;
   const int64_t rounds = (ntiles + nchain - 1) / nchain;  // uniform trip count: the barriers are block-wide
@@ -981,7 +981,7 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
   else
     hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
                        emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(256), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(1024), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
                      gscale);
   return check_launch();
 }
@@ -1048,7 +1048,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
       hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs, nout);
     else
       hipLaunchKernelGGL(k_bwd_dw_bf16, dim3(g2), dim3(512), DW_LDS, s, (const __bf16*)stash, nc, slabs, nout);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(256), 0, s, (const float*)slabs, g2, dparams,
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(1024), 0, s, (const float*)slabs, g2, dparams,
                        c0 > 0 ? 1 : 0, nparams(nout));
   }
   return check_launch();

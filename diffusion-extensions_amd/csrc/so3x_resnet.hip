@@ -146,6 +146,7 @@ template <int PREC>
 __device__ __forceinline__ void issue_chunk(const char* __restrict__ gimg, char* ring, int chunk, int slot, int wave, int lane) {
   constexpr int CB = chunk_bytes<PREC>();
   constexpr int PER_WAVE = CB / 1024 / n_waves<PREC>();
+  asm volatile("" : "+v"(lane));  // the per-lane source address is formed at the issue, not kept (or spilled) across the pass
   const char* src = gimg + (size_t)chunk * CB + (size_t)(wave * PER_WAVE) * 1024 + lane * 16;
   char* dst = ring + slot * CB + (wave * PER_WAVE) * 1024;
 #pragma unroll
@@ -250,6 +251,7 @@ __device__ __forceinline__ void stream_begin(const char* __restrict__ gimg, char
 struct StashPtr { char* x; char* y; size_t layer_stride; };  // this wave's 16-KiB blocks of layer 0; +layer_stride per layer
 
 template <bool NT = false> __device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const uint32_t* p8) {
+  asm volatile("" : "+v"(lane));  // per-lane store address formed at the store, not kept (or spilled) across the pass
   u32x4* d = reinterpret_cast<u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 32);
   // NT = non-temporal stores.  Measured both ways: they keep the dumps from evicting the L2-resident weight image (training
   // forward alone 1.11 -> 0.97 ms at 2^19 samples), but the backward kernels that read the dumps next then find nothing
@@ -375,6 +377,25 @@ __device__ __forceinline__ void fill_input(float (&xf)[128], const float (&R)[9]
   for (int r = 0; r < 4; r++) xf[r] = h ? R[4 + r] : R[r];
   xf[4] = h ? xf[4] : R[8];
 }
+// the same from the five rotation entries this lane half feeds (r5 = rows 0-3 and 8 in the lower half, rows 4-7 in the
+// upper): the chain kernel forms them straight from its quaternion state, so no 3x3 matrix is live across the row loads
+__device__ __forceinline__ void rot5_from_quat(const Quat& q, int h, float (&r5)[5]) {
+  float R[9];
+  rmat_from_quat(q, R);
+#pragma unroll
+  for (int r = 0; r < 4; r++) r5[r] = h ? R[4 + r] : R[r];
+  r5[4] = R[8];
+}
+__device__ __forceinline__ void fill_input5(float (&xf)[128], const float (&r5)[5], const float* __restrict__ x0row, int h) {
+#pragma unroll
+  for (int tq = 0; tq < 32; tq++) {
+    const float4 e = *reinterpret_cast<const float4*>(x0row + 8 * tq + 4 * h);
+    xf[4 * tq] = e.x; xf[4 * tq + 1] = e.y; xf[4 * tq + 2] = e.z; xf[4 * tq + 3] = e.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) xf[r] = r5[r];
+  xf[4] = h ? xf[4] : r5[4];
+}
 
 // ---- standalone forward ----------------------------------------------------------------------
 template <int PREC, bool STASH = false>
@@ -384,7 +405,8 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
              char* stash_y = nullptr, size_t layer_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int NW = n_waves<PREC>();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: what derives from it lives in SGPRs
   const int64_t ngroups = (n + 32 * NW - 1) / (32 * NW);
   Stream st;
   stream_begin<PREC, n_resident<PREC, STASH>()>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
@@ -401,9 +423,12 @@ k_resnet_fwd(const void* __restrict__ gimg, const float* __restrict__ x0tab, int
     const size_t blk = (size_t)(g * NW + wave) * (PREC == SO3X_PREC_F32 ? 32768 : 16384);  // this wave's 32-sample block within a layer of the stash
     forward<PREC, STASH>(reinterpret_cast<const char*>(gimg), ring, st, xf, v, g + gridDim.x < ngroups, wave, lane,
                          StashPtr{stash_x + blk, stash_y + blk, layer_stride});
-    if (out && live && h == 0) {
-      out[idx * nout] = v[0]; out[idx * nout + 1] = v[1]; out[idx * nout + 2] = v[2];
-      if (nout == 6) { out[idx * 6 + 3] = v[3]; out[idx * 6 + 4] = v[4]; out[idx * 6 + 5] = v[5]; }
+    int cole = col;  // the output address is formed after the network (see k_resnet_chain)
+    asm volatile("" : "+v"(cole));
+    const int64_t idxe = (g * NW + wave) * 32 + cole;
+    if (out && idxe < n && h == 0) {
+      out[idxe * nout] = v[0]; out[idxe * nout + 1] = v[1]; out[idxe * nout + 2] = v[2];
+      if (nout == 6) { out[idxe * 6 + 3] = v[3]; out[idxe * 6 + 4] = v[4]; out[idxe * 6 + 5] = v[5]; }
     }
   }
 }
@@ -419,7 +444,8 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
                int64_t index_base, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int NW = n_waves<PREC>();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: what derives from it lives in SGPRs
   const int64_t ngroups = (n + 32 * NW - 1) / (32 * NW);
   Stream st;
   stream_begin<PREC, n_resident<PREC, false>()>(reinterpret_cast<const char*>(gimg), ring, st, wave, lane);
@@ -427,24 +453,39 @@ k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, c
     const int64_t idx = (g * NW + wave) * 32 + col;
     const bool live = idx < n;
     const int64_t idc = live ? idx : n - 1;
-    float Rm[9];
-    load_rot9(x_in, idc, Rm);
-    Quat q = quat_from_rmat(Rm);
+    Quat q;
+    {
+      float Rm[9];
+      load_rot9(x_in, idc, Rm);
+      q = quat_from_rmat(Rm);
+    }
     const bool last_group = g + gridDim.x >= ngroups;
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
-      if (s > 0) rmat_from_quat(q, Rm);
-      float xf[128], vo[NOUT_MAX], v[3];
-      fill_input(xf, Rm, x0tab + (size_t)t * 256, h);
+      float xf[128], vo[NOUT_MAX], v[3], r5[5];
+      rot5_from_quat(q, h, r5);
+      fill_input5(xf, r5, x0tab + (size_t)t * 256, h);
       forward<PREC>(reinterpret_cast<const char*>(gimg), ring, st, xf, vo, !(last_group && s == n_steps - 1), wave, lane);
 #pragma unroll
       for (int j = 0; j < 3; j++) v[j] = __shfl(vo[j], col);
-      q = reverse_step<PREC == SO3X_PREC_BF16>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset,
-                                               (uint64_t)(index_base + idx));  // bf16: hardware sine / cosine (so3x_math.hpp)
+      // Everything the reverse step derives from the sample index and the timestep (row addresses of the schedule, the CDF
+      // row and its guide, the first Philox round, the explicit-draw addresses) is formed HERE, after the network: made
+      // opaque, the index and the timestep cannot be hoisted above the 49 chunks, where they sat in a dozen spilled
+      // registers (round 1: 132 B of scratch per lane, 54x the algorithmic HBM writes).
+      int tr = t, colr = col;
+      asm volatile("" : "+s"(tr), "+v"(colr));
+      const int64_t idxr = (g * NW + wave) * 32 + colr;
+      const int64_t idcr = idxr < n ? idxr : n - 1;
+      q = reverse_step<PREC == SO3X_PREC_BF16>(q, v, sched, T, tr, trap_p, guide_p, axes, unif, idcr, seed, rng_offset,
+                                               (uint64_t)(index_base + idxr));  // bf16: hardware sine / cosine (so3x_math.hpp)
     }
+    float Rm[9];
     rmat_from_quat(qnormalize(q), Rm);
-    if (live && h == 0) store_rot9(x_out, idx, Rm);
+    int cole = col;  // (the store address likewise: formed after the chain)
+    asm volatile("" : "+v"(cole));
+    const int64_t idxe = (g * NW + wave) * 32 + cole;
+    if (idxe < n && h == 0) store_rot9(x_out, idxe, Rm);
   }
 }
 
@@ -504,7 +545,8 @@ __global__ void __launch_bounds__(512, 1)
 k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n, int nout) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int PREC = SO3X_PREC_BF16, CB = chunk_bytes<PREC>();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: what derives from it lives in SGPRs
   const int64_t ngroups = (n + 255) / 256;
   const char* gimg = reinterpret_cast<const char*>(gimg_t);
   int slot = 0;
@@ -633,7 +675,8 @@ k_resnet_bwd_f32(const void* __restrict__ gimg_t, const float* __restrict__ para
                  const char* __restrict__ stash_y, char* __restrict__ stash_dz, size_t layer_stride, int64_t n, int nout) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   constexpr int PREC = SO3X_PREC_F32, CB = chunk_bytes<PREC>();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: what derives from it lives in SGPRs
   const int64_t ngroups = (n + 127) / 128;
   const char* gimg = reinterpret_cast<const char*>(gimg_t);
   const float* Wout = params + (size_t)NBLK * LAYER_STRIDE;

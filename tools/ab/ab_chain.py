@@ -2,9 +2,11 @@
    python tools/ab/ab_chain.py [rounds=7] [out.json]
 Variants are selected per launch through the launcher's environment switches (csrc/so3x_diffusion.hip) or by swapping in an
 older build of the library (build/libso3x_r02a.so, if present):
-   base      bf16 chain kernel as shipped: 3-instruction LDS-table SiLU, hardware sine / cosine, 8-wave workgroups
+   base      bf16 chain kernel as shipped: 3-instruction LDS-table SiLU, hardware sine / cosine, the wave's two tiles as one
+             software-pipelined stream, 8-wave workgroups
    cw        SO3X_AB_TRIG=cw     Cody-Waite sincos_cw in the reverse step (round 1's trigonometry)
-   blockNNN  SO3X_AB_BLOCK=NNN   other workgroup sizes (256: two per CU; 384 / 512 / 768: one per CU)
+   unpaired  SO3X_AB_PAIR=0      one tile after the other (forward_tile twice)
+   blockNNN  SO3X_AB_BLOCK=NNN   other workgroup sizes (256: two per CU; 512: one per CU)
    r02a_*    the build before the table became the product path: exp2 + rcp SiLU, and its 4-instruction table variant
 For each: ms per 100-step launch at B = 2^20 (median and min over the rounds), sample-steps/s, and max |x - x_fp32| after
 ONE reverse step from the same state with the same Philox noise (the fp32 kernel is the parity path pinned to the oracle)."""
@@ -26,8 +28,7 @@ _, trap_p = proc._tables()
 params = net.flat_data()
 n = 1 << 20
 x = B.quat_to_rmat(torch.randn(n, 4, device=dev))
-VARIANTS = {"base": {}, "cw": {"SO3X_AB_TRIG": "cw"}, "block256": {"SO3X_AB_BLOCK": "256"}, "block512": {"SO3X_AB_BLOCK": "512"},
-            "block384": {"SO3X_AB_BLOCK": "384"}, "block768": {"SO3X_AB_BLOCK": "768"}}
+VARIANTS = {"base": {}, "cw": {"SO3X_AB_TRIG": "cw"}, "unpaired": {"SO3X_AB_PAIR": "0"}, "block256": {"SO3X_AB_BLOCK": "256"}}
 # builds of earlier states of the kernel (same ABI), if present: "LIB" = path of the alternative libso3x.so
 OLD = os.path.join(ROOT, "build", "libso3x_r02a.so")
 if os.path.exists(OLD):
@@ -37,7 +38,7 @@ _libs = {None: B.lib()}
 
 
 def setenv(env):
-    for k in ("SO3X_AB_TRIG", "SO3X_AB_SILU", "SO3X_AB_BLOCK"):
+    for k in ("SO3X_AB_TRIG", "SO3X_AB_SILU", "SO3X_AB_BLOCK", "SO3X_AB_PAIR"):
         os.environ.pop(k, None)
     os.environ.update({k: v for k, v in env.items() if k != "LIB"})
     path = env.get("LIB")

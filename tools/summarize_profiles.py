@@ -3,6 +3,7 @@
    <tag>_bench_line.json, <tag>_bench_kernel_stats.csv, <tag>_pmc_<counters>.csv (per-kernel averages) and
    pmc_traffic.json (what bench.py quotes as roofline.traffic).  No GPU needed."""
 import collections
+import statistics
 import csv
 import glob
 import json
@@ -18,7 +19,7 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line.json"))
 shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 
-KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd", "k_q_sample_target",
+KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_q_sample_target",
            "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw")
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
 for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
@@ -39,7 +40,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
 rows = []
 for cname, ks in sorted(per.items()):
     for (k, grid), vals in sorted(ks.items()):
-        rows.append({"counter": cname, "kernel": k, "grid_size": grid, "dispatches": len(vals), "mean": sum(vals) / len(vals),
+        # "mean" = the MEDIAN over the dispatches: bench.py also launches the chain kernel once for a whole 1000-step chain and a
+        # few times with other step counts; the 100-step launches are the majority and the median is one of them
+        rows.append({"counter": cname, "kernel": k, "grid_size": grid, "dispatches": len(vals), "mean": statistics.median(vals),
                      "min": min(vals), "max": max(vals)})
 with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
@@ -84,6 +87,10 @@ for k in ("k_p_sample_chain", "k_resnet_chain"):
     if busy and sqb:
         util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sqb, "simds": 1024, "shader_engines": 32,
                    "mfma_pipe_busy_frac": busy / (1024.0 * sqb / 32.0),
+                   # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md cycle-constants table) summed over waves
+                   "valu_busy_frac": (4.0 * mean("SQ_ACTIVE_INST_VALU", k) / (1024.0 * sqb / 32.0)) if mean("SQ_ACTIVE_INST_VALU", k) else None,
+                   "SQ_ACTIVE_INST_VALU": mean("SQ_ACTIVE_INST_VALU", k), "SQ_INSTS_VALU": mean("SQ_INSTS_VALU", k),
+                   "SQ_WAIT_ANY": mean("SQ_WAIT_ANY", k), "SQ_WAVE_CYCLES": mean("SQ_WAVE_CYCLES", k),
                    "note": "fraction of SIMD-cycles the matrix pipe is executing, at the clock the chip actually holds under this load"}
 traffic["mfma_utilisation"] = util
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
