@@ -1,0 +1,365 @@
+// so3x_torch.cpp -- PyTorch-ROCm custom operators over the C ABI of libso3x.so:  TORCH_LIBRARY(so3x, ...) schemas and
+// their device implementations (dispatch key "CUDA", which is what PyTorch-ROCm calls the HIP device -- torch's key name,
+// not a CUDA path).  Host-only C++ (g++): every op validates its tensors, allocates its outputs and workspaces from
+// torch's caching allocator, takes the CURRENT HIP stream of the tensors' device and calls the extern "C" entry point
+// that include/so3x.h declares.  Nothing is computed here.  Built into libso3x_torch.so by csrc/Makefile and loaded with
+// torch.ops.load_library by so3x/backend.py; the Python classes that keep the reference's names (SO3Diffusion,
+// IsotropicGaussianSO3, RotPredict, util.*) call torch.ops.so3x.* -- SURVEY.md 8b "Torch binding".
+//
+// Ops are functional (fresh outputs) unless the schema marks an argument (a!): the optimizer update and the device-
+// resident counters.  Fake-tensor (meta) kernels and autograd formulas are registered from Python (so3x/ops.py).
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "../../include/so3x.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+
+void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, "so3x: ", what, " failed: ", so3x_error_string(rc), " (code ", rc, ")"); }
+
+const Tensor& dev(const Tensor& x, const char* name, at::ScalarType dt = at::kFloat) {
+  TORCH_CHECK(x.is_cuda(), "so3x: ", name, " lives on ", x.device(), "; the MI355X backend has no CPU path");
+  TORCH_CHECK(x.scalar_type() == dt, "so3x: ", name, " must be ", dt, ", got ", x.scalar_type());
+  TORCH_CHECK(x.is_contiguous(), "so3x: ", name, " must be contiguous");
+  return x;
+}
+so3x_stream_t strm(const Tensor& x) { return (so3x_stream_t)c10::hip::getCurrentHIPStream(x.device().index()).stream(); }
+const float* F(const Tensor& x) { return x.const_data_ptr<float>(); }
+float* Fm(Tensor& x) { return x.mutable_data_ptr<float>(); }
+const float* Fo(const optional<Tensor>& x, const char* name) { return x.has_value() ? F(dev(*x, name)) : nullptr; }
+const int64_t* I64(const Tensor& x) { return x.const_data_ptr<int64_t>(); }
+const uint16_t* Guide(const optional<Tensor>& g) {
+  return g.has_value() ? reinterpret_cast<const uint16_t*>(dev(*g, "guide", at::kShort).const_data_ptr<int16_t>()) : nullptr;
+}
+Tensor f32_like(const Tensor& like, at::IntArrayRef shape) { return at::empty(shape, like.options().dtype(at::kFloat)); }
+Tensor bytes(const Tensor& like, size_t n) { return at::empty({(int64_t)n}, like.options().dtype(at::kByte)); }
+std::vector<int64_t> with_tail(const Tensor& x, int drop, std::initializer_list<int64_t> tail) {
+  std::vector<int64_t> s(x.sizes().begin(), x.sizes().end() - drop);
+  s.insert(s.end(), tail.begin(), tail.end());
+  return s;
+}
+#define GUARD(x) const c10::OptionalDeviceGuard device_guard(at::device_of(x))
+
+// ------------------------------------------------------------------------------------------- rotation algebra
+Tensor quat_to_rmat(const Tensor& q) {
+  GUARD(q);
+  Tensor out = f32_like(q, with_tail(q, 1, {3, 3}));
+  ok(so3x_quat_to_rmat(strm(q), F(dev(q, "quaternions")), Fm(out), q.numel() / 4), "quat_to_rmat");
+  return out;
+}
+#define UNARY_ROT(NAME, CFN, IN_TAIL, OUT_TAIL, INW)                                                  \
+  Tensor NAME(const Tensor& x) {                                                                      \
+    GUARD(x);                                                                                         \
+    Tensor out = f32_like(x, with_tail(x, IN_TAIL, OUT_TAIL));                                        \
+    ok(CFN(strm(x), F(dev(x, #NAME)), Fm(out), x.numel() / INW), #NAME);                              \
+    return out;                                                                                       \
+  }
+UNARY_ROT(log_rmat, so3x_log_rmat, 2, (std::initializer_list<int64_t>{3, 3}), 9)
+UNARY_ROT(log_rmat_vec, so3x_log_rmat_vec, 2, (std::initializer_list<int64_t>{3}), 9)
+UNARY_ROT(exp_skewvec, so3x_exp_skewvec, 1, (std::initializer_list<int64_t>{3, 3}), 3)
+UNARY_ROT(orthogonalise, so3x_orthogonalise, 2, (std::initializer_list<int64_t>{3, 3}), 9)
+
+Tensor so3_scale(const Tensor& R, const Tensor& k, int64_t k_stride) {
+  GUARD(R);
+  Tensor out = at::empty_like(dev(R, "rmat"));
+  ok(so3x_so3_scale(strm(R), F(R), F(dev(k, "scalars")), k_stride, Fm(out), R.numel() / 9), "so3_scale");
+  return out;
+}
+Tensor aa_to_rmat(const Tensor& axis, const Tensor& ang) {
+  GUARD(axis);
+  Tensor out = f32_like(axis, with_tail(axis, 1, {3, 3}));
+  ok(so3x_aa_to_rmat(strm(axis), F(dev(axis, "rot_axis")), F(dev(ang, "ang")), Fm(out), axis.numel() / 3), "aa_to_rmat");
+  return out;
+}
+std::tuple<Tensor, Tensor> rmat_to_aa(const Tensor& R) {
+  GUARD(R);
+  Tensor axis = f32_like(R, with_tail(R, 2, {3})), ang = f32_like(R, with_tail(R, 2, {1}));
+  ok(so3x_rmat_to_aa(strm(R), F(dev(R, "r_mat")), Fm(axis), Fm(ang), R.numel() / 9), "rmat_to_aa");
+  return {axis, ang};
+}
+Tensor so3_lerp(const Tensor& a, int64_t a_stride, const Tensor& b, const Tensor& w, int64_t w_stride) {
+  GUARD(b);
+  Tensor out = at::empty_like(dev(b, "rot_b"));
+  ok(so3x_so3_lerp(strm(b), F(dev(a, "rot_a")), a_stride, F(b), F(dev(w, "weight")), w_stride, Fm(out), b.numel() / 9), "so3_lerp");
+  return out;
+}
+Tensor rmat_dist(const Tensor& a, const Tensor& b) {
+  GUARD(a);
+  Tensor out = f32_like(a, with_tail(a, 2, {}));
+  ok(so3x_rmat_dist(strm(a), F(dev(a, "input")), F(dev(b, "target")), Fm(out), a.numel() / 9), "rmat_dist");
+  return out;
+}
+Tensor rmul(const Tensor& a, int64_t a_stride, const Tensor& b, int64_t b_stride, bool transpose_b) {
+  GUARD(a);
+  const Tensor& big = a.numel() >= b.numel() ? a : b;
+  Tensor out = at::empty_like(big);
+  ok(so3x_rmul(strm(a), F(dev(a, "a")), a_stride, F(dev(b, "b")), b_stride, transpose_b ? 1 : 0, Fm(out), big.numel() / 9), "rmul");
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------- IGSO(3)
+Tensor igso3_eps_ft(const Tensor& omega, const Tensor& eps, int64_t eps_stride) {
+  GUARD(omega);
+  Tensor out = at::empty_like(dev(omega, "omega"));
+  ok(so3x_igso3_eps_ft(strm(omega), F(omega), F(dev(eps, "eps")), eps_stride, Fm(out), omega.numel()), "igso3_eps_ft");
+  return out;
+}
+Tensor igso3_build_tables(const Tensor& eps) {
+  GUARD(eps);
+  Tensor trap = f32_like(eps, {eps.numel(), SO3X_TRAP});
+  ok(so3x_igso3_build_tables(strm(eps), F(dev(eps, "eps")), eps.numel(), Fm(trap)), "igso3_build_tables");
+  return trap;
+}
+Tensor igso3_build_guide(const Tensor& trap) {
+  GUARD(trap);
+  const int64_t rows = trap.numel() / SO3X_TRAP;
+  Tensor guide = at::empty({rows, SO3X_GUIDE_PITCH}, trap.options().dtype(at::kShort));
+  ok(so3x_igso3_build_guide(strm(trap), F(dev(trap, "trap")), rows, reinterpret_cast<uint16_t*>(guide.mutable_data_ptr<int16_t>())),
+     "igso3_build_guide");
+  return guide;
+}
+std::tuple<Tensor, Tensor, Tensor> igso3_sample(const Tensor& trap, const optional<Tensor>& guide, const optional<Tensor>& row_idx,
+                                                int64_t row_const, bool quirk_col0, const optional<Tensor>& axes,
+                                                const optional<Tensor>& unif, int64_t seed, int64_t rng_offset, int64_t index_base,
+                                                const optional<Tensor>& mean, int64_t n, bool want_angle, bool want_axis) {
+  GUARD(trap);
+  Tensor out = f32_like(trap, {n, 3, 3});
+  Tensor ang = want_angle ? f32_like(trap, {n}) : Tensor();
+  Tensor axo = want_axis ? f32_like(trap, {n, 3}) : Tensor();
+  ok(so3x_igso3_sample(strm(trap), F(dev(trap, "trap")), Guide(guide), row_idx.has_value() ? I64(dev(*row_idx, "row_idx", at::kLong)) : nullptr,
+                       row_const, quirk_col0 ? 1 : 0, Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset, index_base,
+                       Fo(mean, "mean"), Fm(out), want_angle ? Fm(ang) : nullptr, want_axis ? Fm(axo) : nullptr, n),
+     "igso3_sample");
+  return {out, ang.defined() ? ang : f32_like(trap, {0}), axo.defined() ? axo : f32_like(trap, {0, 3})};
+}
+std::tuple<Tensor, Tensor, Tensor> igso3_logprob_score(const Tensor& R, const Tensor& eps, int64_t eps_stride, bool want_score,
+                                                       bool want_grad) {
+  GUARD(R);
+  Tensor logp = f32_like(R, with_tail(R, 2, {1}));
+  Tensor score = f32_like(R, want_score ? with_tail(R, 2, {3}) : std::vector<int64_t>{0, 3});
+  Tensor grad = want_grad ? at::empty_like(R) : f32_like(R, {0, 3, 3});
+  ok(so3x_igso3_logprob_score(strm(R), F(dev(R, "rotations")), F(dev(eps, "eps")), eps_stride, Fm(logp), want_score ? Fm(score) : nullptr,
+                              want_grad ? Fm(grad) : nullptr, R.numel() / 9),
+     "igso3_logprob_score");
+  return {logp, score, grad};
+}
+
+// ------------------------------------------------------------------------------------------------ score MLP
+int64_t head_width(const Tensor& params) {
+  const int64_t trunk = SO3X_MLP_PARAMS - 198;
+  for (int64_t k : {3, 6})
+    if (params.numel() == trunk + k * 66) return k;
+  TORCH_CHECK(false, "so3x: score-MLP params must hold ", SO3X_MLP_PARAMS, " (skewvec) or ", SO3X_MLP_PARAMS_ROTMAT, " (rotmat) values");
+}
+Tensor mlp_fwd(const Tensor& params, const Tensor& R, const Tensor& t, int64_t t_stride, int64_t precision, int64_t t_table) {
+  GUARD(R);
+  const int64_t n = R.numel() / 9, n_out = head_width(params);
+  Tensor out = f32_like(R, with_tail(R, 2, {n_out}));
+  Tensor ws = bytes(R, so3x_mlp_workspace_bytes(0, (int)precision, (int)t_table));
+  ok(so3x_mlp_fwd(strm(R), F(dev(params, "params")), F(dev(R, "x")), I64(dev(t, "t", at::kLong)), t_stride, Fm(out), n, (int)n_out,
+                  (int)precision, (int)t_table, ws.mutable_data_ptr(), ws.numel()),
+     "mlp_fwd");
+  return out;
+}
+std::tuple<Tensor, Tensor> mlp_fwd_stash(const Tensor& params, const Tensor& R, const Tensor& t, int64_t t_stride, int64_t t_table) {
+  GUARD(R);
+  const int64_t n = R.numel() / 9, n_out = head_width(params);
+  Tensor out = f32_like(R, with_tail(R, 2, {n_out}));
+  Tensor zs = bytes(R, so3x_mlp_stash_bytes(n));
+  Tensor ws = bytes(R, so3x_mlp_workspace_bytes(0, SO3X_PREC_BF16, (int)t_table));
+  ok(so3x_mlp_fwd_stash(strm(R), F(dev(params, "params")), F(dev(R, "x")), I64(dev(t, "t", at::kLong)), t_stride, Fm(out),
+                        zs.mutable_data_ptr(), n, (int)n_out, SO3X_PREC_BF16, (int)t_table, ws.mutable_data_ptr(), ws.numel()),
+     "mlp_fwd_stash");
+  return {out, zs};
+}
+Tensor mlp_bwd(const Tensor& params, const Tensor& R, const Tensor& t, int64_t t_stride, const Tensor& dout, int64_t precision,
+               int64_t t_table, const optional<Tensor>& zstash) {
+  GUARD(R);
+  const int64_t n = R.numel() / 9, n_out = head_width(params);
+  Tensor dparams = f32_like(R, {params.numel()});
+  Tensor ws = bytes(R, so3x_mlp_workspace_bytes(n, (int)precision, (int)t_table));
+  ok(so3x_mlp_bwd(strm(R), F(dev(params, "params")), F(dev(R, "x")), I64(dev(t, "t", at::kLong)), t_stride, F(dev(dout, "dout")),
+                  Fm(dparams), n, (int)n_out, (int)precision, (int)t_table,
+                  zstash.has_value() ? dev(*zstash, "zstash", at::kByte).const_data_ptr() : nullptr, ws.mutable_data_ptr(), ws.numel()),
+     "mlp_bwd");
+  return dparams;
+}
+
+// ------------------------------------------------------------------------------------------ diffusion steps
+std::tuple<Tensor, Tensor, Tensor> q_sample_target(const Tensor& sched, const optional<Tensor>& trap_q, const optional<Tensor>& guide_q,
+                                                   const Tensor& x0, const Tensor& t, bool quirk_col0, const optional<Tensor>& noise,
+                                                   const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                                                   int64_t rng_offset, const optional<Tensor>& rng_offset_dev, int64_t index_base,
+                                                   bool want_x_t, bool want_target, bool want_noise) {
+  GUARD(x0);
+  const int64_t n = x0.numel() / 9;
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor x_t = want_x_t ? at::empty_like(dev(x0, "x_start")) : f32_like(x0, {0, 3, 3});
+  Tensor tg = f32_like(x0, want_target ? with_tail(x0, 2, {3}) : std::vector<int64_t>{0, 3});
+  Tensor nz = want_noise ? at::empty_like(x0) : f32_like(x0, {0, 3, 3});
+  ok(so3x_q_sample_target(strm(x0), F(sched), T, Fo(trap_q, "trap_q"), Guide(guide_q), F(x0), I64(dev(t, "t", at::kLong)),
+                          quirk_col0 ? 1 : 0, Fo(noise, "noise"), Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset,
+                          rng_offset_dev.has_value() ? I64(dev(*rng_offset_dev, "rng_offset_dev", at::kLong)) : nullptr, index_base,
+                          want_x_t ? Fm(x_t) : nullptr, want_target ? Fm(tg) : nullptr, want_noise ? Fm(nz) : nullptr, n),
+     "q_sample_target");
+  return {x_t, tg, nz};
+}
+std::tuple<Tensor, Tensor> p_mean(const Tensor& sched, const Tensor& x, const Tensor& v, const optional<Tensor>& t, int64_t t_stride,
+                                  int64_t t_const, bool want_x0hat) {
+  GUARD(x);
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor x0h = want_x0hat ? at::empty_like(dev(x, "x")) : f32_like(x, {0, 3, 3});
+  Tensor mean = at::empty_like(x);
+  if (t.has_value())
+    ok(so3x_p_mean_t(strm(x), F(sched), T, F(x), F(dev(v, "noise")), I64(dev(*t, "t", at::kLong)), t_stride, want_x0hat ? Fm(x0h) : nullptr,
+                     Fm(mean), x.numel() / 9),
+       "p_mean");
+  else
+    ok(so3x_p_mean(strm(x), F(sched), T, F(x), F(dev(v, "noise")), (int)t_const, want_x0hat ? Fm(x0h) : nullptr, Fm(mean), x.numel() / 9),
+       "p_mean");
+  return {x0h, mean};
+}
+void chain_into(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x, Tensor& out,
+                int64_t t_start, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed, int64_t rng_offset,
+                int64_t index_base, int64_t precision) {
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(out.numel() == x.numel() && out.device() == x.device(), "so3x: out must match x");
+  Tensor ws = bytes(x, so3x_p_sample_workspace_bytes(T, (int)precision));
+  ok(so3x_p_sample_chain(strm(x), F(dev(params, "params")), F(sched), T, F(dev(trap_p, "trap_p")), Guide(guide_p), F(dev(x, "x")),
+                         Fm(const_cast<Tensor&>(dev(out, "out"))), (int)t_start, (int)n_steps, Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed,
+                         (uint64_t)rng_offset, index_base, x.numel() / 9, (int)precision, ws.mutable_data_ptr(), ws.numel()),
+     "p_sample_chain");
+}
+Tensor p_sample_chain(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                      int64_t t_start, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                      int64_t rng_offset, int64_t index_base, int64_t precision) {
+  GUARD(x);
+  Tensor out = at::empty_like(x);
+  chain_into(params, sched, trap_p, guide_p, x, out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision);
+  return out;
+}
+// the same into a caller-owned tensor, which may be x itself (the steps are applied in place)
+void p_sample_chain_out(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                        int64_t t_start, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                        int64_t rng_offset, int64_t index_base, int64_t precision, Tensor& out) {
+  GUARD(x);
+  chain_into(params, sched, trap_p, guide_p, x, out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision);
+}
+
+// ---------------------------------------------------------------------------------------- one training step
+// -> (loss[1], x_t, t, dout, zstash, workspace, out): everything so3x_train_bwd needs travels as tensors
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> train_fwd(
+    const Tensor& params, const Tensor& sched, const Tensor& trap_q, const optional<Tensor>& guide_q, const Tensor& x0,
+    const optional<Tensor>& t, bool quirk_col0, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed, int64_t rng_offset,
+    optional<Tensor> rng_counter, int64_t index_base, bool want_out) {
+  GUARD(x0);
+  const int64_t n = x0.numel() / 9;
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(params.numel() == SO3X_MLP_PARAMS, "so3x: the fused training step is built for the ", SO3X_MLP_PARAMS, "-parameter skew-vector network");
+  TORCH_CHECK(n > 0, "so3x: empty batch");
+  Tensor tt = t.has_value() ? dev(*t, "t", at::kLong) : at::empty({n}, x0.options().dtype(at::kLong));
+  Tensor x_t = at::empty_like(dev(x0, "x_start"));
+  Tensor dout = f32_like(x0, {n, 3}), loss = f32_like(x0, {1});
+  Tensor out = want_out ? f32_like(x0, {n, 3}) : f32_like(x0, {0, 3});
+  Tensor zs = bytes(x0, so3x_mlp_stash_bytes(n)), ws = bytes(x0, so3x_train_workspace_bytes(n, T));
+  ok(so3x_train_fwd(strm(x0), F(dev(params, "params")), F(sched), T, F(dev(trap_q, "trap_q")), Guide(guide_q), F(x0),
+                    t.has_value() ? I64(tt) : nullptr, t.has_value() ? nullptr : tt.mutable_data_ptr<int64_t>(), quirk_col0 ? 1 : 0,
+                    Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset,
+                    rng_counter.has_value() ? dev(*rng_counter, "rng_counter", at::kLong).mutable_data_ptr<int64_t>() : nullptr, index_base, n,
+                    Fm(x_t), Fm(dout), zs.mutable_data_ptr(), Fm(loss), want_out ? Fm(out) : nullptr, ws.mutable_data_ptr(), ws.numel()),
+     "train_fwd");
+  return {loss, x_t, tt, dout, zs, ws, out};
+}
+Tensor train_bwd(const Tensor& x_t, const Tensor& t, const Tensor& dout, const Tensor& zstash, Tensor& workspace, int64_t T,
+                 const optional<Tensor>& gscale, int64_t n_params) {
+  GUARD(x_t);
+  Tensor grad = f32_like(x_t, {n_params});
+  Tensor& ws = workspace;  // the slabs region is written
+  ok(so3x_train_bwd(strm(x_t), F(dev(x_t, "x_t")), I64(dev(t, "t", at::kLong)), F(dev(dout, "dout")), dev(zstash, "zstash", at::kByte).const_data_ptr(),
+                    x_t.numel() / 9, (int)T, Fo(gscale, "grad_output"), Fm(grad), ws.mutable_data_ptr(), ws.numel()),
+     "train_bwd");
+  return grad;
+}
+void adam_step(Tensor& params, const Tensor& grad, Tensor& exp_avg, Tensor& exp_avg_sq, Tensor& step, double lr, double beta1, double beta2,
+               double eps, double weight_decay, double grad_scale) {
+  GUARD(params);
+  const int64_t n = params.numel();
+  TORCH_CHECK(grad.numel() == n && exp_avg.numel() == n && exp_avg_sq.numel() == n && step.numel() >= 2, "so3x: adam_step buffer sizes differ");
+  dev(params, "params"); dev(exp_avg, "exp_avg"); dev(exp_avg_sq, "exp_avg_sq"); dev(step, "step");
+  ok(so3x_adam_step(strm(params), Fm(params), F(dev(grad, "grad")), Fm(exp_avg), Fm(exp_avg_sq), Fm(step), n, (float)lr, (float)beta1,
+                    (float)beta2, (float)eps, (float)weight_decay, (float)grad_scale),
+     "adam_step");
+}
+
+}  // namespace
+
+TORCH_LIBRARY(so3x, m) {
+  m.def("quat_to_rmat(Tensor q) -> Tensor");
+  m.def("log_rmat(Tensor R) -> Tensor");
+  m.def("log_rmat_vec(Tensor R) -> Tensor");
+  m.def("exp_skewvec(Tensor v) -> Tensor");
+  m.def("orthogonalise(Tensor M) -> Tensor");
+  m.def("so3_scale(Tensor R, Tensor k, int k_stride) -> Tensor");
+  m.def("aa_to_rmat(Tensor axis, Tensor ang) -> Tensor");
+  m.def("rmat_to_aa(Tensor R) -> (Tensor, Tensor)");
+  m.def("so3_lerp(Tensor a, int a_stride, Tensor b, Tensor w, int w_stride) -> Tensor");
+  m.def("rmat_dist(Tensor a, Tensor b) -> Tensor");
+  m.def("rmul(Tensor a, int a_stride, Tensor b, int b_stride, bool transpose_b) -> Tensor");
+  m.def("igso3_eps_ft(Tensor omega, Tensor eps, int eps_stride) -> Tensor");
+  m.def("igso3_build_tables(Tensor eps) -> Tensor");
+  m.def("igso3_build_guide(Tensor trap) -> Tensor");
+  m.def("igso3_sample(Tensor trap, Tensor? guide, Tensor? row_idx, int row_const, bool quirk_col0, Tensor? axes, Tensor? unif, int seed, "
+        "int rng_offset, int index_base, Tensor? mean, int n, bool want_angle, bool want_axis) -> (Tensor, Tensor, Tensor)");
+  m.def("igso3_logprob_score(Tensor R, Tensor eps, int eps_stride, bool want_score, bool want_grad) -> (Tensor, Tensor, Tensor)");
+  m.def("mlp_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int precision, int t_table) -> Tensor");
+  m.def("mlp_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int t_table) -> (Tensor, Tensor)");
+  m.def("mlp_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int precision, int t_table, Tensor? zstash) -> Tensor");
+  m.def("q_sample_target(Tensor sched, Tensor? trap_q, Tensor? guide_q, Tensor x0, Tensor t, bool quirk_col0, Tensor? noise, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, Tensor? rng_offset_dev, int index_base, bool want_x_t, bool want_target, bool want_noise) "
+        "-> (Tensor, Tensor, Tensor)");
+  m.def("p_mean(Tensor sched, Tensor x, Tensor v, Tensor? t, int t_stride, int t_const, bool want_x0hat) -> (Tensor, Tensor)");
+  m.def("p_sample_chain(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, int index_base, int precision) -> Tensor");
+  m.def("p_sample_chain_out(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, int index_base, int precision, Tensor(a!) out) -> ()");
+  m.def("train_fwd(Tensor params, Tensor sched, Tensor trap_q, Tensor? guide_q, Tensor x0, Tensor? t, bool quirk_col0, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, Tensor(a!)? rng_counter, int index_base, bool want_out) "
+        "-> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("train_bwd(Tensor x_t, Tensor t, Tensor dout, Tensor zstash, Tensor(a!) workspace, int T, Tensor? gscale, int n_params) -> Tensor");
+  m.def("adam_step(Tensor(a!) params, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) step, float lr, float beta1, "
+        "float beta2, float eps, float weight_decay, float grad_scale) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
+  m.impl("quat_to_rmat", quat_to_rmat);
+  m.impl("log_rmat", log_rmat);
+  m.impl("log_rmat_vec", log_rmat_vec);
+  m.impl("exp_skewvec", exp_skewvec);
+  m.impl("orthogonalise", orthogonalise);
+  m.impl("so3_scale", so3_scale);
+  m.impl("aa_to_rmat", aa_to_rmat);
+  m.impl("rmat_to_aa", rmat_to_aa);
+  m.impl("so3_lerp", so3_lerp);
+  m.impl("rmat_dist", rmat_dist);
+  m.impl("rmul", rmul);
+  m.impl("igso3_eps_ft", igso3_eps_ft);
+  m.impl("igso3_build_tables", igso3_build_tables);
+  m.impl("igso3_build_guide", igso3_build_guide);
+  m.impl("igso3_sample", igso3_sample);
+  m.impl("igso3_logprob_score", igso3_logprob_score);
+  m.impl("mlp_fwd", mlp_fwd);
+  m.impl("mlp_fwd_stash", mlp_fwd_stash);
+  m.impl("mlp_bwd", mlp_bwd);
+  m.impl("q_sample_target", q_sample_target);
+  m.impl("p_mean", p_mean);
+  m.impl("p_sample_chain", p_sample_chain);
+  m.impl("p_sample_chain_out", p_sample_chain_out);
+  m.impl("train_fwd", train_fwd);
+  m.impl("train_bwd", train_bwd);
+  m.impl("adam_step", adam_step);
+}

@@ -1,9 +1,13 @@
-"""ctypes binding of libso3x.so (include/so3x.h) for torch tensors on an MI355X.
+"""Binding of libso3x.so (include/so3x.h) for torch tensors on an MI355X.
 
-PyTorch is plumbing here: it owns device memory and the HIP stream; every
-computation on the hot path happens in the hand-written HIP kernels behind the
-C ABI.  There is NO CPU path and NO fallback: a missing library, a missing
-symbol, a CPU tensor or a failed launch raises.
+The SO(3) hot path (rotation algebra, IGSO(3), the score MLP, the diffusion steps, the training step) is
+bound as PyTorch-ROCm custom operators: libso3x_torch.so registers TORCH_LIBRARY(so3x, ...) over the C ABI
+(csrc/so3x_torch.cpp) and the functions below call torch.ops.so3x.*.  The widened rows (SE(3) layer, statistics, the
+255-wide network, the rotation-matrix head) still reach the same C ABI through ctypes on data_ptr().
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every computation on the hot path happens in the
+hand-written HIP kernels behind the C ABI.  There is NO CPU path and NO fallback: a missing library, a missing symbol, a
+CPU tensor or a failed launch raises.
 """
 import ctypes as C
 import os
@@ -13,6 +17,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "libso3x.so")
+TORCH_LIB_PATH = os.path.join(_PKG, "libso3x_torch.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "so3x.h")
 
 PREC_F32 = 0
@@ -47,7 +52,7 @@ class So3xError(RuntimeError):
 
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()  # ops() loads lib() under it
 
 
 def lib():
@@ -79,6 +84,41 @@ def lib():
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
+
+
+_ops = None
+
+
+def ops():
+    """torch.ops.so3x after loading libso3x_torch.so (once).  Fails loudly: there is no alternative implementation."""
+    global _ops
+    if _ops is None:
+        with _lock:
+            if _ops is None:
+                lib()  # ABI / symbol check of libso3x.so first
+                if not os.path.exists(TORCH_LIB_PATH):
+                    raise So3xError(f"so3x: {TORCH_LIB_PATH} not found -- build it with `make -C {os.path.join(_PKG, 'csrc')}` "
+                                    "(or __graft_entry__.build()); this backend has no CPU / PyTorch fallback")
+                torch.ops.load_library(TORCH_LIB_PATH)
+                from . import ops as _register  # noqa: F401  (fake-tensor kernels of the operators)
+                _ops = torch.ops.so3x
+    return _ops
+
+
+def _call(fn, *args):
+    """a torch.ops.so3x call whose failures surface as So3xError, as the ctypes path's do"""
+    try:
+        return fn(*args)
+    except RuntimeError as e:
+        if "so3x:" in str(e):
+            raise So3xError(str(e).split("\n")[0]) from None
+        raise
+
+
+def _s64(v):
+    """an unsigned 64-bit seed / offset as the signed int a torch op schema carries"""
+    v = int(v) & 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
 
 
 def _check(rc, what):
@@ -219,45 +259,24 @@ def _rot_in(x, name):
 
 
 def quat_to_rmat(q):
-    q = _dev(q, "quaternions")
-    n = q.numel() // 4
-    out = torch.empty(q.shape[:-1] + (3, 3), dtype=torch.float32, device=q.device)
-    with _Guard(q):
-        _check(lib().so3x_quat_to_rmat(_stream(q), _ptr(q), _ptr(out), _i64(n)), "quat_to_rmat")
-    return out
+    return _call(ops().quat_to_rmat, _dev(q, "quaternions"))
 
 
 def log_rmat(R):
-    R = _rot_in(R, "r_mat")
-    out = torch.empty_like(R)
-    with _Guard(R):
-        _check(lib().so3x_log_rmat(_stream(R), _ptr(R), _ptr(out), _i64(R.numel() // 9)), "log_rmat")
-    return out
+    return _call(ops().log_rmat, _rot_in(R, "r_mat"))
 
 
 def log_rmat_vec(R):
-    R = _rot_in(R, "r_mat")
-    out = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
-    with _Guard(R):
-        _check(lib().so3x_log_rmat_vec(_stream(R), _ptr(R), _ptr(out), _i64(R.numel() // 9)), "log_rmat_vec")
-    return out
+    return _call(ops().log_rmat_vec, _rot_in(R, "r_mat"))
 
 
 def orthogonalise(M):
     """U round(S) V^T of each 3x3 matrix (reference util.py:95-107)"""
-    M = _rot_in(M, "mat")
-    out = torch.empty_like(M)
-    with _Guard(M):
-        _check(lib().so3x_orthogonalise(_stream(M), _ptr(M), _ptr(out), _i64(M.numel() // 9)), "orthogonalise")
-    return out
+    return _call(ops().orthogonalise, _rot_in(M, "mat"))
 
 
 def exp_skewvec(v):
-    v = _dev(v, "vec")
-    out = torch.empty(v.shape[:-1] + (3, 3), dtype=torch.float32, device=v.device)
-    with _Guard(v):
-        _check(lib().so3x_exp_skewvec(_stream(v), _ptr(v), _ptr(out), _i64(v.numel() // 3)), "exp_skewvec")
-    return out
+    return _call(ops().exp_skewvec, _dev(v, "vec"))
 
 
 def _per_sample(s, n, name, device):
@@ -272,12 +291,8 @@ def _per_sample(s, n, name, device):
 
 def so3_scale(R, scalars):
     R = _rot_in(R, "rmat")
-    n = R.numel() // 9
-    k, stride = _per_sample(scalars, n, "scalars", R.device)
-    out = torch.empty_like(R)
-    with _Guard(R):
-        _check(lib().so3x_so3_scale(_stream(R), _ptr(R), _ptr(k), _i64(stride), _ptr(out), _i64(n)), "so3_scale")
-    return out
+    k, stride = _per_sample(scalars, R.numel() // 9, "scalars", R.device)
+    return _call(ops().so3_scale, R, k, stride)
 
 
 def aa_to_rmat(axis, ang):
@@ -286,20 +301,11 @@ def aa_to_rmat(axis, ang):
     ang = _dev(ang, "ang")
     if ang.numel() != n:
         ang = ang.expand(axis.shape[:-1] + (1,)).contiguous()
-    out = torch.empty(axis.shape[:-1] + (3, 3), dtype=torch.float32, device=axis.device)
-    with _Guard(axis):
-        _check(lib().so3x_aa_to_rmat(_stream(axis), _ptr(axis), _ptr(ang), _ptr(out), _i64(n)), "aa_to_rmat")
-    return out
+    return _call(ops().aa_to_rmat, axis, ang)
 
 
 def rmat_to_aa(R):
-    R = _rot_in(R, "r_mat")
-    n = R.numel() // 9
-    axis = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device)
-    ang = torch.empty(R.shape[:-2] + (1,), dtype=torch.float32, device=R.device)
-    with _Guard(R):
-        _check(lib().so3x_rmat_to_aa(_stream(R), _ptr(R), _ptr(axis), _ptr(ang), _i64(n)), "rmat_to_aa")
-    return axis, ang
+    return _call(ops().rmat_to_aa, _rot_in(R, "r_mat"))
 
 
 def so3_lerp(a, b, w):
@@ -316,11 +322,7 @@ def so3_lerp(a, b, w):
     else:
         raise ValueError("so3x: rot_a must be one (3,3) matrix or match rot_b")
     wt, w_stride = _per_sample(w, n, "weight", b.device)
-    out = torch.empty_like(b)
-    with _Guard(b):
-        _check(lib().so3x_so3_lerp(_stream(b), _ptr(a), _i64(a_stride), _ptr(b), _ptr(wt), _i64(w_stride), _ptr(out),
-                                   _i64(n)), "so3_lerp")
-    return out
+    return _call(ops().so3_lerp, a, a_stride, b, wt, w_stride)
 
 
 def rmat_dist(a, b):
@@ -329,10 +331,7 @@ def rmat_dist(a, b):
     if a.shape != b.shape:
         a, b = torch.broadcast_tensors(a, b)
         a, b = a.contiguous(), b.contiguous()
-    out = torch.empty(a.shape[:-2], dtype=torch.float32, device=a.device)
-    with _Guard(a):
-        _check(lib().so3x_rmat_dist(_stream(a), _ptr(a), _ptr(b), _ptr(out), _i64(a.numel() // 9)), "rmat_dist")
-    return out
+    return _call(ops().rmat_dist, a, b)
 
 
 def rmul(a, b, transpose_b=False):
@@ -343,73 +342,43 @@ def rmul(a, b, transpose_b=False):
         raise ValueError(f"so3x: rmul operands must match or one must be a single (3, 3) matrix, got {tuple(a.shape)} and {tuple(b.shape)}")
     sa = 0 if (a.numel() == 9 and n > 1) else 9
     sb = 0 if (b.numel() == 9 and n > 1) else 9
-    shape = a.shape if a.numel() >= b.numel() else b.shape
-    out = torch.empty(shape, dtype=torch.float32, device=a.device)
-    with _Guard(a):
-        _check(lib().so3x_rmul(_stream(a), _ptr(a), _i64(sa), _ptr(b), _i64(sb), C.c_int(int(transpose_b)), _ptr(out),
-                               _i64(n)), "rmul")
-    return out
+    return _call(ops().rmul, a, sa, b, sb, bool(transpose_b))
 
 
 # ----------------------------------------------------------------------------- IGSO(3)
 def igso3_eps_ft(omega, eps):
     omega = _dev(omega, "omega")
-    n = omega.numel()
-    e, stride = _per_sample(eps, n, "eps", omega.device)
-    out = torch.empty_like(omega)
-    with _Guard(omega):
-        _check(lib().so3x_igso3_eps_ft(_stream(omega), _ptr(omega), _ptr(e), _i64(stride), _ptr(out), _i64(n)), "igso3_eps_ft")
-    return out
+    e, stride = _per_sample(eps, omega.numel(), "eps", omega.device)
+    return _call(ops().igso3_eps_ft, omega, e, stride)
 
 
 def igso3_build_tables(eps):
-    eps = _dev(eps, "eps").reshape(-1)
-    trap = torch.empty((eps.numel(), TRAP), dtype=torch.float32, device=eps.device)
-    with _Guard(eps):
-        _check(lib().so3x_igso3_build_tables(_stream(eps), _ptr(eps), _i64(eps.numel()), _ptr(trap)), "igso3_build_tables")
-    return trap
+    return _call(ops().igso3_build_tables, _dev(eps, "eps").reshape(-1))
 
 
 def igso3_build_guide(trap):
     """uint16 [rows, 258] search guide of CDF rows (so3x_igso3_build_guide): pass it wherever rows are looked up per sample."""
-    trap = _dev(trap, "trap")
-    rows = trap.numel() // TRAP
-    guide = torch.empty((rows, GUIDE_PITCH), dtype=torch.int16, device=trap.device)
-    with _Guard(trap):
-        _check(lib().so3x_igso3_build_guide(_stream(trap), _ptr(trap), _i64(rows), _ptr(guide)), "igso3_build_guide")
-    return guide
+    return _call(ops().igso3_build_guide, _dev(trap, "trap"))
 
 
 def igso3_sample(trap, n, row_idx=None, row_const=0, quirk_col0=False, axes=None, unif=None, seed=0, rng_offset=0,
                  index_base=0, mean=None, want_angle=False, want_axis=False, guide=None):
     trap = _dev(trap, "trap")
-    dev = trap.device
     guide = _guide(guide, trap)
     ri = _dev(row_idx, "row_idx", torch.int64).reshape(-1) if row_idx is not None else None
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
     mn = _dev(mean, "mean").reshape(9) if mean is not None else None
-    out = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
-    ang = torch.empty(n, dtype=torch.float32, device=dev) if want_angle else None
-    axo = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_axis else None
-    with _Guard(trap):
-        _check(lib().so3x_igso3_sample(_stream(trap), _ptr(trap), _ptr(guide), _ptr(ri), _i64(row_const), C.c_int(int(quirk_col0)),
-                                       _ptr(ax), _ptr(un), _u64(seed), _u64(rng_offset), _i64(index_base), _ptr(mn),
-                                       _ptr(out), _ptr(ang), _ptr(axo), _i64(n)), "igso3_sample")
-    return out, ang, axo
+    out, ang, axo = _call(ops().igso3_sample, trap, guide, ri, int(row_const), bool(quirk_col0), ax, un, _s64(seed), _s64(rng_offset),
+                          int(index_base), mn, int(n), bool(want_angle), bool(want_axis))
+    return out, (ang if want_angle else None), (axo if want_axis else None)
 
 
 def igso3_logprob_score(R, eps, want_score=True, want_grad=False):
     R = _rot_in(R, "rotations")
-    n = R.numel() // 9
-    e, stride = _per_sample(eps, n, "eps", R.device)
-    logp = torch.empty(R.shape[:-2] + (1,), dtype=torch.float32, device=R.device)
-    score = torch.empty(R.shape[:-2] + (3,), dtype=torch.float32, device=R.device) if want_score else None
-    grad = torch.empty_like(R) if want_grad else None
-    with _Guard(R):
-        _check(lib().so3x_igso3_logprob_score(_stream(R), _ptr(R), _ptr(e), _i64(stride), _ptr(logp), _ptr(score),
-                                              _ptr(grad), _i64(n)), "igso3_logprob_score")
-    return logp, score, grad
+    e, stride = _per_sample(eps, R.numel() // 9, "eps", R.device)
+    logp, score, grad = _call(ops().igso3_logprob_score, R, e, stride, bool(want_score), bool(want_grad))
+    return logp, (score if want_score else None), (grad if want_grad else None)
 
 
 # ----------------------------------------------------------------------------- score MLP
@@ -433,61 +402,34 @@ def _head_width(numel, trunk, d, what):
 def mlp_fwd(params, R, t, precision=PREC_F32, t_table=0):
     """RotPredict forward; returns the RAW network outputs [.., 3] or [.., 6] (six2rmat is a separate op)"""
     params = _dev(params, "params").reshape(-1)
-    n_out = _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
+    _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
     R = _rot_in(R, "x")
-    n = R.numel() // 9
-    tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
-    nb = lib().so3x_mlp_workspace_bytes(_i64(0), C.c_int(precision), C.c_int(int(t_table)))  # forward: image + tables only
-    ws = _workspace(R.device, nb)
-    with _Guard(R):
-        _check(lib().so3x_mlp_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n), C.c_int(n_out),
-                                  C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "mlp_fwd")
-    return out
+    tt, stride = _t_arg(t, R.numel() // 9)
+    return _call(ops().mlp_fwd, params, R, tt, stride, int(precision), int(t_table))
 
 
 def mlp_fwd_stash(params, R, t, t_table):
     """training forward (bf16 operands, bounded timesteps): (out, zstash) -- zstash goes to mlp_bwd(..., zstash=)"""
     params = _dev(params, "params").reshape(-1)
-    n_out = _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
+    _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
     R = _rot_in(R, "x")
-    n = R.numel() // 9
-    tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
-    zstash = torch.empty(lib().so3x_mlp_stash_bytes(_i64(n)), dtype=torch.uint8, device=R.device)
-    nb = lib().so3x_mlp_workspace_bytes(_i64(0), C.c_int(PREC_BF16), C.c_int(int(t_table)))
-    ws = _workspace(R.device, nb)
-    with _Guard(R):
-        _check(lib().so3x_mlp_fwd_stash(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _ptr(zstash),
-                                        _i64(n), C.c_int(n_out), C.c_int(PREC_BF16), C.c_int(int(t_table)), _ptr(ws),
-                                        C.c_size_t(ws.numel())),
-               "mlp_fwd_stash")
-    return out, zstash
+    tt, stride = _t_arg(t, R.numel() // 9)
+    return _call(ops().mlp_fwd_stash, params, R, tt, stride, int(t_table))
 
 
 def mlp_bwd(params, R, t, dout, precision=PREC_F32, t_table=0, zstash=None):
     params = _dev(params, "params").reshape(-1)
     R = _rot_in(R, "x")
-    n = R.numel() // 9
-    tt, stride = _t_arg(t, n)
+    tt, stride = _t_arg(t, R.numel() // 9)
     n_out = _head_width(params.numel(), N_PARAMS - 198, 65, "score-MLP")
     dout = _dev(dout, "dout").reshape(-1, n_out)
-    dparams = torch.empty(params.numel(), dtype=torch.float32, device=R.device)
-    nb = lib().so3x_mlp_workspace_bytes(_i64(n), C.c_int(precision), C.c_int(int(t_table)))
-    ws = _workspace(R.device, nb)
-    with _Guard(R):
-        _check(lib().so3x_mlp_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                  _i64(n), C.c_int(n_out), C.c_int(precision), C.c_int(int(t_table)), _ptr(zstash), _ptr(ws),
-                                  C.c_size_t(ws.numel())),
-               "mlp_bwd")
-    return dparams
+    return _call(ops().mlp_bwd, params, R, tt, stride, dout, int(precision), int(t_table), zstash)
 
 
 # ----------------------------------------------------------------------------- diffusion
 def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None, unif=None, seed=0, rng_offset=0,
                     index_base=0, want_x_t=True, want_target=True, want_noise=False, guide_q=None, rng_offset_dev=None):
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     x0 = _rot_in(x0, "x_start")
     n = x0.numel() // 9
     tt = _dev(t, "t", torch.int64).reshape(-1)
@@ -500,77 +442,48 @@ def q_sample_target(sched, trap_q, x0, t, quirk_col0=True, noise=None, axes=None
     nz = _rot_in(noise, "noise") if noise is not None else None
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
-    dev = x0.device
-    x_t = torch.empty_like(x0) if want_x_t else None
-    tg = torch.empty(x0.shape[:-2] + (3,), dtype=torch.float32, device=dev) if want_target else None
-    nzo = torch.empty_like(x0) if want_noise else None
-    with _Guard(x0):
-        _check(lib().so3x_q_sample_target(_stream(x0), _ptr(sched), C.c_int(T), _ptr(tq), _ptr(guide_q), _ptr(x0), _ptr(tt),
-                                          C.c_int(int(quirk_col0)), _ptr(nz), _ptr(ax), _ptr(un), _u64(seed),
-                                          _u64(rng_offset), _ptr(rng_offset_dev), _i64(index_base), _ptr(x_t), _ptr(tg),
-                                          _ptr(nzo), _i64(n)),
-               "q_sample_target")
-    return x_t, tg, nzo
+    x_t, tg, nzo = _call(ops().q_sample_target, sched, tq, guide_q, x0, tt, bool(quirk_col0), nz, ax, un, _s64(seed), _s64(rng_offset),
+                         rng_offset_dev, int(index_base), bool(want_x_t), bool(want_target), bool(want_noise))
+    return (x_t if want_x_t else None), (tg if want_target else None), (nzo if want_noise else None)
 
 
 # ------------------------------------------------------------------ one training step (so3_train.py:73-76)
 def train_fwd(params, sched, trap_q, x0, t, quirk_col0=True, axes=None, unif=None, seed=0, rng_offset=0, rng_counter=None,
               index_base=0, guide_q=None, want_out=False):
     """SO3Diffusion.p_losses for RotPredict(65, "skewvec") with bf16 operands in three launches (so3x_train_fwd): returns
-    (loss [0-d], carry) where carry = (x_t, t, dout, zstash, workspace) is what train_bwd needs, plus the network output
+    (loss [0-d], carry, out) where carry = (x_t, t, dout, zstash, workspace) is what train_bwd needs and out the network output
     when want_out.  t = None: the timesteps are drawn in the kernel from the samples' Philox blocks (and returned in the
     carry).  rng_counter: device int64 [1], read as an addend of rng_offset and incremented on the device."""
     params = _dev(params, "params").reshape(-1)
     if params.numel() != N_PARAMS:
         raise ValueError(f"so3x: the fused training step is built for the {N_PARAMS}-parameter skew-vector network")
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     trap_q = _dev(trap_q, "trap_q")
     guide_q = _guide(guide_q, trap_q, "guide_q")
     x0 = _rot_in(x0, "x_start")
     n = x0.numel() // 9
     if n == 0:
         raise ValueError("so3x: empty batch")
-    dev = x0.device
-    if t is None:  # drawn in the kernel (SO3Diffusion.forward), returned in the carry
-        tt, t_in, t_draw = torch.empty(n, dtype=torch.int64, device=dev), None, True
-    else:
-        tt = _dev(t, "t", torch.int64).reshape(-1)
-        if tt.numel() != n:
+    if t is not None:
+        t = _dev(t, "t", torch.int64).reshape(-1)
+        if t.numel() != n:
             raise ValueError("so3x: t must have one entry per sample")
-        t_in, t_draw = tt, False
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
     if (ax is None) != (un is None) or (ax is not None and (ax.shape[0] != n or un.numel() != n)):
         raise ValueError("so3x: axes [n, 3] and unif [n] go together")
     if rng_counter is not None:
         rng_counter = _dev(rng_counter, "rng_counter", torch.int64)
-    x_t = torch.empty_like(x0)
-    dout = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    out = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_out else None
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
-    zstash = torch.empty(lib().so3x_mlp_stash_bytes(_i64(n)), dtype=torch.uint8, device=dev)
-    # the workspace travels to train_bwd with the images and tables the forward's prep launch built: owned by this step
-    ws = torch.empty(lib().so3x_train_workspace_bytes(_i64(n), C.c_int(T)), dtype=torch.uint8, device=dev)
-    with _Guard(x0):
-        _check(lib().so3x_train_fwd(_stream(x0), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_q), _ptr(guide_q), _ptr(x0),
-                                    _ptr(t_in), _ptr(tt if t_draw else None), C.c_int(int(quirk_col0)), _ptr(ax), _ptr(un), _u64(seed),
-                                    _u64(rng_offset),
-                                    _ptr(rng_counter), _i64(index_base), _i64(n), _ptr(x_t), _ptr(dout), _ptr(zstash), _ptr(loss),
-                                    _ptr(out), _ptr(ws), C.c_size_t(ws.numel())), "train_fwd")
-    return loss[0], (x_t, tt, dout, zstash, ws), out
+    loss, x_t, tt, dout, zstash, ws, out = _call(ops().train_fwd, params, sched, trap_q, guide_q, x0, t, bool(quirk_col0), ax, un, _s64(seed),
+                                                 _s64(rng_offset), rng_counter, int(index_base), bool(want_out))
+    return loss[0], (x_t, tt, dout, zstash, ws), (out if want_out else None)
 
 
 def train_bwd(carry, n_params=N_PARAMS, T=None, gscale=None):
     """flat gradient [17358] of the loss train_fwd returned (so3x_train_bwd); gscale: 0-d / [1] device tensor or None"""
     x_t, tt, dout, zstash, ws = carry
-    n = x_t.numel() // 9
-    grad = torch.empty(n_params, dtype=torch.float32, device=x_t.device)
     gs = _dev(gscale, "grad_output").reshape(1) if gscale is not None else None
-    with _Guard(x_t):
-        _check(lib().so3x_train_bwd(_stream(x_t), _ptr(x_t), _ptr(tt), _ptr(dout), _ptr(zstash), _i64(n), C.c_int(int(T)), _ptr(gs),
-                                    _ptr(grad), _ptr(ws), C.c_size_t(ws.numel())), "train_bwd")
-    return grad
+    return _call(ops().train_bwd, x_t, tt, dout, zstash, ws, int(T), gs, int(n_params))
 
 
 def adam_step(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0):
@@ -578,13 +491,8 @@ def adam_step(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, we
     for name, x in (("params", params), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq), ("step", step)):
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
             raise So3xError(f"so3x: adam_step needs contiguous fp32 device tensors ({name})")
-    n = params.numel()
-    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or step.numel() < 2:
-        raise ValueError("so3x: adam_step buffer sizes differ")
-    with _Guard(params):
-        _check(lib().so3x_adam_step(_stream(params), _ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(step), _i64(n),
-                                    C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
-                                    C.c_float(grad_scale)), "adam_step")
+    _call(ops().adam_step, params, grad, exp_avg, exp_avg_sq, step, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+          float(grad_scale))
 
 
 def p_mean(sched, x, v, t, want_x0hat=False):
@@ -592,44 +500,32 @@ def p_mean(sched, x, v, t, want_x0hat=False):
     an int64 tensor with one element (shared, read on the device: no host sync) or one per sample (the reference's
     extract(coef, t, ...))."""
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     x = _rot_in(x, "x")
     v = _dev(v, "noise").reshape(-1, 3)
     n = x.numel() // 9
     if v.shape[0] != n:
         raise ValueError(f"so3x: the network output must be [{n}, 3], got {tuple(v.shape)}")
-    x0h = torch.empty_like(x) if want_x0hat else None
-    mean = torch.empty_like(x)
-    with _Guard(x):
-        if isinstance(t, torch.Tensor):
-            tt, stride = _t_arg(t, n)
-            _check(lib().so3x_p_mean_t(_stream(x), _ptr(sched), C.c_int(T), _ptr(x), _ptr(v), _ptr(tt), _i64(stride), _ptr(x0h),
-                                       _ptr(mean), _i64(n)), "p_mean")
-        else:
-            _check(lib().so3x_p_mean(_stream(x), _ptr(sched), C.c_int(T), _ptr(x), _ptr(v), C.c_int(int(t)), _ptr(x0h),
-                                     _ptr(mean), _i64(n)), "p_mean")
-    return x0h, mean
+    if isinstance(t, torch.Tensor):
+        tt, stride = _t_arg(t, n)
+        x0h, mean = _call(ops().p_mean, sched, x, v, tt, stride, 0, bool(want_x0hat))
+    else:
+        x0h, mean = _call(ops().p_mean, sched, x, v, None, 0, int(t), bool(want_x0hat))
+    return (x0h if want_x0hat else None), mean
 
 
 def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0, index_base=0,
                    precision=PREC_BF16, out=None, guide_p=None):
     params = _dev(params, "params").reshape(-1)
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     trap_p = _dev(trap_p, "trap_p")
     x = _rot_in(x, "x")
-    n = x.numel() // 9
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
     guide_p = _guide(guide_p, trap_p, "guide_p")
-    out = torch.empty_like(x) if out is None else _out_like(out, x)
-    nb = lib().so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(precision))
-    ws = _workspace(x.device, nb)
-    with _Guard(x):
-        _check(lib().so3x_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(guide_p), _ptr(x), _ptr(out),
-                                         C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un), _u64(seed),
-                                         _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision), _ptr(ws),
-                                         C.c_size_t(ws.numel())), "p_sample_chain")
+    args = (params, sched, trap_p, guide_p, x, int(t_start), int(n_steps), ax, un, _s64(seed), _s64(rng_offset), int(index_base), int(precision))
+    if out is None:
+        return _call(ops().p_sample_chain, *args)
+    _call(ops().p_sample_chain_out, *args, _out_like(out, x))
     return out
 
 

@@ -1,0 +1,174 @@
+"""Python-side registrations for the torch.ops.so3x operators that csrc/so3x_torch.cpp defines: fake-tensor (meta) kernels
+-- what torch.compile, FakeTensorMode and torch.library.opcheck need to know the output shapes without running a kernel --
+and the autograd formula of the score network's forward (its parameter gradient is the fused backward kernel; the rotation
+inputs and timesteps carry no gradient on this path).  Imported by so3x.backend.ops() right after the
+operator library is loaded."""
+import torch
+from torch.library import register_autograd, register_fake
+
+_TRAP, _GUIDE_PITCH, _STASH_TILE = 999, 258, 17 * 1024
+
+
+def _f32(like, shape):
+    return like.new_empty(shape, dtype=torch.float32)
+
+
+def _head(params):
+    n = params.numel()
+    return 3 if n == 17358 else 6
+
+
+@register_fake("so3x::quat_to_rmat")
+def _(q):
+    return _f32(q, q.shape[:-1] + (3, 3))
+
+
+@register_fake("so3x::log_rmat")
+def _(R):
+    return _f32(R, R.shape)
+
+
+@register_fake("so3x::log_rmat_vec")
+def _(R):
+    return _f32(R, R.shape[:-2] + (3,))
+
+
+@register_fake("so3x::exp_skewvec")
+def _(v):
+    return _f32(v, v.shape[:-1] + (3, 3))
+
+
+@register_fake("so3x::orthogonalise")
+def _(M):
+    return _f32(M, M.shape)
+
+
+@register_fake("so3x::so3_scale")
+def _(R, k, k_stride):
+    return _f32(R, R.shape)
+
+
+@register_fake("so3x::aa_to_rmat")
+def _(axis, ang):
+    return _f32(axis, axis.shape[:-1] + (3, 3))
+
+
+@register_fake("so3x::rmat_to_aa")
+def _(R):
+    return _f32(R, R.shape[:-2] + (3,)), _f32(R, R.shape[:-2] + (1,))
+
+
+@register_fake("so3x::so3_lerp")
+def _(a, a_stride, b, w, w_stride):
+    return _f32(b, b.shape)
+
+
+@register_fake("so3x::rmat_dist")
+def _(a, b):
+    return _f32(a, a.shape[:-2])
+
+
+@register_fake("so3x::rmul")
+def _(a, a_stride, b, b_stride, transpose_b):
+    big = a if a.numel() >= b.numel() else b
+    return _f32(big, big.shape)
+
+
+@register_fake("so3x::igso3_eps_ft")
+def _(omega, eps, eps_stride):
+    return _f32(omega, omega.shape)
+
+
+@register_fake("so3x::igso3_build_tables")
+def _(eps):
+    return _f32(eps, (eps.numel(), _TRAP))
+
+
+@register_fake("so3x::igso3_build_guide")
+def _(trap):
+    return trap.new_empty((trap.numel() // _TRAP, _GUIDE_PITCH), dtype=torch.int16)
+
+
+@register_fake("so3x::igso3_sample")
+def _(trap, guide, row_idx, row_const, quirk_col0, axes, unif, seed, rng_offset, index_base, mean, n, want_angle, want_axis):
+    return _f32(trap, (n, 3, 3)), _f32(trap, (n if want_angle else 0,)), _f32(trap, (n if want_axis else 0, 3))
+
+
+@register_fake("so3x::igso3_logprob_score")
+def _(R, eps, eps_stride, want_score, want_grad):
+    lead = R.shape[:-2]
+    return (_f32(R, lead + (1,)), _f32(R, lead + (3,) if want_score else (0, 3)), _f32(R, R.shape if want_grad else (0, 3, 3)))
+
+
+@register_fake("so3x::mlp_fwd")
+def _(params, x, t, t_stride, precision, t_table):
+    return _f32(x, x.shape[:-2] + (_head(params),))
+
+
+@register_fake("so3x::mlp_fwd_stash")
+def _(params, x, t, t_stride, t_table):
+    n = x.numel() // 9
+    return _f32(x, x.shape[:-2] + (_head(params),)), x.new_empty(((n + 31) // 32 * _STASH_TILE,), dtype=torch.uint8)
+
+
+@register_fake("so3x::mlp_bwd")
+def _(params, x, t, t_stride, dout, precision, t_table, zstash):
+    return _f32(x, (params.numel(),))
+
+
+@register_fake("so3x::q_sample_target")
+def _(sched, trap_q, guide_q, x0, t, quirk_col0, noise, axes, unif, seed, rng_offset, rng_offset_dev, index_base, want_x_t,
+      want_target, want_noise):
+    return (_f32(x0, x0.shape if want_x_t else (0, 3, 3)), _f32(x0, x0.shape[:-2] + (3,) if want_target else (0, 3)),
+            _f32(x0, x0.shape if want_noise else (0, 3, 3)))
+
+
+@register_fake("so3x::p_mean")
+def _(sched, x, v, t, t_stride, t_const, want_x0hat):
+    return _f32(x, x.shape if want_x0hat else (0, 3, 3)), _f32(x, x.shape)
+
+
+@register_fake("so3x::p_sample_chain")
+def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision):
+    return _f32(x, x.shape)
+
+
+@register_fake("so3x::p_sample_chain_out")
+def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision, out):
+    return None
+
+
+@register_fake("so3x::train_fwd")
+def _(params, sched, trap_q, guide_q, x0, t, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, want_out):
+    n = x0.numel() // 9
+    by = lambda k: x0.new_empty((k,), dtype=torch.uint8)  # noqa: E731  (workspace size: an upper bound is all a fake needs)
+    return (_f32(x0, (1,)), _f32(x0, x0.shape), x0.new_empty((n,), dtype=torch.int64), _f32(x0, (n, 3)),
+            by((n + 31) // 32 * _STASH_TILE), by(32 << 20), _f32(x0, (n if want_out else 0, 3)))
+
+
+@register_fake("so3x::train_bwd")
+def _(x_t, t, dout, zstash, workspace, T, gscale, n_params):
+    return _f32(x_t, (n_params,))
+
+
+@register_fake("so3x::adam_step")
+def _(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, grad_scale):
+    return None
+
+
+# ---- autograd of the score network's forward: d loss / d params through so3x_mlp_bwd (the forward is recomputed inside the
+#      backward kernels; the training path proper parks the pre-activations instead: so3x_train_fwd / mlp_fwd_stash)
+def _mlp_setup(ctx, inputs, output):
+    params, x, t, t_stride, precision, t_table = inputs
+    ctx.save_for_backward(params, x, t)
+    ctx.meta = (t_stride, precision, t_table)
+
+
+def _mlp_backward(ctx, dout):
+    params, x, t = ctx.saved_tensors
+    t_stride, precision, t_table = ctx.meta
+    dparams = torch.ops.so3x.mlp_bwd(params, x, t, t_stride, dout.contiguous().reshape(-1, dout.shape[-1]), precision, t_table, None)
+    return dparams, None, None, None, None, None
+
+
+register_autograd("so3x::mlp_fwd", _mlp_backward, setup_context=_mlp_setup)

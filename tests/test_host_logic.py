@@ -308,3 +308,29 @@ def test_gradients_from_a_plain_torch_path_are_gathered():
     assert net.flat_grad() is None
     g = net.gather_flat_grad()
     assert g.numel() == 17358 and net.flat_grad() is g and float(g[0]) == 0.0 and float(g[-1]) == 9.0
+
+
+def test_torch_operator_library_registers_the_hot_path():
+    """libso3x_torch.so: TORCH_LIBRARY(so3x, ...) schemas for every op of the SO(3) hot path, fake-tensor kernels so that
+    shapes propagate without a GPU, and a dispatcher that refuses CPU tensors (no CPU kernels exist)"""
+    ops = B.ops()
+    names = ("quat_to_rmat", "log_rmat", "log_rmat_vec", "exp_skewvec", "orthogonalise", "so3_scale", "aa_to_rmat", "rmat_to_aa",
+             "so3_lerp", "rmat_dist", "rmul", "igso3_eps_ft", "igso3_build_tables", "igso3_build_guide", "igso3_sample",
+             "igso3_logprob_score", "mlp_fwd", "mlp_fwd_stash", "mlp_bwd", "q_sample_target", "p_mean", "p_sample_chain",
+             "p_sample_chain_out", "train_fwd", "train_bwd", "adam_step")
+    for n in names:
+        schema = str(getattr(ops, n).default._schema)
+        assert schema.startswith(f"so3x::{n}("), schema
+    assert "Tensor(a!) params" in str(ops.adam_step.default._schema) and "Tensor(a!)? rng_counter" in str(ops.train_fwd.default._schema)
+    with pytest.raises(NotImplementedError):
+        ops.quat_to_rmat(torch.randn(3, 4))            # the dispatcher has no CPU kernel to offer
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(7, 3, 3, device="cuda")
+        t = torch.empty(7, dtype=torch.int64, device="cuda")
+        p = torch.empty(17358, device="cuda")
+        assert ops.mlp_fwd(p, x, t, 1, 1, 100).shape == (7, 3)
+        assert ops.log_rmat_vec(x).shape == (7, 3) and ops.rmat_dist(x, x).shape == (7,)
+        out, zs = ops.mlp_fwd_stash(p, x, t, 1, 100)
+        assert out.shape == (7, 3) and zs.dtype == torch.uint8 and zs.numel() == 17 * 1024
+        assert ops.mlp_bwd(p, x, t, 1, out, 1, 100, zs).shape == (17358,)

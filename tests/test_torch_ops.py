@@ -1,0 +1,90 @@
+"""GPU tests of the PyTorch-ROCm operator library (libso3x_torch.so, TORCH_LIBRARY(so3x, ...)): torch.library.opcheck on
+the operators of the hot path (schema vs behaviour, fake-tensor kernels, autograd registration, AOT dispatch), the
+dispatcher-level autograd of the score network, and agreement with the raw C ABI reached through ctypes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def env():
+    from so3x import backend as B
+    from so3x.so3_train import RotPredict
+    from so3x.diffusion import SO3Diffusion
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = SO3Diffusion(net, timesteps=100).to(DEV)
+    trap_q, trap_p = proc._tables()
+    n = 200
+    x = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
+    t = torch.randint(0, 100, (n,), device=DEV)
+    return dict(B=B, ops=B.ops(), net=net, proc=proc, trap_q=trap_q, trap_p=trap_p, x=x, t=t, n=n)
+
+
+def test_opcheck_on_the_hot_path_operators(env):
+    from torch.library import opcheck
+    ops, B, proc, x, t, n = env["ops"], env["B"], env["proc"], env["x"], env["t"], env["n"]
+    params = env["net"].flat_data().clone()
+    checks = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_dynamic")
+    opcheck(ops.mlp_fwd.default, (params, x, t, 1, B.PREC_F32, 0), test_utils=checks)
+    opcheck(ops.mlp_fwd.default, (params, x, t, 1, B.PREC_BF16, 100), test_utils=checks)
+    opcheck(ops.mlp_fwd.default, (params.clone().requires_grad_(), x, t, 1, B.PREC_F32, 100), test_utils=checks)
+    dout = torch.randn(n, 3, device=DEV)
+    opcheck(ops.mlp_bwd.default, (params, x, t, 1, dout, B.PREC_F32, 100, None), test_utils=checks)
+    opcheck(ops.q_sample_target.default, (proc._sched, env["trap_q"], proc._guide_q, x, t, True, None, None, None, 5, 0, None, 0, True,
+                                           True, False), test_utils=checks)
+    opcheck(ops.p_sample_chain.default, (params, proc._sched, env["trap_p"], proc._guide_p, x, 50, 3, None, None, 5, 0, 0,
+                                         B.PREC_BF16), test_utils=checks)
+    opcheck(ops.log_rmat_vec.default, (x,), test_utils=checks)
+    opcheck(ops.so3_scale.default, (x, torch.rand(n, device=DEV), 1), test_utils=checks)
+    opcheck(ops.igso3_logprob_score.default, (x, torch.rand(n, device=DEV) * 0.5 + 0.2, 1, True, False), test_utils=checks)
+    m, v, step = torch.zeros_like(params), torch.zeros_like(params), torch.zeros(2, device=DEV)
+    opcheck(ops.adam_step.default, (params.clone(), torch.randn_like(params), m, v, step, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0),
+            test_utils=("test_schema", "test_faketensor"))
+
+
+def test_dispatcher_level_autograd_of_the_score_network(env, golden):
+    """torch.ops.so3x.mlp_fwd is differentiable in its parameters through the registered formula (so3x_mlp_bwd):
+    the reference's autograd gradients of the seed-0 network (tests/golden/score_mlp.npz), fp32"""
+    ops, B = env["ops"], env["B"]
+    g = golden["score_mlp"]
+    params = torch.from_numpy(np.concatenate([g[f"net_{l}_{k}"].reshape(-1) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")])).to(DEV)
+    params.requires_grad_()
+    x, t = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    out = ops.mlp_fwd(params, x, t, 1, B.PREC_F32, 0)
+    assert out.requires_grad
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 2e-5 * np.abs(g["out"]).max()
+    loss = ((out - torch.from_numpy(g["target"]).to(DEV)) ** 2).mean()           # F.mse_loss, as the fixture's loss
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    loss.backward()
+    ref = np.concatenate([g[f"grad_net_{l}_{k}"].reshape(-1) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")])
+    assert np.abs(params.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_operators_equal_the_raw_c_abi(env):
+    """the operator library adds nothing to the numbers: an op and a direct ctypes call of the C entry point it wraps
+    (the maintainer stub of INTEGRATION.md) give bit-identical results"""
+    B, ops, x, n = env["B"], env["ops"], env["x"], env["n"]
+    lib = B.lib()
+    ref = torch.empty(n, 3, device=DEV)
+    rc = lib.so3x_log_rmat_vec(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(ref.data_ptr()),
+                               C.c_int64(n))
+    assert rc == 0 and torch.equal(ops.log_rmat_vec(x), ref)
+    k = torch.rand(n, device=DEV)
+    ref9 = torch.empty_like(x)
+    rc = lib.so3x_so3_scale(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(k.data_ptr()),
+                            C.c_int64(1), C.c_void_p(ref9.data_ptr()), C.c_int64(n))
+    assert rc == 0 and torch.equal(ops.so3_scale(x, k, 1), ref9)
+
+
+def test_errors_surface_as_so3x_errors(env):
+    B, x = env["B"], env["x"]
+    with pytest.raises(B.So3xError, match="no CPU path"):
+        B.log_rmat(x.cpu())
+    with pytest.raises(B.So3xError, match="p_sample_chain failed"):
+        B.p_sample_chain(env["net"].flat_data(), env["proc"]._sched, env["trap_p"], x, 3, 10)     # t_start - n_steps + 1 < 0
