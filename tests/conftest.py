@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: a GPU test that needs ~50 GB of device memory and a minute (still part of -m gpu)")
 
 
 @pytest.fixture(scope="session")
