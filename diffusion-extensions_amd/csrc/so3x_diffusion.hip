@@ -307,9 +307,11 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < so3x_p_sample_workspace_bytes(T, precision)) return SO3X_ERR_WORKSPACE;
   if (n == 0 || n_steps == 0) return SO3X_OK;
-  int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace);
+  // image + the per-timestep rows of the steps this launch runs (t_start - n_steps + 1 .. t_start)
+  const int t_first = t_start - n_steps + 1;
+  int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace, 3, nullptr, true, nullptr, t_first, n_steps);
   if (rc) return rc;
-  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace))) return rc;
+  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace, t_first, n_steps))) return rc;
   const float* beff = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + beff_offset(precision, CHAIN));
   if (precision == SO3X_PREC_F32)
     return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,

@@ -546,9 +546,10 @@ size_t image_bytes_rt(int precision, int variant);
 // One launch: [the weight image] [the transposed image -> wt, optional] [the per-timestep tables when T > 0].
 // want_image = false skips the forward image (the backward with a stash never reads it).
 // zero_word (optional): a device word the launch clears (the arrival ticket of a kernel that follows in the stream).
+// t_count > 0: only the per-timestep rows t_first .. t_first + t_count - 1 are built (a chain launch of a few steps reads no others).
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout = 3,
-                void* wt = nullptr, bool want_image = true, unsigned* zero_word = nullptr);
-int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace);
+                void* wt = nullptr, bool want_image = true, unsigned* zero_word = nullptr, int t_first = 0, int t_count = 0);
+int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace, int t_first = 0, int t_count = 0);
 size_t beff_offset(int precision, int variant);
 // tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32
 inline size_t emb_offset(int precision, int variant, int T) { return beff_offset(precision, variant) + (size_t)T * 96 * sizeof(float); }

@@ -19,6 +19,17 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line.json"))
 shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 
+# per-dispatch durations of the headline kernel from the kernel trace: bench.py launches it with 100 steps (ramp, warm-up, timed
+# region, roofline leg) and once with all 1000 (full_chain), so the stats file's plain average mixes two shapes
+trace = glob.glob(os.path.join(src, "stats", "*kernel_trace.csv"))
+if trace:
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace[0])) if "k_p_sample_chain" in r["Kernel_Name"]]
+    short = sorted(d for d in durs if d < 3 * min(durs))
+    json.dump({"what": "k_p_sample_chain dispatch durations (ms) under rocprofv3 --kernel-trace, same command as the bench line",
+               "dispatches": len(durs), "ms_all": [round(d, 4) for d in durs],
+               "ms_100_step_launches_median": statistics.median(short), "ms_100_step_launches_mean": sum(short) / len(short),
+               "n_100_step_launches": len(short)}, open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
+
 KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_q_sample_target",
            "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw")
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
