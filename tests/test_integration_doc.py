@@ -15,7 +15,7 @@ DEV = "cuda:0"
 def _blocks():
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     # the ctypes stubs (the first python block of the document is the import example for the Python layer)
-    return [b for b in re.findall(r"```python\n(.*?)```", md, flags=re.S) if "_lib" in b]
+    return [b for b in re.findall(r"```python\n(.*?)```", md, flags=re.S) if re.search(r"\b_lib\b", b)]
 
 
 def test_integration_md_has_the_stubs():
