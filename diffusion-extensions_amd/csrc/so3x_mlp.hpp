@@ -241,26 +241,61 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const
   out.h[2][0] = h ? 1.0f : silu<SO3X_PREC_F32>(acc[2][0]);  // row 64 (h=0) / the constant-one row 68 (h=1)
 }
 
+// Table form (FOLD): the lookups of SO3X_ACT_GROUP values are issued together and consumed afterwards, so that the LDS latency
+// (~100 cycles) is paid once per group under counted waits instead of once per four values (what the compiler's own
+// schedule of the value-by-value loop does).
+#ifndef SO3X_ACT_GROUP
+#define SO3X_ACT_GROUP 16
+#endif
 template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab) {
-  auto act = [&](float y) -> float {
-    if constexpr (FOLD) return silu_tab(y, tab);
-    else return silu<SO3X_PREC_BF16>(y);
-  };
+  if constexpr (FOLD) {
+    constexpr int G = SO3X_ACT_GROUP;  // 8, 16 or 32 values per group (32 = both k-steps of a tile pair)
+    float val[32];
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+    for (int g0 = 0; g0 < 32; g0 += G) {
+      float2 e[G];
+      float u[G];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      bf16x8 p;
+      for (int i = 0; i < G; i++) {
+        const int q = g0 + i;
+        u[i] = acc[q >> 4][q & 15];
+        const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[i], 0u, 0u);
+        e[i] = *reinterpret_cast<const float2*>(tab + idx * 8);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; j++) p[j] = (__bf16)act(acc[t][8 * s + j]);
-      out.b[2 * t + s] = p;
+      for (int i = 0; i < G; i++) val[g0 + i] = fmaf(e[i].y, u[i], e[i].x);
     }
-  bf16x8 p;
 #pragma unroll
-  for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
-  p[0] = (__bf16)(h ? 1.0f : act(acc[2][0]));     // row 64 | the constant-one row 68
-  if constexpr (FOLD) p[1] = (__bf16)(h ? 1.0f : 0.0f);  // row 69: the second constant one (carries the table offset)
-  out.b[4] = p;
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        bf16x8 p;
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j] = (__bf16)val[16 * t + 8 * s + j];
+        out.b[2 * t + s] = p;
+      }
+    bf16x8 p;
+#pragma unroll
+    for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
+    p[0] = (__bf16)(h ? 1.0f : silu_tab(acc[2][0], tab));  // row 64 | the constant-one row 68
+    p[1] = (__bf16)(h ? 1.0f : 0.0f);                      // row 69: the second constant one (carries the table offset)
+    out.b[4] = p;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        bf16x8 p;
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j] = (__bf16)silu<SO3X_PREC_BF16>(acc[t][8 * s + j]);
+        out.b[2 * t + s] = p;
+      }
+    bf16x8 p;
+#pragma unroll
+    for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
+    p[0] = (__bf16)(h ? 1.0f : silu<SO3X_PREC_BF16>(acc[2][0]));  // row 64 | the constant-one row 68
+    out.b[4] = p;
+  }
 }
 template <> __device__ __forceinline__ void activate<SO3X_PREC_BF16, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab) {
   activate_bf16<false>(acc, out, h, tab);
@@ -469,16 +504,23 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
 // (15 x 32 cycles), inside one wave's instruction stream -- no reliance on a partner wave being in the complementary phase.
 // Each stage is fenced (sched_barrier) and left to the scheduler inside; accumulators and operands of both tiles are
 // live (96 + 40 registers), which the 8-wave workgroup's 256-register budget holds.
+// `pre` = the five fragments of output tile 0, already in registers (fetched during the previous stage)
 template <int NT>
-__device__ __forceinline__ void mfma_layer_bf16(const char* __restrict__ wl, const Tile<SO3X_PREC_BF16>& in, f32x16 (&acc)[NT], int lane) {
+__device__ __forceinline__ void mfma_layer_bf16(const char* __restrict__ wl, const Tile<SO3X_PREC_BF16>& in, f32x16 (&acc)[NT], int lane,
+                                                const bf16x8 (&pre)[5]) {
   const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
 #pragma unroll
   for (int to = 0; to < NT; to++) {
     f32x16 a = zero16<SO3X_PREC_BF16>();
 #pragma unroll
-    for (int ks = 0; ks < 5; ks++) a = mfma_bf16(w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
+    for (int ks = 0; ks < 5; ks++) a = mfma_bf16(to == 0 ? pre[ks] : w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
     acc[to] = a;
   }
+}
+__device__ __forceinline__ void prefetch_tile0(const char* __restrict__ wl, int lane, bf16x8 (&pre)[5]) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+#pragma unroll
+  for (int ks = 0; ks < 5; ks++) pre[ks] = w[ks * 64 + lane];
 }
 // the layer-0 B operand of tile A (XSRC 1: column c lives in lane c) or B (XSRC 2: lane 32 + c), as layer0_chain_t builds it
 template <int XSRC>
@@ -497,6 +539,9 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
   for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : (j < 4 ? 1.0f : 0.0f)) : xe[j]);  // slot 8h + j; 9..11 = ones
   return b;
 }
+#ifndef SO3X_STAGE_FENCE
+#define SO3X_STAGE_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
 __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8* __restrict__ l0t,
                                                   float* va, float* vb, int lane) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
@@ -510,24 +555,32 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
     accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
     accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
   }
+  // every stage also fetches the first five weight fragments of the NEXT stage (`pre`): a stage's MFMA chain starts on
+  // registers instead of waiting ~120 cycles for its first LDS reads behind the fence
+  bf16x8 pre[5];
+  prefetch_tile0(img + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
   activate_bf16<true>(accA, curA, h, tab);
+  const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     const char* wl = img + (size_t)frag_hidden<PREC, VAR>(l) * FB;
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_layer_bf16<3>(wl, curA, accA, lane);       // MFMA A, layer l      ||
+    const char* wnext = l < 3 ? img + (size_t)frag_hidden<PREC, VAR>(l + 1) * FB : wlast;
+    SO3X_STAGE_FENCE;
+    mfma_layer_bf16<3>(wl, curA, accA, lane, pre);  // MFMA A, layer l      ||
+    prefetch_tile0(wl, lane, pre);                  //   (tile 0 of the same layer again for B)
     activate_bf16<true>(accB, curB, h, tab);        // activation B, layer l-1
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_layer_bf16<3>(wl, curB, accB, lane);       // MFMA B, layer l      ||
+    SO3X_STAGE_FENCE;
+    mfma_layer_bf16<3>(wl, curB, accB, lane, pre);  // MFMA B, layer l      ||
+    prefetch_tile0(wnext, lane, pre);
     activate_bf16<true>(accA, curA, h, tab);        // activation A, layer l
   }
-  const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
   f32x16 lastA[1], lastB[1];
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_layer_bf16<1>(wlast, curA, lastA, lane);     // head A               ||
-  activate_bf16<true>(accB, curB, h, tab);          // activation B, layer 3
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_layer_bf16<1>(wlast, curB, lastB, lane);
+  SO3X_STAGE_FENCE;
+  mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
+  prefetch_tile0(wlast, lane, pre);
+  activate_bf16<true>(accB, curB, h, tab);            // activation B, layer 3
+  SO3X_STAGE_FENCE;
+  mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = lastA[0][k]; vb[k] = lastB[0][k]; }
 }

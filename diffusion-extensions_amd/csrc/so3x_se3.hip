@@ -203,8 +203,9 @@ k_rigid_move(const float* __restrict__ rot, const float* __restrict__ shift, con
 // 12 B written per (rotation, point), the cloud and the rotation stay in registers / L1.  One workgroup per rotation
 // and 768-point slab; consecutive threads write consecutive floats.
 __global__ void __launch_bounds__(kBlock)
-k_rotate_cloud(const float* __restrict__ rot, const float* __restrict__ cloud, float* __restrict__ out, int64_t P) {
+k_rotate_cloud(const float* __restrict__ rot, const float* __restrict__ cloud, int64_t cloud_stride, float* __restrict__ out, int64_t P) {
   const int64_t b = blockIdx.y;
+  cloud += b * cloud_stride;  // 0: one cloud for every rotation; 3 P: a cloud per rotation (aircraft_rotate.py:104-106)
   float R[9];
 #pragma unroll
   for (int j = 0; j < 9; j++) R[j] = rot[b * 9 + j];
@@ -225,14 +226,15 @@ k_rotate_cloud(const float* __restrict__ rot, const float* __restrict__ cloud, f
 
 extern "C" {
 
-int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, float* out, int64_t n, int64_t P) {
-  if (n < 0 || P < 0 || n > 65535 * (int64_t)65535 || ((n && P) && (!rot || !cloud || !out))) return SO3X_ERR_INVALID_ARG;
+int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int64_t cloud_stride, float* out, int64_t n, int64_t P) {
+  if (n < 0 || P < 0 || n > 65535 * (int64_t)65535 || ((n && P) && (!rot || !cloud || !out)) || (cloud_stride != 0 && cloud_stride != 3 * P))
+    return SO3X_ERR_INVALID_ARG;
   if (n == 0 || P == 0) return SO3X_OK;
   const unsigned gx = (unsigned)((3 * P + 3 * kBlock - 1) / (3 * kBlock));
   for (int64_t b0 = 0; b0 < n; b0 += 65535) {  // grid.y limit
     const int64_t nb = n - b0 < 65535 ? n - b0 : 65535;
-    hipLaunchKernelGGL(k_rotate_cloud, dim3(gx, (unsigned)nb), dim3(kBlock), 0, (hipStream_t)s, rot + b0 * 9, cloud,
-                       out + b0 * 3 * P, P);
+    hipLaunchKernelGGL(k_rotate_cloud, dim3(gx, (unsigned)nb), dim3(kBlock), 0, (hipStream_t)s, rot + b0 * 9, cloud + b0 * cloud_stride,
+                       cloud_stride, out + b0 * 3 * P, P);
   }
   return check_launch();
 }

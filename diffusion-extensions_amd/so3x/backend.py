@@ -530,13 +530,22 @@ def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=N
 
 
 def rotate_cloud(rot, cloud):
-    """cloud [P, 3] @ rot[..., 3, 3]^T -> [..., P, 3]  (PointCloudProj, reference models.py:75-91)"""
+    """cloud @ rot[..., 3, 3]^T -> [..., P, 3]  (PointCloudProj, reference models.py:75-91): cloud [P, 3] shared by every rotation,
+    or [n, P, 3], one cloud per rotation (torch.matmul's batching, what aircraft_rotate.py feeds it)"""
     rot = _rot_in(rot, "x")
-    cloud = _dev(cloud, "data").reshape(-1, 3)
-    n, P = rot.numel() // 9, cloud.shape[0]
+    cloud = _dev(cloud, "data")
+    n = rot.numel() // 9
+    if cloud.dim() == 2 or n == 0:
+        cloud = cloud.reshape(-1, 3)
+        P, stride = cloud.shape[0], 0
+    else:
+        if cloud.shape[:-2] != rot.shape[:-2]:
+            raise ValueError(f"so3x: a batch of clouds {tuple(cloud.shape)} needs one rotation each, got {tuple(rot.shape)}")
+        P = cloud.shape[-2]
+        stride = 3 * P
     out = torch.empty(rot.shape[:-2] + (P, 3), dtype=torch.float32, device=rot.device)
     with _Guard(rot):
-        _check(lib().so3x_rotate_cloud(_stream(rot), _ptr(rot), _ptr(cloud), _ptr(out), _i64(n), _i64(P)), "rotate_cloud")
+        _check(lib().so3x_rotate_cloud(_stream(rot), _ptr(rot), _ptr(cloud), _i64(stride), _ptr(out), _i64(n), _i64(P)), "rotate_cloud")
     return out
 
 

@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-__all__ = ["SinusoidalPosEmb", "Siren", "ResLayer", "PointCloudProj"]
+__all__ = ["SinusoidalPosEmb", "Siren", "ResLayer", "PointCloudProj", "PoolRN", "TransformerEnc2", "PlaneNet"]
 
 
 class SinusoidalPosEmb(nn.Module):
@@ -69,3 +69,58 @@ class PointCloudProj(nn.Module):
             from .util import euler_to_rmat
             x = euler_to_rmat(*torch.unbind(x, -1))
         return _b.rotate_cloud(x, self.data)
+
+
+class PoolRN(nn.Module):
+    """Learned-weight mean over the point axis (reference models.py:94-110): out = sum_p w_p lin(x_p) / sum_p w_p with
+    w_p = sigmoid(Linear(x_p)) * mask_p.  mask: [.., P] booleans, None = all points.  (The reference's own default mask is
+    built one axis too wide -- [.., P, 1] and then indexed [..., None], models.py:105-106 -- which only broadcasts when the
+    batch equals the point count; the semantics here are those its masked callers get.)"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.pool = nn.Sequential(nn.Linear(dim, 1), nn.Sigmoid())
+        self.lin = nn.Linear(dim, dim)
+
+    def forward(self, x, mask=None):
+        if mask is None:
+            mask = torch.ones(x.shape[:-1], dtype=torch.bool, device=x.device)
+        weight = self.pool(x) * mask[..., None]
+        w_sum = weight.sum(dim=-2, keepdim=True).clamp(min=1e-6)
+        out = (self.lin(x) * weight).sum(dim=-2, keepdim=True) / w_sum
+        return out[..., 0, :]
+
+
+class TransformerEnc2(nn.Module):
+    """nn.TransformerEncoder with a final LayerNorm on batch-first input (reference models.py:167-182)"""
+
+    def __init__(self, dim=512, heads=4, layers=4):
+        super().__init__()
+        self.encoder = nn.TransformerEncoder(nn.TransformerEncoderLayer(dim, heads), layers, norm=nn.LayerNorm(dim, eps=1e-5))
+
+    def forward(self, x, src_key_padding_mask=None):
+        return self.encoder(x.transpose(0, 1), src_key_padding_mask=src_key_padding_mask).transpose(0, 1)
+
+
+class PlaneNet(nn.Module):
+    """The point-cloud pose denoiser of the aircraft task (reference models.py:185-210): SIREN position encoding of every
+    point (dim/2) next to the timestep's sinusoidal embedding (dim/2), a `layers`-deep nn.TransformerEncoder over the points,
+    PoolRN over the points and a Linear to the 3 skew-vector components -- the `denoise_fn` of ProjectedSO3Diffusion with
+    PointCloudProj as the projection (aircraft_rotate.py:64-106).  Plain torch modules with the reference's state_dict keys
+    (the encoder runs on rocBLAS / MIOpen through torch; the diffusion around it is the fused kernels of this package).
+    Returns [B, 3]: one prediction per cloud.  (The reference's forward ends in `out[..., 0, :]` on that [B, 3] tensor,
+    models.py:210, i.e. it hands back sample 0's row only, and its pooling fails for batch != points -- see PoolRN.)"""
+
+    def __init__(self, dim=512, heads=4, layers=4):
+        super().__init__()
+        self.encoder = nn.TransformerEncoder(nn.TransformerEncoderLayer(dim, heads), layers)
+        self.position_siren = Siren(in_channels=3, out_channels=dim // 2, scale=30)
+        self.time_embedding = SinusoidalPosEmb(dim // 2)
+        self.out_net = nn.Sequential(PoolRN(dim), nn.Linear(dim, 3))
+
+    def forward(self, x, t):
+        x_emb = self.position_siren(x)                                         # [B, P, dim/2]
+        t_emb = self.time_embedding(t)                                         # [B, dim/2]
+        t_in = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)
+        encoding = self.encoder(t_in.transpose(0, 1)).transpose(0, 1)          # sequence-first inside, as the reference
+        return self.out_net(encoding)

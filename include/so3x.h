@@ -267,8 +267,9 @@ int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const
                     const float* frames, float* out_pos, float* out_frames, int64_t S, int64_t L);
 
 /* PointCloudProj (models.py:75-91, so3 = True): the projection the Projected*Diffusion variants (diffusion.py:377-429,
- * 525-573) feed their denoisers with: out[n][P][3] = cloud[P][3] @ rot[n]^T. */
-int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, float* out, int64_t n, int64_t P);
+ * 525-573) feed their denoisers with: out[n][P][3] = cloud @ rot[n]^T.  cloud_stride 0: one cloud [P][3] for every rotation;
+ * 3 P: one cloud per rotation, cloud[n][P][3] (how aircraft_rotate.py:104-106 calls it: a batch of shapes, one pose each). */
+int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int64_t cloud_stride, float* out, int64_t n, int64_t P);
 
 /* ------------------------------------------------------- sample-quality statistics */
 /* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):

@@ -93,3 +93,78 @@ def test_projected_se3_diffusion_matches_base_with_identity_projection():
     out = prj.p_sample_loop((16,), lambda a: a)
     assert out.rot.shape == (16, 3, 3) and torch.isfinite(out.rot).all() and torch.isfinite(out.shift).all()
     assert torch.isfinite(prj(x, lambda a: a))
+
+
+# ------------------------------------------------------------------ PlaneNet (reference models.py:185-210)
+def _planenet(golden, device="cpu"):
+    from so3x.models import PlaneNet
+    g = golden["planenet"]
+    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"])).eval()
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    assert set(net.state_dict().keys()) == set(sd.keys())                      # the reference's checkpoint keys
+    net.load_state_dict(sd)
+    return net.to(device), g
+
+
+def test_planenet_blocks_vs_reference(golden):
+    """PlaneNet with the reference's weights reproduces the reference's own submodules run in its own order (SIREN + time
+    embedding -> TransformerEncoder -> PoolRN with an all-true [B, P] mask -> Linear): CPU, torch against torch"""
+    net, g = _planenet(golden)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
+        x_emb = net.position_siren(torch.from_numpy(g["x"]))
+        t_in = torch.cat((x_emb, net.time_embedding(torch.from_numpy(g["t"]))[:, None, :].expand(x_emb.shape)), dim=2)
+        enc = net.encoder(t_in.transpose(0, 1)).transpose(0, 1)
+    assert out.shape == (6, 3)
+    assert np.abs(enc.numpy() - g["encoding"]).max() < 1e-5
+    assert np.abs(out.numpy() - g["out"]).max() < 1e-5
+    # a masked pool ignores the masked points
+    from so3x.models import PoolRN
+    torch.manual_seed(0)
+    pool = PoolRN(8)
+    x = torch.randn(3, 5, 8)
+    m = torch.tensor([[1, 1, 1, 0, 0]] * 3, dtype=torch.bool)
+    assert torch.allclose(pool(x, m), pool(x[:, :3]), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_planenet_as_the_denoiser_of_projected_so3_diffusion(golden):
+    """the aircraft task's wiring (aircraft_rotate.py:64-106): a batch of point clouds, one pose each, PointCloudProj as the
+    projection, PlaneNet as the denoiser of ProjectedSO3Diffusion -- the noising / target / posterior / noise steps are this
+    package's kernels, the transformer is torch's.  The network equals the reference's on the GPU too, per-sample clouds equal
+    torch.matmul's batching, a few Adam steps lower the loss, and the reverse loop returns rotations."""
+    from so3x.diffusion import ProjectedSO3Diffusion
+    from so3x.models import PointCloudProj
+    from so3x import backend as B
+    net, g = _planenet(golden, DEV)
+    with torch.no_grad():
+        out = net(dev(g["x"]), dev(g["t"], torch.int64))
+    assert float((out - dev(g["out"])).abs().max()) < 1e-4
+    bsz, pts = 16, 24
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    clouds = torch.randn(bsz, pts, 3, device=DEV, generator=gen) * 0.5
+    R = B.quat_to_rmat(torch.randn(bsz, 4, device=DEV, generator=gen))
+    proj = PointCloudProj(clouds)
+    assert float((proj(R) - clouds @ R.transpose(-1, -2)).abs().max()) < 2e-6    # one cloud per rotation
+    net.train()
+    process = ProjectedSO3Diffusion(net, timesteps=50).to(DEV)
+    truepos = process.identity.repeat(bsz, 1, 1)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    torch.manual_seed(0)
+    assert torch.isfinite(process(truepos, proj))                                  # the reference's call, fresh t and noise
+    # ... and on a FIXED batch of timesteps and draws the loss must go down (fresh noise every step hides that in 30 steps)
+    t = torch.randint(0, 50, (bsz,), device=DEV, generator=gen)
+    ax, un = torch.randn(bsz, 3, device=DEV, generator=gen), torch.rand(bsz, device=DEV, generator=gen)
+    process.projection = proj
+    losses = []
+    for _ in range(30):
+        loss = process.p_losses(truepos, t, axes=ax, unif=un)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0]
+    net.eval()
+    x = process.p_sample_loop((bsz,), proj)
+    assert x.shape == (bsz, 3, 3) and torch.isfinite(x).all()
+    assert float((x @ x.transpose(-1, -2) - torch.eye(3, device=DEV)).abs().max()) < 1e-4

@@ -877,3 +877,36 @@ def orthogonalise_golden(n=96):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "orthogonalise":
     orthogonalise_golden()
+
+
+def planenet_golden(B=6, P=24, dim=32, heads=4, layers=1):
+    """The reference's PlaneNet building blocks (models.py:94-110, 185-210) on a small cloud batch: its own submodules run in
+    its own order, with the pooling given an explicit all-true mask of shape [B, P] (the default-mask branch of PoolRN only
+    broadcasts for B == P, and PlaneNet.forward then keeps sample 0's row only: reference bugs, not reproduced).  Stores the
+    state_dict, the inputs, the encoder output and the [B, 3] prediction."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import models as rmodels
+    torch.manual_seed(21)
+    net = rmodels.PlaneNet(dim=dim, heads=heads, layers=layers).eval()
+    x = torch.randn(B, P, 3) * 0.5
+    t = torch.randint(0, 1000, (B,))
+    with torch.no_grad():
+        x_emb = net.position_siren(x)
+        t_emb = net.time_embedding(t)
+        t_in = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)
+        enc = net.encoder(t_in.transpose(0, 1)).transpose(0, 1)
+        pooled = net.out_net[0](enc, mask=torch.ones(B, P, dtype=torch.bool))
+        out = net.out_net[1](pooled)
+    fix = {"x": npy(x), "t": npy(t), "encoding": npy(enc), "pooled": npy(pooled), "out": npy(out),
+           "dim": np.int64(dim), "heads": np.int64(heads), "layers": np.int64(layers)}
+    for k, v in net.state_dict().items():
+        fix["sd_" + k] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "planenet.npz"), **fix)
+    print("planenet.npz", os.path.getsize(os.path.join(OUT, "planenet.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "planenet":
+    planenet_golden()
