@@ -19,8 +19,12 @@
 //                    one slab per block (deterministic, no float atomics);
 //   K3 k_bwd_reduce: sums the slabs into dparams.
 // The stash is fp32 / bf16 with the operand precision; K2 runs exact-fp32 or bf16 MFMA accordingly.
+#include <stdlib.h>
+#include <string.h>
 #include "so3x_common.hpp"
+#include "so3x_igso3.hpp"
 #include "so3x_mlp.hpp"
+#include "so3x_reverse_step.hpp"
 
 using namespace so3x;
 using namespace so3x::mlp;
@@ -686,6 +690,152 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The training forward with the forward noising fused in (diffusion.py:348-357 in ONE launch): a wave owns 64 samples.
+// Lane = sample for the noise draw (Philox, optional in-kernel timestep, inverse-CDF angle, Rodrigues), q_sample and the
+// regression target -- exactly k_q_sample_target's arithmetic -- then the wave's two 32-sample tiles go through the network
+// as in k_mlp_fwd_stash (the halves exchange what the other half feeds to layer 0), and the lane that owns a sample takes
+// its three outputs back for the MSE epilogue.  x_t still goes to HBM (the backward's layer-0 image needs it), the target and
+// the network output never do.  NOT the default: measured against the two-launch form it is no faster (see so3x_train_fwd).
+// ---------------------------------------------------------------------------------------
+struct NoiseArgs {
+  const float* sched; const float* trap_q; const uint16_t* guide_q; const float* x0; const int64_t* t; int64_t* t_draw;
+  const float* axes; const float* unif; const int64_t* rng_offset_dev; uint64_t seed, rng_offset; int64_t index_base; int T, quirk_col0;
+};
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 2)
+k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, NoiseArgs na, float* __restrict__ x_t_out,
+            float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ __attribute__((aligned(16))) float sm[4][kWave * 9];
+  constexpr int VAR = GATHER;
+  constexpr int FB = frag_bytes<PREC>();
+  load_image(gimg, lds, image_bytes<PREC, VAR>());
+  __syncthreads();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* wl = sm[wv];
+  const int T = na.T;
+  uint64_t rng_offset = na.rng_offset;
+  if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];
+  auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
+  const int64_t wrow_t = !na.quirk_col0 ? -1 : (na.t_draw ? drawn_t(philox4x32_10(na.seed, (uint64_t)na.index_base, rng_offset).w) : na.t[0]);
+  const int64_t nchunks = (n + 63) / 64, ntiles = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  float sq = 0.0f;
+  for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const int64_t base = chunk * 64;
+    const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+    const int64_t idx = base + lane;
+    const bool live = lane < cnt;
+    // ---- noise draw, q_sample, target: one lane = one sample (k_q_sample_target's arithmetic)
+    Philox4 r;
+    if (na.t_draw || !na.axes) r = philox4x32_10(na.seed, (uint64_t)(na.index_base + idx), rng_offset);
+    int64_t tt;
+    if (na.t_draw) { tt = drawn_t(r.w); if (live) na.t_draw[idx] = tt; }
+    else tt = na.t[live ? idx : base];
+    float ax[3], u;
+    if (na.axes) {
+      float a[3];
+      wave_load_rows<3>(na.axes, base, cnt, wl, a);
+      float nrm = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);       // distributions.py:36
+      ax[0] = a[0] / nrm; ax[1] = a[1] / nrm; ax[2] = a[2] / nrm;
+      float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // util.py:201
+      ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
+      u = live ? na.unif[idx] : 0.5f;
+    } else {
+      unit_axis(r.x, r.y, ax);
+      u = u01(r.z);
+    }
+    if (!live) { ax[0] = 1.0f; ax[1] = 0.0f; ax[2] = 0.0f; u = 0.5f; }     // dead lanes carry well-defined values: their stash columns are read
+    const float* row = na.trap_q + tt * 999;
+    const float* wrow = wrow_t >= 0 ? na.trap_q + wrow_t * 999 : row;
+    const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, na.guide_q ? na.guide_q + tt * kGuidePitch : nullptr);
+    float nz[9], x[9], w[3], xs[9], xt[9], tg[3];
+    exp_axis_angle(ax, ang, nz);
+    wave_load_rows<9>(na.x0, base, cnt, wl, x);
+    if (!live) { x[0] = 1.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f; x[4] = 1.f; x[5] = 0.f; x[6] = 0.f; x[7] = 0.f; x[8] = 1.f; }
+    const float k = na.sched[S_SQRT_AC * T + tt];
+    log3(x, w);
+    w[0] *= k; w[1] *= k; w[2] *= k;
+    exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
+    mul33(xs, nz, xt);                // x_blend @ noise, :346
+    wave_store_rows<9>(x_t_out, base, cnt, wl, xt);
+    {
+      float lw[3];
+      log3(nz, lw);                   // skew2vec(log_rmat(noise)) * (1/eps), :355
+      const float ie = 1.0f / na.sched[S_SQRT_1MAC * T + tt];
+      tg[0] = lw[0] * ie; tg[1] = lw[1] * ie; tg[2] = lw[2] * ie;
+    }
+    // ---- the network on the wave's two 32-sample tiles (k_mlp_fwd_stash's arithmetic), pre-activations parked per tile
+    const int tlo = (int)tt;
+    const int tA = __shfl(tlo, col), tB = __shfl(tlo, 32 + col);
+    float va[3], vb[3];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int64_t tile = 2 * chunk + half;
+      Z33h z[4];
+      f32x16 a3[3];
+      Tile<PREC> cur;
+      if (half == 0) layer0_chain<PREC, 1>(lds, beff_tab + (size_t)tA * 96, xt, a3, lane);
+      else layer0_chain<PREC, 2>(lds, beff_tab + (size_t)tB * 96, xt, a3, lane);
+      keep_h(a3, z[0]);
+#pragma unroll
+      for (int l = 1; l < 4; l++) {
+        activate_zh<PREC>(z[l - 1], cur, h);
+        hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
+        keep_h(a3, z[l]);
+      }
+      activate_zh<PREC>(z[3], cur, h);
+      f32x16 last[1];
+      hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
+#pragma unroll
+      for (int q = 0; q < 3; q++) (half == 0 ? va : vb)[q] = last[0][q];
+      if (tile < ntiles) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) zstash_store_layer(zstash + (size_t)tile * ZSTASH_TILE, lane, l, z[l]);
+      }
+    }
+    float v[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const float o = __shfl_xor(vb[q], 32);  // tile B's outputs sit in lanes 0..31; their owners are lanes 32..63
+      v[q] = h ? o : va[q];
+    }
+    if (out) wave_store_rows<3>(out, base, cnt, wl, v);
+    float d[3] = {v[0] - tg[0], v[1] - tg[1], v[2] - tg[2]};
+    if (live) sq += d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    d[0] *= la.dscale; d[1] *= la.dscale; d[2] *= la.dscale;
+    wave_store_rows<3>(la.dout, base, cnt, wl, d);
+  }
+  __shared__ double wsum[4];
+  __shared__ int is_last;
+  double vsum = (double)sq;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) vsum += __shfl_xor(vsum, m);
+  if (lane == 0) wsum[wv] = vsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double bs = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = last_block_arrives(la.ticket) ? 1 : 0;
+  }
+  __syncthreads();
+  if (is_last) {
+    double a = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+    if (lane == 0) wsum[wv] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      la.loss[0] = (float)(((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * la.inv_count);
+      if (la.rng_counter) la.rng_counter[0] += 1;
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -1124,25 +1274,41 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
   // one prep launch for the whole step: forward image, transposed image of the backward, per-timestep tables
   int rc = launch_prep(st, params, PREC, GATHER, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
   if (rc) return rc;
-  float* target = reinterpret_cast<float*>(ws + L.target);
-  // noise draw + forward noising + regression target (diffusion.py:349-355)
-  rc = launch_q_sample_target(st, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0, nullptr, axes, unif, seed, rng_offset,
-                              rng_counter, index_base, x_t, target, nullptr, n);
-  if (rc) return rc;
-  const int64_t* tt = t ? t : t_draw;  // the drawn timesteps are in place when the next launch starts
-  static PerDevice attr;
-  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
-  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
   LossArgs la;
-  la.target = target; la.dout = dout; la.loss = loss;
+  la.dout = dout; la.loss = loss;
   la.partial = reinterpret_cast<double*>(ws + L.partial);
   la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
   la.rng_counter = (axes == nullptr || t_draw) ? rng_counter : nullptr;
   la.dscale = (float)(2.0 / (3.0 * (double)n));
   la.inv_count = 1.0 / (3.0 * (double)n);
-  // network forward + stash + MSE and its gradient (so3_train.py:39-49, diffusion.py:353-357)
+  const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
+  const char* ab = getenv("SO3X_AB_TRAINFWD");
+  if (ab && !strcmp(ab, "fused")) {
+    // A/B (SO3X_AB_TRAINFWD=fused): noise draw + q_sample + target + network forward + stash + MSE and its gradient as ONE
+    // launch.  Measured no faster than the two launches below (277.3 vs 275.9 us per 2^19-sample step,
+    // profiles/r02_ab_train_fwd_fused_noising.json): at the two waves per SIMD the stash-carrying forward allows, the noising's
+    // dependent L2 gathers are no longer hidden the way the six-waves-per-SIMD noising kernel hides them.
+    static PerDevice attr_f;
+    if ((rc = ensure_dyn_lds(attr_f, reinterpret_cast<const void*>(&k_train_fwd<PREC>), IMG))) return rc;
+    NoiseArgs na{sched, trap_q, guide_q, x0, t, t_draw, axes, unif, rng_counter, seed, rng_offset, index_base, T, quirk_col0};
+    la.target = nullptr;
+    const int64_t nchunks = (n + 63) / 64, want = (nchunks + 3) / 4;
+    hipLaunchKernelGGL((k_train_fwd<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, st, (const void*)ws, beff, na, x_t, out,
+                       (char*)zstash, n, la);
+    return check_launch();
+  }
+  // the noising kernel (six waves per SIMD: latency-bound gathers), then the network forward with the MSE epilogue
+  float* target = reinterpret_cast<float*>(ws + L.target);
+  rc = launch_q_sample_target(st, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0, nullptr, axes, unif, seed, rng_offset,
+                              rng_counter, index_base, x_t, target, nullptr, n);
+  if (rc) return rc;
+  const int64_t* tt = t ? t : t_draw;
+  static PerDevice attr;
+  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
+  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
+  la.target = target;
   hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, st, (const void*)ws,
-                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), x_t, tt, (int64_t)1, out, (char*)zstash, n, 3, la);
+                     beff, x_t, tt, (int64_t)1, out, (char*)zstash, n, 3, la);
   return check_launch();
 }
 
