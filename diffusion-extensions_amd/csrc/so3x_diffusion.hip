@@ -13,6 +13,9 @@
 using namespace so3x;
 using namespace so3x::mlp;
 
+#ifndef SO3X_ABLATE
+#define SO3X_ABLATE 0
+#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------
@@ -135,23 +138,31 @@ k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, co
 //  * noise: Philox keyed (seed; global sample index, rng_offset + t) or explicit draws.
 // ---------------------------------------------------------------------------------------
 // FAST: hardware sine / cosine in the reverse step (bf16 default; so3x_math.hpp).
-// bf16: ONE workgroup of 8 waves per CU (the image with its SiLU table is 55 KB: at most two workgroups fit a CU's LDS
-// whatever their size).  Measured at B = 2^20 (profiles/r02_ab_chain_blocks.json): 8 waves 6.96 ms per 100 steps, 12 waves
+// bf16: ONE workgroup of 8 waves per CU (the image is 55 KB and the lane-replicated SiLU table 64 KB: 119 of the CU's 160 KB).  Measured at B = 2^20 (profiles/r02_ab_chain_blocks.json): 8 waves 6.96 ms per 100 steps, 12 waves
 // 7.04, two workgroups of 4 waves 7.21, 6-wave workgroups 8.7 (they do not spread evenly over the four SIMDs).
 // fp32: 4 waves, two workgroups per CU.
 template <int PREC> constexpr int chain_threads() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }       // launch bound
 template <int PREC> constexpr int chain_threads_default() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }
-template <int PREC, bool FAST, bool PAIR>
+// WIDE: the SiLU table in its lane-replicated 64 KB form at LDS address 0, the weight image behind it (so3x_mlp.hpp).
+template <int PREC, bool FAST, bool PAIR, bool WIDE>
 __global__ void __launch_bounds__(chain_threads<PREC>(), 2)
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                  int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
                  uint64_t rng_offset, int64_t index_base, int64_t n) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(!WIDE || (PAIR && PREC == SO3X_PREC_BF16), "the wide table belongs to the paired bf16 stream");
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  char* lds = lds_all + (WIDE ? kWideTabBytes : 0);
   load_image(gimg, lds, image_bytes<PREC, CHAIN>());
+  if constexpr (WIDE) {
+    typedef __attribute__((address_space(3))) char* lds_cp;
+    if ((uint32_t)(uintptr_t)(lds_cp)lds_all != 0u) __builtin_trap();  // the byte-insert addressing needs the table at LDS address 0
+    fill_wide_tab(reinterpret_cast<const char*>(gimg) + (size_t)n_frags<PREC, CHAIN>() * frag_bytes<PREC>());
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5;
+  const uint32_t lt = wide_tab_lane(lane);
   const int64_t nchunks = (n + 63) / 64;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -162,6 +173,11 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     float R[9];
     load_rot9(x_in, idc, R);
     Quat q = quat_from_rmat(R);  // the state lives as a unit quaternion for the n_steps of this launch
+    bf16x8 w0[3];  // this step's three layer-0 fragments, fetched a step ahead (an L2 round trip off every step's critical path)
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) w0[k] = l0t_tab[(size_t)t_start * 192 + 64 * k + lane];
+    }
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
@@ -172,7 +188,17 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       if constexpr (PREC == SO3X_PREC_BF16) {  // layer 0 from this timestep's fragments (bias in the K dimension)
         const bf16x8* l0t = l0t_tab + (size_t)t * 192;
         if constexpr (PAIR) {
-          forward_pair_bf16(lds, R, l0t, va, vb, lane);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
+#if SO3X_ABLATE == 2  /* timing experiment only (tools/ab): no network */
+          va[0] = vb[0] = R[1]; va[1] = vb[1] = R[2]; va[2] = vb[2] = R[5];
+#else
+          bf16x8 wn[3];
+          const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
+#pragma unroll
+          for (int k = 0; k < 3; k++) wn[k] = l0n[64 * k + lane];
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
+#pragma unroll
+          for (int k = 0; k < 3; k++) w0[k] = wn[k];
+#endif
         } else {
           forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);
           forward_tile<PREC, CHAIN, 2, true>(lds, R, nullptr, 0, nullptr, vb, lane, l0t);
@@ -187,7 +213,11 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         v[j] = h ? o : va[j];
       }
       // ---- posterior mean + noise (diffusion.py:291-326), so3x_reverse_step.hpp
+#if SO3X_ABLATE == 1  /* timing experiment only (tools/ab): no reverse step */
+      q.w += v[0] * 1e-9f; q.x += v[1] * 1e-9f; q.y += v[2] * 1e-9f;
+#else
       q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+#endif
     }
     rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
@@ -202,24 +232,24 @@ inline int ab_env(const char* name, const char* value) {
   return e && !strcmp(e, value);
 }
 
-template <int PREC, bool FAST, bool PAIR>
+template <int PREC, bool FAST, bool PAIR, bool WIDE = false>
 int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
                    const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                    uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
-  constexpr int IMG = image_bytes<PREC, CHAIN>();
+  constexpr int IMG = image_bytes<PREC, CHAIN>() + (WIDE ? kWideTabBytes : 0);
   int max_blocks = 0;
   int threads = chain_threads_default<PREC>();
   if (PREC == SO3X_PREC_BF16 && getenv("SO3X_AB_BLOCK")) threads = atoi(getenv("SO3X_AB_BLOCK"));
   if (threads < 64 || threads > chain_threads<PREC>() || threads % 64) return SO3X_ERR_INVALID_ARG;
   static PerDevice residents[9];  // one cache per workgroup size (A/B)
   PerDevice& resident = residents[threads / 64];
-  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST, PAIR>), threads, IMG, &max_blocks)) return rc;
+  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST, PAIR, WIDE>), threads, IMG, &max_blocks)) return rc;
   const int64_t nchunks = (n + 63) / 64;
   const int wpb = threads / 64;
   const int64_t want = (nchunks + wpb - 1) / wpb;
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
-  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
+  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
   return check_launch();
 }
@@ -232,7 +262,8 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
   if constexpr (PREC == SO3X_PREC_BF16) {
     if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false, true>(SO3X_CHAIN_ARGS);
     if (ab_env("SO3X_AB_PAIR", "0")) return launch_chain_v<PREC, true, false>(SO3X_CHAIN_ARGS);
-    return launch_chain_v<PREC, true, true>(SO3X_CHAIN_ARGS);
+    if (ab_env("SO3X_AB_TAB", "narrow")) return launch_chain_v<PREC, true, true>(SO3X_CHAIN_ARGS);
+    return launch_chain_v<PREC, true, true, true>(SO3X_CHAIN_ARGS);
   } else {
     return launch_chain_v<PREC, false, false>(SO3X_CHAIN_ARGS);
   }

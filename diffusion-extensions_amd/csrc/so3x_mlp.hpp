@@ -121,6 +121,8 @@ template <int PREC> __host__ __device__ constexpr int l0_emb_slot0() { return PR
 // TRUE activation, so the next layer's weights are the plain ones (x 16 again for its own table coordinate).  The 2 KB table
 // rides at the end of the weight image and reaches LDS with it.  Measured on the chain kernel (profiles/r02_ab_chain_*.json):
 // -11 % time with a 4-instruction form of this, against +3 % LDS-port pressure feared; the LDS port has the room.
+// The chain kernel goes one further (wide_tab_entry below): a lane-replicated copy of the table at LDS address 0 turns the
+// convert's result into the address itself -- TWO vector instructions, and lookups that cannot meet in a bank.
 constexpr float kTabC = 16.0f, kTabD = 127.5f;
 constexpr int kSiluTabEntries = 256, kSiluTabBytes = kSiluTabEntries * 8;
 constexpr int ONE_ROW2 = 69;  // second constant-one hidden row (tile 2, reg 1 of the upper lane half): carries kTabD
@@ -233,6 +235,33 @@ __device__ __forceinline__ float silu_tab(float u, const char* tab) {
   return fmaf(e.y, u, e.x);
 }
 
+// Lane-replicated form of the table (the chain kernel): entry i sits 32 times in the 256-byte row i of a 64 KB block that
+// starts at LDS address 0, copy c at byte 8 c.  v_cvt_pk_u8_f32 can drop its saturated byte into ANY byte of a third operand:
+// with byte 1 of the per-lane constant 8 (lane & 31) it yields the entry's ADDRESS in the one instruction -- no shift-add --
+// and the lookups of a wave can never meet in a bank (lane l always reads banks 2 (l & 31), 2 (l & 31) + 1, whatever its
+// index).  TWO vector instructions per activation (convert, multiply-add) plus the packing.
+constexpr int kWideTabBytes = kSiluTabEntries * 256;
+__device__ __forceinline__ uint32_t wide_tab_lane(int lane) { return 8u * (lane & 31); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2_t* lds_f2_ptr;
+__device__ __forceinline__ float2 wide_tab_entry(float u, uint32_t lt) {
+  const uint32_t addr = __builtin_amdgcn_cvt_pk_u8_f32(u, 1u, lt);  // round to nearest, saturated to 0..255, into bits 8..15
+  const f32x2_t e = *(lds_f2_ptr)(uintptr_t)addr;
+  return float2{e[0], e[1]};
+}
+__device__ __forceinline__ float silu_tabw(float u, uint32_t lt) {
+  const float2 e = wide_tab_entry(u, lt);
+  return fmaf(e.y, u, e.x);
+}
+// fills the block at LDS address 0 from the 2 KB table of a weight image (global); the caller synchronises
+__device__ __forceinline__ void fill_wide_tab(const void* __restrict__ narrow) {
+  const float2* src = reinterpret_cast<const float2*>(narrow);
+  for (int e = threadIdx.x; e < kSiluTabEntries * 32; e += blockDim.x) {
+    const float2 v = src[e >> 5];
+    *(lds_f2_ptr)(uintptr_t)((e >> 5) * 256 + (e & 31) * 8) = f32x2_t{v.x, v.y};
+  }
+}
+
 template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const f32x16 (&acc)[3], Tile<SO3X_PREC_F32>& out, int h, const char*) {
 #pragma unroll
   for (int t = 0; t < 2; t++)
@@ -247,7 +276,8 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const
 #ifndef SO3X_ACT_GROUP
 #define SO3X_ACT_GROUP 16
 #endif
-template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab) {
+template <bool FOLD, bool WIDE = false>
+__device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab, uint32_t lt = 0) {
   if constexpr (FOLD) {
     constexpr int G = SO3X_ACT_GROUP;  // 8, 16 or 32 values per group (32 = both k-steps of a tile pair)
     float val[32];
@@ -259,8 +289,12 @@ template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 
       for (int i = 0; i < G; i++) {
         const int q = g0 + i;
         u[i] = acc[q >> 4][q & 15];
-        const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[i], 0u, 0u);
-        e[i] = *reinterpret_cast<const float2*>(tab + idx * 8);
+        if constexpr (WIDE) {
+          e[i] = wide_tab_entry(u[i], lt);
+        } else {
+          const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[i], 0u, 0u);
+          e[i] = *reinterpret_cast<const float2*>(tab + idx * 8);
+        }
       }
 #pragma unroll
       for (int i = 0; i < G; i++) val[g0 + i] = fmaf(e[i].y, u[i], e[i].x);
@@ -277,7 +311,7 @@ template <bool FOLD> __device__ __forceinline__ void activate_bf16(const f32x16 
     bf16x8 p;
 #pragma unroll
     for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
-    p[0] = (__bf16)(h ? 1.0f : silu_tab(acc[2][0], tab));  // row 64 | the constant-one row 68
+    p[0] = (__bf16)(h ? 1.0f : (WIDE ? silu_tabw(acc[2][0], lt) : silu_tab(acc[2][0], tab)));  // row 64 | the constant-one row 68
     p[1] = (__bf16)(h ? 1.0f : 0.0f);                      // row 69: the second constant one (carries the table offset)
     out.b[4] = p;
   } else {
@@ -542,15 +576,76 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
 #ifndef SO3X_STAGE_FENCE
 #define SO3X_STAGE_FENCE __builtin_amdgcn_sched_barrier(0)
 #endif
-__device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8* __restrict__ l0t,
-                                                  float* va, float* vb, int lane) {
+// The order WITHIN a stage.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles; about six 4-cycle instructions
+// fit the rest (MI355X_MICROARCH.md, issue-cost rows).  The compiler's own order put the lookups between the MFMAs and left
+// the ~50 multiply-adds and packings of a stage as a tail behind them, with the matrix pipe idle (sched_group_barrier
+// pipelines did not move it); stage_gaps below lays the stage out gap by gap instead.  0 = the compiler's order (A/B).
+#ifndef SO3X_STAGE_SCHED
+#define SO3X_STAGE_SCHED 1
+#endif
+// One stage of the paired stream laid out gap by gap: the 15 MFMAs of tile X's layer, and in the gap behind each of them a
+// slice of tile Y's activation -- table lookups for about three values, the multiply-adds of the lookups issued two gaps
+// earlier, the packing of finished pairs -- and ONE weight-fragment read (five MFMAs ahead: the fragments of output tiles 1
+// and 2, then the next stage's first five into `ring`).  A sched_barrier closes every gap, so the emitted order is this one.
+template <bool WIDE>
+__device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const char* __restrict__ wnext, const Tile<SO3X_PREC_BF16>& inX,
+                                           f32x16 (&accX)[3], const f32x16 (&accY)[3], Tile<SO3X_PREC_BF16>& curY, bf16x8 (&ring)[5],
+                                           int lane, int h, const char* tab, uint32_t lt) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+  const bf16x8* wn = reinterpret_cast<const bf16x8*>(wnext);
+  float2 e[33];
+  float val[33];
+  uint32_t pk[16];
+  constexpr int LAST_LOOKUP_GAP = 11;  // lookups in gaps 0..11, multiply-adds two gaps behind, packing one more
+  auto first_of = [](int g) { return g <= 0 ? 0 : (g > LAST_LOOKUP_GAP ? 33 : (33 * g) / (LAST_LOOKUP_GAP + 1)); };
+#pragma unroll
+  for (int g = 0; g < 15; g++) {
+    const int to = g / 5, ks = g % 5;
+    accX[to] = mfma_bf16(ring[ks], inX.b[ks], ks == 0 ? zero16<SO3X_PREC_BF16>() : accX[to]);
+    ring[ks] = g < 10 ? w[(g + 5) * 64 + lane] : wn[(g - 10) * 64 + lane];
+#pragma unroll
+    for (int q = first_of(g); q < first_of(g + 1); q++) {
+      const float u = q < 32 ? accY[q >> 4][q & 15] : accY[2][0];
+      if constexpr (WIDE) {
+        e[q] = wide_tab_entry(u, lt);
+      } else {
+        const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u, 0u, 0u);
+        e[q] = *reinterpret_cast<const float2*>(tab + idx * 8);
+      }
+    }
+#pragma unroll
+    for (int q = first_of(g - 2); q < first_of(g - 1); q++) val[q] = fmaf(e[q].y, q < 32 ? accY[q >> 4][q & 15] : accY[2][0], e[q].x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const bool ready_now = 2 * j + 1 < first_of(g - 2), ready_before = 2 * j + 1 < first_of(g - 3);
+      if (ready_now && !ready_before) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        pk[j] = __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)val[2 * j], (__bf16)val[2 * j + 1]});
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int i = 0; i < 4; i++) curY.b[i] = __builtin_bit_cast(bf16x8, u32x4_t{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]});
+  bf16x8 p;
+#pragma unroll
+  for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
+  p[0] = (__bf16)(h ? 1.0f : val[32]);  // row 64 | the constant-one row 68
+  p[1] = (__bf16)(h ? 1.0f : 0.0f);     // row 69: the second constant one (carries the table offset)
+  curY.b[4] = p;
+}
+
+template <bool WIDE = false>
+__device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8 (&l0w)[3],
+                                                  float* va, float* vb, int lane, uint32_t lt = 0) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
   f32x16 accA[3], accB[3];
   Tile<PREC> curA, curB;
   {  // layer 0 of both tiles from this timestep's three A fragments
-    const bf16x8 w0 = l0t[lane], w1 = l0t[64 + lane], w2 = l0t[128 + lane];
+    const bf16x8 w0 = l0w[0], w1 = l0w[1], w2 = l0w[2];
     const bf16x8 bA = l0_operand<1>(x, lane), bB = l0_operand<2>(x, lane);
     accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
     accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
@@ -559,26 +654,31 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   // registers instead of waiting ~120 cycles for its first LDS reads behind the fence
   bf16x8 pre[5];
   prefetch_tile0(img + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
-  activate_bf16<true>(accA, curA, h, tab);
+  activate_bf16<true, WIDE>(accA, curA, h, tab, lt);
   const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     const char* wl = img + (size_t)frag_hidden<PREC, VAR>(l) * FB;
     const char* wnext = l < 3 ? img + (size_t)frag_hidden<PREC, VAR>(l + 1) * FB : wlast;
     SO3X_STAGE_FENCE;
+#if SO3X_STAGE_SCHED
+    stage_gaps<WIDE>(wl, wl, curA, accA, accB, curB, pre, lane, h, tab, lt);     // MFMA A, layer l || activation B, layer l-1
+    stage_gaps<WIDE>(wl, wnext, curB, accB, accA, curA, pre, lane, h, tab, lt);  // MFMA B, layer l || activation A, layer l
+#else
     mfma_layer_bf16<3>(wl, curA, accA, lane, pre);  // MFMA A, layer l      ||
     prefetch_tile0(wl, lane, pre);                  //   (tile 0 of the same layer again for B)
-    activate_bf16<true>(accB, curB, h, tab);        // activation B, layer l-1
+    activate_bf16<true, WIDE>(accB, curB, h, tab, lt);        // activation B, layer l-1
     SO3X_STAGE_FENCE;
     mfma_layer_bf16<3>(wl, curB, accB, lane, pre);  // MFMA B, layer l      ||
     prefetch_tile0(wnext, lane, pre);
-    activate_bf16<true>(accA, curA, h, tab);        // activation A, layer l
+    activate_bf16<true, WIDE>(accA, curA, h, tab, lt);        // activation A, layer l
+#endif
   }
   f32x16 lastA[1], lastB[1];
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
   prefetch_tile0(wlast, lane, pre);
-  activate_bf16<true>(accB, curB, h, tab);            // activation B, layer 3
+  activate_bf16<true, WIDE>(accB, curB, h, tab, lt);            // activation B, layer 3
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
 #pragma unroll
