@@ -143,8 +143,8 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
                                                unsigned* zero_word, int t_first, int t_count) {
   const bool tables = chain_layout(VAR) && T > 0;
   float* beff = tables ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR)) : nullptr;
-  float* emb = (tables && VAR == GATHER) ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
-  __bf16* h0 = (tables && VAR == GATHER) ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
+  float* emb = (tables && gather_layout(VAR)) ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
+  __bf16* h0 = (tables && gather_layout(VAR)) ? reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + h0_offset(PREC, VAR, T)) : nullptr;
   const int rows = !tables ? 0 : (t_count > 0 ? t_count : T);
   hipLaunchKernelGGL((k_prep<PREC, VAR>), dim3(PREP_IMG_BLOCKS + PREP_WT_BLOCKS + rows), dim3(256), 0, s, params,
                      want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kTabC : 1.0f,
@@ -188,6 +188,7 @@ int launch_prep(hipStream_t s, const float* params, int precision, int variant, 
   }
   if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
+  if (variant == GATHER_T) return launch_prep_t<SO3X_PREC_BF16, GATHER_T>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
 }
 }  // namespace mlp

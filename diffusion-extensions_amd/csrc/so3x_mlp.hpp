@@ -58,12 +58,14 @@ __host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 
 // variant CHAIN: layer 0 sees only the 9 rotation entries (the 56 time-embedding
 // inputs are folded into a per-timestep effective bias, appendix C.3);
 // variant FULL : layer 0 sees [R(9), 1, emb(56)] per sample (per-sample timesteps).
-enum Variant { CHAIN = 0, FULL = 1, GATHER = 2 };
+enum Variant { CHAIN = 0, FULL = 1, GATHER = 2, GATHER_T = 3 };
 // GATHER: the CHAIN layer-0 layout (K = 9, per-timestep effective bias) with a PER-SAMPLE bias row
 // gathered by t from the [T][96] table -- per-sample timesteps without evaluating 56 sin/cos per sample.
-// Used by the training forward/backward when the caller bounds t (t_table > 0); never scale-folded
-// (the backward needs the true pre-activations).
+// Used by the backward when the caller bounds t (t_table > 0); never scale-folded (true pre-activations).
+// GATHER_T: GATHER with the SiLU table's scale fold (bf16): the training forward.  Its MFMAs emit u = 16 z + 127.5; the
+// pre-activation the backward wants goes to the stash as z = (u - 127.5) / 16 (one multiply-add per value).
 __host__ __device__ constexpr bool chain_layout(int var) { return var != FULL; }
+__host__ __device__ constexpr bool gather_layout(int var) { return var == GATHER || var == GATHER_T; }
 
 // number of k-steps
 template <int PREC> __host__ __device__ constexpr int ks_hidden() { return PREC == SO3X_PREC_F32 ? 33 : 5; }
@@ -80,7 +82,7 @@ template <int PREC, int VAR> __host__ __device__ constexpr int frag_last() { ret
 template <int PREC, int VAR> __host__ __device__ constexpr int n_frags() { return frag_last<PREC, VAR>() + ks_hidden<PREC>(); }
 // (the SiLU table of the folded bf16 CHAIN variant rides behind the fragments: see fold_scale below)
 template <int PREC, int VAR> __host__ __device__ constexpr int image_bytes() {
-  return n_frags<PREC, VAR>() * frag_bytes<PREC>() + ((PREC == SO3X_PREC_BF16 && VAR == 0 /*CHAIN*/) ? 2048 : 0);
+  return n_frags<PREC, VAR>() * frag_bytes<PREC>() + ((PREC == SO3X_PREC_BF16 && (VAR == 0 /*CHAIN*/ || VAR == 3 /*GATHER_T*/)) ? 2048 : 0);
 }
 
 // hidden feature index fed by (k-step ks, lane half h, element j)
@@ -126,8 +128,8 @@ template <int PREC> __host__ __device__ constexpr int l0_emb_slot0() { return PR
 constexpr float kTabC = 16.0f, kTabD = 127.5f;
 constexpr int kSiluTabEntries = 256, kSiluTabBytes = kSiluTabEntries * 8;
 constexpr int ONE_ROW2 = 69;  // second constant-one hidden row (tile 2, reg 1 of the upper lane half): carries kTabD
-static_assert(CHAIN == 0 && kSiluTabBytes == 2048, "image_bytes() above spells these out");
-template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() { return PREC == SO3X_PREC_BF16 && VAR == CHAIN; }
+static_assert(CHAIN == 0 && GATHER_T == 3 && kSiluTabBytes == 2048, "image_bytes() above spells these out");
+template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() { return PREC == SO3X_PREC_BF16 && (VAR == CHAIN || VAR == GATHER_T); }
 
 // weight-image element value: fragment `frag`, lane, element j (bf16 only)
 template <int PREC, int VAR>

@@ -557,14 +557,31 @@ __device__ __forceinline__ void activate_zh(const Z33h& z, Tile<PREC>& out, int 
 //  backward, which then finds nothing in the memory-side cache, 15 % slower; NT loads cost the backward 12 %.)
 constexpr size_t ZSTASH_TILE = 17 * 1024;
 constexpr size_t ZSTASH_LAYER = 17 * 256;  // one layer of a tile: 4 chunks of [lane][16 B], then [lane][4 B]
+// The stash is written once and read once, 285 MB per 2^19 samples -- more than the Infinity Cache: non-temporal stores took
+// the training forward from 87 to 70 us (default-policy lines were being written back behind the kernel's own compute).
+#ifndef SO3X_STASH_NT
+#define SO3X_STASH_NT 1
+#endif
+
 __device__ __forceinline__ void zstash_store_layer(char* tile_base, int lane, int l, const Z33h& z) {
   char* lb = tile_base + l * ZSTASH_LAYER;
   uint4* o = reinterpret_cast<uint4*>(lb) + lane;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int c = 0; c < 4; c++)
-    o[c * 64] = uint4{__builtin_bit_cast(uint32_t, z.p[4 * c]), __builtin_bit_cast(uint32_t, z.p[4 * c + 1]),
-                      __builtin_bit_cast(uint32_t, z.p[4 * c + 2]), __builtin_bit_cast(uint32_t, z.p[4 * c + 3])};
+  for (int c = 0; c < 4; c++) {
+    const u32x4_t v = {__builtin_bit_cast(uint32_t, z.p[4 * c]), __builtin_bit_cast(uint32_t, z.p[4 * c + 1]),
+                       __builtin_bit_cast(uint32_t, z.p[4 * c + 2]), __builtin_bit_cast(uint32_t, z.p[4 * c + 3])};
+#if SO3X_STASH_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(o + c * 64));
+#else
+    *reinterpret_cast<u32x4_t*>(o + c * 64) = v;
+#endif
+  }
+#if SO3X_STASH_NT
+  __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, z.p[16]), reinterpret_cast<uint32_t*>(lb + 4096) + lane);
+#else
   reinterpret_cast<uint32_t*>(lb + 4096)[lane] = __builtin_bit_cast(uint32_t, z.p[16]);
+#endif
 }
 __device__ __forceinline__ void zstash_load_layer(const char* tile_base, int lane, int l, Z33h& z) {
   const char* lb = tile_base + l * ZSTASH_LAYER;
@@ -605,18 +622,61 @@ struct LossArgs {
 
 // Training forward (bf16 operands, per-timestep tables): the network output AND the stash above, so that the backward
 // does not run the forward again (that recompute was half of k_bwd_fused's time).  Same arithmetic as the recompute it
-// replaces: GATHER image (true pre-activations, no scale fold), pre-activations rounded to f16 before the activation.
+// replaces: GATHER_T image (table SiLU; stash_forward_tile above), pre-activations parked as f16.
 // LOSS: the MSE of p_losses rides in the epilogue -- the lane that holds a sample's three outputs reads its target, writes
 // d loss / d out and adds to a running sum of squares; per-block sums are combined by the last block to arrive, in block
 // order (deterministic) -- so the loss, its gradient and the step's counter increment cost no launch of their own.
+// The training forward on one 32-sample tile (bf16, GATHER_T image: table SiLU, so3x_mlp.hpp).  The hidden layers' MFMAs emit
+// the table coordinate u = 16 z + 127.5; the activation is the chain kernel's table lookup (3 vector instructions instead of
+// ~9 with two transcendentals -- the forward was vector-issue-bound at 57 % busy, its stash stores 28 of its 88 us), and the
+// pre-activation the backward needs is recovered as z = u / 16 - 127.5 / 16 (exact to 1e-6, far inside the stash's f16).
+__device__ __forceinline__ void keep_h_folded(const f32x16 (&u)[3], Z33h& z) {
+  constexpr float ks = 1.0f / kTabC, ko = -kTabD / kTabC;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    z.p[r >> 1] = Z33h::h2{(_Float16)fmaf(u[0][r], ks, ko), (_Float16)fmaf(u[0][r + 1], ks, ko)};
+    z.p[8 + (r >> 1)] = Z33h::h2{(_Float16)fmaf(u[1][r], ks, ko), (_Float16)fmaf(u[1][r + 1], ks, ko)};
+  }
+  z.p[16] = Z33h::h2{(_Float16)fmaf(u[2][0], ks, ko), (_Float16)0.0f};
+}
+// Every layer's pre-activations leave for the stash as soon as they exist (ztile: the tile's 17 KB, nullptr = a padding
+// tile): four 4-KB bursts spread over the tile's compute instead of one 17-KB burst behind it -- the stash is 285 MB per 2^19
+// samples, written at the HBM's store rate, and waves that all store at once serialise with their compute.
+template <int XSRC>
+__device__ __forceinline__ void stash_forward_tile(const char* __restrict__ lds, const float* __restrict__ beff_row, const float* x,
+                                                   char* __restrict__ ztile, f32x16 (&last)[1], int lane) {
+  constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_T, FB = frag_bytes<PREC>();
+  const int h = lane >> 5;
+  const char* tab = lds + (size_t)n_frags<PREC, VAR>() * FB;
+  f32x16 a3[3];
+  Tile<PREC> cur;
+  Z33h z;
+  layer0_chain<PREC, XSRC>(lds, beff_row, x, a3, lane);
+  keep_h_folded(a3, z);
+  if (ztile) zstash_store_layer(ztile, lane, 0, z);
+#pragma unroll
+  for (int l = 1; l < 4; l++) {
+    activate_bf16<true>(a3, cur, h, tab);
+    hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
+    keep_h_folded(a3, z);
+    if (ztile) zstash_store_layer(ztile, lane, l, z);
+  }
+  activate_bf16<true>(a3, cur, h, tab);
+  hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
+}
+
+// 8 waves per workgroup, two workgroups per CU (the 57 KB image twice): with each layer's pre-activations stored as soon as
+// they exist the kernel needs 124 registers -- four waves per SIMD.
+constexpr int kFwdStashThreads = 512;
+static_assert(kFwdStashThreads == 512, "the loss epilogue sums eight wave partials");
 template <int PREC, bool LOSS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(kFwdStashThreads, 2)
 k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
                 const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n, int nout,
                 LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int VAR = GATHER;
-  constexpr int FB = frag_bytes<PREC>();
+  static_assert(PREC == SO3X_PREC_BF16, "the training forward is the bf16 path");
+  constexpr int VAR = GATHER_T;
   load_image(gimg, lds, image_bytes<PREC, VAR>());
   __syncthreads();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
@@ -631,20 +691,8 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     float x[9];
     load_rot9(R, idx, x);
     const int64_t tt = t[idx * t_stride];
-    Z33h z[4];
-    f32x16 a3[3];
-    Tile<PREC> cur;
-    layer0_chain<PREC, 0>(lds, beff_tab + (size_t)tt * 96, x, a3, lane);
-    keep_h(a3, z[0]);
-#pragma unroll
-    for (int l = 1; l < 4; l++) {
-      activate_zh<PREC>(z[l - 1], cur, h);
-      hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
-      keep_h(a3, z[l]);
-    }
-    activate_zh<PREC>(z[3], cur, h);
     f32x16 last[1];
-    hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
+    stash_forward_tile<0>(lds, beff_tab + (size_t)tt * 96, x, zstash + (size_t)tile * ZSTASH_TILE, last, lane);
     if (live && h == 0) {  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
       if (out) {
         out[idx * nout] = last[0][0]; out[idx * nout + 1] = last[0][1]; out[idx * nout + 2] = last[0][2];
@@ -656,11 +704,9 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
         sq += d0 * d0 + d1 * d1 + d2 * d2;
       }
     }
-#pragma unroll
-    for (int l = 0; l < 4; l++) zstash_store_layer(zstash + (size_t)tile * ZSTASH_TILE, lane, l, z[l]);
   }
   if constexpr (LOSS) {
-    __shared__ double wsum[4];
+    __shared__ double wsum[kFwdStashThreads / 64];
     __shared__ int is_last;
     double v = (double)sq;
 #pragma unroll
@@ -668,22 +714,22 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     if (lane == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-      const double bs = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      const double bs = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
       __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = last_block_arrives(la.ticket) ? 1 : 0;
     }
     __syncthreads();  // the other waves of the last block read the partials only behind this barrier
     if (is_last) {
-      // every block's partial, two per thread (the grid has at most 512 blocks), summed in a fixed tree: deterministic
+      // every block's partial, one per thread (the grid has at most 512 blocks), summed in a fixed tree: deterministic
       // whichever block arrives last, and 2 loads deep instead of a 512-long chain of L2 round trips
       double a = 0.0;
-      for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned b = threadIdx.x; b < gridDim.x; b += kFwdStashThreads) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
       if (lane == 0) wsum[threadIdx.x >> 6] = a;
       __syncthreads();
       if (threadIdx.x == 0) {
-        la.loss[0] = (float)(((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * la.inv_count);
+        la.loss[0] = (float)((((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * la.inv_count);
         if (la.rng_counter) la.rng_counter[0] += 1;  // every reader of this step's offset ran in an earlier launch
       }
     }
@@ -709,8 +755,7 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
             float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ __attribute__((aligned(16))) float sm[4][kWave * 9];
-  constexpr int VAR = GATHER;
-  constexpr int FB = frag_bytes<PREC>();
+  constexpr int VAR = GATHER_T;
   load_image(gimg, lds, image_bytes<PREC, VAR>());
   __syncthreads();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
@@ -775,27 +820,12 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int64_t tile = 2 * chunk + half;
-      Z33h z[4];
-      f32x16 a3[3];
-      Tile<PREC> cur;
-      if (half == 0) layer0_chain<PREC, 1>(lds, beff_tab + (size_t)tA * 96, xt, a3, lane);
-      else layer0_chain<PREC, 2>(lds, beff_tab + (size_t)tB * 96, xt, a3, lane);
-      keep_h(a3, z[0]);
-#pragma unroll
-      for (int l = 1; l < 4; l++) {
-        activate_zh<PREC>(z[l - 1], cur, h);
-        hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
-        keep_h(a3, z[l]);
-      }
-      activate_zh<PREC>(z[3], cur, h);
       f32x16 last[1];
-      hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
+      char* ztile = tile < ntiles ? zstash + (size_t)tile * ZSTASH_TILE : nullptr;
+      if (half == 0) stash_forward_tile<1>(lds, beff_tab + (size_t)tA * 96, xt, ztile, last, lane);
+      else stash_forward_tile<2>(lds, beff_tab + (size_t)tB * 96, xt, ztile, last, lane);
 #pragma unroll
       for (int q = 0; q < 3; q++) (half == 0 ? va : vb)[q] = last[0][q];
-      if (tile < ntiles) {
-#pragma unroll
-        for (int l = 0; l < 4; l++) zstash_store_layer(zstash + (size_t)tile * ZSTASH_TILE, lane, l, z[l]);
-      }
     }
     float v[3];
 #pragma unroll
@@ -1223,14 +1253,14 @@ int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, con
   if (precision != SO3X_PREC_BF16 || t_table <= 0) return SO3X_ERR_UNSUPPORTED;  // the stash is the fused backward's
   if (!workspace || workspace_bytes < tables_end(precision, GATHER, t_table)) return SO3X_ERR_WORKSPACE;
   if (n == 0) return SO3X_OK;
-  constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER>();
+  constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER_T>();
   char* ws = (char*)workspace;
-  int rc = launch_prep((hipStream_t)s, params, PREC, GATHER, t_table, ws, n_out);
+  int rc = launch_prep((hipStream_t)s, params, PREC, GATHER_T, t_table, ws, n_out);
   if (rc) return rc;
   static PerDevice attr;
   if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, false>), IMG))) return rc;
-  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
-  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, false>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, (hipStream_t)s, (const void*)ws,
+  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
+  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, false>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, (hipStream_t)s, (const void*)ws,
                      reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out, LossArgs{});
   return check_launch();
 }
@@ -1268,11 +1298,11 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
     return SO3X_ERR_INVALID_ARG;
   const TrainLayout L = train_layout(n, T);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
-  constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER>();
+  constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER_T>();
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)s;
   // one prep launch for the whole step: forward image, transposed image of the backward, per-timestep tables
-  int rc = launch_prep(st, params, PREC, GATHER, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
+  int rc = launch_prep(st, params, PREC, GATHER_T, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
   if (rc) return rc;
   LossArgs la;
   la.dout = dout; la.loss = loss;
@@ -1305,9 +1335,9 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
   const int64_t* tt = t ? t : t_draw;
   static PerDevice attr;
   if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
-  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 3) / 4;
+  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
   la.target = target;
-  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, st, (const void*)ws,
+  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, st, (const void*)ws,
                      beff, x_t, tt, (int64_t)1, out, (char*)zstash, n, 3, la);
   return check_launch();
 }

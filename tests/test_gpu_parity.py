@@ -713,8 +713,11 @@ def test_search_guide_is_bit_identical(mods):
 
 
 def test_training_forward_stash_equals_recompute(mods, golden, net):
-    """so3x_mlp_fwd_stash + so3x_mlp_bwd(zstash) == so3x_mlp_bwd with the forward recomputed inside: the parked
-    pre-activations are the recomputed ones bit for bit, so the gradients are too; the output matches the plain forward."""
+    """so3x_mlp_fwd_stash + so3x_mlp_bwd(zstash) vs so3x_mlp_bwd with the forward recomputed inside: the training forward
+    runs on the table-folded weight image (u = 16 z + 127.5, SiLU from the LDS table) and parks z = (u - 127.5) / 16 as f16,
+    the recompute runs exp-based SiLUs on the plain image -- the two see activations that differ by the table's 1.3e-4 and
+    pre-activations that differ in f16's last place, so the gradients agree to ~1e-3 of their norm, not bit for bit; the
+    output matches the plain forward."""
     B = mods["B"]
     params = net.flat_params_nograd()
     for n in (1, 77, 4100):
@@ -728,7 +731,8 @@ def test_training_forward_stash_equals_recompute(mods, golden, net):
         assert float((out - ref_out).abs().max()) < 3e-2          # same operands; the plain forward folds the SiLU scale
         g_stash = B.mlp_bwd(params, x, t, dout, B.PREC_BF16, 300, zstash=zs)
         g_rec = B.mlp_bwd(params, x, t, dout, B.PREC_BF16, 300)
-        assert torch.equal(g_stash, g_rec)
+        assert torch.isfinite(g_stash).all()
+        assert float((g_stash - g_rec).norm() / g_rec.norm()) < 4e-3, n
     with pytest.raises(B.So3xError):
         B.mlp_bwd(params, x, t, dout, B.PREC_F32, 300, zstash=zs)    # the stash belongs to the bf16 fused path
 
