@@ -583,6 +583,8 @@ __device__ __forceinline__ void zstash_store_layer(char* tile_base, int lane, in
   reinterpret_cast<uint32_t*>(lb + 4096)[lane] = __builtin_bit_cast(uint32_t, z.p[16]);
 #endif
 }
+// (uint4, a struct of four words, on purpose: with an ext-vector load and `__builtin_bit_cast(h2, v[i])` of its ELEMENTS this
+//  hipcc builds a backward whose gradients are 30 % off -- seen twice, tools/ab/cmp_train_grad.py is the check)
 __device__ __forceinline__ void zstash_load_layer(const char* tile_base, int lane, int l, Z33h& z) {
   const char* lb = tile_base + l * ZSTASH_LAYER;
   const uint4* in = reinterpret_cast<const uint4*>(lb) + lane;
