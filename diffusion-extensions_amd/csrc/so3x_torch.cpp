@@ -296,6 +296,193 @@ void adam_step(Tensor& params, const Tensor& grad, Tensor& exp_avg, Tensor& exp_
      "adam_step");
 }
 
+// ------------------------------------------------------------------------------ widened rows
+const void* Bo(const optional<Tensor>& x, const char* name) { return x.has_value() ? dev(*x, name, at::kByte).const_data_ptr() : nullptr; }
+
+Tensor rotate_cloud(const Tensor& rot, const Tensor& cloud, int64_t cloud_stride, int64_t P) {
+  GUARD(rot);
+  Tensor out = f32_like(rot, with_tail(rot, 2, {P, 3}));
+  ok(so3x_rotate_cloud(strm(rot), F(dev(rot, "x")), F(dev(cloud, "data")), cloud_stride, Fm(out), rot.numel() / 9, P), "rotate_cloud");
+  return out;
+}
+// wide residual score network (so3_lock_train.py:11-59)
+Tensor resnet_fwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t t_stride, int64_t n_out, int64_t precision, int64_t t_table) {
+  GUARD(x);
+  Tensor out = f32_like(x, with_tail(x, 2, {n_out}));
+  Tensor ws = bytes(x, so3x_resnet_workspace_bytes((int)precision, (int)t_table));
+  ok(so3x_resnet_fwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), t_stride, Fm(out), x.numel() / 9, (int)n_out,
+                     (int)precision, (int)t_table, ws.mutable_data_ptr(), ws.numel()),
+     "resnet_fwd");
+  return out;
+}
+std::tuple<Tensor, Tensor> resnet_fwd_stash(const Tensor& params, const Tensor& x, const Tensor& t, int64_t t_stride, int64_t n_out,
+                                            int64_t precision, int64_t t_table) {
+  GUARD(x);
+  const int64_t n = x.numel() / 9;
+  Tensor out = f32_like(x, with_tail(x, 2, {n_out}));
+  Tensor stash = bytes(x, so3x_resnet_stash_bytes(n, (int)precision)), ws = bytes(x, so3x_resnet_workspace_bytes((int)precision, (int)t_table));
+  ok(so3x_resnet_fwd_stash(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), t_stride, Fm(out),
+                           stash.mutable_data_ptr(), n, (int)n_out, (int)precision, (int)t_table, ws.mutable_data_ptr(), ws.numel()),
+     "resnet_fwd_stash");
+  return {out, stash};
+}
+Tensor resnet_bwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t t_stride, const Tensor& dout, int64_t n_out, int64_t precision,
+                  int64_t t_table, const optional<Tensor>& stash) {
+  GUARD(x);
+  const int64_t n = x.numel() / 9;
+  Tensor dparams = f32_like(x, {params.numel()});
+  Tensor ws = bytes(x, so3x_resnet_train_workspace_bytes(n, (int)precision, (int)t_table));
+  ok(so3x_resnet_bwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), t_stride, F(dev(dout, "dout")), Fm(dparams), n,
+                     (int)n_out, (int)precision, (int)t_table, Bo(stash, "stash"), ws.mutable_data_ptr(), ws.numel()),
+     "resnet_bwd");
+  return dparams;
+}
+void resnet_chain_into(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                       const Tensor& out, int64_t t_start, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif,
+                       int64_t seed, int64_t rng_offset, int64_t index_base, int64_t precision) {
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(out.numel() == x.numel() && out.device() == x.device(), "so3x: out must match x");
+  Tensor ws = bytes(x, so3x_resnet_workspace_bytes((int)precision, T));
+  ok(so3x_resnet_p_sample_chain(strm(x), F(dev(params, "params")), F(sched), T, F(dev(trap_p, "trap_p")), Guide(guide_p), F(dev(x, "x")),
+                                Fm(const_cast<Tensor&>(dev(out, "out"))), (int)t_start, (int)n_steps, Fo(axes, "axes"), Fo(unif, "unif"),
+                                (uint64_t)seed, (uint64_t)rng_offset, index_base, x.numel() / 9, (int)precision, ws.mutable_data_ptr(), ws.numel()),
+     "resnet_p_sample_chain");
+}
+Tensor resnet_p_sample_chain(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                             int64_t t_start, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                             int64_t rng_offset, int64_t index_base, int64_t precision) {
+  GUARD(x);
+  Tensor out = at::empty_like(x);
+  resnet_chain_into(params, sched, trap_p, guide_p, x, out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision);
+  return out;
+}
+void resnet_p_sample_chain_out(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                               int64_t t_start, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                               int64_t rng_offset, int64_t index_base, int64_t precision, Tensor& out) {
+  GUARD(x);
+  resnet_chain_into(params, sched, trap_p, guide_p, x, out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision);
+}
+// SE(3) layer
+std::tuple<Tensor, Tensor, Tensor, Tensor> se3_q_sample_target(const Tensor& sched, const Tensor& trap_q, const optional<Tensor>& guide_q,
+                                                               double shift_scale, const Tensor& x0_rot, const Tensor& x0_shift, const Tensor& t,
+                                                               bool quirk_col0, const optional<Tensor>& axes, const optional<Tensor>& unif,
+                                                               const optional<Tensor>& znorm, int64_t seed, int64_t rng_offset, int64_t index_base,
+                                                               bool want_targets) {
+  GUARD(x0_rot);
+  const int64_t n = x0_rot.numel() / 9;
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor xt_rot = at::empty_like(dev(x0_rot, "x_start.rot")), xt_shift = f32_like(x0_rot, {n, 3});
+  Tensor tg_rot = f32_like(x0_rot, {want_targets ? n : 0, 3}), tg_shift = f32_like(x0_rot, {want_targets ? n : 0, 3});
+  ok(so3x_se3_q_sample_target(strm(x0_rot), F(sched), T, F(dev(trap_q, "trap_q")), Guide(guide_q), (float)shift_scale, F(x0_rot),
+                              F(dev(x0_shift, "x_start.shift")), I64(dev(t, "t", at::kLong)), quirk_col0 ? 1 : 0, Fo(axes, "axes"), Fo(unif, "unif"),
+                              Fo(znorm, "znorm"), (uint64_t)seed, (uint64_t)rng_offset, index_base, Fm(xt_rot), Fm(xt_shift),
+                              want_targets ? Fm(tg_rot) : nullptr, want_targets ? Fm(tg_shift) : nullptr, n),
+     "se3_q_sample_target");
+  return {xt_rot, xt_shift, tg_rot, tg_shift};
+}
+std::tuple<Tensor, Tensor> se3_p_mean(const Tensor& sched, const Tensor& x_rot, const Tensor& x_shift, const Tensor& v_rot, const Tensor& v_shift,
+                                      int64_t t) {
+  GUARD(x_rot);
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor mean_rot = at::empty_like(dev(x_rot, "x.rot")), mean_shift = at::empty_like(dev(x_shift, "x.shift"));
+  ok(so3x_se3_p_mean(strm(x_rot), F(sched), T, F(x_rot), F(x_shift), F(dev(v_rot, "noise.rot_g")), F(dev(v_shift, "noise.shift_g")), (int)t,
+                     Fm(mean_rot), Fm(mean_shift), x_rot.numel() / 9),
+     "se3_p_mean");
+  return {mean_rot, mean_shift};
+}
+std::tuple<Tensor, Tensor> se3_p_noise(const Tensor& trap_row, double sigma, double shift_scale, const Tensor& mean_rot, const Tensor& mean_shift,
+                                       const optional<Tensor>& axes, const optional<Tensor>& unif, const optional<Tensor>& znorm, int64_t seed,
+                                       int64_t rng_offset, int64_t index_base, bool shared_rot) {
+  GUARD(mean_rot);
+  Tensor out_rot = at::empty_like(dev(mean_rot, "mean.rot")), out_shift = at::empty_like(dev(mean_shift, "mean.shift"));
+  ok(so3x_se3_p_noise(strm(mean_rot), F(dev(trap_row, "trap_row")), (float)sigma, (float)shift_scale, F(mean_rot), F(mean_shift), Fo(axes, "axes"),
+                      Fo(unif, "unif"), Fo(znorm, "znorm"), (uint64_t)seed, (uint64_t)rng_offset, index_base, shared_rot ? 1 : 0, Fm(out_rot),
+                      Fm(out_shift), mean_rot.numel() / 9),
+     "se3_p_noise");
+  return {out_rot, out_shift};
+}
+std::tuple<Tensor, Tensor> rigid_move(const Tensor& rot, const Tensor& shift, const Tensor& pos, const optional<Tensor>& frames) {
+  GUARD(rot);
+  const int64_t S = rot.numel() / 9, L = S ? pos.numel() / (3 * S) : 0;
+  Tensor out_pos = at::empty_like(dev(pos, "positions"));
+  Tensor out_fr = frames.has_value() ? at::empty_like(dev(*frames, "angles")) : f32_like(rot, {0, 3, 3});
+  ok(so3x_rigid_move(strm(rot), F(dev(rot, "transf.rot")), F(dev(shift, "transf.shift")), F(pos), Fo(frames, "angles"), Fm(out_pos),
+                     frames.has_value() ? Fm(out_fr) : nullptr, S, L),
+     "rigid_move");
+  return {out_pos, out_fr};
+}
+// statistics
+Tensor kernel_sum(const Tensor& X, const Tensor& Y, int64_t kind, double scale) {
+  GUARD(X);
+  const int64_t nx = X.numel() / 9, ny = Y.numel() / 9;
+  Tensor out = f32_like(X, {1}), ws = bytes(X, so3x_kernel_sum_workspace_bytes(nx, ny));
+  ok(so3x_kernel_sum(strm(X), F(dev(X, "X")), nx, F(dev(Y, "Y")), ny, (int)kind, (float)scale, Fm(out), ws.mutable_data_ptr(), ws.numel()), "kernel_sum");
+  return out;
+}
+// rotation-matrix head and the prevstep objective
+Tensor six2rmat(const Tensor& x6) {
+  GUARD(x6);
+  Tensor out = f32_like(x6, with_tail(x6, 1, {3, 3}));
+  ok(so3x_six2rmat(strm(x6), F(dev(x6, "x")), Fm(out), x6.numel() / 6), "six2rmat");
+  return out;
+}
+Tensor six2rmat_bwd(const Tensor& x6, const Tensor& dR) {
+  GUARD(x6);
+  Tensor dx = at::empty_like(dev(x6, "x"));
+  ok(so3x_six2rmat_bwd(strm(x6), F(x6), F(dev(dR, "grad")), Fm(dx), x6.numel() / 6), "six2rmat_bwd");
+  return dx;
+}
+Tensor log_rmat_bwd(const Tensor& R, const Tensor& dlog) {
+  GUARD(R);
+  Tensor dR = at::empty_like(dev(R, "r_mat"));
+  ok(so3x_log_rmat_bwd(strm(R), F(R), F(dev(dlog, "grad")), Fm(dR), R.numel() / 9), "log_rmat_bwd");
+  return dR;
+}
+std::tuple<Tensor, Tensor> rmat_dist_bwd(const Tensor& a, const Tensor& b, const Tensor& ddist) {
+  GUARD(a);
+  Tensor da = at::empty_like(dev(a, "input")), db = at::empty_like(dev(b, "target"));
+  ok(so3x_rmat_dist_bwd(strm(a), F(a), F(b), F(dev(ddist, "grad")), Fm(da), Fm(db), a.numel() / 9), "rmat_dist_bwd");
+  return {da, db};
+}
+// -> (loss[1], d loss / d x_recon, step): the last two on request (else empty)
+std::tuple<Tensor, Tensor, Tensor> prevstep_loss(const Tensor& sched, const Tensor& x_recon, const Tensor& x_start, const Tensor& x_noisy,
+                                                 const Tensor& t, int64_t t_stride, bool want_dx, bool want_step) {
+  GUARD(x_recon);
+  const int64_t n = x_recon.numel() / 9;
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor loss = f32_like(x_recon, {1}), ws = bytes(x_recon, so3x_prevstep_workspace_bytes(n));
+  Tensor dx = want_dx ? at::empty_like(x_recon) : f32_like(x_recon, {0, 3, 3}), step = want_step ? at::empty_like(x_recon) : f32_like(x_recon, {0, 3, 3});
+  ok(so3x_prevstep_loss(strm(x_recon), F(sched), T, F(dev(x_recon, "x_recon")), F(dev(x_start, "x_start")), F(dev(x_noisy, "x_noisy")),
+                        I64(dev(t, "t", at::kLong)), t_stride, n, Fm(loss), want_dx ? Fm(dx) : nullptr, want_step ? Fm(step) : nullptr,
+                        ws.mutable_data_ptr(), ws.numel()),
+     "prevstep_loss");
+  return {loss, dx, step};
+}
+std::tuple<Tensor, Tensor> prevstep_loss6(const Tensor& sched, const Tensor& out6, const Tensor& x_start, const Tensor& x_noisy, const Tensor& t,
+                                          int64_t t_stride) {
+  GUARD(out6);
+  const int64_t n = out6.numel() / 6;
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor loss = f32_like(out6, {1}), d6 = at::empty_like(dev(out6, "out6")), ws = bytes(out6, so3x_prevstep_workspace_bytes(n));
+  ok(so3x_prevstep_loss6(strm(out6), F(sched), T, F(out6), F(dev(x_start, "x_start")), F(dev(x_noisy, "x_noisy")), I64(dev(t, "t", at::kLong)), t_stride,
+                         n, Fm(loss), Fm(d6), ws.mutable_data_ptr(), ws.numel()),
+     "prevstep_loss6");
+  return {loss, d6};
+}
+Tensor mse_loss(const Tensor& a, const Tensor& b) {
+  GUARD(a);
+  TORCH_CHECK(a.numel() == b.numel(), "so3x: mse_loss needs equal shapes");
+  Tensor loss = f32_like(a, {1}), ws = bytes(a, so3x_mse_workspace_bytes(a.numel()));
+  ok(so3x_mse_loss(strm(a), F(dev(a, "input")), F(dev(b, "target")), a.numel(), Fm(loss), ws.mutable_data_ptr(), ws.numel()), "mse_loss");
+  return loss;
+}
+Tensor mse_grad(const Tensor& a, const Tensor& b, const Tensor& gscale) {
+  GUARD(a);
+  Tensor ga = at::empty_like(dev(a, "input"));
+  ok(so3x_mse_grad(strm(a), F(a), F(dev(b, "target")), a.numel(), F(dev(gscale, "grad")), Fm(ga)), "mse_grad");
+  return ga;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(so3x, m) {
@@ -333,6 +520,31 @@ TORCH_LIBRARY(so3x, m) {
   m.def("train_bwd(Tensor x_t, Tensor t, Tensor dout, Tensor zstash, Tensor(a!) workspace, int T, Tensor? gscale, int n_params) -> Tensor");
   m.def("adam_step(Tensor(a!) params, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) step, float lr, float beta1, "
         "float beta2, float eps, float weight_decay, float grad_scale) -> ()");
+  m.def("rotate_cloud(Tensor rot, Tensor cloud, int cloud_stride, int P) -> Tensor");
+  m.def("resnet_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> Tensor");
+  m.def("resnet_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> (Tensor, Tensor)");
+  m.def("resnet_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int n_out, int precision, int t_table, Tensor? stash) -> Tensor");
+  m.def("resnet_p_sample_chain(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, int index_base, int precision) -> Tensor");
+  m.def("resnet_p_sample_chain_out(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, int index_base, int precision, Tensor(a!) out) -> ()");
+  m.def("se3_q_sample_target(Tensor sched, Tensor trap_q, Tensor? guide_q, float shift_scale, Tensor x0_rot, Tensor x0_shift, Tensor t, "
+        "bool quirk_col0, Tensor? axes, Tensor? unif, Tensor? znorm, int seed, int rng_offset, int index_base, bool want_targets) "
+        "-> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("se3_p_mean(Tensor sched, Tensor x_rot, Tensor x_shift, Tensor v_rot, Tensor v_shift, int t) -> (Tensor, Tensor)");
+  m.def("se3_p_noise(Tensor trap_row, float sigma, float shift_scale, Tensor mean_rot, Tensor mean_shift, Tensor? axes, Tensor? unif, "
+        "Tensor? znorm, int seed, int rng_offset, int index_base, bool shared_rot) -> (Tensor, Tensor)");
+  m.def("rigid_move(Tensor rot, Tensor shift, Tensor pos, Tensor? frames) -> (Tensor, Tensor)");
+  m.def("kernel_sum(Tensor X, Tensor Y, int kind, float scale) -> Tensor");
+  m.def("six2rmat(Tensor x6) -> Tensor");
+  m.def("six2rmat_bwd(Tensor x6, Tensor dR) -> Tensor");
+  m.def("log_rmat_bwd(Tensor R, Tensor dlog) -> Tensor");
+  m.def("rmat_dist_bwd(Tensor a, Tensor b, Tensor ddist) -> (Tensor, Tensor)");
+  m.def("prevstep_loss(Tensor sched, Tensor x_recon, Tensor x_start, Tensor x_noisy, Tensor t, int t_stride, bool want_dx, bool want_step) "
+        "-> (Tensor, Tensor, Tensor)");
+  m.def("prevstep_loss6(Tensor sched, Tensor out6, Tensor x_start, Tensor x_noisy, Tensor t, int t_stride) -> (Tensor, Tensor)");
+  m.def("mse_loss(Tensor a, Tensor b) -> Tensor");
+  m.def("mse_grad(Tensor a, Tensor b, Tensor gscale) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
@@ -362,4 +574,23 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("train_fwd", train_fwd);
   m.impl("train_bwd", train_bwd);
   m.impl("adam_step", adam_step);
+  m.impl("rotate_cloud", rotate_cloud);
+  m.impl("resnet_fwd", resnet_fwd);
+  m.impl("resnet_fwd_stash", resnet_fwd_stash);
+  m.impl("resnet_bwd", resnet_bwd);
+  m.impl("resnet_p_sample_chain", resnet_p_sample_chain);
+  m.impl("resnet_p_sample_chain_out", resnet_p_sample_chain_out);
+  m.impl("se3_q_sample_target", se3_q_sample_target);
+  m.impl("se3_p_mean", se3_p_mean);
+  m.impl("se3_p_noise", se3_p_noise);
+  m.impl("rigid_move", rigid_move);
+  m.impl("kernel_sum", kernel_sum);
+  m.impl("six2rmat", six2rmat);
+  m.impl("six2rmat_bwd", six2rmat_bwd);
+  m.impl("log_rmat_bwd", log_rmat_bwd);
+  m.impl("rmat_dist_bwd", rmat_dist_bwd);
+  m.impl("prevstep_loss", prevstep_loss);
+  m.impl("prevstep_loss6", prevstep_loss6);
+  m.impl("mse_loss", mse_loss);
+  m.impl("mse_grad", mse_grad);
 }

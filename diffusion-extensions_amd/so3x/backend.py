@@ -1,9 +1,10 @@
 """Binding of libso3x.so (include/so3x.h) for torch tensors on an MI355X.
 
-The SO(3) hot path (rotation algebra, IGSO(3), the score MLP, the diffusion steps, the training step) is
-bound as PyTorch-ROCm custom operators: libso3x_torch.so registers TORCH_LIBRARY(so3x, ...) over the C ABI
-(csrc/so3x_torch.cpp) and the functions below call torch.ops.so3x.*.  The widened rows (SE(3) layer, statistics, the
-255-wide network, the rotation-matrix head) still reach the same C ABI through ctypes on data_ptr().
+Every device entry point -- the SO(3) hot path (rotation algebra, IGSO(3), the score MLP, the diffusion
+steps, the training step) and the widened rows (SE(3) layer, statistics, the 255-wide network, the rotation-matrix head)
+-- is bound as a PyTorch-ROCm custom operator: libso3x_torch.so registers TORCH_LIBRARY(so3x, ...) over the C ABI
+(csrc/so3x_torch.cpp) and the functions below call torch.ops.so3x.*.  ctypes is left for the four host-side table
+builders (schedules, IGSO(3) knots, embedding frequencies: numpy in, numpy out) and the ABI / symbol check at load time.
 
 PyTorch is plumbing here: it owns device memory and the HIP stream; every computation on the hot path happens in the
 hand-written HIP kernels behind the C ABI.  There is NO CPU path and NO fallback: a missing library, a missing symbol, a
@@ -137,10 +138,6 @@ def _dev(x, name, dtype=torch.float32):
     return x if x.is_contiguous() else x.contiguous()
 
 
-def _ptr(x):
-    return C.c_void_p(x.data_ptr()) if x is not None else None
-
-
 def _guide(g, trap, name="guide"):
     """optional uint16 search guide of `trap` (igso3_build_guide): same device, one 258-entry row per CDF row"""
     if g is None:
@@ -155,37 +152,6 @@ def _out_like(out, x, name="out"):
     if out.dtype != torch.float32 or not out.is_cuda or out.device != x.device or not out.is_contiguous() or out.numel() != x.numel():
         raise ValueError(f"so3x: {name} must be a contiguous fp32 tensor of {x.numel()} elements on {x.device}")
     return out
-
-
-def _stream(x):
-    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-
-
-def _i64(v):
-    return C.c_int64(int(v))
-
-
-def _u64(v):
-    return C.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
-
-
-class _Guard:
-    """Makes the tensor's GPU the current HIP device for the launch.  When it already is (the one-process-per-GPU
-    layout always), entering costs two integer reads instead of a torch.cuda.device context (~10 us per call, a
-    measurable share of a host-bound training step)."""
-    __slots__ = ("g",)
-
-    def __init__(self, x):
-        idx = x.device.index
-        self.g = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(x.device)
-
-    def __enter__(self):
-        if self.g is not None:
-            self.g.__enter__()
-
-    def __exit__(self, *a):
-        if self.g is not None:
-            self.g.__exit__(*a)
 
 
 # ----------------------------------------------------------------------------- host-side
@@ -219,36 +185,6 @@ def posemb_freqs(half_dim=28):
     out = np.empty(half_dim, np.float32)
     _check(lib().so3x_posemb_freqs(C.c_int(half_dim), out.ctypes.data_as(C.c_void_p)), "posemb_freqs")
     return out
-
-
-# ----------------------------------------------------------------------------- workspaces
-_ws = {}
-
-
-def _ws_key(device):
-    """one scratch buffer per (device, stream): calls on different streams may run concurrently, and a buffer first
-    requested while a hipGraph is being captured is allocated from that graph's private pool -- it stays valid for the
-    graph's lifetime whatever eager calls on other streams request later"""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return (idx, torch.cuda.current_stream(idx).cuda_stream)
-
-
-def _capturing():
-    return torch.cuda.is_current_stream_capturing()
-
-
-def _workspace(device, nbytes):
-    if _capturing():
-        # every capture shares torch's one capture stream: a cached per-stream buffer would be handed from one graph's
-        # private pool to the next graph.  A buffer allocated here belongs to the graph being captured and lives as long
-        # as it does; stream order makes its reuse by later allocations of the same capture safe.
-        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-    key = _ws_key(device)
-    buf = _ws.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws[key] = buf
-    return buf
 
 
 # ----------------------------------------------------------------------------- rotations
@@ -543,10 +479,7 @@ def rotate_cloud(rot, cloud):
             raise ValueError(f"so3x: a batch of clouds {tuple(cloud.shape)} needs one rotation each, got {tuple(rot.shape)}")
         P = cloud.shape[-2]
         stride = 3 * P
-    out = torch.empty(rot.shape[:-2] + (P, 3), dtype=torch.float32, device=rot.device)
-    with _Guard(rot):
-        _check(lib().so3x_rotate_cloud(_stream(rot), _ptr(rot), _ptr(cloud), _i64(stride), _ptr(out), _i64(n), _i64(P)), "rotate_cloud")
-    return out
+    return _call(ops().rotate_cloud, rot, cloud, int(stride), int(P))
 
 
 # ------------------------------------------------- wide residual score network (so3_lock_train.py:11-59)
@@ -559,15 +492,8 @@ def resnet_fwd(params, R, t, t_table, precision=PREC_F32):
     params = _dev(params, "params").reshape(-1)
     n_out = _head_width(params.numel(), _RESNET_TRUNK, 255, "wide-net")
     R = _rot_in(R, "x")
-    n = R.numel() // 9
-    tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
-    nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(int(t_table)))
-    ws = _workspace(R.device, nb)
-    with _Guard(R):
-        _check(lib().so3x_resnet_fwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _i64(n), C.c_int(n_out),
-                                     C.c_int(precision), C.c_int(int(t_table)), _ptr(ws), C.c_size_t(ws.numel())), "resnet_fwd")
-    return out
+    tt, stride = _t_arg(t, R.numel() // 9)
+    return _call(ops().resnet_fwd, params, R, tt, stride, n_out, int(precision), int(t_table))
 
 
 def resnet_fwd_stash(params, R, t, t_table, precision=PREC_BF16):
@@ -575,18 +501,8 @@ def resnet_fwd_stash(params, R, t, t_table, precision=PREC_BF16):
     params = _dev(params, "params").reshape(-1)
     n_out = _head_width(params.numel(), _RESNET_TRUNK, 255, "wide-net")
     R = _rot_in(R, "x")
-    n = R.numel() // 9
-    tt, stride = _t_arg(t, n)
-    out = torch.empty(R.shape[:-2] + (n_out,), dtype=torch.float32, device=R.device)
-    stash = torch.empty(lib().so3x_resnet_stash_bytes(_i64(n), C.c_int(precision)), dtype=torch.uint8, device=R.device)
-    nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(int(t_table)))
-    ws = _workspace(R.device, nb)
-    with _Guard(R):
-        _check(lib().so3x_resnet_fwd_stash(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(out), _ptr(stash),
-                                           _i64(n), C.c_int(n_out), C.c_int(precision), C.c_int(int(t_table)), _ptr(ws),
-                                           C.c_size_t(ws.numel())),
-               "resnet_fwd_stash")
-    return out, stash
+    tt, stride = _t_arg(t, R.numel() // 9)
+    return _call(ops().resnet_fwd_stash, params, R, tt, stride, n_out, int(precision), int(t_table))
 
 
 def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16, stash=None):
@@ -594,18 +510,9 @@ def resnet_bwd(params, R, t, dout, t_table, precision=PREC_BF16, stash=None):
     params = _dev(params, "params").reshape(-1)
     n_out = _head_width(params.numel(), _RESNET_TRUNK, 255, "wide-net")
     R = _rot_in(R, "x")
-    n = R.numel() // 9
-    tt, stride = _t_arg(t, n)
+    tt, stride = _t_arg(t, R.numel() // 9)
     dout = _dev(dout, "dout").reshape(-1, n_out)
-    dparams = torch.empty(params.numel(), dtype=torch.float32, device=R.device)
-    nb = lib().so3x_resnet_train_workspace_bytes(_i64(n), C.c_int(precision), C.c_int(int(t_table)))
-    ws = _workspace(R.device, nb)
-    with _Guard(R):
-        _check(lib().so3x_resnet_bwd(_stream(R), _ptr(params), _ptr(R), _ptr(tt), _i64(stride), _ptr(dout), _ptr(dparams),
-                                     _i64(n), C.c_int(n_out), C.c_int(precision), C.c_int(int(t_table)), _ptr(stash), _ptr(ws),
-                                     C.c_size_t(ws.numel())),
-               "resnet_bwd")
-    return dparams
+    return _call(ops().resnet_bwd, params, R, tt, stride, dout, n_out, int(precision), int(t_table), stash)
 
 
 def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0,
@@ -614,21 +521,15 @@ def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None,
     if params.numel() != N_PARAMS_RESNET:
         raise ValueError(f"so3x: params must hold {N_PARAMS_RESNET} values")
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     trap_p = _dev(trap_p, "trap_p")
     x = _rot_in(x, "x")
-    n = x.numel() // 9
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
     guide_p = _guide(guide_p, trap_p, "guide_p")
-    out = torch.empty_like(x) if out is None else _out_like(out, x)
-    nb = lib().so3x_resnet_workspace_bytes(C.c_int(precision), C.c_int(T))
-    ws = _workspace(x.device, nb)
-    with _Guard(x):
-        _check(lib().so3x_resnet_p_sample_chain(_stream(x), _ptr(params), _ptr(sched), C.c_int(T), _ptr(trap_p), _ptr(guide_p), _ptr(x),
-                                                _ptr(out), C.c_int(int(t_start)), C.c_int(int(n_steps)), _ptr(ax), _ptr(un),
-                                                _u64(seed), _u64(rng_offset), _i64(index_base), _i64(n), C.c_int(precision),
-                                                _ptr(ws), C.c_size_t(ws.numel())), "resnet_p_sample_chain")
+    args = (params, sched, trap_p, guide_p, x, int(t_start), int(n_steps), ax, un, _s64(seed), _s64(rng_offset), int(index_base), int(precision))
+    if out is None:
+        return _call(ops().resnet_p_sample_chain, *args)
+    _call(ops().resnet_p_sample_chain_out, *args, _out_like(out, x))
     return out
 
 
@@ -636,7 +537,6 @@ def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None,
 def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_col0=True, axes=None, unif=None, znorm=None,
                         seed=0, rng_offset=0, index_base=0, want_targets=True, guide_q=None):
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     x0_rot = _rot_in(x0_rot, "x_start.rot")
     n = x0_rot.numel() // 9
     x0_shift = _dev(x0_shift, "x_start.shift").reshape(n, 3)
@@ -646,34 +546,19 @@ def se3_q_sample_target(sched, trap_q, shift_scale, x0_rot, x0_shift, t, quirk_c
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
     zn = _dev(znorm, "znorm").reshape(-1, 3) if znorm is not None else None
-    dev = x0_rot.device
-    xt_rot = torch.empty_like(x0_rot)
-    xt_shift = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    tg_rot = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
-    tg_shift = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_targets else None
-    with _Guard(x0_rot):
-        _check(lib().so3x_se3_q_sample_target(_stream(x0_rot), _ptr(sched), C.c_int(T), _ptr(trap_q), _ptr(guide_q),
-                                              C.c_float(float(shift_scale)), _ptr(x0_rot), _ptr(x0_shift), _ptr(tt),
-                                              C.c_int(int(quirk_col0)), _ptr(ax), _ptr(un), _ptr(zn), _u64(seed),
-                                              _u64(rng_offset), _i64(index_base), _ptr(xt_rot), _ptr(xt_shift),
-                                              _ptr(tg_rot), _ptr(tg_shift), _i64(n)), "se3_q_sample_target")
-    return xt_rot, xt_shift, tg_rot, tg_shift
+    xt_rot, xt_shift, tg_rot, tg_shift = _call(ops().se3_q_sample_target, sched, trap_q, guide_q, float(shift_scale), x0_rot, x0_shift, tt,
+                                               bool(quirk_col0), ax, un, zn, _s64(seed), _s64(rng_offset), int(index_base), bool(want_targets))
+    return xt_rot, xt_shift, (tg_rot if want_targets else None), (tg_shift if want_targets else None)
 
 
 def se3_p_mean(sched, x_rot, x_shift, v_rot, v_shift, t):
     sched = _dev(sched, "sched")
-    T = sched.shape[1]
     x_rot = _rot_in(x_rot, "x.rot")
     n = x_rot.numel() // 9
     x_shift = _dev(x_shift, "x.shift").reshape(n, 3)
     v_rot = _dev(v_rot, "noise.rot_g").reshape(n, 3)
     v_shift = _dev(v_shift, "noise.shift_g").reshape(n, 3)
-    mean_rot = torch.empty_like(x_rot)
-    mean_shift = torch.empty_like(x_shift)
-    with _Guard(x_rot):
-        _check(lib().so3x_se3_p_mean(_stream(x_rot), _ptr(sched), C.c_int(T), _ptr(x_rot), _ptr(x_shift), _ptr(v_rot),
-                                     _ptr(v_shift), C.c_int(int(t)), _ptr(mean_rot), _ptr(mean_shift), _i64(n)), "se3_p_mean")
-    return mean_rot, mean_shift
+    return _call(ops().se3_p_mean, sched, x_rot, x_shift, v_rot, v_shift, int(t))
 
 
 def se3_p_noise(trap_row, sigma, shift_scale, mean_rot, mean_shift, axes=None, unif=None, znorm=None, seed=0, rng_offset=0,
@@ -684,14 +569,8 @@ def se3_p_noise(trap_row, sigma, shift_scale, mean_rot, mean_shift, axes=None, u
     ax = _dev(axes, "axes").reshape(-1) if axes is not None else None
     un = _dev(unif, "unif").reshape(-1) if unif is not None else None
     zn = _dev(znorm, "znorm").reshape(-1, 3) if znorm is not None else None
-    out_rot = torch.empty_like(mean_rot)
-    out_shift = torch.empty_like(mean_shift)
-    with _Guard(mean_rot):
-        _check(lib().so3x_se3_p_noise(_stream(mean_rot), _ptr(_dev(trap_row, "trap_row")), C.c_float(float(sigma)),
-                                      C.c_float(float(shift_scale)), _ptr(mean_rot), _ptr(mean_shift), _ptr(ax), _ptr(un),
-                                      _ptr(zn), _u64(seed), _u64(rng_offset), _i64(index_base), C.c_int(int(shared_rot)),
-                                      _ptr(out_rot), _ptr(out_shift), _i64(n)), "se3_p_noise")
-    return out_rot, out_shift
+    return _call(ops().se3_p_noise, _dev(trap_row, "trap_row"), float(sigma), float(shift_scale), mean_rot, mean_shift, ax, un, zn,
+                 _s64(seed), _s64(rng_offset), int(index_base), bool(shared_rot))
 
 
 def rigid_move(rot, shift, pos, frames=None):
@@ -700,14 +579,9 @@ def rigid_move(rot, shift, pos, frames=None):
     S = rot.numel() // 9
     shift = _dev(shift, "transf.shift").reshape(S, 3)
     pos = _dev(pos, "positions")
-    L = pos.numel() // (3 * S)
     fr = _dev(frames, "angles") if frames is not None else None
-    out_pos = torch.empty_like(pos)
-    out_fr = torch.empty_like(fr) if fr is not None else None
-    with _Guard(rot):
-        _check(lib().so3x_rigid_move(_stream(rot), _ptr(rot), _ptr(shift), _ptr(pos), _ptr(fr), _ptr(out_pos), _ptr(out_fr),
-                                     _i64(S), _i64(L)), "rigid_move")
-    return out_pos, out_fr
+    out_pos, out_fr = _call(ops().rigid_move, rot, shift, pos, fr)
+    return out_pos, (out_fr if fr is not None else None)
 
 
 # ----------------------------------------------------------------------------- statistics
@@ -719,65 +593,26 @@ def kernel_sum(X, Y, kind=KERNEL_GAUSSIAN, scale=1.0):
     """scale * sum_ij k(X_i, Y_j) as a 0-d tensor (no host sync)."""
     X = _rot_in(X, "X").reshape(-1, 3, 3)
     Y = _rot_in(Y, "Y").reshape(-1, 3, 3)
-    nx, ny = X.shape[0], Y.shape[0]
-    out = torch.empty(1, dtype=torch.float32, device=X.device)
-    nb = lib().so3x_kernel_sum_workspace_bytes(_i64(nx), _i64(ny))
-    ws = _workspace(X.device, nb)
-    with _Guard(X):
-        _check(lib().so3x_kernel_sum(_stream(X), _ptr(X), _i64(nx), _ptr(Y), _i64(ny), C.c_int(int(kind)),
-                                     C.c_float(float(scale)), _ptr(out), _ptr(ws), C.c_size_t(ws.numel())), "kernel_sum")
-    return out[0]
+    return _call(ops().kernel_sum, X, Y, int(kind), float(scale))[0]
 
 
 # ------------------------------------------ rotation-matrix head + "prevstep" objective (8f row 3)
-class _Six2Rmat(torch.autograd.Function):
-    """six2rmat (reference util.py:67-76) with its closed-form backward"""
-
-    @staticmethod
-    def forward(ctx, x):
-        x = _dev(x, "x")
-        if x.shape[-1] != 6:
-            raise ValueError("so3x: six2rmat needs [..., 6]")
-        ctx.save_for_backward(x)
-        out = torch.empty(x.shape[:-1] + (3, 3), dtype=torch.float32, device=x.device)
-        with _Guard(x):
-            _check(lib().so3x_six2rmat(_stream(x), _ptr(x), _ptr(out), _i64(x.numel() // 6)), "six2rmat")
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        g = _dev(g, "grad")
-        dx = torch.empty_like(x)
-        with _Guard(x):
-            _check(lib().so3x_six2rmat_bwd(_stream(x), _ptr(x), _ptr(g), _ptr(dx), _i64(x.numel() // 6)), "six2rmat_bwd")
-        return dx
-
-
 def six2rmat(x):
-    return _Six2Rmat.apply(x)
+    """six2rmat (reference util.py:67-76); torch.ops.so3x.six2rmat carries its closed-form backward (so3x/ops.py)"""
+    x = _dev(x, "x")
+    if x.shape[-1] != 6:
+        raise ValueError("so3x: six2rmat needs [..., 6]")
+    return _call(ops().six2rmat, x)
 
 
 def log_rmat_bwd(R, dlog):
     """autograd of log_rmat: dL/dlog [.., 3, 3] -> dL/dR"""
-    R = _rot_in(R, "r_mat")
-    dlog = _rot_in(dlog, "grad")
-    dR = torch.empty_like(R)
-    with _Guard(R):
-        _check(lib().so3x_log_rmat_bwd(_stream(R), _ptr(R), _ptr(dlog), _ptr(dR), _i64(R.numel() // 9)), "log_rmat_bwd")
-    return dR
+    return _call(ops().log_rmat_bwd, _rot_in(R, "r_mat"), _rot_in(dlog, "grad"))
 
 
 def rmat_dist_bwd(a, b, ddist):
     """autograd of rmat_dist: dL/ddist [..] -> (dL/da, dL/db)"""
-    a = _rot_in(a, "input")
-    b = _rot_in(b, "target")
-    g = _dev(ddist, "grad").reshape(-1)
-    da, db = torch.empty_like(a), torch.empty_like(b)
-    with _Guard(a):
-        _check(lib().so3x_rmat_dist_bwd(_stream(a), _ptr(a), _ptr(b), _ptr(g), _ptr(da), _ptr(db), _i64(a.numel() // 9)),
-               "rmat_dist_bwd")
-    return da, db
+    return _call(ops().rmat_dist_bwd, _rot_in(a, "input"), _rot_in(b, "target"), _dev(ddist, "grad").reshape(-1))
 
 
 class _LogRmat(torch.autograd.Function):
@@ -827,16 +662,8 @@ class _PrevstepLoss(torch.autograd.Function):
         x_recon = _rot_in(x_recon, "x_recon")
         x_start = _rot_in(x_start, "x_start")
         x_noisy = _rot_in(x_noisy, "x_noisy")
-        n = x_recon.numel() // 9
-        tt, stride = _t_arg(t, n)
-        T = sched.shape[1]
-        loss = torch.empty(1, dtype=torch.float32, device=x_recon.device)
-        dx = torch.empty_like(x_recon)
-        ws = _workspace_small(x_recon.device, lib().so3x_prevstep_workspace_bytes(_i64(n)))
-        with _Guard(x_recon):
-            _check(lib().so3x_prevstep_loss(_stream(x_recon), _ptr(sched), C.c_int(T), _ptr(x_recon), _ptr(x_start), _ptr(x_noisy),
-                                            _ptr(tt), _i64(stride), _i64(n), _ptr(loss), _ptr(dx), None, _ptr(ws),
-                                            C.c_size_t(ws.numel())), "prevstep_loss")
+        tt, stride = _t_arg(t, x_recon.numel() // 9)
+        loss, dx, _ = _call(ops().prevstep_loss, _dev(sched, "sched"), x_recon, x_start, x_noisy, tt, stride, True, False)
         ctx.save_for_backward(dx)
         return loss[0]
 
@@ -858,15 +685,8 @@ class _PrevstepLoss6(torch.autograd.Function):
         out6 = _dev(out6, "out6").reshape(-1, 6)
         x_start = _rot_in(x_start, "x_start")
         x_noisy = _rot_in(x_noisy, "x_noisy")
-        n = out6.shape[0]
-        tt, stride = _t_arg(t, n)
-        loss = torch.empty(1, dtype=torch.float32, device=out6.device)
-        d6 = torch.empty_like(out6)
-        ws = _workspace_small(out6.device, lib().so3x_prevstep_workspace_bytes(_i64(n)))
-        with _Guard(out6):
-            _check(lib().so3x_prevstep_loss6(_stream(out6), _ptr(sched), C.c_int(sched.shape[1]), _ptr(out6), _ptr(x_start),
-                                             _ptr(x_noisy), _ptr(tt), _i64(stride), _i64(n), _ptr(loss), _ptr(d6), _ptr(ws),
-                                             C.c_size_t(ws.numel())), "prevstep_loss6")
+        tt, stride = _t_arg(t, out6.shape[0])
+        loss, d6 = _call(ops().prevstep_loss6, _dev(sched, "sched"), out6, x_start, x_noisy, tt, stride)
         ctx.save_for_backward(d6)
         return loss[0]
 
@@ -884,16 +704,8 @@ def prevstep_step(sched, x_start, x_noisy, t):
     """the rotation from x_noisy to the posterior mean of the previous step (reference diffusion.py:360-364)"""
     x_start = _rot_in(x_start, "x_start")
     x_noisy = _rot_in(x_noisy, "x_noisy")
-    n = x_start.numel() // 9
-    tt, stride = _t_arg(t, n)
-    loss = torch.empty(1, dtype=torch.float32, device=x_start.device)
-    step = torch.empty_like(x_start)
-    ws = _workspace_small(x_start.device, lib().so3x_prevstep_workspace_bytes(_i64(n)))
-    with _Guard(x_start):
-        _check(lib().so3x_prevstep_loss(_stream(x_start), _ptr(sched), C.c_int(sched.shape[1]), _ptr(x_noisy), _ptr(x_start),
-                                        _ptr(x_noisy), _ptr(tt), _i64(stride), _i64(n), _ptr(loss), None, _ptr(step), _ptr(ws),
-                                        C.c_size_t(ws.numel())), "prevstep_step")
-    return step
+    tt, stride = _t_arg(t, x_start.numel() // 9)
+    return _call(ops().prevstep_loss, _dev(sched, "sched"), x_noisy, x_start, x_noisy, tt, stride, False, True)[2]
 
 
 class _MSELoss(torch.autograd.Function):
@@ -906,36 +718,12 @@ class _MSELoss(torch.autograd.Function):
         if a.shape != b.shape:
             raise ValueError("so3x: mse_loss needs equal shapes")
         ctx.save_for_backward(a, b)
-        loss = torch.empty(1, dtype=torch.float32, device=a.device)
-        ws = _workspace_small(a.device, lib().so3x_mse_workspace_bytes(_i64(a.numel())))
-        with _Guard(a):
-            _check(lib().so3x_mse_loss(_stream(a), _ptr(a), _ptr(b), _i64(a.numel()), _ptr(loss), _ptr(ws),
-                                       C.c_size_t(ws.numel())), "mse_loss")
-        return loss[0]
+        return _call(ops().mse_loss, a, b)[0]
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        ga = torch.empty_like(a)
-        gs = _dev(g.reshape(1), "grad")
-        with _Guard(a):
-            _check(lib().so3x_mse_grad(_stream(a), _ptr(a), _ptr(b), _i64(a.numel()), _ptr(gs), _ptr(ga)), "mse_grad")
-        return ga, None
-
-
-_ws_small = {}
-
-
-def _workspace_small(device, nbytes):
-    """separate small scratch so the loss reduction never aliases the MLP workspace"""
-    if _capturing():
-        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-    key = _ws_key(device)
-    buf = _ws_small.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_small[key] = buf
-    return buf
+        return _call(ops().mse_grad, a, b, _dev(g.reshape(1), "grad")), None
 
 
 def mse_loss(a, b):

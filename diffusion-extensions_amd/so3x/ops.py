@@ -172,3 +172,117 @@ def _mlp_backward(ctx, dout):
 
 
 register_autograd("so3x::mlp_fwd", _mlp_backward, setup_context=_mlp_setup)
+
+# ---- widened rows
+_RESNET_STASH = {0: 13 * 1024, 1: 13 * 512}  # bytes per sample: an upper bound is all a fake needs
+
+
+@register_fake("so3x::rotate_cloud")
+def _(rot, cloud, cloud_stride, P):
+    return _f32(rot, rot.shape[:-2] + (P, 3))
+
+
+@register_fake("so3x::resnet_fwd")
+def _(params, x, t, t_stride, n_out, precision, t_table):
+    return _f32(x, x.shape[:-2] + (n_out,))
+
+
+@register_fake("so3x::resnet_fwd_stash")
+def _(params, x, t, t_stride, n_out, precision, t_table):
+    n = x.numel() // 9
+    return _f32(x, x.shape[:-2] + (n_out,)), x.new_empty((n * _RESNET_STASH.get(precision, 13 * 1024),), dtype=torch.uint8)
+
+
+@register_fake("so3x::resnet_bwd")
+def _(params, x, t, t_stride, dout, n_out, precision, t_table, stash):
+    return _f32(x, (params.numel(),))
+
+
+@register_fake("so3x::resnet_p_sample_chain")
+def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision):
+    return _f32(x, x.shape)
+
+
+@register_fake("so3x::resnet_p_sample_chain_out")
+def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision, out):
+    return None
+
+
+@register_fake("so3x::se3_q_sample_target")
+def _(sched, trap_q, guide_q, shift_scale, x0_rot, x0_shift, t, quirk_col0, axes, unif, znorm, seed, rng_offset, index_base, want_targets):
+    n = x0_rot.numel() // 9
+    k = n if want_targets else 0
+    return _f32(x0_rot, x0_rot.shape), _f32(x0_rot, (n, 3)), _f32(x0_rot, (k, 3)), _f32(x0_rot, (k, 3))
+
+
+@register_fake("so3x::se3_p_mean")
+def _(sched, x_rot, x_shift, v_rot, v_shift, t):
+    return _f32(x_rot, x_rot.shape), _f32(x_shift, x_shift.shape)
+
+
+@register_fake("so3x::se3_p_noise")
+def _(trap_row, sigma, shift_scale, mean_rot, mean_shift, axes, unif, znorm, seed, rng_offset, index_base, shared_rot):
+    return _f32(mean_rot, mean_rot.shape), _f32(mean_shift, mean_shift.shape)
+
+
+@register_fake("so3x::rigid_move")
+def _(rot, shift, pos, frames):
+    return _f32(pos, pos.shape), _f32(pos, frames.shape if frames is not None else (0, 3, 3))
+
+
+@register_fake("so3x::kernel_sum")
+def _(X, Y, kind, scale):
+    return _f32(X, (1,))
+
+
+@register_fake("so3x::six2rmat")
+def _(x6):
+    return _f32(x6, x6.shape[:-1] + (3, 3))
+
+
+@register_fake("so3x::six2rmat_bwd")
+def _(x6, dR):
+    return _f32(x6, x6.shape)
+
+
+@register_fake("so3x::log_rmat_bwd")
+def _(R, dlog):
+    return _f32(R, R.shape)
+
+
+@register_fake("so3x::rmat_dist_bwd")
+def _(a, b, ddist):
+    return _f32(a, a.shape), _f32(b, b.shape)
+
+
+@register_fake("so3x::prevstep_loss")
+def _(sched, x_recon, x_start, x_noisy, t, t_stride, want_dx, want_step):
+    return (_f32(x_recon, (1,)), _f32(x_recon, x_recon.shape if want_dx else (0, 3, 3)), _f32(x_recon, x_recon.shape if want_step else (0, 3, 3)))
+
+
+@register_fake("so3x::prevstep_loss6")
+def _(sched, out6, x_start, x_noisy, t, t_stride):
+    return _f32(out6, (1,)), _f32(out6, out6.shape)
+
+
+@register_fake("so3x::mse_loss")
+def _(a, b):
+    return _f32(a, (1,))
+
+
+@register_fake("so3x::mse_grad")
+def _(a, b, gscale):
+    return _f32(a, a.shape)
+
+
+# ---- autograd of six2rmat (reference util.py:67-76 under torch autograd): the closed-form backward kernel
+def _six_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+
+
+def _six_backward(ctx, g):
+    (x6,) = ctx.saved_tensors
+    return torch.ops.so3x.six2rmat_bwd(x6, g.contiguous())
+
+
+register_autograd("so3x::six2rmat", _six_backward, setup_context=_six_setup)

@@ -48,6 +48,48 @@ def test_opcheck_on_the_hot_path_operators(env):
             test_utils=("test_schema", "test_faketensor"))
 
 
+def test_opcheck_on_the_widened_rows(env):
+    """the operators of SURVEY 8f's rows (SE(3) layer, statistics, the 255-wide network, the rotation-matrix head and its
+    objective): schema, fake kernels, autograd registration, AOT dispatch -- and six2rmat's registered backward against a
+    finite difference"""
+    from torch.library import opcheck
+    ops, B, proc, x, t, n = env["ops"], env["B"], env["proc"], env["x"], env["t"], env["n"]
+    checks = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_dynamic")
+    sh = torch.randn(n, 3, device=DEV)
+    opcheck(ops.se3_q_sample_target.default, (proc._sched, env["trap_q"], proc._guide_q, 10.0, x, sh, t, True, None, None, None, 3, 0, 0, True),
+            test_utils=checks)
+    opcheck(ops.se3_p_mean.default, (proc._sched, x, sh, torch.randn(n, 3, device=DEV), torch.randn(n, 3, device=DEV), 40), test_utils=checks)
+    opcheck(ops.se3_p_noise.default, (env["trap_p"][40].contiguous(), 0.3, 10.0, x, sh, None, None, None, 3, 0, 0, True), test_utils=checks)
+    pos = torch.randn(n, 7, 3, device=DEV)
+    opcheck(ops.rigid_move.default, (x, sh, pos, None), test_utils=checks)
+    opcheck(ops.rigid_move.default, (x, sh, pos, B.quat_to_rmat(torch.randn(n, 7, 4, device=DEV))), test_utils=checks)
+    opcheck(ops.rotate_cloud.default, (x, torch.randn(11, 3, device=DEV), 0, 11), test_utils=checks)
+    opcheck(ops.kernel_sum.default, (x, x[:50].contiguous(), B.KERNEL_GAUSSIAN, 1.0), test_utils=checks)
+    opcheck(ops.mse_loss.default, (sh, torch.randn(n, 3, device=DEV)), test_utils=checks)
+    opcheck(ops.mse_grad.default, (sh, torch.randn(n, 3, device=DEV), torch.ones(1, device=DEV)), test_utils=checks)
+    x6 = torch.randn(n, 6, device=DEV)
+    opcheck(ops.six2rmat.default, (x6,), test_utils=checks)
+    opcheck(ops.six2rmat.default, (x6.clone().requires_grad_(),), test_utils=checks)
+    opcheck(ops.log_rmat_bwd.default, (x, torch.randn(n, 3, 3, device=DEV)), test_utils=checks)
+    opcheck(ops.rmat_dist_bwd.default, (x, x.flip(0).contiguous(), torch.randn(n, device=DEV)), test_utils=checks)
+    opcheck(ops.prevstep_loss.default, (proc._sched, x, x.flip(0).contiguous(), x.roll(1, 0).contiguous(), t, 1, True, False), test_utils=checks)
+    opcheck(ops.prevstep_loss6.default, (proc._sched, x6, x, x.roll(1, 0).contiguous(), t, 1), test_utils=checks)
+    from so3x.so3_lock_train import RotPredict as WideNet
+    wide = WideNet(out_type="skewvec", precision="bf16").to(DEV)
+    wp = wide.flat_data().clone()
+    opcheck(ops.resnet_fwd.default, (wp, x, t, 1, 3, B.PREC_BF16, 100), test_utils=checks)
+    opcheck(ops.resnet_p_sample_chain.default, (wp, proc._sched, env["trap_p"], proc._guide_p, x, 50, 2, None, None, 5, 0, 0, B.PREC_BF16),
+            test_utils=checks)
+    # the registered backward of six2rmat: directional finite difference in fp32
+    a = x6[:16].clone().requires_grad_()
+    w = torch.randn(16, 3, 3, device=DEV)
+    (ops.six2rmat(a) * w).sum().backward()
+    d = torch.randn_like(a)
+    h = 1e-3
+    fd = ((ops.six2rmat(a.detach() + h * d) - ops.six2rmat(a.detach() - h * d)) * w).sum() / (2 * h)
+    assert abs(float((a.grad * d).sum()) - float(fd)) < 2e-3 * max(1.0, abs(float(fd)))
+
+
 def test_dispatcher_level_autograd_of_the_score_network(env, golden):
     """torch.ops.so3x.mlp_fwd is differentiable in its parameters through the registered formula (so3x_mlp_bwd):
     the reference's autograd gradients of the seed-0 network (tests/golden/score_mlp.npz), fp32"""
