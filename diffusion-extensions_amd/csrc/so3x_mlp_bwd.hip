@@ -876,20 +876,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 __device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L, int ch, uint32_t lo, uint32_t hi) {
   *reinterpret_cast<uint2*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = uint2{lo, hi};
 }
-// one pass over a layer's pre-activations: packed H = silu(Z) * lv (with the constant-one row in the upper half of
-// tile 2) and the derivative silu'(Z) in fp32
-template <int PREC>
-__device__ __forceinline__ void silu_pass(const Z33h& z, float lv, int h, uint32_t (&ph)[17], float (&dv)[33]) {
+// one pass over a layer's pre-activations: packed H = silu(Z) (with the constant-one row in the upper half of tile 2) and
+// the derivative silu'(Z) in fp32.  H of a dead column (a sample index past n) is NOT zeroed: its dZ is an exact zero in
+// every layer (dZ_4 = dout * 0, and the chain maps a zero column to a zero column), so whatever finite H it holds -- the
+// forward parks finite pre-activations for every column of every tile -- adds exactly nothing to dW = dZ H^T.  That is
+// 33 multiplies per pass off the chain wave (9 % of its vector instructions).
+// (MASK: the recomputing variant keeps the multiply by the live flag -- without it the register allocator of THAT kernel,
+//  which spills already, does worse.)
+template <int PREC, bool MASK = false>
+__device__ __forceinline__ void silu_pass(const Z33h& z, int h, uint32_t (&ph)[17], float (&dv)[33], float lv = 1.0f) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     float a0, a1;
     silu_grad<PREC>(z.get(2 * r), &a0, &dv[2 * r]);
     silu_grad<PREC>(z.get(2 * r + 1), &a1, &dv[2 * r + 1]);
-    ph[r] = pack_bf16x2(a0 * lv, a1 * lv);
+    ph[r] = MASK ? pack_bf16x2(a0 * lv, a1 * lv) : pack_bf16x2(a0, a1);
   }
   float a;
   silu_grad<PREC>(z.get(32), &a, &dv[32]);
-  ph[16] = pack_bf16x2(h ? lv : a * lv, 0.0f);
+  ph[16] = MASK ? pack_bf16x2(h ? lv : a * lv, 0.0f) : pack_bf16x2(h ? 1.0f : a, 0.0f);
 }
 // dH = W^T dZ with dZ given as packed bf16 pairs (the MFMA operand bits as they are)
 template <int PREC, int L>
@@ -1037,7 +1042,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       float x[9];
       load_rot9(R, sc, x);
       const int64_t tt = t[sc * t_stride];
-      const float lv = live ? 1.0f : 0.0f;  // dead columns contribute exact zeros to every dW sum
+      const float lv = live ? 1.0f : 0.0f;  // dead columns: dZ_4 = 0, hence every dZ_l = 0 and no contribution to any dW sum
       const char* ztile = STASHED ? zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE : nullptr;
       // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them), fetched now, stored five layers
       // later: six 16-byte loads instead of 56 four-byte gathers waited for on the spot
@@ -1072,10 +1077,10 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
         if (nout == 6) pdz[2] = pack_bf16x2(dp[4] * lv, dp[5] * lv);
       }
       if constexpr (STASHED) {
-        silu_pass<PREC>(zb[0], lv, h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
+        silu_pass<PREC>(zb[0], h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
         zstash_load_layer(ztile, lane, 1, zb[0]);   // z1: used two layers from now
       } else {
-        silu_pass<PREC>(z[3], lv, h, ph, dnext);
+        silu_pass<PREC, true>(z[3], h, ph, dnext, lv);
       }
 #pragma unroll
       for (int l = 4; l >= 0; l--) {
@@ -1120,14 +1125,14 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
             // every fetch is issued two uses (~two layers, more than an HBM round trip) ahead:  l = 4 uses z2 (buffer 1)
             // and fetches z0 into it;  l = 3 uses z1 (buffer 0, fetched at the top of the round) and fetches the NEXT
             // round's z3;  l = 2 uses z0 and fetches the next round's z2
-            if (l > 1) silu_pass<PREC>(zb[l & 1 ? 0 : 1], lv, h, ph, dnext);
+            if (l > 1) silu_pass<PREC>(zb[l & 1 ? 0 : 1], h, ph, dnext);
             const int64_t ntile = (rd + 1) * nchain + (int64_t)blockIdx.x * 4 + wid;
             const char* nz = zstash + (size_t)(ntile < ntiles ? ntile : ntiles - 1) * ZSTASH_TILE;
             if (l == 4) zstash_load_layer(ztile, lane, 0, zb[1]);
             if (l == 3) zstash_load_layer(nz, lane, 3, zb[0]);
             if (l == 2) zstash_load_layer(nz, lane, 2, zb[1]);
           } else {
-            if (l > 1) silu_pass<PREC>(z[l - 2], lv, h, ph, dnext);     // H_{l-1} = silu(Z_{l-2}), silu'(Z_{l-2})
+            if (l > 1) silu_pass<PREC, true>(z[l - 2], h, ph, dnext, lv);     // H_{l-1} = silu(Z_{l-2}), silu'(Z_{l-2})
           }
         }
         __syncthreads();  // B2: the dW waves are done with the images
