@@ -136,7 +136,9 @@ __device__ __forceinline__ void wave_load_rows(const float* __restrict__ g, int6
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int W>
+// NT: non-temporal stores for outputs that are written once and not read back by this kernel (streaming kernels)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+template <int W, bool NT = false>
 __device__ __forceinline__ void wave_store_rows(float* __restrict__ g, int64_t base, int cnt, float* wlds, const float* r) {
   const int lane = threadIdx.x & 63;
   float* dst = g + base * W;
@@ -150,7 +152,10 @@ __device__ __forceinline__ void wave_store_rows(float* __restrict__ g, int64_t b
 #pragma unroll
     for (int i = 0; i < (W * 16 + 63) / 64; i++) {
       const int k = lane + 64 * i;
-      if (k < W * 16) d4[k] = s4[k];
+      if (k < W * 16) {
+        if constexpr (NT) __builtin_nontemporal_store(reinterpret_cast<const f32x4_nt*>(wlds)[k], reinterpret_cast<f32x4_nt*>(dst) + k);
+        else d4[k] = s4[k];
+      }
     }
   } else {
     for (int i = lane; i < cnt * W; i += 64) dst[i] = wlds[i];
@@ -162,13 +167,23 @@ __device__ __forceinline__ void wave_store_rows(float* __restrict__ g, int64_t b
 // registers (9 VGPRs) before computing the current tile, land them in LDS when their turn comes.
 // Only for full, 16-B-aligned tiles (the caller falls back to wave_load_rows otherwise).
 struct Pref9 { float4 a, b, c; };
+template <bool NT = false>
 __device__ __forceinline__ Pref9 wave_prefetch9(const float* __restrict__ g, int64_t base) {
   const int lane = threadIdx.x & 63;
   const float4* s4 = reinterpret_cast<const float4*>(g + base * 9);
   Pref9 p;
-  p.a = s4[lane];
-  p.b = s4[lane + 64];
-  p.c = lane < 16 ? s4[lane + 128] : float4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (NT) {  // read-once input of a streaming kernel
+    const f32x4_nt* v4 = reinterpret_cast<const f32x4_nt*>(g + base * 9);
+    const f32x4_nt a = __builtin_nontemporal_load(v4 + lane), b = __builtin_nontemporal_load(v4 + lane + 64);
+    p.a = float4{a[0], a[1], a[2], a[3]};
+    p.b = float4{b[0], b[1], b[2], b[3]};
+    if (lane < 16) { const f32x4_nt c = __builtin_nontemporal_load(v4 + lane + 128); p.c = float4{c[0], c[1], c[2], c[3]}; }
+    else p.c = float4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    p.a = s4[lane];
+    p.b = s4[lane + 64];
+    p.c = lane < 16 ? s4[lane + 128] : float4{0.f, 0.f, 0.f, 0.f};
+  }
   return p;
 }
 __device__ __forceinline__ void wave_commit9(const Pref9& p, float* wlds, float* r) {

@@ -149,6 +149,24 @@ __device__ __attribute__((noinline)) float logp_identity_f64(float e) {
 // by design.  The reference evaluates the density in fp64, casts to fp32 and logs in fp32
 // (distributions.py:53-77); igso3_logf_dlog_f32 reproduces that result in fp32 arithmetic
 // (so3x_igso3.hpp) -- the fp64 form was VALU-bound at 27 % of HBM peak.
+#ifndef SO3X_LPS_NT
+#define SO3X_LPS_NT 1
+#endif
+// Non-temporal STORES of the outputs: +1-3 % (2^20: 60.4 -> 61.2 % of 8 TB/s, 2^24: 69.9 -> 71.9 %, tools/ab/ab_logprob.py).
+// Non-temporal LOADS of the inputs: -8 % -- back-to-back calls on the same rotations find them in the memory-side cache.
+#ifndef SO3X_LPS_NTL
+#define SO3X_LPS_NTL 0
+#endif
+#if SO3X_LPS_NTL
+#define SO3X_LPS_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SO3X_LPS_LOAD(p) (*(p))
+#endif
+#if SO3X_LPS_NT
+#define SO3X_LPS_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define SO3X_LPS_STORE(v, p) (*(p) = (v))
+#endif
 __global__ void __launch_bounds__(kBlock, 5)
 k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int64_t eps_stride, float* __restrict__ logp,
                 float* __restrict__ score_vec, float* __restrict__ grad_R, int64_t n) {
@@ -165,7 +183,7 @@ k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int6
   Pref9 pf;
   float pe = 1.0f;
   bool have = full(wave);
-  if (have) { pf = wave_prefetch9(R, wave * kWave); pe = eps[(wave * kWave + lane) * eps_stride]; }
+  if (have) { pf = wave_prefetch9<SO3X_LPS_NTL>(R, wave * kWave); pe = SO3X_LPS_LOAD(eps + (wave * kWave + lane) * eps_stride); }
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kWave;
     const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
@@ -181,7 +199,7 @@ k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int6
       wave_load_rows<9>(R, base, cnt, wl, r);
     }
     have = full(tile + nwaves);
-    if (have) { pf = wave_prefetch9(R, (tile + nwaves) * kWave); pe = eps[((tile + nwaves) * kWave + lane) * eps_stride]; }
+    if (have) { pf = wave_prefetch9<SO3X_LPS_NTL>(R, (tile + nwaves) * kWave); pe = SO3X_LPS_LOAD(eps + ((tile + nwaves) * kWave + lane) * eps_stride); }
     float sn_om, cs_om;
     const float ang = log3_sc(r, w, &sn_om, &cs_om);   // rmat_to_aa angle (util.py:217): |w| = atan2(s, c)
     float lp, dl;
@@ -191,11 +209,11 @@ k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int6
     } else {
       lp = igso3_logf_dlog_f32(ang, e, sn_om, cs_om, &dl);
     }
-    if (live) logp[idx] = lp;
+    if (live) SO3X_LPS_STORE(lp, logp + idx);
     if (score_vec) {
       const float k = dl * frcp(ang);
       float sv[3] = {k * w[0], k * w[1], k * w[2]};
-      wave_store_rows<3>(score_vec, base, cnt, wl, sv);
+      wave_store_rows<3, SO3X_LPS_NT>(score_vec, base, cnt, wl, sv);
     }
     if (grad_R) {
       // d omega / dR = [ c/(4s) (R - R^T) - (s/2) I ] / (s^2 + c^2)   
