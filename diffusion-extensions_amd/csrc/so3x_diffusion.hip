@@ -126,6 +126,23 @@ k_p_mean(const float* __restrict__ sched, int T, const float* __restrict__ x, co
   }
 }
 
+// ---- per-timestep CDF records of the bf16 chain kernel: [999 floats of trap_p row t][258 uint16 of guide row t][pad] = 4,608
+//      bytes, 16-byte aligned, so that a wave brings its step's row into LDS with five LDS-DMA instructions at the top of the
+//      step and the inverse-CDF search of the reverse step (a chain of 4-8 dependent loads) runs on LDS instead of L2.
+constexpr int kCdfRec = 4608, kCdfGuideOff = 999 * 4;
+static_assert(kCdfGuideOff + kGuidePitch * 2 <= kCdfRec && kCdfRec % 512 == 0, "record layout");
+inline size_t cdf_offset(int T) { return (l0t_end(T) + 255) & ~(size_t)255; }
+inline size_t cdf_end(int T) { return cdf_offset(T) + (size_t)T * kCdfRec; }
+__global__ void __launch_bounds__(256) k_prep_cdf(const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p, char* __restrict__ rec,
+                                                  int t_first) {
+  const int t = t_first + blockIdx.x;
+  char* r = rec + (size_t)t * kCdfRec;
+  for (int i = threadIdx.x; i < 999; i += 256) reinterpret_cast<float*>(r)[i] = trap_p[(size_t)t * 999 + i];
+  for (int i = threadIdx.x; i < (kCdfRec - kCdfGuideOff) / 2; i += 256)
+    reinterpret_cast<uint16_t*>(r + kCdfGuideOff)[i] = (guide_p && i < kGuidePitch) ? guide_p[(size_t)t * kGuidePitch + i] : (uint16_t)0;
+}
+constexpr int kChainKnotsBytes = 4096, kChainRowBufBytes = 8 * kCdfRec;  // LDS behind the weight image (WIDE variant)
+
 // ---------------------------------------------------------------------------------------
 // A13: chain-resident reverse sampler.
 //  * one wave owns 64 samples; each lane keeps its rotation in 9 VGPRs for ALL n_steps
@@ -150,7 +167,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                  int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
-                 uint64_t rng_offset, int64_t index_base, int64_t n) {
+                 uint64_t rng_offset, int64_t index_base, int64_t n, const char* __restrict__ cdf_rec) {
   static_assert(!WIDE || (PAIR && PREC == SO3X_PREC_BF16), "the wide table belongs to the paired bf16 stream");
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   char* lds = lds_all + (WIDE ? kWideTabBytes : 0);
@@ -160,6 +177,12 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     if ((uint32_t)(uintptr_t)(lds_cp)lds_all != 0u) __builtin_trap();  // the byte-insert addressing needs the table at LDS address 0
     fill_wide_tab(reinterpret_cast<const char*>(gimg) + (size_t)n_frags<PREC, CHAIN>() * frag_bytes<PREC>());
   }
+  // WIDE: the knots of the IGSO(3) CDF (shared by every timestep) and one 4.5-KB record buffer per wave behind the image
+  char* knots_lds = lds + image_bytes<PREC, CHAIN>();
+  char* rowbuf = knots_lds + kChainKnotsBytes + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kCdfRec;
+  const bool staged = WIDE && cdf_rec != nullptr && axes == nullptr;
+  if (staged)
+    for (int i = threadIdx.x; i < 1000; i += blockDim.x) reinterpret_cast<float*>(knots_lds)[i] = SO3X_KNOTS_DATA[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const uint32_t lt = wide_tab_lane(lane);
@@ -185,12 +208,25 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       if (s > 0) rmat_from_quat(q, R);
       const float* beff = beff_tab + (size_t)t * 96;
       float va[3], vb[3], v[3];
+      StepCoef coef{};
       if constexpr (PREC == SO3X_PREC_BF16) {  // layer 0 from this timestep's fragments (bias in the K dimension)
         const bf16x8* l0t = l0t_tab + (size_t)t * 192;
         if constexpr (PAIR) {
 #if SO3X_ABLATE == 2  /* timing experiment only (tools/ab): no network */
           va[0] = vb[0] = R[1]; va[1] = vb[1] = R[2]; va[2] = vb[2] = R[5];
 #else
+          // the step's schedule scalars: scalar loads issued here, a network away from their use
+          coef = StepCoef{sched[S_RECIP * T + t], sched[S_RECIPM1 * T + t], sched[S_COEF1 * T + t], sched[S_COEF2 * T + t]};
+          if (staged) {  // this step's CDF record -> LDS (five 1-KB / 512-B DMAs); it lands while the network runs
+            const char* src = cdf_rec + (size_t)t * kCdfRec + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                               (__attribute__((address_space(3))) void*)(rowbuf + i * 1024), 16, 0, 0);
+            if (lane < 32)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096),
+                                               (__attribute__((address_space(3))) void*)(rowbuf + 4096), 16, 0, 0);
+          }
           bf16x8 wn[3];
           const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
 #pragma unroll
@@ -216,7 +252,15 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #if SO3X_ABLATE == 1  /* timing experiment only (tools/ab): no reverse step */
       q.w += v[0] * 1e-9f; q.x += v[1] * 1e-9f; q.y += v[2] * 1e-9f;
 #else
-      q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+      if (staged) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (and is visible to this wave's LDS reads)
+        q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx),
+                               reinterpret_cast<const float*>(rowbuf),
+                               guide_p ? reinterpret_cast<const uint16_t*>(rowbuf + kCdfGuideOff) : nullptr,
+                               reinterpret_cast<const float*>(knots_lds), &coef);
+      } else {
+        q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
+      }
 #endif
     }
     rmat_from_quat(qnormalize(q), R);
@@ -236,7 +280,7 @@ template <int PREC, bool FAST, bool PAIR, bool WIDE = false>
 int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
                    const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                    uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
-  constexpr int IMG = image_bytes<PREC, CHAIN>() + (WIDE ? kWideTabBytes : 0);
+  constexpr int IMG = image_bytes<PREC, CHAIN>() + (WIDE ? kWideTabBytes + kChainKnotsBytes + kChainRowBufBytes : 0);
   int max_blocks = 0;
   int threads = chain_threads_default<PREC>();
   if (PREC == SO3X_PREC_BF16 && getenv("SO3X_AB_BLOCK")) threads = atoi(getenv("SO3X_AB_BLOCK"));
@@ -250,7 +294,8 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
   hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
-                     t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
+                     t_start, n_steps, axes, unif, seed, rng_offset, index_base, n,
+                     (WIDE && !ab_env("SO3X_AB_CDF", "global")) ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr);
   return check_launch();
 }
 
@@ -324,7 +369,7 @@ int so3x_p_mean_t(so3x_stream_t s, const float* sched, int T, const float* x, co
 size_t so3x_p_sample_workspace_bytes(int T, int precision) {
   const int p = precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16;
   const int Tn = T > 0 ? T : 0;
-  return p == SO3X_PREC_BF16 ? l0t_end(Tn) : beff_offset(p, CHAIN) + (size_t)Tn * 96 * sizeof(float);
+  return p == SO3X_PREC_BF16 ? cdf_end(Tn) : beff_offset(p, CHAIN) + (size_t)Tn * 96 * sizeof(float);
 }
 
 int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,
@@ -343,6 +388,11 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
   int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace, 3, nullptr, true, nullptr, t_first, n_steps);
   if (rc) return rc;
   if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace, t_first, n_steps))) return rc;
+  if (precision == SO3X_PREC_BF16) {  // the CDF records of the steps this launch runs (LDS-DMA source of the chain kernel)
+    hipLaunchKernelGGL(k_prep_cdf, dim3(n_steps), dim3(256), 0, (hipStream_t)s, trap_p, guide_p,
+                       reinterpret_cast<char*>(workspace) + cdf_offset(T), t_first);
+    if ((rc = check_launch())) return rc;
+  }
   const float* beff = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + beff_offset(precision, CHAIN));
   if (precision == SO3X_PREC_F32)
     return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,

@@ -589,6 +589,9 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
 // slice of tile Y's activation -- table lookups for about three values, the multiply-adds of the lookups issued two gaps
 // earlier, the packing of finished pairs -- and ONE weight-fragment read (five MFMAs ahead: the fragments of output tiles 1
 // and 2, then the next stage's first five into `ring`).  A sched_barrier closes every gap, so the emitted order is this one.
+#ifndef SO3X_STAGE_LAG
+#define SO3X_STAGE_LAG 2
+#endif
 template <bool WIDE>
 __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const char* __restrict__ wnext, const Tile<SO3X_PREC_BF16>& inX,
                                            f32x16 (&accX)[3], const f32x16 (&accY)[3], Tile<SO3X_PREC_BF16>& curY, bf16x8 (&ring)[5],
@@ -598,7 +601,8 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
   float2 e[33];
   float val[33];
   uint32_t pk[16];
-  constexpr int LAST_LOOKUP_GAP = 11;  // lookups in gaps 0..11, multiply-adds two gaps behind, packing one more
+  constexpr int LAG = SO3X_STAGE_LAG;  // gaps between a lookup and its multiply-add (the LDS round trip under load)
+  constexpr int LAST_LOOKUP_GAP = 13 - LAG;  // lookups in gaps 0..13-LAG, multiply-adds LAG gaps behind, packing one more
   auto first_of = [](int g) { return g <= 0 ? 0 : (g > LAST_LOOKUP_GAP ? 33 : (33 * g) / (LAST_LOOKUP_GAP + 1)); };
 #pragma unroll
   for (int g = 0; g < 15; g++) {
@@ -616,10 +620,10 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
       }
     }
 #pragma unroll
-    for (int q = first_of(g - 2); q < first_of(g - 1); q++) val[q] = fmaf(e[q].y, q < 32 ? accY[q >> 4][q & 15] : accY[2][0], e[q].x);
+    for (int q = first_of(g - LAG); q < first_of(g - LAG + 1); q++) val[q] = fmaf(e[q].y, q < 32 ? accY[q >> 4][q & 15] : accY[2][0], e[q].x);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      const bool ready_now = 2 * j + 1 < first_of(g - 2), ready_before = 2 * j + 1 < first_of(g - 3);
+      const bool ready_now = 2 * j + 1 < first_of(g - LAG), ready_before = 2 * j + 1 < first_of(g - LAG - 1);
       if (ready_now && !ready_before) {
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
         pk[j] = __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)val[2 * j], (__bf16)val[2 * j + 1]});

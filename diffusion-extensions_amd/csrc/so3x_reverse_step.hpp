@@ -13,14 +13,18 @@ enum { S_SQRT_AC = 3, S_SQRT_1MAC = 4, S_RECIP = 6, S_RECIPM1 = 7, S_COEF1 = 10,
 //   x0hat = exp(a log x) exp(b v)^T,   mean = exp(c1 log x0hat) exp(c2 log x),   x' = mean @ IGSO3(sigma_t) (t > 0).
 // idc = clamped sample index for the explicit-draw arrays, gidx = global index keying the Philox counter.
 // FAST: hardware sine / cosine for the five exponentials (so3x_math.hpp sincos_sel; the bf16 chain kernels).
+// the four schedule scalars of a step, for callers that fetch them ahead of time (scalar loads issued at the top of the step)
+struct StepCoef { float a, b, c1, c2; };
+
 template <bool FAST = false>
 __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const float* __restrict__ sched, int T, int t,
                                              const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p,
                                              const float* __restrict__ axes,
                                              const float* __restrict__ unif, int64_t idc, uint64_t seed, uint64_t rng_offset,
-                                             uint64_t gidx) {
-  const float a = sched[S_RECIP * T + t], b = sched[S_RECIPM1 * T + t];
-  const float c1 = sched[S_COEF1 * T + t], c2 = sched[S_COEF2 * T + t];
+                                             uint64_t gidx, const float* row_l = nullptr, const uint16_t* grow_l = nullptr,
+                                             const float* knots_l = nullptr, const StepCoef* coef = nullptr) {
+  const float a = coef ? coef->a : sched[S_RECIP * T + t], b = coef ? coef->b : sched[S_RECIPM1 * T + t];
+  const float c1 = coef ? coef->c1 : sched[S_COEF1 * T + t], c2 = coef ? coef->c2 : sched[S_COEF2 * T + t];
   float ax[3], axh[3], vax[3];
   const float th = quat_axis_angle(q, ax);
   const float vn = fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -43,9 +47,11 @@ __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const 
       unit_axis(r.x, r.y, nax);
       u = u01(r.z);
     }
-    const float* row = trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
-    const uint16_t* grow = guide_p ? guide_p + (size_t)t * kGuidePitch : nullptr;  // optional search guide (bit-identical)
-    const float ang = axes ? igso3_angle<true>(row, row, SO3X_KNOTS_DATA, u, grow) : igso3_angle<false>(row, row, SO3X_KNOTS_DATA, u, grow);
+    // row_l / grow_l / knots_l: this timestep's CDF row, guide row and the knots staged in LDS by the caller (the chain kernel)
+    const float* row = row_l ? row_l : trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
+    const uint16_t* grow = row_l ? grow_l : (guide_p ? guide_p + (size_t)t * kGuidePitch : nullptr);  // optional search guide (bit-identical)
+    const float* kn = knots_l ? knots_l : SO3X_KNOTS_DATA;
+    const float ang = axes ? igso3_angle<true>(row, row, kn, u, grow) : igso3_angle<false>(row, row, kn, u, grow);
     q = qmul(q, quat_axis_angle_exp<FAST>(nax, ang));   // model_mean @ sample, :326
   }
   // no per-step renormalisation: q is rebuilt from (axis, angle) pairs every step, so its norm error is

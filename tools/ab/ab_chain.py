@@ -5,6 +5,7 @@ older build of the library (build/libso3x_r02a.so, if present):
    base      bf16 chain kernel as shipped: 2-instruction SiLU from the lane-replicated LDS table, hardware sine / cosine, the
              wave's two tiles as one software-pipelined stream, 8-wave workgroups
    narrow_tab SO3X_AB_TAB=narrow the 2 KB table with its shift-add addressing (3 instructions; bit-identical results)
+   cdf_global SO3X_AB_CDF=global the inverse-CDF search of the reverse step on global memory instead of the LDS-staged record
    cw        SO3X_AB_TRIG=cw     Cody-Waite sincos_cw in the reverse step (round 1's trigonometry)
    unpaired  SO3X_AB_PAIR=0      one tile after the other (forward_tile twice)
    blockNNN  SO3X_AB_BLOCK=NNN   other workgroup sizes (256: two per CU; 512: one per CU)
@@ -29,7 +30,8 @@ _, trap_p = proc._tables()
 params = net.flat_data()
 n = 1 << 20
 x = B.quat_to_rmat(torch.randn(n, 4, device=dev))
-VARIANTS = {"base": {}, "narrow_tab": {"SO3X_AB_TAB": "narrow"}, "cw": {"SO3X_AB_TRIG": "cw"}, "unpaired": {"SO3X_AB_PAIR": "0"}, "block256": {"SO3X_AB_BLOCK": "256"}}
+VARIANTS = {"base": {}, "narrow_tab": {"SO3X_AB_TAB": "narrow"}, "cw": {"SO3X_AB_TRIG": "cw"}, "unpaired": {"SO3X_AB_PAIR": "0"}, "block256": {"SO3X_AB_BLOCK": "256"},
+            "cdf_global": {"SO3X_AB_CDF": "global"}}
 # builds of earlier states of the kernel (same ABI), if present: "LIB" = path of the alternative libso3x.so
 import glob
 for path in sorted(glob.glob(os.path.join(ROOT, "build", "libso3x_*.so"))):
@@ -45,7 +47,7 @@ _cur = [None]
 
 
 def setenv(env):
-    for k in ("SO3X_AB_TRIG", "SO3X_AB_SILU", "SO3X_AB_BLOCK", "SO3X_AB_PAIR", "SO3X_AB_TAB"):
+    for k in ("SO3X_AB_TRIG", "SO3X_AB_SILU", "SO3X_AB_BLOCK", "SO3X_AB_PAIR", "SO3X_AB_TAB", "SO3X_AB_CDF"):
         os.environ.pop(k, None)
     os.environ.update({k: v for k, v in env.items() if k != "LIB"})
     path = env.get("LIB")
@@ -85,6 +87,10 @@ for r in range(rounds):
 setenv({})
 same = bool(torch.equal(run(20, 600), (setenv(VARIANTS["narrow_tab"]), run(20, 600))[1]))
 print("wide table vs narrow table after 20 steps at B = 2^20: bit-identical =", same)
+assert same
+setenv({})
+same = bool(torch.equal(run(20, 600), (setenv(VARIANTS["cdf_global"]), run(20, 600))[1]))
+print("CDF row staged in LDS vs read from global memory, 20 steps: bit-identical =", same)
 assert same
 setenv({})
 xs = x[:65536].contiguous()
