@@ -16,6 +16,16 @@ using namespace so3x::mlp;
 #ifndef SO3X_ABLATE
 #define SO3X_ABLATE 0
 #endif
+// -DSO3X_STAMPS=1: timing build (tools/ab): wave 0 of workgroup 0 accumulates s_memtime intervals of a step's phases and writes
+// them over the first bytes of x_out (the results of samples 0, 1 are destroyed)
+#ifndef SO3X_STAMPS
+#define SO3X_STAMPS 0
+#endif
+#if SO3X_STAMPS
+#define SO3X_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_last; stamp_last = now_; } while (0)
+#else
+#define SO3X_STAMP(k) do { } while (0)
+#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------
@@ -201,6 +211,9 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #pragma unroll
       for (int k = 0; k < 3; k++) w0[k] = l0t_tab[(size_t)t_start * 192 + 64 * k + lane];
     }
+#if SO3X_STAMPS
+    uint64_t stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
@@ -231,7 +244,13 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
           const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
 #pragma unroll
           for (int k = 0; k < 3; k++) wn[k] = l0n[64 * k + lane];
+          SO3X_STAMP(0);  // step top: rmat, scalar loads, DMA issue, prefetch
+#if SO3X_STAMPS
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, stamp_acc, &stamp_last);
+#else
           forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
+#endif
+          SO3X_STAMP(1);  // the two head stages
 #pragma unroll
           for (int k = 0; k < 3; k++) w0[k] = wn[k];
 #endif
@@ -252,6 +271,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #if SO3X_ABLATE == 1  /* timing experiment only (tools/ab): no reverse step */
       q.w += v[0] * 1e-9f; q.x += v[1] * 1e-9f; q.y += v[2] * 1e-9f;
 #else
+      SO3X_STAMP(2);  // output exchange
       if (staged) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (and is visible to this wave's LDS reads)
         q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx),
@@ -262,9 +282,16 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
       }
 #endif
+      SO3X_STAMP(3);  // the reverse step
     }
     rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
+#if SO3X_STAMPS
+    if (chunk == 0 && lane == 0) {
+      uint64_t* o = reinterpret_cast<uint64_t*>(x_out);
+      for (int k = 0; k < 6; k++) o[k] = stamp_acc[k];
+    }
+#endif
   }
 }
 

@@ -620,7 +620,8 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
       }
     }
 #pragma unroll
-    for (int q = first_of(g - LAG); q < first_of(g - LAG + 1); q++) val[q] = fmaf(e[q].y, q < 32 ? accY[q >> 4][q & 15] : accY[2][0], e[q].x);
+    for (int q = first_of(g - LAG + 1) - 1; q >= first_of(g - LAG); q--)  // newest lookup first: ONE counted wait covers the gap's multiply-adds
+      val[q] = fmaf(e[q].y, q < 32 ? accY[q >> 4][q & 15] : accY[2][0], e[q].x);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const bool ready_now = 2 * j + 1 < first_of(g - LAG), ready_before = 2 * j + 1 < first_of(g - LAG - 1);
@@ -643,8 +644,17 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
 }
 
 template <bool WIDE = false>
+#ifndef SO3X_STAMPS
+#define SO3X_STAMPS 0
+#endif
+#if SO3X_STAMPS  // timing build: phase stamps of the caller's accumulators (so3x_diffusion.hip)
+#define SO3X_FP_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - *stamp_last; *stamp_last = now_; } while (0)
+#else
+#define SO3X_FP_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8 (&l0w)[3],
-                                                  float* va, float* vb, int lane, uint32_t lt = 0) {
+                                                  float* va, float* vb, int lane, uint32_t lt = 0, uint64_t* stamp_acc = nullptr,
+                                                  uint64_t* stamp_last = nullptr) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
@@ -661,6 +671,7 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   bf16x8 pre[5];
   prefetch_tile0(img + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
   activate_bf16<true, WIDE>(accA, curA, h, tab, lt);
+  SO3X_FP_STAMP(4);  // layer 0 of both tiles + activation A, layer 0
   const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
 #pragma unroll
   for (int l = 1; l < 4; l++) {
@@ -680,6 +691,7 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
     activate_bf16<true, WIDE>(accA, curA, h, tab, lt);        // activation A, layer l
 #endif
   }
+  SO3X_FP_STAMP(5);  // the six 15-MFMA stages
   f32x16 lastA[1], lastB[1];
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
