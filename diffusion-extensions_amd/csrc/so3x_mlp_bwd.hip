@@ -1027,6 +1027,51 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
     char* my_img = fimg_all + wid * FIMG_BYTES;
     FimgStoreLane SL = fimg_store_lane(col);
     Z33h zb[2];  // STASHED: the two rolling pre-activation buffers
+    // STASHED: the round's timestep and its three dout values are fetched a round ahead (tt_pf, dp_pf): phase stamps showed a
+    // quarter of a round going by before its first image store -- an HBM round trip for t and dout on the critical path
+    // (then the table row addressed by t), with the rotation held in nine registers for five layers on top
+    auto sample_of = [&](int64_t rd_, bool* live_) {
+      const int64_t tile_ = rd_ * nchain + (int64_t)blockIdx.x * 4 + wid, s_ = tile_ * 32 + col;
+      *live_ = tile_ < ntiles && s_ < n;
+      return *live_ ? s_ : n - 1;
+    };
+    int64_t tt_pf = 0;
+    float dp_pf[3] = {0.f, 0.f, 0.f};  // (a 6-wide head fetches its other three on the spot)
+    if constexpr (STASHED) {
+      bool lv0;
+      const int64_t s0 = sample_of(0, &lv0);
+      tt_pf = t[s0 * t_stride];
+      if (h == 0) { dp_pf[0] = dout[s0 * nout]; dp_pf[1] = dout[s0 * nout + 1]; dp_pf[2] = dout[s0 * nout + 2]; }
+    }
+    // Everything that goes into an image is kept as packed bf16 pairs (the exact MFMA operand bits).
+    uint32_t pdz[17], ph[17];
+    float dnext[33];  // silu'(Z_{l-1}) of the layer about to be differentiated
+    // STASHED: the head of a round -- dZ_4 from the prefetched dout, H_4 = silu(Z_3) and silu'(Z_3) from buffer 0, the fetch
+    // of z1 -- runs behind the previous round's LAST first barrier, while the dW waves take the layer-0 products (the chain
+    // wave had nothing to do there: 2 k cycles per round at that barrier, and as many for this head at the top of the next)
+    auto head_of_round = [&](int64_t rd_) {
+      bool live_;
+      const int64_t sc_ = sample_of(rd_ < rounds ? rd_ : rounds - 1, &live_);
+      const float lv_ = live_ ? 1.0f : 0.0f;
+      const int64_t tile_ = rd_ * nchain + (int64_t)blockIdx.x * 4 + wid;
+      const char* ztile_ = zstash + (size_t)(tile_ < ntiles ? tile_ : ntiles - 1) * ZSTASH_TILE;
+#pragma unroll
+      for (int r = 0; r < 17; r++) pdz[r] = 0u;
+      if (h == 0) {  // dZ_4 = dout in K slots / image columns 0..5 of the lower half (head_of_row)
+        pdz[0] = pack_bf16x2(dp_pf[0] * lv_, dp_pf[1] * lv_);
+        pdz[1] = pack_bf16x2(dp_pf[2] * lv_, nout == 6 ? dout[sc_ * 6 + 3] * lv_ : 0.0f);
+        if (nout == 6) pdz[2] = pack_bf16x2(dout[sc_ * 6 + 4] * lv_, dout[sc_ * 6 + 5] * lv_);
+      }
+      silu_pass<PREC>(zb[0], h, ph, dnext);       // H_4 = silu(Z_3), and silu'(Z_3)
+      zstash_load_layer(ztile_, lane, 1, zb[0]);  // z1: used two layers from now
+    };
+    if constexpr (STASHED) {
+      const int64_t tile0 = (int64_t)blockIdx.x * 4 + wid;
+      const char* zt0 = zstash + (size_t)(tile0 < ntiles ? tile0 : ntiles - 1) * ZSTASH_TILE;
+      zstash_load_layer(zt0, lane, 3, zb[0]);
+      zstash_load_layer(zt0, lane, 2, zb[1]);
+      head_of_round(0);
+    }
     for (int64_t rd = 0; rd < rounds; rd++) {
       asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per round: no hoisting of the ~90 store addresses
       const int64_t tile = rd * nchain + (int64_t)blockIdx.x * 4 + wid;
@@ -1040,8 +1085,8 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       Z33h z[STASHED ? 1 : 4];
       f32x16 dh[3];
       float x[9];
-      load_rot9(R, sc, x);
-      const int64_t tt = t[sc * t_stride];
+      if constexpr (!STASHED) load_rot9(R, sc, x);  // STASHED: fetched behind layer 1, stored with the layer-0 image
+      const int64_t tt = STASHED ? tt_pf : t[sc * t_stride];
       const float lv = live ? 1.0f : 0.0f;  // dead columns: dZ_4 = 0, hence every dZ_l = 0 and no contribution to any dW sum
       const char* ztile = STASHED ? zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE : nullptr;
       // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them), fetched now, stored five layers
@@ -1050,7 +1095,6 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
 #pragma unroll
       for (int i = 0; i < 6; i++) hq[i] = h0_tab[(size_t)tt * 12 + 6 * h + i];
       if constexpr (STASHED) {
-        if (rd == 0) { zstash_load_layer(ztile, lane, 3, zb[0]); zstash_load_layer(ztile, lane, 2, zb[1]); }
       } else {
         f32x16 a3[3];
         Tile<PREC> cur;
@@ -1065,21 +1109,15 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       }
       // ---- backward, software-pipelined one layer ahead so that the chain waves work while the dW waves
       //      consume the images:   [write images of layer l] B1 [dH_l, dZ_{l-1}, silu pass for layer l-1] B2
-      // Everything that goes into an image is kept as packed bf16 pairs (the exact MFMA operand bits).
-      uint32_t pdz[17], ph[17];
-      float dnext[33];  // silu'(Z_{l-1}) of the layer about to be differentiated
+      if constexpr (!STASHED) {
 #pragma unroll
-      for (int r = 0; r < 17; r++) pdz[r] = 0u;
-      if (h == 0) {  // dZ_4 = dout in K slots / image columns 0..5 of the lower half (head_of_row)
-        const float* dp = dout + sc * nout;
-        pdz[0] = pack_bf16x2(dp[0] * lv, dp[1] * lv);
-        pdz[1] = pack_bf16x2(dp[2] * lv, nout == 6 ? dp[3] * lv : 0.0f);
-        if (nout == 6) pdz[2] = pack_bf16x2(dp[4] * lv, dp[5] * lv);
-      }
-      if constexpr (STASHED) {
-        silu_pass<PREC>(zb[0], h, ph, dnext);  // H_4 = silu(Z_3), and silu'(Z_3)
-        zstash_load_layer(ztile, lane, 1, zb[0]);   // z1: used two layers from now
-      } else {
+        for (int r = 0; r < 17; r++) pdz[r] = 0u;
+        if (h == 0) {  // dZ_4 = dout in K slots / image columns 0..5 of the lower half (head_of_row)
+          const float* dp = dout + sc * nout;
+          pdz[0] = pack_bf16x2(dp[0] * lv, dp[1] * lv);
+          pdz[1] = pack_bf16x2(dp[2] * lv, nout == 6 ? dp[3] * lv : 0.0f);
+          if (nout == 6) pdz[2] = pack_bf16x2(dp[4] * lv, dp[5] * lv);
+        }
         silu_pass<PREC, true>(z[3], h, ph, dnext, lv);
       }
 #pragma unroll
@@ -1131,9 +1169,18 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
             if (l == 4) zstash_load_layer(ztile, lane, 0, zb[1]);
             if (l == 3) zstash_load_layer(nz, lane, 3, zb[0]);
             if (l == 2) zstash_load_layer(nz, lane, 2, zb[1]);
+            if (l == 2) {  // next round's timestep and dout
+              bool nl;
+              const int64_t sn = sample_of(rd + 1 < rounds ? rd + 1 : rd, &nl);
+              tt_pf = t[sn * t_stride];
+              if (h == 0) { dp_pf[0] = dout[sn * nout]; dp_pf[1] = dout[sn * nout + 1]; dp_pf[2] = dout[sn * nout + 2]; }
+            }
+            if (l == 1) load_rot9(R, sc, x);
           } else {
             if (l > 1) silu_pass<PREC, true>(z[l - 2], h, ph, dnext, lv);     // H_{l-1} = silu(Z_{l-2}), silu'(Z_{l-2})
           }
+        } else if constexpr (STASHED) {
+          head_of_round(rd + 1);  // the next round's head, while the dW waves take this round's layer-0 products
         }
         __syncthreads();  // B2: the dW waves are done with the images
       }
