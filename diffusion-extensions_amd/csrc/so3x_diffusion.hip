@@ -38,14 +38,21 @@ namespace {
 // t_draw != nullptr: the timesteps are not given but drawn here -- t_i = floor(T * w_i / 2^32) from the fourth word of the
 // sample's Philox block (the other three feed the noise), written to t_draw for the kernels that follow; SO3Diffusion.forward's
 // `t = randint(0, T, (b,))` (diffusion.py:373) keyed, like the noise, by the global sample index.
-__global__ void __launch_bounds__(kBlock, 6)
+// LEAN: the training step's form (noise drawn here: no noise_in, no explicit axes / uniforms) as its own instantiation at
+// 64 registers -- eight waves per SIMD hold all 8,192 tiles of a 2^19-sample step at once; at the generic kernel's 67
+// registers (seven waves) the last eighth of the tiles ran as a second round: 23.7 -> 20.1 us (tools/ab/ab_qsample.py).
+template <bool LEAN>
+__global__ void __launch_bounds__(kBlock, LEAN ? 8 : 6)
 k_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q,
                   const uint16_t* __restrict__ guide_q, const float* __restrict__ x0,
-                  const int64_t* __restrict__ t, int64_t* __restrict__ t_draw, int quirk_col0, const float* __restrict__ noise_in,
-                  const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
+                  const int64_t* __restrict__ t, int64_t* __restrict__ t_draw, int quirk_col0, const float* __restrict__ noise_in_,
+                  const float* __restrict__ axes_, const float* __restrict__ unif_, uint64_t seed, uint64_t rng_offset,
                   const int64_t* __restrict__ rng_offset_dev, int64_t index_base, float* __restrict__ x_t,
                   float* __restrict__ target, float* __restrict__ noise_out, int64_t n) {
   __shared__ __attribute__((aligned(16))) float sm[kBlock / kWave][kWave * 9];
+  const float* noise_in = LEAN ? nullptr : noise_in_;
+  const float* axes = LEAN ? nullptr : axes_;
+  const float* unif = LEAN ? nullptr : unif_;
   if (rng_offset_dev) rng_offset += (uint64_t)rng_offset_dev[0];  // device-resident part of the counter (hipGraph replays)
   float* wl = sm[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
@@ -357,8 +364,12 @@ int launch_q_sample_target(hipStream_t s, const float* sched, int T, const float
   const int64_t nt64 = (n + kWave - 1) / kWave;
   int64_t want = (nt64 + 3) / 4;   // one tile per wave
   if (want > (1 << 20)) want = 1 << 20;
-  hipLaunchKernelGGL(k_q_sample_target, dim3((unsigned)want), dim3(kBlock), 0, s, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0,
-                     noise_in, axes, unif, seed, rng_offset, rng_offset_dev, index_base, x_t, target, noise_out, n);
+  if (!noise_in && !axes)
+    hipLaunchKernelGGL(k_q_sample_target<true>, dim3((unsigned)want), dim3(kBlock), 0, s, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0,
+                       noise_in, axes, unif, seed, rng_offset, rng_offset_dev, index_base, x_t, target, noise_out, n);
+  else
+    hipLaunchKernelGGL(k_q_sample_target<false>, dim3((unsigned)want), dim3(kBlock), 0, s, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0,
+                       noise_in, axes, unif, seed, rng_offset, rng_offset_dev, index_base, x_t, target, noise_out, n);
   return check_launch();
 }
 }  // namespace so3x
