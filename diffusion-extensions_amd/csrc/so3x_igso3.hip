@@ -152,6 +152,12 @@ __device__ __attribute__((noinline)) float logp_identity_f64(float e) {
 #ifndef SO3X_LPS_NT
 #define SO3X_LPS_NT 1
 #endif
+// Waves per SIMD asked of the instantiation without the dense gradient: 6 (80 registers, no spill).  Measured on one box
+// (tools/ab/ab_logprob.py), 2^20 / 2^24 evaluations: generic kernel at 5 waves 61 % / 72 % of 8 TB/s; this instantiation at
+// 5: 64.2 / 72.6, at 6: 66.4 / 77.6, at 7: 65.7 / 77.5, at 8 (16 B of scratch): 62.0 / 71.6.
+#ifndef SO3X_LPS_OCC
+#define SO3X_LPS_OCC 6
+#endif
 // Non-temporal STORES of the outputs: +1-3 % (2^20: 60.4 -> 61.2 % of 8 TB/s, 2^24: 69.9 -> 71.9 %, tools/ab/ab_logprob.py).
 // Non-temporal LOADS of the inputs: -8 % -- back-to-back calls on the same rotations find them in the memory-side cache.
 #ifndef SO3X_LPS_NTL
@@ -167,9 +173,11 @@ __device__ __attribute__((noinline)) float logp_identity_f64(float e) {
 #else
 #define SO3X_LPS_STORE(v, p) (*(p) = (v))
 #endif
-__global__ void __launch_bounds__(kBlock, 5)
+template <bool GRAD>  // GRAD: the dense d logp / dR output as well (rare); without it the kernel is its own, leaner instantiation
+__global__ void __launch_bounds__(kBlock, GRAD ? 5 : SO3X_LPS_OCC)
 k_logprob_score(const float* __restrict__ R, const float* __restrict__ eps, int64_t eps_stride, float* __restrict__ logp,
-                float* __restrict__ score_vec, float* __restrict__ grad_R, int64_t n) {
+                float* __restrict__ score_vec, float* __restrict__ grad_R_, int64_t n) {
+  float* grad_R = GRAD ? grad_R_ : nullptr;
   // wave-private staging: every wave streams its own 64-sample tiles, no workgroup barrier
   __shared__ __attribute__((aligned(16))) float sm[kBlock / kWave][kWave * 9];
   float* wl = sm[threadIdx.x >> 6];
@@ -281,8 +289,10 @@ int so3x_igso3_logprob_score(so3x_stream_t s, const float* R, const float* eps, 
   const int64_t nt64 = (n + kWave - 1) / kWave;
   int64_t want = (nt64 + 3) / 4;
   if (want > (1 << 20)) want = 1 << 20;
-  hipLaunchKernelGGL(k_logprob_score, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, R, eps,
-                     eps_stride, logp, score_vec, grad_R, n);
+  if (grad_R)
+    hipLaunchKernelGGL(k_logprob_score<true>, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, R, eps, eps_stride, logp, score_vec, grad_R, n);
+  else
+    hipLaunchKernelGGL(k_logprob_score<false>, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s, R, eps, eps_stride, logp, score_vec, grad_R, n);
   return check_launch();
 }
 
