@@ -521,7 +521,8 @@ def test_chain_bf16_kernel_forms_agree(mods, net, monkeypatch):
     """The shipped bf16 chain kernel (lane-replicated SiLU table whose address is the convert's result, stages laid out MFMA
     gap by MFMA gap) against its other forms, selected by the launcher's A/B switches: the 2 KB table with shift-add addressing
     must give the SAME BITS (same index, same entry, same multiply-add -- only the addressing differs); one tile after the
-    other instead of the paired stream likewise (same arithmetic per tile); Cody-Waite instead of hardware sine / cosine
+    other instead of the paired stream likewise (same arithmetic per tile), and so must the reverse step's inverse-CDF search
+    on global memory instead of the per-wave LDS record the kernel stages by LDS-DMA; Cody-Waite instead of hardware sine / cosine
     agrees to the trigonometry's 1e-6 per step.  Ragged sizes cover partial waves and a partial last workgroup."""
     B = mods["B"]
     proc = mods["diff"].SO3Diffusion(net, timesteps=1000).to(DEV)
@@ -530,7 +531,7 @@ def test_chain_bf16_kernel_forms_agree(mods, net, monkeypatch):
     for n in (1, 63, 65, 4100, 70000):
         x = mods["util"].quat_to_rmat(torch.randn(n, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n)))
         run = lambda: B.p_sample_chain(params, proc._sched, trap_p, x, 420, 12, seed=3, rng_offset=5, precision=1)  # noqa: E731
-        for k in ("SO3X_AB_TAB", "SO3X_AB_PAIR", "SO3X_AB_TRIG", "SO3X_AB_BLOCK"):
+        for k in ("SO3X_AB_TAB", "SO3X_AB_PAIR", "SO3X_AB_TRIG", "SO3X_AB_BLOCK", "SO3X_AB_CDF"):
             monkeypatch.delenv(k, raising=False)
         base = run()
         assert torch.isfinite(base).all()
@@ -543,6 +544,9 @@ def test_chain_bf16_kernel_forms_agree(mods, net, monkeypatch):
         monkeypatch.setenv("SO3X_AB_BLOCK", "256")
         assert torch.equal(run(), base), n
         monkeypatch.delenv("SO3X_AB_BLOCK")
+        monkeypatch.setenv("SO3X_AB_CDF", "global")   # inverse-CDF search on global memory instead of the LDS-staged record
+        assert torch.equal(run(), base), n
+        monkeypatch.delenv("SO3X_AB_CDF")
         monkeypatch.setenv("SO3X_AB_TRIG", "cw")
         d = (run() - base).abs().reshape(n, -1).max(1).values
         assert float(d.median()) < 2e-5 and float(d.quantile(0.99) if n > 100 else d.max()) < 2e-3, (n, float(d.max()))
