@@ -585,6 +585,9 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
 #ifndef SO3X_STAGE_SCHED
 #define SO3X_STAGE_SCHED 1
 #endif
+#ifndef SO3X_CHAIN_PRIO
+#define SO3X_CHAIN_PRIO 1
+#endif
 // One stage of the paired stream laid out gap by gap: the 15 MFMAs of tile X's layer, and in the gap behind each of them a
 // slice of tile Y's activation -- table lookups for about three values, the multiply-adds of the lookups issued two gaps
 // earlier, the packing of finished pairs -- and ONE weight-fragment read (five MFMAs ahead: the fragments of output tiles 1
@@ -673,6 +676,14 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   activate_bf16<true, WIDE>(accA, curA, h, tab, lt);
   SO3X_FP_STAMP(4);  // layer 0 of both tiles + activation A, layer 0
   const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
+  // Wave priority by phase (s_setprio; SO3X_CHAIN_PRIO = 0 for the A/B): the six MFMA stages at 3, the output-layer stages
+  // at 1, everything else of a step -- its top, layer 0, the all-vector reverse step -- at 0.  The two waves of a SIMD run
+  // the same program at equal priority and the arbiter interleaved them instruction by instruction; with the stages on top a
+  // wave in its stages keeps the matrix pipe fed and its partner's vector work fills what is left: 5.97 -> 5.51 ms per 100
+  // steps.  Any split helped (reverse step on top: 5.82; network on top: 5.78; a fixed winner per SIMD: nothing).
+#if SO3X_CHAIN_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     const char* wl = img + (size_t)frag_hidden<PREC, VAR>(l) * FB;
@@ -692,6 +703,9 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
 #endif
   }
   SO3X_FP_STAMP(5);  // the six 15-MFMA stages
+#if SO3X_CHAIN_PRIO
+  __builtin_amdgcn_s_setprio(1);
+#endif
   f32x16 lastA[1], lastB[1];
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
@@ -699,6 +713,9 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   activate_bf16<true, WIDE>(accB, curB, h, tab, lt);            // activation B, layer 3
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
+#if SO3X_CHAIN_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = lastA[0][k]; vb[k] = lastB[0][k]; }
 }
