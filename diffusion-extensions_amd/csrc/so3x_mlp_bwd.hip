@@ -425,16 +425,20 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
   write_slab(slabs, acc, wid, i, h, n_out);
 }
 
-// 32 parameters x 32 slab groups per block of 1024 threads: coalesced 128-B reads, every thread's (at most 8) loads
-// independent and in flight together -- the kernel is a latency chain, not a bandwidth problem (18 MB) -- fixed summation
-// order (deterministic).  (8 groups of 256 threads took 9.5 us for 256 slabs; this takes ~5.)
-constexpr int RED_GROUPS = 32;
+// RED_PPB parameters x RED_GROUPS slab groups per block of 1024 threads: coalesced reads, every thread's loads independent
+// and in flight together -- the kernel is a latency chain, not a bandwidth problem (18 MB) -- fixed summation order
+// (deterministic).  64 x 16: 272 workgroups, ONE round on the chip (two 1024-thread workgroups per CU); 32 x 32 was 543
+// workgroups = one round and a 31-workgroup tail.
+#ifndef SO3X_RED_PPB
+#define SO3X_RED_PPB 64
+#endif
+constexpr int RED_PPB = SO3X_RED_PPB, RED_GROUPS = 1024 / RED_PPB;
 __global__ void __launch_bounds__(1024)
 k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
              const float* __restrict__ gscale = nullptr) {
-  __shared__ float part[RED_GROUPS][33];
-  const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int idx = blockIdx.x * 32 + p;
+  __shared__ float part[RED_GROUPS][RED_PPB + 1];
+  const int p = threadIdx.x % RED_PPB, g = threadIdx.x / RED_PPB;
+  const int idx = blockIdx.x * RED_PPB + p;
   float s = 0.0f;
   if (idx < np) {
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -1215,7 +1219,7 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
   else
     hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
                        emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(1024), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
                      gscale);
   return check_launch();
 }
@@ -1282,7 +1286,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
       hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs, nout);
     else
       hipLaunchKernelGGL(k_bwd_dw_bf16, dim3(g2), dim3(512), DW_LDS, s, (const __bf16*)stash, nc, slabs, nout);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + 31) / 32), dim3(1024), 0, s, (const float*)slabs, g2, dparams,
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, (const float*)slabs, g2, dparams,
                        c0 > 0 ? 1 : 0, nparams(nout));
   }
   return check_launch();
