@@ -302,13 +302,18 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
   }
 }
 
-// A/B switches of the chain kernel, read once from the environment by the launcher (tools/ab/ab_chain.py interleaves the
-// variants in one process; not part of the ABI): SO3X_AB_TRIG=cw forces the Cody-Waite sine / cosine in the bf16 kernel,
-// SO3X_AB_BLOCK=<threads> the workgroup size (bf16 kernel, multiple of 64 up to 768).
+// The product launcher takes no switch from anywhere but its arguments: ONE bf16 form (hardware sine / cosine, paired stream,
+// lane-replicated table, LDS-staged CDF record, 8-wave workgroups) and the fp32 parity form.  -DSO3X_AB_BUILD (the second
+// library libso3x_ab.so that tools/ab and tests/test_gpu_parity.py::test_chain_bf16_kernel_forms_agree load explicitly; never the
+// library the package loads) adds the other forms behind environment switches read per launch: SO3X_AB_TRIG=cw forces the
+// Cody-Waite sine / cosine in the bf16 kernel, SO3X_AB_PAIR=0 one tile after the other, SO3X_AB_TAB=narrow the 2 KB table,
+// SO3X_AB_CDF=global the search on global memory, SO3X_AB_BLOCK=<threads> the workgroup size (multiple of 64 up to 512).
+#ifdef SO3X_AB_BUILD
 inline int ab_env(const char* name, const char* value) {
   const char* e = getenv(name);
   return e && !strcmp(e, value);
 }
+#endif
 
 template <int PREC, bool FAST, bool PAIR, bool WIDE = false>
 int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
@@ -317,10 +322,16 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   constexpr int IMG = image_bytes<PREC, CHAIN>() + (WIDE ? kWideTabBytes + kChainKnotsBytes + kChainRowBufBytes : 0);
   int max_blocks = 0;
   int threads = chain_threads_default<PREC>();
+  bool staged_cdf = WIDE;
+#ifdef SO3X_AB_BUILD
   if (PREC == SO3X_PREC_BF16 && getenv("SO3X_AB_BLOCK")) threads = atoi(getenv("SO3X_AB_BLOCK"));
   if (threads < 64 || threads > chain_threads<PREC>() || threads % 64) return SO3X_ERR_INVALID_ARG;
-  static PerDevice residents[9];  // one cache per workgroup size (A/B)
+  if (ab_env("SO3X_AB_CDF", "global")) staged_cdf = false;
+  static PerDevice residents[9];  // one cache per workgroup size
   PerDevice& resident = residents[threads / 64];
+#else
+  static PerDevice resident;
+#endif
   if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST, PAIR, WIDE>), threads, IMG, &max_blocks)) return rc;
   const int64_t nchunks = (n + 63) / 64;
   const int wpb = threads / 64;
@@ -329,7 +340,7 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
   hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n,
-                     (WIDE && !ab_env("SO3X_AB_CDF", "global")) ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr);
+                     staged_cdf ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr);
   return check_launch();
 }
 
@@ -339,9 +350,11 @@ int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* 
                  uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
 #define SO3X_CHAIN_ARGS s, ws, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n
   if constexpr (PREC == SO3X_PREC_BF16) {
-    if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false, true>(SO3X_CHAIN_ARGS);
+#ifdef SO3X_AB_BUILD
+    if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false, true, true>(SO3X_CHAIN_ARGS);
     if (ab_env("SO3X_AB_PAIR", "0")) return launch_chain_v<PREC, true, false>(SO3X_CHAIN_ARGS);
     if (ab_env("SO3X_AB_TAB", "narrow")) return launch_chain_v<PREC, true, true>(SO3X_CHAIN_ARGS);
+#endif
     return launch_chain_v<PREC, true, true, true>(SO3X_CHAIN_ARGS);
   } else {
     return launch_chain_v<PREC, false, false>(SO3X_CHAIN_ARGS);

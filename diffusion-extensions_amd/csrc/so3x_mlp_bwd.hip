@@ -1370,6 +1370,7 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
   la.dscale = (float)(2.0 / (3.0 * (double)n));
   la.inv_count = 1.0 / (3.0 * (double)n);
   const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
+#ifdef SO3X_AB_BUILD  /* libso3x_ab.so only (tools/ab/ab_trainfwd.py); the product launcher reads no environment */
   const char* ab = getenv("SO3X_AB_TRAINFWD");
   if (ab && !strcmp(ab, "fused")) {
     // A/B (SO3X_AB_TRAINFWD=fused): noise draw + q_sample + target + network forward + stash + MSE and its gradient as ONE
@@ -1385,6 +1386,7 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
                        (char*)zstash, n, la);
     return check_launch();
   }
+#endif
   // the noising kernel (six waves per SIMD: latency-bound gathers), then the network forward with the MSE epilogue
   float* target = reinterpret_cast<float*>(ws + L.target);
   rc = launch_q_sample_target(st, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0, nullptr, axes, unif, seed, rng_offset,

@@ -2,6 +2,8 @@
 Python host layer -> ctypes -> the C ABI of libso3x.so and compares against the CPU
 oracle (oracle/) and the golden vectors captured from the reference.
 Gates G1-G5: SURVEY.md section 8c."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -517,24 +519,55 @@ def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
     assert abs(np.median(err[lanes < 32]) - np.median(err[lanes >= 32])) < 2e-3 * max(1.0, coef[1])
 
 
+def _ab_chain(proc, trap_p, params, x, t_start, n_steps, seed, rng_offset):
+    """so3x_p_sample_chain (bf16) of the A/B build libso3x_ab.so through its raw C ABI.  The A/B build is the same ABI compiled
+    with -DSO3X_AB_BUILD: the only library whose launcher reads the SO3X_AB_* environment switches (csrc/so3x_diffusion.hip);
+    the library the package loads has ONE bf16 form and no getenv."""
+    import ctypes as C
+    from so3x import backend as B
+    path = os.path.join(os.path.dirname(B.LIB_PATH), "libso3x_ab.so")
+    if not hasattr(_ab_chain, "lib"):
+        _ab_chain.lib = C.CDLL(path)
+    lib = _ab_chain.lib
+    lib.so3x_p_sample_workspace_bytes.restype = C.c_size_t
+    T = proc._sched.shape[1]
+    nb = lib.so3x_p_sample_workspace_bytes(C.c_int(T), C.c_int(1))
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    out = torch.empty_like(x)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = lib.so3x_p_sample_chain(C.c_void_p(torch.cuda.current_stream().cuda_stream), P(params), P(proc._sched), C.c_int(T), P(trap_p),
+                                 P(proc._guide_p), P(x), P(out), C.c_int(t_start), C.c_int(n_steps), None, None, C.c_uint64(seed),
+                                 C.c_uint64(rng_offset), C.c_int64(0), C.c_int64(x.shape[0]), C.c_int(1), P(ws), C.c_size_t(nb))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out
+
+
+_AB_KEYS = ("SO3X_AB_TAB", "SO3X_AB_PAIR", "SO3X_AB_TRIG", "SO3X_AB_BLOCK", "SO3X_AB_CDF")
+
+
 def test_chain_bf16_kernel_forms_agree(mods, net, monkeypatch):
     """The shipped bf16 chain kernel (lane-replicated SiLU table whose address is the convert's result, stages laid out MFMA
-    gap by MFMA gap) against its other forms, selected by the launcher's A/B switches: the 2 KB table with shift-add addressing
-    must give the SAME BITS (same index, same entry, same multiply-add -- only the addressing differs); one tile after the
-    other instead of the paired stream likewise (same arithmetic per tile), and so must the reverse step's inverse-CDF search
-    on global memory instead of the per-wave LDS record the kernel stages by LDS-DMA; Cody-Waite instead of hardware sine / cosine
-    agrees to the trigonometry's 1e-6 per step.  Ragged sizes cover partial waves and a partial last workgroup."""
+    gap by MFMA gap) against its other forms, which exist only in the A/B build (libso3x_ab.so, loaded here by path): the 2 KB
+    table with shift-add addressing must give the SAME BITS (same index, same entry, same multiply-add -- only the addressing
+    differs); one tile after the other instead of the paired stream likewise (same arithmetic per tile), and so must the reverse
+    step's inverse-CDF search on global memory instead of the per-wave LDS record the kernel stages by LDS-DMA; Cody-Waite
+    instead of hardware sine / cosine agrees to the trigonometry's 1e-6 per step.  The product library (no switches) must give
+    the bits of the A/B build's default form AND must not react to the switches.  Ragged sizes cover partial waves and a
+    partial last workgroup."""
     B = mods["B"]
     proc = mods["diff"].SO3Diffusion(net, timesteps=1000).to(DEV)
     _, trap_p = proc._tables()
     params = net.flat_params_nograd()
     for n in (1, 63, 65, 4100, 70000):
         x = mods["util"].quat_to_rmat(torch.randn(n, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n)))
-        run = lambda: B.p_sample_chain(params, proc._sched, trap_p, x, 420, 12, seed=3, rng_offset=5, precision=1)  # noqa: E731
-        for k in ("SO3X_AB_TAB", "SO3X_AB_PAIR", "SO3X_AB_TRIG", "SO3X_AB_BLOCK", "SO3X_AB_CDF"):
+        run = lambda: _ab_chain(proc, trap_p, params, x, 420, 12, 3, 5)  # noqa: E731
+        for k in _AB_KEYS:
             monkeypatch.delenv(k, raising=False)
         base = run()
         assert torch.isfinite(base).all()
+        shipped = B.p_sample_chain(params, proc._sched, trap_p, x, 420, 12, seed=3, rng_offset=5, precision=1)
+        assert torch.equal(shipped, base), n
         monkeypatch.setenv("SO3X_AB_TAB", "narrow")
         assert torch.equal(run(), base), n
         monkeypatch.delenv("SO3X_AB_TAB")
@@ -550,7 +583,42 @@ def test_chain_bf16_kernel_forms_agree(mods, net, monkeypatch):
         monkeypatch.setenv("SO3X_AB_TRIG", "cw")
         d = (run() - base).abs().reshape(n, -1).max(1).values
         assert float(d.median()) < 2e-5 and float(d.quantile(0.99) if n > 100 else d.max()) < 2e-3, (n, float(d.max()))
+        # the product library has no such switch: same bits with the variable exported
+        assert torch.equal(B.p_sample_chain(params, proc._sched, trap_p, x, 420, 12, seed=3, rng_offset=5, precision=1), base), n
         monkeypatch.delenv("SO3X_AB_TRIG")
+
+
+@pytest.mark.parametrize("t_start", [999, 960])
+def test_chain_bf16_hardware_trig_at_the_head_of_the_chain(mods, net, monkeypatch, t_start):
+    """the hardware sine / cosine (v_sin / v_cos behind v_fract range reduction, csrc/so3x_math.hpp) against
+    Cody-Waite where the Rodrigues angle is LARGEST: at t >= 950 the reverse step scales a matrix log by
+    sqrt_recip_alphas_cumprod up to 20291 (reference diffusion.py:291-297, util.py:349-361), i.e. arguments of up to ~1e4
+    revolutions go through the range reduction.  Ten steps from t = 999 (and from 960) with the two trigonometries on the same
+    state and noise, step by step so that the comparison is of ONE step (the map itself amplifies differences of the state by
+    up to 2e4 there, which is the reference's conditioning, not the trigonometry's).
+
+    Tolerance: v_fract(theta / 2 pi) keeps the fraction of a 24-bit float: at theta = 6.4e4 rad (1e4 revolutions) one ulp of
+    the argument is 2^-10 of a revolution... for BOTH forms -- the product theta = scale * |log| is rounded to fp32 before
+    either reduction sees it, so the two can differ only by their own reduction error: Cody-Waite ~1e-7 absolute, v_fract +
+    v_sin ~2^-23 of a revolution x 2 pi = 7.5e-7 of angle plus the 1e-6 of v_sin itself.  Gate: median 5e-6, 99th percentile
+    2e-4 (a sample near the log's pi branch amplifies through 1 / (pi - omega)), per step."""
+    proc = mods["diff"].SO3Diffusion(net, timesteps=1000).to(DEV)
+    _, trap_p = proc._tables()
+    params = net.flat_params_nograd()
+    n = 4096
+    x = mods["util"].quat_to_rmat(torch.randn(n, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(77)))
+    for k in _AB_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    for s in range(10):
+        t = t_start - s
+        hw = _ab_chain(proc, trap_p, params, x, t, 1, 3, 5)
+        monkeypatch.setenv("SO3X_AB_TRIG", "cw")
+        cw = _ab_chain(proc, trap_p, params, x, t, 1, 3, 5)
+        monkeypatch.delenv("SO3X_AB_TRIG")
+        assert torch.isfinite(hw).all() and torch.isfinite(cw).all()
+        d = (hw - cw).abs().reshape(n, -1).max(1).values
+        assert float(d.median()) < 5e-6 and float(d.quantile(0.99)) < 2e-4, (t, float(d.median()), float(d.quantile(0.99)), float(d.max()))
+        x = hw
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

@@ -38,6 +38,25 @@ def test_no_oracle_or_cpu_fallback_in_product():
                 assert "oracle" not in src.lower(), f"{f} mentions the oracle"
 
 
+def test_product_library_has_no_environment_switches():
+    """libso3x.so reads no environment variable (getenv races with setenv, and an exported variable must never change
+    arithmetic) and ships ONE bf16 form of the chain kernel; the A/B forms live in libso3x_ab.so (-DSO3X_AB_BUILD), which
+    only tools/ab and one parity test load by path."""
+    dyn = subprocess.run(["nm", "-D", "--undefined-only", B.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in dyn
+    syms = subprocess.run(["nm", B.LIB_PATH], capture_output=True, text=True, check=True).stdout  # mangled: I<PREC>E... = template args
+    stubs = [l for l in syms.splitlines() if "__device_stub__k_p_sample_chainI" in l]
+    assert len(stubs) == 2, stubs   # <fp32 parity form>, <bf16 product form>
+    assert sum("k_p_sample_chainILi1E" in l for l in stubs) == 1
+    assert not any("k_train_fwdI" in l for l in syms.splitlines())   # the fused noising + forward experiment is A/B-only too
+    ab = os.path.join(os.path.dirname(B.LIB_PATH), "libso3x_ab.so")
+    assert os.path.exists(ab), "make -C csrc builds the A/B library beside the product one"
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", ab], capture_output=True, text=True, check=True).stdout
+    for f in os.listdir(os.path.join(PKG, "so3x")):   # and the package never loads it
+        if f.endswith(".py"):
+            assert "libso3x_ab" not in open(os.path.join(PKG, "so3x", f)).read(), f
+
+
 def test_schedule_matches_golden(golden):
     g = golden["schedule"]
     for T in (100, 1000):

@@ -1,7 +1,7 @@
 """A/B of the headline kernel's variants, interleaved in ONE process (cdna_hip_programming.md 5.4 rule 24):
    python tools/ab/ab_chain.py [rounds=7] [out.json]
-Variants are selected per launch through the launcher's environment switches (csrc/so3x_diffusion.hip) or by swapping in an
-older build of the library (build/libso3x_r02a.so, if present):
+Variants are selected per launch through the environment switches of the A/B build (libso3x_ab.so = csrc/so3x_diffusion.hip
+compiled with -DSO3X_AB_BUILD; the product library has none) or by swapping in an older build of the library (build/libso3x_r02a.so, if present):
    base      bf16 chain kernel as shipped: 2-instruction SiLU from the lane-replicated LDS table, hardware sine / cosine, the
              wave's two tiles as one software-pipelined stream, 8-wave workgroups
    narrow_tab SO3X_AB_TAB=narrow the 2 KB table with its shift-add addressing (3 instructions; bit-identical results)
@@ -42,7 +42,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "build", "libso3x_*.so"))):
     elif not name.startswith("bwd"):
         VARIANTS["lib_" + name] = {"LIB": path}
 import ctypes as C
-_libs = {None: C.CDLL(B.LIB_PATH)}
+_libs = {None: C.CDLL(os.path.join(os.path.dirname(B.LIB_PATH), "libso3x_ab.so"))}  # the A/B build: the only one with the switches
 _cur = [None]
 
 

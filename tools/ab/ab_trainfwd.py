@@ -1,6 +1,8 @@
 """A/B of the training step's forward half inside the replayed graph: the two-launch form (default: noising kernel, then forward
 with the MSE epilogue) against the fused noising + forward kernel (SO3X_AB_TRAINFWD=fused), interleaved rounds, 2^19 samples, bf16.
-     python tools/ab/ab_trainfwd.py [rounds=7] [out.json]"""
+     LD_PRELOAD=diffusion-extensions_amd/libso3x_ab.so python tools/ab/ab_trainfwd.py [rounds=7] [out.json]
+The switch exists only in the A/B build (libso3x_ab.so, -DSO3X_AB_BUILD); preloading it makes the operator library bind the
+so3x_* entry points to it instead of the product library, which reads no environment."""
 import sys, os, json, statistics
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
