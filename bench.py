@@ -7,15 +7,21 @@ synthetic random-quaternion inputs, seed-0 default-init weights, in-kernel Philo
 One "step" = one p_sample application to the whole batch; K steps run as consecutive
 timesteps T-1, T-2, ... (wrapping after t = 0) inside the chain-resident kernel.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), and as the plain command above -- then this process starts the N ranks itself as
+child processes (before anything here imports torch or touches a GPU; it never does), passes rank 0's JSON line through and
+exits with the worst child's code.
 
 Prints ONE JSON line on rank 0.  Multi-GPU = the batch axis sharded (weak scaling, 2^20 per
 GPU), no data-path collective (samples are independent; Philox streams keyed by the global
-sample index).
+sample index); the training leg all-reduces its flat gradient once per step (RCCL).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +29,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+def _self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: N children of this same command with the rendezvous in their environment
+    (one rank per GPU, LOCAL_RANK = RANK; on a box with fewer GPUs than ranks the children share devices round-robin --
+    parallel.init() -- which with SO3X_DIST_BACKEND=gloo exercises this path on a one-GPU box).  stdout of rank 0 is the job's
+    stdout; the other ranks' output goes to stderr.  The parent stays a pure-Python supervisor: no torch import, no HIP call."""
+    import socket
+    with socket.socket() as sk:   # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SO3X_BENCH_CHILD="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr, stderr=None))
+    rcs = []
+    try:
+        for pr in procs:
+            rcs.append(pr.wait())
+    except BaseException:
+        for pr in procs:   # exactly the processes started here
+            if pr.poll() is None:
+                pr.kill()
+        raise
+    return max((abs(rc) for rc in rcs), default=0)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _ap = argparse.ArgumentParser(add_help=False)
+    _ap.add_argument("--gpus", type=int, default=1)
+    _n = _ap.parse_known_args()[0].gpus
+    if _n > 1:
+        sys.exit(_self_launch(_n, sys.argv[1:]))
 
 import numpy as np
 import torch
@@ -145,10 +187,11 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         barrier()
-        tm = torch.tensor([el], device=dev, dtype=torch.float64)
+        tm = torch.tensor([el, -el], device=dev, dtype=torch.float64)
         if ctx.world_size > 1:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        return float(tm.item()) / reps
+        wall.fastest_rank = -float(tm[1].item()) / reps
+        return float(tm[0].item()) / reps
 
     out = {"batch_per_gpu": n, "global_batch": n * ctx.world_size, "ranks": ctx.world_size, "mlp_operands": "bf16",
            "optimizer": "so3x.optim.Adam (one launch on the flat buffers; torch.optim.Adam's update rule)",
@@ -162,15 +205,27 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
         for _ in range(3):
             eager()
         out["eager_python_loop_ms_per_step"] = wall(eager, 10) * 1e3
+    serial_ms = None
+    if ctx.world_size == 1:  # the round-2 form beside it: forward -> backward -> all-reduce -> Adam as ONE stream
+        ts = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size, pipeline=False)
+        for _ in range(warm):
+            ts.replay()
+        serial_ms = wall(ts.replay, reps) * 1e3
+        del ts
     tg = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size)
     for _ in range(warm):
         tg.replay()
     sec = wall(tg.replay, reps)
+    tg.flush()
     loss = parallel.mean_scalar(tg.loss.clone(), ctx)
-    out.update({"ms_per_step": sec * 1e3, "samples_per_s": n * ctx.world_size / sec, "mode": {
-        "in_graph": "one captured hipGraph per step" + ("" if ctx.world_size == 1 else ", all-reduce inside"),
-        "split": "two captured hipGraphs per step with the all-reduce between them"}[tg.mode],
-        "algorithmic_TFLOPs_per_gpu": 94120 * n / sec / 1e12, "loss": loss, "finite": bool(loss == loss), "steps_timed": reps})
+    out.update({"ms_per_step": sec * 1e3, "ms_per_step_fastest_rank": wall.fastest_rank * 1e3, "samples_per_s": n * ctx.world_size / sec,
+                "mode": {"in_graph": "one captured hipGraph per step" + ("" if ctx.world_size == 1 else ", all-reduce inside"),
+                         "split": "captured hipGraphs with the eager all-reduce between them"}[tg.mode],
+                "pipelined": tg.pipelined,
+                "pipeline": "noising of batch k on a second stream beside [slab reduction -> all-reduce -> Adam] of batch k-1 (so3x/graphs.py)"
+                            if tg.pipelined else None,
+                "serial_graph_ms_per_step": serial_ms,
+                "algorithmic_TFLOPs_per_gpu": 94120 * n / sec / 1e12, "loss": loss, "finite": bool(loss == loss), "steps_timed": reps})
     if ctx.world_size > 1:
         flat = net.gather_flat_grad()
         def ar():
@@ -215,37 +270,46 @@ def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
     nt = 1 << 19
     proc = SO3Diffusion(wnet, timesteps=sched.shape[1]).to(dev)
     x0 = B.quat_to_rmat(torch.randn(nt, 4, device=dev))
-    opt = torch.optim.Adam(wnet.parameters(), lr=3e-4, fused=True)
-
-    def step():
-        loss = proc(x0)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-
-    ms = timed(step, 3)
+    from so3x import optim as so3x_optim
+    from so3x.graphs import TrainStepGraph
+    opt = so3x_optim.Adam(wnet, lr=3e-4)   # the product's optimizer, as the 65-wide leg: one launch on the flat 392,448-float buffers
+    tg = TrainStepGraph(proc, opt, x0.shape)   # serial form (the pipelined stages are the 65-wide network's)
+    for _ in range(3):
+        tg.replay()
+    ms = timed(tg.replay, 5)
     out["train_step"] = {"batch": nt, "ms_per_step": ms, "samples_per_s": nt / (ms * 1e-3), "operands": "bf16",
-                         "algorithmic_TFLOPs": 3 * flop * nt / (ms * 1e-3) / 1e12, "optimizer": "torch Adam (fused=True)"}
+                         "algorithmic_TFLOPs": 3 * flop * nt / (ms * 1e-3) / 1e12, "optimizer": "so3x.optim.Adam",
+                         "mode": "one captured hipGraph per step (so3x.graphs.TrainStepGraph)", "finite": bool(torch.isfinite(tg.loss).item())}
     return out
 
 
-def igso3_eval_roofline(B, torch, n=1 << 20, reps=50):
-    """BASELINE config 2: IGSO(3) log-density + score, per-sample eps, HBM-bound kernel.  The C ABI is called
-    directly with preallocated outputs, captured once into a HIP graph and replayed, so the events bracket
-    back-to-back kernel launches (the Python wrapper's per-call allocation otherwise leaves the GPU idle
-    between 15-us kernels)."""
+def igso3_eval_roofline(B, torch, n=1 << 20, reps=50, eps_input="schedule", sched=None):
+    """BASELINE config 2: IGSO(3) log-density + score, HBM-bound kernel, on the inputs BASELINE.md section 4 states:
+    eps_input "scalar" = (2a) one eps = 0.5 for the whole batch; "schedule" = (2b) eps_i = sqrt(1 - abar_{t_i}) from the
+    schedule, t_i = randint(0, T) seed 0 -- the eps the training loss sees, including the small-eps rows where most
+    rotations sit far out in the density's tail; "uniform" = eps ~ U(0.1, 1), round 2's easier input, kept for continuity
+    and labelled as NOT a BASELINE input.  The C ABI is called directly with preallocated outputs, captured once into a HIP
+    graph and replayed, so the events bracket back-to-back kernel launches (the Python wrapper's per-call allocation
+    otherwise leaves the GPU idle between 15-us kernels)."""
     import ctypes as C
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev).manual_seed(0)
     R = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
-    eps = torch.rand(n, device=dev, generator=g) * 0.9 + 0.1
+    if eps_input == "scalar":
+        eps, eps_stride = torch.full((1,), 0.5, device=dev), 0
+    elif eps_input == "schedule":
+        ti = torch.randint(0, sched.shape[1], (n,), device=dev, generator=g)
+        eps, eps_stride = sched[4][ti].contiguous(), 1      # sqrt_one_minus_alphas_cumprod[t_i]
+    else:
+        eps, eps_stride = torch.rand(n, device=dev, generator=g) * 0.9 + 0.1, 1
+    bytes_per_eval = IGSO3_BYTES_PER_EVAL - (4 if eps_stride == 0 else 0)
     logp = torch.empty(n, device=dev)
     score = torch.empty(n, 3, device=dev)
     lib = B.lib()
 
     def launch():
         rc = lib.so3x_igso3_logprob_score(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(R.data_ptr()),
-                                          C.c_void_p(eps.data_ptr()), C.c_int64(1), C.c_void_p(logp.data_ptr()),
+                                          C.c_void_p(eps.data_ptr()), C.c_int64(eps_stride), C.c_void_p(logp.data_ptr()),
                                           C.c_void_p(score.data_ptr()), None, C.c_int64(n))
         assert rc == 0, rc
 
@@ -267,11 +331,61 @@ def igso3_eval_roofline(B, torch, n=1 << 20, reps=50):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    gbs = IGSO3_BYTES_PER_EVAL * n / (ms * 1e-3) / 1e9
-    return {"kernel": "k_logprob_score", "evals_per_s": n / (ms * 1e-3), "bound": "hbm", "achieved": gbs,
+    gbs = bytes_per_eval * n / (ms * 1e-3) / 1e9
+    finite = float(torch.isfinite(logp).float().mean().item())
+    return {"kernel": "k_logprob_score", "eps_input": {"scalar": "2a: eps = 0.5 for every sample", "uniform": "eps ~ U(0.1, 1) (round 2's input; NOT a BASELINE input)",
+                                                        "schedule": "2b: eps_i = sqrt(1 - abar_t_i), t_i = randint(0, T), seed 0"}[eps_input],
+            "evals_per_s": n / (ms * 1e-3), "bound": "hbm", "achieved": gbs,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "n": n, "ms": ms,
-            "bytes_per_eval": IGSO3_BYTES_PER_EVAL, "launches": reps, "timing": "HIP events around a graph replay",
-            "traffic": pmc_traffic("k_logprob_score", n=n)}
+            "bytes_per_eval": bytes_per_eval, "launches": reps, "timing": "HIP events around a graph replay",
+            "finite_logp_frac": finite, "traffic": pmc_traffic("k_logprob_score", n=n, eps_input=eps_input)}
+
+
+def se3_legs(B, torch, reps=20):
+    """BASELINE config 5's device work per GPU (prot_train.py's SE(3) path; reference prot_util.py:73-81, diffusion.py:432-522):
+    `k_rigid_move` -- every residue of 4096 structures x 256 residues moved by its structure's rigid transform (positions
+    AND frames: 48 B in + 48 B out per residue) -- and `se3_q_sample_target` (IGSO3 x R^3 noising + both regression targets,
+    2^20 frames: 36 + 12 + 8 B in, 36 + 12 + 12 + 12 B out).  HIP events around `reps` back-to-back launches."""
+    from so3x.se3 import SE3Diffusion, AffineGrad
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    S, L = 4096, 256
+    rot = B.quat_to_rmat(torch.randn(S, 4, device=dev, generator=g))
+    shift = torch.randn(S, 3, device=dev, generator=g)
+    pos = torch.randn(S, L, 3, device=dev, generator=g)
+    frames = B.quat_to_rmat(torch.randn(S, L, 4, device=dev, generator=g))
+    ms = timed(lambda: B.rigid_move(rot, shift, pos, frames))
+    gbs = 96 * S * L / (ms * 1e-3) / 1e9
+    out = {"rigid_move": {"kernel": "k_rigid_move", "structures": S, "residues_per_structure": L, "bytes_per_residue": 96, "ms": ms,
+                          "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                          "timing": "HIP events around back-to-back operator calls (includes their output allocation)",
+                          "traffic": pmc_traffic("k_rigid_move", structures=S, residues=L)}}
+    n = 1 << 20
+    proc3 = SE3Diffusion(lambda x, t: AffineGrad(x.rot[..., 0], x.shift), timesteps=1000).to(dev)
+    tq, _ = proc3._tables()
+    xr = B.quat_to_rmat(torch.randn(n, 4, device=dev, generator=g))
+    xs = torch.randn(n, 3, device=dev, generator=g)
+    tt = torch.randint(0, 1000, (n,), device=dev, generator=g)
+    ms = timed(lambda: B.se3_q_sample_target(proc3._sched, tq, 75.0, xr, xs, tt, seed=1))
+    nb = 36 + 12 + 8 + 36 + 12 + 12 + 12
+    gbs = nb * n / (ms * 1e-3) / 1e9
+    out["se3_q_sample_target"] = {"kernel": "k_se3_q_sample_target", "n": n, "bytes_per_frame": nb, "ms": ms, "bound": "hbm (nominal; per-sample CDF-row gathers + VALU in fact)",
+                                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                  "traffic": pmc_traffic("k_se3_q_sample_target", n=n)}
+    return out
 
 
 def main():
@@ -293,9 +407,8 @@ def main():
     from so3x.diffusion import SO3Diffusion
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if world != args.gpus and args.gpus > 1:   # (a plain `--gpus N` never gets here: _self_launch above started the ranks)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or with no launcher at all")
     ctx = parallel.init()
     dev = ctx.device
     if dev.type != "cuda":
@@ -332,10 +445,10 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
-    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([el, -el], device=dev, dtype=torch.float64)
     if ctx.world_size > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    el = float(tmax.item())
+    el, el_fastest = float(tmax[0].item()), -float(tmax[1].item())
     ok = bool(torch.isfinite(x).all().item())
 
     # ---- roofline of the dominant kernel on a FIXED shape (100 steps per launch, 5 launches, HIP events on the launch
@@ -378,6 +491,11 @@ def main():
         except Exception as e:  # report, never hide
             train = {"error": repr(e)}
 
+    devices = [f"{dev} ({torch.cuda.get_device_name(dev)})"]
+    if ctx.world_size > 1:  # what each rank actually ran on
+        devices = [None] * ctx.world_size
+        torch.distributed.all_gather_object(devices, f"rank {ctx.rank}: {dev} ({torch.cuda.get_device_name(dev)})")
+
     if ctx.rank == 0:
         total = ctx.world_size * n * args.steps
         line = {
@@ -391,6 +509,12 @@ def main():
                        "parallelism": f"batch-sharded x{ctx.world_size}, no collective",
                        "launches_timed": launches, "clock_ramp_steps_untimed": RAMP},
             "finite": ok,
+            "ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+            "launcher": "self (bench.py started the ranks)" if os.environ.get("SO3X_BENCH_CHILD") else
+                        ("torch.distributed.run / external" if ctx.world_size > 1 else "single process"),
+            "rank_ms_per_step": {"slowest": el / args.steps * 1e3, "fastest": el_fastest / args.steps * 1e3},
+            "devices": devices,
             "full_chain": {"what": "one complete p_sample_loop: IGSO3(1) start, T reverse steps, ONE kernel launch", "batch_per_gpu": n,
                            "timesteps": T, "seconds": full_s, "sample_steps_per_s": ctx.world_size * n * T / full_s, "finite": full_ok},
             "roofline": {"kernel": "k_p_sample_chain", "bound": "mfma", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS,
@@ -408,12 +532,20 @@ def main():
         if train is not None:
             line["train_step"] = train
         if not args.no_extras and ctx.world_size == 1:
-            try:
-                line["igso3_eval"] = igso3_eval_roofline(B, torch)
-                big = igso3_eval_roofline(B, torch, n=1 << 24, reps=10)
-                line["igso3_eval"]["at_n_2p24"] = {k: big[k] for k in ("achieved", "frac", "ms", "evals_per_s")}
+            try:  # BASELINE config 2 on its stated inputs: (2b) per-sample eps from the schedule is the headline of this leg
+                leg = igso3_eval_roofline(B, torch, eps_input="schedule", sched=proc._sched)
+                big = igso3_eval_roofline(B, torch, n=1 << 24, reps=10, eps_input="schedule", sched=proc._sched)
+                leg["at_n_2p24"] = {k: big[k] for k in ("achieved", "frac", "ms", "evals_per_s")}
+                leg["scalar_eps_0p5"] = igso3_eval_roofline(B, torch, eps_input="scalar")
+                leg["uniform_eps_not_a_baseline_input"] = {k: v for k, v in igso3_eval_roofline(B, torch, eps_input="uniform").items()
+                                                           if k in ("eps_input", "achieved", "frac", "ms", "finite_logp_frac")}
+                line["igso3_eval"] = leg
             except Exception as e:  # report, never hide
                 line["igso3_eval"] = {"error": repr(e)}
+            try:  # BASELINE config 5's per-GPU device work
+                line["se3"] = se3_legs(B, torch)
+            except Exception as e:
+                line["se3"] = {"error": repr(e)}
             try:
                 line["wide_net"] = wide_net_extra(B, torch, proc._sched, trap_p)
             except Exception as e:

@@ -35,9 +35,11 @@ namespace {
 // Wave-private staging (one 64-sample tile per wave, no workgroup barrier), launched one tile per wave on an
 // oversubscribed grid like k_logprob_score: the per-sample CDF-row search is a chain of ~10 dependent L2 loads, and
 // only other resident waves hide it.
-// t_draw != nullptr: the timesteps are not given but drawn here -- t_i = floor(T * w_i / 2^32) from the fourth word of the
-// sample's Philox block (the other three feed the noise), written to t_draw for the kernels that follow; SO3Diffusion.forward's
-// `t = randint(0, T, (b,))` (diffusion.py:373) keyed, like the noise, by the global sample index.
+// t == nullptr: the timesteps are not given but drawn here -- t_i = floor(T * w_i / 2^32) from the fourth word of the
+// sample's Philox block (the other three feed the noise); SO3Diffusion.forward's `t = randint(0, T, (b,))` (diffusion.py:373)
+// keyed, like the noise, by the global sample index.  Given timesteps are clamped to [0, T-1] (the reference raises IndexError;
+// a kernel cannot, and must not read outside its tables).  t_draw (optional): where the timesteps actually used are written
+// for the kernels that follow.
 // LEAN: the training step's form (noise drawn here: no noise_in, no explicit axes / uniforms) as its own instantiation at
 // 64 registers -- eight waves per SIMD hold all 8,192 tiles of a 2^19-sample step at once; at the generic kernel's 67
 // registers (seven waves) the last eighth of the tiles ran as a second round: 23.7 -> 20.1 us (tools/ab/ab_qsample.py).
@@ -60,22 +62,22 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
   auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
-  // distributions.py:42-43: column 0 == sample 0's eps
-  const int64_t wrow_t = !quirk_col0 ? -1 : (t_draw ? drawn_t(philox4x32_10(seed, (uint64_t)index_base, rng_offset).w) : t[0]);
+  auto clamp_t = [&](int64_t v) -> int64_t { return v < 0 ? 0 : (v >= T ? T - 1 : v); };  // as k_p_mean: never index outside a table
+  // distributions.py:42-43: column 0 == sample 0's eps.  With drawn timesteps that is GLOBAL sample 0's draw (Philox index 0,
+  // whatever this shard's index_base), so every shard of a data-parallel run uses the row the single-process run uses; with
+  // caller-supplied timesteps it is this call's t[0], as in the reference (the caller decides what a shard's t[0] is).
+  const int64_t wrow_t = !quirk_col0 ? -1 : (t ? clamp_t(t[0]) : drawn_t(philox4x32_10(seed, (uint64_t)0, rng_offset).w));
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kWave;
     const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
     const int64_t idx = base + lane;
     const bool live = lane < cnt;
     Philox4 r;
-    if (t_draw || (!noise_in && !axes)) r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
+    if (!t || (!noise_in && !axes)) r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
     int64_t tt;
-    if (t_draw) {
-      tt = drawn_t(r.w);
-      if (live) t_draw[idx] = tt;
-    } else {
-      tt = t[live ? idx : base];
-    }
+    if (t) tt = clamp_t(t[live ? idx : base]);
+    else tt = drawn_t(r.w);
+    if (t_draw && live) t_draw[idx] = tt;  // the timesteps the kernels behind this one gather with: drawn here, or the caller's, clamped
     float nz[9];
     if (noise_in) {
       wave_load_rows<9>(noise_in, base, cnt, wl, nz);
@@ -370,7 +372,7 @@ int launch_q_sample_target(hipStream_t s, const float* sched, int T, const float
                            const int64_t* t, int64_t* t_draw, int quirk_col0, const float* noise_in, const float* axes,
                            const float* unif, uint64_t seed, uint64_t rng_offset, const int64_t* rng_offset_dev, int64_t index_base,
                            float* x_t, float* target, float* noise_out, int64_t n) {
-  if (n < 0 || T <= 0 || (n && (!sched || !x0 || ((t == nullptr) == (t_draw == nullptr)))) || (n && !noise_in && !trap_q) ||
+  if (n < 0 || T <= 0 || (n && (!sched || !x0 || (!t && !t_draw))) || (n && !noise_in && !trap_q) ||
       ((axes == nullptr) != (unif == nullptr)))
     return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;

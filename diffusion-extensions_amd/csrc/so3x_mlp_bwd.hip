@@ -771,7 +771,8 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
   uint64_t rng_offset = na.rng_offset;
   if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];
   auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
-  const int64_t wrow_t = !na.quirk_col0 ? -1 : (na.t_draw ? drawn_t(philox4x32_10(na.seed, (uint64_t)na.index_base, rng_offset).w) : na.t[0]);
+  auto clamp_t = [&](int64_t v) -> int64_t { return v < 0 ? 0 : (v >= T ? T - 1 : v); };
+  const int64_t wrow_t = !na.quirk_col0 ? -1 : (na.t ? clamp_t(na.t[0]) : drawn_t(philox4x32_10(na.seed, (uint64_t)0, rng_offset).w));
   const int64_t nchunks = (n + 63) / 64, ntiles = (n + 31) / 32;
   const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
   float sq = 0.0f;
@@ -782,10 +783,10 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
     const bool live = lane < cnt;
     // ---- noise draw, q_sample, target: one lane = one sample (k_q_sample_target's arithmetic)
     Philox4 r;
-    if (na.t_draw || !na.axes) r = philox4x32_10(na.seed, (uint64_t)(na.index_base + idx), rng_offset);
+    if (!na.t || !na.axes) r = philox4x32_10(na.seed, (uint64_t)(na.index_base + idx), rng_offset);
     int64_t tt;
-    if (na.t_draw) { tt = drawn_t(r.w); if (live) na.t_draw[idx] = tt; }
-    else tt = na.t[live ? idx : base];
+    tt = na.t ? clamp_t(na.t[live ? idx : base]) : drawn_t(r.w);
+    if (live) na.t_draw[idx] = tt;
     float ax[3], u;
     if (na.axes) {
       float a[3];
@@ -1219,8 +1220,17 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
   else
     hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
                        emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
+  if (!dparams) return check_launch();  // partial slabs only: launch_slab_reduce follows (so3x_train_bwd_reduce)
   hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
                      gscale);
+  return check_launch();
+}
+
+// the fixed-order sum of the partial slabs k_bwd_fused left for n samples (same grid rule as launch_fused_bwd)
+inline int launch_slab_reduce(hipStream_t s, const float* slabs, int64_t n, int nout, float* dparams, const float* gscale) {
+  const int64_t nt = (n + 31) / 32;
+  const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, slabs, gf, dparams, 0, nparams(nout), gscale);
   return check_launch();
 }
 
@@ -1347,13 +1357,23 @@ int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int
 // ---- one training step of SO3Diffusion(RotPredict(out_type="skewvec")) under loss_type="skewvec", bf16 MLP operands ----
 size_t so3x_train_workspace_bytes(int64_t n, int T) { return train_layout(n, T > 0 ? T : 0).end; }
 
-int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
-                   const float* x0, const int64_t* t, int64_t* t_draw, int quirk_col0, const float* axes, const float* unif, uint64_t seed,
-                   uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, float* dout, void* zstash,
-                   float* loss, float* out, void* workspace, size_t workspace_bytes) {
-  if (n <= 0 || T <= 0 || !params || !sched || !trap_q || !x0 || ((t == nullptr) == (t_draw == nullptr)) || !x_t || !dout ||
-      !zstash || !loss || ((axes == nullptr) != (unif == nullptr)))
-    return SO3X_ERR_INVALID_ARG;
+// The step in stages.  A captured data-parallel step pipelines them: the noising of batch k+1 (a function of the data and the
+// Philox counter only) runs on a second stream beside [slab reduction -> gradient all-reduce -> Adam] of batch k.
+int so3x_train_noise(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q, const float* x0,
+                     const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif, uint64_t seed,
+                     uint64_t rng_offset, const int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, void* workspace,
+                     size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !sched || !trap_q || !x0 || !t_used || !x_t || ((axes == nullptr) != (unif == nullptr))) return SO3X_ERR_INVALID_ARG;
+  const TrainLayout L = train_layout(n, T);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  // the noising kernel (eight waves per SIMD: latency-bound gathers) leaves x_t, the timesteps used and the regression target
+  return launch_q_sample_target((hipStream_t)s, sched, T, trap_q, guide_q, x0, t, t_used, quirk_col0, nullptr, axes, unif, seed, rng_offset,
+                                rng_counter, index_base, x_t, reinterpret_cast<float*>((char*)workspace + L.target), nullptr, n);
+}
+
+int so3x_train_net(so3x_stream_t s, const float* params, int T, const float* x_t, const int64_t* t_used, int64_t n, float* dout,
+                   void* zstash, float* loss, float* out, int64_t* rng_counter, void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !params || !x_t || !t_used || !dout || !zstash || !loss) return SO3X_ERR_INVALID_ARG;
   const TrainLayout L = train_layout(n, T);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
   constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER_T>();
@@ -1366,10 +1386,27 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
   la.dout = dout; la.loss = loss;
   la.partial = reinterpret_cast<double*>(ws + L.partial);
   la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
-  la.rng_counter = (axes == nullptr || t_draw) ? rng_counter : nullptr;
+  la.rng_counter = rng_counter;
   la.dscale = (float)(2.0 / (3.0 * (double)n));
   la.inv_count = 1.0 / (3.0 * (double)n);
+  la.target = reinterpret_cast<float*>(ws + L.target);
   const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
+  static PerDevice attr;
+  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
+  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
+  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, st, (const void*)ws,
+                     beff, x_t, t_used, (int64_t)1, out, (char*)zstash, n, 3, la);
+  return check_launch();
+}
+
+int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                   const float* x0, const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif, uint64_t seed,
+                   uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, float* dout, void* zstash,
+                   float* loss, float* out, void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !params || !sched || !trap_q || !x0 || !t_used || !x_t || !dout || !zstash || !loss ||
+      ((axes == nullptr) != (unif == nullptr)))
+    return SO3X_ERR_INVALID_ARG;
+  int64_t* counter = (axes == nullptr || t == nullptr) ? rng_counter : nullptr;  // advanced only by a call that drew from it
 #ifdef SO3X_AB_BUILD  /* libso3x_ab.so only (tools/ab/ab_trainfwd.py); the product launcher reads no environment */
   const char* ab = getenv("SO3X_AB_TRAINFWD");
   if (ab && !strcmp(ab, "fused")) {
@@ -1377,34 +1414,40 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
     // launch.  Measured no faster than the two launches below (277.3 vs 275.9 us per 2^19-sample step,
     // profiles/r02_ab_train_fwd_fused_noising.json): at the two waves per SIMD the stash-carrying forward allows, the noising's
     // dependent L2 gathers are no longer hidden the way the six-waves-per-SIMD noising kernel hides them.
+    const TrainLayout L = train_layout(n, T);
+    if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+    constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER_T>();
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)s;
+    int rc = launch_prep(st, params, PREC, GATHER_T, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
+    if (rc) return rc;
+    LossArgs la;
+    la.dout = dout; la.loss = loss;
+    la.partial = reinterpret_cast<double*>(ws + L.partial);
+    la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
+    la.rng_counter = counter;
+    la.dscale = (float)(2.0 / (3.0 * (double)n));
+    la.inv_count = 1.0 / (3.0 * (double)n);
+    la.target = nullptr;
+    const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
     static PerDevice attr_f;
     if ((rc = ensure_dyn_lds(attr_f, reinterpret_cast<const void*>(&k_train_fwd<PREC>), IMG))) return rc;
-    NoiseArgs na{sched, trap_q, guide_q, x0, t, t_draw, axes, unif, rng_counter, seed, rng_offset, index_base, T, quirk_col0};
-    la.target = nullptr;
+    NoiseArgs na{sched, trap_q, guide_q, x0, t, t_used, axes, unif, rng_counter, seed, rng_offset, index_base, T, quirk_col0};
     const int64_t nchunks = (n + 63) / 64, want = (nchunks + 3) / 4;
     hipLaunchKernelGGL((k_train_fwd<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, st, (const void*)ws, beff, na, x_t, out,
                        (char*)zstash, n, la);
     return check_launch();
   }
 #endif
-  // the noising kernel (six waves per SIMD: latency-bound gathers), then the network forward with the MSE epilogue
-  float* target = reinterpret_cast<float*>(ws + L.target);
-  rc = launch_q_sample_target(st, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0, nullptr, axes, unif, seed, rng_offset,
-                              rng_counter, index_base, x_t, target, nullptr, n);
-  if (rc) return rc;
-  const int64_t* tt = t ? t : t_draw;
-  static PerDevice attr;
-  if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
-  const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
-  la.target = target;
-  hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, st, (const void*)ws,
-                     beff, x_t, tt, (int64_t)1, out, (char*)zstash, n, 3, la);
-  return check_launch();
+  if (int rc = so3x_train_noise(s, sched, T, trap_q, guide_q, x0, t, t_used, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, n,
+                                x_t, workspace, workspace_bytes))
+    return rc;
+  return so3x_train_net(s, params, T, x_t, t_used, n, dout, zstash, loss, out, counter, workspace, workspace_bytes);
 }
 
-int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
-                   const float* gscale, float* grad, void* workspace, size_t workspace_bytes) {
-  if (n <= 0 || T <= 0 || !x_t || !t || !dout || !zstash || !grad) return SO3X_ERR_INVALID_ARG;
+int so3x_train_bwd_partial(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
+                           void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !x_t || !t || !dout || !zstash) return SO3X_ERR_INVALID_ARG;
   const TrainLayout L = train_layout(n, T);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
   constexpr int PREC = SO3X_PREC_BF16;
@@ -1412,7 +1455,21 @@ int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const fl
   return launch_fused_bwd((hipStream_t)s, ws, ws + L.wt, reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)),
                           reinterpret_cast<const float*>(ws + emb_offset(PREC, GATHER, T)),
                           reinterpret_cast<const uint4*>(ws + h0_offset(PREC, GATHER, T)), x_t, t, 1, dout,
-                          reinterpret_cast<float*>(const_cast<char*>(ws) + L.slabs), n, (const char*)zstash, 3, grad, gscale);
+                          reinterpret_cast<float*>(const_cast<char*>(ws) + L.slabs), n, (const char*)zstash, 3, nullptr, nullptr);
+}
+
+int so3x_train_bwd_reduce(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !grad) return SO3X_ERR_INVALID_ARG;
+  const TrainLayout L = train_layout(n, T);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  return launch_slab_reduce((hipStream_t)s, reinterpret_cast<const float*>((const char*)workspace + L.slabs), n, 3, grad, gscale);
+}
+
+int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
+                   const float* gscale, float* grad, void* workspace, size_t workspace_bytes) {
+  if (!grad) return SO3X_ERR_INVALID_ARG;
+  if (int rc = so3x_train_bwd_partial(s, x_t, t, dout, zstash, n, T, workspace, workspace_bytes)) return rc;
+  return so3x_train_bwd_reduce(s, n, T, gscale, grad, workspace, workspace_bytes);
 }
 
 }  // extern "C"

@@ -262,13 +262,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> train_fwd(
   const int T = (int)dev(sched, "sched").size(1);
   TORCH_CHECK(params.numel() == SO3X_MLP_PARAMS, "so3x: the fused training step is built for the ", SO3X_MLP_PARAMS, "-parameter skew-vector network");
   TORCH_CHECK(n > 0, "so3x: empty batch");
-  Tensor tt = t.has_value() ? dev(*t, "t", at::kLong) : at::empty({n}, x0.options().dtype(at::kLong));
+  Tensor tt = at::empty({n}, x0.options().dtype(at::kLong));  // the timesteps the step ran with: always a fresh tensor, never the caller's t
   Tensor x_t = at::empty_like(dev(x0, "x_start"));
   Tensor dout = f32_like(x0, {n, 3}), loss = f32_like(x0, {1});
   Tensor out = want_out ? f32_like(x0, {n, 3}) : f32_like(x0, {0, 3});
   Tensor zs = bytes(x0, so3x_mlp_stash_bytes(n)), ws = bytes(x0, so3x_train_workspace_bytes(n, T));
   ok(so3x_train_fwd(strm(x0), F(dev(params, "params")), F(sched), T, F(dev(trap_q, "trap_q")), Guide(guide_q), F(x0),
-                    t.has_value() ? I64(tt) : nullptr, t.has_value() ? nullptr : tt.mutable_data_ptr<int64_t>(), quirk_col0 ? 1 : 0,
+                    t.has_value() ? I64(dev(*t, "t", at::kLong)) : nullptr, tt.mutable_data_ptr<int64_t>(), quirk_col0 ? 1 : 0,
                     Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset,
                     rng_counter.has_value() ? dev(*rng_counter, "rng_counter", at::kLong).mutable_data_ptr<int64_t>() : nullptr, index_base, n,
                     Fm(x_t), Fm(dout), zs.mutable_data_ptr(), Fm(loss), want_out ? Fm(out) : nullptr, ws.mutable_data_ptr(), ws.numel()),
@@ -284,6 +284,50 @@ Tensor train_bwd(const Tensor& x_t, const Tensor& t, const Tensor& dout, const T
                     x_t.numel() / 9, (int)T, Fo(gscale, "grad_output"), Fm(grad), ws.mutable_data_ptr(), ws.numel()),
      "train_bwd");
   return grad;
+}
+// the step in stages, on caller-owned buffers (so3x.graphs.TrainStepGraph pipelines them across two streams)
+void train_noise(const Tensor& sched, const Tensor& trap_q, const optional<Tensor>& guide_q, const Tensor& x0, const optional<Tensor>& t,
+                 bool quirk_col0, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed, int64_t rng_offset,
+                 const optional<Tensor>& rng_counter, int64_t index_base, Tensor& x_t, Tensor& t_used, Tensor& workspace) {
+  GUARD(x0);
+  const int64_t n = x0.numel() / 9;
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(n > 0 && x_t.numel() == n * 9 && t_used.numel() == n, "so3x: train_noise buffer sizes differ");
+  dev(x_t, "x_t"); dev(workspace, "workspace", at::kByte);
+  ok(so3x_train_noise(strm(x0), F(sched), T, F(dev(trap_q, "trap_q")), Guide(guide_q), F(dev(x0, "x_start")),
+                      t.has_value() ? I64(dev(*t, "t", at::kLong)) : nullptr, dev(t_used, "t_used", at::kLong).mutable_data_ptr<int64_t>(),
+                      quirk_col0 ? 1 : 0, Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset,
+                      rng_counter.has_value() ? I64(dev(*rng_counter, "rng_counter", at::kLong)) : nullptr, index_base, n, Fm(x_t),
+                      workspace.mutable_data_ptr(), workspace.numel()),
+     "train_noise");
+}
+void train_net(const Tensor& params, int64_t T, const Tensor& x_t, const Tensor& t_used, Tensor& dout, Tensor& zstash, Tensor& loss,
+               optional<Tensor> out, optional<Tensor> rng_counter, Tensor& workspace) {
+  GUARD(x_t);
+  const int64_t n = x_t.numel() / 9;
+  TORCH_CHECK(params.numel() == SO3X_MLP_PARAMS, "so3x: the fused training step is built for the ", SO3X_MLP_PARAMS, "-parameter skew-vector network");
+  TORCH_CHECK(n > 0 && dout.numel() == n * 3 && t_used.numel() == n && loss.numel() >= 1 && (size_t)zstash.numel() >= so3x_mlp_stash_bytes(n) &&
+              (!out.has_value() || out->numel() == n * 3), "so3x: train_net buffer sizes differ");
+  dev(dout, "dout"); dev(loss, "loss"); dev(zstash, "zstash", at::kByte); dev(workspace, "workspace", at::kByte);
+  ok(so3x_train_net(strm(x_t), F(dev(params, "params")), (int)T, F(dev(x_t, "x_t")), I64(dev(t_used, "t_used", at::kLong)), n, Fm(dout),
+                    zstash.mutable_data_ptr(), Fm(loss), out.has_value() ? dev(*out, "out").mutable_data_ptr<float>() : nullptr,
+                    rng_counter.has_value() ? dev(*rng_counter, "rng_counter", at::kLong).mutable_data_ptr<int64_t>() : nullptr,
+                    workspace.mutable_data_ptr(), workspace.numel()),
+     "train_net");
+}
+void train_bwd_partial(const Tensor& x_t, const Tensor& t, const Tensor& dout, const Tensor& zstash, int64_t T, Tensor& workspace) {
+  GUARD(x_t);
+  dev(workspace, "workspace", at::kByte);
+  ok(so3x_train_bwd_partial(strm(x_t), F(dev(x_t, "x_t")), I64(dev(t, "t", at::kLong)), F(dev(dout, "dout")),
+                            dev(zstash, "zstash", at::kByte).const_data_ptr(), x_t.numel() / 9, (int)T, workspace.mutable_data_ptr(), workspace.numel()),
+     "train_bwd_partial");
+}
+void train_bwd_reduce(int64_t n, int64_t T, const optional<Tensor>& gscale, Tensor& grad, const Tensor& workspace) {
+  GUARD(grad);
+  TORCH_CHECK(grad.numel() == SO3X_MLP_PARAMS, "so3x: train_bwd_reduce writes the ", SO3X_MLP_PARAMS, "-parameter flat gradient");
+  ok(so3x_train_bwd_reduce(strm(grad), n, (int)T, Fo(gscale, "grad_output"), dev(grad, "grad").mutable_data_ptr<float>(),
+                           dev(workspace, "workspace", at::kByte).const_data_ptr(), workspace.numel()),
+     "train_bwd_reduce");
 }
 void adam_step(Tensor& params, const Tensor& grad, Tensor& exp_avg, Tensor& exp_avg_sq, Tensor& step, double lr, double beta1, double beta2,
                double eps, double weight_decay, double grad_scale) {
@@ -518,6 +562,12 @@ TORCH_LIBRARY(so3x, m) {
         "Tensor? unif, int seed, int rng_offset, Tensor(a!)? rng_counter, int index_base, bool want_out) "
         "-> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("train_bwd(Tensor x_t, Tensor t, Tensor dout, Tensor zstash, Tensor(a!) workspace, int T, Tensor? gscale, int n_params) -> Tensor");
+  m.def("train_noise(Tensor sched, Tensor trap_q, Tensor? guide_q, Tensor x0, Tensor? t, bool quirk_col0, Tensor? axes, Tensor? unif, int seed, "
+        "int rng_offset, Tensor? rng_counter, int index_base, Tensor(a!) x_t, Tensor(b!) t_used, Tensor(c!) workspace) -> ()");
+  m.def("train_net(Tensor params, int T, Tensor x_t, Tensor t_used, Tensor(a!) dout, Tensor(b!) zstash, Tensor(c!) loss, Tensor(d!)? out, "
+        "Tensor(e!)? rng_counter, Tensor(f!) workspace) -> ()");
+  m.def("train_bwd_partial(Tensor x_t, Tensor t, Tensor dout, Tensor zstash, int T, Tensor(a!) workspace) -> ()");
+  m.def("train_bwd_reduce(int n, int T, Tensor? gscale, Tensor(a!) grad, Tensor workspace) -> ()");
   m.def("adam_step(Tensor(a!) params, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) step, float lr, float beta1, "
         "float beta2, float eps, float weight_decay, float grad_scale) -> ()");
   m.def("rotate_cloud(Tensor rot, Tensor cloud, int cloud_stride, int P) -> Tensor");
@@ -573,6 +623,10 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("p_sample_chain_out", p_sample_chain_out);
   m.impl("train_fwd", train_fwd);
   m.impl("train_bwd", train_bwd);
+  m.impl("train_noise", train_noise);
+  m.impl("train_net", train_net);
+  m.impl("train_bwd_partial", train_bwd_partial);
+  m.impl("train_bwd_reduce", train_bwd_reduce);
   m.impl("adam_step", adam_step);
   m.impl("rotate_cloud", rotate_cloud);
   m.impl("resnet_fwd", resnet_fwd);

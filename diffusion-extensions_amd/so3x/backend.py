@@ -45,6 +45,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
+    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce",
 )
 
 
@@ -81,7 +82,7 @@ def lib():
                 l.so3x_resnet_stash_bytes.restype = C.c_size_t
                 l.so3x_prevstep_workspace_bytes.restype = C.c_size_t
                 l.so3x_train_workspace_bytes.restype = C.c_size_t
-                if l.so3x_abi_version() != 4:
+                if l.so3x_abi_version() != 5:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -420,6 +421,57 @@ def train_bwd(carry, n_params=N_PARAMS, T=None, gscale=None):
     x_t, tt, dout, zstash, ws = carry
     gs = _dev(gscale, "grad_output").reshape(1) if gscale is not None else None
     return _call(ops().train_bwd, x_t, tt, dout, zstash, ws, int(T), gs, int(n_params))
+
+
+class TrainBuffers:
+    """Caller-owned buffers of one training step in stages (so3x_train_noise / _net / _bwd_partial / _bwd_reduce): allocated once,
+    reused by every step -- what a captured, software-pipelined step (so3x.graphs.TrainStepGraph) runs on."""
+
+    def __init__(self, n, T, device, want_out=False):
+        l = lib()
+        self.n, self.T = int(n), int(T)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_t = torch.empty((self.n, 3, 3), **f32)
+        self.t_used = torch.empty((self.n,), dtype=torch.int64, device=device)
+        self.dout = torch.empty((self.n, 3), **f32)
+        self.loss = torch.zeros((1,), **f32)
+        self.out = torch.empty((self.n, 3), **f32) if want_out else None
+        self.zstash = torch.empty((int(l.so3x_mlp_stash_bytes(C.c_int64(self.n))),), dtype=torch.uint8, device=device)
+        self.workspace = torch.empty((int(l.so3x_train_workspace_bytes(C.c_int64(self.n), C.c_int(self.T))),), dtype=torch.uint8, device=device)
+        self.grad = torch.zeros((N_PARAMS,), **f32)
+
+
+def train_noise(buf, sched, trap_q, x0, t=None, quirk_col0=True, axes=None, unif=None, seed=0, rng_offset=0, rng_counter=None,
+                index_base=0, guide_q=None):
+    """stage 1 of a training step: noise draw + q_sample + regression target for batch x0 into buf.x_t / buf.t_used / the target
+    region of buf.workspace.  Depends on the data and the Philox counter only (not on the parameters)."""
+    x0 = _rot_in(x0, "x_start")
+    if x0.numel() // 9 != buf.n:
+        raise ValueError("so3x: batch size differs from the buffers'")
+    if t is not None:
+        t = _dev(t, "t", torch.int64).reshape(-1)
+    _call(ops().train_noise, _dev(sched, "sched"), _dev(trap_q, "trap_q"), _guide(guide_q, trap_q, "guide_q"), x0, t, bool(quirk_col0),
+          _dev(axes, "axes").reshape(-1, 3) if axes is not None else None, _dev(unif, "unif").reshape(-1) if unif is not None else None,
+          _s64(seed), _s64(rng_offset), rng_counter, int(index_base), buf.x_t, buf.t_used, buf.workspace)
+
+
+def train_net(buf, params, rng_counter=None):
+    """stage 2: weight images from the CURRENT params + network forward + stash + MSE and its gradient -> buf.loss, buf.dout;
+    rng_counter (device int64 [1]) is advanced by one if given"""
+    _call(ops().train_net, _dev(params, "params").reshape(-1), buf.T, buf.x_t, buf.t_used, buf.dout, buf.zstash, buf.loss, buf.out, rng_counter,
+          buf.workspace)
+
+
+def train_bwd_partial(buf):
+    """stage 3: the fused backward -> per-workgroup partial slabs in buf.workspace"""
+    _call(ops().train_bwd_partial, buf.x_t, buf.t_used, buf.dout, buf.zstash, buf.T, buf.workspace)
+
+
+def train_bwd_reduce(buf, gscale=None, grad=None):
+    """stage 4: fixed-order sum of the slabs (x gscale) -> the flat gradient (buf.grad unless another tensor is given)"""
+    g = buf.grad if grad is None else grad
+    _call(ops().train_bwd_reduce, buf.n, buf.T, _dev(gscale, "grad_output").reshape(1) if gscale is not None else None, g, buf.workspace)
+    return g
 
 
 def adam_step(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0):

@@ -28,12 +28,12 @@ class _FlatView(torch.autograd.Function):
     def backward(ctx, dflat):
         net = ctx.net
         params = net._flat_params
-        if dflat.is_contiguous() and all(p.grad is None for p in params):
+        if dflat.is_contiguous() and all(p.grad is None for p in params if p.requires_grad):
             net._install_flat_grad(dflat)
             return (None,) * (1 + len(params))
         off, out = 0, []
         for p in params:
-            out.append(dflat[off:off + p.numel()].view_as(p))
+            out.append(dflat[off:off + p.numel()].view_as(p) if p.requires_grad else None)
             off += p.numel()
         return (None, *out)
 
@@ -63,12 +63,20 @@ class FlatParamsMixin:
         self._flat, self._flat_params, self._flat_grad = flat, params, None
 
     def _flat_ok(self):
+        """the cached list IS the module's current parameters (identity: load_state_dict(assign=True) or any replacement of an
+        nn.Parameter re-homes them without touching the old objects) and each of them sits at its offset of the flat buffer"""
         f, ps = self._flat, self._flat_params
         if f is None or len(ps) == 0:
             return False
-        last = ps[-1]
-        return (ps[0].data_ptr() == f.data_ptr() and ps[0].device == f.device
-                and last.data_ptr() == f.data_ptr() + 4 * (f.numel() - last.numel()))
+        cur = list(self.net.parameters())
+        if len(cur) != len(ps) or any(a is not b for a, b in zip(cur, ps)):
+            return False
+        off, es = 0, f.element_size()
+        for p in ps:
+            if p.device != f.device or p.dtype != f.dtype or not p.is_contiguous() or p.data_ptr() != f.data_ptr() + es * off:
+                return False
+            off += p.numel()
+        return off == f.numel()
 
     def _ensure_flat(self):
         # .to(device) / deepcopy / a caller assigning p.data re-home the parameters: adopt them again
@@ -94,20 +102,25 @@ class FlatParamsMixin:
         return _FlatView.apply(self, *self._flat_params)
 
     def _install_flat_grad(self, dflat):
+        """the parameters' .grad become views of `dflat` (frozen parameters -- requires_grad False -- keep theirs untouched, as
+        autograd would leave them)"""
         off = 0
         for p in self._flat_params:
-            p.grad = dflat[off:off + p.numel()].view(p.shape)
+            if p.requires_grad:
+                p.grad = dflat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         self._flat_grad = dflat
 
     def flat_grad(self):
         """the flat gradient if every parameter's .grad currently is a view of one flat tensor, else None"""
         g, ps = self._flat_grad, self._flat_params
-        if g is None or not ps or ps[0].grad is None or ps[-1].grad is None:
+        if g is None or not ps:
             return None
-        last = ps[-1]
-        if ps[0].grad.data_ptr() != g.data_ptr() or last.grad.data_ptr() != g.data_ptr() + 4 * (g.numel() - last.numel()):
-            return None
+        off, es = 0, g.element_size()
+        for p in ps:
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != g.data_ptr() + es * off):
+                return None
+            off += p.numel()
         return g
 
     def gather_flat_grad(self):

@@ -141,14 +141,44 @@ def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng
 @register_fake("so3x::train_fwd")
 def _(params, sched, trap_q, guide_q, x0, t, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, want_out):
     n = x0.numel() // 9
-    by = lambda k: x0.new_empty((k,), dtype=torch.uint8)  # noqa: E731  (workspace size: an upper bound is all a fake needs)
+    by = lambda k: x0.new_empty((k,), dtype=torch.uint8)  # noqa: E731
     return (_f32(x0, (1,)), _f32(x0, x0.shape), x0.new_empty((n,), dtype=torch.int64), _f32(x0, (n, 3)),
-            by((n + 31) // 32 * _STASH_TILE), by(32 << 20), _f32(x0, (n if want_out else 0, 3)))
+            by((n + 31) // 32 * _STASH_TILE), by(_train_workspace_bytes(n, sched.shape[1])), _f32(x0, (n if want_out else 0, 3)))
+
+
+def _train_workspace_bytes(n, T):
+    """so3x_train_workspace_bytes (a host-side size function of the C ABI); symbolic sizes get an upper bound"""
+    try:
+        import ctypes as C
+        from .backend import lib
+        return int(lib().so3x_train_workspace_bytes(C.c_int64(int(n)), C.c_int(int(T))))
+    except Exception:  # noqa: BLE001
+        return 32 << 20
 
 
 @register_fake("so3x::train_bwd")
 def _(x_t, t, dout, zstash, workspace, T, gscale, n_params):
     return _f32(x_t, (n_params,))
+
+
+@register_fake("so3x::train_noise")
+def _(sched, trap_q, guide_q, x0, t, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, x_t, t_used, workspace):
+    return None
+
+
+@register_fake("so3x::train_net")
+def _(params, T, x_t, t_used, dout, zstash, loss, out, rng_counter, workspace):
+    return None
+
+
+@register_fake("so3x::train_bwd_partial")
+def _(x_t, t, dout, zstash, T, workspace):
+    return None
+
+
+@register_fake("so3x::train_bwd_reduce")
+def _(n, T, gscale, grad, workspace):
+    return None
 
 
 @register_fake("so3x::adam_step")

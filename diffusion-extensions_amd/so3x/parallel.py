@@ -35,7 +35,14 @@ def init(backend: str = None, device: str = None) -> Ctx:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device is None:
-        device = f"cuda:{local}" if torch.cuda.is_available() else "cpu"
+        if torch.cuda.is_available():
+            ndev = torch.cuda.device_count()
+            if local >= ndev and world > 1 and (backend or os.environ.get("SO3X_DIST_BACKEND") or "nccl") == "nccl":
+                raise RuntimeError(f"so3x: LOCAL_RANK {local} but {ndev} GPU(s) visible: RCCL needs one GPU per rank "
+                                   "(ranks may share a device only over SO3X_DIST_BACKEND=gloo, for testing the plumbing)")
+            device = f"cuda:{local % ndev}"
+        else:
+            device = "cpu"
     dev = torch.device(device)
     if dev.type == "cuda":
         torch.cuda.set_device(dev)

@@ -152,9 +152,14 @@ def main(argv=None):
             lval = parallel.mean_scalar(loss.detach(), ctx)
             if ctx.rank == 0:
                 print(json.dumps({"step": i, "loss": lval, "elapsed_s": round(time.time() - t0, 3)}), flush=True)
-        if i % args.save_every == 0 and ctx.rank == 0:
-            os.makedirs(os.path.dirname(args.weights) or ".", exist_ok=True)
-            torch.save(net.state_dict(), args.weights)
+        if i % args.save_every == 0:
+            if graph is not None:
+                graph.flush()  # the pipelined step is one update behind: apply it before the parameters are read (all ranks: a collective)
+            if ctx.rank == 0:
+                os.makedirs(os.path.dirname(args.weights) or ".", exist_ok=True)
+                torch.save(net.state_dict(), args.weights)
+    if graph is not None:
+        graph.flush()
     parallel.finalize(ctx)
     return net
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 4
+#define SO3X_ABI_VERSION 5
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -172,7 +172,9 @@ int so3x_mlp_bwd(so3x_stream_t s, const float* params, const float* R, const int
  * sched = device copy of the [13][T] table.  noise_in != NULL teacher-forces the noise
  * (then trap_q/axes/unif are ignored).  x_t, target, noise_out optional outputs.
  * rng_offset_dev (optional): a device-resident int64 added to rng_offset at run time, so that a captured hipGraph of a
- * training step draws fresh noise on every replay (the caller increments it inside the graph). */
+ * training step draws fresh noise on every replay (the caller increments it inside the graph).
+ * t is clamped to [0, T-1] (as so3x_p_mean_t does): an out-of-range timestep reads the nearest table row instead of
+ * memory outside the tables (the reference raises IndexError, diffusion.py:16). */
 int so3x_q_sample_target(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                          const float* x0, const int64_t* t, int quirk_col0, const float* noise_in,
                          const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset, const int64_t* rng_offset_dev,
@@ -318,22 +320,44 @@ int so3x_prevstep_loss6(so3x_stream_t s, const float* sched, int T, const float*
  *                  pass the SAME workspace, untouched, and do not change params in between.  rng_counter (optional,
  *                  device int64): read as an addend of rng_offset and incremented by one by this call, so that a
  *                  captured hipGraph of the step draws fresh noise on every replay.  out (optional): the network output.
- *                  Exactly one of t / t_draw is given.  t: the timesteps, int64 [n] (p_losses(x, t)).  t_draw: int64 [n]
- *                  OUTPUT -- the timesteps are drawn in the kernel (SO3Diffusion.forward's randint(0, T, (b,)),
- *                  diffusion.py:373), t_i = floor(T w_i / 2^32) with w_i the spare fourth word of sample i's Philox block,
- *                  so that they are, like the noise, a function of (seed, global sample index, offset) alone; pass the
- *                  buffer to so3x_train_bwd as its t.
+ *                  t (optional): the timesteps, int64 [n] (p_losses(x, t)), clamped to [0, T-1] (the reference raises
+ *                  IndexError outside that range; a kernel must not read outside its tables).  t == NULL: the timesteps are
+ *                  drawn in the kernel (SO3Diffusion.forward's randint(0, T, (b,)), diffusion.py:373), t_i = floor(T w_i /
+ *                  2^32) with w_i the spare fourth word of sample i's Philox block, so that they are, like the noise, a
+ *                  function of (seed, global sample index, offset) alone.  t_used: int64 [n] OUTPUT, always -- the timesteps
+ *                  the step ran with (drawn, or the caller's clamped); pass it to so3x_train_bwd as its t.  It never
+ *                  aliases t.  quirk_col0 (distributions.py:42-43, "column 0 is sample 0's row"): with drawn timesteps the
+ *                  row is GLOBAL sample 0's (Philox index 0 whatever index_base is: every shard of a data-parallel run uses
+ *                  the single-process run's row), with given timesteps this call's t[0].
  * so3x_train_bwd   autograd of the above wrt the 17,358 parameters (so3_train.py:75): grad[17358] = gscale[0] *
  *                  d loss / d params (gscale: device-resident upstream gradient of the scalar loss, NULL = 1).
+ * The same step in stages (version 5), for callers that pipeline it -- so3x.graphs.TrainStepGraph runs the noising of batch
+ * k+1 on a second stream beside [slab reduction -> gradient all-reduce -> Adam] of batch k:
+ *   so3x_train_fwd = so3x_train_noise (x0, draws -> x_t, t_used, the regression target inside the workspace; reads
+ *                    rng_counter, does not advance it) + so3x_train_net (prep of the weight images from params + network
+ *                    forward + stash + MSE and its gradient; advances rng_counter if given);
+ *   so3x_train_bwd = so3x_train_bwd_partial (fused backward -> per-workgroup partial slabs inside the workspace) +
+ *                    so3x_train_bwd_reduce (fixed-order sum of the slabs x gscale -> grad).
+ *   Same workspace for all four; params must not change between so3x_train_net and so3x_train_bwd_partial.
  * so3x_adam_step   torch.optim.Adam.step() (so3_train.py:64,76; amsgrad = maximize = False) on flat buffers of n
  *                  floats: the gradient is multiplied by grad_scale first (1/world_size after a summed all-reduce).
  *                  step: TWO device floats, zero-initialised once by the caller: [0] = the step count, advanced by this
  *                  call (torch's state['step']), [1] = scratch. */
 size_t so3x_train_workspace_bytes(int64_t n, int T);
 int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
-                   const float* x0, const int64_t* t, int64_t* t_draw, int quirk_col0, const float* axes, const float* unif,
+                   const float* x0, const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif,
                    uint64_t seed, uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, float* dout,
                    void* zstash, float* loss, float* out, void* workspace, size_t workspace_bytes);
+int so3x_train_noise(so3x_stream_t s, const float* sched, int T, const float* trap_q, const uint16_t* guide_q, const float* x0,
+                     const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif, uint64_t seed,
+                     uint64_t rng_offset, const int64_t* rng_counter, int64_t index_base, int64_t n, float* x_t, void* workspace,
+                     size_t workspace_bytes);
+int so3x_train_net(so3x_stream_t s, const float* params, int T, const float* x_t, const int64_t* t_used, int64_t n, float* dout,
+                   void* zstash, float* loss, float* out, int64_t* rng_counter, void* workspace, size_t workspace_bytes);
+int so3x_train_bwd_partial(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
+                           void* workspace, size_t workspace_bytes);
+int so3x_train_bwd_reduce(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace,
+                          size_t workspace_bytes);
 int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
                    const float* gscale, float* grad, void* workspace, size_t workspace_bytes);
 int so3x_adam_step(so3x_stream_t s, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n,

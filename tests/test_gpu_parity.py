@@ -519,6 +519,50 @@ def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
     assert abs(np.median(err[lanes < 32]) - np.median(err[lanes >= 32])) < 2e-3 * max(1.0, coef[1])
 
 
+@pytest.mark.parametrize("t", [950, 998, 999])
+def test_chain_bf16_step_vs_oracle_at_the_head_of_the_chain(mods, golden, net, t):
+    """the SHIPPED bf16 chain kernel (256-entry SiLU table, hardware v_sin / v_cos behind v_fract range
+    reduction, layer-0 bias split into bf16 + remainder) step-wise against the f64 oracle with the same Philox noise where the
+    reverse step is hardest: t >= 950, where x0hat = so3_scale(x_t, a_t) @ exp(-b_t v) scales a matrix log by up to 20291 and
+    the Rodrigues angle reaches 1e4 revolutions (reference diffusion.py:291-326, util.py:349-361).  The tolerance is derived in
+    conftest.reverse_step_bound: fp32 conditioning of the two logs + the bf16 network's error dv carried through
+    exp(b_t .), log and the c1_t scaling, saturating at c1_t * 2 pi.  dv = 2e-2 absolute (bf16 operands through five layers:
+    ~2e-2 relative on |v| ~ 0.3, test_chain_bf16_step_vs_oracle; generous on purpose -- at t >= 998 the bound has saturated
+    anyway, at t = 950 it contributes 1.4e-3).  A wrong schedule coefficient, noise row, trig range reduction or operand
+    exchange shows up as O(0.1 - 1) errors, far outside it."""
+    from conftest import reverse_step_bound
+    B = mods["B"]
+    T = 1000
+    proc = mods["diff"].SO3Diffusion(net, timesteps=T).to(DEV)
+    _, trap_p = proc._tables()
+    sched = O.schedule_from_betas(O.cosine_beta_schedule(T))
+    params_np = O.flat_params(golden["score_mlp"])
+    n = 640 + 37   # ten full waves and a ragged one
+    x0 = O.quat_to_rmat(np.random.default_rng(t).standard_normal((n, 4)).astype(np.float32))
+    out = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=1))
+    coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
+    v = O.mlp_fwd(params_np, x0, np.full(n, t), "f64")
+    x0h, ref = O.p_mean(x0, v, *coef, "f64")
+    _, ang, ax = B.igso3_sample(trap_p, n, row_const=t, seed=9, rng_offset=7 + t, want_angle=True, want_axis=True)
+    ref = O.rmul(ref, O.aa_to_rmat(host(ax), host(ang), "f64"), "f64")
+    _, a1 = O.rmat_to_aa(x0, "f64")
+    _, a2 = O.rmat_to_aa(x0h, "f64")
+    bound = reverse_step_bound(coef, a1[:, 0], a2[:, 0], dv=2e-2)
+    err = np.abs(out - ref).reshape(n, -1).max(1)
+    assert np.isfinite(out).all()
+    assert (err <= bound).all(), (t, float(err.max()), float(bound[np.argmax(err - bound)]))
+    assert bound.max() < 2.5e-2                      # the gate is never vacuous: c1_t * 2 pi <= 1.9e-2 plus the fp32 terms
+    assert np.abs(out @ out.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+    # the two halves of a wave must agree in quality (a broken operand exchange shows up as one bad half)
+    lanes = np.arange(n) % 64
+    assert abs(np.median(err[lanes < 32]) - np.median(err[lanes >= 32])) < 0.5 * np.median(err) + 1e-5
+    # and the fp32 parity kernel on the same step sits inside the dv = 0 bound (same derivation, no network term)
+    out32 = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=0))
+    err32 = np.abs(out32 - ref).reshape(n, -1).max(1)
+    b32 = reverse_step_bound(coef, a1[:, 0], a2[:, 0], dv=2e-6)
+    assert (err32 <= b32).all(), (t, float(err32.max()), float(b32[np.argmax(err32 - b32)]))
+
+
 def _ab_chain(proc, trap_p, params, x, t_start, n_steps, seed, rng_offset):
     """so3x_p_sample_chain (bf16) of the A/B build libso3x_ab.so through its raw C ABI.  The A/B build is the same ABI compiled
     with -DSO3X_AB_BUILD: the only library whose launcher reads the SO3X_AB_* environment switches (csrc/so3x_diffusion.hip);

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/so3x.h but not exported"
     assert declared == set(B.SYMBOLS)
-    assert B.lib().so3x_abi_version() == 4
+    assert B.lib().so3x_abi_version() == 5
 
 
 def test_no_oracle_or_cpu_fallback_in_product():
@@ -354,3 +354,26 @@ def test_torch_operator_library_registers_the_hot_path():
         out, zs = ops.mlp_fwd_stash(p, x, t, 1, 100)
         assert out.shape == (7, 3) and zs.dtype == torch.uint8 and zs.numel() == 17 * 1024
         assert ops.mlp_bwd(p, x, t, 1, out, 1, 100, zs).shape == (17358,)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_without_touching_a_gpu():
+    """VERDICT r2 missing #2: `python3 bench.py --gpus N` (the driver's plain command) used to exit with 'needs
+    torch.distributed.run'.  Now the parent starts the N ranks itself -- before it imports torch or anything that could
+    initialise a GPU (a process that has must never be replaced or forked on this pool) -- and returns the worst child's code.
+    Here, without a GPU, both children must come up with the rendezvous in their environment, rendezvous over gloo, and refuse
+    loudly (no CPU path); the parent must report failure."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    first_torch = min(n.lineno for n in ast.walk(tree) if isinstance(n, (ast.Import, ast.ImportFrom)) and n.col_offset == 0
+                      and any(a.name.split(".")[0] in ("torch", "numpy", "so3x") for a in n.names))
+    launch = next(n.lineno for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "_self_launch")
+    assert launch < first_torch, "the self-launch must come before torch is imported"
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_self_launch")
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and any(a.name.split(".")[0] == "torch" for a in n.names) for n in ast.walk(fn))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("needs an MI355X") == 2, r.stdout + r.stderr   # both ranks started, met, and refused
+    assert "needs torch.distributed.run" not in r.stdout + r.stderr

@@ -143,6 +143,37 @@ def test_resnet_chain_step_vs_oracle(B, golden, prec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("t", [950, 998, 999])
+def test_resnet_chain_bf16_step_vs_oracle_at_the_head_of_the_chain(B, golden, t):
+    """the wide network's bf16 chain kernel at t >= 950 (hardware sine / cosine on 1e4-revolution arguments), step-wise against the
+    f64 oracle with the tolerance derived in conftest.reverse_step_bound (the 65-wide twin of this test is
+    tests/test_gpu_parity.py::test_chain_bf16_step_vs_oracle_at_the_head_of_the_chain).  dv = 3e-2: bf16 operands through the
+    seven 255-wide layers (measured ~1e-2 absolute on |v| ~ 0.5)."""
+    from conftest import reverse_step_bound
+    g = golden["resnet"]
+    T = 1000
+    betas = O.cosine_beta_schedule(T)
+    sched = O.schedule_from_betas(betas)
+    sched_d = dev(B.schedule_from_betas(betas))
+    trap_p = B.igso3_build_tables(sched_d[12])
+    n = 300
+    x0 = O.quat_to_rmat(np.random.default_rng(t).standard_normal((n, 4)).astype(np.float32))
+    coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
+    v = O.resnet_fwd(g["params"], x0, np.full(n, t), "f64")
+    x0h, ref = O.p_mean(x0, v, *coef, "f64")
+    _, ang, ax = B.igso3_sample(trap_p, n, row_const=t, seed=4, rng_offset=20 + t, want_angle=True, want_axis=True)
+    ref = O.rmul(ref, O.aa_to_rmat(host(ax), host(ang), "f64"), "f64")
+    _, a1 = O.rmat_to_aa(x0, "f64")
+    _, a2 = O.rmat_to_aa(x0h, "f64")
+    for prec, dv in ((1, 3e-2), (0, 2e-6)):
+        out = host(B.resnet_p_sample_chain(dev(g["params"]), sched_d, trap_p, dev(x0), t, 1, seed=4, rng_offset=20, precision=prec))
+        err = np.abs(out - ref).reshape(n, -1).max(1)
+        bound = reverse_step_bound(coef, a1[:, 0], a2[:, 0], dv=dv)
+        assert np.isfinite(out).all() and (err <= bound).all(), (t, prec, float(err.max()), float(bound[np.argmax(err - bound)]))
+        assert np.abs(out @ out.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("prec", [0, 1])
 def test_resnet_chain_span_reproducible_and_shard_invariant(B, golden, prec):
     g = golden["resnet"]

@@ -92,7 +92,30 @@ def test_config_2_density_and_score_at_2p20(mods):
         sub = torch.randperm(n, device=DEV, generator=g)[:4096]
         ref = O.igso3_log_prob(host(R[sub]), host(ev[sub]))
         got = host(logp[sub, 0])
-        assert (np.isfinite(ref) == np.isfinite(got)).mean() > 0.995        # the same samples are beyond the reference's cut-off
+        # The finite / -inf pattern.  The reference's log-density is -inf in exactly two cases
+        # (distributions.py:53-77): (i) (w - 2 pi) exp(pi w / v) overflows float64 and `vals[vals.isinf()] = 0` zeroes the density:
+        # x + ln(2 pi - w) > ln(DBL_MAX) = 709.78 with x = pi w / v; (ii) the float64 value is below half the smallest fp32
+        # denormal and `.float()` rounds it to 0: ln f < ln 2^-150 = -103.97.  Both conditions read the angle w multiplied by
+        # up to pi / v = 8e4 (eps_0 = 6e-3), and the angle read off an fp32 rotation matrix carries ~3e-7 whatever the formula
+        # (device: atan2 in fp32; checker: float64 arithmetic on the same fp32 entries): the two sides of either threshold can
+        # differ by ~0.03 in the exponent.  So: the pattern must be IDENTICAL wherever both margins exceed 0.1, and such
+        # samples must be all but a sliver of the batch; only inside the band may a sample fall on the other side.
+        _, w64 = O.rmat_to_aa(host(R[sub]), "f64")
+        w64 = w64[:, 0].astype(np.float64)
+        v64 = host(ev[sub]).astype(np.float64) ** 2
+        x64 = np.pi * w64 / v64
+        m_over = x64 + np.log(2 * np.pi - w64) - 709.782712893384
+        e1, e2 = np.exp(-np.pi * (np.pi - w64) / v64), np.exp(-np.pi * (np.pi + w64) / v64)
+        g64 = w64 - (w64 - 2 * np.pi) * e1 - (w64 + 2 * np.pi) * e2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lnf = 0.5 * np.log(np.pi) - 1.5 * np.log(v64) + v64 / 4 - w64 ** 2 / (4 * v64) + np.log(g64) - np.log(2 * np.sin(w64 / 2))
+        m_under = lnf + 150 * np.log(2.0)
+        decided = (np.abs(m_over) > 0.1) & (np.abs(m_under) > 0.1) & (w64 > 0)
+        assert decided.mean() > 0.99, decided.mean()
+        want_finite = (m_over < 0) & (m_under > 0)
+        assert (np.isfinite(ref)[decided] == want_finite[decided]).all()    # the checker agrees with the two stated conditions
+        assert (np.isfinite(got)[decided] == np.isfinite(ref)[decided]).all(), int((np.isfinite(got) != np.isfinite(ref))[decided].sum())
+        assert (np.isfinite(ref) == np.isfinite(got)).mean() > 0.995        # and inside the band only a handful may flip
         both = np.isfinite(ref) & np.isfinite(got)
         assert both.sum() > 1000
         assert np.abs(got[both] - ref[both]).max() < 2e-4 * np.maximum(1.0, np.abs(ref[both])).max()

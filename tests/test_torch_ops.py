@@ -48,6 +48,42 @@ def test_opcheck_on_the_hot_path_operators(env):
             test_utils=("test_schema", "test_faketensor"))
 
 
+def test_opcheck_on_the_training_step_operators(env):
+    """train_fwd used to hand the caller's `t` back as an output (an alias the schema does not declare); now the
+    timesteps the step ran with are always a fresh tensor.  Schema-vs-behaviour and fake kernels of the whole-step operators
+    and of the stage operators a pipelined captured step is made of, with given and with in-kernel timesteps."""
+    from torch.library import opcheck
+    ops, B, proc, x, t, n = env["ops"], env["B"], env["proc"], env["x"], env["t"], env["n"]
+    params = env["net"].flat_data().clone()
+    checks = ("test_schema", "test_faketensor")
+    T = proc.num_timesteps
+    for tt, counter in ((t, None), (None, None), (None, torch.zeros(1, dtype=torch.int64, device=DEV))):
+        opcheck(ops.train_fwd.default, (params, proc._sched, env["trap_q"], proc._guide_q, x, tt, True, None, None, 5, 0, counter, 0, True),
+                test_utils=checks)
+    loss, carry, _ = B.train_fwd(params, proc._sched, env["trap_q"], x, t, seed=5, guide_q=proc._guide_q)
+    x_t, t_used, dout, zstash, ws = carry
+    assert t_used.data_ptr() != t.data_ptr() and torch.equal(t_used, t)
+    opcheck(ops.train_bwd.default, (x_t, t_used, dout, zstash, ws, T, None, params.numel()), test_utils=checks)
+    opcheck(ops.train_bwd.default, (x_t, t_used, dout, zstash, ws, T, torch.full((1,), 0.5, device=DEV), params.numel()), test_utils=checks)
+    buf = B.TrainBuffers(n, T, DEV, want_out=True)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    opcheck(ops.train_noise.default, (proc._sched, env["trap_q"], proc._guide_q, x, None, True, None, None, 5, 0, counter, 0, buf.x_t, buf.t_used,
+                                      buf.workspace), test_utils=checks)
+    opcheck(ops.train_noise.default, (proc._sched, env["trap_q"], proc._guide_q, x, t, True, None, None, 5, 0, None, 0, buf.x_t, buf.t_used,
+                                      buf.workspace), test_utils=checks)
+    opcheck(ops.train_net.default, (params, T, buf.x_t, buf.t_used, buf.dout, buf.zstash, buf.loss, buf.out, counter, buf.workspace),
+            test_utils=checks)
+    opcheck(ops.train_bwd_partial.default, (buf.x_t, buf.t_used, buf.dout, buf.zstash, T, buf.workspace), test_utils=checks)
+    opcheck(ops.train_bwd_reduce.default, (n, T, None, buf.grad, buf.workspace), test_utils=checks)
+    # the stages compose to the whole-step operators, bit for bit
+    B.train_noise(buf, proc._sched, env["trap_q"], x, t, seed=5, guide_q=proc._guide_q)
+    B.train_net(buf, params)
+    B.train_bwd_partial(buf)
+    g = B.train_bwd_reduce(buf)
+    assert torch.equal(buf.loss[0], loss) and torch.equal(buf.x_t, x_t) and torch.equal(buf.dout, dout)
+    assert torch.equal(g, B.train_bwd(carry, params.numel(), T))
+
+
 def test_opcheck_on_the_widened_rows(env):
     """the operators of SURVEY 8f's rows (SE(3) layer, statistics, the 255-wide network, the rotation-matrix head and its
     objective): schema, fake kernels, autograd registration, AOT dispatch -- and six2rmat's registered backward against a
