@@ -152,6 +152,13 @@ constexpr int kCdfRec = 4608, kCdfGuideOff = 999 * 4;
 static_assert(kCdfGuideOff + kGuidePitch * 2 <= kCdfRec && kCdfRec % 512 == 0, "record layout");
 inline size_t cdf_offset(int T) { return (l0t_end(T) + 255) & ~(size_t)255; }
 inline size_t cdf_end(int T) { return cdf_offset(T) + (size_t)T * kCdfRec; }
+// ... then two 64-bit words the chain kernel leaves per launch: the shader-clock ticks (s_memtime) and the 100 MHz reference ticks
+// (s_memrealtime) wave 0 of workgroup 0 spent in it -- their quotient x 100 MHz is the clock the launch actually ran at
+// (MI355X_MICROARCH.md, DVFS give-back), which bench.py needs to price the vector issue port.  Two scalar instructions at
+// either end of a launch, none inside the step loop.
+constexpr size_t kClockBytes = 64;
+inline size_t clock_offset_bf16(int T) { return (cdf_end(T) + 63) & ~(size_t)63; }
+inline size_t clock_offset_f32(int T) { return (beff_offset(SO3X_PREC_F32, CHAIN) + (size_t)T * 96 * sizeof(float) + 63) & ~(size_t)63; }
 __global__ void __launch_bounds__(256) k_prep_cdf(const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p, char* __restrict__ rec,
                                                   int t_first) {
   const int t = t_first + blockIdx.x;
@@ -186,7 +193,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                  int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
-                 uint64_t rng_offset, int64_t index_base, int64_t n, const char* __restrict__ cdf_rec) {
+                 uint64_t rng_offset, int64_t index_base, int64_t n, const char* __restrict__ cdf_rec, uint64_t* __restrict__ clk) {
   static_assert(!WIDE || (PAIR && PREC == SO3X_PREC_BF16), "the wide table belongs to the paired bf16 stream");
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   char* lds = lds_all + (WIDE ? kWideTabBytes : 0);
@@ -208,6 +215,13 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
   const int64_t nchunks = (n + 63) / 64;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  uint64_t clk0 = 0, ref0 = 0;
+  const bool stamping = clk != nullptr && wave == 0;  // wave-uniform
+  if (stamping) {
+    clk0 = __builtin_amdgcn_s_memtime();
+    ref0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) here, so that no stamp is outstanding when the step loop counts its LDS reads
+  }
   for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const int64_t idx = chunk * 64 + lane;
     const bool live = idx < n;
@@ -302,6 +316,10 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     }
 #endif
   }
+  if (stamping) {
+    const uint64_t clk1 = __builtin_amdgcn_s_memtime(), ref1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { clk[0] = clk1 - clk0; clk[1] = ref1 - ref0; }
+  }
 }
 
 // The product launcher takes no switch from anywhere but its arguments: ONE bf16 form (hardware sine / cosine, paired stream,
@@ -342,7 +360,9 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
   hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n,
-                     staged_cdf ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr);
+                     staged_cdf ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr,
+                     reinterpret_cast<uint64_t*>(const_cast<char*>(reinterpret_cast<const char*>(ws)) +
+                                                 (PREC == SO3X_PREC_BF16 ? clock_offset_bf16(T) : clock_offset_f32(T))));
   return check_launch();
 }
 
@@ -422,7 +442,12 @@ int so3x_p_mean_t(so3x_stream_t s, const float* sched, int T, const float* x, co
 size_t so3x_p_sample_workspace_bytes(int T, int precision) {
   const int p = precision == SO3X_PREC_F32 ? SO3X_PREC_F32 : SO3X_PREC_BF16;
   const int Tn = T > 0 ? T : 0;
-  return p == SO3X_PREC_BF16 ? cdf_end(Tn) : beff_offset(p, CHAIN) + (size_t)Tn * 96 * sizeof(float);
+  return (p == SO3X_PREC_BF16 ? clock_offset_bf16(Tn) : clock_offset_f32(Tn)) + kClockBytes;
+}
+
+size_t so3x_p_sample_clock_offset(int T, int precision) {
+  const int Tn = T > 0 ? T : 0;
+  return precision == SO3X_PREC_F32 ? clock_offset_f32(Tn) : clock_offset_bf16(Tn);
 }
 
 int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,

@@ -45,7 +45,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
-    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce",
+    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset",
 )
 
 
@@ -75,6 +75,7 @@ def lib():
                 l.so3x_mlp_workspace_bytes.restype = C.c_size_t
                 l.so3x_mlp_stash_bytes.restype = C.c_size_t
                 l.so3x_p_sample_workspace_bytes.restype = C.c_size_t
+                l.so3x_p_sample_clock_offset.restype = C.c_size_t
                 l.so3x_kernel_sum_workspace_bytes.restype = C.c_size_t
                 l.so3x_mse_workspace_bytes.restype = C.c_size_t
                 l.so3x_resnet_workspace_bytes.restype = C.c_size_t

@@ -9,8 +9,8 @@ itself increments, `t` is drawn in the noising kernel, and so3x.optim.Adam keeps
 
 Two forms.
 
-**Pipelined** (the default for the path BASELINE config 4 names: SO3Diffusion + the 65-wide skew-vector RotPredict with bf16
-operands + so3x.optim.Adam).  The step runs as its C-ABI stages (so3x_train_noise / _net / _bwd_partial / _bwd_reduce /
+**Pipelined** (the default, in a data-parallel run, for the path BASELINE config 4 names: SO3Diffusion + the 65-wide
+skew-vector RotPredict with bf16 operands + so3x.optim.Adam).  The step runs as its C-ABI stages (so3x_train_noise / _net / _bwd_partial / _bwd_reduce /
 so3x_adam_step, no autograd in between), and the graph boundary sits BEHIND THE FUSED BACKWARD instead of behind the optimizer:
 
     replay k:   side stream:  noise(batch k)                                      --+
@@ -60,7 +60,8 @@ class TrainStepGraph:
     """process: SO3Diffusion (or a subclass whose p_losses honours `rng_counter`); optimizer: so3x.optim.Adam, or a
     capturable torch optimizer (torch.optim.Adam(params, lr, fused=True, capturable=True)); batch_shape: the fixed shape of
     this rank's data batch; ctx: so3x.parallel.Ctx (None = single process); n_global: the global batch (for unequal shards).
-    pipeline: "auto" (pipelined where the path allows), True (required), False (the serial form).
+    pipeline: "auto" (pipelined where the path allows AND there is a gradient collective to hide, i.e. world size > 1), True
+    (pipelined, also in a single process), False (the serial form).
 
         g = TrainStepGraph(process, optim, x.shape, ctx=ctx)
         for x in data: loss = g.step(x)          # loss: 0-d device tensor, overwritten by the next replay
@@ -90,7 +91,10 @@ class TrainStepGraph:
         if pipeline is True and not eligible:
             raise ValueError("so3x: the pipelined step is built for SO3Diffusion(loss_type='skewvec', draw_t_in_kernel) + the 65-wide "
                              "skew-vector RotPredict with bf16 operands + so3x.optim.Adam")
-        self.pipelined = bool(eligible and pipeline in ("auto", True))
+        # "auto": pipelined where there is a collective to hide.  In a single process every kernel of the tail fills the chip
+        # for its few microseconds, the noising kernel finds no free wave slots beside them, and the fork / join edges cost
+        # ~2 us: measured 0.2430 vs 0.2402 ms per 2^19-sample step (bench.py train_step, round 3) -- so the serial form stays.
+        self.pipelined = bool(eligible and (pipeline is True or (pipeline == "auto" and self.world > 1)))
         snap = self._snapshot()
         self.x = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.x[..., 0, 0] = self.x[..., 1, 1] = self.x[..., 2, 2] = 1.0

@@ -194,8 +194,12 @@ int so3x_p_mean_t(so3x_stream_t s, const float* sched, int T, const float* x, co
  * network fused in: applies n_steps reverse steps t_start, t_start-1, ... to x in place
  * (x_out may alias x_in).  trap_p = CDF rows of the posterior sigma [T][999].
  * axes/unif: explicit draws for ONE step (n_steps must be 1), else in-kernel Philox with
- * counter (index_base + i, rng_offset + t).  guide_p: optional search guide of trap_p (so3x_igso3_build_guide). */
+ * counter (index_base + i, rng_offset + t).  guide_p: optional search guide of trap_p (so3x_igso3_build_guide).
+ * Diagnostics: every launch leaves two uint64 at byte so3x_p_sample_clock_offset(T, precision) of its workspace -- the
+ * shader-clock ticks and the 100 MHz reference ticks that wave 0 of workgroup 0 spent in the kernel; ticks / reference
+ * x 100 MHz = the clock the launch ran at (the chip lowers it under load; bench.py prices the vector issue port with it). */
 size_t so3x_p_sample_workspace_bytes(int T, int precision);
+size_t so3x_p_sample_clock_offset(int T, int precision);
 int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T,
                         const float* trap_p, const uint16_t* guide_p, const float* x_in, float* x_out, int t_start,
                         int n_steps, const float* axes, const float* unif, uint64_t seed,

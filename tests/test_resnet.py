@@ -333,11 +333,16 @@ def test_wide_net_training_step_as_a_captured_graph(B):
     x = B.quat_to_rmat(torch.randn(600, 4, device=DEV))
     before = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
     g = TrainStepGraph(proc, opt, x.shape, warmup=2)
+    # construction leaves no trace: the two warm-up steps (real updates on a placeholder batch) are undone -- parameters,
+    # Adam's moments and step counts, the Philox counter
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in net.parameters()]), before) and int(proc.rng_counter) == 0
+    assert all(float(st["step"]) == 0 and not st["exp_avg"].any() for st in opt.state.values())
     losses = [float(g.step(x)) for _ in range(5)]
     after = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert all(np.isfinite(losses)) and len(set(losses)) == 5
     assert float((after - before).abs().max()) > 1e-4 and torch.isfinite(after).all()
-    assert int(proc.rng_counter) == 2 + 5              # warm-up + replays (capture records, it does not execute)
+    assert int(proc.rng_counter) == 5                  # the replays only (capture records, it does not execute)
+    assert all(float(st["step"]) == 5 for st in opt.state.values())
 
 
 def _wide_from_flat(flat, precision):
