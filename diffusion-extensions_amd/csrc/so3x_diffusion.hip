@@ -184,11 +184,18 @@ constexpr int kChainKnotsBytes = 4096, kChainRowBufBytes = 8 * kCdfRec;  // LDS 
 // bf16: ONE workgroup of 8 waves per CU (the image is 55 KB and the lane-replicated SiLU table 64 KB: 119 of the CU's 160 KB).  Measured at B = 2^20 (profiles/r02_ab_chain_blocks.json): 8 waves 6.96 ms per 100 steps, 12 waves
 // 7.04, two workgroups of 4 waves 7.21, 6-wave workgroups 8.7 (they do not spread evenly over the four SIMDs).
 // fp32: 4 waves, two workgroups per CU.
-template <int PREC> constexpr int chain_threads() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }       // launch bound
+// (A/B build: the unpaired bf16 form may be launched with up to SO3X_AB_UNPAIRED_THREADS threads -- 768 = three waves per SIMD
+//  at <= 168 registers, 1024 = four at <= 128 -- to measure what occupancy buys a kernel bound by the vector issue port)
+#ifndef SO3X_AB_UNPAIRED_THREADS
+#define SO3X_AB_UNPAIRED_THREADS 512
+#endif
+template <int PREC, bool PAIR = true> constexpr int chain_threads() {       // launch bound
+  return PREC == SO3X_PREC_BF16 ? (PAIR ? 512 : SO3X_AB_UNPAIRED_THREADS) : 256;
+}
 template <int PREC> constexpr int chain_threads_default() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }
 // WIDE: the SiLU table in its lane-replicated 64 KB form at LDS address 0, the weight image behind it (so3x_mlp.hpp).
 template <int PREC, bool FAST, bool PAIR, bool WIDE>
-__global__ void __launch_bounds__(chain_threads<PREC>(), 2)
+__global__ void __launch_bounds__((chain_threads<PREC, PAIR>()), (chain_threads<PREC, PAIR>() > 512 ? chain_threads<PREC, PAIR>() / 256 : 2))
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
@@ -209,6 +216,15 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
   const bool staged = WIDE && cdf_rec != nullptr && axes == nullptr;
   if (staged)
     for (int i = threadIdx.x; i < 1000; i += blockDim.x) reinterpret_cast<float*>(knots_lds)[i] = SO3X_KNOTS_DATA[i];
+#if SO3X_STAGE_TOKEN
+  // one token per SIMD behind the 4,000 bytes of knots; a wave finds its SIMD in HW_REG_HW_ID (id 4), bits 5:4
+  unsigned* stage_token = nullptr;
+  if constexpr (WIDE) {
+    unsigned* toks = reinterpret_cast<unsigned*>(knots_lds + 4000);
+    if (threadIdx.x < 4) toks[threadIdx.x] = 0u;
+    stage_token = toks + (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3);
+  }
+#endif
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const uint32_t lt = wide_tab_lane(lane);
@@ -241,6 +257,9 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
       // ---- score network: v = RotPredict(x, t)  (diffusion.py:309)
+#if defined(SO3X_PRIO_TOP)
+      if constexpr (PAIR) __builtin_amdgcn_s_setprio(SO3X_PRIO_TOP);
+#endif
       if (s > 0) rmat_from_quat(q, R);
       const float* beff = beff_tab + (size_t)t * 96;
       float va[3], vb[3], v[3];
@@ -270,6 +289,8 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
           SO3X_STAMP(0);  // step top: rmat, scalar loads, DMA issue, prefetch
 #if SO3X_STAMPS
           forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, stamp_acc, &stamp_last);
+#elif SO3X_STAGE_TOKEN
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, stage_token);
 #else
           forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
 #endif
@@ -295,6 +316,9 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       q.w += v[0] * 1e-9f; q.x += v[1] * 1e-9f; q.y += v[2] * 1e-9f;
 #else
       SO3X_STAMP(2);  // output exchange
+#if defined(SO3X_PRIO_REVERSE)
+      if constexpr (PAIR) __builtin_amdgcn_s_setprio(SO3X_PRIO_REVERSE);
+#endif
       if (staged) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (and is visible to this wave's LDS reads)
         q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx),
@@ -345,9 +369,9 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   bool staged_cdf = WIDE;
 #ifdef SO3X_AB_BUILD
   if (PREC == SO3X_PREC_BF16 && getenv("SO3X_AB_BLOCK")) threads = atoi(getenv("SO3X_AB_BLOCK"));
-  if (threads < 64 || threads > chain_threads<PREC>() || threads % 64) return SO3X_ERR_INVALID_ARG;
+  if (threads < 64 || threads > chain_threads<PREC, PAIR>() || threads % 64) return SO3X_ERR_INVALID_ARG;
   if (ab_env("SO3X_AB_CDF", "global")) staged_cdf = false;
-  static PerDevice residents[9];  // one cache per workgroup size
+  static PerDevice residents[17];  // one cache per workgroup size
   PerDevice& resident = residents[threads / 64];
 #else
   static PerDevice resident;

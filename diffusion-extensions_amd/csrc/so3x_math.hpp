@@ -186,8 +186,11 @@ struct Philox4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+#ifndef SO3X_PHILOX_ROUNDS   /* A/B knob only: the product is Philox4x32-10 */
+#define SO3X_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < SO3X_PHILOX_ROUNDS; r++) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

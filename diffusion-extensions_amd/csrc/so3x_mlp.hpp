@@ -588,6 +588,19 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
 #ifndef SO3X_CHAIN_PRIO
 #define SO3X_CHAIN_PRIO 1
 #endif
+#ifndef SO3X_STAGE_TOKEN
+#define SO3X_STAGE_TOKEN 0
+#endif
+// the priorities themselves (A/B knobs; tools/ab/build_variant.sh): the six MFMA stages, the two head stages, the rest of a step
+#ifndef SO3X_PRIO_STAGE
+#define SO3X_PRIO_STAGE 3
+#endif
+#ifndef SO3X_PRIO_HEAD
+#define SO3X_PRIO_HEAD 1
+#endif
+#ifndef SO3X_PRIO_REST
+#define SO3X_PRIO_REST 0
+#endif
 // One stage of the paired stream laid out gap by gap: the 15 MFMAs of tile X's layer, and in the gap behind each of them a
 // slice of tile Y's activation -- table lookups for about three values, the multiply-adds of the lookups issued two gaps
 // earlier, the packing of finished pairs -- and ONE weight-fragment read (five MFMAs ahead: the fragments of output tiles 1
@@ -657,7 +670,7 @@ template <bool WIDE = false>
 #endif
 __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8 (&l0w)[3],
                                                   float* va, float* vb, int lane, uint32_t lt = 0, uint64_t* stamp_acc = nullptr,
-                                                  uint64_t* stamp_last = nullptr) {
+                                                  uint64_t* stamp_last = nullptr, unsigned* stage_token = nullptr) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
@@ -681,8 +694,20 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   // the same program at equal priority and the arbiter interleaved them instruction by instruction; with the stages on top a
   // wave in its stages keeps the matrix pipe fed and its partner's vector work fills what is left: 5.97 -> 5.51 ms per 100
   // steps.  Any split helped (reverse step on top: 5.82; network on top: 5.78; a fixed winner per SIMD: nothing).
+#if SO3X_STAGE_TOKEN
+  // A/B experiment: the two waves of a SIMD take turns in the six MFMA stages (a per-SIMD token in LDS), so that a wave's
+  // stages run beside its partner's vector phases instead of beside its partner's stages
+  if (stage_token) {
+    for (;;) {
+      unsigned got = 1;
+      if (lane == 0) got = atomicCAS(stage_token, 0u, 1u);
+      if (__builtin_amdgcn_readfirstlane(got) == 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+#endif
 #if SO3X_CHAIN_PRIO
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(SO3X_PRIO_STAGE);
 #endif
 #pragma unroll
   for (int l = 1; l < 4; l++) {
@@ -703,8 +728,11 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
 #endif
   }
   SO3X_FP_STAMP(5);  // the six 15-MFMA stages
+#if SO3X_STAGE_TOKEN
+  if (stage_token && lane == 0) atomicExch(stage_token, 0u);
+#endif
 #if SO3X_CHAIN_PRIO
-  __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(SO3X_PRIO_HEAD);
 #endif
   f32x16 lastA[1], lastB[1];
   SO3X_STAGE_FENCE;
@@ -714,7 +742,7 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
 #if SO3X_CHAIN_PRIO
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(SO3X_PRIO_REST);
 #endif
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = lastA[0][k]; vb[k] = lastB[0][k]; }
