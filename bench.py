@@ -373,7 +373,7 @@ def igso3_eval_roofline(B, torch, n=1 << 20, reps=50, eps_input="schedule", sche
             "evals_per_s": n / (ms * 1e-3), "bound": "hbm", "achieved": gbs,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "n": n, "ms": ms,
             "bytes_per_eval": bytes_per_eval, "launches": reps, "timing": "HIP events around a graph replay",
-            "finite_logp_frac": finite, "traffic": pmc_traffic("k_logprob_score", n=n, eps_input=eps_input)}
+            "finite_logp_frac": finite, "traffic": pmc_traffic("k_logprob_score:" + eps_input, n=n, eps_input=eps_input)}
 
 
 def se3_legs(B, torch, reps=20):

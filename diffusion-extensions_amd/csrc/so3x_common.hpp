@@ -199,6 +199,31 @@ __device__ __forceinline__ void wave_commit9(const Pref9& p, float* wlds, float*
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same prefetch with NO registers held: the tile's 2,304 bytes go global -> LDS by LDS-DMA (three global_load_lds_dwordx4:
+// 64 + 64 + 16 lanes x 16 B), asynchronously; wave_dma9_commit waits for them (vmcnt) and reads the lane's nine floats.
+// Full, 16-byte-aligned tiles only.  The staging buffer must not be touched in between.
+__device__ __forceinline__ void wave_dma9(const float* __restrict__ g, int64_t base, float* wlds) {
+  const int lane = threadIdx.x & 63;
+  const char* src = reinterpret_cast<const char*>(g + base * 9) + lane * 16;
+  char* dst = reinterpret_cast<char*>(wlds);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's earlier reads of the buffer are done before new data may land
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
+                                   (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+  if (lane < 16)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2048),
+                                     (__attribute__((address_space(3))) void*)(dst + 2048), 16, 0, 0);
+}
+__device__ __forceinline__ void wave_dma9_commit(const float* wlds, float* r) {
+  const int lane = threadIdx.x & 63;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed and are visible to this wave's LDS reads
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 9; j++) r[j] = wlds[lane * 9 + j];
+  __builtin_amdgcn_wave_barrier();
+}
+
 // A lane's whole rotation (36 contiguous bytes, 4-byte aligned) moved with three wide accesses
 // (dwordx4 + dwordx3 + dwordx2) instead of nine 4-byte ones at a 36-byte lane stride: the nine
 // partial-line stores showed up as 5.8x WRITE_SIZE inflation in the PMC pass of round 1.

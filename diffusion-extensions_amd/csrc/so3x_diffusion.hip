@@ -72,6 +72,12 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
     const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
     const int64_t idx = base + lane;
     const bool live = lane < cnt;
+    // LEAN: the tile's x0 is requested FIRST (LDS-DMA straight into the wave's staging buffer: no registers held) and lands while the noise chain runs
+    // -- Philox, timestep, guide, CDF window: two dependent L2 round trips -- instead of behind it: with one tile per wave and
+    // every wave of the launch resident at once, all waves walk their dependent round trips in step and each one adds to the
+    // kernel's time
+    const bool prefetched = LEAN && cnt == kWave && ((reinterpret_cast<uintptr_t>(x0 + base * 9) & 15) == 0);
+    if (prefetched) wave_dma9(x0, base, wl);
     Philox4 r;
     if (!t || (!noise_in && !axes)) r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
     int64_t tt;
@@ -79,6 +85,7 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
     else tt = drawn_t(r.w);
     if (t_draw && live) t_draw[idx] = tt;  // the timesteps the kernels behind this one gather with: drawn here, or the caller's, clamped
     float nz[9];
+    float nlog[3] = {0.f, 0.f, 0.f};  // LEAN: axis * angle of the noise drawn here
     if (noise_in) {
       wave_load_rows<9>(noise_in, base, cnt, wl, nz);
     } else {
@@ -95,13 +102,20 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
         unit_axis(r.x, r.y, ax);
         u = u01(r.z);
       }
-      const float* row = trap_q + tt * 999;
+#ifdef SO3X_QS_SAME_ROW  /* timing experiment only (tools/ab): every lane searches row 500 -- what do the per-sample rows cost? */
+      const int64_t tq = 500;
+#else
+      const int64_t tq = tt;
+#endif
+      const float* row = trap_q + tq * 999;
       const float* wrow = wrow_t >= 0 ? trap_q + wrow_t * 999 : row;
-      const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tt * kGuidePitch : nullptr);
+      const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tq * kGuidePitch : nullptr);
       exp_axis_angle(ax, ang, nz);
+      if constexpr (LEAN) { nlog[0] = ax[0] * ang; nlog[1] = ax[1] * ang; nlog[2] = ax[2] * ang; }
     }
     float x[9], w[3], xs[9], xt[9];
-    wave_load_rows<9>(x0, base, cnt, wl, x);
+    if (prefetched) wave_dma9_commit(wl, x);
+    else wave_load_rows<9>(x0, base, cnt, wl, x);
     const float k = sched[S_SQRT_AC * T + tt];
     log3(x, w);
     w[0] *= k; w[1] *= k; w[2] *= k;
@@ -110,7 +124,11 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
     if (x_t) wave_store_rows<9>(x_t, base, cnt, wl, xt);
     if (target) {
       float lw[3];
-      log3(nz, lw);                   // skew2vec(log_rmat(noise)) * (1/eps), :355
+      // skew2vec(log_rmat(noise)) * (1/eps), :355.  LEAN (the noise was built here from a unit axis and an angle in [0, pi]):
+      // log(exp(hat(axis * angle))) IS axis * angle -- taken directly instead of through the matrix and an atan2 log, which
+      // can only return it with the fp32 rounding of nine matrix entries on top (amplified by 1 / (pi - angle) near pi)
+      if constexpr (LEAN) { lw[0] = nlog[0]; lw[1] = nlog[1]; lw[2] = nlog[2]; }
+      else log3(nz, lw);
       const float ie = 1.0f / sched[S_SQRT_1MAC * T + tt];
       float tg[3] = {lw[0] * ie, lw[1] * ie, lw[2] * ie};
       wave_store_rows<3>(target, base, cnt, wl, tg);

@@ -104,7 +104,7 @@ k_igso3_sample(const float* __restrict__ trap, const uint16_t* __restrict__ guid
     const int64_t ri = live ? (row_idx ? row_idx[idx] : row_const) : (row_idx ? row_idx[base] : row_const);
     const float* row = trap + ri * 999;
     const float* wrow = wrow_i >= 0 ? trap + wrow_i * 999 : row;
-    float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, guide ? guide + ri * kGuidePitch : nullptr);
+    float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, guide ? guide + ri * kGuidePitch : nullptr);
     float r9[9], o[9];
     exp_axis_angle(ax, ang, r9);
     if (mean) {

@@ -803,7 +803,7 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
     if (!live) { ax[0] = 1.0f; ax[1] = 0.0f; ax[2] = 0.0f; u = 0.5f; }     // dead lanes carry well-defined values: their stash columns are read
     const float* row = na.trap_q + tt * 999;
     const float* wrow = wrow_t >= 0 ? na.trap_q + wrow_t * 999 : row;
-    const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, na.guide_q ? na.guide_q + tt * kGuidePitch : nullptr);
+    const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, na.guide_q ? na.guide_q + tt * kGuidePitch : nullptr);
     float nz[9], x[9], w[3], xs[9], xt[9], tg[3];
     exp_axis_angle(ax, ang, nz);
     wave_load_rows<9>(na.x0, base, cnt, wl, x);

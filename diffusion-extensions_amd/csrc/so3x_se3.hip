@@ -56,7 +56,7 @@ k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __res
     }
     const float* row = trap_q + tt * 999;
     const float* wrow = wrow_t >= 0 ? trap_q + wrow_t * 999 : row;
-    const float ang = igso3_angle(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tt * kGuidePitch : nullptr);
+    const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tt * kGuidePitch : nullptr);
     float nz[9], x[9], w[3], xs[9], xt[9], sh[3];
     exp_axis_angle(ax, ang, nz);
     load_rows<9>(x0_rot, base, cnt, sm, x);

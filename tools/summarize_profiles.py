@@ -30,9 +30,10 @@ if trace:
                "ms_100_step_launches_median": statistics.median(short), "ms_100_step_launches_mean": sum(short) / len(short),
                "n_100_step_launches": len(short)}, open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
 
-KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_q_sample_target",
-           "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw")
+KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_se3_q_sample_target",
+           "k_q_sample_target", "k_rigid_move", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_reduce", "k_adam", "k_prep")
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
+legs = {}  # counter -> the k_logprob_score dispatches at 2^20 evaluations in dispatch order, split into bench.py's three legs
 for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
     f = glob.glob(os.path.join(d, "*counter_collection.csv"))
     if not f:
@@ -48,6 +49,20 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
         short = next((k for k in KERNELS if k in kname), None)
         if short:
             per.setdefault(cname, {}).setdefault((short, grid), []).append(v)
+    # bench.py times k_logprob_score at 2^20 evaluations on three inputs, in this order: eps from the schedule (config 2b),
+    # [the 2^24 run], scalar eps (2a), eps ~ U(0.1, 1); same kernel, same grid -- told apart by dispatch order
+    lp = sorted((int(did), grid) for did, (kname, grid) in meta.items() if "k_logprob_score" in kname)
+    if lp:
+        small = min(g for _, g in lp)
+        big_ids = [d for d, g in lp if g != small]
+        first_big, last_big = (min(big_ids), max(big_ids)) if big_ids else (1 << 62, 1 << 62)
+        after = [d for d, g in lp if g == small and d > last_big]
+        groups = {"schedule": [d for d, g in lp if g == small and d < first_big], "scalar": after[:len(after) // 2], "uniform": after[len(after) // 2:]}
+        for cname in set(c for _, c in disp):
+            for leg, ids in groups.items():
+                vals = [disp[(str(d), cname)] for d in ids if (str(d), cname) in disp]
+                if vals:
+                    legs.setdefault(cname, {})[leg] = statistics.median(vals)
 rows = []
 for cname, ks in sorted(per.items()):
     for (k, grid), vals in sorted(ks.items()):
@@ -89,11 +104,22 @@ if lg:
     traffic["k_logprob_score"] = dict(config={"n": 1 << 20}, algorithmic_bytes_per_launch=56 << 20, **rec(small))
     if big is not small:
         traffic["k_logprob_score"]["at_n_2p24"] = dict(algorithmic_bytes_per_launch=56 << 24, **rec(big))
+    for leg, nbytes in (("schedule", 56), ("scalar", 52), ("uniform", 56)):   # per input of bench.py's igso3_eval legs
+        f_, w_ = legs.get("FETCH_SIZE", {}).get(leg), legs.get("WRITE_SIZE", {}).get(leg)
+        if f_ is not None and w_ is not None:
+            traffic["k_logprob_score:" + leg] = {"config": {"n": 1 << 20, "eps_input": leg}, "algorithmic_bytes_per_launch": nbytes << 20,
+                                                 "fetch_size_kb": f_, "write_size_kb": w_, "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
+for k, cfg, alg in (("k_rigid_move", {"structures": 4096, "residues": 256}, 96 * 4096 * 256), ("k_se3_q_sample_target", {"n": 1 << 20}, 128 << 20),
+                    ("k_q_sample_target", {"n": 1 << 19}, 92 << 19), ("k_mlp_fwd_stash", {"n": 1 << 19}, None), ("k_bwd_fused", {"n": 1 << 19}, None)):
+    f_, w_ = mean("FETCH_SIZE", k), mean("WRITE_SIZE", k)
+    if f_ is not None and w_ is not None:
+        traffic[k] = {"config": cfg, "algorithmic_bytes_per_launch": alg, "fetch_size_kb": f_, "write_size_kb": w_,
+                      "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
 # matrix-pipe utilisation of the two chain kernels.  SQ_VALU_MFMA_BUSY_CYCLES sums the cycles each SIMD's matrix pipe is
 # executing (= MFMAs x 32 for v_mfma_f32_32x32x16_bf16, checked against SQ_INSTS_VALU_MFMA_MOPS_BF16); SQ_BUSY_CYCLES is
 # the kernel's duration in shader cycles counted once per shader engine (32 on this chip: 8 XCDs x 4).
 util = {}
-for k in ("k_p_sample_chain", "k_resnet_chain"):
+for k in ("k_p_sample_chain", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_q_sample_target"):
     busy, sqb = mean("SQ_VALU_MFMA_BUSY_CYCLES", k), mean("SQ_BUSY_CYCLES", k)
     if busy and sqb:
         util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sqb, "simds": 1024, "shader_engines": 32,
