@@ -879,6 +879,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L, int ch, uint32_t lo, uint32_t hi) {
+#if SO3X_BWD_ABL & 4
+  if (ch != 0) return;
+#endif
   *reinterpret_cast<uint2*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = uint2{lo, hi};
 }
 // one pass over a layer's pre-activations: packed H = silu(Z) (with the constant-one row in the upper half of tile 2) and
@@ -888,11 +891,31 @@ __device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L,
 // 33 multiplies per pass off the chain wave (9 % of its vector instructions).
 // (MASK: the recomputing variant keeps the multiply by the live flag -- without it the register allocator of THAT kernel,
 //  which spills already, does worse.)
+// -DSO3X_BWD_ABL=<bits> (timing experiments only, tools/ab; results meaningless): 1 = the dW waves skip their MFMAs and operand
+// reads (they still meet every barrier), 2 = the chain waves skip the dH MFMAs, 4 = the chain waves skip their image stores
+#ifndef SO3X_BWD_ABL
+#define SO3X_BWD_ABL 0
+#endif
+#if SO3X_BWD_ABL & 1
+#define SO3X_DW_MFMA(a, b, c) (c)
+#else
+#define SO3X_DW_MFMA(a, b, c) mfma_bf16(a, b, c)
+#endif
+// -DSO3X_BWD_ABL_SILU=<k> (timing experiments only, tools/ab): the first k register pairs of a pass keep the real arithmetic, the
+// rest copy z through (results meaningless) -- how much of the backward is the chain wave's transcendental stream?
+#ifndef SO3X_BWD_ABL_SILU
+#define SO3X_BWD_ABL_SILU 16
+#endif
 template <int PREC, bool MASK = false>
 __device__ __forceinline__ void silu_pass(const Z33h& z, int h, uint32_t (&ph)[17], float (&dv)[33], float lv = 1.0f) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     float a0, a1;
+    if (r >= SO3X_BWD_ABL_SILU) {
+      a0 = z.get(2 * r); a1 = z.get(2 * r + 1); dv[2 * r] = 1.0f; dv[2 * r + 1] = 0.5f;
+      ph[r] = pack_bf16x2(a0, a1);
+      continue;
+    }
     silu_grad<PREC>(z.get(2 * r), &a0, &dv[2 * r]);
     silu_grad<PREC>(z.get(2 * r + 1), &a1, &dv[2 * r + 1]);
     ph[r] = MASK ? pack_bf16x2(a0 * lv, a1 * lv) : pack_bf16x2(a0, a1);
@@ -918,7 +941,13 @@ __device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const u
     __builtin_amdgcn_sched_barrier(0);
     f32x16 a = zero16<PREC>();
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) a = mfma_bf16(w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane], b[ks], a);
+    for (int ks = 0; ks < KS; ks++) {
+#if SO3X_BWD_ABL & 2
+      a[ks] += __builtin_bit_cast(float, pdz[ks]);
+#else
+      a = mfma_bf16(w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane], b[ks], a);
+#endif
+    }
     dh[to] = a;
   }
 }
@@ -955,7 +984,7 @@ __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, fl
           for (int w = 0; w < 4; w++) {
             const char* im = fimg_all + w * FIMG_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) acc[9] = mfma_bf16(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
+            for (int ks = 0; ks < 2; ks++) acc[9] = SO3X_DW_MFMA(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
           }
         }
       } else if (dw_row(DWI, l) != 3) {
@@ -969,7 +998,7 @@ __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, fl
           for (int ks = 0; ks < 2; ks++) {
             const bf16x8 a = fimg_frag(im, RL, 32 * to, ks);
 #pragma unroll
-            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
+            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = SO3X_DW_MFMA(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
           }
         }
       }
