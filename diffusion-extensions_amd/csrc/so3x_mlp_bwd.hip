@@ -648,9 +648,9 @@ __device__ __forceinline__ void keep_h_folded(const f32x16 (&u)[3], Z33h& z) {
 // Every layer's pre-activations leave for the stash as soon as they exist (ztile: the tile's 17 KB, nullptr = a padding
 // tile): four 4-KB bursts spread over the tile's compute instead of one 17-KB burst behind it -- the stash is 285 MB per 2^19
 // samples, written at the HBM's store rate, and waves that all store at once serialise with their compute.
-template <int XSRC>
+template <int XSRC, bool WIDE = false>
 __device__ __forceinline__ void stash_forward_tile(const char* __restrict__ lds, const float* __restrict__ beff_row, const float* x,
-                                                   char* __restrict__ ztile, f32x16 (&last)[1], int lane) {
+                                                   char* __restrict__ ztile, f32x16 (&last)[1], int lane, uint32_t lt = 0) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_T, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = lds + (size_t)n_frags<PREC, VAR>() * FB;
@@ -662,12 +662,12 @@ __device__ __forceinline__ void stash_forward_tile(const char* __restrict__ lds,
   if (ztile) zstash_store_layer(ztile, lane, 0, z);
 #pragma unroll
   for (int l = 1; l < 4; l++) {
-    activate_bf16<true>(a3, cur, h, tab);
+    activate_bf16<true, WIDE>(a3, cur, h, tab, lt);
     hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, a3, lane);
     keep_h_folded(a3, z);
     if (ztile) zstash_store_layer(ztile, lane, l, z);
   }
-  activate_bf16<true>(a3, cur, h, tab);
+  activate_bf16<true, WIDE>(a3, cur, h, tab, lt);
   hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane);
 }
 
@@ -741,6 +741,226 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------
+// k_mlp_fwd_stash with the lane-replicated 64 KB SiLU table (2-instruction lookup instead of 3): ONE 16-wave workgroup per CU
+// shares the table and the image (121 KB), still four waves per SIMD.  MEASURED AND NOT SHIPPED: bit-identical and the same
+// time (235.2-235.6 against 235.7-235.8 us per step, profiles/r03_ab_train_fwd_paired.json) -- 264 vector instructions fewer
+// per tile buy nothing in a kernel bound by its 285 MB of stash stores.  -DSO3X_TRAIN_FWD_WIDE=1 selects it (A/B only).
+// ---------------------------------------------------------------------------------------
+#ifndef SO3X_TRAIN_FWD_WIDE
+#define SO3X_TRAIN_FWD_WIDE 0
+#endif
+#if SO3X_TRAIN_FWD_WIDE
+constexpr int kFwdWideThreads = 1024;
+template <bool LOSS>
+__global__ void __launch_bounds__(kFwdWideThreads, 4)
+k_mlp_fwd_stash_wide(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
+                     const int64_t* __restrict__ t, float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_T, FB = frag_bytes<PREC>();
+  char* lds = lds_all + kWideTabBytes;
+  load_image(gimg, lds, image_bytes<PREC, VAR>());
+  {
+    typedef __attribute__((address_space(3))) char* lds_cp;
+    if ((uint32_t)(uintptr_t)(lds_cp)lds_all != 0u) __builtin_trap();  // the byte-insert addressing needs the table at LDS address 0
+  }
+  fill_wide_tab(reinterpret_cast<const char*>(gimg) + (size_t)n_frags<PREC, VAR>() * FB);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const uint32_t lt = wide_tab_lane(lane);
+  const int64_t ntiles = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float sq = 0.0f;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    int64_t idx = tile * 32 + col;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    float x[9];
+    load_rot9(R, idx, x);
+    const int64_t tt = t[idx];
+    f32x16 last[1];
+    stash_forward_tile<0, true>(lds, beff_tab + (size_t)tt * 96, x, zstash + (size_t)tile * ZSTASH_TILE, last, lane, lt);
+    if (live && h == 0) {
+      if (out) { out[idx * 3] = last[0][0]; out[idx * 3 + 1] = last[0][1]; out[idx * 3 + 2] = last[0][2]; }
+      if constexpr (LOSS) {
+        const float d0 = last[0][0] - la.target[idx * 3], d1 = last[0][1] - la.target[idx * 3 + 1], d2 = last[0][2] - la.target[idx * 3 + 2];
+        la.dout[idx * 3] = d0 * la.dscale; la.dout[idx * 3 + 1] = d1 * la.dscale; la.dout[idx * 3 + 2] = d2 * la.dscale;
+        sq += d0 * d0 + d1 * d1 + d2 * d2;
+      }
+    }
+  }
+  if constexpr (LOSS) {
+    // (no static __shared__ here: the table must sit at LDS address 0, i.e. the dynamic block comes first)
+    constexpr int NW = kFwdWideThreads / 64;
+    double* wsum = reinterpret_cast<double*>(lds + ((image_bytes<PREC, VAR>() + 15) & ~15));
+    int& is_last = *reinterpret_cast<int*>(wsum + NW);
+    double v = (double)sq;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (lane == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double bs = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w += 4) bs += (wsum[w] + wsum[w + 1]) + (wsum[w + 2] + wsum[w + 3]);
+      __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = last_block_arrives(la.ticket) ? 1 : 0;
+    }
+    __syncthreads();
+    if (is_last) {
+      double a = 0.0;
+      for (unsigned b = threadIdx.x; b < gridDim.x; b += kFwdWideThreads) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+      __syncthreads();
+      if (lane == 0) wsum[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) tot += (wsum[w] + wsum[w + 1]) + (wsum[w + 2] + wsum[w + 3]);
+        la.loss[0] = (float)(tot * la.inv_count);
+        if (la.rng_counter) la.rng_counter[0] += 1;
+      }
+    }
+  }
+}
+
+#endif  // SO3X_TRAIN_FWD_WIDE
+
+// ---------------------------------------------------------------------------------------
+// The training forward as the chain kernel's PAIRED stream (round 3).  k_mlp_fwd_stash above runs one 32-sample tile after the
+// other with the 3-instruction table lookup at four waves per SIMD; the reverse chain's network phase does the same arithmetic
+// in half the time (26 us against 49 us of compute per 2^19 samples) because a wave there owns TWO tiles and each stage lays
+// tile Y's activation -- the 2-instruction lookup in the lane-replicated 64 KB table -- into the gaps of tile X's 15 MFMAs
+// (stage_gaps, so3x_mlp.hpp).  Here: a wave owns 64 consecutive samples (lane = sample for x_t and t; tile A = samples 0..31,
+// tile B = 32..63), layer 0 keeps the per-sample effective-bias rows of the GATHER_T layout (every sample has its own
+// timestep), the six stages are the chain kernel's, and a tile's pre-activations leave for the stash right behind the stage
+// that produced them (the same 17 dwords per lane and layer, same tile order: the fused backward reads them unchanged).
+// Bit-identical outputs, stash and loss to k_mlp_fwd_stash (same MFMA order per tile, same table entries).
+// LDS: 64 KB table at address 0 + the 57 KB image: one 8-wave workgroup per CU.
+// ---------------------------------------------------------------------------------------
+// MEASURED AND NOT SHIPPED (profiles/r03_ab_train_fwd_paired.json): bit-identical, and 5 us SLOWER per 2^19-sample step (237.9 against
+// 232.6 us).  The chain kernel's network phase has no memory traffic inside a step; here every 64-sample chunk opens with an HBM
+// round trip for x_t and t and 18 dependent 16-byte gathers of per-sample bias rows per lane (201 MB of L2 traffic per launch),
+// and closes each stage with its stash stores -- at TWO waves per SIMD (230 registers) that latency is exposed, at the four
+// of the one-tile-at-a-time kernel it is covered.  Kept behind -DSO3X_TRAIN_FWD_PAIR=1 for the A/B only.
+#ifndef SO3X_TRAIN_FWD_PAIR
+#define SO3X_TRAIN_FWD_PAIR 0
+#endif
+#if SO3X_TRAIN_FWD_PAIR
+template <bool LOSS>
+__global__ void __launch_bounds__(kFwdStashThreads, 2)
+k_mlp_fwd_stash_pair(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
+                     const int64_t* __restrict__ t, float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_T, FB = frag_bytes<PREC>();
+  char* lds = lds_all + kWideTabBytes;
+  load_image(gimg, lds, image_bytes<PREC, VAR>());
+  {
+    typedef __attribute__((address_space(3))) char* lds_cp;
+    if ((uint32_t)(uintptr_t)(lds_cp)lds_all != 0u) __builtin_trap();  // the byte-insert addressing needs the table at LDS address 0
+  }
+  fill_wide_tab(reinterpret_cast<const char*>(gimg) + (size_t)n_frags<PREC, VAR>() * FB);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const uint32_t lt = wide_tab_lane(lane);
+  const char* tab = lds + (size_t)n_frags<PREC, VAR>() * FB;  // (the narrow table: unused by the WIDE lookups)
+  const int64_t nchunks = (n + 63) / 64, ntiles = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const char* wlast = lds + (size_t)frag_last<PREC, VAR>() * FB;
+  float sq = 0.0f;
+  for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const int64_t idx = chunk * 64 + lane;
+    const int64_t idc = idx < n ? idx : n - 1;
+    float x[9];
+    load_rot9(R, idc, x);
+    const int tt = (int)t[idc];
+    const int ttA = __shfl(tt, col), ttB = __shfl(tt, 32 + col);  // the timestep of this lane's COLUMN in either tile
+    char* ztA = zstash + (size_t)(2 * chunk) * ZSTASH_TILE;
+    char* ztB = ztA + ZSTASH_TILE;
+    const bool haveB = 2 * chunk + 1 < ntiles;
+    f32x16 accA[3], accB[3];
+    Tile<PREC> curA, curB;
+    Z33h z;
+    layer0_chain<PREC, 1>(lds, beff_tab + (size_t)ttA * 96, x, accA, lane);
+    layer0_chain<PREC, 2>(lds, beff_tab + (size_t)ttB * 96, x, accB, lane);
+    keep_h_folded(accA, z);
+    zstash_store_layer(ztA, lane, 0, z);
+    keep_h_folded(accB, z);
+    if (haveB) zstash_store_layer(ztB, lane, 0, z);
+    bf16x8 pre[5];
+    prefetch_tile0(lds + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
+    activate_bf16<true, true>(accA, curA, h, tab, lt);
+#pragma unroll
+    for (int l = 1; l < 4; l++) {
+      const char* wl = lds + (size_t)frag_hidden<PREC, VAR>(l) * FB;
+      const char* wnext = l < 3 ? lds + (size_t)frag_hidden<PREC, VAR>(l + 1) * FB : wlast;
+      SO3X_STAGE_FENCE;
+      stage_gaps<true>(wl, wl, curA, accA, accB, curB, pre, lane, h, tab, lt);     // MFMA A, layer l || activation B, layer l-1
+      keep_h_folded(accA, z);
+      zstash_store_layer(ztA, lane, l, z);
+      SO3X_STAGE_FENCE;
+      stage_gaps<true>(wl, wnext, curB, accB, accA, curA, pre, lane, h, tab, lt);  // MFMA B, layer l || activation A, layer l
+      keep_h_folded(accB, z);
+      if (haveB) zstash_store_layer(ztB, lane, l, z);
+    }
+    f32x16 lastA[1], lastB[1];
+    SO3X_STAGE_FENCE;
+    mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A || activation B, layer 3
+    prefetch_tile0(wlast, lane, pre);
+    activate_bf16<true, true>(accB, curB, h, tab, lt);
+    SO3X_STAGE_FENCE;
+    mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
+    if (h == 0) {  // head outputs = regs 0..2 of the lower half: column c of tile A is sample 64 chunk + c, of tile B 32 more
+#pragma unroll
+      for (int tile = 0; tile < 2; tile++) {
+        const int64_t s = chunk * 64 + 32 * tile + col;
+        if (s >= n) continue;
+        const float o0 = tile ? lastB[0][0] : lastA[0][0], o1 = tile ? lastB[0][1] : lastA[0][1], o2 = tile ? lastB[0][2] : lastA[0][2];
+        if (out) { out[s * 3] = o0; out[s * 3 + 1] = o1; out[s * 3 + 2] = o2; }
+        if constexpr (LOSS) {
+          const float d0 = o0 - la.target[s * 3], d1 = o1 - la.target[s * 3 + 1], d2 = o2 - la.target[s * 3 + 2];
+          la.dout[s * 3] = d0 * la.dscale; la.dout[s * 3 + 1] = d1 * la.dscale; la.dout[s * 3 + 2] = d2 * la.dscale;
+          sq += d0 * d0 + d1 * d1 + d2 * d2;
+        }
+      }
+    }
+  }
+  if constexpr (LOSS) {
+    // (no static __shared__ in this kernel: the table must sit at LDS address 0, i.e. the dynamic block must come first)
+    double* wsum = reinterpret_cast<double*>(lds + ((image_bytes<PREC, VAR>() + 15) & ~15));
+    int& is_last = *reinterpret_cast<int*>(wsum + kFwdStashThreads / 64);
+    double v = (double)sq;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (lane == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double bs = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
+      __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = last_block_arrives(la.ticket) ? 1 : 0;
+    }
+    __syncthreads();
+    if (is_last) {
+      double a = 0.0;
+      for (unsigned b = threadIdx.x; b < gridDim.x; b += kFwdStashThreads) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+      if (lane == 0) wsum[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        la.loss[0] = (float)((((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * la.inv_count);
+        if (la.rng_counter) la.rng_counter[0] += 1;
+      }
+    }
+  }
+}
+
+#endif  // SO3X_TRAIN_FWD_PAIR
 
 // ---------------------------------------------------------------------------------------
 // The training forward with the forward noising fused in (diffusion.py:348-357 in ONE launch): a wave owns 64 samples.
@@ -1420,12 +1640,36 @@ int so3x_train_net(so3x_stream_t s, const float* params, int T, const float* x_t
   la.inv_count = 1.0 / (3.0 * (double)n);
   la.target = reinterpret_cast<float*>(ws + L.target);
   const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
+#if SO3X_TRAIN_FWD_WIDE
+  {  // one 16-wave workgroup per CU around the 64 KB table + the image
+    constexpr int LDSW = kWideTabBytes + ((IMG + 15) & ~15) + 256;
+    static PerDevice resident_w;
+    int max_blocks = 0;
+    if ((rc = resident_blocks(resident_w, reinterpret_cast<const void*>(&k_mlp_fwd_stash_wide<true>), kFwdWideThreads, LDSW, &max_blocks))) return rc;
+    const int64_t ntiles = (n + 31) / 32, want = (ntiles + 15) / 16;
+    hipLaunchKernelGGL((k_mlp_fwd_stash_wide<true>), dim3((int)(want < max_blocks ? want : max_blocks)), dim3(kFwdWideThreads), LDSW, st,
+                       (const void*)ws, beff, x_t, t_used, out, (char*)zstash, n, la);
+    return check_launch();
+  }
+#elif SO3X_TRAIN_FWD_PAIR
+  {  // the paired stream: one 8-wave workgroup per CU (64 KB table + image), 64 samples per wave
+    constexpr int LDSB = kWideTabBytes + ((IMG + 15) & ~15) + 128;  // table + image + the loss epilogue's eight partials and flag
+    static PerDevice resident;
+    int max_blocks = 0;
+    if ((rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_mlp_fwd_stash_pair<true>), kFwdStashThreads, LDSB, &max_blocks))) return rc;
+    const int64_t nchunks = (n + 63) / 64, want = (nchunks + 7) / 8;
+    hipLaunchKernelGGL((k_mlp_fwd_stash_pair<true>), dim3((int)(want < max_blocks ? want : max_blocks)), dim3(kFwdStashThreads), LDSB, st,
+                       (const void*)ws, beff, x_t, t_used, out, (char*)zstash, n, la);
+    return check_launch();
+  }
+#else
   static PerDevice attr;
   if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
   const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
   hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, st, (const void*)ws,
                      beff, x_t, t_used, (int64_t)1, out, (char*)zstash, n, 3, la);
   return check_launch();
+#endif
 }
 
 int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
