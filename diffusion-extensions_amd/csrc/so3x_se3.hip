@@ -20,31 +20,46 @@ __device__ __forceinline__ void unit_axis_from(const float* a, float* ax) {  // 
   ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
 }
 
-// q_sample + p_losses targets: 84 B (rotation) + 24 B in / 24 B out (shift) per sample
-__global__ void __launch_bounds__(kBlock)
+// q_sample + p_losses targets: 84 B (rotation) + 24 B in / 24 B out (shift) per sample.
+// Round 3: laid out like k_q_sample_target (so3x_diffusion.hip) -- wave-private staging, one 64-frame tile per wave on an
+// oversubscribed grid (no workgroup barrier: the per-frame CDF-row search is a chain of dependent L2 round trips that only other
+// resident waves hide), and with in-kernel draws (LEAN) the frame's rotation tile comes in by LDS-DMA while the noise chain runs
+// and the rotation target is axis * angle itself.  timesteps are clamped to [0, T-1] as everywhere.
+template <bool LEAN>
+__global__ void __launch_bounds__(kBlock, LEAN ? 6 : 4)
 k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __restrict__ trap_q,
                       const uint16_t* __restrict__ guide_q, float shift_scale,
                       const float* __restrict__ x0_rot, const float* __restrict__ x0_shift, const int64_t* __restrict__ t,
-                      int quirk_col0, const float* __restrict__ axes, const float* __restrict__ unif,
-                      const float* __restrict__ znorm, uint64_t seed, uint64_t rng_offset, int64_t index_base,
+                      int quirk_col0, const float* __restrict__ axes_, const float* __restrict__ unif_,
+                      const float* __restrict__ znorm_, uint64_t seed, uint64_t rng_offset, int64_t index_base,
                       float* __restrict__ xt_rot, float* __restrict__ xt_shift, float* __restrict__ target_rot,
                       float* __restrict__ target_shift, int64_t n) {
-  __shared__ __attribute__((aligned(16))) float sm[kTile * 9];
-  const int64_t ntiles = (n + kTile - 1) / kTile;
-  const int64_t wrow_t = quirk_col0 ? t[0] : -1;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * kTile;
-    const int cnt = (int)((n - base) < kTile ? (n - base) : kTile);
-    const int64_t idx = base + threadIdx.x;
-    const bool live = threadIdx.x < cnt;
-    const int64_t tt = t[live ? idx : base];
+  __shared__ __attribute__((aligned(16))) float sm[kBlock / kWave][kWave * 9];
+  const float* axes = LEAN ? nullptr : axes_;
+  const float* unif = LEAN ? nullptr : unif_;
+  const float* znorm = LEAN ? nullptr : znorm_;
+  float* wl = sm[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t ntiles = (n + kWave - 1) / kWave;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+  auto clamp_t = [&](int64_t v) -> int64_t { return v < 0 ? 0 : (v >= T ? T - 1 : v); };
+  const int64_t wrow_t = quirk_col0 ? clamp_t(t[0]) : -1;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * kWave;
+    const int cnt = (int)((n - base) < kWave ? (n - base) : kWave);
+    const int64_t idx = base + lane;
+    const bool live = lane < cnt;
+    const bool prefetched = LEAN && cnt == kWave && ((reinterpret_cast<uintptr_t>(x0_rot + base * 9) & 15) == 0);
+    if (prefetched) wave_dma9(x0_rot, base, wl);
+    const int64_t tt = clamp_t(t[live ? idx : base]);
     float ax[3], u, z[3];
     if (axes) {
       float a[3];
-      load_rows<3>(axes, base, cnt, sm, a);
+      wave_load_rows<3>(axes, base, cnt, wl, a);
       unit_axis_from(a, ax);
       u = live ? unif[idx] : 0.5f;
-      load_rows<3>(znorm, base, cnt, sm, z);
+      wave_load_rows<3>(znorm, base, cnt, wl, z);
     } else {
       Philox4 r = philox4x32_10(seed, (uint64_t)(index_base + idx), rng_offset);
       unit_axis(r.x, r.y, ax);
@@ -59,8 +74,9 @@ k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __res
     const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tt * kGuidePitch : nullptr);
     float nz[9], x[9], w[3], xs[9], xt[9], sh[3];
     exp_axis_angle(ax, ang, nz);
-    load_rows<9>(x0_rot, base, cnt, sm, x);
-    load_rows<3>(x0_shift, base, cnt, sm, sh);
+    if (prefetched) wave_dma9_commit(wl, x);
+    else wave_load_rows<9>(x0_rot, base, cnt, wl, x);
+    wave_load_rows<3>(x0_shift, base, cnt, wl, sh);
     const float k = sched[S_SQRT_AC * T + tt], eps = sched[S_SQRT_1MAC * T + tt];
     log3(x, w);
     w[0] *= k; w[1] *= k; w[2] *= k;
@@ -68,19 +84,20 @@ k_se3_q_sample_target(const float* __restrict__ sched, int T, const float* __res
     mul33(xs, nz, xt);                                   // x_blend.rot @ noise.rot   (diffusion.py:503)
     const float ns = eps * shift_scale;                  // Normal(scale = eps * shift_scale), distributions.py:96
     float xo[3] = {sh[0] * k + z[0] * ns, sh[1] * k + z[1] * ns, sh[2] * k + z[2] * ns};  // x_blend.shift + noise.shift
-    if (xt_rot) store_rows<9>(xt_rot, base, cnt, sm, xt);
-    if (xt_shift) store_rows<3>(xt_shift, base, cnt, sm, xo);
+    if (xt_rot) wave_store_rows<9>(xt_rot, base, cnt, wl, xt);
+    if (xt_shift) wave_store_rows<3>(xt_shift, base, cnt, wl, xo);
     if (target_rot) {
       float lw[3];
-      log3(nz, lw);
+      if constexpr (LEAN) { lw[0] = ax[0] * ang; lw[1] = ax[1] * ang; lw[2] = ax[2] * ang; }  // log(exp(hat(axis * angle))), exactly
+      else log3(nz, lw);
       const float ie = 1.0f / eps;
       float tg[3] = {lw[0] * ie, lw[1] * ie, lw[2] * ie};                               // diffusion.py:512
-      store_rows<3>(target_rot, base, cnt, sm, tg);
+      wave_store_rows<3>(target_rot, base, cnt, wl, tg);
     }
     if (target_shift) {
       const float inv = 1.0f / (eps * shift_scale);                                      // diffusion.py:511
       float tg[3] = {z[0] * ns * inv, z[1] * ns * inv, z[2] * ns * inv};
-      store_rows<3>(target_shift, base, cnt, sm, tg);
+      wave_store_rows<3>(target_shift, base, cnt, wl, tg);
     }
   }
 }
@@ -248,9 +265,17 @@ int so3x_se3_q_sample_target(so3x_stream_t s, const float* sched, int T, const f
   if (n < 0 || T <= 0 || (n && (!sched || !trap_q || !x0_rot || !x0_shift || !t)) || (nexp != 0 && nexp != 3))
     return SO3X_ERR_INVALID_ARG;
   if (n == 0) return SO3X_OK;
-  hipLaunchKernelGGL(k_se3_q_sample_target, dim3(grid_for_tiles((n + kTile - 1) / kTile)), dim3(kBlock), 0, (hipStream_t)s,
-                     sched, T, trap_q, guide_q, shift_scale, x0_rot, x0_shift, t, quirk_col0, axes, unif, znorm, seed, rng_offset,
-                     index_base, xt_rot, xt_shift, target_rot, target_shift, n);
+  const int64_t nt64 = (n + kWave - 1) / kWave;
+  int64_t want = (nt64 + 3) / 4;   // one tile per wave
+  if (want > (1 << 20)) want = 1 << 20;
+  if (nexp == 0)
+    hipLaunchKernelGGL(k_se3_q_sample_target<true>, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s,
+                       sched, T, trap_q, guide_q, shift_scale, x0_rot, x0_shift, t, quirk_col0, axes, unif, znorm, seed, rng_offset,
+                       index_base, xt_rot, xt_shift, target_rot, target_shift, n);
+  else
+    hipLaunchKernelGGL(k_se3_q_sample_target<false>, dim3((unsigned)want), dim3(kBlock), 0, (hipStream_t)s,
+                       sched, T, trap_q, guide_q, shift_scale, x0_rot, x0_shift, t, quirk_col0, axes, unif, znorm, seed, rng_offset,
+                       index_base, xt_rot, xt_shift, target_rot, target_shift, n);
   return check_launch();
 }
 
