@@ -239,14 +239,19 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
         for _ in range(3):
             eager()
         out["eager_python_loop_ms_per_step"] = wall(eager, 10) * 1e3
-    other_ms = None
-    if ctx.world_size == 1:  # the form "auto" does not pick in a single process, beside it: the pipelined one (nothing to hide at N = 1)
-        ts = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size, pipeline=True)
-        for _ in range(warm):
-            ts.replay()
-        other_ms = wall(ts.replay, reps) * 1e3
-        ts.flush()
-        del ts
+    other_ms = staged_ms = None
+    if ctx.world_size == 1:  # the forms "auto" does not pick in a single process, beside it: the pipelined one (nothing to hide at
+        for form in (True, "staged"):  # N = 1) and the stages in one stream with reduction + Adam as one launch (five launches)
+            ts = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size, pipeline=form)
+            for _ in range(warm):
+                ts.replay()
+            ms_ = wall(ts.replay, reps) * 1e3
+            ts.flush()
+            del ts
+            if form is True:
+                other_ms = ms_
+            else:
+                staged_ms = ms_
     tg = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size)
     for _ in range(warm):
         tg.replay()
@@ -257,6 +262,8 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
                 "mode": {"in_graph": "one captured hipGraph per step" + ("" if ctx.world_size == 1 else ", all-reduce inside"),
                          "split": "captured hipGraphs with the eager all-reduce between them"}[tg.mode],
                 "pipelined": tg.pipelined,
+                "form": "pipelined stages" if tg.pipelined else "serial graph of six launches",
+                "staged_five_launch_ms_per_step_at_one_gpu": staged_ms,
                 "pipeline": "noising of batch k on a second stream beside [slab reduction -> all-reduce -> Adam] of batch k-1 (so3x/graphs.py)"
                             if tg.pipelined else None,
                 "pipelined_ms_per_step_at_one_gpu": other_ms,

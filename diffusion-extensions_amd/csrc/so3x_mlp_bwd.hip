@@ -463,6 +463,65 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
   }
 }
 
+// The same reduction with torch.optim.Adam's update of the reduced parameters in its epilogue (so3x_optim.hip's k_adam, term for
+// term): in a single process nothing sits between the slab reduction and the optimizer, and a 17,358-element update is all launch
+// latency (5 us of a 0.235 ms step).  Every block reads the step count before any block advances it (the last one to arrive does).
+struct AdamArgs { float* p; float* m; float* v; float* step; unsigned* ticket; float lr, beta1, beta2, eps, weight_decay, grad_scale; };
+__global__ void __launch_bounds__(1024)
+k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int np, const float* __restrict__ gscale,
+                  AdamArgs ad) {
+  __shared__ float part[RED_GROUPS][RED_PPB + 1];
+  __shared__ float sc[2];
+  const int p = threadIdx.x % RED_PPB, g = threadIdx.x / RED_PPB;
+  const int idx = blockIdx.x * RED_PPB + p;
+  if (threadIdx.x == 1023) {  // (a thread of the last group: the scalars are ready when the partial sums are)
+    const double k = (double)ad.step[0] + 1.0;
+    const double bc1 = 1.0 - pow((double)ad.beta1, k), bc2 = 1.0 - pow((double)ad.beta2, k);
+    sc[0] = (float)(-(double)ad.lr / bc1);
+    sc[1] = (float)sqrt(bc2);
+  }
+  float s = 0.0f;
+  if (idx < np) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = g;
+    for (; b + 3 * RED_GROUPS < nslabs; b += 4 * RED_GROUPS) {
+      s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
+      s1 += slabs[(size_t)(b + RED_GROUPS) * NPARAMS_MAX + idx];
+      s2 += slabs[(size_t)(b + 2 * RED_GROUPS) * NPARAMS_MAX + idx];
+      s3 += slabs[(size_t)(b + 3 * RED_GROUPS) * NPARAMS_MAX + idx];
+    }
+    for (; b < nslabs; b += RED_GROUPS) s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[g][p] = s;
+  __syncthreads();
+  if (g == 0 && idx < np) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RED_GROUPS; k++) t += part[k][p];
+    if (gscale) t *= gscale[0];
+    dparams[idx] = t;
+    const float neg_step_size = sc[0], bc2_sqrt = sc[1];
+    float gi = t * ad.grad_scale;
+    const float pi = ad.p[idx];
+    if (ad.weight_decay != 0.0f) gi = fmaf(ad.weight_decay, pi, gi);
+    float mi = ad.m[idx], vi = ad.v[idx];
+    mi = mi + (1.0f - ad.beta1) * (gi - mi);
+    vi = vi * ad.beta2 + (1.0f - ad.beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
+    ad.p[idx] = pi + neg_step_size * (mi / denom);
+    ad.m[idx] = mi;
+    ad.v[idx] = vi;
+  }
+  if (threadIdx.x == 1023) {
+    const unsigned mine = __hip_atomic_fetch_add(ad.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mine == gridDim.x - 1) {
+      __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ad.step[0] = ad.step[0] + 1.0f;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Fused backward (bf16, bounded timesteps): K1 and K2 in ONE kernel, no HBM stash.
 //   * a block = 4 waves = 128 samples per round; every wave recomputes the forward of its 32-sample tile
@@ -1736,6 +1795,20 @@ int so3x_train_bwd_reduce(so3x_stream_t s, int64_t n, int T, const float* gscale
   const TrainLayout L = train_layout(n, T);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
   return launch_slab_reduce((hipStream_t)s, reinterpret_cast<const float*>((const char*)workspace + L.slabs), n, 3, grad, gscale);
+}
+
+int so3x_train_bwd_reduce_adam(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace,
+                               size_t workspace_bytes, float* params, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_scale) {
+  if (n <= 0 || T <= 0 || !grad || !params || !exp_avg || !exp_avg_sq || !step) return SO3X_ERR_INVALID_ARG;
+  const TrainLayout L = train_layout(n, T);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  const int64_t nt = (n + 31) / 32;
+  const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
+  AdamArgs ad{params, exp_avg, exp_avg_sq, step, reinterpret_cast<unsigned*>(step + 1), lr, beta1, beta2, eps, weight_decay, grad_scale};
+  hipLaunchKernelGGL(k_bwd_reduce_adam, dim3((nparams(3) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, (hipStream_t)s,
+                     reinterpret_cast<const float*>((const char*)workspace + L.slabs), gf, grad, nparams(3), gscale, ad);
+  return check_launch();
 }
 
 int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,

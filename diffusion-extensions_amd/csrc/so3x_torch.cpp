@@ -329,6 +329,20 @@ void train_bwd_reduce(int64_t n, int64_t T, const optional<Tensor>& gscale, Tens
                            dev(workspace, "workspace", at::kByte).const_data_ptr(), workspace.numel()),
      "train_bwd_reduce");
 }
+void train_bwd_reduce_adam(int64_t n, int64_t T, const optional<Tensor>& gscale, Tensor& grad, const Tensor& workspace, Tensor& params,
+                           Tensor& exp_avg, Tensor& exp_avg_sq, Tensor& step, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, double grad_scale) {
+  GUARD(grad);
+  const int64_t np = params.numel();
+  TORCH_CHECK(np == SO3X_MLP_PARAMS && grad.numel() == np && exp_avg.numel() == np && exp_avg_sq.numel() == np && step.numel() >= 2,
+              "so3x: train_bwd_reduce_adam works on the ", SO3X_MLP_PARAMS, "-parameter flat buffers");
+  dev(params, "params"); dev(exp_avg, "exp_avg"); dev(exp_avg_sq, "exp_avg_sq"); dev(step, "step");
+  ok(so3x_train_bwd_reduce_adam(strm(grad), n, (int)T, Fo(gscale, "grad_output"), dev(grad, "grad").mutable_data_ptr<float>(),
+                                dev(workspace, "workspace", at::kByte).const_data_ptr(), workspace.numel(), Fm(params), Fm(exp_avg),
+                                Fm(exp_avg_sq), Fm(step), (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay,
+                                (float)grad_scale),
+     "train_bwd_reduce_adam");
+}
 void adam_step(Tensor& params, const Tensor& grad, Tensor& exp_avg, Tensor& exp_avg_sq, Tensor& step, double lr, double beta1, double beta2,
                double eps, double weight_decay, double grad_scale) {
   GUARD(params);
@@ -568,6 +582,8 @@ TORCH_LIBRARY(so3x, m) {
         "Tensor(e!)? rng_counter, Tensor(f!) workspace) -> ()");
   m.def("train_bwd_partial(Tensor x_t, Tensor t, Tensor dout, Tensor zstash, int T, Tensor(a!) workspace) -> ()");
   m.def("train_bwd_reduce(int n, int T, Tensor? gscale, Tensor(a!) grad, Tensor workspace) -> ()");
+  m.def("train_bwd_reduce_adam(int n, int T, Tensor? gscale, Tensor(a!) grad, Tensor workspace, Tensor(b!) params, Tensor(c!) exp_avg, "
+        "Tensor(d!) exp_avg_sq, Tensor(e!) step, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale) -> ()");
   m.def("adam_step(Tensor(a!) params, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) step, float lr, float beta1, "
         "float beta2, float eps, float weight_decay, float grad_scale) -> ()");
   m.def("rotate_cloud(Tensor rot, Tensor cloud, int cloud_stride, int P) -> Tensor");
@@ -627,6 +643,7 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("train_net", train_net);
   m.impl("train_bwd_partial", train_bwd_partial);
   m.impl("train_bwd_reduce", train_bwd_reduce);
+  m.impl("train_bwd_reduce_adam", train_bwd_reduce_adam);
   m.impl("adam_step", adam_step);
   m.impl("rotate_cloud", rotate_cloud);
   m.impl("resnet_fwd", resnet_fwd);

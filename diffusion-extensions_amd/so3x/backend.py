@@ -45,7 +45,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
-    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset",
+    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam",
 )
 
 
@@ -473,6 +473,15 @@ def train_bwd_reduce(buf, gscale=None, grad=None):
     g = buf.grad if grad is None else grad
     _call(ops().train_bwd_reduce, buf.n, buf.T, _dev(gscale, "grad_output").reshape(1) if gscale is not None else None, g, buf.workspace)
     return g
+
+
+def train_bwd_reduce_adam(buf, params, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0, gscale=None):
+    """stage 4 and the optimizer in ONE launch (single-process training): buf.grad = the reduced gradient, then torch.optim.Adam's
+    update of `params` with it -- bit-identical to train_bwd_reduce followed by adam_step"""
+    _call(ops().train_bwd_reduce_adam, buf.n, buf.T, _dev(gscale, "grad_output").reshape(1) if gscale is not None else None, buf.grad,
+          buf.workspace, params, exp_avg, exp_avg_sq, step, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+          float(grad_scale))
+    return buf.grad
 
 
 def adam_step(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0):

@@ -24,8 +24,11 @@ pipeline: after `step(x)` returns, the loss is batch k's, and the parameters car
 outstanding tail (call it before reading / saving / sampling from the parameters; `step` after a flush starts the pipeline
 again).
 
-**Serial** (any other process / denoiser / optimizer): forward, backward (autograd), all-reduce and optimizer captured as one
-stream, as in round 2.
+**Serial** (a single process, any other process / denoiser / optimizer, or `pipeline=False`): forward, backward (autograd),
+all-reduce and optimizer captured as one stream, as in round 2.  With no collective the tail's kernels fill the chip for their
+few microseconds and the noising finds no room beside them: measured, the pipelined form is 2-4 us SLOWER in a single process,
+and `pipeline="staged"` -- the stages as one stream with the slab reduction and Adam as ONE launch
+(`so3x_train_bwd_reduce_adam`), five launches, no autograd -- exactly as fast as this form.
 
 Data-parallel (one process per GPU): `allreduce="in_graph"` captures the collective with the rest -- ONE graph launch per step;
 `"split"` issues the collective eagerly between two graph launches, for stacks whose collectives cannot be captured (gloo);
@@ -60,8 +63,9 @@ class TrainStepGraph:
     """process: SO3Diffusion (or a subclass whose p_losses honours `rng_counter`); optimizer: so3x.optim.Adam, or a
     capturable torch optimizer (torch.optim.Adam(params, lr, fused=True, capturable=True)); batch_shape: the fixed shape of
     this rank's data batch; ctx: so3x.parallel.Ctx (None = single process); n_global: the global batch (for unequal shards).
-    pipeline: "auto" (pipelined where the path allows AND there is a gradient collective to hide, i.e. world size > 1), True
-    (pipelined, also in a single process), False (the serial form).
+    pipeline: "auto" (pipelined where the path allows AND there is a gradient collective to hide, i.e. world size > 1; the serial
+    form in a single process), True (pipelined, also in a single process), False (the serial form), "staged" (single process:
+    the stages in one stream, reduction + Adam as one launch).
 
         g = TrainStepGraph(process, optim, x.shape, ctx=ctx)
         for x in data: loss = g.step(x)          # loss: 0-d device tensor, overwritten by the next replay
@@ -95,6 +99,12 @@ class TrainStepGraph:
         # for its few microseconds, the noising kernel finds no free wave slots beside them, and the fork / join edges cost
         # ~2 us: measured 0.2430 vs 0.2402 ms per 2^19-sample step (bench.py train_step, round 3) -- so the serial form stays.
         self.pipelined = bool(eligible and (pipeline is True or (pipeline == "auto" and self.world > 1)))
+        # pipeline="staged" (single process; A/B): the same stages as ONE stream with the slab reduction and the optimizer as one
+        # launch (so3x_train_bwd_reduce_adam) -- five launches, no autograd.  Measured the same as the autograd-driven serial
+        # graph (0.2376 against 0.2366 ms: inside a graph a 5-us launch costs nothing extra), so "auto" keeps the serial form.
+        if pipeline == "staged" and not (eligible and self.world == 1):
+            raise ValueError("so3x: pipeline='staged' is the single-process form of the path the pipelined step is built for")
+        self.staged = pipeline == "staged"
         snap = self._snapshot()
         self.x = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.x[..., 0, 0] = self.x[..., 1, 1] = self.x[..., 2, 2] = 1.0
@@ -103,7 +113,7 @@ class TrainStepGraph:
         self._one = torch.ones((), dtype=torch.float32, device=dev)  # d loss / d loss: given, not filled by a launch per step
         self._pending = False      # pipelined: a backward's slabs are waiting for their reduction / all-reduce / update
         self._side = torch.cuda.Stream(device=dev)
-        if self.pipelined:
+        if self.pipelined or self.staged:
             self.buf = _b.TrainBuffers(self.n_local, process.num_timesteps, dev)
             self.net.flat_data()                         # (re-)adopt the parameters into the flat buffer if they were re-homed
             self.net._install_flat_grad(self.buf.grad)   # the .grad views alias the buffer the reduction writes
@@ -115,6 +125,8 @@ class TrainStepGraph:
             for _ in range(warmup):     # optimizer state, and the communicator's first collective
                 if self.pipelined:
                     self._noise(); self._net(); self._bwd(); self._tail()
+                elif self.staged:
+                    self._noise(); self._net(); self._bwd(); self.optimizer.step_with_reduction(self.buf)
                 else:
                     self._fwd_bwd()
                     self._allreduce()
@@ -186,7 +198,7 @@ class TrainStepGraph:
                 for k, v in st.items():
                     if isinstance(v, torch.Tensor):
                         v.zero_() if old is None else v.copy_(old[k])
-        if self.pipelined:
+        if self.pipelined or self.staged:
             self.buf.grad.zero_(); self.buf.loss.zero_()
         self._pending = False
         torch.cuda.synchronize(self.dev)
@@ -240,6 +252,15 @@ class TrainStepGraph:
 
     # ------------------------------------------------------------------ capture
     def _capture_in_graph(self, inject_failure=False):
+        if self.staged:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._noise(); self._net(); self._bwd()
+                if inject_failure:
+                    raise RuntimeError("so3x: injected capture failure (test)")
+                self.optimizer.step_with_reduction(self.buf)
+            self.graph = g
+            return
         if not self.pipelined:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -181,6 +181,11 @@ def _(n, T, gscale, grad, workspace):
     return None
 
 
+@register_fake("so3x::train_bwd_reduce_adam")
+def _(n, T, gscale, grad, workspace, params, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, grad_scale):
+    return None
+
+
 @register_fake("so3x::adam_step")
 def _(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, grad_scale):
     return None

@@ -54,6 +54,15 @@ class Adam(torch.optim.Optimizer):
         _b.adam_step(flat, grad, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
         return loss
 
+    @torch.no_grad()
+    def step_with_reduction(self, buf):
+        """the slab reduction of a staged training step (so3x.backend.TrainBuffers) and this optimizer's update as ONE launch --
+        what a single-process captured step uses instead of train_bwd_reduce + step() (same arithmetic, bit-identical)"""
+        flat = self.net.flat_data()
+        m, v, step = self._state(flat)
+        g = self.param_groups[0]
+        _b.train_bwd_reduce_adam(buf, flat, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
+
     def state_dict(self):
         return {"exp_avg": self._m, "exp_avg_sq": self._v, "step": self._step, "param_groups": [dict((k, v) for k, v in g.items() if k != "params")
                                                                                                 for g in self.param_groups]}

@@ -362,6 +362,12 @@ int so3x_train_bwd_partial(so3x_stream_t s, const float* x_t, const int64_t* t, 
                            void* workspace, size_t workspace_bytes);
 int so3x_train_bwd_reduce(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace,
                           size_t workspace_bytes);
+/* so3x_train_bwd_reduce followed by so3x_adam_step on the same 17,358 parameters, as ONE launch (single-process training: nothing
+ * sits between the reduction and the optimizer; a data-parallel step puts its all-reduce there and uses the two calls).  grad is
+ * still written.  Same arithmetic, term for term: bit-identical parameters. */
+int so3x_train_bwd_reduce_adam(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace,
+                               size_t workspace_bytes, float* params, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_scale);
 int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const float* dout, const void* zstash, int64_t n, int T,
                    const float* gscale, float* grad, void* workspace, size_t workspace_bytes);
 int so3x_adam_step(so3x_stream_t s, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n,

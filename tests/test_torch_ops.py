@@ -75,6 +75,21 @@ def test_opcheck_on_the_training_step_operators(env):
             test_utils=checks)
     opcheck(ops.train_bwd_partial.default, (buf.x_t, buf.t_used, buf.dout, buf.zstash, T, buf.workspace), test_utils=checks)
     opcheck(ops.train_bwd_reduce.default, (n, T, None, buf.grad, buf.workspace), test_utils=checks)
+    m_, v_, st_ = torch.zeros_like(params), torch.zeros_like(params), torch.zeros(2, device=DEV)
+    opcheck(ops.train_bwd_reduce_adam.default, (n, T, None, buf.grad, buf.workspace, params.clone(), m_, v_, st_, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0),
+            test_utils=checks)
+    # reduction + Adam in one launch == the two launches, bit for bit (parameters, moments, step count, gradient)
+    B.train_noise(buf, proc._sched, env["trap_q"], x, t, seed=5, guide_q=proc._guide_q)
+    B.train_net(buf, params)
+    B.train_bwd_partial(buf)
+    pa, ma, va, sa = params.clone(), torch.zeros_like(params), torch.zeros_like(params), torch.zeros(2, device=DEV)
+    pb, mb, vb, sb = params.clone(), torch.zeros_like(params), torch.zeros_like(params), torch.zeros(2, device=DEV)
+    for _ in range(3):
+        ga = B.train_bwd_reduce(buf).clone()
+        B.adam_step(pa, ga, ma, va, sa, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.5)
+        gb = B.train_bwd_reduce_adam(buf, pb, mb, vb, sb, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.5).clone()
+        assert torch.equal(ga, gb) and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb)
+    assert float(sa[0]) == 3.0 and not torch.equal(pa, params)
     # the stages compose to the whole-step operators, bit for bit
     B.train_noise(buf, proc._sched, env["trap_q"], x, t, seed=5, guide_q=proc._guide_q)
     B.train_net(buf, params)

@@ -193,8 +193,9 @@ def _run_steps(mods, base, x, mode, steps=4, optimizer="so3x"):
     if mode != "eager":
         # NO rewind here: construction (warm-up steps on a placeholder batch + capture) must leave parameters, optimizer state and
         # counters exactly as it found them (the first replay is the first eager step)
-        g = TrainStepGraph(proc, opt, x.shape, warmup=2, pipeline={"graph": "auto", "serial": False, "pipelined": True}[mode])
+        g = TrainStepGraph(proc, opt, x.shape, warmup=2, pipeline={"graph": "auto", "serial": False, "pipelined": True, "staged": "staged"}[mode])
         assert g.pipelined == (mode == "pipelined")   # "auto" pipelines only where there is a collective to hide (world size > 1)
+        assert g.staged == (mode == "staged")         # the stages as one stream, reduction + Adam as ONE launch
         assert torch.equal(net.flat_data(), base.flat_data()) and int(proc.rng_counter) == 0
     losses = []
     for _ in range(steps):
@@ -218,7 +219,7 @@ def test_graph_replay_equals_the_eager_loop_bit_for_bit(mods):
     torch.manual_seed(0)
     base = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
     x = mods["util"].quat_to_rmat(torch.randn(2048, 4, device=DEV))
-    for optimizer, modes in (("so3x", ("pipelined", "serial")), ("torch", ("graph",))):
+    for optimizer, modes in (("so3x", ("pipelined", "serial", "graph", "staged")), ("torch", ("graph",))):
         le, pe, ce, _, _ = _run_steps(mods, base, x, "eager", optimizer=optimizer)
         for mode in modes:
             lg, pg, cg, _, _ = _run_steps(mods, base, x, mode, optimizer=optimizer)
