@@ -646,6 +646,19 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
         pk[j] = __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)val[2 * j], (__bf16)val[2 * j + 1]});
       }
     }
+#if defined(SO3X_EXTRA_WAIT)  /* timing experiment only (tools/ab): what does one more (always satisfied) s_waitcnt / s_nop per gap cost? */
+#if SO3X_EXTRA_WAIT == 1
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+#elif SO3X_EXTRA_WAIT == 2
+    asm volatile("s_nop 0" ::: "memory");
+#elif SO3X_EXTRA_WAIT == 3   /* one more plain vector instruction per gap */
+    { float dummy_; asm volatile("v_add_f32 %0, %1, %1" : "=v"(dummy_) : "v"(val[0])); }
+#elif SO3X_EXTRA_WAIT == 4   /* one more LDS read per gap (address 0 = the table: always valid) */
+    { uint32_t dummy_; asm volatile("ds_read_b32 %0, %1" : "=v"(dummy_) : "v"(0u) : "memory"); }
+#elif SO3X_EXTRA_WAIT == 5   /* three more plain vector instructions per gap */
+    { float d0_, d1_, d2_; asm volatile("v_add_f32 %0, %3, %3\n\tv_add_f32 %1, %3, %3\n\tv_add_f32 %2, %3, %3" : "=v"(d0_), "=v"(d1_), "=v"(d2_) : "v"(val[0])); }
+#endif
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));

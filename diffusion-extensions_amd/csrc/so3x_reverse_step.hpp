@@ -51,7 +51,16 @@ __device__ __forceinline__ Quat reverse_step(Quat q, const float (&v)[3], const 
     const float* row = row_l ? row_l : trap_p + (size_t)t * 999;  // IsotropicGaussianSO3(model_stdev[0]), :325
     const uint16_t* grow = row_l ? grow_l : (guide_p ? guide_p + (size_t)t * kGuidePitch : nullptr);  // optional search guide (bit-identical)
     const float* kn = knots_l ? knots_l : SO3X_KNOTS_DATA;
-    const float ang = axes ? igso3_angle<true>(row, row, kn, u, grow) : igso3_angle<false>(row, row, kn, u, grow);
+    // SO3X_CHAIN_SEARCH=1 (A/B): on the LDS-staged row, the guided search as [guide] -> [8-knot window] with 9-ary narrowing of wide
+    // brackets (igso3_angle_windowed: two dependent LDS round trips for 96 % of the lanes instead of the bisection's, which a wave
+    // walks for its WORST lane: 6-9) -- the same index, bit-identical angles
+#ifndef SO3X_CHAIN_SEARCH
+#define SO3X_CHAIN_SEARCH 0
+#endif
+    float ang;
+    if (axes) ang = igso3_angle<true>(row, row, kn, u, grow);
+    else if (SO3X_CHAIN_SEARCH && row_l && grow) ang = igso3_angle_windowed<false>(row, row, kn, u, grow);
+    else ang = igso3_angle<false>(row, row, kn, u, grow);
     q = qmul(q, quat_axis_angle_exp<FAST>(nax, ang));   // model_mean @ sample, :326
   }
   // no per-step renormalisation: q is rebuilt from (axis, angle) pairs every step, so its norm error is
