@@ -441,6 +441,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=100, help="reverse steps fused into one chain-kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--train-timeout", type=float, default=240.0, help="N > 1: seconds the training leg may take before the line is printed without it")
     args = ap.parse_args()
 
     from so3x import backend as B
@@ -539,19 +540,12 @@ def main():
     full_ok = bool(torch.isfinite(xf).all().item())
     del xf
 
-    # ---- BASELINE config 4: the training step, on every rank (gradient all-reduce when N > 1)
-    train = None
-    if not args.no_extras:
-        try:
-            train = train_leg(B, torch, ctx, T)
-        except Exception as e:  # report, never hide
-            train = {"error": repr(e)}
-
     devices = [f"{dev} ({torch.cuda.get_device_name(dev)})"]
     if ctx.world_size > 1:  # what each rank actually ran on
         devices = [None] * ctx.world_size
         torch.distributed.all_gather_object(devices, f"rank {ctx.rank}: {dev} ({torch.cuda.get_device_name(dev)})")
 
+    line = None
     if ctx.rank == 0:
         total = ctx.world_size * n * args.steps
         line = {
@@ -587,6 +581,34 @@ def main():
                                  "(the shape profiled under profiles/); the kernel's real bound is the VALU issue port "
                                  "(valu_busy_frac_pmc; DESIGN.md section 4); algorithmic HBM traffic is 72 B/sample per launch"},
         }
+
+    # ---- BASELINE config 4: the training step, on every rank (gradient all-reduce when N > 1).  The headline above is complete at
+    #      this point; with more than one rank the leg runs under a watchdog, so that a collective that never returns (this leg is
+    #      the only part of the run with a data-path collective, and no multi-GPU node was available to any round) costs the
+    #      training numbers, not the line: rank 0 prints what it has with the reason, every rank exits.
+    train = None
+    if not args.no_extras:
+        watchdog = None
+        if ctx.world_size > 1:
+            import threading
+
+            def give_up():
+                if ctx.rank == 0 and line is not None:
+                    line["train_step"] = {"error": f"no result after {args.train_timeout} s (a collective that did not return?); the headline above is unaffected"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)   # the reason is in the line; a non-zero code would discard the headline the line carries
+
+            watchdog = threading.Timer(args.train_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            train = train_leg(B, torch, ctx, T)
+        except Exception as e:  # report, never hide
+            train = {"error": repr(e)}
+        if watchdog is not None:
+            watchdog.cancel()
+
+    if ctx.rank == 0:
         if train is not None:
             line["train_step"] = train
         if not args.no_extras and ctx.world_size == 1:
