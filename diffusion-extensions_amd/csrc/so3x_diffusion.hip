@@ -121,7 +121,10 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
     w[0] *= k; w[1] *= k; w[2] *= k;
     exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
     mul33(xs, nz, xt);                // x_blend @ noise, :346
-    if (x_t) wave_store_rows<9>(x_t, base, cnt, wl, xt);
+#ifndef SO3X_QS_NT   /* A/B: non-temporal stores of the lean kernel's outputs (do the streams push the CDF tables out of the L2?) */
+#define SO3X_QS_NT 0
+#endif
+    if (x_t) wave_store_rows<9, LEAN && SO3X_QS_NT>(x_t, base, cnt, wl, xt);
     if (target) {
       float lw[3];
       // skew2vec(log_rmat(noise)) * (1/eps), :355.  LEAN (the noise was built here from a unit axis and an angle in [0, pi]):
@@ -131,7 +134,7 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
       else log3(nz, lw);
       const float ie = 1.0f / sched[S_SQRT_1MAC * T + tt];
       float tg[3] = {lw[0] * ie, lw[1] * ie, lw[2] * ie};
-      wave_store_rows<3>(target, base, cnt, wl, tg);
+      wave_store_rows<3, LEAN && SO3X_QS_NT>(target, base, cnt, wl, tg);
     }
     if (noise_out) wave_store_rows<9>(noise_out, base, cnt, wl, nz);
   }
