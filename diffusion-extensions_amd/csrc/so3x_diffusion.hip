@@ -328,8 +328,14 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
         forward_tile<PREC, CHAIN, 2>(lds, R, beff, 0, nullptr, vb, lane);  // tile B = samples 32..63
       }
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const float o = __shfl_xor(vb[j], 32);  // tile B results sit in lanes 0..31, owners are lanes 32..63
+      for (int j = 0; j < 3; j++) {  // tile B results sit in lanes 0..31, their owners are lanes 32..63
+#if SO3X_L0_SWAP
+        if constexpr (PAIR) {  // one v_permlane32_swap: [va of the lower half | vb of the lower half] (no LDS exchange, no select)
+          v[j] = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, va[j]), __builtin_bit_cast(uint32_t, vb[j]), false, false)[0]);
+          continue;
+        }
+#endif
+        const float o = __shfl_xor(vb[j], 32);
         v[j] = h ? o : va[j];
       }
       // ---- posterior mean + noise (diffusion.py:291-326), so3x_reverse_step.hpp

@@ -575,6 +575,30 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
   for (int j = 0; j < 8; j++) b[j] = (__bf16)(h ? (j == 0 ? x8 : (j < 4 ? 1.0f : 0.0f)) : xe[j]);  // slot 8h + j; 9..11 = ones
   return b;
 }
+// Both layer-0 B operands of a 64-sample wave at once (tile A = the lower lane half's samples, tile B = the upper half's), with
+// v_permlane32_swap_b32 (gfx950: swaps the upper 32 lanes of its first operand with the lower 32 of its second) instead of nine
+// ds_bpermute exchanges and two select chains.  Every lane packs its OWN entries -- P_w = (x[2w], x[2w+1]), Q = (x[8], 1) -- and
+// word w of the two operands is one swap:   swap(D = P_w, S = C_w)  ->  D' = [P_w of the lower half | C_w of the lower half] = tile A,
+//                                                                   S' = [P_w of the upper half | C_w of the upper half] = tile B,
+// with C_0 = Q (slot 8 = R[8], slot 9 = one) and C_1 = (1, 1), C_2 = C_3 = 0 (slots 10, 11 = ones, 12..15 = padding).
+// Same bf16 bits as l0_operand<1> / <2>.
+#ifndef SO3X_L0_SWAP
+#define SO3X_L0_SWAP 1
+#endif
+__device__ __forceinline__ void l0_operands_pair(const float* x, bf16x8& bA, bf16x8& bB) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  auto pk = [](float a, float b) { return __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)a, (__bf16)b}); };
+  const uint32_t c[4] = {pk(x[8], 1.0f), 0x3F803F80u, 0u, 0u};
+  uint32_t wa[4], wb[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const auto r = __builtin_amdgcn_permlane32_swap(pk(x[2 * w], x[2 * w + 1]), c[w], false, false);
+    wa[w] = r[0]; wb[w] = r[1];
+  }
+  bA = __builtin_bit_cast(bf16x8, u32x4_t{wa[0], wa[1], wa[2], wa[3]});
+  bB = __builtin_bit_cast(bf16x8, u32x4_t{wb[0], wb[1], wb[2], wb[3]});
+}
 #ifndef SO3X_STAGE_FENCE
 #define SO3X_STAGE_FENCE __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -691,7 +715,12 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   Tile<PREC> curA, curB;
   {  // layer 0 of both tiles from this timestep's three A fragments
     const bf16x8 w0 = l0w[0], w1 = l0w[1], w2 = l0w[2];
+#if SO3X_L0_SWAP
+    bf16x8 bA, bB;
+    l0_operands_pair(x, bA, bB);
+#else
     const bf16x8 bA = l0_operand<1>(x, lane), bB = l0_operand<2>(x, lane);
+#endif
     accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
     accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
   }
