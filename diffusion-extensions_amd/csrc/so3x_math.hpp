@@ -88,6 +88,22 @@ __device__ __forceinline__ float atan2_pos(float s, float c) {
   return c < 0.0f ? 3.14159265358979324f - r : r;
 }
 
+// the same for c >= 0 (result in [0, pi/2]): what a quaternion's angle needs -- atan2(|xyz|, |w|) -- without the dead c < 0 fold
+__device__ __forceinline__ float atan2_pos_pos(float s, float c) {
+  const float mx = fmaxf(s, c), mn = fminf(s, c);
+  const float a = fdiv(mn, mx);
+  const float z = a * a;
+  float q = -0x1.1d7010p-8f;
+  q = fmaf(q, z, 0x1.797dd0p-6f);
+  q = fmaf(q, z, -0x1.d9485ep-5f);
+  q = fmaf(q, z, 0x1.912c20p-4f);
+  q = fmaf(q, z, -0x1.1e3d90p-3f);
+  q = fmaf(q, z, 0x1.98d610p-3f);
+  q = fmaf(q, z, -0x1.5550f2p-2f);
+  const float r = fmaf(a * z, q, a);
+  return s > c ? 1.57079632679489662f - r : r;
+}
+
 // vee(R - R^T)-based log, as a 3-vector.  util.py:164-192.
 //   s = |v|/2, c = (tr R - 1)/2, angle = atan2(s, c), w = v * angle/(2 s);
 //   angle == 0 -> 0 (util.py:174).  s == 0 with c < 0 (exact pi) is the reference's
@@ -375,16 +391,17 @@ __device__ __forceinline__ Quat quat_from_rmat(const float* R) {  // Shepperd's 
 }
 // rotation angle in [0, pi] and unit axis (zero vector at the identity, where the angle is 0 anyway)
 __device__ __forceinline__ float quat_axis_angle(const Quat& q, float* ax) {
-  const float sg = q.w < 0.f ? -1.f : 1.f;  // q and -q are the same rotation: take w >= 0
+  // q and -q are the same rotation: take w >= 0, i.e. the axis carries the sign of w (one bit-field insert) and the angle |w|
   const float n = fsqrt(q.x * q.x + q.y * q.y + q.z * q.z);
-  const float inv = n > 0.f ? sg * frcp(n) : 0.f;
+  const float inv = n > 0.f ? __builtin_copysignf(frcp(n), q.w) : 0.f;
   ax[0] = q.x * inv; ax[1] = q.y * inv; ax[2] = q.z * inv;
-  return 2.f * atan2_pos(n, sg * q.w);
+  return 2.f * atan2_pos_pos(n, fabsf(q.w));
 }
 template <bool FAST = false>
 __device__ __forceinline__ Quat quat_axis_angle_exp(const float* ax, float ang) {
   float sn, cs;
-  sincos_sel<FAST>(0.5f * ang, &sn, &cs);
+  if constexpr (FAST) sincos_rev(__builtin_amdgcn_fractf(ang * 0.07957747154594767f), &sn, &cs);  // half the angle, in revolutions: one multiply
+  else sincos_sel<false>(0.5f * ang, &sn, &cs);
   return Quat{cs, sn * ax[0], sn * ax[1], sn * ax[2]};
 }
 
