@@ -16,6 +16,11 @@ using namespace so3x::mlp;
 #ifndef SO3X_ABLATE
 #define SO3X_ABLATE 0
 #endif
+// 1: the next step's layer-0 fragments are loaded into the registers the current step's layer 0 has just read (so3x_mlp.hpp,
+// forward_pair_bf16), 0: into a second set at the top of the step and moved over behind the network (round 2)
+#ifndef SO3X_L0_RELOAD
+#define SO3X_L0_RELOAD 1
+#endif
 // -DSO3X_STAMPS=1: timing build (tools/ab): wave 0 of workgroup 0 accumulates s_memtime intervals of a step's phases and writes
 // them over the first bytes of x_out (the results of samples 0, 1 are destroyed)
 #ifndef SO3X_STAMPS
@@ -303,21 +308,27 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
               __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096),
                                                (__attribute__((address_space(3))) void*)(rowbuf + 4096), 16, 0, 0);
           }
-          bf16x8 wn[3];
           const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
+#if !SO3X_L0_RELOAD
+          bf16x8 wn[3];
 #pragma unroll
           for (int k = 0; k < 3; k++) wn[k] = l0n[64 * k + lane];
+#endif
           SO3X_STAMP(0);  // step top: rmat, scalar loads, DMA issue, prefetch
 #if SO3X_STAMPS
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, stamp_acc, &stamp_last);
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, stamp_acc, &stamp_last, nullptr, SO3X_L0_RELOAD ? l0n : nullptr);
 #elif SO3X_STAGE_TOKEN
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, stage_token);
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, stage_token, SO3X_L0_RELOAD ? l0n : nullptr);
+#elif SO3X_L0_RELOAD
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, nullptr, l0n);  // (reloads w0 for the next step itself)
 #else
           forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
 #endif
           SO3X_STAMP(1);  // the two head stages
+#if !SO3X_L0_RELOAD
 #pragma unroll
           for (int k = 0; k < 3; k++) w0[k] = wn[k];
+#endif
 #endif
         } else {
           forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);

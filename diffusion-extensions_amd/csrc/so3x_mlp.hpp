@@ -615,6 +615,9 @@ __device__ __forceinline__ void l0_operands_pair(const float* x, bf16x8& bA, bf1
 #ifndef SO3X_STAGE_TOKEN
 #define SO3X_STAGE_TOKEN 0
 #endif
+#ifndef SO3X_HEAD_REUSE   /* 1: the two head stages share their five weight fragments in registers */
+#define SO3X_HEAD_REUSE 1
+#endif
 // the priorities themselves (A/B knobs; tools/ab/build_variant.sh): the six MFMA stages, the two head stages, the rest of a step
 #ifndef SO3X_PRIO_STAGE
 #define SO3X_PRIO_STAGE 3
@@ -705,9 +708,10 @@ template <bool WIDE = false>
 #else
 #define SO3X_FP_STAMP(k) do { } while (0)
 #endif
-__device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, const bf16x8 (&l0w)[3],
+__device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, bf16x8 (&l0w)[3],
                                                   float* va, float* vb, int lane, uint32_t lt = 0, uint64_t* stamp_acc = nullptr,
-                                                  uint64_t* stamp_last = nullptr, unsigned* stage_token = nullptr) {
+                                                  uint64_t* stamp_last = nullptr, unsigned* stage_token = nullptr,
+                                                  const bf16x8* __restrict__ l0next = nullptr) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
@@ -723,6 +727,12 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
 #endif
     accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
     accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
+  }
+  // the NEXT step's three layer-0 fragments go straight into the registers this step's six MFMAs have just read (an L2 round
+  // trip that lands during the stages; no second set of twelve registers, no twelve moves per step)
+  if (l0next) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) l0w[k] = l0next[64 * k + lane];
   }
   // every stage also fetches the first five weight fragments of the NEXT stage (`pre`): a stage's MFMA chain starts on
   // registers instead of waiting ~120 cycles for its first LDS reads behind the fence
@@ -779,8 +789,10 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   f32x16 lastA[1], lastB[1];
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
-  prefetch_tile0(wlast, lane, pre);
-  activate_bf16<true, WIDE>(accB, curB, h, tab, lt);            // activation B, layer 3
+#if !SO3X_HEAD_REUSE
+  prefetch_tile0(wlast, lane, pre);                   // (round 2 read the head's five fragments a second time for tile B)
+#endif
+  activate_bf16<true, WIDE>(accB, curB, h, tab, lt);            // activation B, layer 3 (head B below takes the SAME five fragments)
   SO3X_STAGE_FENCE;
   mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
 #if SO3X_CHAIN_PRIO
