@@ -16,6 +16,17 @@ using namespace so3x::mlp;
 #ifndef SO3X_ABLATE
 #define SO3X_ABLATE 0
 #endif
+// SO3X_DMA_LATE=1 (A/B: measured 4 % SLOWER): the record's DMA issued behind layer 0's MFMAs (forward_pair_bf16) instead of at the
+// top of the step.  SO3X_DMA_ASM=1: the five LDS-DMA instructions written as inline assembly, so that the compiler's wait-count
+// pass does not see an LDS writer in flight and put `s_waitcnt vmcnt(0)` in front of the next LDS read (the weight fragments of
+// layer 0: an exposed L2 round trip at the top of every step); the kernel's own `s_waitcnt vmcnt(0)` in front of the reverse
+// step is what orders the record's arrival against its reads, as before.
+#ifndef SO3X_DMA_LATE
+#define SO3X_DMA_LATE 0
+#endif
+#ifndef SO3X_DMA_ASM
+#define SO3X_DMA_ASM 1
+#endif
 // 1: the next step's layer-0 fragments are loaded into the registers the current step's layer 0 has just read (so3x_mlp.hpp,
 // forward_pair_bf16), 0: into a second set at the top of the step and moved over behind the network (round 2)
 #ifndef SO3X_L0_RELOAD
@@ -275,6 +286,11 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     if constexpr (PAIR) {
 #pragma unroll
       for (int k = 0; k < 3; k++) w0[k] = l0t_tab[(size_t)t_start * 192 + 64 * k + lane];
+#if SO3X_DMA_ASM
+      // once per chunk: the step loop is entered with nothing the compiler tracks in flight (see below).  A use of the loaded
+      // registers, not a wait instruction: the wait-count pass drops an explicit wait it deems early and re-inserts it at the use
+      asm volatile("" :: "v"(w0[0]), "v"(w0[1]), "v"(w0[2]));
+#endif
     }
 #if SO3X_STAMPS
     uint64_t stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
@@ -298,8 +314,25 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #else
           // the step's schedule scalars: scalar loads issued here, a network away from their use
           coef = StepCoef{sched[S_RECIP * T + t], sched[S_RECIPM1 * T + t], sched[S_COEF1 * T + t], sched[S_COEF2 * T + t]};
-          if (staged) {  // this step's CDF record -> LDS (five 1-KB / 512-B DMAs); it lands while the network runs
+          const char* dma_src = (staged && SO3X_DMA_LATE && SO3X_L0_RELOAD && !SO3X_STAMPS && !SO3X_STAGE_TOKEN) ? cdf_rec + (size_t)t * kCdfRec + lane * 16 : nullptr;
+          if (staged && !dma_src) {  // this step's CDF record -> LDS (five 1-KB / 512-B DMAs); it lands while the network runs
             const char* src = cdf_rec + (size_t)t * kCdfRec + lane * 16;
+#if SO3X_DMA_ASM
+            {
+              typedef __attribute__((address_space(3))) char* lds_cp;
+              const uint32_t dst = (uint32_t)(uintptr_t)(lds_cp)rowbuf;  // wave-uniform LDS byte address of this wave's record buffer
+              // M0 = LDS base; the instruction adds its immediate offset to the global AND the LDS address, and 16 bytes per lane.
+              // The fifth piece (512 B, offset beyond the 13-bit immediate) is the lower 32 lanes'.
+              asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                           "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                           "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                           "global_load_lds_dwordx4 %0, off offset:3072"
+                           :: "v"(src), "s"(dst) : "memory", "m0", "scc");
+              if (lane < 32)  // (the immediate offset is 13 bits signed: the fifth piece takes its own pointer)
+                asm volatile("s_add_u32 m0, %1, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :: "v"(src + 4096), "s"(dst) : "memory", "m0", "scc");
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 4; i++)
               __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
@@ -307,6 +340,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
             if (lane < 32)
               __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096),
                                                (__attribute__((address_space(3))) void*)(rowbuf + 4096), 16, 0, 0);
+#endif
           }
           const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
 #if !SO3X_L0_RELOAD
@@ -320,7 +354,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #elif SO3X_STAGE_TOKEN
           forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, stage_token, SO3X_L0_RELOAD ? l0n : nullptr);
 #elif SO3X_L0_RELOAD
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, nullptr, l0n);  // (reloads w0 for the next step itself)
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, nullptr, l0n, dma_src, rowbuf);  // (reloads w0 for the next step, issues the record's DMA)
 #else
           forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
 #endif
@@ -357,8 +391,19 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
 #if defined(SO3X_PRIO_REVERSE)
       if constexpr (PAIR) __builtin_amdgcn_s_setprio(SO3X_PRIO_REVERSE);
 #endif
+#if SO3X_DMA_ASM
+      // the record has landed (and is visible to this wave's LDS reads).  As the BUILTIN, which the compiler's wait-count pass
+      // reads, and on EVERY path to the loop's back edge: it then knows that nothing it tracks -- the next step's layer-0
+      // fragments, requested behind this step's layer 0 -- is still in flight, and puts no wait in front of the next step's first
+      // MFMAs, where one would also cover the record DMA issued just before them (0x0F70 = vmcnt(0) alone)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      asm volatile("" ::: "memory");
+#endif
       if (staged) {
+#if SO3X_DMA_ASM
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (and is visible to this wave's LDS reads)
+#endif
         q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx),
                                reinterpret_cast<const float*>(rowbuf),
                                guide_p ? reinterpret_cast<const uint16_t*>(rowbuf + kCdfGuideOff) : nullptr,

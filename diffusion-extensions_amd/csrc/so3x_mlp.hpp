@@ -711,7 +711,8 @@ template <bool WIDE = false>
 __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, bf16x8 (&l0w)[3],
                                                   float* va, float* vb, int lane, uint32_t lt = 0, uint64_t* stamp_acc = nullptr,
                                                   uint64_t* stamp_last = nullptr, unsigned* stage_token = nullptr,
-                                                  const bf16x8* __restrict__ l0next = nullptr) {
+                                                  const bf16x8* __restrict__ l0next = nullptr, const char* dma_src = nullptr,
+                                                  char* dma_dst = nullptr) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
@@ -733,6 +734,18 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   if (l0next) {
 #pragma unroll
     for (int k = 0; k < 3; k++) l0w[k] = l0next[64 * k + lane];
+  }
+  // ... and the step's 4.5 KB CDF record goes global -> LDS by five LDS-DMA instructions HERE, behind layer 0's MFMAs: issued at
+  // the top of the step they sat in front of the wait that guards those MFMAs' fragments (the compiler cannot count past the
+  // DMA pieces: s_waitcnt vmcnt(0)), i.e. every step opened with an exposed L2 round trip.  dma_src = record + 16 lane.
+  if (dma_src) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dma_dst + i * 1024), 16, 0, 0);
+    if (lane < 32)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + 4096),
+                                       (__attribute__((address_space(3))) void*)(dma_dst + 4096), 16, 0, 0);
   }
   // every stage also fetches the first five weight fragments of the NEXT stage (`pre`): a stage's MFMA chain starts on
   // registers instead of waiting ~120 cycles for its first LDS reads behind the fence
