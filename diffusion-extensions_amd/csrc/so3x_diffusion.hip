@@ -505,6 +505,9 @@ int launch_q_sample_target(hipStream_t s, const float* sched, int T, const float
   if (n == 0) return SO3X_OK;
   const int64_t nt64 = (n + kWave - 1) / kWave;
   int64_t want = (nt64 + 3) / 4;   // one tile per wave
+#ifdef SO3X_QS_TILES_PER_WAVE   /* A/B: several tiles per wave (the waves drift apart: reads of one overlap the stores of another) */
+  want = (want + SO3X_QS_TILES_PER_WAVE - 1) / SO3X_QS_TILES_PER_WAVE;
+#endif
   if (want > (1 << 20)) want = 1 << 20;
   if (!noise_in && !axes)
     hipLaunchKernelGGL(k_q_sample_target<true>, dim3((unsigned)want), dim3(kBlock), 0, s, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0,
