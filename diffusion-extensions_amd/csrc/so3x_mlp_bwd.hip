@@ -1335,6 +1335,10 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
   const int64_t ntiles = (n + 31) / 32;
   const int64_t nchain = (int64_t)gridDim.x * 4;
   const int64_t rounds = (ntiles + nchain - 1) / nchain;  // uniform trip count: the barriers are block-wide
+#if defined(SO3X_BWD_PRIO)   /* A/B: wave priority by role (1: the chain waves above the dW waves, 2: the other way round) */
+  if ((wid < 4) == (SO3X_BWD_PRIO == 1)) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
   if (wid < 4) {
     // =============================== chain waves ===============================
     char* my_img = fimg_all + wid * FIMG_BYTES;
