@@ -20,7 +20,9 @@ const Freqs& host_freqs() {
 
 size_t image_bytes_rt(int precision, int variant) {
   if (precision == SO3X_PREC_F32) return chain_layout(variant) ? image_bytes<SO3X_PREC_F32, CHAIN>() : image_bytes<SO3X_PREC_F32, FULL>();
-  return chain_layout(variant) ? image_bytes<SO3X_PREC_BF16, CHAIN>() : image_bytes<SO3X_PREC_BF16, FULL>();
+  // (every chain-layout variant reserves the largest of their images -- GATHER_TD's, with its 4 KB table -- so that the tables
+  //  behind the image sit at one offset whichever variant the prep launch wrote)
+  return chain_layout(variant) ? image_bytes<SO3X_PREC_BF16, GATHER_TD>() : image_bytes<SO3X_PREC_BF16, FULL>();
 }
 size_t beff_offset(int precision, int variant) { return (image_bytes_rt(precision, variant) + 255) & ~(size_t)255; }
 
@@ -48,9 +50,11 @@ __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, 
       if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
       else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
     }
-    if (fold_scale<PREC, VAR>() && blockIdx.x == PREP_IMG_BLOCKS - 1)  // the SiLU table behind the fragments
-      reinterpret_cast<float2*>(reinterpret_cast<char*>(img) + (size_t)n_frags<PREC, VAR>() * frag_bytes<PREC>())[threadIdx.x] =
-          silu_table_entry(threadIdx.x);
+    if (fold_scale<PREC, VAR>() && blockIdx.x == PREP_IMG_BLOCKS - 1) {  // the SiLU table behind the fragments
+      char* tab = reinterpret_cast<char*>(img) + (size_t)n_frags<PREC, VAR>() * frag_bytes<PREC>();
+      if constexpr (VAR == GATHER_TD) reinterpret_cast<float4*>(tab)[threadIdx.x] = silu_table_entry4(threadIdx.x);
+      else reinterpret_cast<float2*>(tab)[threadIdx.x] = silu_table_entry(threadIdx.x);
+    }
     return;
   }
   if (blockIdx.x < PREP_IMG_BLOCKS + PREP_WT_BLOCKS) {
@@ -189,6 +193,7 @@ int launch_prep(hipStream_t s, const float* params, int precision, int variant, 
   if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   if (variant == GATHER_T) return launch_prep_t<SO3X_PREC_BF16, GATHER_T>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
+  if (variant == GATHER_TD) return launch_prep_t<SO3X_PREC_BF16, GATHER_TD>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   return launch_prep_t<SO3X_PREC_BF16, FULL>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
 }
 }  // namespace mlp

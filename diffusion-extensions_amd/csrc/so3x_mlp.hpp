@@ -58,14 +58,16 @@ __host__ __device__ constexpr int row_of(int reg, int h) { return (reg & 3) + 8 
 // variant CHAIN: layer 0 sees only the 9 rotation entries (the 56 time-embedding
 // inputs are folded into a per-timestep effective bias, appendix C.3);
 // variant FULL : layer 0 sees [R(9), 1, emb(56)] per sample (per-sample timesteps).
-enum Variant { CHAIN = 0, FULL = 1, GATHER = 2, GATHER_T = 3 };
+enum Variant { CHAIN = 0, FULL = 1, GATHER = 2, GATHER_T = 3, GATHER_TD = 4 };
 // GATHER: the CHAIN layer-0 layout (K = 9, per-timestep effective bias) with a PER-SAMPLE bias row
 // gathered by t from the [T][96] table -- per-sample timesteps without evaluating 56 sin/cos per sample.
 // Used by the backward when the caller bounds t (t_table > 0); never scale-folded (true pre-activations).
 // GATHER_T: GATHER with the SiLU table's scale fold (bf16): the training forward.  Its MFMAs emit u = 16 z + 127.5; the
 // pre-activation the backward wants goes to the stash as z = (u - 127.5) / 16 (one multiply-add per value).
+// GATHER_TD: GATHER_T with 16-byte table entries (alpha, beta, alpha', beta'): one lookup yields silu(z) AND silu'(z) -- the
+// forward of the one-kernel training step (so3x_train_fused.hip) parks the derivative instead of the pre-activation.
 __host__ __device__ constexpr bool chain_layout(int var) { return var != FULL; }
-__host__ __device__ constexpr bool gather_layout(int var) { return var == GATHER || var == GATHER_T; }
+__host__ __device__ constexpr bool gather_layout(int var) { return var == GATHER || var == GATHER_T || var == GATHER_TD; }
 
 // number of k-steps
 template <int PREC> __host__ __device__ constexpr int ks_hidden() { return PREC == SO3X_PREC_F32 ? 33 : 5; }
@@ -82,7 +84,8 @@ template <int PREC, int VAR> __host__ __device__ constexpr int frag_last() { ret
 template <int PREC, int VAR> __host__ __device__ constexpr int n_frags() { return frag_last<PREC, VAR>() + ks_hidden<PREC>(); }
 // (the SiLU table of the folded bf16 CHAIN variant rides behind the fragments: see fold_scale below)
 template <int PREC, int VAR> __host__ __device__ constexpr int image_bytes() {
-  return n_frags<PREC, VAR>() * frag_bytes<PREC>() + ((PREC == SO3X_PREC_BF16 && (VAR == 0 /*CHAIN*/ || VAR == 3 /*GATHER_T*/)) ? 2048 : 0);
+  return n_frags<PREC, VAR>() * frag_bytes<PREC>() +
+         (PREC != SO3X_PREC_BF16 ? 0 : ((VAR == 0 /*CHAIN*/ || VAR == 3 /*GATHER_T*/) ? 2048 : (VAR == 4 /*GATHER_TD*/ ? 4096 : 0)));
 }
 
 // hidden feature index fed by (k-step ks, lane half h, element j)
@@ -128,8 +131,10 @@ template <int PREC> __host__ __device__ constexpr int l0_emb_slot0() { return PR
 constexpr float kTabC = 16.0f, kTabD = 127.5f;
 constexpr int kSiluTabEntries = 256, kSiluTabBytes = kSiluTabEntries * 8;
 constexpr int ONE_ROW2 = 69;  // second constant-one hidden row (tile 2, reg 1 of the upper lane half): carries kTabD
-static_assert(CHAIN == 0 && GATHER_T == 3 && kSiluTabBytes == 2048, "image_bytes() above spells these out");
-template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() { return PREC == SO3X_PREC_BF16 && (VAR == CHAIN || VAR == GATHER_T); }
+static_assert(CHAIN == 0 && GATHER_T == 3 && GATHER_TD == 4 && kSiluTabBytes == 2048, "image_bytes() above spells these out");
+template <int PREC, int VAR> __host__ __device__ constexpr bool fold_scale() {
+  return PREC == SO3X_PREC_BF16 && (VAR == CHAIN || VAR == GATHER_T || VAR == GATHER_TD);
+}
 
 // weight-image element value: fragment `frag`, lane, element j (bf16 only)
 template <int PREC, int VAR>
@@ -170,6 +175,22 @@ __device__ inline float2 silu_table_entry(int i) {
   return float2{az - bz * kTabD / kTabC, bz / kTabC};                        // in terms of u = 16 z + 127.5
 }
 
+// entry i of the GATHER_TD table: (alpha, beta) as above and (alpha', beta') with silu'(z) = alpha' + beta' u on the same
+// interval -- the secant of silu' = sigma (1 + z (1 - sigma)), centred like silu's (max |error| 1.2e-4; silu' is parked as f16)
+__device__ inline float4 silu_table_entry4(int i) {
+  const float2 e = silu_table_entry(i);
+  const float h = 1.0f / kTabC, z0 = ((float)i - 128.0f) * h, z1 = z0 + h, zm = z0 + 0.5f * h;
+  auto g = [](float z) { const float sg = 1.0f / (1.0f + expf(-z)); return sg * (1.0f + z * (1.0f - sg)); };
+  float bz, az;
+  if (i == 0) { bz = 0.0f; az = g(zm); }                                   // z < -7.94: silu' -> 0
+  else if (i == kSiluTabEntries - 1) { bz = 0.0f; az = g(zm); }             // z >= 7.94: silu' -> 1
+  else {
+    bz = (g(z1) - g(z0)) * kTabC;
+    az = g(z0) - bz * z0;
+    az += 0.5f * (g(zm) - (az + bz * zm));
+  }
+  return float4{e.x, e.y, az - bz * kTabD / kTabC, bz / kTabC};
+}
 
 // ---- transposed-weight image (A operand of dH = W^T dZ in the backward), global/L2-resident -----------
 // fragment order: layers 1..3: [l-1][To(in-feature tile) 3][ks over out-features KH], then layer 4: [To 3][K4]

@@ -25,9 +25,11 @@
 #include "so3x_igso3.hpp"
 #include "so3x_mlp.hpp"
 #include "so3x_reverse_step.hpp"
+#include "so3x_train.hpp"
 
 using namespace so3x;
 using namespace so3x::mlp;
+using namespace so3x::train;
 
 namespace {
 
@@ -36,7 +38,6 @@ constexpr int H_BASE(int l) { return HROWS * l; }
 constexpr int DZ_BASE(int l) { return 5 * HROWS + D * l; }
 constexpr int STASH_ROWS = 5 * HROWS + 4 * D + NOUT_MAX;  // 596 (the dZ_4 rows beyond n_out hold zeros)
 constexpr int CHUNK = 1 << 19;  // samples per stash chunk: 596 rows x 2^19 x 4 B = 1.24 GB of workspace (288 GB HBM)
-constexpr int DW_BLOCKS = 256;
 constexpr int NPAIRS = 39;                      // 4 layers x 3x3 tiles + last layer 1x3
 
 struct Z33 { float v[33]; };  // [0..15] tile 0, [16..31] tile 1, [32] = tile 2 reg 0 (feature 64 in the lower half)
@@ -106,7 +107,6 @@ __device__ __forceinline__ int z33_row0(int q) { return q < 32 ? 32 * (q >> 4) +
 // around a barrier once per tile round (4 tiles per block per round).
 // Pre-activations are kept as 33 live registers per layer (tiles 0,1 + feature 64).
 // ---------------------------------------------------------------------------------------
-template <int PREC> __host__ __device__ constexpr int wt_bytes() { return wt_nfrags<PREC>() * frag_bytes<PREC>(); }
 template <int PREC> __host__ __device__ constexpr bool swap_images() { return PREC == SO3X_PREC_F32; }
 template <int PREC, int VAR> __host__ __device__ constexpr int stage_lds_bytes() {
   return swap_images<PREC>() ? (image_bytes<PREC, VAR>() > wt_bytes<PREC>() ? image_bytes<PREC, VAR>() : wt_bytes<PREC>())
@@ -537,56 +537,6 @@ k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict
 //         chunk' = chunk ^ ((row & 7) | ((((row >> 1) ^ (row >> 3)) & 1) << 3)),  8-byte chunks, 384-byte rows.
 // LDS: forward image 53 KB + transposed image 48 KB + 4 x 12 KB = 149 KB (one block per CU).
 // ---------------------------------------------------------------------------------------
-constexpr int FIMG_COLS = 192;                 // dZ block [0, 96), H block [96, 192)
-constexpr int FIMG_PITCH = FIMG_COLS * 2;      // bytes per sample row
-constexpr int FIMG_BYTES = 32 * FIMG_PITCH;    // 12,288 per (wave, layer)
-
-__device__ __forceinline__ int fimg_off(int row, int col /*multiple of 4*/) {
-  int ch = col >> 2;
-  ch ^= (row & 7) | ((((row >> 1) ^ (row >> 3)) & 1) << 3);
-  return row * FIMG_PITCH + ch * 8;
-}
-// Addressing is split into a per-lane part computed once per round (a handful of VGPRs) and compile-time
-// constants that fold into the DS instructions' offset field; the round loop makes the per-lane parts opaque
-// (empty asm) so the compiler does not hoist ~800 loop-invariant address registers and spill them.
-struct FimgStoreLane { int rowbase, swz8; };  // rowbase = row * pitch; swz8 = 8 * swizzle(row)
-__device__ __forceinline__ FimgStoreLane fimg_store_lane(int row) {
-  return FimgStoreLane{row * FIMG_PITCH, 8 * ((row & 7) | ((((row >> 1) ^ (row >> 3)) & 1) << 3))};
-}
-// chunk index `ch` (= column / 4) is a compile-time constant plus the lane-half bit h in bit 0
-__device__ __forceinline__ void fimg_store4(char* img, const FimgStoreLane& L, int ch, float a, float b, float c, float d) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-  *reinterpret_cast<bf16x4*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = v;
-}
-// transposed-read lane offsets: [part (rows +0 / +4)][cbit (bit 3 of the tile's first chunk)]
-struct FimgReadLane { int off[2][2]; };
-__device__ __forceinline__ FimgReadLane fimg_read_lane(int lane) {
-  const int h = lane >> 5, l32 = lane & 31, G = l32 >> 4, q = (l32 & 15) >> 2, pp = l32 & 3;
-  FimgReadLane L;
-#pragma unroll
-  for (int part = 0; part < 2; part++)
-#pragma unroll
-    for (int cbit = 0; cbit < 2; cbit++) {
-      const int row = 8 * h + q + 4 * part;                                  // row within a 16-sample k-step
-      const int sw = ((q + 4 * part) & 7) | ((((q >> 1) ^ h) & 1) << 3);       // swizzle(16 ks + row): ks drops out
-      L.off[part][cbit] = row * FIMG_PITCH + 8 * ((8 * cbit + 4 * G + pp) ^ sw);
-    }
-  return L;
-}
-// MFMA operand (8 bf16 = samples 16 ks + 8 h + 0..7 of feature cb + (lane & 31)); cb in {0,32,64,96,128,160}
-__device__ __forceinline__ bf16x8 fimg_frag(const char* img, const FimgReadLane& L, int cb, int ks) {
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) s16x4* lds_p;
-  const int chb = cb >> 2, cbit = (chb >> 3) & 1;
-  const int konst = 16 * ks * FIMG_PITCH + (chb & ~15) * 8;                  // folds into the instruction offset
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[0][cbit]));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[1][cbit]));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 // pre-activations of the fused kernel are parked as packed f16 (66 -> 17 VGPRs per layer would be 33 fp32):
 // 11 significant bits on O(1..10) values, well inside the bf16 path's tolerance, and it is what lets the
 // 160 persistent dW accumulator registers + 4 layers of Z fit the 512-register budget without scratch.
@@ -659,31 +609,6 @@ __device__ __forceinline__ void zstash_load_layer(const char* tile_base, int lan
   }
   z.p[16] = __builtin_bit_cast(Z33h::h2, reinterpret_cast<const uint32_t*>(lb + 4096)[lane]);
 }
-
-// Arrival ticket of a grid (MI355X_MICROARCH.md, hand-off table row 1): the calling thread has stored this block's
-// contribution with agent-scope (sc1) stores; it drains them, takes a ticket, and the block whose ticket is the last one
-// may read every block's contribution with agent-scope loads.  The last arriver resets the ticket, so the word is zero
-// again when the launch ends; the prep launch of the step clears it anyway (a fresh workspace holds garbage).  One
-// calling thread per block.
-__device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (mine != gridDim.x - 1) return false;
-  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
-
-// What the fused MSE epilogue of the training forward needs (diffusion.py:357: F.mse_loss over the n x 3 outputs).
-struct LossArgs {
-  const float* target;   // [n][3] regression targets
-  float* dout;           // [n][3] d loss / d out = 2 (out - target) / (3 n)
-  float* loss;           // [1]
-  double* partial;       // [gridDim.x] per-block sums of squared differences
-  unsigned* ticket;      // arrival ticket, zero between launches
-  int64_t* rng_counter;  // optional: device-resident Philox offset of the noise draw, incremented once per step
-  float dscale;          // 2 / (3 n)
-  double inv_count;      // 1 / (3 n)
-};
 
 // Training forward (bf16 operands, per-timestep tables): the network output AND the stash above, so that the backward
 // does not run the forward again (that recompute was half of k_bwd_fused's time).  Same arithmetic as the recompute it
@@ -1029,10 +954,6 @@ k_mlp_fwd_stash_pair(const void* __restrict__ gimg, const float* __restrict__ be
 // its three outputs back for the MSE epilogue.  x_t still goes to HBM (the backward's layer-0 image needs it), the target and
 // the network output never do.  NOT the default: measured against the two-launch form it is no faster (see so3x_train_fwd).
 // ---------------------------------------------------------------------------------------
-struct NoiseArgs {
-  const float* sched; const float* trap_q; const uint16_t* guide_q; const float* x0; const int64_t* t; int64_t* t_draw;
-  const float* axes; const float* unif; const int64_t* rng_offset_dev; uint64_t seed, rng_offset; int64_t index_base; int T, quirk_col0;
-};
 
 template <int PREC>
 __global__ void __launch_bounds__(256, 2)
@@ -1152,17 +1073,6 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
   }
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v = {(__bf16)a, (__bf16)b};
-  return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L, int ch, uint32_t lo, uint32_t hi) {
-#if SO3X_BWD_ABL & 4
-  if (ch != 0) return;
-#endif
-  *reinterpret_cast<uint2*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = uint2{lo, hi};
-}
 // one pass over a layer's pre-activations: packed H = silu(Z) (with the constant-one row in the upper half of tile 2) and
 // the derivative silu'(Z) in fp32.  H of a dead column (a sample index past n) is NOT zeroed: its dZ is an exact zero in
 // every layer (dZ_4 = dout * 0, and the chain maps a zero column to a zero column), so whatever finite H it holds -- the
@@ -1170,16 +1080,6 @@ __device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L,
 // 33 multiplies per pass off the chain wave (9 % of its vector instructions).
 // (MASK: the recomputing variant keeps the multiply by the live flag -- without it the register allocator of THAT kernel,
 //  which spills already, does worse.)
-// -DSO3X_BWD_ABL=<bits> (timing experiments only, tools/ab; results meaningless): 1 = the dW waves skip their MFMAs and operand
-// reads (they still meet every barrier), 2 = the chain waves skip the dH MFMAs, 4 = the chain waves skip their image stores
-#ifndef SO3X_BWD_ABL
-#define SO3X_BWD_ABL 0
-#endif
-#if SO3X_BWD_ABL & 1
-#define SO3X_DW_MFMA(a, b, c) (c)
-#else
-#define SO3X_DW_MFMA(a, b, c) mfma_bf16(a, b, c)
-#endif
 // -DSO3X_BWD_ABL_SILU=<k> (timing experiments only, tools/ab): the first k register pairs of a pass keep the real arithmetic, the
 // rest copy z through (results meaningless) -- how much of the backward is the chain wave's transcendental stream?
 #ifndef SO3X_BWD_ABL_SILU
@@ -1203,47 +1103,12 @@ __device__ __forceinline__ void silu_pass(const Z33h& z, int h, uint32_t (&ph)[1
   silu_grad<PREC>(z.get(32), &a, &dv[32]);
   ph[16] = MASK ? pack_bf16x2(h ? lv : a * lv, 0.0f) : pack_bf16x2(h ? 1.0f : a, 0.0f);
 }
-// dH = W^T dZ with dZ given as packed bf16 pairs (the MFMA operand bits as they are)
-template <int PREC, int L>
-__device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const uint32_t (&pdz)[17], f32x16 (&dh)[3], int lane) {
-  const bf16x8* w = reinterpret_cast<const bf16x8*>(wt);
-  constexpr int KS = L < 4 ? 5 : 1;
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  bf16x8 b[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    const u32x4 v = ks < 4 ? u32x4{pdz[4 * ks], pdz[4 * ks + 1], pdz[4 * ks + 2], pdz[4 * ks + 3]} : u32x4{pdz[16], 0u, 0u, 0u};
-    b[ks] = __builtin_bit_cast(bf16x8, v);
-  }
-#pragma unroll
-  for (int to = 0; to < 3; to++) {
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 a = zero16<PREC>();
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-#if SO3X_BWD_ABL & 2
-      a[ks] += __builtin_bit_cast(float, pdz[ks]);
-#else
-      a = mfma_bf16(w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane], b[ks], a);
-#endif
-    }
-    dh[to] = a;
-  }
-}
-
 // The dW role of k_bwd_fused for dW wave DWI (0..3): owns pairs p = DWI + 4k of the 39 (dZ tile, H tile) pairs.
 // Ownership of the 39 dW tiles by the four dW waves.  In the hidden layers (3 x 3 tiles each) a wave owns a whole ROW
 // of tiles -- the three pairs that share the dZ tile `to` -- so the A fragments are read once per row instead of once per
 // pair (64 transposed reads per layer instead of 96); the wave that gets no row in layer l is (l + 3) & 3, so every
 // wave works in three of the four layers, and the three tiles of the output layer go one each to waves 0..2: 10/10/10/9
 // persistent accumulators.  Everything here is compile-time per DWI.
-__host__ __device__ constexpr int dw_row(int dwi, int l) { return (dwi - l) & 3; }              // 0..2 = the row, 3 = idle in layer l
-__host__ __device__ constexpr int dw_slot(int dwi, int l) {                                       // index of layer l among the wave's active layers
-  int c = 0;
-  for (int q = 0; q < l; q++) c += dw_row(dwi, q) != 3;
-  return c;
-}
-
 // The dW role of k_bwd_fused for dW wave DWI (0..3).
 template <int PREC, int DWI>
 __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, float* __restrict__ slabs, int lane, int nout) {
@@ -1544,21 +1409,6 @@ inline int launch_slab_reduce(hipStream_t s, const float* slabs, int64_t n, int 
   const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
   hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, slabs, gf, dparams, 0, nparams(nout), gscale);
   return check_launch();
-}
-
-// Training-step workspace (so3x_train_fwd / so3x_train_bwd): what ONE prep launch builds for both halves of the step,
-// the dW partial slabs, the regression targets and the loss bookkeeping.
-struct TrainLayout { size_t wt, slabs, target, partial, ticket, end; };
-inline TrainLayout train_layout(int64_t n, int T) {
-  constexpr int PREC = SO3X_PREC_BF16;
-  TrainLayout L;
-  L.wt = (tables_end(PREC, GATHER, T) + 255) & ~(size_t)255;
-  L.slabs = (L.wt + (size_t)wt_nfrags<PREC>() * frag_bytes<PREC>() + 255) & ~(size_t)255;
-  L.target = L.slabs + (size_t)DW_BLOCKS * NPARAMS_MAX * sizeof(float);
-  L.partial = (L.target + (size_t)(n > 0 ? n : 0) * 3 * sizeof(float) + 255) & ~(size_t)255;
-  L.ticket = L.partial + 512 * sizeof(double);
-  L.end = L.ticket + 256;
-  return L;
 }
 
 // workspace layout: [weight image | (t_table: beff, emb tables)] [transposed image] [slabs] [stash]

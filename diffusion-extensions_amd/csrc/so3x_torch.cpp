@@ -285,6 +285,29 @@ Tensor train_bwd(const Tensor& x_t, const Tensor& t, const Tensor& dout, const T
      "train_bwd");
   return grad;
 }
+// noising + forward + loss + backward down to the partial dW slabs as ONE kernel, on caller-owned buffers (train_bwd_reduce /
+// train_bwd_reduce_adam with the same n, T, workspace follows)
+void train_fused(const Tensor& params, const Tensor& sched, const Tensor& trap_q, const optional<Tensor>& guide_q, const Tensor& x0,
+                 const optional<Tensor>& t, bool quirk_col0, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                 int64_t rng_offset, optional<Tensor> rng_counter, int64_t index_base, Tensor& loss, optional<Tensor> t_used, optional<Tensor> x_t,
+                 optional<Tensor> out, Tensor& workspace) {
+  GUARD(x0);
+  const int64_t n = x0.numel() / 9;
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(params.numel() == SO3X_MLP_PARAMS, "so3x: the fused training step is built for the ", SO3X_MLP_PARAMS, "-parameter skew-vector network");
+  TORCH_CHECK(n > 0, "so3x: empty batch");
+  TORCH_CHECK(loss.numel() >= 1 && (!t_used.has_value() || t_used->numel() == n) && (!x_t.has_value() || x_t->numel() == n * 9) &&
+              (!out.has_value() || out->numel() == n * 3) && (!t.has_value() || t->numel() == n), "so3x: train_fused buffer sizes differ");
+  dev(loss, "loss"); dev(workspace, "workspace", at::kByte);
+  ok(so3x_train_fused(strm(x0), F(dev(params, "params")), F(sched), T, F(dev(trap_q, "trap_q")), Guide(guide_q), F(dev(x0, "x_start")),
+                      t.has_value() ? I64(dev(*t, "t", at::kLong)) : nullptr,
+                      t_used.has_value() ? dev(*t_used, "t_used", at::kLong).mutable_data_ptr<int64_t>() : nullptr, quirk_col0 ? 1 : 0,
+                      Fo(axes, "axes"), Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset,
+                      rng_counter.has_value() ? dev(*rng_counter, "rng_counter", at::kLong).mutable_data_ptr<int64_t>() : nullptr, index_base, n,
+                      Fm(loss), x_t.has_value() ? dev(*x_t, "x_t").mutable_data_ptr<float>() : nullptr,
+                      out.has_value() ? dev(*out, "out").mutable_data_ptr<float>() : nullptr, workspace.mutable_data_ptr(), workspace.numel()),
+     "train_fused");
+}
 // the step in stages, on caller-owned buffers (so3x.graphs.TrainStepGraph pipelines them across two streams)
 void train_noise(const Tensor& sched, const Tensor& trap_q, const optional<Tensor>& guide_q, const Tensor& x0, const optional<Tensor>& t,
                  bool quirk_col0, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed, int64_t rng_offset,
@@ -576,6 +599,9 @@ TORCH_LIBRARY(so3x, m) {
         "Tensor? unif, int seed, int rng_offset, Tensor(a!)? rng_counter, int index_base, bool want_out) "
         "-> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("train_bwd(Tensor x_t, Tensor t, Tensor dout, Tensor zstash, Tensor(a!) workspace, int T, Tensor? gscale, int n_params) -> Tensor");
+  m.def("train_fused(Tensor params, Tensor sched, Tensor trap_q, Tensor? guide_q, Tensor x0, Tensor? t, bool quirk_col0, Tensor? axes, "
+        "Tensor? unif, int seed, int rng_offset, Tensor(a!)? rng_counter, int index_base, Tensor(b!) loss, Tensor(c!)? t_used, "
+        "Tensor(d!)? x_t, Tensor(e!)? out, Tensor(f!) workspace) -> ()");
   m.def("train_noise(Tensor sched, Tensor trap_q, Tensor? guide_q, Tensor x0, Tensor? t, bool quirk_col0, Tensor? axes, Tensor? unif, int seed, "
         "int rng_offset, Tensor? rng_counter, int index_base, Tensor(a!) x_t, Tensor(b!) t_used, Tensor(c!) workspace) -> ()");
   m.def("train_net(Tensor params, int T, Tensor x_t, Tensor t_used, Tensor(a!) dout, Tensor(b!) zstash, Tensor(c!) loss, Tensor(d!)? out, "
@@ -639,6 +665,7 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("p_sample_chain_out", p_sample_chain_out);
   m.impl("train_fwd", train_fwd);
   m.impl("train_bwd", train_bwd);
+  m.impl("train_fused", train_fused);
   m.impl("train_noise", train_noise);
   m.impl("train_net", train_net);
   m.impl("train_bwd_partial", train_bwd_partial);

@@ -1,0 +1,499 @@
+// so3x_train_fused.hip -- one training step of SO3Diffusion(RotPredict(65, "skewvec")) under loss_type="skewvec"
+// (reference so3_train.py:73-75: loss = process(truepos); loss.backward()) as ONE kernel: noise draw + q_sample + regression
+// target (diffusion.py:339-355, distributions.py:33-51), the network forward (so3_train.py:39-49), the MSE and its gradient
+// (diffusion.py:357) and the whole backward down to per-workgroup dW partial slabs.  Nothing per-sample goes through HBM:
+// a sample costs its 36 bytes of x_0 in (the staged step -- so3x_mlp_bwd.hip -- wrote and re-read ~1.4 KB per sample:
+// x_t, target, timestep, dout and a 544-byte pre-activation stash between three kernels).
+//
+// Nothing in the math needs a grid-wide barrier between forward and backward: d loss / d out = 2 (out - target) / (3 n) is
+// per sample with n known up front; only the REPORTED loss is a reduction (arrival ticket, as in the staged forward).
+//
+// Workgroup = 8 waves, one per CU (LDS 158 KB), as k_bwd_fused:
+//   * waves 0-3 ("chain"): one 32-sample tile per round each -- forward through the LDS-resident weight image with the
+//     table SiLU, whose 16-byte entries (GATHER_TD image, so3x_mlp.hpp) yield silu(z) AND silu'(z) in one lookup: the
+//     activations are kept as packed bf16 pairs (they ARE the next layer's MFMA operand and, later, the H_l image of the dW
+//     products) and the derivatives as packed f16 pairs, 4 x (17 + 17) registers -- the pre-activations themselves are never
+//     kept, so the backward has no transcendental and no stash to wait for: dZ_{l-1} = dH_l * silu'(Z_{l-1}) is one
+//     multiply per value.  Then the dZ chain on the transposed image, handing dZ_l / H_l to the dW waves through the per-wave
+//     LDS images of so3x_train.hpp, two barriers per layer.
+//   * waves 4-7 ("dW"): the 39 dW tiles as persistent MFMA accumulators (dw_row), and -- in the time the chain waves spend in
+//     their forward, when the images are idle -- the NOISING of the tiles two rounds ahead: lane = sample (Philox block,
+//     timestep, inverse-CDF angle, Rodrigues, q_sample, target: k_q_sample_target's arithmetic, bit for bit), 64 samples per
+//     pass every other round; x_t leaves as the packed bf16 pairs the network's layer 0 and the H_0 image want, with the
+//     target and the timestep, through a 4.5 KB hand-over buffer in LDS.
+#include "so3x_common.hpp"
+#include "so3x_igso3.hpp"
+#include "so3x_mlp.hpp"
+#include "so3x_reverse_step.hpp"
+#include "so3x_train.hpp"
+
+using namespace so3x;
+using namespace so3x::mlp;
+using namespace so3x::train;
+
+namespace {
+
+constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_TD, FB = frag_bytes<PREC>();
+constexpr int IMG = image_bytes<PREC, VAR>();                 // 53 fragments + the 4 KB (silu, silu') table
+constexpr int WTB = wt_bytes<PREC>();                         // transposed image: 48 fragments
+constexpr int REC_DW = 8;                                     // hand-over record of a sample: x_t as 5 bf16 pairs, target[3]
+constexpr int HAND_BYTES = 128 * REC_DW * 4 + 128 * 4;        // ... + the timesteps
+constexpr int LDS_WT = IMG, LDS_FIMG = LDS_WT + WTB, LDS_HAND = LDS_FIMG + 4 * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES;
+constexpr int LDS_TOTAL = LDS_RED + 128;
+static_assert(LDS_TOTAL <= 160 * 1024 && LDS_HAND % 16 == 0, "one workgroup per CU");
+
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, h2{(_Float16)a, (_Float16)b});
+}
+__device__ __forceinline__ float f16_lo(uint32_t w) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return (float)__builtin_bit_cast(h2, w)[0];
+}
+__device__ __forceinline__ float f16_hi(uint32_t w) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return (float)__builtin_bit_cast(h2, w)[1];
+}
+
+// what a noising lane hands to the chain wave that owns its sample
+struct Hand { uint32_t xb[5]; float tg[3]; int tt; };
+
+// One sample of SO3Diffusion.forward's front half (diffusion.py:339-355, 373): k_q_sample_target's arithmetic (so3x_diffusion.hip),
+// operation for operation -- the staged step and this one draw the same noise, timesteps and targets bit for bit.
+// EXPLICIT: the caller supplies the sampler's draws (axes, unif: the parity paths); otherwise they come from the sample's Philox block.
+// sc = the sample index clamped into [0, n) (dead lanes compute on it and are overwritten afterwards).
+template <bool EXPLICIT>
+__device__ __forceinline__ Hand noise_sample(const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t, int64_t sc, bool live,
+                                             float* __restrict__ x_t_out) {
+  const int T = na.T;
+#ifdef EXP_NONOISE
+  { Hand hd; hd.xb[0] = (uint32_t)sc; hd.xb[1] = hd.xb[2] = hd.xb[3] = hd.xb[4] = 0; hd.tg[0] = hd.tg[1] = hd.tg[2] = 0.f; hd.tt = 0; return hd; }
+#endif
+  auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
+  auto clamp_t = [&](int64_t v) -> int64_t { return v < 0 ? 0 : (v >= T ? T - 1 : v); };
+  Philox4 r{0u, 0u, 0u, 0u};
+  if (!na.t || !EXPLICIT) r = philox4x32_10(na.seed, (uint64_t)(na.index_base + sc), rng_offset);
+  const int64_t tt = na.t ? clamp_t(na.t[sc]) : drawn_t(r.w);
+  if (na.t_draw && live) na.t_draw[sc] = tt;
+  float ax[3], u;
+  if constexpr (EXPLICIT) {
+    const float a0 = na.axes[sc * 3], a1 = na.axes[sc * 3 + 1], a2 = na.axes[sc * 3 + 2];
+    const float nrm = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);             // distributions.py:36
+    ax[0] = a0 / nrm; ax[1] = a1 / nrm; ax[2] = a2 / nrm;
+    const float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // util.py:201
+    ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
+    u = na.unif[sc];
+  } else {
+    unit_axis(r.x, r.y, ax);
+    u = u01(r.z);
+  }
+  const float* row = na.trap_q + tt * 999;
+  const float* wrow = wrow_t >= 0 ? na.trap_q + wrow_t * 999 : row;
+  const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, na.guide_q ? na.guide_q + tt * kGuidePitch : nullptr);
+  float nz[9], x[9], w[3], xs[9], xt[9], lw[3];
+  exp_axis_angle(ax, ang, nz);
+  load_rot9(na.x0, sc, x);
+  const float k = na.sched[S_SQRT_AC * T + tt];
+  log3(x, w);
+  w[0] *= k; w[1] *= k; w[2] *= k;
+  exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
+  mul33(xs, nz, xt);                // x_blend @ noise, :346
+  if (x_t_out && live) store_rot9(x_t_out, sc, xt);
+  // skew2vec(log_rmat(noise)) / eps, :355 -- of a noise built here from a unit axis and an angle in [0, pi] it IS axis * angle
+  if constexpr (EXPLICIT) log3(nz, lw);
+  else { lw[0] = ax[0] * ang; lw[1] = ax[1] * ang; lw[2] = ax[2] * ang; }
+  const float ie = 1.0f / na.sched[S_SQRT_1MAC * T + tt];
+  Hand hd;
+  hd.tg[0] = lw[0] * ie; hd.tg[1] = lw[1] * ie; hd.tg[2] = lw[2] * ie;
+  hd.xb[0] = pack_bf16x2(xt[0], xt[1]); hd.xb[1] = pack_bf16x2(xt[2], xt[3]); hd.xb[2] = pack_bf16x2(xt[4], xt[5]);
+  hd.xb[3] = pack_bf16x2(xt[6], xt[7]); hd.xb[4] = pack_bf16x2(xt[8], 1.0f);
+  hd.tt = (int)tt;
+  if (!live) {  // a column past the batch: well-defined finite inputs (its dZ is an exact zero in every layer)
+    hd.xb[0] = 0x00003F80u; hd.xb[1] = 0u; hd.xb[2] = 0x00003F80u; hd.xb[3] = 0u; hd.xb[4] = 0x3F803F80u;
+    hd.tg[0] = hd.tg[1] = hd.tg[2] = 0.0f;
+    hd.tt = 0;
+  }
+  return hd;
+}
+
+// SiLU and its derivative for one layer's 33 pre-activation coordinates u = 16 z + 127.5 (the MFMAs emit them: GATHER_TD image):
+// hp = silu(z) as packed bf16 pairs in the order of the next layer's B operand (word w of k-step k = hp[4 k + w]; word 16 = the
+// fifth k-step's first: feature 64 | the constant ones of rows 68, 69), dp = silu'(z) as packed f16 pairs in the same order.
+// The lookups of eight values are issued together and consumed afterwards (one LDS round trip per group).
+__device__ __forceinline__ void activate_td(const f32x16 (&acc)[3], uint32_t (&hp)[17], uint32_t (&dp)[17], int h, const char* tab) {
+#ifndef ACT_G
+#define ACT_G 8
+#endif
+  constexpr int G = ACT_G;
+#pragma unroll
+  for (int g0 = 0; g0 < 32; g0 += G) {
+    float4 e[G];
+    float u[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+      const int q = g0 + i;
+      u[i] = acc[q >> 4][q & 15];
+      const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[i], 0u, 0u);  // round to nearest, saturated to 0..255
+      e[i] = *reinterpret_cast<const float4*>(tab + idx * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < G; i += 2) {
+      hp[(g0 + i) >> 1] = pack_bf16x2(fmaf(e[i].y, u[i], e[i].x), fmaf(e[i + 1].y, u[i + 1], e[i + 1].x));
+      dp[(g0 + i) >> 1] = pack_f16x2(fmaf(e[i].w, u[i], e[i].z), fmaf(e[i + 1].w, u[i + 1], e[i + 1].z));
+      // the packed words ARE the parked state: opaque, so that the compiler keeps them and not their two fp32 sources each
+      // (it sank the packing to the backward's uses and spilled 264 fp32 values per round)
+      asm volatile("" : "+v"(hp[(g0 + i) >> 1]), "+v"(dp[(g0 + i) >> 1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one group's lookups (32 registers) in flight at a time
+  }
+  const float u = acc[2][0];
+  const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u, 0u, 0u);
+  const float4 e = *reinterpret_cast<const float4*>(tab + idx * 16);
+  hp[16] = h ? 0x3F803F80u : pack_bf16x2(fmaf(e.y, u, e.x), 0.0f);   // rows 68, 69: the constant ones (bias / table offset carriers)
+  dp[16] = h ? 0u : pack_f16x2(fmaf(e.w, u, e.z), 0.0f);
+  asm volatile("" : "+v"(hp[16]), "+v"(dp[16]));
+}
+
+__device__ __forceinline__ void operand_of(const uint32_t (&hp)[17], Tile<PREC>& t) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int k = 0; k < 4; k++) t.b[k] = __builtin_bit_cast(bf16x8, u32x4_t{hp[4 * k], hp[4 * k + 1], hp[4 * k + 2], hp[4 * k + 3]});
+  t.b[4] = __builtin_bit_cast(bf16x8, u32x4_t{hp[16], 0u, 0u, 0u});
+}
+
+// ---- the dW waves: k_bwd_fused's dW role (so3x_mlp_bwd.hip) + the noising of the tiles ahead -----------------------------------
+struct Geo { int64_t n, ntiles, nchain, rounds; };
+
+template <int DWI, bool EXPLICIT>
+__device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t,
+                                              float* __restrict__ x_t_out, float* __restrict__ slabs, int lane) {
+  const char* fimg_all = lds + LDS_FIMG;
+  uint32_t* rec = reinterpret_cast<uint32_t*>(lds + LDS_HAND) + (DWI * 32 + (lane & 31)) * REC_DW;
+  int* ht = reinterpret_cast<int*>(lds + LDS_HAND + 128 * REC_DW * 4) + DWI * 32 + (lane & 31);
+  const int col = lane & 31, h = lane >> 5;
+  f32x16 acc[10];  // [3 slot + ti] for the hidden layers, [9] = the wave's tile of the output layer
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
+  // a noising pass covers the wave's tile of round `ra` (lanes 0..31) and of round ra + 1 (lanes 32..63)
+  auto pass = [&](int64_t ra) -> Hand {
+    const int64_t r = ra + h;
+    const int64_t tile = r * g.nchain + (int64_t)blockIdx.x * 4 + DWI, s = tile * 32 + col;
+    const bool live = r < g.rounds && tile < g.ntiles && s < g.n;
+    return noise_sample<EXPLICIT>(na, rng_offset, wrow_t, live ? s : g.n - 1, live, x_t_out);
+  };
+  auto hand_over = [&](const Hand& hd) {
+    *reinterpret_cast<uint4*>(rec) = uint4{hd.xb[0], hd.xb[1], hd.xb[2], hd.xb[3]};
+    *reinterpret_cast<uint4*>(rec + 4) = uint4{hd.xb[4], __float_as_uint(hd.tg[0]), __float_as_uint(hd.tg[1]), __float_as_uint(hd.tg[2])};
+    *ht = hd.tt;
+  };
+  Hand hd = pass(0);
+  if (h == 0) hand_over(hd);
+  __syncthreads();  // P: round 0's samples are in the hand-over buffer
+  FimgReadLane RL = fimg_read_lane(lane);
+  for (int64_t rd = 0; rd < g.rounds; rd++) {
+    asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
+    // odd rounds: the samples of rounds rd + 1, rd + 2 are drawn while the chain waves run their forward (the images are idle)
+    if (rd & 1) hd = pass(rd + 1);
+#pragma unroll
+    for (int l = 4; l >= 0; l--) {
+      __syncthreads();  // B1: images of layer l complete
+      if (l == 4) {
+        // the chain waves read round rd's records before this barrier and read round rd + 1's behind the round's last one
+        if (h == (int)((rd & 1) ^ 1)) hand_over(hd);
+        if (DWI < 3) {
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            const char* im = fimg_all + w * FIMG_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) acc[9] = mfma_bf16(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
+          }
+        }
+      } else if (dw_row(DWI, l) != 3) {
+        const int to = dw_row(DWI, l), sl = dw_slot(DWI, l);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const char* im = fimg_all + w * FIMG_BYTES;
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) {
+            const bf16x8 a = fimg_frag(im, RL, 32 * to, ks);
+#pragma unroll
+            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
+          }
+        }
+      }
+      __syncthreads();  // B2: done with the images
+    }
+  }
+  // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
+  float* slab = slabs + (size_t)blockIdx.x * NPARAMS_MAX;
+  int colw = col, hw = h;
+  asm volatile("" : "+v"(colw), "+v"(hw));  // (no slab addresses computed -- and spilled -- in front of the round loop)
+  auto write_tile = [&](const f32x16& a, int l, int to, int ti) {
+    const int in_f = 32 * ti + colw;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int out = l < 4 ? 32 * to + row_of(r, hw) : head_of_row(row_of(r, hw));
+      if (out < 0 || out >= (l < 4 ? D : 3)) continue;
+      int pc;  // weight column, -2 = bias, -1 = padding
+      if (l == 0) pc = in_f < 9 ? in_f : (in_f == 9 ? -2 : (in_f < 66 ? in_f - 1 : -1));
+      else pc = in_f < D ? in_f : (in_f == ONE_ROW ? -2 : -1);
+      if (pc == -1) continue;
+      const int base = l * LAYER_STRIDE;
+      slab[pc >= 0 ? base + out * D + pc : base + (l < 4 ? D : 3) * D + out] = a[r];
+    }
+  };
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    if (dw_row(DWI, l) == 3) continue;
+#pragma unroll
+    for (int ti = 0; ti < 3; ti++) write_tile(acc[3 * dw_slot(DWI, l) + ti], l, dw_row(DWI, l), ti);
+  }
+  if (DWI < 3) write_tile(acc[9], 4, 0, DWI);
+}
+
+template <bool EXPLICIT>
+__global__ void __launch_bounds__(512, 2)
+k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
+              const uint4* __restrict__ h0_tab, NoiseArgs na, float* __restrict__ x_t_out, float* __restrict__ out,
+              float* __restrict__ slabs, int64_t n, LossArgs la) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* wt_lds = lds + LDS_WT;
+  char* fimg_all = lds + LDS_FIMG;
+  load_image(gimg, lds, IMG);
+  load_image(gwt, wt_lds, WTB);
+  for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
+  Geo g;
+  g.n = n;
+  g.ntiles = (n + 31) / 32;
+  g.nchain = (int64_t)gridDim.x * 4;
+  g.rounds = (g.ntiles + g.nchain - 1) / g.nchain;  // uniform trip count: the barriers are block-wide
+  uint64_t rng_offset = na.rng_offset;
+  if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];  // device-resident part of the counter (hipGraph replays)
+  __syncthreads();  // S0: images, tables
+  float sq = 0.0f;
+  if (wid < 4) {
+    // =============================== chain waves ===============================
+    char* my_img = fimg_all + wid * FIMG_BYTES;
+    const char* tab = lds + (size_t)n_frags<PREC, VAR>() * FB;
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(lds + LDS_HAND) + (wid * 32 + col) * REC_DW;
+    const int* ht = reinterpret_cast<const int*>(lds + LDS_HAND + 128 * REC_DW * 4) + wid * 32 + col;
+    FimgStoreLane SL = fimg_store_lane(col);
+    __syncthreads();  // P
+    for (int64_t rd = 0; rd < g.rounds; rd++) {
+      asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per round: no hoisting of the ~90 store addresses
+      // ... and none of the 101 weight-fragment reads: the images are loop-invariant, and hoisted out of the round loop they
+      // are 400 registers' worth of spills (seen: 2.4 KB of scratch per lane)
+      int lane_r = lane;
+      asm volatile("" : "+v"(lane_r));
+      const int64_t tile = rd * g.nchain + (int64_t)blockIdx.x * 4 + wid;
+      const int64_t s = tile * 32 + col;
+      const bool live = tile < g.ntiles && s < n;
+      // ---- this round's samples from the dW waves: x_t as bf16 pairs, target, timestep
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      // (uint4, a struct of four words, on purpose: this hipcc miscompiles __builtin_bit_cast of the ELEMENTS of an ext-vector
+      //  load -- every element came back as element 0; so3x_mlp_bwd.hip's zstash_load_layer met the same bug)
+      const uint4 r0 = *reinterpret_cast<const uint4*>(rec), r1 = *reinterpret_cast<const uint4*>(rec + 4);
+      const int tt = *ht;
+      const uint32_t xb[5] = {r0.x, r0.y, r0.z, r0.w, r1.x};
+      const float tg[3] = {__uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
+      // ---- forward: layer 0 from the per-timestep effective-bias row (K = 9: the rotation entries), then the hidden layers
+      uint32_t hpk[4][17], dpk[4][17];
+      f32x16 acc[3];
+      {
+        const float* beff = beff_tab + (size_t)tt * 96;
+#pragma unroll
+        for (int to = 0; to < 3; to++) {
+          f32x16 a;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (to == 2 && q > 0) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) a[4 * q + r] = 0.0f;
+            } else {
+              const float4 v = *reinterpret_cast<const float4*>(beff + 32 * to + 8 * q + 4 * h);
+              a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+          }
+          acc[to] = a;
+        }
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, u32x4_t{h ? (xb[4] & 0xFFFFu) : xb[0], h ? 0u : xb[1], h ? 0u : xb[2], h ? 0u : xb[3]});
+        const bf16x8* w = reinterpret_cast<const bf16x8*>(lds);
+#pragma unroll
+        for (int to = 0; to < 3; to++) acc[to] = mfma_bf16(w[to * 64 + lane_r], b0, acc[to]);
+      }
+      activate_td(acc, hpk[0], dpk[0], h, tab);
+#ifdef EXP_NOFWD
+#pragma unroll
+      for (int l = 1; l < 4; l++)
+#pragma unroll
+        for (int r = 0; r < 17; r++) { hpk[l][r] = hpk[0][r] + l; dpk[l][r] = dpk[0][r] + l; }
+#else
+#pragma unroll
+      for (int l = 1; l < 4; l++) {
+        Tile<PREC> cur;
+        operand_of(hpk[l - 1], cur);
+        hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane_r);
+        activate_td(acc, hpk[l], dpk[l], h, tab);
+      }
+#endif
+      f32x16 last[1];
+      {
+        Tile<PREC> cur;
+        operand_of(hpk[3], cur);
+        hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane_r);
+      }
+      // ---- MSE and its gradient (diffusion.py:357): head outputs 0..2 = regs 0..2 of the lower half (head_of_row)
+      uint32_t pdz[17];
+#pragma unroll
+      for (int r = 0; r < 17; r++) pdz[r] = 0u;
+      if (h == 0) {
+        const float d0 = last[0][0] - tg[0], d1 = last[0][1] - tg[1], d2 = last[0][2] - tg[2];
+        if (live) {
+          sq += d0 * d0 + d1 * d1 + d2 * d2;
+          if (out) { out[s * 3] = last[0][0]; out[s * 3 + 1] = last[0][1]; out[s * 3 + 2] = last[0][2]; }
+        }
+        const float sc = live ? la.dscale : 0.0f;  // dead columns: dZ_4 = 0, hence every dZ_l = 0 and no contribution to any dW sum
+        pdz[0] = pack_bf16x2(d0 * sc, d1 * sc);
+        pdz[1] = pack_bf16x2(d2 * sc, 0.0f);
+      }
+      // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them), fetched now, stored five layers later
+      uint4 hq[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) hq[i] = h0_tab[(size_t)tt * 12 + 6 * h + i];
+      // ---- backward:   [write images of layer l] B1 [dH_l, dZ_{l-1}] B2
+      f32x16 dh[3];
+#pragma unroll
+      for (int l = 4; l >= 0; l--) {
+#pragma unroll
+        for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 2 * c8 + h, pdz[2 * c8], pdz[2 * c8 + 1]);
+        fimg_store_pk(my_img, SL, 16 + h, h ? 0u : pdz[16], 0u);
+        if (l > 0) {
+          const uint32_t (&ph)[17] = hpk[l - 1];  // H_l = silu(Z_{l-1}): the forward's operand bits
+#pragma unroll
+          for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 24 + 2 * c8 + h, ph[2 * c8], ph[2 * c8 + 1]);
+          fimg_store_pk(my_img, SL, 24 + 16 + h, ph[16], 0u);
+        } else {  // H_0 = the network input: [0..8] R, [9] one, [10..65] emb(t), zeros; the two lanes of a column split the row
+          const uint32_t hd[24] = {hq[0].x, hq[0].y, hq[0].z, hq[0].w, hq[1].x, hq[1].y, hq[1].z, hq[1].w, hq[2].x, hq[2].y, hq[2].z, hq[2].w,
+                                   hq[3].x, hq[3].y, hq[3].z, hq[3].w, hq[4].x, hq[4].y, hq[4].z, hq[4].w, hq[5].x, hq[5].y, hq[5].z, hq[5].w};
+#pragma unroll
+          for (int c4 = 0; c4 < 12; c4++) {
+            const int ch0 = 24 + 12 * h + c4;  // chunk of the 4 consecutive input slots 48 h + 4 c4 ..
+            uint32_t lo = hd[2 * c4], hi = hd[2 * c4 + 1];
+            if (c4 < 3) {  // the lower half's first three chunks carry the rotation entries and the constant one
+              const uint32_t plo = c4 == 0 ? xb[0] : (c4 == 1 ? xb[2] : xb[4]);
+              const uint32_t phi = c4 == 0 ? xb[1] : (c4 == 1 ? xb[3] : hi);
+              lo = h ? lo : plo;
+              hi = h ? hi : phi;
+            }
+            fimg_store_pk(my_img, SL, ch0, live ? lo : 0u, live ? hi : 0u);
+          }
+        }
+        __syncthreads();  // B1: images of layer l complete -- the dW waves consume them while this wave goes on
+        if (l > 0) {
+          if (l == 4) dh_layer_pk<PREC, 4>(wt_lds, pdz, dh, lane_r);
+          if (l == 3) dh_layer_pk<PREC, 3>(wt_lds, pdz, dh, lane_r);
+          if (l == 2) dh_layer_pk<PREC, 2>(wt_lds, pdz, dh, lane_r);
+          if (l == 1) dh_layer_pk<PREC, 1>(wt_lds, pdz, dh, lane_r);
+          const uint32_t (&dp)[17] = dpk[l - 1];  // silu'(Z_{l-1}), parked by the forward
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const float g0 = (r < 8 ? dh[0][2 * r] : dh[1][2 * r - 16]) * f16_lo(dp[r]);
+            const float g1 = (r < 8 ? dh[0][2 * r + 1] : dh[1][2 * r - 15]) * f16_hi(dp[r]);
+            pdz[r] = pack_bf16x2(g0, g1);
+          }
+          pdz[16] = pack_bf16x2(h ? 0.0f : dh[2][0] * f16_lo(dp[16]), 0.0f);  // upper half of tile 2 / reg 0 = the constant-one row
+        }
+        __syncthreads();  // B2: the dW waves are done with the images
+      }
+    }
+  } else {
+    // ================================ dW waves =================================
+    // distributions.py:42-43: column 0 == sample 0's eps.  With drawn timesteps that is GLOBAL sample 0's draw (Philox index 0,
+    // whatever this shard's index_base); with caller-supplied timesteps this call's t[0], as in the reference.
+    const int T = na.T;
+    int64_t wrow_t = -1;
+    if (na.quirk_col0) {
+      if (na.t) { const int64_t v = na.t[0]; wrow_t = v < 0 ? 0 : (v >= T ? T - 1 : v); }
+      else wrow_t = (int64_t)(((uint64_t)philox4x32_10(na.seed, (uint64_t)0, rng_offset).w * (uint64_t)T) >> 32);
+    }
+    switch (wid - 4) {
+      case 0: dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+      case 1: dw_role_fused<1, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+      case 2: dw_role_fused<2, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+      default: dw_role_fused<3, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+    }
+  }
+  // ---- the reported loss: per-block sums of squares combined by the last block to arrive, in a fixed tree (deterministic)
+  double* wsum = reinterpret_cast<double*>(lds + LDS_RED);
+  int* is_last = reinterpret_cast<int*>(lds + LDS_RED + 64);
+  double v = (double)sq;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if (lane == 0) wsum[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double bs = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *is_last = last_block_arrives(la.ticket) ? 1 : 0;
+  }
+  __syncthreads();  // the other waves of the last block read the partials only behind this barrier
+  if (*is_last) {
+    double a = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 512) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+    __syncthreads();
+    if (lane == 0) wsum[wid] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      la.loss[0] = (float)((((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * la.inv_count);
+      if (la.rng_counter) la.rng_counter[0] += 1;  // every block read this step's offset at its start
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int so3x_train_fused(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                     const float* x0, const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif, uint64_t seed,
+                     uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* loss, float* x_t, float* out,
+                     void* workspace, size_t workspace_bytes) {
+  if (n <= 0 || T <= 0 || !params || !sched || !trap_q || !x0 || !loss || ((axes == nullptr) != (unif == nullptr))) return SO3X_ERR_INVALID_ARG;
+  const TrainLayout L = train_layout(n, T);
+  if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)s;
+  // one prep launch: forward image (with the (silu, silu') table), transposed image, per-timestep tables; clears the ticket
+  int rc = launch_prep(st, params, PREC, VAR, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
+  if (rc) return rc;
+  int64_t* counter = (axes == nullptr || t == nullptr) ? rng_counter : nullptr;  // advanced only by a call that drew from it
+  LossArgs la;
+  la.target = nullptr; la.dout = nullptr; la.loss = loss;
+  la.partial = reinterpret_cast<double*>(ws + L.partial);
+  la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
+  la.rng_counter = counter;
+  la.dscale = (float)(2.0 / (3.0 * (double)n));
+  la.inv_count = 1.0 / (3.0 * (double)n);
+  NoiseArgs na{sched, trap_q, guide_q, x0, t, t_used, axes, unif, rng_counter, seed, rng_offset, index_base, T, quirk_col0};
+  const int64_t nt = (n + 31) / 32;
+  const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);  // = the slab count so3x_train_bwd_reduce sums
+  const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
+  const uint4* h0 = reinterpret_cast<const uint4*>(ws + h0_offset(PREC, GATHER, T));
+  float* slabs = reinterpret_cast<float*>(ws + L.slabs);
+  static PerDevice attr_e, attr_p;
+  if (axes) {
+    if ((rc = ensure_dyn_lds(attr_e, reinterpret_cast<const void*>(&k_train_fused<true>), LDS_TOTAL))) return rc;
+    hipLaunchKernelGGL((k_train_fused<true>), dim3(gf), dim3(512), LDS_TOTAL, st, (const void*)ws, (const void*)(ws + L.wt), beff, h0, na, x_t, out,
+                       slabs, n, la);
+  } else {
+    if ((rc = ensure_dyn_lds(attr_p, reinterpret_cast<const void*>(&k_train_fused<false>), LDS_TOTAL))) return rc;
+    hipLaunchKernelGGL((k_train_fused<false>), dim3(gf), dim3(512), LDS_TOTAL, st, (const void*)ws, (const void*)(ws + L.wt), beff, h0, na, x_t, out,
+                       slabs, n, la);
+  }
+  return check_launch();
+}
+
+}  // extern "C"

@@ -45,7 +45,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
-    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam",
+    "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam", "so3x_train_fused",
 )
 
 
@@ -83,7 +83,7 @@ def lib():
                 l.so3x_resnet_stash_bytes.restype = C.c_size_t
                 l.so3x_prevstep_workspace_bytes.restype = C.c_size_t
                 l.so3x_train_workspace_bytes.restype = C.c_size_t
-                if l.so3x_abi_version() != 5:
+                if l.so3x_abi_version() != 6:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -461,6 +461,24 @@ def train_net(buf, params, rng_counter=None):
     rng_counter (device int64 [1]) is advanced by one if given"""
     _call(ops().train_net, _dev(params, "params").reshape(-1), buf.T, buf.x_t, buf.t_used, buf.dout, buf.zstash, buf.loss, buf.out, rng_counter,
           buf.workspace)
+
+
+def train_fused(buf, params, sched, trap_q, x0, t=None, quirk_col0=True, axes=None, unif=None, seed=0, rng_offset=0, rng_counter=None,
+                index_base=0, guide_q=None, want_t=False, want_x_t=False, want_out=False):
+    """noising + network forward + MSE + backward down to the partial dW slabs as ONE kernel (so3x_train_fused) into buf.loss and
+    the slab region of buf.workspace; train_bwd_reduce / train_bwd_reduce_adam follows.  x_t, target, dout and the pre-activations
+    never leave the chip; want_t / want_x_t / want_out (tests) fill buf.t_used / buf.x_t / buf.out."""
+    x0 = _rot_in(x0, "x_start")
+    if x0.numel() // 9 != buf.n:
+        raise ValueError("so3x: batch size differs from the buffers'")
+    if t is not None:
+        t = _dev(t, "t", torch.int64).reshape(-1)
+    if want_out and buf.out is None:
+        buf.out = torch.empty((buf.n, 3), dtype=torch.float32, device=x0.device)
+    _call(ops().train_fused, _dev(params, "params").reshape(-1), _dev(sched, "sched"), _dev(trap_q, "trap_q"), _guide(guide_q, trap_q, "guide_q"),
+          x0, t, bool(quirk_col0), _dev(axes, "axes").reshape(-1, 3) if axes is not None else None,
+          _dev(unif, "unif").reshape(-1) if unif is not None else None, _s64(seed), _s64(rng_offset), rng_counter, int(index_base), buf.loss,
+          buf.t_used if want_t else None, buf.x_t if want_x_t else None, buf.out if want_out else None, buf.workspace)
 
 
 def train_bwd_partial(buf):

@@ -161,6 +161,11 @@ def _(x_t, t, dout, zstash, workspace, T, gscale, n_params):
     return _f32(x_t, (n_params,))
 
 
+@register_fake("so3x::train_fused")
+def _(params, sched, trap_q, guide_q, x0, t, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, loss, t_used, x_t, out, workspace):
+    return None
+
+
 @register_fake("so3x::train_noise")
 def _(sched, trap_q, guide_q, x0, t, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, x_t, t_used, workspace):
     return None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 5
+#define SO3X_ABI_VERSION 6
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -372,6 +372,19 @@ int so3x_train_bwd(so3x_stream_t s, const float* x_t, const int64_t* t, const fl
                    const float* gscale, float* grad, void* workspace, size_t workspace_bytes);
 int so3x_adam_step(so3x_stream_t s, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale);
+/* so3x_train_fused (version 6): so3x_train_fwd + so3x_train_bwd_partial as ONE kernel (after the prep launch) -- `loss =
+ * process(truepos); loss.backward()` of so3_train.py:73-75 up to the per-workgroup partial dW slabs.  Noise draw, q_sample and
+ * target (diffusion.py:339-355), network forward (so3_train.py:39-49), MSE and d loss / d out (diffusion.py:357), the dZ chain and
+ * the dW products run per 32-sample tile inside one workgroup; x_t, target, timesteps, dout and the pre-activations never go
+ * through HBM (a sample costs its 36 bytes of x0).  Same arguments and meaning as so3x_train_fwd, same draws bit for bit (Philox
+ * keyed by (seed, index_base + i, rng_offset + *rng_counter); t == NULL: drawn in the kernel; quirk_col0 as there); rng_counter
+ * is advanced by one when the call drew from it.  loss[0] = mean((out - target)^2).  The slabs land where
+ * so3x_train_bwd_reduce / so3x_train_bwd_reduce_adam (same n, T, workspace) expect them: call one of those next for grad[17358].
+ * Optional outputs (NULL = not written; parity tests and debugging): t_used int64 [n], x_t [n][3][3], out [n][3]. */
+int so3x_train_fused(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
+                     const float* x0, const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif,
+                     uint64_t seed, uint64_t rng_offset, int64_t* rng_counter, int64_t index_base, int64_t n, float* loss, float* x_t,
+                     float* out, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,144 @@
+"""GPU tests of the one-kernel training step (so3x_train_fused: noising + network forward + MSE + backward down to the dW
+slabs in ONE launch; reference so3_train.py:73-75, diffusion.py:339-357): against the reference's own recorded training
+steps (tests/golden/train_step.npz), against the staged step (so3x_train_fwd / so3x_train_bwd) on the same draws, on ragged
+batches, and at BASELINE config 4's shard size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from so3x import util, diffusion, so3_train, backend, optim, rng
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return dict(util=util, diff=diffusion, train=so3_train, B=backend, optim=optim, rng=rng)
+
+
+def _golden_net(mods, golden, precision="bf16"):
+    g = golden["score_mlp"]
+    n = mods["train"].RotPredict(out_type="skewvec", precision=precision)
+    n.load_state_dict({f"net.{l}.{k}": torch.from_numpy(g[f"net_{l}_{k}"]) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")})
+    return n.to(DEV)
+
+
+def _fused(B, proc, params, x0, t=None, axes=None, unif=None, seed=0, rng_offset=0, index_base=0, quirk=True, rng_counter=None):
+    """(loss, grad, t_used, x_t, out) of one so3x_train_fused + so3x_train_bwd_reduce"""
+    n = x0.shape[0]
+    buf = B.TrainBuffers(n, proc.num_timesteps, DEV, want_out=True)
+    trap_q, _ = proc._tables()
+    B.train_fused(buf, params, proc._sched, trap_q, x0, t, quirk_col0=quirk, axes=axes, unif=unif, seed=seed, rng_offset=rng_offset,
+                  rng_counter=rng_counter, index_base=index_base, guide_q=proc._guide_q, want_t=True, want_x_t=True, want_out=True)
+    grad = torch.empty(17358, device=DEV)
+    B.train_bwd_reduce(buf, grad=grad)
+    return buf.loss[0].clone(), grad, buf.t_used.clone(), buf.x_t.clone(), buf.out.clone()
+
+
+def _same_draws(ts, xs, os_, t_used, x_t, out):
+    """the two steps are separate translation units: the compiler contracts a*b+c into fused multiply-adds differently in each, so
+    the noised rotations agree to an ulp or two of fp32 (not bit for bit), and the network outputs wherever that ulp does not flip
+    the bf16 rounding of an input"""
+    return (torch.equal(ts, t_used) and float((xs - x_t).abs().max()) < 4e-7 and float((os_ - out).abs().max()) < 5e-3
+            and float((os_ != out).any(1).float().mean()) < 0.05)
+
+
+def _staged(B, proc, params, x0, t=None, axes=None, unif=None, seed=0, rng_offset=0, index_base=0, quirk=True):
+    trap_q, _ = proc._tables()
+    loss, carry, out = B.train_fwd(params, proc._sched, trap_q, x0, t, quirk_col0=quirk, axes=axes, unif=unif, seed=seed, rng_offset=rng_offset,
+                                   index_base=index_base, guide_q=proc._guide_q, want_out=True)
+    grad = B.train_bwd(carry, 17358, proc.num_timesteps)
+    return loss, grad, carry[1], carry[0], out
+
+
+def test_one_kernel_step_reproduces_the_reference_training_step(mods, golden):
+    """the reference's six recorded training steps (T in {100, 1000} x 3 seeds: t, sampler draws, x_t, loss, all 17,358
+    gradients of its own autograd) through so3x_train_fused on the recorded draws: x_t to G1, loss and gradients to the
+    bf16-operand accuracy the staged step is held to; and the staged step on the same draws: same timesteps, x_t to an ulp, the same network
+    output (same noising arithmetic, same forward), gradients to the accuracy of the parked silu'."""
+    B = mods["B"]
+    g = golden["train_step"]
+    net = _golden_net(mods, golden)
+    for T in (100, 1000):
+        for seed in (0, 1, 2):
+            pre = f"T{T}_s{seed}_"
+            proc = mods["diff"].SO3Diffusion(net, timesteps=T, betas=golden["schedule"][f"betas64_{T}"]).to(DEV)
+            x0, t = dev(g[pre + "x0"]), dev(g[pre + "t"], torch.int64)
+            ax, un = dev(g[pre + "axes"]), dev(g[pre + "unif"])
+            params = net.flat_data()
+            loss, grad, t_used, x_t, out = _fused(B, proc, params, x0, t, ax, un)
+            ref = g[pre + "grad_flat"]
+            assert torch.equal(t_used, t)
+            assert np.abs(host(x_t) - g[pre + "x_t"]).max() < 1e-5
+            assert abs(float(loss) - float(g[pre + "loss"])) < 1e-2 * float(g[pre + "loss"])
+            assert np.abs(host(grad) - ref).max() < 5e-2 * np.abs(ref).max()
+            assert np.linalg.norm(host(grad) - ref) < 4e-2 * np.linalg.norm(ref)
+            ls, gs, ts, xs, os_ = _staged(B, proc, params, x0, t, ax, un)
+            assert _same_draws(ts, xs, os_, t_used, x_t, out)
+            assert abs(float(loss) - float(ls)) < 2e-5 * float(ls)
+            assert float((grad - gs).abs().max()) < 1e-2 * float(gs.abs().max())
+            assert float((grad - gs).norm()) < 2e-2 * float(gs.norm())
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 127, 129, 1000, 4097, 70001])
+def test_one_kernel_step_on_ragged_batches(mods, n):
+    """drawn timesteps and Philox noise on batch sizes around the tile (32), round (128 per workgroup) and grid boundaries:
+    the one-kernel step draws what the staged step draws (t exactly, x_t to an ulp), its network output is the staged forward's,
+    loss and gradient agree"""
+    B = mods["B"]
+    torch.manual_seed(1)
+    net = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = mods["diff"].SO3Diffusion(net, timesteps=1000).to(DEV)
+    x0 = B.quat_to_rmat(torch.randn(n, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n)))
+    params = net.flat_data()
+    for quirk in (True, False):
+        loss, grad, t_used, x_t, out = _fused(B, proc, params, x0, seed=7, rng_offset=3, index_base=11, quirk=quirk)
+        ls, gs, ts, xs, os_ = _staged(B, proc, params, x0, seed=7, rng_offset=3, index_base=11, quirk=quirk)
+        assert torch.isfinite(loss) and torch.isfinite(grad).all()
+        assert _same_draws(ts, xs, os_, t_used, x_t, out)
+        assert abs(float(loss) - float(ls)) < 2e-5 * float(ls)
+        assert float((grad - gs).abs().max()) < 1e-2 * float(gs.abs().max())
+
+
+def test_one_kernel_step_at_the_shard_size_of_config_4(mods):
+    """2^19 samples (BASELINE config 4's per-GPU shard): finite, deterministic, additive over a split of the batch (the noise
+    and the in-kernel timesteps are keyed by the global sample index), equal to the staged step; the device-resident Philox
+    counter advances by one per call and changes the draw"""
+    B = mods["B"]
+    torch.manual_seed(0)
+    net = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = mods["diff"].SO3Diffusion(net, timesteps=1000).to(DEV)
+    n = 1 << 19
+    x0 = B.quat_to_rmat(torch.randn(n, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)))
+    params = net.flat_data()
+    loss, grad, t, x_t, out = _fused(B, proc, params, x0, seed=5, rng_offset=17)
+    assert torch.isfinite(loss) and torch.isfinite(grad).all() and torch.isfinite(x_t).all()
+    assert int(t.min()) == 0 and int(t.max()) == 999
+    l2, g2, t2, x2, o2 = _fused(B, proc, params, x0, seed=5, rng_offset=17)
+    assert torch.equal(loss, l2) and torch.equal(grad, g2) and torch.equal(x_t, x2)                     # deterministic
+    ls, gs, ts, xs, os_ = _staged(B, proc, params, x0, seed=5, rng_offset=17)
+    assert _same_draws(ts, xs, os_, t, x_t, out)
+    assert abs(float(loss) - float(ls)) < 2e-5 * float(ls)
+    assert float((grad - gs).abs().max()) < 1e-2 * float(gs.abs().max())
+    cut = 200_000
+    la, ga, ta, xa, _ = _fused(B, proc, params, x0[:cut], seed=5, rng_offset=17, index_base=0)
+    lb, gb, tb, xb, _ = _fused(B, proc, params, x0[cut:], seed=5, rng_offset=17, index_base=cut)
+    assert torch.equal(ta, t[:cut]) and torch.equal(tb, t[cut:]) and torch.equal(xa, x_t[:cut]) and torch.equal(xb, x_t[cut:])
+    wa, wb = cut / n, (n - cut) / n
+    assert abs(float(loss) - (wa * float(la) + wb * float(lb))) < 1e-5 * float(loss)
+    assert float((grad - (wa * ga + wb * gb)).abs().max()) < 2e-4 * float(grad.abs().max())
+    ctr = torch.tensor([17], dtype=torch.int64, device=DEV)
+    l3, g3, t3, _, _ = _fused(B, proc, params, x0, seed=5, rng_offset=0, rng_counter=ctr)
+    assert int(ctr) == 18 and torch.equal(l3, loss) and torch.equal(g3, grad)                            # offset + counter = 17
+    l4, _, t4, _, _ = _fused(B, proc, params, x0, seed=5, rng_offset=0, rng_counter=ctr)
+    assert int(ctr) == 19 and not torch.equal(t4, t3)

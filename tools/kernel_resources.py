@@ -5,7 +5,7 @@ tests/test_kernel_resources.py runs scan() over the sources and fails when a hot
 import os, re, subprocess, sys, tempfile
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diffusion-extensions_amd", "csrc")
-SOURCES = ("so3x_rotation.hip", "so3x_igso3.hip", "so3x_mlp.hip", "so3x_mlp_bwd.hip", "so3x_diffusion.hip", "so3x_resnet.hip",
+SOURCES = ("so3x_rotation.hip", "so3x_igso3.hip", "so3x_mlp.hip", "so3x_mlp_bwd.hip", "so3x_train_fused.hip", "so3x_diffusion.hip", "so3x_resnet.hip",
            "so3x_se3.hip", "so3x_stats.hip", "so3x_rotgrad.hip", "so3x_optim.hip")
 KEYS = {"VGPRs": r"VGPRs: (\d+)", "AGPRs": r"AGPRs: (\d+)", "scratch": r"ScratchSize \[bytes/lane\]: (\d+)",
         "occ": r"Occupancy \[waves/SIMD\]: (\d+)", "lds": r"LDS Size \[bytes/block\]: (\d+)"}
