@@ -40,7 +40,11 @@ constexpr int STASH_ROWS = 5 * HROWS + 4 * D + NOUT_MAX;  // 596 (the dZ_4 rows 
 constexpr int CHUNK = 1 << 19;  // samples per stash chunk: 596 rows x 2^19 x 4 B = 1.24 GB of workspace (288 GB HBM)
 constexpr int NPAIRS = 39;                      // 4 layers x 3x3 tiles + last layer 1x3
 
-struct Z33 { float v[33]; };  // [0..15] tile 0, [16..31] tile 1, [32] = tile 2 reg 0 (feature 64 in the lower half)
+struct Z33 { float v[33]; };
+
+// timesteps index per-timestep tables: clamped to [0, T-1] wherever a kernel gathers with them (the reference raises IndexError
+// outside that range; a kernel cannot, and must not read outside its tables -- a caller's uninitialised buffer included)
+__device__ __forceinline__ int64_t clamp_t(int64_t v, int T) { return T <= 0 ? v : (v < 0 ? 0 : (v >= T ? T - 1 : v)); }  // [0..15] tile 0, [16..31] tile 1, [32] = tile 2 reg 0 (feature 64 in the lower half)
 
 // silu and its derivative from the pre-activation
 template <int PREC> __device__ __forceinline__ void silu_grad(float z, float* hval, float* dval) {
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(256, 1)
 k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
             int64_t t_stride, const float* __restrict__ dout, Freqs fr, typename Stash<PREC>::T* __restrict__ stash,
-            int64_t nc /*samples in this chunk*/, int nout) {
+            int64_t nc /*samples in this chunk*/, int nout, int T /*rows of the per-timestep tables; 0 = none*/) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool SWAP = swap_images<PREC>();
   constexpr int FB = frag_bytes<PREC>();
@@ -166,7 +170,7 @@ k_bwd_stage(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       float x[9];
 #pragma unroll
       for (int j = 0; j < 9; j++) x[j] = R[sc * 9 + j];
-      const int64_t tt = t[sc * t_stride];
+      const int64_t tt = VAR == GATHER ? clamp_t(t[sc * t_stride], T) : t[sc * t_stride];
 #pragma unroll
       for (int k = 0; k < NOUT_MAX; k++) dd[k] = k < nout ? dout[sc * nout + k] : 0.0f;
       // ---- layer-0 input rows of the stash: [0..8] R, [9] one, [10..65] emb (canonical order);
@@ -572,9 +576,6 @@ constexpr size_t ZSTASH_TILE = 17 * 1024;
 constexpr size_t ZSTASH_LAYER = 17 * 256;  // one layer of a tile: 4 chunks of [lane][16 B], then [lane][4 B]
 // The stash is written once and read once, 285 MB per 2^19 samples -- more than the Infinity Cache: non-temporal stores took
 // the training forward from 87 to 70 us (default-policy lines were being written back behind the kernel's own compute).
-#ifndef SO3X_STASH_NT
-#define SO3X_STASH_NT 1
-#endif
 
 __device__ __forceinline__ void zstash_store_layer(char* tile_base, int lane, int l, const Z33h& z) {
   char* lb = tile_base + l * ZSTASH_LAYER;
@@ -584,17 +585,9 @@ __device__ __forceinline__ void zstash_store_layer(char* tile_base, int lane, in
   for (int c = 0; c < 4; c++) {
     const u32x4_t v = {__builtin_bit_cast(uint32_t, z.p[4 * c]), __builtin_bit_cast(uint32_t, z.p[4 * c + 1]),
                        __builtin_bit_cast(uint32_t, z.p[4 * c + 2]), __builtin_bit_cast(uint32_t, z.p[4 * c + 3])};
-#if SO3X_STASH_NT
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(o + c * 64));
-#else
-    *reinterpret_cast<u32x4_t*>(o + c * 64) = v;
-#endif
   }
-#if SO3X_STASH_NT
   __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, z.p[16]), reinterpret_cast<uint32_t*>(lb + 4096) + lane);
-#else
-  reinterpret_cast<uint32_t*>(lb + 4096)[lane] = __builtin_bit_cast(uint32_t, z.p[16]);
-#endif
 }
 // (uint4, a struct of four words, on purpose: with an ext-vector load and `__builtin_bit_cast(h2, v[i])` of its ELEMENTS this
 //  hipcc builds a backward whose gradients are 30 % off -- seen twice, tools/ab/cmp_train_grad.py is the check)
@@ -663,7 +656,7 @@ template <int PREC, bool LOSS>
 __global__ void __launch_bounds__(kFwdStashThreads, 2)
 k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
                 const int64_t* __restrict__ t, int64_t t_stride, float* __restrict__ out, char* __restrict__ zstash, int64_t n, int nout,
-                LossArgs la) {
+                LossArgs la, int T) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(PREC == SO3X_PREC_BF16, "the training forward is the bf16 path");
   constexpr int VAR = GATHER_T;
@@ -680,7 +673,7 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
     if (!live) idx = n - 1;
     float x[9];
     load_rot9(R, idx, x);
-    const int64_t tt = t[idx * t_stride];
+    const int64_t tt = clamp_t(t[idx * t_stride], T);
     f32x16 last[1];
     stash_forward_tile<0>(lds, beff_tab + (size_t)tt * 96, x, zstash + (size_t)tile * ZSTASH_TILE, last, lane);
     if (live && h == 0) {  // head outputs 0..5 = regs 0..5 of the lower half (head_of_row)
@@ -726,352 +719,6 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// k_mlp_fwd_stash with the lane-replicated 64 KB SiLU table (2-instruction lookup instead of 3): ONE 16-wave workgroup per CU
-// shares the table and the image (121 KB), still four waves per SIMD.  MEASURED AND NOT SHIPPED: bit-identical and the same
-// time (235.2-235.6 against 235.7-235.8 us per step, profiles/r03_ab_train_fwd_paired.json) -- 264 vector instructions fewer
-// per tile buy nothing in a kernel bound by its 285 MB of stash stores.  -DSO3X_TRAIN_FWD_WIDE=1 selects it (A/B only).
-// ---------------------------------------------------------------------------------------
-#ifndef SO3X_TRAIN_FWD_WIDE
-#define SO3X_TRAIN_FWD_WIDE 0
-#endif
-#if SO3X_TRAIN_FWD_WIDE
-constexpr int kFwdWideThreads = 1024;
-template <bool LOSS>
-__global__ void __launch_bounds__(kFwdWideThreads, 4)
-k_mlp_fwd_stash_wide(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
-                     const int64_t* __restrict__ t, float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
-  extern __shared__ __attribute__((aligned(16))) char lds_all[];
-  constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_T, FB = frag_bytes<PREC>();
-  char* lds = lds_all + kWideTabBytes;
-  load_image(gimg, lds, image_bytes<PREC, VAR>());
-  {
-    typedef __attribute__((address_space(3))) char* lds_cp;
-    if ((uint32_t)(uintptr_t)(lds_cp)lds_all != 0u) __builtin_trap();  // the byte-insert addressing needs the table at LDS address 0
-  }
-  fill_wide_tab(reinterpret_cast<const char*>(gimg) + (size_t)n_frags<PREC, VAR>() * FB);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-  const uint32_t lt = wide_tab_lane(lane);
-  const int64_t ntiles = (n + 31) / 32;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  float sq = 0.0f;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-    int64_t idx = tile * 32 + col;
-    const bool live = idx < n;
-    if (!live) idx = n - 1;
-    float x[9];
-    load_rot9(R, idx, x);
-    const int64_t tt = t[idx];
-    f32x16 last[1];
-    stash_forward_tile<0, true>(lds, beff_tab + (size_t)tt * 96, x, zstash + (size_t)tile * ZSTASH_TILE, last, lane, lt);
-    if (live && h == 0) {
-      if (out) { out[idx * 3] = last[0][0]; out[idx * 3 + 1] = last[0][1]; out[idx * 3 + 2] = last[0][2]; }
-      if constexpr (LOSS) {
-        const float d0 = last[0][0] - la.target[idx * 3], d1 = last[0][1] - la.target[idx * 3 + 1], d2 = last[0][2] - la.target[idx * 3 + 2];
-        la.dout[idx * 3] = d0 * la.dscale; la.dout[idx * 3 + 1] = d1 * la.dscale; la.dout[idx * 3 + 2] = d2 * la.dscale;
-        sq += d0 * d0 + d1 * d1 + d2 * d2;
-      }
-    }
-  }
-  if constexpr (LOSS) {
-    // (no static __shared__ here: the table must sit at LDS address 0, i.e. the dynamic block comes first)
-    constexpr int NW = kFwdWideThreads / 64;
-    double* wsum = reinterpret_cast<double*>(lds + ((image_bytes<PREC, VAR>() + 15) & ~15));
-    int& is_last = *reinterpret_cast<int*>(wsum + NW);
-    double v = (double)sq;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if (lane == 0) wsum[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double bs = 0.0;
-#pragma unroll
-      for (int w = 0; w < NW; w += 4) bs += (wsum[w] + wsum[w + 1]) + (wsum[w + 2] + wsum[w + 3]);
-      __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = last_block_arrives(la.ticket) ? 1 : 0;
-    }
-    __syncthreads();
-    if (is_last) {
-      double a = 0.0;
-      for (unsigned b = threadIdx.x; b < gridDim.x; b += kFwdWideThreads) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-      __syncthreads();
-      if (lane == 0) wsum[threadIdx.x >> 6] = a;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; w += 4) tot += (wsum[w] + wsum[w + 1]) + (wsum[w + 2] + wsum[w + 3]);
-        la.loss[0] = (float)(tot * la.inv_count);
-        if (la.rng_counter) la.rng_counter[0] += 1;
-      }
-    }
-  }
-}
-
-#endif  // SO3X_TRAIN_FWD_WIDE
-
-// ---------------------------------------------------------------------------------------
-// The training forward as the chain kernel's PAIRED stream (round 3).  k_mlp_fwd_stash above runs one 32-sample tile after the
-// other with the 3-instruction table lookup at four waves per SIMD; the reverse chain's network phase does the same arithmetic
-// in half the time (26 us against 49 us of compute per 2^19 samples) because a wave there owns TWO tiles and each stage lays
-// tile Y's activation -- the 2-instruction lookup in the lane-replicated 64 KB table -- into the gaps of tile X's 15 MFMAs
-// (stage_gaps, so3x_mlp.hpp).  Here: a wave owns 64 consecutive samples (lane = sample for x_t and t; tile A = samples 0..31,
-// tile B = 32..63), layer 0 keeps the per-sample effective-bias rows of the GATHER_T layout (every sample has its own
-// timestep), the six stages are the chain kernel's, and a tile's pre-activations leave for the stash right behind the stage
-// that produced them (the same 17 dwords per lane and layer, same tile order: the fused backward reads them unchanged).
-// Bit-identical outputs, stash and loss to k_mlp_fwd_stash (same MFMA order per tile, same table entries).
-// LDS: 64 KB table at address 0 + the 57 KB image: one 8-wave workgroup per CU.
-// ---------------------------------------------------------------------------------------
-// MEASURED AND NOT SHIPPED (profiles/r03_ab_train_fwd_paired.json): bit-identical, and 5 us SLOWER per 2^19-sample step (237.9 against
-// 232.6 us).  The chain kernel's network phase has no memory traffic inside a step; here every 64-sample chunk opens with an HBM
-// round trip for x_t and t and 18 dependent 16-byte gathers of per-sample bias rows per lane (201 MB of L2 traffic per launch),
-// and closes each stage with its stash stores -- at TWO waves per SIMD (230 registers) that latency is exposed, at the four
-// of the one-tile-at-a-time kernel it is covered.  Kept behind -DSO3X_TRAIN_FWD_PAIR=1 for the A/B only.
-#ifndef SO3X_TRAIN_FWD_PAIR
-#define SO3X_TRAIN_FWD_PAIR 0
-#endif
-#if SO3X_TRAIN_FWD_PAIR
-template <bool LOSS>
-__global__ void __launch_bounds__(kFwdStashThreads, 2)
-k_mlp_fwd_stash_pair(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const float* __restrict__ R,
-                     const int64_t* __restrict__ t, float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
-  extern __shared__ __attribute__((aligned(16))) char lds_all[];
-  constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_T, FB = frag_bytes<PREC>();
-  char* lds = lds_all + kWideTabBytes;
-  load_image(gimg, lds, image_bytes<PREC, VAR>());
-  {
-    typedef __attribute__((address_space(3))) char* lds_cp;
-    if ((uint32_t)(uintptr_t)(lds_cp)lds_all != 0u) __builtin_trap();  // the byte-insert addressing needs the table at LDS address 0
-  }
-  fill_wide_tab(reinterpret_cast<const char*>(gimg) + (size_t)n_frags<PREC, VAR>() * FB);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-  const uint32_t lt = wide_tab_lane(lane);
-  const char* tab = lds + (size_t)n_frags<PREC, VAR>() * FB;  // (the narrow table: unused by the WIDE lookups)
-  const int64_t nchunks = (n + 63) / 64, ntiles = (n + 31) / 32;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const char* wlast = lds + (size_t)frag_last<PREC, VAR>() * FB;
-  float sq = 0.0f;
-  for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const int64_t idx = chunk * 64 + lane;
-    const int64_t idc = idx < n ? idx : n - 1;
-    float x[9];
-    load_rot9(R, idc, x);
-    const int tt = (int)t[idc];
-    const int ttA = __shfl(tt, col), ttB = __shfl(tt, 32 + col);  // the timestep of this lane's COLUMN in either tile
-    char* ztA = zstash + (size_t)(2 * chunk) * ZSTASH_TILE;
-    char* ztB = ztA + ZSTASH_TILE;
-    const bool haveB = 2 * chunk + 1 < ntiles;
-    f32x16 accA[3], accB[3];
-    Tile<PREC> curA, curB;
-    Z33h z;
-    layer0_chain<PREC, 1>(lds, beff_tab + (size_t)ttA * 96, x, accA, lane);
-    layer0_chain<PREC, 2>(lds, beff_tab + (size_t)ttB * 96, x, accB, lane);
-    keep_h_folded(accA, z);
-    zstash_store_layer(ztA, lane, 0, z);
-    keep_h_folded(accB, z);
-    if (haveB) zstash_store_layer(ztB, lane, 0, z);
-    bf16x8 pre[5];
-    prefetch_tile0(lds + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
-    activate_bf16<true, true>(accA, curA, h, tab, lt);
-#pragma unroll
-    for (int l = 1; l < 4; l++) {
-      const char* wl = lds + (size_t)frag_hidden<PREC, VAR>(l) * FB;
-      const char* wnext = l < 3 ? lds + (size_t)frag_hidden<PREC, VAR>(l + 1) * FB : wlast;
-      SO3X_STAGE_FENCE;
-      stage_gaps<true>(wl, wl, curA, accA, accB, curB, pre, lane, h, tab, lt);     // MFMA A, layer l || activation B, layer l-1
-      keep_h_folded(accA, z);
-      zstash_store_layer(ztA, lane, l, z);
-      SO3X_STAGE_FENCE;
-      stage_gaps<true>(wl, wnext, curB, accB, accA, curA, pre, lane, h, tab, lt);  // MFMA B, layer l || activation A, layer l
-      keep_h_folded(accB, z);
-      if (haveB) zstash_store_layer(ztB, lane, l, z);
-    }
-    f32x16 lastA[1], lastB[1];
-    SO3X_STAGE_FENCE;
-    mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A || activation B, layer 3
-    prefetch_tile0(wlast, lane, pre);
-    activate_bf16<true, true>(accB, curB, h, tab, lt);
-    SO3X_STAGE_FENCE;
-    mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
-    if (h == 0) {  // head outputs = regs 0..2 of the lower half: column c of tile A is sample 64 chunk + c, of tile B 32 more
-#pragma unroll
-      for (int tile = 0; tile < 2; tile++) {
-        const int64_t s = chunk * 64 + 32 * tile + col;
-        if (s >= n) continue;
-        const float o0 = tile ? lastB[0][0] : lastA[0][0], o1 = tile ? lastB[0][1] : lastA[0][1], o2 = tile ? lastB[0][2] : lastA[0][2];
-        if (out) { out[s * 3] = o0; out[s * 3 + 1] = o1; out[s * 3 + 2] = o2; }
-        if constexpr (LOSS) {
-          const float d0 = o0 - la.target[s * 3], d1 = o1 - la.target[s * 3 + 1], d2 = o2 - la.target[s * 3 + 2];
-          la.dout[s * 3] = d0 * la.dscale; la.dout[s * 3 + 1] = d1 * la.dscale; la.dout[s * 3 + 2] = d2 * la.dscale;
-          sq += d0 * d0 + d1 * d1 + d2 * d2;
-        }
-      }
-    }
-  }
-  if constexpr (LOSS) {
-    // (no static __shared__ in this kernel: the table must sit at LDS address 0, i.e. the dynamic block must come first)
-    double* wsum = reinterpret_cast<double*>(lds + ((image_bytes<PREC, VAR>() + 15) & ~15));
-    int& is_last = *reinterpret_cast<int*>(wsum + kFwdStashThreads / 64);
-    double v = (double)sq;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if (lane == 0) wsum[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double bs = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
-      __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = last_block_arrives(la.ticket) ? 1 : 0;
-    }
-    __syncthreads();
-    if (is_last) {
-      double a = 0.0;
-      for (unsigned b = threadIdx.x; b < gridDim.x; b += kFwdStashThreads) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-      if (lane == 0) wsum[threadIdx.x >> 6] = a;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        la.loss[0] = (float)((((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * la.inv_count);
-        if (la.rng_counter) la.rng_counter[0] += 1;
-      }
-    }
-  }
-}
-
-#endif  // SO3X_TRAIN_FWD_PAIR
-
-// ---------------------------------------------------------------------------------------
-// The training forward with the forward noising fused in (diffusion.py:348-357 in ONE launch): a wave owns 64 samples.
-// Lane = sample for the noise draw (Philox, optional in-kernel timestep, inverse-CDF angle, Rodrigues), q_sample and the
-// regression target -- exactly k_q_sample_target's arithmetic -- then the wave's two 32-sample tiles go through the network
-// as in k_mlp_fwd_stash (the halves exchange what the other half feeds to layer 0), and the lane that owns a sample takes
-// its three outputs back for the MSE epilogue.  x_t still goes to HBM (the backward's layer-0 image needs it), the target and
-// the network output never do.  NOT the default: measured against the two-launch form it is no faster (see so3x_train_fwd).
-// ---------------------------------------------------------------------------------------
-
-template <int PREC>
-__global__ void __launch_bounds__(256, 2)
-k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, NoiseArgs na, float* __restrict__ x_t_out,
-            float* __restrict__ out, char* __restrict__ zstash, int64_t n, LossArgs la) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  __shared__ __attribute__((aligned(16))) float sm[4][kWave * 9];
-  constexpr int VAR = GATHER_T;
-  load_image(gimg, lds, image_bytes<PREC, VAR>());
-  __syncthreads();
-  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* wl = sm[wv];
-  const int T = na.T;
-  uint64_t rng_offset = na.rng_offset;
-  if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];
-  auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
-  auto clamp_t = [&](int64_t v) -> int64_t { return v < 0 ? 0 : (v >= T ? T - 1 : v); };
-  const int64_t wrow_t = !na.quirk_col0 ? -1 : (na.t ? clamp_t(na.t[0]) : drawn_t(philox4x32_10(na.seed, (uint64_t)0, rng_offset).w));
-  const int64_t nchunks = (n + 63) / 64, ntiles = (n + 31) / 32;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
-  float sq = 0.0f;
-  for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const int64_t base = chunk * 64;
-    const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-    const int64_t idx = base + lane;
-    const bool live = lane < cnt;
-    // ---- noise draw, q_sample, target: one lane = one sample (k_q_sample_target's arithmetic)
-    Philox4 r;
-    if (!na.t || !na.axes) r = philox4x32_10(na.seed, (uint64_t)(na.index_base + idx), rng_offset);
-    int64_t tt;
-    tt = na.t ? clamp_t(na.t[live ? idx : base]) : drawn_t(r.w);
-    if (live) na.t_draw[idx] = tt;
-    float ax[3], u;
-    if (na.axes) {
-      float a[3];
-      wave_load_rows<3>(na.axes, base, cnt, wl, a);
-      float nrm = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);       // distributions.py:36
-      ax[0] = a[0] / nrm; ax[1] = a[1] / nrm; ax[2] = a[2] / nrm;
-      float n2 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // util.py:201
-      ax[0] /= n2; ax[1] /= n2; ax[2] /= n2;
-      u = live ? na.unif[idx] : 0.5f;
-    } else {
-      unit_axis(r.x, r.y, ax);
-      u = u01(r.z);
-    }
-    if (!live) { ax[0] = 1.0f; ax[1] = 0.0f; ax[2] = 0.0f; u = 0.5f; }     // dead lanes carry well-defined values: their stash columns are read
-    const float* row = na.trap_q + tt * 999;
-    const float* wrow = wrow_t >= 0 ? na.trap_q + wrow_t * 999 : row;
-    const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, na.guide_q ? na.guide_q + tt * kGuidePitch : nullptr);
-    float nz[9], x[9], w[3], xs[9], xt[9], tg[3];
-    exp_axis_angle(ax, ang, nz);
-    wave_load_rows<9>(na.x0, base, cnt, wl, x);
-    if (!live) { x[0] = 1.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f; x[4] = 1.f; x[5] = 0.f; x[6] = 0.f; x[7] = 0.f; x[8] = 1.f; }
-    const float k = na.sched[S_SQRT_AC * T + tt];
-    log3(x, w);
-    w[0] *= k; w[1] *= k; w[2] *= k;
-    exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
-    mul33(xs, nz, xt);                // x_blend @ noise, :346
-    wave_store_rows<9>(x_t_out, base, cnt, wl, xt);
-    {
-      float lw[3];
-      log3(nz, lw);                   // skew2vec(log_rmat(noise)) * (1/eps), :355
-      const float ie = 1.0f / na.sched[S_SQRT_1MAC * T + tt];
-      tg[0] = lw[0] * ie; tg[1] = lw[1] * ie; tg[2] = lw[2] * ie;
-    }
-    // ---- the network on the wave's two 32-sample tiles (k_mlp_fwd_stash's arithmetic), pre-activations parked per tile
-    const int tlo = (int)tt;
-    const int tA = __shfl(tlo, col), tB = __shfl(tlo, 32 + col);
-    float va[3], vb[3];
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int64_t tile = 2 * chunk + half;
-      f32x16 last[1];
-      char* ztile = tile < ntiles ? zstash + (size_t)tile * ZSTASH_TILE : nullptr;
-      if (half == 0) stash_forward_tile<1>(lds, beff_tab + (size_t)tA * 96, xt, ztile, last, lane);
-      else stash_forward_tile<2>(lds, beff_tab + (size_t)tB * 96, xt, ztile, last, lane);
-#pragma unroll
-      for (int q = 0; q < 3; q++) (half == 0 ? va : vb)[q] = last[0][q];
-    }
-    float v[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const float o = __shfl_xor(vb[q], 32);  // tile B's outputs sit in lanes 0..31; their owners are lanes 32..63
-      v[q] = h ? o : va[q];
-    }
-    if (out) wave_store_rows<3>(out, base, cnt, wl, v);
-    float d[3] = {v[0] - tg[0], v[1] - tg[1], v[2] - tg[2]};
-    if (live) sq += d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    d[0] *= la.dscale; d[1] *= la.dscale; d[2] *= la.dscale;
-    wave_store_rows<3>(la.dout, base, cnt, wl, d);
-  }
-  __shared__ double wsum[4];
-  __shared__ int is_last;
-  double vsum = (double)sq;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) vsum += __shfl_xor(vsum, m);
-  if (lane == 0) wsum[wv] = vsum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double bs = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = last_block_arrives(la.ticket) ? 1 : 0;
-  }
-  __syncthreads();
-  if (is_last) {
-    double a = 0.0;
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) a += __hip_atomic_load(la.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-    if (lane == 0) wsum[wv] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      la.loss[0] = (float)(((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * la.inv_count);
-      if (la.rng_counter) la.rng_counter[0] += 1;
-    }
-  }
-}
 
 // one pass over a layer's pre-activations: packed H = silu(Z) (with the constant-one row in the upper half of tile 2) and
 // the derivative silu'(Z) in fp32.  H of a dead column (a sample index past n) is NOT zeroed: its dZ is an exact zero in
@@ -1080,21 +727,11 @@ k_train_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, N
 // 33 multiplies per pass off the chain wave (9 % of its vector instructions).
 // (MASK: the recomputing variant keeps the multiply by the live flag -- without it the register allocator of THAT kernel,
 //  which spills already, does worse.)
-// -DSO3X_BWD_ABL_SILU=<k> (timing experiments only, tools/ab): the first k register pairs of a pass keep the real arithmetic, the
-// rest copy z through (results meaningless) -- how much of the backward is the chain wave's transcendental stream?
-#ifndef SO3X_BWD_ABL_SILU
-#define SO3X_BWD_ABL_SILU 16
-#endif
 template <int PREC, bool MASK = false>
 __device__ __forceinline__ void silu_pass(const Z33h& z, int h, uint32_t (&ph)[17], float (&dv)[33], float lv = 1.0f) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     float a0, a1;
-    if (r >= SO3X_BWD_ABL_SILU) {
-      a0 = z.get(2 * r); a1 = z.get(2 * r + 1); dv[2 * r] = 1.0f; dv[2 * r + 1] = 0.5f;
-      ph[r] = pack_bf16x2(a0, a1);
-      continue;
-    }
     silu_grad<PREC>(z.get(2 * r), &a0, &dv[2 * r]);
     silu_grad<PREC>(z.get(2 * r + 1), &a1, &dv[2 * r + 1]);
     ph[r] = MASK ? pack_bf16x2(a0 * lv, a1 * lv) : pack_bf16x2(a0, a1);
@@ -1128,7 +765,7 @@ __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, fl
           for (int w = 0; w < 4; w++) {
             const char* im = fimg_all + w * FIMG_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) acc[9] = SO3X_DW_MFMA(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
+            for (int ks = 0; ks < 2; ks++) acc[9] = mfma_bf16(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
           }
         }
       } else if (dw_row(DWI, l) != 3) {
@@ -1142,7 +779,7 @@ __device__ __forceinline__ void dw_role(const char* fimg_all, int64_t rounds, fl
           for (int ks = 0; ks < 2; ks++) {
             const bf16x8 a = fimg_frag(im, RL, 32 * to, ks);
 #pragma unroll
-            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = SO3X_DW_MFMA(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
+            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
           }
         }
       }
@@ -1179,7 +816,7 @@ __global__ void __launch_bounds__(512, 2)
 k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const float* __restrict__ beff_tab,
             const float* __restrict__ emb_tab, const float* __restrict__ R, const int64_t* __restrict__ t,
             int64_t t_stride, const float* __restrict__ dout, float* __restrict__ slabs, int64_t n,
-            const char* __restrict__ zstash, const uint4* __restrict__ h0_tab, int nout) {
+            const char* __restrict__ zstash, const uint4* __restrict__ h0_tab, int nout, int T) {
   // Wave specialisation: waves 0-3 ("chain" waves) load (STASHED) or recompute the forward's pre-activations and run the dZ chain for one 32-sample
   // tile each; waves 4-7 ("dW" waves) own the 39 dW tiles (10/10/10/9, persistent accumulators; dw_row) and only consume
   // the LDS images.  One chain wave and one dW wave share a SIMD, so the dW MFMAs run under the chain waves'
@@ -1200,10 +837,6 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
   const int64_t ntiles = (n + 31) / 32;
   const int64_t nchain = (int64_t)gridDim.x * 4;
   const int64_t rounds = (ntiles + nchain - 1) / nchain;  // uniform trip count: the barriers are block-wide
-#if defined(SO3X_BWD_PRIO)   /* A/B: wave priority by role (1: the chain waves above the dW waves, 2: the other way round) */
-  if ((wid < 4) == (SO3X_BWD_PRIO == 1)) __builtin_amdgcn_s_setprio(3);
-  else __builtin_amdgcn_s_setprio(0);
-#endif
   if (wid < 4) {
     // =============================== chain waves ===============================
     char* my_img = fimg_all + wid * FIMG_BYTES;
@@ -1222,7 +855,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
     if constexpr (STASHED) {
       bool lv0;
       const int64_t s0 = sample_of(0, &lv0);
-      tt_pf = t[s0 * t_stride];
+      tt_pf = clamp_t(t[s0 * t_stride], T);
       if (h == 0) { dp_pf[0] = dout[s0 * nout]; dp_pf[1] = dout[s0 * nout + 1]; dp_pf[2] = dout[s0 * nout + 2]; }
     }
     // Everything that goes into an image is kept as packed bf16 pairs (the exact MFMA operand bits).
@@ -1268,7 +901,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
       f32x16 dh[3];
       float x[9];
       if constexpr (!STASHED) load_rot9(R, sc, x);  // STASHED: fetched behind layer 1, stored with the layer-0 image
-      const int64_t tt = STASHED ? tt_pf : t[sc * t_stride];
+      const int64_t tt = STASHED ? tt_pf : clamp_t(t[sc * t_stride], T);
       const float lv = live ? 1.0f : 0.0f;  // dead columns: dZ_4 = 0, hence every dZ_l = 0 and no contribution to any dW sum
       const char* ztile = STASHED ? zstash + (size_t)(active ? tile : ntiles - 1) * ZSTASH_TILE : nullptr;
       // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them), fetched now, stored five layers
@@ -1354,7 +987,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
             if (l == 2) {  // next round's timestep and dout
               bool nl;
               const int64_t sn = sample_of(rd + 1 < rounds ? rd + 1 : rd, &nl);
-              tt_pf = t[sn * t_stride];
+              tt_pf = clamp_t(t[sn * t_stride], T);
               if (h == 0) { dp_pf[0] = dout[sn * nout]; dp_pf[1] = dout[sn * nout + 1]; dp_pf[2] = dout[sn * nout + 2]; }
             }
             if (l == 1) load_rot9(R, sc, x);
@@ -1383,7 +1016,7 @@ k_bwd_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const f
 // k_bwd_fused + the slab reduction for the whole batch; the images and tables are where launch_prep left them.
 inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, const float* beff, const float* emb, const uint4* h0,
                             const float* R, const int64_t* t, int64_t t_stride, const float* dout, float* slabs, int64_t n,
-                            const char* zstash, int nout, float* dparams, const float* gscale) {
+                            const char* zstash, int nout, float* dparams, const float* gscale, int T) {
   constexpr int PREC = SO3X_PREC_BF16;
   constexpr int FUSED_LDS = image_bytes<PREC, GATHER>() + wt_bytes<PREC>() + 4 * FIMG_BYTES;
   static PerDevice attr_f0, attr_f1;
@@ -1393,10 +1026,10 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
   const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
   if (zstash)
     hipLaunchKernelGGL((k_bwd_fused<PREC, true>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
-                       emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
+                       emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout, T);
   else
     hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
-                       emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout);
+                       emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout, T);
   if (!dparams) return check_launch();  // partial slabs only: launch_slab_reduce follows (so3x_train_bwd_reduce)
   hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
                      gscale);
@@ -1445,14 +1078,14 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
   float* slabs = reinterpret_cast<float*>(ws + L.slabs);
   ST* stash = reinterpret_cast<ST*>(ws + L.stash);
   if constexpr (PREC == SO3X_PREC_BF16 && VAR == GATHER)  // fused path: no dZ/H stash, one launch for the whole batch
-    return launch_fused_bwd(s, ws, ws + L.wt, beff, emb, h0, R, t, t_stride, dout, slabs, n, zstash, nout, dparams, nullptr);
+    return launch_fused_bwd(s, ws, ws + L.wt, beff, emb, h0, R, t, t_stride, dout, slabs, n, zstash, nout, dparams, nullptr, t_table);
   for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
     const int64_t nc = (n - c0) < CHUNK ? (n - c0) : CHUNK;
     const int64_t ntiles = (nc + 31) / 32;
     const int g1 = (int)((ntiles + 3) / 4 < 256 ? (ntiles + 3) / 4 : 256);
     hipLaunchKernelGGL((k_bwd_stage<PREC, VAR>), dim3(g1), dim3(256), STAGE_LDS, s, (const void*)ws,
                        (const void*)(ws + L.wt), beff, emb, R + c0 * 9, t + (t_stride ? c0 : 0), t_stride, dout + c0 * nout,
-                       host_freqs(), stash, nc, nout);
+                       host_freqs(), stash, nc, nout, t_table);
     const int g2 = (int)(ntiles < DW_BLOCKS ? ntiles : DW_BLOCKS);
     if constexpr (PREC == SO3X_PREC_F32)
       hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs, nout);
@@ -1491,7 +1124,7 @@ int so3x_mlp_fwd_stash(so3x_stream_t s, const float* params, const float* R, con
   if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, false>), IMG))) return rc;
   const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
   hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, false>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, (hipStream_t)s, (const void*)ws,
-                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out, LossArgs{});
+                     reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)), R, t, t_stride, out, (char*)zstash, n, n_out, LossArgs{}, t_table);
   return check_launch();
 }
 
@@ -1553,36 +1186,12 @@ int so3x_train_net(so3x_stream_t s, const float* params, int T, const float* x_t
   la.inv_count = 1.0 / (3.0 * (double)n);
   la.target = reinterpret_cast<float*>(ws + L.target);
   const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
-#if SO3X_TRAIN_FWD_WIDE
-  {  // one 16-wave workgroup per CU around the 64 KB table + the image
-    constexpr int LDSW = kWideTabBytes + ((IMG + 15) & ~15) + 256;
-    static PerDevice resident_w;
-    int max_blocks = 0;
-    if ((rc = resident_blocks(resident_w, reinterpret_cast<const void*>(&k_mlp_fwd_stash_wide<true>), kFwdWideThreads, LDSW, &max_blocks))) return rc;
-    const int64_t ntiles = (n + 31) / 32, want = (ntiles + 15) / 16;
-    hipLaunchKernelGGL((k_mlp_fwd_stash_wide<true>), dim3((int)(want < max_blocks ? want : max_blocks)), dim3(kFwdWideThreads), LDSW, st,
-                       (const void*)ws, beff, x_t, t_used, out, (char*)zstash, n, la);
-    return check_launch();
-  }
-#elif SO3X_TRAIN_FWD_PAIR
-  {  // the paired stream: one 8-wave workgroup per CU (64 KB table + image), 64 samples per wave
-    constexpr int LDSB = kWideTabBytes + ((IMG + 15) & ~15) + 128;  // table + image + the loss epilogue's eight partials and flag
-    static PerDevice resident;
-    int max_blocks = 0;
-    if ((rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_mlp_fwd_stash_pair<true>), kFwdStashThreads, LDSB, &max_blocks))) return rc;
-    const int64_t nchunks = (n + 63) / 64, want = (nchunks + 7) / 8;
-    hipLaunchKernelGGL((k_mlp_fwd_stash_pair<true>), dim3((int)(want < max_blocks ? want : max_blocks)), dim3(kFwdStashThreads), LDSB, st,
-                       (const void*)ws, beff, x_t, t_used, out, (char*)zstash, n, la);
-    return check_launch();
-  }
-#else
   static PerDevice attr;
   if ((rc = ensure_dyn_lds(attr, reinterpret_cast<const void*>(&k_mlp_fwd_stash<PREC, true>), IMG))) return rc;
   const int64_t ntiles = (n + 31) / 32, want = (ntiles + 7) / 8;
   hipLaunchKernelGGL((k_mlp_fwd_stash<PREC, true>), dim3((int)(want < 512 ? want : 512)), dim3(kFwdStashThreads), IMG, st, (const void*)ws,
-                     beff, x_t, t_used, (int64_t)1, out, (char*)zstash, n, 3, la);
+                     beff, x_t, t_used, (int64_t)1, out, (char*)zstash, n, 3, la, T);
   return check_launch();
-#endif
 }
 
 int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
@@ -1593,38 +1202,6 @@ int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int
       ((axes == nullptr) != (unif == nullptr)))
     return SO3X_ERR_INVALID_ARG;
   int64_t* counter = (axes == nullptr || t == nullptr) ? rng_counter : nullptr;  // advanced only by a call that drew from it
-#ifdef SO3X_AB_BUILD  /* libso3x_ab.so only (tools/ab/ab_trainfwd.py); the product launcher reads no environment */
-  const char* ab = getenv("SO3X_AB_TRAINFWD");
-  if (ab && !strcmp(ab, "fused")) {
-    // A/B (SO3X_AB_TRAINFWD=fused): noise draw + q_sample + target + network forward + stash + MSE and its gradient as ONE
-    // launch.  Measured no faster than the two launches below (277.3 vs 275.9 us per 2^19-sample step,
-    // profiles/r02_ab_train_fwd_fused_noising.json): at the two waves per SIMD the stash-carrying forward allows, the noising's
-    // dependent L2 gathers are no longer hidden the way the six-waves-per-SIMD noising kernel hides them.
-    const TrainLayout L = train_layout(n, T);
-    if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
-    constexpr int PREC = SO3X_PREC_BF16, IMG = image_bytes<PREC, GATHER_T>();
-    char* ws = (char*)workspace;
-    hipStream_t st = (hipStream_t)s;
-    int rc = launch_prep(st, params, PREC, GATHER_T, T, ws, 3, (void*)(ws + L.wt), true, reinterpret_cast<unsigned*>(ws + L.ticket));
-    if (rc) return rc;
-    LossArgs la;
-    la.dout = dout; la.loss = loss;
-    la.partial = reinterpret_cast<double*>(ws + L.partial);
-    la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
-    la.rng_counter = counter;
-    la.dscale = (float)(2.0 / (3.0 * (double)n));
-    la.inv_count = 1.0 / (3.0 * (double)n);
-    la.target = nullptr;
-    const float* beff = reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER));
-    static PerDevice attr_f;
-    if ((rc = ensure_dyn_lds(attr_f, reinterpret_cast<const void*>(&k_train_fwd<PREC>), IMG))) return rc;
-    NoiseArgs na{sched, trap_q, guide_q, x0, t, t_used, axes, unif, rng_counter, seed, rng_offset, index_base, T, quirk_col0};
-    const int64_t nchunks = (n + 63) / 64, want = (nchunks + 3) / 4;
-    hipLaunchKernelGGL((k_train_fwd<PREC>), dim3((int)(want < 512 ? want : 512)), dim3(256), IMG, st, (const void*)ws, beff, na, x_t, out,
-                       (char*)zstash, n, la);
-    return check_launch();
-  }
-#endif
   if (int rc = so3x_train_noise(s, sched, T, trap_q, guide_q, x0, t, t_used, quirk_col0, axes, unif, seed, rng_offset, rng_counter, index_base, n,
                                 x_t, workspace, workspace_bytes))
     return rc;
@@ -1641,7 +1218,7 @@ int so3x_train_bwd_partial(so3x_stream_t s, const float* x_t, const int64_t* t, 
   return launch_fused_bwd((hipStream_t)s, ws, ws + L.wt, reinterpret_cast<const float*>(ws + beff_offset(PREC, GATHER)),
                           reinterpret_cast<const float*>(ws + emb_offset(PREC, GATHER, T)),
                           reinterpret_cast<const uint4*>(ws + h0_offset(PREC, GATHER, T)), x_t, t, 1, dout,
-                          reinterpret_cast<float*>(const_cast<char*>(ws) + L.slabs), n, (const char*)zstash, 3, nullptr, nullptr);
+                          reinterpret_cast<float*>(const_cast<char*>(ws) + L.slabs), n, (const char*)zstash, 3, nullptr, nullptr, T);
 }
 
 int so3x_train_bwd_reduce(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace, size_t workspace_bytes) {

@@ -14,16 +14,6 @@ using namespace so3x::mlp;
 constexpr int DW_BLOCKS = 256;                  // workgroups (= partial dW slabs) of a backward launch: one per CU
 template <int PREC> __host__ __device__ constexpr int wt_bytes() { return wt_nfrags<PREC>() * frag_bytes<PREC>(); }
 
-// -DSO3X_BWD_ABL=<bits> (timing experiments only, tools/ab; results meaningless): 1 = the dW waves skip their MFMAs and operand
-// reads (they still meet every barrier), 2 = the chain waves skip the dH MFMAs, 4 = the chain waves skip their image stores
-#ifndef SO3X_BWD_ABL
-#define SO3X_BWD_ABL 0
-#endif
-#if SO3X_BWD_ABL & 1
-#define SO3X_DW_MFMA(a, b, c) (c)
-#else
-#define SO3X_DW_MFMA(a, b, c) mfma_bf16(a, b, c)
-#endif
 
 constexpr int FIMG_COLS = 192;                 // dZ block [0, 96), H block [96, 192)
 constexpr int FIMG_PITCH = FIMG_COLS * 2;      // bytes per sample row
@@ -82,9 +72,6 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ void fimg_store_pk(char* img, const FimgStoreLane& L, int ch, uint32_t lo, uint32_t hi) {
-#if SO3X_BWD_ABL & 4
-  if (ch != 0) return;
-#endif
   *reinterpret_cast<uint2*>(img + L.rowbase + ((ch * 8) ^ L.swz8)) = uint2{lo, hi};
 }
 
@@ -106,11 +93,7 @@ __device__ __forceinline__ void dh_layer_pk(const void* __restrict__ wt, const u
     f32x16 a = zero16<PREC>();
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-#if SO3X_BWD_ABL & 2
-      a[ks] += __builtin_bit_cast(float, pdz[ks]);
-#else
       a = mfma_bf16(w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane], b[ks], a);
-#endif
     }
     dh[to] = a;
   }

@@ -161,6 +161,11 @@ __device__ __forceinline__ void operand_of(const uint32_t (&hp)[17], Tile<PREC>&
   t.b[4] = __builtin_bit_cast(bf16x8, u32x4_t{hp[16], 0u, 0u, 0u});
 }
 
+#ifdef EXP_NODW
+#define TF_DW_MFMA(a, b, c) (c)
+#else
+#define TF_DW_MFMA(a, b, c) mfma_bf16(a, b, c)
+#endif
 // ---- the dW waves: k_bwd_fused's dW role (so3x_mlp_bwd.hip) + the noising of the tiles ahead -----------------------------------
 struct Geo { int64_t n, ntiles, nchain, rounds; };
 
@@ -205,7 +210,7 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
           for (int w = 0; w < 4; w++) {
             const char* im = fimg_all + w * FIMG_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) acc[9] = mfma_bf16(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
+            for (int ks = 0; ks < 2; ks++) acc[9] = TF_DW_MFMA(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
           }
         }
       } else if (dw_row(DWI, l) != 3) {
@@ -217,7 +222,7 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
           for (int ks = 0; ks < 2; ks++) {
             const bf16x8 a = fimg_frag(im, RL, 32 * to, ks);
 #pragma unroll
-            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
+            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = TF_DW_MFMA(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
           }
         }
       }
@@ -391,10 +396,17 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
         }
         __syncthreads();  // B1: images of layer l complete -- the dW waves consume them while this wave goes on
         if (l > 0) {
+#ifdef EXP_NODH
+#pragma unroll
+          for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dh[q][r] = __uint_as_float(pdz[r]);
+#else
           if (l == 4) dh_layer_pk<PREC, 4>(wt_lds, pdz, dh, lane_r);
           if (l == 3) dh_layer_pk<PREC, 3>(wt_lds, pdz, dh, lane_r);
           if (l == 2) dh_layer_pk<PREC, 2>(wt_lds, pdz, dh, lane_r);
           if (l == 1) dh_layer_pk<PREC, 1>(wt_lds, pdz, dh, lane_r);
+#endif
           const uint32_t (&dp)[17] = dpk[l - 1];  // silu'(Z_{l-1}), parked by the forward
 #pragma unroll
           for (int r = 0; r < 16; r++) {

@@ -425,21 +425,26 @@ def train_bwd(carry, n_params=N_PARAMS, T=None, gscale=None):
 
 
 class TrainBuffers:
-    """Caller-owned buffers of one training step in stages (so3x_train_noise / _net / _bwd_partial / _bwd_reduce): allocated once,
-    reused by every step -- what a captured, software-pipelined step (so3x.graphs.TrainStepGraph) runs on."""
+    """Caller-owned buffers of one training step (so3x_train_fused, or the stages so3x_train_noise / _net / _bwd_partial, and the
+    reductions behind either): allocated once, reused by every step -- what a captured step (so3x.graphs.TrainStepGraph) runs on.
+    staged=False: only what the one-kernel step needs (loss, workspace, flat gradient); x_t / t_used / out appear on demand."""
 
-    def __init__(self, n, T, device, want_out=False):
+    def __init__(self, n, T, device, want_out=False, staged=True):
         l = lib()
         self.n, self.T = int(n), int(T)
+        self.device = device
         f32 = dict(dtype=torch.float32, device=device)
-        self.x_t = torch.empty((self.n, 3, 3), **f32)
-        self.t_used = torch.empty((self.n,), dtype=torch.int64, device=device)
-        self.dout = torch.empty((self.n, 3), **f32)
         self.loss = torch.zeros((1,), **f32)
-        self.out = torch.empty((self.n, 3), **f32) if want_out else None
-        self.zstash = torch.empty((int(l.so3x_mlp_stash_bytes(C.c_int64(self.n))),), dtype=torch.uint8, device=device)
         self.workspace = torch.empty((int(l.so3x_train_workspace_bytes(C.c_int64(self.n), C.c_int(self.T))),), dtype=torch.uint8, device=device)
         self.grad = torch.zeros((N_PARAMS,), **f32)
+        self.x_t = self.t_used = self.dout = self.zstash = self.out = None
+        if staged:
+            self.x_t = torch.empty((self.n, 3, 3), **f32)
+            self.t_used = torch.empty((self.n,), dtype=torch.int64, device=device)
+            self.dout = torch.empty((self.n, 3), **f32)
+            self.zstash = torch.empty((int(l.so3x_mlp_stash_bytes(C.c_int64(self.n))),), dtype=torch.uint8, device=device)
+        if want_out:
+            self.out = torch.empty((self.n, 3), **f32)
 
 
 def train_noise(buf, sched, trap_q, x0, t=None, quirk_col0=True, axes=None, unif=None, seed=0, rng_offset=0, rng_counter=None,
@@ -475,6 +480,10 @@ def train_fused(buf, params, sched, trap_q, x0, t=None, quirk_col0=True, axes=No
         t = _dev(t, "t", torch.int64).reshape(-1)
     if want_out and buf.out is None:
         buf.out = torch.empty((buf.n, 3), dtype=torch.float32, device=x0.device)
+    if want_x_t and buf.x_t is None:
+        buf.x_t = torch.empty((buf.n, 3, 3), dtype=torch.float32, device=x0.device)
+    if want_t and buf.t_used is None:
+        buf.t_used = torch.empty((buf.n,), dtype=torch.int64, device=x0.device)
     _call(ops().train_fused, _dev(params, "params").reshape(-1), _dev(sched, "sched"), _dev(trap_q, "trap_q"), _guide(guide_q, trap_q, "guide_q"),
           x0, t, bool(quirk_col0), _dev(axes, "axes").reshape(-1, 3) if axes is not None else None,
           _dev(unif, "unif").reshape(-1) if unif is not None else None, _s64(seed), _s64(rng_offset), rng_counter, int(index_base), buf.loss,

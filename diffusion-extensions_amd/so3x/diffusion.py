@@ -56,27 +56,38 @@ def noise_like(shape, device, repeat=False):
 
 
 class _FusedSkewvecLoss(torch.autograd.Function):
-    """p_losses of loss_type="skewvec" for the 65-wide RotPredict with bf16 operands (reference diffusion.py:348-357) as
-    the two C-ABI calls of a training step: forward = so3x_train_fwd (noise draw, q_sample, target, network with its
-    pre-activations parked, MSE and its gradient: three launches), backward = so3x_train_bwd (fused backward + reduction:
-    two launches) returning the FLAT parameter gradient.  Only the parameters carry gradients."""
+    """p_losses of loss_type="skewvec" for the 65-wide RotPredict with bf16 operands (reference diffusion.py:348-357).
+    forward = so3x_train_fused: noise draw, q_sample, target, network forward, MSE AND the whole backward down to per-workgroup
+    dW partial slabs in ONE kernel (nothing in the math needs the loss before the backward: d loss / d out is per sample);
+    backward = so3x_train_bwd_reduce: the fixed-order sum of the slabs times the upstream gradient -> the FLAT parameter
+    gradient.  Only the parameters carry gradients.  `proc.train_step_kernel = "staged"` selects round 3's
+    form instead (so3x_train_fwd / so3x_train_bwd: three kernels with the pre-activations parked in HBM)."""
 
     @staticmethod
     def forward(ctx, flat, proc, x_start, t, axes, unif):
         trap_q, _ = proc._tables()
         dev_rng = proc.rng_counter is not None and (axes is None or t is None)
-        loss, carry, _ = _b.train_fwd(flat, proc._sched, trap_q, x_start, t, quirk_col0=proc.quirk_col0, axes=axes, unif=unif,
-                                      seed=_rng.seed(),
-                                      rng_offset=0 if (dev_rng or (axes is not None and t is not None)) else _rng.next_offset(),
-                                      rng_counter=proc.rng_counter if dev_rng else None, index_base=proc.index_base,
-                                      guide_q=proc._guide_q)
-        ctx.carry, ctx.T, ctx.n_params = carry, proc.num_timesteps, flat.numel()
-        return loss
+        kw = dict(quirk_col0=proc.quirk_col0, axes=axes, unif=unif, seed=_rng.seed(),
+                  rng_offset=0 if (dev_rng or (axes is not None and t is not None)) else _rng.next_offset(),
+                  rng_counter=proc.rng_counter if dev_rng else None, index_base=proc.index_base, guide_q=proc._guide_q)
+        ctx.T, ctx.n_params = proc.num_timesteps, flat.numel()
+        if proc.train_step_kernel == "staged":
+            loss, ctx.carry, _ = _b.train_fwd(flat, proc._sched, trap_q, x_start, t, **kw)
+            ctx.buf = None
+            return loss
+        buf = _b.TrainBuffers(x_start.numel() // 9, proc.num_timesteps, x_start.device, staged=False)
+        _b.train_fused(buf, flat, proc._sched, trap_q, x_start, t, **kw)
+        ctx.buf = buf
+        return buf.loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        grad = _b.train_bwd(ctx.carry, ctx.n_params, ctx.T, gscale=g)
-        ctx.carry = None
+        if ctx.buf is None:
+            grad = _b.train_bwd(ctx.carry, ctx.n_params, ctx.T, gscale=g)
+            ctx.carry = None
+        else:
+            grad = _b.train_bwd_reduce(ctx.buf, gscale=g)
+            ctx.buf = None
         return grad, None, None, None, None, None
 
 
@@ -102,6 +113,7 @@ class SO3Diffusion(nn.Module):
         # call, which is what a captured hipGraph of the training step needs to draw fresh noise on every replay.
         self.rng_counter = None
         self.draw_t_in_kernel = True  # forward(): timesteps from the samples' Philox blocks on the training fast path
+        self.train_step_kernel = "fused"  # the fast path's device work: "fused" = ONE kernel (so3x_train_fused), "staged" = round 3's three
 
         sched = _b.schedule_from_betas(betas)  # float64 math, fp32 storage, as diffusion.py:62-92
         for i, name in enumerate(_SCHED_NAMES):

@@ -7,7 +7,13 @@ nothing and never synchronise, so the step is capturable as it is; the one host-
 replays -- the Philox offset of the noise draw -- lives in a device counter (`SO3Diffusion.rng_counter`) that the step
 itself increments, `t` is drawn in the noising kernel, and so3x.optim.Adam keeps its step count on the device.
 
-Two forms.
+Three forms.
+
+**One-kernel** (round 4; the default wherever the path below applies, any world size): so3x_train_fused -- noising, forward, loss
+and the whole backward down to the dW slabs in ONE launch -- then the slab reduction with Adam in its epilogue (single process:
+three launches per step with the prep), or slab reduction -> all-reduce -> Adam (data-parallel).  The noising is inside the
+kernel, so there is nothing left to run beside the tail: the kernel is ~90 us shorter than the three it replaces, which is more
+than the pipelined form below could hide.
 
 **Pipelined** (the default, in a data-parallel run, for the path BASELINE config 4 names: SO3Diffusion + the 65-wide
 skew-vector RotPredict with bf16 operands + so3x.optim.Adam).  The step runs as its C-ABI stages (so3x_train_noise / _net / _bwd_partial / _bwd_reduce /
@@ -63,9 +69,9 @@ class TrainStepGraph:
     """process: SO3Diffusion (or a subclass whose p_losses honours `rng_counter`); optimizer: so3x.optim.Adam, or a
     capturable torch optimizer (torch.optim.Adam(params, lr, fused=True, capturable=True)); batch_shape: the fixed shape of
     this rank's data batch; ctx: so3x.parallel.Ctx (None = single process); n_global: the global batch (for unequal shards).
-    pipeline: "auto" (pipelined where the path allows AND there is a gradient collective to hide, i.e. world size > 1; the serial
-    form in a single process), True (pipelined, also in a single process), False (the serial form), "staged" (single process:
-    the stages in one stream, reduction + Adam as one launch).
+    pipeline: "auto" (the one-kernel step where the path allows, else the serial form), "fused" (the one-kernel step, or raise),
+    True (round 3's pipelined stages), False (the serial form: autograd), "staged" (single process: round 3's stages in one stream,
+    reduction + Adam as one launch).
 
         g = TrainStepGraph(process, optim, x.shape, ctx=ctx)
         for x in data: loss = g.step(x)          # loss: 0-d device tensor, overwritten by the next replay
@@ -91,14 +97,23 @@ class TrainStepGraph:
             raise ValueError("allreduce must be 'auto', 'in_graph' or 'split'")
         from .optim import Adam as _So3xAdam
         eligible = (process._lean(None) and process.draw_t_in_kernel and isinstance(optimizer, _So3xAdam) and optimizer.net is self.net
-                    and self.n_local > 0)
+                    and self.n_local > 0 and all(p.requires_grad for p in self.net.net.parameters()))
         if pipeline is True and not eligible:
             raise ValueError("so3x: the pipelined step is built for SO3Diffusion(loss_type='skewvec', draw_t_in_kernel) + the 65-wide "
                              "skew-vector RotPredict with bf16 operands + so3x.optim.Adam")
         # "auto": pipelined where there is a collective to hide.  In a single process every kernel of the tail fills the chip
         # for its few microseconds, the noising kernel finds no free wave slots beside them, and the fork / join edges cost
         # ~2 us: measured 0.2430 vs 0.2402 ms per 2^19-sample step (bench.py train_step, round 3) -- so the serial form stays.
-        self.pipelined = bool(eligible and (pipeline is True or (pipeline == "auto" and self.world > 1)))
+        if pipeline == "fused" and not eligible:
+            raise ValueError("so3x: the one-kernel step is built for SO3Diffusion(loss_type='skewvec', draw_t_in_kernel) + the 65-wide "
+                             "skew-vector RotPredict with bf16 operands + so3x.optim.Adam")
+        # "auto": the one-kernel step (so3x_train_fused) wherever it applies -- measured 0.2066 against 0.2446 ms for the staged
+        # launches at 2^19 samples in its first form (profiles/r04_ab_train_fused_v1.json)
+        self.fused = bool(eligible and pipeline in ("auto", "fused") and getattr(process, "train_step_kernel", "fused") == "fused")
+        self.pipelined = bool(eligible and pipeline is True)
+        # ... decided TOGETHER (as in_graph / split below): the forms differ in their sequence of collectives (the pipelined one
+        # flushes with an extra all-reduce), so a rank whose shard is empty must not take another form than its peers
+        self.fused, self.pipelined = self._all_ranks(self.fused), self._all_ranks(self.pipelined)
         # pipeline="staged" (single process; A/B): the same stages as ONE stream with the slab reduction and the optimizer as one
         # launch (so3x_train_bwd_reduce_adam) -- five launches, no autograd.  Measured the same as the autograd-driven serial
         # graph (0.2376 against 0.2366 ms: inside a graph a 5-us launch costs nothing extra), so "auto" keeps the serial form.
@@ -113,48 +128,52 @@ class TrainStepGraph:
         self._one = torch.ones((), dtype=torch.float32, device=dev)  # d loss / d loss: given, not filled by a launch per step
         self._pending = False      # pipelined: a backward's slabs are waiting for their reduction / all-reduce / update
         self._side = torch.cuda.Stream(device=dev)
-        if self.pipelined or self.staged:
-            self.buf = _b.TrainBuffers(self.n_local, process.num_timesteps, dev)
+        if self.pipelined or self.staged or self.fused:
+            self.buf = _b.TrainBuffers(self.n_local, process.num_timesteps, dev, staged=not self.fused)
             self.net.flat_data()                         # (re-)adopt the parameters into the flat buffer if they were re-homed
             self.net._install_flat_grad(self.buf.grad)   # the .grad views alias the buffer the reduction writes
             self.loss = self.buf.loss[0]
             process._tables()
-        warm = torch.cuda.Stream(device=dev)
-        warm.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(warm):   # warm-up off the default stream: one-time attribute / occupancy queries, allocator pools,
-            for _ in range(warmup):     # optimizer state, and the communicator's first collective
-                if self.pipelined:
-                    self._noise(); self._net(); self._bwd(); self._tail()
-                elif self.staged:
-                    self._noise(); self._net(); self._bwd(); self.optimizer.step_with_reduction(self.buf)
+        try:   # whatever happens below, construction leaves no trace: warm-up updates, moments, counters are undone
+            warm = torch.cuda.Stream(device=dev)
+            warm.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(warm):   # warm-up off the default stream: one-time attribute / occupancy queries, allocator pools,
+                for _ in range(warmup):     # optimizer state, and the communicator's first collective
+                    if self.fused:
+                        self._fused_step(); self._fused_tail()
+                    elif self.pipelined:
+                        self._noise(); self._net(); self._bwd(); self._tail()
+                    elif self.staged:
+                        self._noise(); self._net(); self._bwd(); self.optimizer.step_with_reduction(self.buf)
+                    else:
+                        self._fwd_bwd()
+                        self._allreduce()
+                        self.optimizer.step()
+            torch.cuda.current_stream(dev).wait_stream(warm)
+            self.mode = None
+            self.graph = self.graph_opt = None
+            if allreduce == "auto" and self.world > 1 and dist.get_backend() != "nccl" and not _assume_capturable:
+                allreduce = "split"  # host-staged collectives (gloo) cannot be captured: do not try
+            if self.world == 1 or allreduce in ("auto", "in_graph"):
+                err = None
+                try:
+                    self._capture_in_graph(_inject_capture_failure)
+                except Exception as e:  # noqa: BLE001 -- whatever the stack raises inside a capture
+                    err = e
+                    torch.cuda.synchronize(dev)
+                # the decision is taken TOGETHER: one rank replaying [.. all-reduce ..] as a graph while another issues it eagerly
+                # between two graphs would still match, but a rank that raised here while its peers went on would not
+                if self._all_ranks(err is None):
+                    self.mode = "in_graph"
                 else:
-                    self._fwd_bwd()
-                    self._allreduce()
-                    self.optimizer.step()
-        torch.cuda.current_stream(dev).wait_stream(warm)
-        self.mode = None
-        self.graph = self.graph_opt = None
-        if allreduce == "auto" and self.world > 1 and dist.get_backend() != "nccl" and not _assume_capturable:
-            allreduce = "split"  # host-staged collectives (gloo) cannot be captured: do not try
-        if self.world == 1 or allreduce in ("auto", "in_graph"):
-            err = None
-            try:
-                self._capture_in_graph(_inject_capture_failure)
-            except Exception as e:  # noqa: BLE001 -- whatever the stack raises inside a capture
-                err = e
-                torch.cuda.synchronize(dev)
-            # the decision is taken TOGETHER: one rank replaying [.. all-reduce ..] as a graph while another issues it eagerly
-            # between two graphs would still match, but a rank that raised here while its peers went on would not
-            if self._all_ranks(err is None):
-                self.mode = "in_graph"
-            else:
-                self.graph = self.graph_head = self.graph_tail = None
-                if self.world == 1 or allreduce == "in_graph":
-                    raise err if err is not None else RuntimeError("so3x: another rank could not capture the all-reduce inside the graph")
-        if self.mode is None:
-            self._capture_split()
-            self.mode = "split"
-        self._restore(snap)
+                    self.graph = self.graph_head = self.graph_tail = None
+                    if self.world == 1 or allreduce == "in_graph":
+                        raise err if err is not None else RuntimeError("so3x: another rank could not capture the all-reduce inside the graph")
+            if self.mode is None:
+                self._capture_split()
+                self.mode = "split"
+        finally:
+            self._restore(snap)
         self._hyper = _hyper_of(optimizer)
 
     # ------------------------------------------------------------------ state around the warm-up
@@ -198,7 +217,7 @@ class TrainStepGraph:
                 for k, v in st.items():
                     if isinstance(v, torch.Tensor):
                         v.zero_() if old is None else v.copy_(old[k])
-        if self.pipelined or self.staged:
+        if self.pipelined or self.staged or self.fused:
             self.buf.grad.zero_(); self.buf.loss.zero_()
         self._pending = False
         torch.cuda.synchronize(self.dev)
@@ -220,10 +239,22 @@ class TrainStepGraph:
 
     def _allreduce(self):
         if self.world > 1:
-            if self.pipelined:
+            if self.pipelined or self.fused:
                 parallel.allreduce_flat(self.buf.grad, self.ctx, n_local=self.n_local, n_global=self.n_global, optimizer=self.optimizer)
             else:
                 parallel.allreduce_gradients(self.net, self.ctx, n_local=self.n_local, n_global=self.n_global, optimizer=self.optimizer)
+
+    # the one-kernel step (so3x.h: so3x_train_fused) and what follows it
+    def _fused_step(self):
+        p = self.process
+        _b.train_fused(self.buf, self.net.flat_data(), p._sched, p._trap_q, self.x, None, quirk_col0=p.quirk_col0, seed=_rng.seed(),
+                       rng_offset=0, rng_counter=p.rng_counter, index_base=p.index_base, guide_q=p._guide_q)
+
+    def _fused_tail(self):
+        if self.world == 1:
+            self.optimizer.step_with_reduction(self.buf)   # slab reduction + Adam: one launch
+        else:
+            self._tail()                                   # slab reduction -> all-reduce -> Adam
 
     # the stages of the pipelined form (so3x.h: so3x_train_noise / _net / _bwd_partial / _bwd_reduce, so3x_adam_step)
     def _noise(self):
@@ -252,6 +283,15 @@ class TrainStepGraph:
 
     # ------------------------------------------------------------------ capture
     def _capture_in_graph(self, inject_failure=False):
+        if self.fused:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._fused_step()
+                if inject_failure:
+                    raise RuntimeError("so3x: injected capture failure (test)")
+                self._fused_tail()
+            self.graph = g
+            return
         if self.staged:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -286,6 +326,15 @@ class TrainStepGraph:
         self.graph_head, self.graph, self.graph_tail = head, steady, tail
 
     def _capture_split(self):
+        if self.fused:   # [one-kernel step, slab reduction] -> eager all-reduce -> [Adam]
+            g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._fused_step()
+                _b.train_bwd_reduce(self.buf)
+            with torch.cuda.graph(g2, pool=g.pool()):
+                self.optimizer.step()
+            self.graph, self.graph_opt = g, g2
+            return
         if not self.pipelined:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

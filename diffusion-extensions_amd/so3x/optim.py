@@ -37,6 +37,16 @@ class Adam(torch.optim.Optimizer):
             self._step = torch.zeros(2, dtype=torch.float32, device=flat.device)  # [count, scratch]
         return self._m, self._v, self._step
 
+    def _frozen_slices(self):
+        """[offset, end) of every parameter with requires_grad False.  torch.optim.Adam leaves such parameters (grad None)
+        untouched; the one-launch update runs over the whole flat buffer, so their values and moments are put back after it."""
+        out, off = [], 0
+        for p in self.net._flat_params:
+            if not p.requires_grad:
+                out.append((off, off + p.numel()))
+            off += p.numel()
+        return out
+
     @property
     def step_count(self) -> int:
         return 0 if self._step is None else int(self._step[0].item())
@@ -51,7 +61,10 @@ class Adam(torch.optim.Optimizer):
         grad = self.net.gather_flat_grad()
         m, v, step = self._state(flat)
         g = self.param_groups[0]
+        frozen = [(a, b, flat[a:b].clone(), m[a:b].clone(), v[a:b].clone()) for a, b in self._frozen_slices()]
         _b.adam_step(flat, grad, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
+        for a, b, pf, pm, pv in frozen:
+            flat[a:b].copy_(pf); m[a:b].copy_(pm); v[a:b].copy_(pv)
         return loss
 
     @torch.no_grad()
@@ -59,6 +72,8 @@ class Adam(torch.optim.Optimizer):
         """the slab reduction of a staged training step (so3x.backend.TrainBuffers) and this optimizer's update as ONE launch --
         what a single-process captured step uses instead of train_bwd_reduce + step() (same arithmetic, bit-identical)"""
         flat = self.net.flat_data()
+        if self._frozen_slices():
+            raise ValueError("so3x.optim.Adam.step_with_reduction updates every parameter; with frozen parameters use step()")
         m, v, step = self._state(flat)
         g = self.param_groups[0]
         _b.train_bwd_reduce_adam(buf, flat, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)

@@ -12,6 +12,13 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 DEV = "cuda:0"
 
 
@@ -1330,7 +1337,7 @@ def test_sharded_sampling_is_invariant_to_the_number_of_ranks(tmp_path):
     script = tmp_path / "shard_worker.py"
     script.write_text(_SHARD_WORKER)
     outp = str(tmp_path / "two_ranks.pt")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", LOCAL_RANK="0", SO3X_DIST_BACKEND="gloo")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", LOCAL_RANK="0", SO3X_DIST_BACKEND="gloo")
     procs = [subprocess.Popen([sys.executable, str(script), PKG, outp], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]

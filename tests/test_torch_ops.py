@@ -71,10 +71,19 @@ def test_opcheck_on_the_training_step_operators(env):
                                       buf.workspace), test_utils=checks)
     opcheck(ops.train_noise.default, (proc._sched, env["trap_q"], proc._guide_q, x, t, True, None, None, 5, 0, None, 0, buf.x_t, buf.t_used,
                                       buf.workspace), test_utils=checks)
+    # (opcheck runs an operator on COPIES of its arguments: the buffers themselves are still torch.empty here; the kernels clamp
+    #  whatever timesteps they are handed -- an uninitialised t_used once indexed the bias table out of its aperture)
     opcheck(ops.train_net.default, (params, T, buf.x_t, buf.t_used, buf.dout, buf.zstash, buf.loss, buf.out, counter, buf.workspace),
             test_utils=checks)
+    B.train_noise(buf, proc._sched, env["trap_q"], x, t, seed=5, guide_q=proc._guide_q)
+    B.train_net(buf, params)
     opcheck(ops.train_bwd_partial.default, (buf.x_t, buf.t_used, buf.dout, buf.zstash, T, buf.workspace), test_utils=checks)
     opcheck(ops.train_bwd_reduce.default, (n, T, None, buf.grad, buf.workspace), test_utils=checks)
+    for tt, ctr in ((t, None), (None, counter)):   # the one-kernel step: every optional output present / absent
+        opcheck(ops.train_fused.default, (params, proc._sched, env["trap_q"], proc._guide_q, x, tt, True, None, None, 5, 0, ctr, 0, buf.loss,
+                                          buf.t_used, buf.x_t, buf.out, buf.workspace), test_utils=checks)
+        opcheck(ops.train_fused.default, (params, proc._sched, env["trap_q"], proc._guide_q, x, tt, True, None, None, 5, 0, ctr, 0, buf.loss,
+                                          None, None, None, buf.workspace), test_utils=checks)
     m_, v_, st_ = torch.zeros_like(params), torch.zeros_like(params), torch.zeros(2, device=DEV)
     opcheck(ops.train_bwd_reduce_adam.default, (n, T, None, buf.grad, buf.workspace, params.clone(), m_, v_, st_, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0),
             test_utils=checks)

@@ -47,10 +47,11 @@ def test_fused_step_reproduces_the_reference_training_step(mods, golden):
     B = mods["B"]
     g = golden["train_step"]
     net = _golden_net(mods, golden, "bf16")
-    for T in (100, 1000):
-        for seed in (0, 1, 2):
+    for T, seed, kernel in [(T, seed, k) for T in (100, 1000) for seed in (0, 1, 2) for k in ("fused", "staged")]:
+        if True:
             pre = f"T{T}_s{seed}_"
             proc = mods["diff"].SO3Diffusion(net, timesteps=T, betas=golden["schedule"][f"betas64_{T}"]).to(DEV)
+            proc.train_step_kernel = kernel   # the one-kernel step (round 4, the default) and round 3's three launches
             x0, t = dev(g[pre + "x0"]), dev(g[pre + "t"], torch.int64)
             ax, un = dev(g[pre + "axes"]), dev(g[pre + "unif"])
             net.zero_grad(set_to_none=True)
@@ -73,8 +74,10 @@ def test_fused_step_reproduces_the_reference_training_step(mods, golden):
             l2 = ((out - target) ** 2).mean()
             dout = (out - target) * (2.0 / (3 * n))
             g2 = B.mlp_bwd(params, x_t, t, dout, B.PREC_BF16, T, zstash=zs)
-            assert abs(float(loss.detach()) - float(l2)) < 2e-6 * float(l2)
-            assert float((flat - g2).abs().max()) < 2e-6 * float(g2.abs().max())
+            # staged: the same kernels -> fp32 rounding; one-kernel: the same forward (loss to rounding), the backward multiplies by
+            # the silu' the forward parked (table, f16) instead of re-evaluating it from f16 pre-activations
+            assert abs(float(loss.detach()) - float(l2)) < (2e-6 if kernel == "staged" else 2e-5) * float(l2)
+            assert float((flat - g2).abs().max()) < (2e-6 if kernel == "staged" else 1e-2) * float(g2.abs().max())
 
 
 def test_fused_step_pieces_vs_oracle(mods, golden):
@@ -181,10 +184,47 @@ def test_so3x_adam_follows_torch_adam_on_the_network(mods):
     assert float((pa - pb).abs().max()) < 5e-7
 
 
-def _run_steps(mods, base, x, mode, steps=4, optimizer="so3x"):
+def test_frozen_parameters_stay_frozen(mods):
+    """the flat-buffer optimizer runs ONE launch over all 17,358 values and the fused backward returns a full flat
+    gradient; a parameter with requires_grad False must nevertheless keep its value and moments, as under torch.optim.Adam
+    (which skips parameters whose .grad is None) -- twin networks, one layer frozen, same gradients"""
+    torch.manual_seed(2)
+    a = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    b = copy.deepcopy(a)
+    for net in (a, b):
+        net.net[2].weight.requires_grad_(False)
+        net.net[2].bias.requires_grad_(False)
+    proc = mods["diff"].SO3Diffusion(a, timesteps=100).to(DEV)
+    oa = mods["optim"].Adam(a, lr=1e-3, weight_decay=1e-2)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3, weight_decay=1e-2)
+    x = mods["util"].quat_to_rmat(torch.randn(1024, 4, device=DEV))
+    w0, b0 = a.net[2].weight.detach().clone(), a.net[2].bias.detach().clone()
+    for _ in range(5):
+        oa.zero_grad(set_to_none=True)
+        loss = proc(x)                      # the one-kernel step: a full flat gradient comes back
+        loss.backward()
+        assert a.net[2].weight.grad is None and a.net[0].weight.grad is not None
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            pb.grad = None if pa.grad is None else pa.grad.detach().clone()
+        oa.step()
+        ob.step()
+    assert torch.equal(a.net[2].weight, w0) and torch.equal(a.net[2].bias, b0)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) < 5e-7
+    from so3x.graphs import TrainStepGraph
+    g = TrainStepGraph(proc, oa, x.shape)   # not every parameter trains: the generic serial form, whose optimizer step keeps them
+    assert not g.fused
+    g.step(x)
+    assert torch.equal(a.net[2].weight, w0)
+    with pytest.raises(ValueError, match="frozen"):
+        oa.step_with_reduction(None)
+
+
+def _run_steps(mods, base, x, mode, steps=4, optimizer="so3x", kernel="fused"):
     from so3x.graphs import TrainStepGraph
     net = copy.deepcopy(base)
     proc = mods["diff"].SO3Diffusion(net, timesteps=100).to(DEV)
+    proc.train_step_kernel = kernel
     proc.rng_counter = torch.zeros(1, dtype=torch.int64, device=DEV)
     mods["rng"].manual_seed(7)
     make_opt = (lambda: mods["optim"].Adam(net, lr=1e-3)) if optimizer == "so3x" else \
@@ -193,9 +233,11 @@ def _run_steps(mods, base, x, mode, steps=4, optimizer="so3x"):
     if mode != "eager":
         # NO rewind here: construction (warm-up steps on a placeholder batch + capture) must leave parameters, optimizer state and
         # counters exactly as it found them (the first replay is the first eager step)
-        g = TrainStepGraph(proc, opt, x.shape, warmup=2, pipeline={"graph": "auto", "serial": False, "pipelined": True, "staged": "staged"}[mode])
-        assert g.pipelined == (mode == "pipelined")   # "auto" pipelines only where there is a collective to hide (world size > 1)
-        assert g.staged == (mode == "staged")         # the stages as one stream, reduction + Adam as ONE launch
+        g = TrainStepGraph(proc, opt, x.shape, warmup=2, pipeline={"graph": "auto", "serial": False, "pipelined": True, "staged": "staged", "fused": "fused"}[mode])
+        assert g.pipelined == (mode == "pipelined")   # round 3's pipelined stages: on request only
+        assert g.staged == (mode == "staged")         # round 3's stages as one stream, reduction + Adam as ONE launch
+        # "auto" = the one-kernel step + [reduction + Adam] wherever the path allows (so3x.optim.Adam, train_step_kernel "fused")
+        assert g.fused == (kernel == "fused" and optimizer == "so3x" and mode in ("graph", "fused"))
         assert torch.equal(net.flat_data(), base.flat_data()) and int(proc.rng_counter) == 0
     losses = []
     for _ in range(steps):
@@ -219,14 +261,15 @@ def test_graph_replay_equals_the_eager_loop_bit_for_bit(mods):
     torch.manual_seed(0)
     base = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
     x = mods["util"].quat_to_rmat(torch.randn(2048, 4, device=DEV))
-    for optimizer, modes in (("so3x", ("pipelined", "serial", "graph", "staged")), ("torch", ("graph",))):
-        le, pe, ce, _, _ = _run_steps(mods, base, x, "eager", optimizer=optimizer)
+    for optimizer, kernel, modes in (("so3x", "fused", ("serial", "graph", "fused")), ("so3x", "staged", ("pipelined", "serial", "graph", "staged")),
+                                     ("torch", "fused", ("graph",)), ("torch", "staged", ("graph",))):
+        le, pe, ce, _, _ = _run_steps(mods, base, x, "eager", optimizer=optimizer, kernel=kernel)
         for mode in modes:
-            lg, pg, cg, _, _ = _run_steps(mods, base, x, mode, optimizer=optimizer)
+            lg, pg, cg, _, _ = _run_steps(mods, base, x, mode, optimizer=optimizer, kernel=kernel)
             assert ce == cg == 4
             assert len(set(lg)) == 4 and all(np.isfinite(lg))              # different noise and timesteps on every replay
-            assert le == lg, (optimizer, mode, le, lg)
-            assert torch.equal(pe, pg), (optimizer, mode)
+            assert le == lg, (optimizer, kernel, mode, le, lg)
+            assert torch.equal(pe, pg), (optimizer, kernel, mode)
             assert not torch.equal(pe, base.flat_data())
 
 
@@ -242,6 +285,7 @@ def test_pipelined_step_is_one_update_behind_until_flushed(mods):
     def fresh():
         net = copy.deepcopy(base)
         proc = mods["diff"].SO3Diffusion(net, timesteps=100).to(DEV)
+        proc.train_step_kernel = "staged"   # the pipelined form is made of round 3's stages
         proc.rng_counter = torch.zeros(1, dtype=torch.int64, device=DEV)
         mods["rng"].manual_seed(11)
         return net, proc, mods["optim"].Adam(net, lr=1e-3)
@@ -350,7 +394,10 @@ def test_sampling_after_graph_training_sees_the_new_weights(mods):
 _DP_GRAPH_WORKER = r'''
 import os, sys, json, torch
 sys.path.insert(0, sys.argv[1])
-mode = sys.argv[2]                           # "eager" | "graph"
+mode = sys.argv[2]                           # "eager" | "graph" | "eager-staged" | "graph-pipelined"
+kernel = "staged" if mode.endswith(("-staged", "-pipelined")) else "fused"
+pipe = True if mode.endswith("-pipelined") else "auto"
+mode = mode.split("-")[0]
 from so3x import parallel, backend as B, rng, optim
 from so3x.so3_train import RotPredict
 from so3x.diffusion import SO3Diffusion
@@ -362,6 +409,7 @@ parallel.broadcast_parameters(net, ctx)
 start = net.flat_data().clone()
 proc = SO3Diffusion(net, timesteps=100).to(ctx.device)   # default quirk_col0=True: global sample 0's row on every shard
 proc.rng_counter = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+proc.train_step_kernel = kernel
 rng.manual_seed(7)
 opt = optim.Adam(net, lr=1e-3)
 glob = 4096
@@ -371,8 +419,9 @@ x_all = B.quat_to_rmat(torch.randn(glob, 4, generator=torch.Generator().manual_s
 x = x_all[lo:hi].contiguous()
 losses = []
 if mode == "graph":
-    g = TrainStepGraph(proc, opt, x.shape, warmup=2, ctx=ctx, n_global=glob)
-    assert g.pipelined == (ctx.world_size > 1) and torch.equal(net.flat_data(), start) and int(proc.rng_counter) == 0   # construction leaves no trace
+    g = TrainStepGraph(proc, opt, x.shape, warmup=2, ctx=ctx, n_global=glob, pipeline=pipe)
+    assert g.fused == (kernel == "fused") and g.pipelined == (pipe is True)
+    assert torch.equal(net.flat_data(), start) and int(proc.rng_counter) == 0   # construction leaves no trace
     for _ in range(5):
         losses.append(parallel.mean_scalar(g.step(x).clone(), ctx))
     g.flush()
@@ -398,6 +447,14 @@ print("OK", ctx.rank, gmode, losses)
 '''
 
 
+def _free_port():
+    """a port the kernel just handed out and released (as bench.py does): no fixed numbers that a neighbouring job may hold"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _launch(tmp_path, mode, world, port, out):
     script = tmp_path / "dp_graph_worker.py"
     script.write_text(_DP_GRAPH_WORKER)
@@ -417,11 +474,15 @@ def test_data_parallel_graph_step_two_ranks_on_one_gpu(tmp_path):
     ([forward + backward] graph, flat-gradient all-reduce, [Adam] graph) keeps the replicas bit-identical and equals the
     eager data-parallel loop bit for bit; and both equal -- to summation-order rounding -- the single-process run on the
     whole batch (noise and timesteps are keyed by the global sample index)."""
-    eager2 = _launch(tmp_path, "eager", 2, 29551, tmp_path / "e2.pt")
-    graph2 = _launch(tmp_path, "graph", 2, 29553, tmp_path / "g2.pt")
+    eager2 = _launch(tmp_path, "eager", 2, _free_port(), tmp_path / "e2.pt")
+    graph2 = _launch(tmp_path, "graph", 2, _free_port(), tmp_path / "g2.pt")
     assert graph2["mode"] == "split"                                     # gloo cannot be captured: two graphs + eager collective
     assert graph2["losses"] == eager2["losses"] and torch.equal(graph2["params"], eager2["params"])
-    graph1 = _launch(tmp_path, "graph", 1, 29555, tmp_path / "g1.pt")
+    # round 3's pipelined stages (on request) against the eager loop on the same three kernels
+    eager2s = _launch(tmp_path, "eager-staged", 2, _free_port(), tmp_path / "e2s.pt")
+    graph2p = _launch(tmp_path, "graph-pipelined", 2, _free_port(), tmp_path / "g2p.pt")
+    assert graph2p["mode"] == "split" and graph2p["losses"] == eager2s["losses"] and torch.equal(graph2p["params"], eager2s["params"])
+    graph1 = _launch(tmp_path, "graph", 1, _free_port(), tmp_path / "g1.pt")
     assert graph1["mode"] == "in_graph"
     assert np.allclose(graph1["losses"], graph2["losses"], rtol=1e-4)
     # Adam's first updates are +-lr whatever a gradient's size, so the few gradients that are zero to rounding may move
@@ -437,7 +498,7 @@ def test_rccl_all_reduce_is_capturable_in_the_training_graph(tmp_path):
     code = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29557', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1)
 from so3x import parallel, backend as B, optim
@@ -449,16 +510,19 @@ net = RotPredict(out_type='skewvec', precision='bf16').to('cuda:0')
 proc = SO3Diffusion(net, timesteps=100).to('cuda:0')
 opt = optim.Adam(net, lr=1e-3)
 x = B.quat_to_rmat(torch.randn(1024, 4, device='cuda:0'))
-g = TrainStepGraph(proc, opt, x.shape, ctx=ctx, allreduce='in_graph')   # ctx says world size 2: the pipelined form
-before = net.flat_data().clone()
-l = [float(g.step(x)) for _ in range(3)]
-g.flush()
-assert g.pipelined and g.mode == 'in_graph' and all(v == v for v in l) and not torch.equal(before, net.flat_data())
+for pipe in ('auto', True):   # the one-kernel step -> reduce -> all-reduce -> Adam, and round 3's pipelined stages
+    proc.train_step_kernel = 'fused' if pipe == 'auto' else 'staged'
+    g = TrainStepGraph(proc, opt, x.shape, ctx=ctx, allreduce='in_graph', pipeline=pipe)   # ctx says world size 2: the collective is issued
+    before = net.flat_data().clone()
+    l = [float(g.step(x)) for _ in range(3)]
+    g.flush()
+    assert g.fused == (pipe == 'auto') and g.pipelined == (pipe is True) and g.mode == 'in_graph'
+    assert all(v == v for v in l) and not torch.equal(before, net.flat_data())
 dist.destroy_process_group()
 print('OK', l)
 """
     from conftest import PKG
-    r = subprocess.run([sys.executable, "-c", code, PKG], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code, PKG, str(_free_port())], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
@@ -519,7 +583,7 @@ def test_in_graph_or_split_is_decided_by_all_ranks_together(tmp_path, inject):
     script = tmp_path / "capture_failure_worker.py"
     script.write_text(_CAPTURE_FAILURE_WORKER)
     from conftest import PKG
-    port = 29561 if inject == "inject" else 29563
+    port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", LOCAL_RANK="0", SO3X_DIST_BACKEND="gloo")
     procs = [subprocess.Popen([sys.executable, str(script), PKG, inject], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
