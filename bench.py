@@ -47,16 +47,37 @@ def _self_launch(n_ranks, argv):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr, stderr=None))
-    rcs = []
+    # poll ALL the ranks: the first one to fail ends the job at once (a rank that died in its imports would otherwise leave its
+    # peers in the rendezvous until torch's timeout, minutes later) and its code is the job's
+    rcs = [None] * n_ranks
+    failed_at = None
     try:
-        for pr in procs:
-            rcs.append(pr.wait())
+        while any(rc is None for rc in rcs):
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = pr.poll()
+            if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+                failed_at = time.monotonic()
+            # peers of a failed rank get two seconds to fail by themselves (they usually hit the same wall, and say so); then they
+            # are ended -- in a collective whose partner is gone they would sit until torch's timeout
+            if failed_at is not None and time.monotonic() - failed_at > 2.0:
+                for pr in procs:   # exactly the processes started here
+                    if pr.poll() is None:
+                        pr.terminate()
+                for pr in procs:
+                    try:
+                        pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                break
+            time.sleep(0.05)
+        rcs = [pr.poll() for pr in procs]
     except BaseException:
-        for pr in procs:   # exactly the processes started here
+        for pr in procs:
             if pr.poll() is None:
                 pr.kill()
         raise
-    return max((abs(rc) for rc in rcs), default=0)
+    return max((abs(rc) if rc is not None else 1 for rc in rcs), default=0)
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
@@ -94,60 +115,103 @@ def run_steps(B, params, sched, trap_p, x, T, nsteps, seed, index_base, precisio
     return launches
 
 
-def cpu_baseline(T, params_np, betas, budget_s=12.0):
-    """The oracle (C restatement, OpenMP over the batch) timed on this box's host cores on a bounded
-    sample of the same workload: n rotations x a few reverse steps around the middle of the chain."""
+def cpu_baseline(T, params_np, betas, budget_s=6.0):
+    """The oracle (C restatement, OpenMP over the batch, all host threads) timed on this box's host cores on a bounded sample of
+    the same workload: 2^17 rotations x as many reverse steps around the middle of the chain as ~6 s of CPU work hold.  The timed
+    build is the oracle's source compiled -O3 -march=native -fopenmp ON THIS HOST (oracle/Makefile: libso3_oracle_fast.so; the
+    checker build stays -O2 -ffp-contract=off) and is called on preallocated arrays: only the C call sits in the timed region."""
     from oracle import oracle as O
-    sched = O.schedule_from_betas(betas)
-    trap_p = O.igso3_build_tables(np.exp(np.float32(0.5) * sched[9]))
+    sched = np.ascontiguousarray(O.schedule_from_betas(betas), np.float32)
+    trap_p = np.ascontiguousarray(O.igso3_build_tables(np.exp(np.float32(0.5) * sched[9])), np.float32)
+    params_np = np.ascontiguousarray(params_np, np.float32).ravel()
     rng = np.random.default_rng(0)
-    n = 1 << 15
-    x = O.quat_to_rmat(rng.standard_normal((n, 4)).astype(np.float32))
+    n = 1 << 17
+    x = np.ascontiguousarray(O.quat_to_rmat(rng.standard_normal((n, 4)).astype(np.float32)), np.float32).reshape(n, 9)
+    y = np.empty_like(x)
     axes = rng.standard_normal((n, 3)).astype(np.float32)
     unif = rng.random(n, dtype=np.float32)
-    O.p_sample_step(params_np, sched, trap_p, x[:1024], 500, axes[:1024], unif[:1024])  # warm
+    O.p_sample_step_timed(params_np, sched, trap_p, x, 500, axes, unif, y)  # builds the timed library on this host; warms the threads
     t0 = time.perf_counter()
     steps = 0
     tt = T // 2
     while True:
-        x = O.p_sample_step(params_np, sched, trap_p, x, tt, axes, unif)
+        O.p_sample_step_timed(params_np, sched, trap_p, x, tt, axes, unif, y)
+        x, y = y, x
         steps += 1
         tt = tt - 1 if tt > 0 else T - 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 1000:  # ~12 s of CPU work whatever the host's core count
+        if el > budget_s or steps >= 1000:
             break
     return {"value": n * steps / el, "unit": "sample-steps/s", "cores": O.omp_threads(), "kind": "port",
-            "sample": f"{n} rotations x {steps} reverse steps (t from {T // 2} down), {el:.1f} s of CPU work"}
+            "host_cpus": os.cpu_count(), "torch_num_threads": torch.get_num_threads(), "build": O.FAST_FLAGS,
+            "sample": f"{n} rotations x {steps} reverse steps (t from {T // 2} down), {el:.1f} s of CPU work, {O.omp_threads()} OpenMP threads, "
+                      f"oracle source built {O.FAST_FLAGS} on this host"}
+
+
+class Pmc:
+    """The committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/summarize_profiles.py from a
+    tools/profile_round.sh run).  PMC counters cannot be read from inside this process, so every PMC-derived field of the line is a
+    QUOTE from that file -- and says so: `pmc_source` names the profile (round tag, the git commit it was summarised at) and
+    whether the kernel sources are still the ones it was taken on (sha256 over csrc/ + include/so3x.h, recorded on the GPU box at
+    profile time).  When they are not, nothing is quoted: a stale profile must not price a new kernel."""
+
+    def __init__(self):
+        self.data, self.meta, self.fresh = {}, {}, False
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                self.data = json.load(f)
+            self.meta = self.data.get("_meta", {})
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from csrc_digest import digest
+            self.fresh = bool(self.meta.get("csrc_sha256")) and self.meta["csrc_sha256"] == digest(ROOT)
+        except (OSError, ValueError, ImportError):
+            pass
+
+    @property
+    def source(self):
+        if not self.data:
+            return "none: profiles/pmc_traffic.json missing"
+        tag = f"committed profile {self.meta.get('tag', '?')} (profiles/pmc_traffic.json, summarised at git {self.meta.get('git', '?')})"
+        return tag + (": kernel sources unchanged since it was taken" if self.fresh else
+                      ": STALE -- the kernel sources changed since it was taken; PMC-derived fields withheld")
+
+    def traffic(self, kernel, **match):
+        """HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md + WRITE_SIZE), only when the
+        profiled configuration matches this run"""
+        rec = self.data.get(kernel) if self.fresh else None
+        if rec and all(rec.get("config", {}).get(k) == v for k, v in match.items()):
+            return rec["hbm_bytes_per_launch"]
+        return None
+
+    def counter(self, kernel, name):
+        try:
+            return self.data["mfma_utilisation"][kernel][name] if self.fresh else None
+        except KeyError:
+            return None
+
+
+PMC = Pmc()
 
 
 def pmc_traffic(kernel, **match):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json; FETCH_SIZE
-    doubled per the gfx950 rule of MI355X_MICROARCH.md, WRITE_SIZE as is).  PMC counters cannot be read from
-    inside this process; the value is reported only when the profiled configuration matches this run."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(kernel)
-        if rec and all(rec.get("config", {}).get(k) == v for k, v in match.items()):
-            return rec["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    return PMC.traffic(kernel, **match)
 
 
 def pmc_mfma_busy(kernel):
-    """matrix-pipe busy fraction of `kernel` from the committed PMC pass (profiles/pmc_traffic.json), or None"""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["mfma_utilisation"][kernel]["mfma_pipe_busy_frac"]
-    except (OSError, ValueError, KeyError):
-        return None
+    return PMC.counter(kernel, "mfma_pipe_busy_frac")
 
 
 def pmc_counter(kernel, name):
+    return PMC.counter(kernel, name)
+
+
+def isa_mix(name):
+    """instruction mix of a kernel's hot loop (profiles/<tag>_<name>_isa_mix.json: tools/count_isa.py on the committed sources,
+    written by tools/summarize_profiles.py), or None when the sources changed since"""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["mfma_utilisation"][kernel][name]
-    except (OSError, ValueError, KeyError):
+        with open(os.path.join(ROOT, "profiles", f"{PMC.meta.get('tag', 'r04')}_{name}_isa_mix.json")) as f:
+            return json.load(f) if PMC.fresh else None
+    except (OSError, ValueError):
         return None
 
 
@@ -178,12 +242,7 @@ class RawChain:
 
 
 def pmc_valu_busy(kernel):
-    """vector-ALU busy fraction of `kernel` (SQ_ACTIVE_INST_VALU over SIMD-cycles) from the committed PMC pass, or None"""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["mfma_utilisation"][kernel]["valu_busy_frac"]
-    except (OSError, ValueError, KeyError):
-        return None
+    return PMC.counter(kernel, "valu_busy_frac")
 
 
 def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
@@ -240,8 +299,8 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
             eager()
         out["eager_python_loop_ms_per_step"] = wall(eager, 10) * 1e3
     other_ms = staged_ms = None
-    if ctx.world_size == 1:  # the forms "auto" does not pick in a single process, beside it: the pipelined one (nothing to hide at
-        for form in (True, "staged"):  # N = 1) and the stages in one stream with reduction + Adam as one launch (five launches)
+    if ctx.world_size == 1:  # round 3's forms beside it (three kernels with the pre-activation stash in HBM): the pipelined stages and
+        for form in (True, "staged"):  # the stages in one stream with reduction + Adam as one launch (five launches)
             ts = TrainStepGraph(proc, opt, x0.shape, ctx=ctx, n_global=n * ctx.world_size, pipeline=form)
             for _ in range(warm):
                 ts.replay()
@@ -261,13 +320,17 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
     out.update({"ms_per_step": sec * 1e3, "ms_per_step_fastest_rank": wall.fastest_rank * 1e3, "samples_per_s": n * ctx.world_size / sec,
                 "mode": {"in_graph": "one captured hipGraph per step" + ("" if ctx.world_size == 1 else ", all-reduce inside"),
                          "split": "captured hipGraphs with the eager all-reduce between them"}[tg.mode],
-                "pipelined": tg.pipelined,
-                "form": "pipelined stages" if tg.pipelined else "serial graph of six launches",
-                "staged_five_launch_ms_per_step_at_one_gpu": staged_ms,
-                "pipeline": "noising of batch k on a second stream beside [slab reduction -> all-reduce -> Adam] of batch k-1 (so3x/graphs.py)"
-                            if tg.pipelined else None,
-                "pipelined_ms_per_step_at_one_gpu": other_ms,
+                "pipelined": tg.pipelined, "one_kernel": tg.fused,
+                "form": ("one-kernel step: prep -> k_train_fused (noising + forward + loss + backward) -> " +
+                         ("[slab reduction + Adam]" if ctx.world_size == 1 else "slab reduction -> all-reduce -> Adam")) if tg.fused
+                        else ("pipelined stages" if tg.pipelined else "serial graph of six launches"),
+                "round3_staged_five_launch_ms_per_step_at_one_gpu": staged_ms,
+                "round3_pipelined_ms_per_step_at_one_gpu": other_ms,
                 "algorithmic_TFLOPs_per_gpu": 94120 * n / sec / 1e12, "loss": loss, "finite": bool(loss == loss), "steps_timed": reps})
+    try:
+        out["kernel"] = fused_kernel_leg(B, torch, proc, net, x0, n, T)
+    except Exception as e:  # report, never hide
+        out["kernel"] = {"error": repr(e)}
     if ctx.world_size > 1:
         flat = net.gather_flat_grad()
         def ar():
@@ -276,6 +339,45 @@ def train_leg(B, torch, ctx, T, n=1 << 19, reps=50, warm=20):
             ar()
         out["allreduce_us"] = wall(ar, 50) * 1e6
     return out
+
+
+TRAIN_FLOP_PER_SAMPLE = 94120   # 34,190 forward + 59,930 backward (dW + dX of layers 2-5), SURVEY.md 8d
+
+
+def fused_kernel_leg(B, torch, proc, net, x0, n, T, reps=20):
+    """so3x_train_fused alone (the prep launch + k_train_fused) through the raw C ABI, HIP events around `reps` back-to-back calls:
+    the dominant kernel of the training step against the bf16 MFMA peak on its ALGORITHMIC flops (94,120 per sample) and its
+    algorithmic HBM bytes (36 B of x_0 per sample in; one 70 KB partial slab per workgroup out)."""
+    import ctypes as C
+    lib = B.lib()
+    trap_q, _ = proc._tables()
+    params = net.flat_data()
+    loss = torch.zeros(1, device=x0.device)
+    ctr = torch.zeros(1, dtype=torch.int64, device=x0.device)
+    ws = torch.empty(int(lib.so3x_train_workspace_bytes(C.c_int64(n), C.c_int(T))), dtype=torch.uint8, device=x0.device)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def call():
+        rc = lib.so3x_train_fused(C.c_void_p(torch.cuda.current_stream().cuda_stream), P(params), P(proc._sched), C.c_int(T), P(trap_q),
+                                  P(proc._guide_q), P(x0), None, None, C.c_int(1), None, None, C.c_uint64(1), C.c_uint64(0), P(ctr), C.c_int64(0),
+                                  C.c_int64(n), P(loss), None, None, P(ws), C.c_size_t(ws.numel()))
+        assert rc == 0, rc
+    for _ in range(5):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = TRAIN_FLOP_PER_SAMPLE * n / (ms * 1e-3) / 1e12
+    slab_bytes = 256 * 17556 * 4
+    return {"kernel": "k_train_fused (+ k_prep: weight images and per-timestep tables)", "ms_per_call": ms, "bound": "mfma (nominal); LDS bandwidth + one wave's issue rate in fact (DESIGN.md section 4)",
+            "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_MFMA_PEAK_TFLOPS, "flop_per_sample": TRAIN_FLOP_PER_SAMPLE,
+            "algorithmic_hbm_bytes_per_call": 36 * n + slab_bytes, "traffic": pmc_traffic("k_train_fused", n=n),
+            "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_train_fused"), "pmc_source": PMC.source, "timing": "HIP events around back-to-back raw C-ABI calls",
+            "finite": bool(torch.isfinite(loss).item())}
 
 
 def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
@@ -514,16 +616,23 @@ def main():
     # A SIMD serves two waves: port cycles of one wave-step / SIMD cycles per wave-step (live time x live clock).
     port = None
     iv = pmc_counter("k_p_sample_chain", "SQ_INSTS_VALU")
-    if prec == B.PREC_BF16 and clock_ghz and iv:
+    if prec == B.PREC_BF16 and clock_ghz and iv and isa_mix("chain"):
         wave_steps = ((n + 63) // 64) * RL_STEPS
         n_valu = iv / ((1 << 20) // 64 * 100)              # the profile's shape: 2^20 samples, 100 steps per launch
-        n_mfma, n_trans = 106, 58                          # tools/count_isa.py on the staged path (profiles/r03_chain_isa_mix.json)
+        mix = isa_mix("chain") or {}
+        n_mfma, n_trans = mix.get("mfma_per_wave_step"), mix.get("trans_per_wave_step")   # tools/count_isa.py on the step loop
         port_cycles = (n_valu - n_mfma - n_trans) * 4 + n_trans * 8 + n_mfma * 8
         simd_cycles = ms_per_launch * 1e-3 * clock_ghz * 1e9 / (wave_steps / 1024.0)
         port = {"frac": port_cycles / simd_cycles, "port_cycles_per_wave_step": port_cycles, "simd_cycles_per_wave_step": simd_cycles,
-                "vector_instructions_per_wave_step_pmc": n_valu, "mfma": n_mfma, "transcendental": n_trans}
+                "vector_instructions_per_wave_step_pmc": n_valu, "mfma": n_mfma, "transcendental": n_trans,
+                "source": "SQ_INSTS_VALU: " + PMC.source + "; mfma / transcendental counts: profiles/" + f"{PMC.meta.get('tag', 'r04')}_chain_isa_mix.json"
+                          " (tools/count_isa.py); time and clock: this run"}
     flop_per_launch = MLP_FLOP_PER_SAMPLE * n * RL_STEPS
     tflops = flop_per_launch / (ms_per_launch * 1e-3) / 1e12
+    # ISSUED matrix work: the PMC count of bf16 MFMA "MOPS" per launch of the profiled shape (x 512 flop each: the padded 96-row
+    # tiles and the fifth k-step included) over THIS run's launch time -- the other way to read "40 % MFMA utilisation"
+    mops = pmc_counter("k_p_sample_chain", "SQ_INSTS_VALU_MFMA_MOPS_BF16")
+    issued_tflops = None if (not mops or n != (1 << 20) or prec != B.PREC_BF16) else mops * 512.0 / (ms_per_launch * 1e-3) / 1e12
 
     # ---- the metric verbatim: one complete p_sample_loop, B rotations through all T reverse steps (diffusion.py:328-337)
     proc.p_sample_loop((256,))  # untimed: first-use initialisation of the start distribution (its CDF table; ~25 ms of host work)
@@ -569,6 +678,9 @@ def main():
                            "timesteps": T, "seconds": full_s, "sample_steps_per_s": ctx.world_size * n * T / full_s, "finite": full_ok},
             "roofline": {"kernel": "k_p_sample_chain", "bound": "mfma", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
+                         "issued_frac": None if issued_tflops is None else issued_tflops / BF16_MFMA_PEAK_TFLOPS,
+                         "issued_TFLOPs": issued_tflops,
+                         "pmc_source": PMC.source, "silu": "256-entry secant table (max abs error 1.3e-4), bf16 chain kernel",
                          "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=RL_STEPS, precision=args.precision),
                          "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_p_sample_chain"),
                          "valu_busy_frac_pmc": pmc_valu_busy("k_p_sample_chain"),
@@ -577,6 +689,9 @@ def main():
                          "launches": RL_LAUNCHES, "steps_per_launch": RL_STEPS, "ms_per_launch": ms_per_launch,
                          "sample_steps_per_s": n * RL_STEPS / (ms_per_launch * 1e-3),
                          "flop_per_sample_step": MLP_FLOP_PER_SAMPLE,
+                         "measured_here": ["achieved", "frac", "ms_per_launch", "sample_steps_per_s", "in_kernel_clock_ghz"],
+                         "quoted_from_the_committed_profile": ["traffic", "mfma_pipe_busy_frac_pmc", "valu_busy_frac_pmc", "issued_frac (count)",
+                                                               "valu_port_bound_frac (instruction counts)"],
                          "note": "algorithmic MLP flops vs the dense bf16 MFMA peak, on a fixed 100-step launch timed with HIP events "
                                  "(the shape profiled under profiles/); the kernel's real bound is the VALU issue port "
                                  "(valu_busy_frac_pmc; DESIGN.md section 4); algorithmic HBM traffic is 72 B/sample per launch"},
@@ -595,8 +710,11 @@ def main():
             def give_up():
                 if ctx.rank == 0 and line is not None:
                     line["train_step"] = {"error": f"no result after {args.train_timeout} s (a collective that did not return?); the headline above is unaffected"}
+                    line["exit_code"] = 3
                     print(json.dumps(line), flush=True)
-                os._exit(0)   # the reason is in the line; a non-zero code would discard the headline the line carries
+                # NON-ZERO, on every rank: a collective that never returned is a failed run (kernels or collectives may still be in
+                # flight); the line above carries the headline and the reason for whoever reads stdout
+                os._exit(3)
 
             watchdog = threading.Timer(args.train_timeout, give_up)
             watchdog.daemon = True

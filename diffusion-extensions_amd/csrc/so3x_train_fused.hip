@@ -38,9 +38,12 @@ constexpr int IMG = image_bytes<PREC, VAR>();                 // 53 fragments + 
 constexpr int WTB = wt_bytes<PREC>();                         // transposed image: 48 fragments
 constexpr int REC_DW = 8;                                     // hand-over record of a sample: x_t as 5 bf16 pairs, target[3]
 constexpr int HAND_BYTES = 128 * REC_DW * 4 + 128 * 4;        // ... + the timesteps
-constexpr int LDS_WT = IMG, LDS_FIMG = LDS_WT + WTB, LDS_HAND = LDS_FIMG + 4 * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES;
-constexpr int LDS_TOTAL = LDS_RED + 128;
-static_assert(LDS_TOTAL <= 160 * 1024 && LDS_HAND % 16 == 0, "one workgroup per CU");
+// LDS: the hand-over images FIRST -- their 150 distinct read / store addresses per round are (per-lane base) + constant, and a
+// DS instruction's offset field holds 16 bits: behind the 107 KB of weight images every one of them cost an address register
+// (60 VGPRs in the dW waves, beside 160 accumulators) -- then the hand-over records, the loss scratch, the two weight images
+constexpr int LDS_FIMG = 0, LDS_HAND = LDS_FIMG + 4 * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES, LDS_IMG = LDS_RED + 128;
+constexpr int LDS_WT = LDS_IMG + IMG, LDS_TOTAL = LDS_WT + WTB;
+static_assert(LDS_TOTAL <= 160 * 1024 && LDS_HAND % 16 == 0 && LDS_IMG % 16 == 0, "one workgroup per CU");
 
 __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -66,9 +69,6 @@ template <bool EXPLICIT>
 __device__ __forceinline__ Hand noise_sample(const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t, int64_t sc, bool live,
                                              float* __restrict__ x_t_out) {
   const int T = na.T;
-#ifdef EXP_NONOISE
-  { Hand hd; hd.xb[0] = (uint32_t)sc; hd.xb[1] = hd.xb[2] = hd.xb[3] = hd.xb[4] = 0; hd.tg[0] = hd.tg[1] = hd.tg[2] = 0.f; hd.tt = 0; return hd; }
-#endif
   auto drawn_t = [&](uint32_t w) -> int64_t { return (int64_t)(((uint64_t)w * (uint64_t)T) >> 32); };
   auto clamp_t = [&](int64_t v) -> int64_t { return v < 0 ? 0 : (v >= T ? T - 1 : v); };
   Philox4 r{0u, 0u, 0u, 0u};
@@ -121,36 +121,43 @@ __device__ __forceinline__ Hand noise_sample(const NoiseArgs& na, uint64_t rng_o
 // fifth k-step's first: feature 64 | the constant ones of rows 68, 69), dp = silu'(z) as packed f16 pairs in the same order.
 // The lookups of eight values are issued together and consumed afterwards (one LDS round trip per group).
 __device__ __forceinline__ void activate_td(const f32x16 (&acc)[3], uint32_t (&hp)[17], uint32_t (&dp)[17], int h, const char* tab) {
-#ifndef ACT_G
-#define ACT_G 8
-#endif
-  constexpr int G = ACT_G;
-#pragma unroll
-  for (int g0 = 0; g0 < 32; g0 += G) {
-    float4 e[G];
-    float u[G];
+  // Eight groups of four values + the single value of tile 2 as a two-deep software pipeline: the lookups of group g + 1 are issued in
+  // front of the arithmetic of group g, so a lone wave (nothing else on its SIMD hides an LDS round trip) pays the latency once per
+  // layer instead of once per group (five sequential groups of eight cost 1.4 k cycles per layer: phase stamps, round 4)
+  constexpr int G = 4, NG = 8;
+  float4 e[2][G];
+  float u[2][G];
+  auto lookups = [&](int g) {
 #pragma unroll
     for (int i = 0; i < G; i++) {
-      const int q = g0 + i;
-      u[i] = acc[q >> 4][q & 15];
-      const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[i], 0u, 0u);  // round to nearest, saturated to 0..255
-      e[i] = *reinterpret_cast<const float4*>(tab + idx * 16);
+      const int q = G * g + i;
+      u[g & 1][i] = acc[q >> 4][q & 15];
+      const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[g & 1][i], 0u, 0u);  // round to nearest, saturated to 0..255
+      e[g & 1][i] = *reinterpret_cast<const float4*>(tab + idx * 16);
     }
+  };
+  const float ul = acc[2][0];
+  lookups(0);
+  float4 el;
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if (g + 1 < NG) lookups(g + 1);
+    else el = *reinterpret_cast<const float4*>(tab + __builtin_amdgcn_cvt_pk_u8_f32(ul, 0u, 0u) * 16);
 #pragma unroll
     for (int i = 0; i < G; i += 2) {
-      hp[(g0 + i) >> 1] = pack_bf16x2(fmaf(e[i].y, u[i], e[i].x), fmaf(e[i + 1].y, u[i + 1], e[i + 1].x));
-      dp[(g0 + i) >> 1] = pack_f16x2(fmaf(e[i].w, u[i], e[i].z), fmaf(e[i + 1].w, u[i + 1], e[i + 1].z));
+      const float4 e0 = e[g & 1][i], e1 = e[g & 1][i + 1];
+      const float u0 = u[g & 1][i], u1 = u[g & 1][i + 1];
+      const int w = (G * g + i) >> 1;
+      hp[w] = pack_bf16x2(fmaf(e0.y, u0, e0.x), fmaf(e1.y, u1, e1.x));
+      dp[w] = pack_f16x2(fmaf(e0.w, u0, e0.z), fmaf(e1.w, u1, e1.z));
       // the packed words ARE the parked state: opaque, so that the compiler keeps them and not their two fp32 sources each
       // (it sank the packing to the backward's uses and spilled 264 fp32 values per round)
-      asm volatile("" : "+v"(hp[(g0 + i) >> 1]), "+v"(dp[(g0 + i) >> 1]));
+      asm volatile("" : "+v"(hp[w]), "+v"(dp[w]));
     }
-    __builtin_amdgcn_sched_barrier(0);  // one group's lookups (32 registers) in flight at a time
+    __builtin_amdgcn_sched_barrier(0);
   }
-  const float u = acc[2][0];
-  const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u, 0u, 0u);
-  const float4 e = *reinterpret_cast<const float4*>(tab + idx * 16);
-  hp[16] = h ? 0x3F803F80u : pack_bf16x2(fmaf(e.y, u, e.x), 0.0f);   // rows 68, 69: the constant ones (bias / table offset carriers)
-  dp[16] = h ? 0u : pack_f16x2(fmaf(e.w, u, e.z), 0.0f);
+  hp[16] = h ? 0x3F803F80u : pack_bf16x2(fmaf(el.y, ul, el.x), 0.0f);   // rows 68, 69: the constant ones (bias / table offset carriers)
+  dp[16] = h ? 0u : pack_f16x2(fmaf(el.w, ul, el.z), 0.0f);
   asm volatile("" : "+v"(hp[16]), "+v"(dp[16]));
 }
 
@@ -161,17 +168,21 @@ __device__ __forceinline__ void operand_of(const uint32_t (&hp)[17], Tile<PREC>&
   t.b[4] = __builtin_bit_cast(bf16x8, u32x4_t{hp[16], 0u, 0u, 0u});
 }
 
-#ifdef EXP_NODW
-#define TF_DW_MFMA(a, b, c) (c)
-#else
-#define TF_DW_MFMA(a, b, c) mfma_bf16(a, b, c)
-#endif
 // ---- the dW waves: k_bwd_fused's dW role (so3x_mlp_bwd.hip) + the noising of the tiles ahead -----------------------------------
 struct Geo { int64_t n, ntiles, nchain, rounds; };
+// -DTF_STAMPS (timing build, tools/ab/fused_stamps.py; results of `out` destroyed): workgroup 0's chain wave 0 and dW wave 0 leave
+// s_memtime stamps of a round's phases in the `out` buffer: stamps[role][round][32]
+#ifdef TF_STAMPS
+#define TF_STAMP(role, k) do { if (blockIdx.x == 0 && stamp_base && rd < 64) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); \
+    if (lane == 0) stamp_base[((role) * 64 + rd) * 32 + (k)] = now_; } } while (0)
+#else
+#define TF_STAMP(role, k) do { } while (0)
+#endif
+constexpr int RING = 3;  // operand ring of the dW products: stages (image, k-step) in flight, 16 registers each
 
 template <int DWI, bool EXPLICIT>
 __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t,
-                                              float* __restrict__ x_t_out, float* __restrict__ slabs, int lane) {
+                                              float* __restrict__ x_t_out, float* __restrict__ slabs, int lane, uint64_t* stamp_base = nullptr) {
   const char* fimg_all = lds + LDS_FIMG;
   uint32_t* rec = reinterpret_cast<uint32_t*>(lds + LDS_HAND) + (DWI * 32 + (lane & 31)) * REC_DW;
   int* ht = reinterpret_cast<int*>(lds + LDS_HAND + 128 * REC_DW * 4) + DWI * 32 + (lane & 31);
@@ -181,6 +192,11 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
   for (int k = 0; k < 10; k++) acc[k] = zero16<PREC>();
   // a noising pass covers the wave's tile of round `ra` (lanes 0..31) and of round ra + 1 (lanes 32..63)
   auto pass = [&](int64_t ra) -> Hand {
+    // (the lane index is made opaque here: nothing per-lane of the pass -- sample index, row and table addresses -- is computed
+    //  in front of the round loop and kept alive, or spilled, beside the 160 accumulator registers)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int col = lane_o & 31, h = lane_o >> 5;
     const int64_t r = ra + h;
     const int64_t tile = r * g.nchain + (int64_t)blockIdx.x * 4 + DWI, s = tile * 32 + col;
     const bool live = r < g.rounds && tile < g.ntiles && s < g.n;
@@ -197,36 +213,64 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
   FimgReadLane RL = fimg_read_lane(lane);
   for (int64_t rd = 0; rd < g.rounds; rd++) {
     asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
-    // odd rounds: the samples of rounds rd + 1, rd + 2 are drawn while the chain waves run their forward (the images are idle)
-    if (rd & 1) hd = pass(rd + 1);
+    if (DWI == 0) TF_STAMP(1, 0);
 #pragma unroll
     for (int l = 4; l >= 0; l--) {
       __syncthreads();  // B1: images of layer l complete
+      if (DWI == 0) TF_STAMP(1, 2 + 3 * (4 - l));
       if (l == 4) {
         // the chain waves read round rd's records before this barrier and read round rd + 1's behind the round's last one
         if (h == (int)((rd & 1) ^ 1)) hand_over(hd);
+      }
+      // The layer's products as EIGHT stages (image w, k-step ks) through a RING-slot operand ring: the transposed reads of
+      // stage s + RING - 1 are issued in front of the MFMAs of stage s.  Left to itself the compiler reused two operand registers for
+      // every MFMA -- read, s_waitcnt lgkmcnt(0), MFMA, 24 times per layer: an LDS round trip per MFMA, and this phase (not
+      // the chain waves' dH) was what every layer of the backward waited for.
+      if (l == 4) {
         if (DWI < 3) {
+          bf16x8 ra[RING], rb[RING];
+          auto load4 = [&](int st) {
+            const char* im = fimg_all + (st >> 1) * FIMG_BYTES;
+            ra[st % RING] = fimg_frag(im, RL, 0, st & 1);
+            rb[st % RING] = fimg_frag(im, RL, 96 + 32 * DWI, st & 1);
+          };
 #pragma unroll
-          for (int w = 0; w < 4; w++) {
-            const char* im = fimg_all + w * FIMG_BYTES;
+          for (int st = 0; st < RING - 1; st++) load4(st);
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) acc[9] = TF_DW_MFMA(fimg_frag(im, RL, 0, ks), fimg_frag(im, RL, 96 + 32 * DWI, ks), acc[9]);
+          for (int st = 0; st < 8; st++) {
+            if (st + RING - 1 < 8) load4(st + RING - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[9] = mfma_bf16(ra[st % RING], rb[st % RING], acc[9]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       } else if (dw_row(DWI, l) != 3) {
         const int to = dw_row(DWI, l), sl = dw_slot(DWI, l);
+        bf16x8 ra[RING], rb[RING][3];
+        auto load = [&](int st) {
+          const char* im = fimg_all + (st >> 1) * FIMG_BYTES;
+          ra[st % RING] = fimg_frag(im, RL, 32 * to, st & 1);
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-          const char* im = fimg_all + w * FIMG_BYTES;
+          for (int ti = 0; ti < 3; ti++) rb[st % RING][ti] = fimg_frag(im, RL, 96 + 32 * ti, st & 1);
+        };
 #pragma unroll
-          for (int ks = 0; ks < 2; ks++) {
-            const bf16x8 a = fimg_frag(im, RL, 32 * to, ks);
+        for (int st = 0; st < RING - 1; st++) load(st);
 #pragma unroll
-            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = TF_DW_MFMA(a, fimg_frag(im, RL, 96 + 32 * ti, ks), acc[3 * sl + ti]);
-          }
+        for (int st = 0; st < 8; st++) {
+          if (st + RING - 1 < 8) load(st + RING - 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(ra[st % RING], rb[st % RING][ti], acc[3 * sl + ti]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (DWI == 0) TF_STAMP(1, 3 + 3 * (4 - l));
+      // behind an even round's last products: the samples of rounds rd + 2, rd + 3 are drawn while the chain waves run the NEXT
+      // round's forward (which they start behind this layer's first barrier; the images are idle until their second)
+      if (l == 0 && !(rd & 1)) hd = pass(rd + 2);
+      if (DWI == 0 && l == 0) TF_STAMP(1, 1);
       __syncthreads();  // B2: done with the images
+      if (DWI == 0) TF_STAMP(1, 4 + 3 * (4 - l));
     }
   }
   // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
@@ -262,9 +306,10 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
               const uint4* __restrict__ h0_tab, NoiseArgs na, float* __restrict__ x_t_out, float* __restrict__ out,
               float* __restrict__ slabs, int64_t n, LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* img_lds = lds + LDS_IMG;
   char* wt_lds = lds + LDS_WT;
   char* fimg_all = lds + LDS_FIMG;
-  load_image(gimg, lds, IMG);
+  load_image(gimg, img_lds, IMG);
   load_image(gwt, wt_lds, WTB);
   for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
@@ -276,15 +321,39 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
   uint64_t rng_offset = na.rng_offset;
   if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];  // device-resident part of the counter (hipGraph replays)
   __syncthreads();  // S0: images, tables
+#ifdef TF_STAMPS
+  uint64_t* stamp_base = reinterpret_cast<uint64_t*>(out);
+  out = nullptr;
+#endif
   float sq = 0.0f;
   if (wid < 4) {
     // =============================== chain waves ===============================
     char* my_img = fimg_all + wid * FIMG_BYTES;
-    const char* tab = lds + (size_t)n_frags<PREC, VAR>() * FB;
+    const char* tab = img_lds + (size_t)n_frags<PREC, VAR>() * FB;
     const uint32_t* rec = reinterpret_cast<const uint32_t*>(lds + LDS_HAND) + (wid * 32 + col) * REC_DW;
     const int* ht = reinterpret_cast<const int*>(lds + LDS_HAND + 128 * REC_DW * 4) + wid * 32 + col;
     FimgStoreLane SL = fimg_store_lane(col);
     __syncthreads();  // P
+    // A round's inputs: the samples the dW waves handed over (x_t as bf16 pairs, target, timestep) and the timestep's effective-bias
+    // row (nine 16-byte gathers from L2, per lane).  They are fetched a round AHEAD -- behind the round's last first barrier, while
+    // the dW waves take the layer-0 products -- so the row's L2 round trip (2.5 k cycles at the top of every round when it was
+    // fetched there) and the last barrier's wait (1.1 k) lie under the dW waves' work, and the forward starts on registers.
+    uint32_t xb[5];
+    float tg[3];
+    int tt;
+    float4 bq[9];
+    auto load_top = [&]() {
+      // (uint4, a struct of four words, on purpose: this hipcc miscompiles __builtin_bit_cast of the ELEMENTS of an ext-vector
+      //  load -- every element came back as element 0; so3x_mlp_bwd.hip's zstash_load_layer met the same bug)
+      const uint4 r0 = *reinterpret_cast<const uint4*>(rec), r1 = *reinterpret_cast<const uint4*>(rec + 4);
+      tt = *ht;
+      xb[0] = r0.x; xb[1] = r0.y; xb[2] = r0.z; xb[3] = r0.w; xb[4] = r1.x;
+      tg[0] = __uint_as_float(r1.y); tg[1] = __uint_as_float(r1.z); tg[2] = __uint_as_float(r1.w);
+      const float* beff = beff_tab + (size_t)tt * 96;
+#pragma unroll
+      for (int q = 0; q < 9; q++) bq[q] = *reinterpret_cast<const float4*>(beff + 8 * q + 4 * h);  // rows 8 q + 4 h ..: tiles 0, 1 and (q = 8) 2
+    };
+    load_top();
     for (int64_t rd = 0; rd < g.rounds; rd++) {
       asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per round: no hoisting of the ~90 store addresses
       // ... and none of the 101 weight-fragment reads: the images are loop-invariant, and hoisted out of the round loop they
@@ -294,19 +363,12 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
       const int64_t tile = rd * g.nchain + (int64_t)blockIdx.x * 4 + wid;
       const int64_t s = tile * 32 + col;
       const bool live = tile < g.ntiles && s < n;
-      // ---- this round's samples from the dW waves: x_t as bf16 pairs, target, timestep
+      if (wid == 0) TF_STAMP(0, 0);
       typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-      // (uint4, a struct of four words, on purpose: this hipcc miscompiles __builtin_bit_cast of the ELEMENTS of an ext-vector
-      //  load -- every element came back as element 0; so3x_mlp_bwd.hip's zstash_load_layer met the same bug)
-      const uint4 r0 = *reinterpret_cast<const uint4*>(rec), r1 = *reinterpret_cast<const uint4*>(rec + 4);
-      const int tt = *ht;
-      const uint32_t xb[5] = {r0.x, r0.y, r0.z, r0.w, r1.x};
-      const float tg[3] = {__uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
       // ---- forward: layer 0 from the per-timestep effective-bias row (K = 9: the rotation entries), then the hidden layers
       uint32_t hpk[4][17], dpk[4][17];
       f32x16 acc[3];
       {
-        const float* beff = beff_tab + (size_t)tt * 96;
 #pragma unroll
         for (int to = 0; to < 3; to++) {
           f32x16 a;
@@ -316,37 +378,33 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
 #pragma unroll
               for (int r = 0; r < 4; r++) a[4 * q + r] = 0.0f;
             } else {
-              const float4 v = *reinterpret_cast<const float4*>(beff + 32 * to + 8 * q + 4 * h);
+              const float4 v = bq[4 * to + q];
               a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
             }
           }
           acc[to] = a;
         }
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, u32x4_t{h ? (xb[4] & 0xFFFFu) : xb[0], h ? 0u : xb[1], h ? 0u : xb[2], h ? 0u : xb[3]});
-        const bf16x8* w = reinterpret_cast<const bf16x8*>(lds);
+        const bf16x8* w = reinterpret_cast<const bf16x8*>(img_lds);
 #pragma unroll
         for (int to = 0; to < 3; to++) acc[to] = mfma_bf16(w[to * 64 + lane_r], b0, acc[to]);
       }
+      if (wid == 0) TF_STAMP(0, 1);
       activate_td(acc, hpk[0], dpk[0], h, tab);
-#ifdef EXP_NOFWD
-#pragma unroll
-      for (int l = 1; l < 4; l++)
-#pragma unroll
-        for (int r = 0; r < 17; r++) { hpk[l][r] = hpk[0][r] + l; dpk[l][r] = dpk[0][r] + l; }
-#else
+      if (wid == 0) TF_STAMP(0, 2);
 #pragma unroll
       for (int l = 1; l < 4; l++) {
         Tile<PREC> cur;
         operand_of(hpk[l - 1], cur);
-        hidden_layer<PREC, 3>(lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane_r);
+        hidden_layer<PREC, 3>(img_lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane_r);
         activate_td(acc, hpk[l], dpk[l], h, tab);
       }
-#endif
+      if (wid == 0) TF_STAMP(0, 3);
       f32x16 last[1];
       {
         Tile<PREC> cur;
         operand_of(hpk[3], cur);
-        hidden_layer<PREC, 1>(lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane_r);
+        hidden_layer<PREC, 1>(img_lds + (size_t)frag_last<PREC, VAR>() * FB, cur, last, lane_r);
       }
       // ---- MSE and its gradient (diffusion.py:357): head outputs 0..2 = regs 0..2 of the lower half (head_of_row)
       uint32_t pdz[17];
@@ -362,12 +420,13 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
         pdz[0] = pack_bf16x2(d0 * sc, d1 * sc);
         pdz[1] = pack_bf16x2(d2 * sc, 0.0f);
       }
-      // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them), fetched now, stored five layers later
+      // the previous round's LAST barrier, deferred to here: this round's forward ran beside the dW waves' layer-0 products of the
+      // previous one (it touches no image); the first image store below is what has to wait for them
+      if (rd > 0) __syncthreads();  // B2 of layer 0, round rd - 1
       uint4 hq[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) hq[i] = h0_tab[(size_t)tt * 12 + 6 * h + i];
       // ---- backward:   [write images of layer l] B1 [dH_l, dZ_{l-1}] B2
       f32x16 dh[3];
+      if (wid == 0) TF_STAMP(0, 4);
 #pragma unroll
       for (int l = 4; l >= 0; l--) {
 #pragma unroll
@@ -394,19 +453,14 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
             fimg_store_pk(my_img, SL, ch0, live ? lo : 0u, live ? hi : 0u);
           }
         }
+        if (wid == 0) TF_STAMP(0, 5 + 4 * (4 - l));
         __syncthreads();  // B1: images of layer l complete -- the dW waves consume them while this wave goes on
+        if (wid == 0) TF_STAMP(0, 6 + 4 * (4 - l));
         if (l > 0) {
-#ifdef EXP_NODH
-#pragma unroll
-          for (int q = 0; q < 3; q++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) dh[q][r] = __uint_as_float(pdz[r]);
-#else
           if (l == 4) dh_layer_pk<PREC, 4>(wt_lds, pdz, dh, lane_r);
           if (l == 3) dh_layer_pk<PREC, 3>(wt_lds, pdz, dh, lane_r);
           if (l == 2) dh_layer_pk<PREC, 2>(wt_lds, pdz, dh, lane_r);
           if (l == 1) dh_layer_pk<PREC, 1>(wt_lds, pdz, dh, lane_r);
-#endif
           const uint32_t (&dp)[17] = dpk[l - 1];  // silu'(Z_{l-1}), parked by the forward
 #pragma unroll
           for (int r = 0; r < 16; r++) {
@@ -415,10 +469,21 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
             pdz[r] = pack_bf16x2(g0, g1);
           }
           pdz[16] = pack_bf16x2(h ? 0.0f : dh[2][0] * f16_lo(dp[16]), 0.0f);  // upper half of tile 2 / reg 0 = the constant-one row
+          // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them): six 16-byte gathers, two layers
+          // ahead of their store
+          if (l == 3) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) hq[i] = h0_tab[(size_t)tt * 12 + 6 * h + i];
+          }
+        } else {
+          load_top();  // the next round's samples and bias row (the dW waves wrote the records behind this round's first barrier)
         }
-        __syncthreads();  // B2: the dW waves are done with the images
+        if (wid == 0) TF_STAMP(0, 7 + 4 * (4 - l));
+        if (l > 0) __syncthreads();  // B2: the dW waves are done with the images (layer 0's: at the top of the next round's backward)
+        if (wid == 0) TF_STAMP(0, 8 + 4 * (4 - l));
       }
     }
+    __syncthreads();  // B2 of layer 0 of the last round
   } else {
     // ================================ dW waves =================================
     // distributions.py:42-43: column 0 == sample 0's eps.  With drawn timesteps that is GLOBAL sample 0's draw (Philox index 0,
@@ -430,7 +495,12 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
       else wrow_t = (int64_t)(((uint64_t)philox4x32_10(na.seed, (uint64_t)0, rng_offset).w * (uint64_t)T) >> 32);
     }
     switch (wid - 4) {
-      case 0: dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+      case 0:
+#ifdef TF_STAMPS
+        dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, stamp_base); break;
+#else
+        dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+#endif
       case 1: dw_role_fused<1, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
       case 2: dw_role_fused<2, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
       default: dw_role_fused<3, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;

@@ -401,6 +401,26 @@ def omp_threads():
     return int(lib().so3o_omp_threads())
 
 
+FAST_FLAGS = "-O3 -march=native -fopenmp (contraction allowed)"
+_fast = None
+
+
+def p_sample_step_timed(params, sched, trap_p, x, t, axes, unif, out):
+    """so3o_p_sample_step_f32 of the TIMED build (libso3_oracle_fast.so: the same source compiled FAST_FLAGS ON THIS HOST -- the
+    GPU box's cores differ from the build container's, so it is (re)built where it runs) on preallocated, contiguous fp32
+    arrays: nothing but the C call inside the caller's timed region.  bench.py's cpu_baseline leg only; never a checker."""
+    global _fast
+    if _fast is None:
+        path = os.path.join(_HERE, "libso3_oracle_fast.so")
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libso3_oracle_fast.so"])
+        _fast = C.CDLL(path)
+    T = sched.shape[1]
+    k, _ = knots()
+    fr = posemb_freqs()
+    _fast.so3o_p_sample_step_f32(_p(params), _p(fr), _p(sched), C.c_int(T), _p(trap_p), _p(k), _p(x), C.c_int(int(t)), _p(axes), _p(unif),
+                                 _p(out), C.c_long(x.shape[0]))
+
+
 def flat_params(state):
     """state: mapping with net_{0,2,4,6,8}_{weight,bias} (tests/golden/score_mlp.npz naming)."""
     parts = []

@@ -401,9 +401,22 @@ def test_p_sample_step_vs_golden_G2(mods, golden, net, tval):
     x0h, mean = mods["B"].p_mean(proc._sched, x, dev(g[pre + "v"]), tval, want_x0hat=True)
     err = frob_err(host(mean), g[pre + "mean_64f"])
     ref_err = frob_err(g[pre + "mean"], g[pre + "mean_64f"])
-    # G2: not worse than the reference's own fp32-vs-fp64 error (both are rounding noise amplified by the
-    # same conditioning, up to 2e4 at t = 999, so the comparison is on the batch statistics, not per sample)
-    assert err.max() <= max(1e-5, 2 * ref_err.max()), (err.max(), ref_err.max())
+    # G2, PER SAMPLE: err_i <= max(1e-5, 2 ref_err_i), the reference's own fp32-vs-fp64 error on that sample.  Both are
+    # rounding noise amplified by the same conditioning (up to 2e4 at t = 999), but they are INDEPENDENT draws of it, so a sample
+    # on which the reference happened to round luckily may exceed its own limit: the survey's outlier budget bounds how many
+    # (<= 2 % for t <= 998, 40 % at t = 999, measured on the reference's own fp32 path), and NO sample may exceed what its
+    # conditioning allows (conftest.reverse_step_bound with an exact network: the derived per-sample tolerance of the chain
+    # tests) -- one badly conditioned reference sample no longer licenses every device sample.
+    from conftest import reverse_step_bound
+    lim = np.maximum(1e-5, 2 * ref_err)
+    over = err > lim
+    assert over.mean() <= (0.45 if tval == 999 else 0.03), (tval, over.mean())
+    sch = host(proc._sched)
+    coef = tuple(float(sch[i][tval]) for i in (6, 7, 10, 11))
+    om_x = O.rmat_to_aa(g["x"], "f64")[1][:, 0]
+    om_h = O.rmat_to_aa(g[pre + "x0hat_64f"], "f64")[1][:, 0]
+    bound = reverse_step_bound(coef, om_x, om_h, dv=0.0)
+    assert (err <= np.maximum(lim, bound)).all(), (tval, float((err / np.maximum(lim, bound)).max()))
     assert np.median(err) <= max(2e-6, 2 * np.median(ref_err))
     # fused step (MLP + mean + noise) with explicit draws, fp32 network
     t = torch.full((n,), tval, device=DEV, dtype=torch.long)

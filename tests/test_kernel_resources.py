@@ -20,7 +20,7 @@ KNOWN = {
     "k_bwd_fused<1, false>": (512, "backward that recomputes the forward: kept for callers without a stash, not what training runs"),
     "k_bwd_stage<1, 1>": (64, "generic staged backward, bf16 with unbounded timesteps: parity / fallback path"),
 }
-HOT = ("k_p_sample_chain", "k_resnet_chain", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_fused<1, true>", "k_mlp_fwd_stash",
+HOT = ("k_p_sample_chain", "k_train_fused", "k_resnet_chain", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_fused<1, true>", "k_mlp_fwd_stash",
        "k_mlp_fwd", "k_q_sample_target", "k_logprob_score", "k_igso3_sample", "k_bwd_reduce", "k_adam", "k_prep")
 
 

@@ -590,3 +590,26 @@ def test_in_graph_or_split_is_decided_by_all_ranks_together(tmp_path, inject):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """the driver's 8-GPU command has only ever seen world sizes 1 and 2.  `python3 bench.py --gpus 8` as the
+    plain command (bench.py starts its eight ranks itself, all on this box's one GPU, collectives over gloo): rendezvous on a
+    free port, barriers, max-over-ranks timing, the training leg's one-kernel step with its 8-way gradient all-reduce, ONE
+    well-formed line from rank 0, exit code 0 -- inside five minutes.  The throughput is meaningless; the plumbing is the point."""
+    import json
+    from conftest import ROOT
+    env = dict(os.environ, SO3X_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch-log2", "15", "--steps", "100", "--warmup", "20",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["backend"] == "gloo" and len(line["devices"]) == 8
+    assert line["finite"] and line["value"] > 0 and line["scaling"] == "weak"
+    tr = line["train_step"]
+    assert "error" not in tr, tr
+    assert tr["ranks"] == 8 and tr["global_batch"] == 8 * tr["batch_per_gpu"] and tr["finite"] and tr["one_kernel"]
+    assert tr["allreduce_us"] > 0 and tr["mode"].startswith("captured hipGraphs with the eager all-reduce")

@@ -43,7 +43,8 @@ def loop_mix(src, pattern, extra=(), depth=0):
             cnt[l.split()[0]] += 1
     groups = collections.Counter()
     for op, c in cnt.items():
-        g = ("mfma" if op.startswith("v_mfma") else "trans" if op in TRANS else "valu" if op.startswith("v_") else
+        base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+        g = ("mfma" if op.startswith("v_mfma") else "trans" if base in TRANS else "valu" if op.startswith("v_") else
              "salu" if op.startswith("s_") else "lds" if op.startswith("ds_") else
              "vmem" if op.startswith(("global_", "buffer_", "flat_", "scratch_")) else "other")
         groups[g] += c

@@ -7,6 +7,9 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/profile_$tag
 mkdir -p $out
 cd $R
+# what the counters below belong to: the digest of the kernel sources AS THEY ARE ON THIS BOX (bench.py quotes PMC fields only
+# while profiles/pmc_traffic.json's digest matches the sources it runs with)
+python3 tools/csrc_digest.py > $out/csrc_sha256.txt
 python3 bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
 tail -1 $out/bench_stdout.txt > $out/bench_line.json
 cd /tmp; export TMPDIR=/tmp

@@ -30,7 +30,7 @@ if trace:
                "ms_100_step_launches_median": statistics.median(short), "ms_100_step_launches_mean": sum(short) / len(short),
                "n_100_step_launches": len(short)}, open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
 
-KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_se3_q_sample_target",
+KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_se3_q_sample_target",
            "k_q_sample_target", "k_rigid_move", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_reduce", "k_adam", "k_prep")
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
 legs = {}  # counter -> the k_logprob_score dispatches at 2^20 evaluations in dispatch order, split into bench.py's three legs
@@ -109,7 +109,7 @@ if lg:
         if f_ is not None and w_ is not None:
             traffic["k_logprob_score:" + leg] = {"config": {"n": 1 << 20, "eps_input": leg}, "algorithmic_bytes_per_launch": nbytes << 20,
                                                  "fetch_size_kb": f_, "write_size_kb": w_, "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
-for k, cfg, alg in (("k_rigid_move", {"structures": 4096, "residues": 256}, 96 * 4096 * 256), ("k_se3_q_sample_target", {"n": 1 << 20}, 128 << 20),
+for k, cfg, alg in (("k_train_fused", {"n": 1 << 19}, 36 * (1 << 19) + 256 * 17556 * 4), ("k_rigid_move", {"structures": 4096, "residues": 256}, 96 * 4096 * 256), ("k_se3_q_sample_target", {"n": 1 << 20}, 128 << 20),
                     ("k_q_sample_target", {"n": 1 << 19}, 92 << 19), ("k_mlp_fwd_stash", {"n": 1 << 19}, None), ("k_bwd_fused", {"n": 1 << 19}, None)):
     f_, w_ = mean("FETCH_SIZE", k), mean("WRITE_SIZE", k)
     if f_ is not None and w_ is not None:
@@ -119,7 +119,7 @@ for k, cfg, alg in (("k_rigid_move", {"structures": 4096, "residues": 256}, 96 *
 # executing (= MFMAs x 32 for v_mfma_f32_32x32x16_bf16, checked against SQ_INSTS_VALU_MFMA_MOPS_BF16); SQ_BUSY_CYCLES is
 # the kernel's duration in shader cycles counted once per shader engine (32 on this chip: 8 XCDs x 4).
 util = {}
-for k in ("k_p_sample_chain", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash", "k_q_sample_target"):
+for k in ("k_p_sample_chain", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_q_sample_target"):
     busy, sqb = mean("SQ_VALU_MFMA_BUSY_CYCLES", k), mean("SQ_BUSY_CYCLES", k)
     if busy and sqb:
         util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sqb, "simds": 1024, "shader_engines": 32,
@@ -128,7 +128,33 @@ for k in ("k_p_sample_chain", "k_resnet_chain", "k_bwd_fused", "k_mlp_fwd_stash"
                    "valu_busy_frac": (4.0 * mean("SQ_ACTIVE_INST_VALU", k) / (1024.0 * sqb / 32.0)) if mean("SQ_ACTIVE_INST_VALU", k) else None,
                    "SQ_ACTIVE_INST_VALU": mean("SQ_ACTIVE_INST_VALU", k), "SQ_INSTS_VALU": mean("SQ_INSTS_VALU", k),
                    "SQ_WAIT_ANY": mean("SQ_WAIT_ANY", k), "SQ_WAVE_CYCLES": mean("SQ_WAVE_CYCLES", k),
+                   "SQ_INSTS_VALU_MFMA_MOPS_BF16": mean("SQ_INSTS_VALU_MFMA_MOPS_BF16", k),
+                   "SQ_INSTS_LDS": mean("SQ_INSTS_LDS", k), "SQ_LDS_BANK_CONFLICT": mean("SQ_LDS_BANK_CONFLICT", k),
+                   "SQ_LDS_IDX_ACTIVE": mean("SQ_LDS_IDX_ACTIVE", k),
                    "note": "fraction of SIMD-cycles the matrix pipe is executing, at the clock the chip actually holds under this load"}
 traffic["mfma_utilisation"] = util
+# provenance: which sources the counters were taken on (digest recorded on the GPU box by tools/profile_round.sh) and where the
+# summary was made; bench.py withholds every PMC-derived field once the kernel sources no longer match
+import subprocess
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_digest import digest
+try:
+    prof_digest = open(os.path.join(src, "csrc_sha256.txt")).read().strip()
+except OSError:
+    prof_digest = None
+git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+traffic["_meta"] = {"tag": tag, "csrc_sha256": prof_digest, "csrc_sha256_at_summary": digest(ROOT), "git": git,
+                    "note": "csrc_sha256 = tools/csrc_digest.py on the GPU box at profile time; bench.py quotes PMC fields only while it matches"}
+# instruction mix of the chain kernel's step loop, from the same sources (no GPU needed): what bench.py's vector-port accounting
+# takes its MFMA / transcendental counts from
+try:
+    from count_isa import loop_mix
+    cnt, groups = loop_mix("so3x_diffusion.hip", "k_p_sample_chainILi1E", depth=1)
+    json.dump({"what": "instruction mix of k_p_sample_chain<bf16>'s per-step loop (tools/count_isa.py, LOOP_DEPTH=1) on the sources of "
+                       "csrc_sha256_at_summary", "csrc_sha256": digest(ROOT), "per_64_sample_wave_step": dict(groups),
+               "mfma_per_wave_step": groups.get("mfma"), "trans_per_wave_step": groups.get("trans"), "top": dict(cnt.most_common(40))},
+              open(os.path.join(dst, f"{tag}_chain_isa_mix.json"), "w"), indent=1)
+except Exception as e:  # noqa: BLE001
+    print("isa mix failed:", e)
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:3000])
