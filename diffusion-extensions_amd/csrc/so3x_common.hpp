@@ -208,15 +208,12 @@ __device__ __forceinline__ void wave_dma9(const float* __restrict__ g, int64_t b
   char* dst = reinterpret_cast<char*>(wlds);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's earlier reads of the buffer are done before new data may land
   __builtin_amdgcn_wave_barrier();
-#ifndef SO3X_DMA9_AUX   /* A/B: cache policy bits of the tile's LDS-DMA (2 = non-temporal) */
-#define SO3X_DMA9_AUX 0
-#endif
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, SO3X_DMA9_AUX);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
-                                   (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, SO3X_DMA9_AUX);
+                                   (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
   if (lane < 16)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2048),
-                                     (__attribute__((address_space(3))) void*)(dst + 2048), 16, 0, SO3X_DMA9_AUX);
+                                     (__attribute__((address_space(3))) void*)(dst + 2048), 16, 0, 0);
 }
 __device__ __forceinline__ void wave_dma9_commit(const float* wlds, float* r) {
   const int lane = threadIdx.x & 63;

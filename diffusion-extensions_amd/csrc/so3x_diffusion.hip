@@ -13,35 +13,14 @@
 using namespace so3x;
 using namespace so3x::mlp;
 
-#ifndef SO3X_ABLATE
-#define SO3X_ABLATE 0
-#endif
-// SO3X_DMA_LATE=1 (A/B: measured 4 % SLOWER): the record's DMA issued behind layer 0's MFMAs (forward_pair_bf16) instead of at the
-// top of the step.  SO3X_DMA_ASM=1: the five LDS-DMA instructions written as inline assembly, so that the compiler's wait-count
-// pass does not see an LDS writer in flight and put `s_waitcnt vmcnt(0)` in front of the next LDS read (the weight fragments of
-// layer 0: an exposed L2 round trip at the top of every step); the kernel's own `s_waitcnt vmcnt(0)` in front of the reverse
-// step is what orders the record's arrival against its reads, as before.
-#ifndef SO3X_DMA_LATE
-#define SO3X_DMA_LATE 0
-#endif
-#ifndef SO3X_DMA_ASM
-#define SO3X_DMA_ASM 1
-#endif
-// 1: the next step's layer-0 fragments are loaded into the registers the current step's layer 0 has just read (so3x_mlp.hpp,
-// forward_pair_bf16), 0: into a second set at the top of the step and moved over behind the network (round 2)
-#ifndef SO3X_L0_RELOAD
-#define SO3X_L0_RELOAD 1
-#endif
-// -DSO3X_STAMPS=1: timing build (tools/ab): wave 0 of workgroup 0 accumulates s_memtime intervals of a step's phases and writes
-// them over the first bytes of x_out (the results of samples 0, 1 are destroyed)
-#ifndef SO3X_STAMPS
-#define SO3X_STAMPS 0
-#endif
-#if SO3X_STAMPS
-#define SO3X_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_last; stamp_last = now_; } while (0)
-#else
-#define SO3X_STAMP(k) do { } while (0)
-#endif
+// (Round 4: the forms this file carried behind macros -- the record's DMA issued late, the builtin instead of the inline-assembly
+//  LDS-DMA, a second register set for the next step's layer-0 fragments, a per-SIMD stage token, phase stamps, ablations -- were
+//  measured in rounds 2 and 3 (profiles/r02_ab_chain_*.json, r03_ab_chain_*.json), lost or served their purpose, and are gone
+//  from the tree; what is here is the shipped kernel.  The environment-switched forms of the A/B library stay: SO3X_AB_BUILD.)
+// The step's five LDS-DMA instructions are inline assembly, so that the compiler's wait-count pass does not see an LDS writer in
+// flight and put `s_waitcnt vmcnt(0)` in front of the next LDS read (the weight fragments of layer 0: an exposed L2 round trip at
+// the top of every step); the kernel's own `s_waitcnt vmcnt(0)` in front of the reverse step orders the record's arrival
+// against its reads.  The next step's layer-0 fragments are loaded into the registers the current step's layer 0 has just read.
 namespace {
 
 // ---------------------------------------------------------------------------------------
@@ -118,11 +97,7 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
         unit_axis(r.x, r.y, ax);
         u = u01(r.z);
       }
-#ifdef SO3X_QS_SAME_ROW  /* timing experiment only (tools/ab): every lane searches row 500 -- what do the per-sample rows cost? */
-      const int64_t tq = 500;
-#else
       const int64_t tq = tt;
-#endif
       const float* row = trap_q + tq * 999;
       const float* wrow = wrow_t >= 0 ? trap_q + wrow_t * 999 : row;
       const float ang = igso3_angle_global(row, wrow, SO3X_KNOTS_DATA, u, guide_q ? guide_q + tq * kGuidePitch : nullptr);
@@ -137,10 +112,7 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
     w[0] *= k; w[1] *= k; w[2] *= k;
     exp3(w, xs);                      // so3_scale(x_start, sqrt(abar_t)), diffusion.py:344-345
     mul33(xs, nz, xt);                // x_blend @ noise, :346
-#ifndef SO3X_QS_NT   /* A/B: non-temporal stores of the lean kernel's outputs (do the streams push the CDF tables out of the L2?) */
-#define SO3X_QS_NT 0
-#endif
-    if (x_t) wave_store_rows<9, LEAN && SO3X_QS_NT>(x_t, base, cnt, wl, xt);
+    if (x_t) wave_store_rows<9>(x_t, base, cnt, wl, xt);
     if (target) {
       float lw[3];
       // skew2vec(log_rmat(noise)) * (1/eps), :355.  LEAN (the noise was built here from a unit axis and an angle in [0, pi]):
@@ -150,7 +122,7 @@ k_q_sample_target(const float* __restrict__ sched, int T, const float* __restric
       else log3(nz, lw);
       const float ie = 1.0f / sched[S_SQRT_1MAC * T + tt];
       float tg[3] = {lw[0] * ie, lw[1] * ie, lw[2] * ie};
-      wave_store_rows<3, LEAN && SO3X_QS_NT>(target, base, cnt, wl, tg);
+      wave_store_rows<3>(target, base, cnt, wl, tg);
     }
     if (noise_out) wave_store_rows<9>(noise_out, base, cnt, wl, nz);
   }
@@ -253,15 +225,6 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
   const bool staged = WIDE && cdf_rec != nullptr && axes == nullptr;
   if (staged)
     for (int i = threadIdx.x; i < 1000; i += blockDim.x) reinterpret_cast<float*>(knots_lds)[i] = SO3X_KNOTS_DATA[i];
-#if SO3X_STAGE_TOKEN
-  // one token per SIMD behind the 4,000 bytes of knots; a wave finds its SIMD in HW_REG_HW_ID (id 4), bits 5:4
-  unsigned* stage_token = nullptr;
-  if constexpr (WIDE) {
-    unsigned* toks = reinterpret_cast<unsigned*>(knots_lds + 4000);
-    if (threadIdx.x < 4) toks[threadIdx.x] = 0u;
-    stage_token = toks + (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3);
-  }
-#endif
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const uint32_t lt = wide_tab_lane(lane);
@@ -286,22 +249,14 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
     if constexpr (PAIR) {
 #pragma unroll
       for (int k = 0; k < 3; k++) w0[k] = l0t_tab[(size_t)t_start * 192 + 64 * k + lane];
-#if SO3X_DMA_ASM
       // once per chunk: the step loop is entered with nothing the compiler tracks in flight (see below).  A use of the loaded
       // registers, not a wait instruction: the wait-count pass drops an explicit wait it deems early and re-inserts it at the use
       asm volatile("" :: "v"(w0[0]), "v"(w0[1]), "v"(w0[2]));
-#endif
     }
-#if SO3X_STAMPS
-    uint64_t stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll 1
     for (int s = 0; s < n_steps; s++) {
       const int t = t_start - s;
       // ---- score network: v = RotPredict(x, t)  (diffusion.py:309)
-#if defined(SO3X_PRIO_TOP)
-      if constexpr (PAIR) __builtin_amdgcn_s_setprio(SO3X_PRIO_TOP);
-#endif
       if (s > 0) rmat_from_quat(q, R);
       const float* beff = beff_tab + (size_t)t * 96;
       float va[3], vb[3], v[3];
@@ -309,15 +264,10 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       if constexpr (PREC == SO3X_PREC_BF16) {  // layer 0 from this timestep's fragments (bias in the K dimension)
         const bf16x8* l0t = l0t_tab + (size_t)t * 192;
         if constexpr (PAIR) {
-#if SO3X_ABLATE == 2  /* timing experiment only (tools/ab): no network */
-          va[0] = vb[0] = R[1]; va[1] = vb[1] = R[2]; va[2] = vb[2] = R[5];
-#else
           // the step's schedule scalars: scalar loads issued here, a network away from their use
           coef = StepCoef{sched[S_RECIP * T + t], sched[S_RECIPM1 * T + t], sched[S_COEF1 * T + t], sched[S_COEF2 * T + t]};
-          const char* dma_src = (staged && SO3X_DMA_LATE && SO3X_L0_RELOAD && !SO3X_STAMPS && !SO3X_STAGE_TOKEN) ? cdf_rec + (size_t)t * kCdfRec + lane * 16 : nullptr;
-          if (staged && !dma_src) {  // this step's CDF record -> LDS (five 1-KB / 512-B DMAs); it lands while the network runs
+          if (staged) {  // this step's CDF record -> LDS (five 1-KB / 512-B DMAs); it lands while the network runs
             const char* src = cdf_rec + (size_t)t * kCdfRec + lane * 16;
-#if SO3X_DMA_ASM
             {
               typedef __attribute__((address_space(3))) char* lds_cp;
               const uint32_t dst = (uint32_t)(uintptr_t)(lds_cp)rowbuf;  // wave-uniform LDS byte address of this wave's record buffer
@@ -332,38 +282,9 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
                 asm volatile("s_add_u32 m0, %1, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                              :: "v"(src + 4096), "s"(dst) : "memory", "m0", "scc");
             }
-#else
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                               (__attribute__((address_space(3))) void*)(rowbuf + i * 1024), 16, 0, 0);
-            if (lane < 32)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096),
-                                               (__attribute__((address_space(3))) void*)(rowbuf + 4096), 16, 0, 0);
-#endif
           }
           const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
-#if !SO3X_L0_RELOAD
-          bf16x8 wn[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++) wn[k] = l0n[64 * k + lane];
-#endif
-          SO3X_STAMP(0);  // step top: rmat, scalar loads, DMA issue, prefetch
-#if SO3X_STAMPS
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, stamp_acc, &stamp_last, nullptr, SO3X_L0_RELOAD ? l0n : nullptr);
-#elif SO3X_STAGE_TOKEN
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, stage_token, SO3X_L0_RELOAD ? l0n : nullptr);
-#elif SO3X_L0_RELOAD
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, nullptr, nullptr, nullptr, l0n, dma_src, rowbuf);  // (reloads w0 for the next step, issues the record's DMA)
-#else
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt);  // both tiles as one software-pipelined stream (so3x_mlp.hpp)
-#endif
-          SO3X_STAMP(1);  // the two head stages
-#if !SO3X_L0_RELOAD
-#pragma unroll
-          for (int k = 0; k < 3; k++) w0[k] = wn[k];
-#endif
-#endif
+          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, l0n);  // both tiles as one software-pipelined stream; reloads w0 for the next step
         } else {
           forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);
           forward_tile<PREC, CHAIN, 2, true>(lds, R, nullptr, 0, nullptr, vb, lane, l0t);
@@ -374,36 +295,21 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {  // tile B results sit in lanes 0..31, their owners are lanes 32..63
-#if SO3X_L0_SWAP
         if constexpr (PAIR) {  // one v_permlane32_swap: [va of the lower half | vb of the lower half] (no LDS exchange, no select)
           v[j] = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, va[j]), __builtin_bit_cast(uint32_t, vb[j]), false, false)[0]);
           continue;
         }
-#endif
         const float o = __shfl_xor(vb[j], 32);
         v[j] = h ? o : va[j];
       }
       // ---- posterior mean + noise (diffusion.py:291-326), so3x_reverse_step.hpp
-#if SO3X_ABLATE == 1  /* timing experiment only (tools/ab): no reverse step */
-      q.w += v[0] * 1e-9f; q.x += v[1] * 1e-9f; q.y += v[2] * 1e-9f;
-#else
-      SO3X_STAMP(2);  // output exchange
-#if defined(SO3X_PRIO_REVERSE)
-      if constexpr (PAIR) __builtin_amdgcn_s_setprio(SO3X_PRIO_REVERSE);
-#endif
-#if SO3X_DMA_ASM
       // the record has landed (and is visible to this wave's LDS reads).  As the BUILTIN, which the compiler's wait-count pass
       // reads, and on EVERY path to the loop's back edge: it then knows that nothing it tracks -- the next step's layer-0
       // fragments, requested behind this step's layer 0 -- is still in flight, and puts no wait in front of the next step's first
       // MFMAs, where one would also cover the record DMA issued just before them (0x0F70 = vmcnt(0) alone)
       __builtin_amdgcn_s_waitcnt(0x0F70);
       asm volatile("" ::: "memory");
-#endif
       if (staged) {
-#if SO3X_DMA_ASM
-#else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (and is visible to this wave's LDS reads)
-#endif
         q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx),
                                reinterpret_cast<const float*>(rowbuf),
                                guide_p ? reinterpret_cast<const uint16_t*>(rowbuf + kCdfGuideOff) : nullptr,
@@ -411,17 +317,9 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
       } else {
         q = reverse_step<FAST>(q, v, sched, T, t, trap_p, guide_p, axes, unif, idc, seed, rng_offset, (uint64_t)(index_base + idx));
       }
-#endif
-      SO3X_STAMP(3);  // the reverse step
     }
     rmat_from_quat(qnormalize(q), R);
     if (live) store_rot9(x_out, idx, R);
-#if SO3X_STAMPS
-    if (chunk == 0 && lane == 0) {
-      uint64_t* o = reinterpret_cast<uint64_t*>(x_out);
-      for (int k = 0; k < 6; k++) o[k] = stamp_acc[k];
-    }
-#endif
   }
   if (stamping) {
     const uint64_t clk1 = __builtin_amdgcn_s_memtime(), ref1 = __builtin_amdgcn_s_memrealtime();
@@ -505,9 +403,6 @@ int launch_q_sample_target(hipStream_t s, const float* sched, int T, const float
   if (n == 0) return SO3X_OK;
   const int64_t nt64 = (n + kWave - 1) / kWave;
   int64_t want = (nt64 + 3) / 4;   // one tile per wave
-#ifdef SO3X_QS_TILES_PER_WAVE   /* A/B: several tiles per wave (the waves drift apart: reads of one overlap the stores of another) */
-  want = (want + SO3X_QS_TILES_PER_WAVE - 1) / SO3X_QS_TILES_PER_WAVE;
-#endif
   if (want > (1 << 20)) want = 1 << 20;
   if (!noise_in && !axes)
     hipLaunchKernelGGL(k_q_sample_target<true>, dim3((unsigned)want), dim3(kBlock), 0, s, sched, T, trap_q, guide_q, x0, t, t_draw, quirk_col0,

@@ -202,24 +202,13 @@ struct Philox4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-#ifndef SO3X_PHILOX_ROUNDS   /* A/B knob only: the product is Philox4x32-10 */
-#define SO3X_PHILOX_ROUNDS 10
-#endif
 #pragma unroll
-  for (int r = 0; r < SO3X_PHILOX_ROUNDS; r++) {
+  for (int r = 0; r < 10; r++) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     // a ^ b ^ c as ONE v_bitop3_b32 (truth table 0x96; gfx950): hipcc emits two v_xor for the plain expression
-#ifndef SO3X_PHILOX_XOR3   /* 0: the plain expression (A/B) */
-#define SO3X_PHILOX_XOR3 1
-#endif
-#if SO3X_PHILOX_XOR3
     uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
     uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
-#else
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-#endif
     uint32_t n1 = (uint32_t)p1;
     uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;

@@ -293,16 +293,13 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const
   out.h[2][0] = h ? 1.0f : silu<SO3X_PREC_F32>(acc[2][0]);  // row 64 (h=0) / the constant-one row 68 (h=1)
 }
 
-// Table form (FOLD): the lookups of SO3X_ACT_GROUP values are issued together and consumed afterwards, so that the LDS latency
+// Table form (FOLD): the lookups of 16 values are issued together and consumed afterwards, so that the LDS latency
 // (~100 cycles) is paid once per group under counted waits instead of once per four values (what the compiler's own
 // schedule of the value-by-value loop does).
-#ifndef SO3X_ACT_GROUP
-#define SO3X_ACT_GROUP 16
-#endif
 template <bool FOLD, bool WIDE = false>
 __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab, uint32_t lt = 0) {
   if constexpr (FOLD) {
-    constexpr int G = SO3X_ACT_GROUP;  // 8, 16 or 32 values per group (32 = both k-steps of a tile pair)
+    constexpr int G = 16;  // 8, 16 or 32 values per group (32 = both k-steps of a tile pair)
     float val[32];
 #pragma unroll
     for (int g0 = 0; g0 < 32; g0 += G) {
@@ -603,9 +600,6 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
 //                                                                   S' = [P_w of the upper half | C_w of the upper half] = tile B,
 // with C_0 = Q (slot 8 = R[8], slot 9 = one) and C_1 = (1, 1), C_2 = C_3 = 0 (slots 10, 11 = ones, 12..15 = padding).
 // Same bf16 bits as l0_operand<1> / <2>.
-#ifndef SO3X_L0_SWAP
-#define SO3X_L0_SWAP 1
-#endif
 __device__ __forceinline__ void l0_operands_pair(const float* x, bf16x8& bA, bf16x8& bB) {
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -620,42 +614,14 @@ __device__ __forceinline__ void l0_operands_pair(const float* x, bf16x8& bA, bf1
   bA = __builtin_bit_cast(bf16x8, u32x4_t{wa[0], wa[1], wa[2], wa[3]});
   bB = __builtin_bit_cast(bf16x8, u32x4_t{wb[0], wb[1], wb[2], wb[3]});
 }
-#ifndef SO3X_STAGE_FENCE
-#define SO3X_STAGE_FENCE __builtin_amdgcn_sched_barrier(0)
-#endif
 // The order WITHIN a stage.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles; about six 4-cycle instructions
 // fit the rest (MI355X_MICROARCH.md, issue-cost rows).  The compiler's own order put the lookups between the MFMAs and left
 // the ~50 multiply-adds and packings of a stage as a tail behind them, with the matrix pipe idle (sched_group_barrier
-// pipelines did not move it); stage_gaps below lays the stage out gap by gap instead.  0 = the compiler's order (A/B).
-#ifndef SO3X_STAGE_SCHED
-#define SO3X_STAGE_SCHED 1
-#endif
-#ifndef SO3X_CHAIN_PRIO
-#define SO3X_CHAIN_PRIO 1
-#endif
-#ifndef SO3X_STAGE_TOKEN
-#define SO3X_STAGE_TOKEN 0
-#endif
-#ifndef SO3X_HEAD_REUSE   /* 1: the two head stages share their five weight fragments in registers */
-#define SO3X_HEAD_REUSE 1
-#endif
-// the priorities themselves (A/B knobs; tools/ab/build_variant.sh): the six MFMA stages, the two head stages, the rest of a step
-#ifndef SO3X_PRIO_STAGE
-#define SO3X_PRIO_STAGE 3
-#endif
-#ifndef SO3X_PRIO_HEAD
-#define SO3X_PRIO_HEAD 1
-#endif
-#ifndef SO3X_PRIO_REST
-#define SO3X_PRIO_REST 0
-#endif
+// pipelines did not move it); stage_gaps below lays the stage out gap by gap instead.
 // One stage of the paired stream laid out gap by gap: the 15 MFMAs of tile X's layer, and in the gap behind each of them a
 // slice of tile Y's activation -- table lookups for about three values, the multiply-adds of the lookups issued two gaps
 // earlier, the packing of finished pairs -- and ONE weight-fragment read (five MFMAs ahead: the fragments of output tiles 1
 // and 2, then the next stage's first five into `ring`).  A sched_barrier closes every gap, so the emitted order is this one.
-#ifndef SO3X_STAGE_LAG
-#define SO3X_STAGE_LAG 2
-#endif
 template <bool WIDE>
 __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const char* __restrict__ wnext, const Tile<SO3X_PREC_BF16>& inX,
                                            f32x16 (&accX)[3], const f32x16 (&accY)[3], Tile<SO3X_PREC_BF16>& curY, bf16x8 (&ring)[5],
@@ -665,7 +631,7 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
   float2 e[33];
   float val[33];
   uint32_t pk[16];
-  constexpr int LAG = SO3X_STAGE_LAG;  // gaps between a lookup and its multiply-add (the LDS round trip under load)
+  constexpr int LAG = 2;  // gaps between a lookup and its multiply-add (the LDS round trip under load)
   constexpr int LAST_LOOKUP_GAP = 13 - LAG;  // lookups in gaps 0..13-LAG, multiply-adds LAG gaps behind, packing one more
   auto first_of = [](int g) { return g <= 0 ? 0 : (g > LAST_LOOKUP_GAP ? 33 : (33 * g) / (LAST_LOOKUP_GAP + 1)); };
 #pragma unroll
@@ -694,19 +660,6 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
         pk[j] = __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)val[2 * j], (__bf16)val[2 * j + 1]});
       }
     }
-#if defined(SO3X_EXTRA_WAIT)  /* timing experiment only (tools/ab): what does one more (always satisfied) s_waitcnt / s_nop per gap cost? */
-#if SO3X_EXTRA_WAIT == 1
-    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
-#elif SO3X_EXTRA_WAIT == 2
-    asm volatile("s_nop 0" ::: "memory");
-#elif SO3X_EXTRA_WAIT == 3   /* one more plain vector instruction per gap */
-    { float dummy_; asm volatile("v_add_f32 %0, %1, %1" : "=v"(dummy_) : "v"(val[0])); }
-#elif SO3X_EXTRA_WAIT == 4   /* one more LDS read per gap (address 0 = the table: always valid) */
-    { uint32_t dummy_; asm volatile("ds_read_b32 %0, %1" : "=v"(dummy_) : "v"(0u) : "memory"); }
-#elif SO3X_EXTRA_WAIT == 5   /* three more plain vector instructions per gap */
-    { float d0_, d1_, d2_; asm volatile("v_add_f32 %0, %3, %3\n\tv_add_f32 %1, %3, %3\n\tv_add_f32 %2, %3, %3" : "=v"(d0_), "=v"(d1_), "=v"(d2_) : "v"(val[0])); }
-#endif
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -721,19 +674,9 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
 }
 
 template <bool WIDE = false>
-#ifndef SO3X_STAMPS
-#define SO3X_STAMPS 0
-#endif
-#if SO3X_STAMPS  // timing build: phase stamps of the caller's accumulators (so3x_diffusion.hip)
-#define SO3X_FP_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - *stamp_last; *stamp_last = now_; } while (0)
-#else
-#define SO3X_FP_STAMP(k) do { } while (0)
-#endif
 __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, bf16x8 (&l0w)[3],
-                                                  float* va, float* vb, int lane, uint32_t lt = 0, uint64_t* stamp_acc = nullptr,
-                                                  uint64_t* stamp_last = nullptr, unsigned* stage_token = nullptr,
-                                                  const bf16x8* __restrict__ l0next = nullptr, const char* dma_src = nullptr,
-                                                  char* dma_dst = nullptr) {
+                                                  float* va, float* vb, int lane, uint32_t lt = 0,
+                                                  const bf16x8* __restrict__ l0next = nullptr) {
   constexpr int PREC = SO3X_PREC_BF16, VAR = CHAIN, FB = frag_bytes<PREC>();
   const int h = lane >> 5;
   const char* tab = img + (size_t)n_frags<PREC, VAR>() * FB;
@@ -741,12 +684,8 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   Tile<PREC> curA, curB;
   {  // layer 0 of both tiles from this timestep's three A fragments
     const bf16x8 w0 = l0w[0], w1 = l0w[1], w2 = l0w[2];
-#if SO3X_L0_SWAP
     bf16x8 bA, bB;
     l0_operands_pair(x, bA, bB);
-#else
-    const bf16x8 bA = l0_operand<1>(x, lane), bB = l0_operand<2>(x, lane);
-#endif
     accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
     accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
   }
@@ -756,82 +695,34 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
 #pragma unroll
     for (int k = 0; k < 3; k++) l0w[k] = l0next[64 * k + lane];
   }
-  // ... and the step's 4.5 KB CDF record goes global -> LDS by five LDS-DMA instructions HERE, behind layer 0's MFMAs: issued at
-  // the top of the step they sat in front of the wait that guards those MFMAs' fragments (the compiler cannot count past the
-  // DMA pieces: s_waitcnt vmcnt(0)), i.e. every step opened with an exposed L2 round trip.  dma_src = record + 16 lane.
-  if (dma_src) {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(dma_dst + i * 1024), 16, 0, 0);
-    if (lane < 32)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + 4096),
-                                       (__attribute__((address_space(3))) void*)(dma_dst + 4096), 16, 0, 0);
-  }
   // every stage also fetches the first five weight fragments of the NEXT stage (`pre`): a stage's MFMA chain starts on
   // registers instead of waiting ~120 cycles for its first LDS reads behind the fence
   bf16x8 pre[5];
   prefetch_tile0(img + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
   activate_bf16<true, WIDE>(accA, curA, h, tab, lt);
-  SO3X_FP_STAMP(4);  // layer 0 of both tiles + activation A, layer 0
   const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
-  // Wave priority by phase (s_setprio; SO3X_CHAIN_PRIO = 0 for the A/B): the six MFMA stages at 3, the output-layer stages
+  // Wave priority by phase (s_setprio): the six MFMA stages at 3, the output-layer stages
   // at 1, everything else of a step -- its top, layer 0, the all-vector reverse step -- at 0.  The two waves of a SIMD run
   // the same program at equal priority and the arbiter interleaved them instruction by instruction; with the stages on top a
   // wave in its stages keeps the matrix pipe fed and its partner's vector work fills what is left: 5.97 -> 5.51 ms per 100
   // steps.  Any split helped (reverse step on top: 5.82; network on top: 5.78; a fixed winner per SIMD: nothing).
-#if SO3X_STAGE_TOKEN
-  // A/B experiment: the two waves of a SIMD take turns in the six MFMA stages (a per-SIMD token in LDS), so that a wave's
-  // stages run beside its partner's vector phases instead of beside its partner's stages
-  if (stage_token) {
-    for (;;) {
-      unsigned got = 1;
-      if (lane == 0) got = atomicCAS(stage_token, 0u, 1u);
-      if (__builtin_amdgcn_readfirstlane(got) == 0) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-#endif
-#if SO3X_CHAIN_PRIO
-  __builtin_amdgcn_s_setprio(SO3X_PRIO_STAGE);
-#endif
+  __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int l = 1; l < 4; l++) {
     const char* wl = img + (size_t)frag_hidden<PREC, VAR>(l) * FB;
     const char* wnext = l < 3 ? img + (size_t)frag_hidden<PREC, VAR>(l + 1) * FB : wlast;
-    SO3X_STAGE_FENCE;
-#if SO3X_STAGE_SCHED
+    __builtin_amdgcn_sched_barrier(0);
     stage_gaps<WIDE>(wl, wl, curA, accA, accB, curB, pre, lane, h, tab, lt);     // MFMA A, layer l || activation B, layer l-1
     stage_gaps<WIDE>(wl, wnext, curB, accB, accA, curA, pre, lane, h, tab, lt);  // MFMA B, layer l || activation A, layer l
-#else
-    mfma_layer_bf16<3>(wl, curA, accA, lane, pre);  // MFMA A, layer l      ||
-    prefetch_tile0(wl, lane, pre);                  //   (tile 0 of the same layer again for B)
-    activate_bf16<true, WIDE>(accB, curB, h, tab, lt);        // activation B, layer l-1
-    SO3X_STAGE_FENCE;
-    mfma_layer_bf16<3>(wl, curB, accB, lane, pre);  // MFMA B, layer l      ||
-    prefetch_tile0(wnext, lane, pre);
-    activate_bf16<true, WIDE>(accA, curA, h, tab, lt);        // activation A, layer l
-#endif
   }
-  SO3X_FP_STAMP(5);  // the six 15-MFMA stages
-#if SO3X_STAGE_TOKEN
-  if (stage_token && lane == 0) atomicExch(stage_token, 0u);
-#endif
-#if SO3X_CHAIN_PRIO
-  __builtin_amdgcn_s_setprio(SO3X_PRIO_HEAD);
-#endif
+  __builtin_amdgcn_s_setprio(1);
   f32x16 lastA[1], lastB[1];
-  SO3X_STAGE_FENCE;
+  __builtin_amdgcn_sched_barrier(0);
   mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
-#if !SO3X_HEAD_REUSE
-  prefetch_tile0(wlast, lane, pre);                   // (round 2 read the head's five fragments a second time for tile B)
-#endif
   activate_bf16<true, WIDE>(accB, curB, h, tab, lt);            // activation B, layer 3 (head B below takes the SAME five fragments)
-  SO3X_STAGE_FENCE;
+  __builtin_amdgcn_sched_barrier(0);
   mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
-#if SO3X_CHAIN_PRIO
-  __builtin_amdgcn_s_setprio(SO3X_PRIO_REST);
-#endif
+  __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = lastA[0][k]; vb[k] = lastB[0][k]; }
 }

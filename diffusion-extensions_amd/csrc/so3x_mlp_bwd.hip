@@ -433,10 +433,7 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
 // and in flight together -- the kernel is a latency chain, not a bandwidth problem (18 MB) -- fixed summation order
 // (deterministic).  64 x 16: 272 workgroups, ONE round on the chip (two 1024-thread workgroups per CU); 32 x 32 was 543
 // workgroups = one round and a 31-workgroup tail.
-#ifndef SO3X_RED_PPB
-#define SO3X_RED_PPB 64
-#endif
-constexpr int RED_PPB = SO3X_RED_PPB, RED_GROUPS = 1024 / RED_PPB;
+constexpr int RED_PPB = 64, RED_GROUPS = 1024 / RED_PPB;
 __global__ void __launch_bounds__(1024)
 k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
              const float* __restrict__ gscale = nullptr) {
