@@ -20,7 +20,7 @@ def _blocks():
 
 def test_integration_md_has_the_stubs():
     src = "\n".join(_blocks())
-    for name in ("def so3_scale", "def p_sample_loop", "def mlp_forward_for_training", "def mlp_backward"):
+    for name in ("def so3_scale", "def p_sample_loop", "def mlp_forward_for_training", "def mlp_backward", "def training_step_loss_and_grad"):
         assert name in src
     compile(src.replace('ctypes.CDLL("diffusion-extensions_amd/libso3x.so")', "None"), "INTEGRATION.md", "exec")
 
@@ -39,7 +39,7 @@ def test_integration_md_stubs_run_and_agree_with_the_binding():
     finally:
         os.chdir(cwd)
     lib = ns["_lib"]
-    for f in ("so3x_mlp_stash_bytes", "so3x_mlp_workspace_bytes", "so3x_p_sample_workspace_bytes"):
+    for f in ("so3x_mlp_stash_bytes", "so3x_mlp_workspace_bytes", "so3x_p_sample_workspace_bytes", "so3x_train_workspace_bytes"):
         getattr(lib, f).restype = ctypes.c_size_t
     lib.so3x_error_string.restype = ctypes.c_char_p
     net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
@@ -55,6 +55,12 @@ def test_integration_md_stubs_run_and_agree_with_the_binding():
     assert torch.equal(ns["mlp_backward"](params, x, t, 100, dout, stash, ws), B.mlp_bwd(params, x, t, dout, 1, 100, zstash=zs))
     k = torch.rand(n, device=DEV)
     assert torch.equal(ns["so3_scale"](x, k), B.so3_scale(x, k))
+    # the one-kernel training step of the stub == the binding's (same seed and offset: same draws)
+    trap_q, _ = proc._tables()
+    loss, grad = ns["training_step_loss_and_grad"](params, proc._sched, trap_q, x, 100, 5, 3)
+    buf = B.TrainBuffers(n, 100, DEV, staged=False)
+    B.train_fused(buf, params, proc._sched, trap_q, x, None, seed=5, rng_offset=3)
+    assert torch.equal(loss, buf.loss) and torch.equal(grad, B.train_bwd_reduce(buf))
     _, trap_p = proc._tables()
     xs = ns["p_sample_loop"](params, proc._sched, trap_p, x.clone(), 100, 5)
     eye = torch.eye(3, device=DEV)
