@@ -45,6 +45,8 @@ nxt = c[1:, 0] - c[:-1, 24]                # end of round -> next top
 res["chain_wave0_cycles_per_phase_median"] = {nm: float(np.median(d[1:-1, i])) for i, nm in enumerate(names_c[1:])}
 res["chain_round_cycles_median"] = float(np.median(c[2:, 0] - c[1:-1, 0]))
 res["chain_between_rounds"] = float(np.median(nxt))
+res["chain_forward_cycles_by_round"] = [float(x) for x in (c[:, 4] - c[:, 0])]     # even rounds carry the dW waves' noise pass on the same SIMDs
+res["chain_backward_cycles_by_round"] = [float(x) for x in (c[:, 24] - c[:, 4])]
 w = st[1, :rounds, :17].astype(np.float64)
 order = [0] + sum([[2 + 3 * k, 3 + 3 * k, 4 + 3 * k] for k in range(4)], []) + [14, 15, 1, 16]   # ... B1(0), products(0), noise pass, B2(0)
 names_w = sum([[f"B1w{l}", f"mfma{l}", f"B2w{l}"] for l in (4, 3, 2, 1)], []) + ["B1w0", "mfma0", "noise", "B2w0"]
