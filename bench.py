@@ -634,6 +634,33 @@ def main():
     mops = pmc_counter("k_p_sample_chain", "SQ_INSTS_VALU_MFMA_MOPS_BF16")
     issued_tflops = None if (not mops or n != (1 << 20) or prec != B.PREC_BF16) else mops * 512.0 / (ms_per_launch * 1e-3) / 1e12
 
+    # ---- the f16-operand LEG of the same kernel (SO3X_PREC_F16): a labelled extra beside the bf16 headline -- what
+    #      "config 3 names bf16" costs or buys -- same shape, three launches, HIP events.  Never the headline.
+    f16_leg = None
+    if prec == B.PREC_BF16 and not args.no_extras:
+        try:
+            xf16 = x.clone()
+            B.p_sample_chain(params, proc._sched, trap_p, xf16, T - 1, RL_STEPS, seed=1, rng_offset=20_000, index_base=index_base,
+                             precision=B.PREC_F16, out=xf16, guide_p=proc._guide_p)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(3):
+                B.p_sample_chain(params, proc._sched, trap_p, xf16, T - 1 - 100 * i, RL_STEPS, seed=1, rng_offset=20_100 + 100 * i,
+                                 index_base=index_base, precision=B.PREC_F16, out=xf16, guide_p=proc._guide_p)
+            e1.record()
+            torch.cuda.synchronize()
+            ms16 = e0.elapsed_time(e1) / 3
+            f16_leg = {"what": "the same kernel with IEEE half operand bits (SO3X_PREC_F16): labelled extra, NOT the headline (BASELINE config 3 names bf16)",
+                       "ms_per_launch": ms16, "sample_steps_per_s": n * RL_STEPS / (ms16 * 1e-3),
+                       "frac": MLP_FLOP_PER_SAMPLE * n * RL_STEPS / (ms16 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                       "vs_bf16_time": ms16 / ms_per_launch, "finite": bool(torch.isfinite(xf16).all().item()),
+                       "note": "2.5x closer to the fp32 chain per step (median 6e-7 vs 1.5e-6) and ~8 % SLOWER: v_fma_mixlo / mixhi_f16 fuse an "
+                               "activation's multiply-add, conversion and pack but issue at the packed-op rate, and the kernel needs 256 "
+                               "registers (profiles/r04_ab_chain_f16_operands.json)"}
+            del xf16
+        except Exception as e:  # report, never hide
+            f16_leg = {"error": repr(e)}
+
     # ---- the metric verbatim: one complete p_sample_loop, B rotations through all T reverse steps (diffusion.py:328-337)
     proc.p_sample_loop((256,))  # untimed: first-use initialisation of the start distribution (its CDF table; ~25 ms of host work)
     torch.cuda.synchronize()
@@ -681,6 +708,7 @@ def main():
                          "issued_frac": None if issued_tflops is None else issued_tflops / BF16_MFMA_PEAK_TFLOPS,
                          "issued_TFLOPs": issued_tflops,
                          "pmc_source": PMC.source, "silu": "256-entry secant table (max abs error 1.3e-4), bf16 chain kernel",
+                         "f16_operand_leg": f16_leg,
                          "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=RL_STEPS, precision=args.precision),
                          "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_p_sample_chain"),
                          "valu_busy_frac_pmc": pmc_valu_busy("k_p_sample_chain"),

@@ -203,7 +203,8 @@ template <int PREC, bool PAIR = true> constexpr int chain_threads() {       // l
 }
 template <int PREC> constexpr int chain_threads_default() { return PREC == SO3X_PREC_BF16 ? 512 : 256; }
 // WIDE: the SiLU table in its lane-replicated 64 KB form at LDS address 0, the weight image behind it (so3x_mlp.hpp).
-template <int PREC, bool FAST, bool PAIR, bool WIDE>
+// F16: the paired stream's f16-operand leg (SO3X_PREC_F16: the same images with IEEE half bits, so3x_mlp.hpp)
+template <int PREC, bool FAST, bool PAIR, bool WIDE, bool F16 = false>
 __global__ void __launch_bounds__((chain_threads<PREC, PAIR>()), (chain_threads<PREC, PAIR>() > 512 ? chain_threads<PREC, PAIR>() / 256 : 2))
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
@@ -211,6 +212,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
                  int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
                  uint64_t rng_offset, int64_t index_base, int64_t n, const char* __restrict__ cdf_rec, uint64_t* __restrict__ clk) {
   static_assert(!WIDE || (PAIR && PREC == SO3X_PREC_BF16), "the wide table belongs to the paired bf16 stream");
+  static_assert(!F16 || WIDE, "the f16 operands are a leg of the shipped (paired, wide-table) stream");
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   char* lds = lds_all + (WIDE ? kWideTabBytes : 0);
   load_image(gimg, lds, image_bytes<PREC, CHAIN>());
@@ -284,7 +286,7 @@ k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_t
             }
           }
           const bf16x8* l0n = l0t_tab + (size_t)(s + 1 < n_steps ? t - 1 : t) * 192;
-          forward_pair_bf16<WIDE>(lds, R, w0, va, vb, lane, lt, l0n);  // both tiles as one software-pipelined stream; reloads w0 for the next step
+          forward_pair_bf16<WIDE, F16>(lds, R, w0, va, vb, lane, lt, l0n);  // both tiles as one software-pipelined stream; reloads w0 for the next step
         } else {
           forward_tile<PREC, CHAIN, 1, true>(lds, R, nullptr, 0, nullptr, va, lane, l0t);
           forward_tile<PREC, CHAIN, 2, true>(lds, R, nullptr, 0, nullptr, vb, lane, l0t);
@@ -340,7 +342,7 @@ inline int ab_env(const char* name, const char* value) {
 }
 #endif
 
-template <int PREC, bool FAST, bool PAIR, bool WIDE = false>
+template <int PREC, bool FAST, bool PAIR, bool WIDE = false, bool F16 = false>
 int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
                    const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                    uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
@@ -357,13 +359,13 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
 #else
   static PerDevice resident;
 #endif
-  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST, PAIR, WIDE>), threads, IMG, &max_blocks)) return rc;
+  if (int rc = resident_blocks(resident, reinterpret_cast<const void*>(&k_p_sample_chain<PREC, FAST, PAIR, WIDE, F16>), threads, IMG, &max_blocks)) return rc;
   const int64_t nchunks = (n + 63) / 64;
   const int wpb = threads / 64;
   const int64_t want = (nchunks + wpb - 1) / wpb;
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
-  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
+  hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE, F16>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
                      t_start, n_steps, axes, unif, seed, rng_offset, index_base, n,
                      staged_cdf ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr,
                      reinterpret_cast<uint64_t*>(const_cast<char*>(reinterpret_cast<const char*>(ws)) +
@@ -374,9 +376,10 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
 template <int PREC>
 int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
                  const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
-                 uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
+                 uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, bool f16 = false) {
 #define SO3X_CHAIN_ARGS s, ws, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n
   if constexpr (PREC == SO3X_PREC_BF16) {
+    if (f16) return launch_chain_v<PREC, true, true, true, true>(SO3X_CHAIN_ARGS);
 #ifdef SO3X_AB_BUILD
     if (ab_env("SO3X_AB_TRIG", "cw")) return launch_chain_v<PREC, false, true, true>(SO3X_CHAIN_ARGS);
     if (ab_env("SO3X_AB_PAIR", "0")) return launch_chain_v<PREC, true, false>(SO3X_CHAIN_ARGS);
@@ -463,14 +466,16 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
       (n && (!params || !sched || !trap_p || !x_in || !x_out)) || ((axes == nullptr) != (unif == nullptr)) ||
       (axes && n_steps > 1))
     return SO3X_ERR_INVALID_ARG;
-  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F16) return SO3X_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < so3x_p_sample_workspace_bytes(T, precision)) return SO3X_ERR_WORKSPACE;
   if (n == 0 || n_steps == 0) return SO3X_OK;
+  const bool f16 = precision == SO3X_PREC_F16;   // the bf16 path's images, tables and kernel with IEEE half operand bits
+  if (f16) precision = SO3X_PREC_BF16;
   // image + the per-timestep rows of the steps this launch runs (t_start - n_steps + 1 .. t_start)
   const int t_first = t_start - n_steps + 1;
-  int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace, 3, nullptr, true, nullptr, t_first, n_steps);
+  int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace, 3, nullptr, true, nullptr, t_first, n_steps, f16);
   if (rc) return rc;
-  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace, t_first, n_steps))) return rc;
+  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace, t_first, n_steps, f16))) return rc;
   if (precision == SO3X_PREC_BF16) {  // the CDF records of the steps this launch runs (LDS-DMA source of the chain kernel)
     hipLaunchKernelGGL(k_prep_cdf, dim3(n_steps), dim3(256), 0, (hipStream_t)s, trap_p, guide_p,
                        reinterpret_cast<char*>(workspace) + cdf_offset(T), t_first);
@@ -481,7 +486,7 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
     return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,
                                        unif, seed, rng_offset, index_base, n);
   return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,
-                                      unif, seed, rng_offset, index_base, n);
+                                      unif, seed, rng_offset, index_base, n, f16);
 }
 
 }  // extern "C"

@@ -38,7 +38,7 @@ constexpr int PREP_IMG_BLOCKS = 32, PREP_WT_BLOCKS = 32;
 template <int PREC, int VAR>
 __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, void* __restrict__ img, void* __restrict__ wt, int nout,
                                               Freqs fr, int T, float scale, float offset, float* __restrict__ beff, float* __restrict__ emb_tab,
-                                              __bf16* __restrict__ h0_tab, unsigned* __restrict__ zero_word, int t_first) {
+                                              __bf16* __restrict__ h0_tab, unsigned* __restrict__ zero_word, int t_first, int f16) {
   constexpr int EPL = PREC == SO3X_PREC_F32 ? 1 : 8;  // elements per lane per fragment
   if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // arrival ticket of the launch that follows
   if (blockIdx.x < PREP_IMG_BLOCKS) {
@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, 
       const int j = e % EPL, lane = (e / EPL) % 64, frag = e / (EPL * 64);
       const float v = image_value<PREC, VAR>(params, frag, lane, j, nout);
       if (PREC == SO3X_PREC_F32) reinterpret_cast<float*>(img)[e] = v;
+      else if (f16) reinterpret_cast<_Float16*>(img)[e] = (_Float16)v;
       else reinterpret_cast<__bf16*>(img)[e] = (__bf16)v;
     }
     if (fold_scale<PREC, VAR>() && blockIdx.x == PREP_IMG_BLOCKS - 1) {  // the SiLU table behind the fragments
@@ -94,23 +95,23 @@ __global__ void __launch_bounds__(256) k_prep(const float* __restrict__ params, 
 // element j of lane (i, h) of tile `to` feeds K slot 8h + j:  slots 0..8 = 16 W_0[o][slot], 9 / 10 = bf16 halves of
 // 16 beff[t][o], 11 = the table offset 127.5 (k_prep wrote beff as 16 beff + 127.5), o = 32 to + i.
 __global__ void __launch_bounds__(192) k_prep_l0t(const float* __restrict__ params, const float* __restrict__ beff, void* __restrict__ l0t,
-                                                  int t_first) {
+                                                  int t_first, int f16) {
   const int t = t_first + blockIdx.x, to = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int o = 32 * to + i;
   const float be = beff[(size_t)t * 96 + o] - kTabD;
-  const __bf16 hi = (__bf16)be;
-  bf16x8 v;
+  const float hi = f16 ? (float)(_Float16)be : (float)(__bf16)be;   // the bias as value + remainder in two K slots
+  float val8[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int slot = 8 * h + j;
     float val = 0.0f;
     if (slot < 9) val = o < D ? kTabC * params[o * D + slot] : 0.0f;
-    else if (slot == 9) val = (float)hi;
-    else if (slot == 10) val = be - (float)hi;
+    else if (slot == 9) val = hi;
+    else if (slot == 10) val = be - hi;
     else if (slot == 11) val = kTabD;
-    v[j] = (__bf16)val;
+    val8[j] = val;
   }
-  reinterpret_cast<bf16x8*>(l0t)[((size_t)t * 3 + to) * 64 + lane] = v;
+  reinterpret_cast<bf16x8*>(l0t)[((size_t)t * 3 + to) * 64 + lane] = f16 ? pack_octet<true>(val8) : pack_octet<false>(val8);
 }
 
 // ---- standalone forward ---------------------------------------------------------------
@@ -144,7 +145,7 @@ k_mlp_fwd(const void* __restrict__ gimg, const float* __restrict__ beff_tab, con
 }
 
 template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* params, int T, void* ws, int nout, void* wt, bool want_image,
-                                               unsigned* zero_word, int t_first, int t_count) {
+                                               unsigned* zero_word, int t_first, int t_count, bool f16 = false) {
   const bool tables = chain_layout(VAR) && T > 0;
   float* beff = tables ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + beff_offset(PREC, VAR)) : nullptr;
   float* emb = (tables && gather_layout(VAR)) ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + emb_offset(PREC, VAR, T)) : nullptr;
@@ -152,7 +153,7 @@ template <int PREC, int VAR> int launch_prep_t(hipStream_t s, const float* param
   const int rows = !tables ? 0 : (t_count > 0 ? t_count : T);
   hipLaunchKernelGGL((k_prep<PREC, VAR>), dim3(PREP_IMG_BLOCKS + PREP_WT_BLOCKS + rows), dim3(256), 0, s, params,
                      want_image ? ws : nullptr, wt, nout, host_freqs(), T, fold_scale<PREC, VAR>() ? kTabC : 1.0f,
-                     fold_scale<PREC, VAR>() ? kTabD : 0.0f, beff, emb, h0, zero_word, t_count > 0 ? t_first : 0);
+                     fold_scale<PREC, VAR>() ? kTabD : 0.0f, beff, emb, h0, zero_word, t_count > 0 ? t_first : 0, f16 ? 1 : 0);
   return check_launch();
 }
 
@@ -176,21 +177,21 @@ int launch_fwd_t(hipStream_t s, const void* ws, const float* R, const int64_t* t
 namespace so3x {
 namespace mlp {
 // after launch_prep(bf16, CHAIN, T): the per-timestep layer-0 fragments of the chain kernel, workspace >= l0t_end(T)
-int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace, int t_first, int t_count) {
+int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace, int t_first, int t_count, bool f16) {
   char* ws = reinterpret_cast<char*>(workspace);
   hipLaunchKernelGGL(k_prep_l0t, dim3(t_count > 0 ? t_count : T), dim3(192), 0, s, params,
                      reinterpret_cast<const float*>(ws + beff_offset(SO3X_PREC_BF16, CHAIN)), (void*)(ws + l0t_offset(T)),
-                     t_count > 0 ? t_first : 0);
+                     t_count > 0 ? t_first : 0, f16 ? 1 : 0);
   return check_launch();
 }
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout, void* wt,
-                bool want_image, unsigned* zero_word, int t_first, int t_count) {
+                bool want_image, unsigned* zero_word, int t_first, int t_count, bool f16) {
   if (precision == SO3X_PREC_F32) {
     if (variant == CHAIN) return launch_prep_t<SO3X_PREC_F32, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
     if (variant == GATHER) return launch_prep_t<SO3X_PREC_F32, GATHER>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
     return launch_prep_t<SO3X_PREC_F32, FULL>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   }
-  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
+  if (variant == CHAIN) return launch_prep_t<SO3X_PREC_BF16, CHAIN>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count, f16);
   if (variant == GATHER) return launch_prep_t<SO3X_PREC_BF16, GATHER>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   if (variant == GATHER_T) return launch_prep_t<SO3X_PREC_BF16, GATHER_T>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);
   if (variant == GATHER_TD) return launch_prep_t<SO3X_PREC_BF16, GATHER_TD>(s, params, T, workspace, nout, wt, want_image, zero_word, t_first, t_count);

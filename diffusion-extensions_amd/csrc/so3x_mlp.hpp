@@ -246,6 +246,28 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// F16 = the f16-operand leg of the paired chain stream (SO3X_PREC_F16; so3x_p_sample_chain only): the SAME image layout, 16-bit
+// slots and registers, but the slots hold IEEE half bits and the products run on v_mfma_f32_32x32x16_f16 (same rate as bf16).
+// What it buys: an activation's multiply-add, conversion and pack become ONE instruction each half (v_fma_mixlo / mixhi_f16)
+// instead of fma + half a v_cvt_pk_bf16_f32; f16 carries three more mantissa bits than bf16.  bf16x8 stays the container type.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> __device__ __forceinline__ f32x16 mfma_op(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ uint32_t pack_pair(float a, float b) {
+  if constexpr (F16) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, h2_t{(_Float16)a, (_Float16)b});
+  } else {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, b2_t{(__bf16)a, (__bf16)b});
+  }
+}
+template <bool F16> __device__ __forceinline__ bf16x8 pack_octet(const float* v) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(bf16x8, u32x4_t{pack_pair<F16>(v[0], v[1]), pack_pair<F16>(v[2], v[3]), pack_pair<F16>(v[4], v[5]), pack_pair<F16>(v[6], v[7])});
+}
 
 // activation + repack of the three accumulator tiles into the next layer's operand
 template <int PREC, bool FOLD = false> __device__ __forceinline__ void activate(const f32x16 (&acc)[3], Tile<PREC>& out, int h,
@@ -296,7 +318,7 @@ template <> __device__ __forceinline__ void activate<SO3X_PREC_F32, false>(const
 // Table form (FOLD): the lookups of 16 values are issued together and consumed afterwards, so that the LDS latency
 // (~100 cycles) is paid once per group under counted waits instead of once per four values (what the compiler's own
 // schedule of the value-by-value loop does).
-template <bool FOLD, bool WIDE = false>
+template <bool FOLD, bool WIDE = false, bool F16 = false>
 __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_PREC_BF16>& out, int h, const char* tab, uint32_t lt = 0) {
   if constexpr (FOLD) {
     constexpr int G = 16;  // 8, 16 or 32 values per group (32 = both k-steps of a tile pair)
@@ -322,18 +344,10 @@ __device__ __forceinline__ void activate_bf16(const f32x16 (&acc)[3], Tile<SO3X_
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
-        bf16x8 p;
-#pragma unroll
-        for (int j = 0; j < 8; j++) p[j] = (__bf16)val[16 * t + 8 * s + j];
-        out.b[2 * t + s] = p;
-      }
-    bf16x8 p;
-#pragma unroll
-    for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
-    p[0] = (__bf16)(h ? 1.0f : (WIDE ? silu_tabw(acc[2][0], lt) : silu_tab(acc[2][0], tab)));  // row 64 | the constant-one row 68
-    p[1] = (__bf16)(h ? 1.0f : 0.0f);                      // row 69: the second constant one (carries the table offset)
-    out.b[4] = p;
+      for (int s = 0; s < 2; s++) out.b[2 * t + s] = pack_octet<F16>(&val[16 * t + 8 * s]);
+    const float last8[8] = {h ? 1.0f : (WIDE ? silu_tabw(acc[2][0], lt) : silu_tab(acc[2][0], tab)),   // row 64 | the constant-one row 68
+                            h ? 1.0f : 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                              // row 69: the second constant one (table offset)
+    out.b[4] = pack_octet<F16>(last8);
   } else {
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -559,7 +573,7 @@ __device__ __forceinline__ void forward_tile(const char* __restrict__ img /*LDS 
 // Each stage is fenced (sched_barrier) and left to the scheduler inside; accumulators and operands of both tiles are
 // live (96 + 40 registers), which the 8-wave workgroup's 256-register budget holds.
 // `pre` = the five fragments of output tile 0, already in registers (fetched during the previous stage)
-template <int NT>
+template <int NT, bool F16 = false>
 __device__ __forceinline__ void mfma_layer_bf16(const char* __restrict__ wl, const Tile<SO3X_PREC_BF16>& in, f32x16 (&acc)[NT], int lane,
                                                 const bf16x8 (&pre)[5]) {
   const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
@@ -567,7 +581,7 @@ __device__ __forceinline__ void mfma_layer_bf16(const char* __restrict__ wl, con
   for (int to = 0; to < NT; to++) {
     f32x16 a = zero16<SO3X_PREC_BF16>();
 #pragma unroll
-    for (int ks = 0; ks < 5; ks++) a = mfma_bf16(to == 0 ? pre[ks] : w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
+    for (int ks = 0; ks < 5; ks++) a = mfma_op<F16>(to == 0 ? pre[ks] : w[(to * 5 + ks) * 64 + lane], in.b[ks], a);
     acc[to] = a;
   }
 }
@@ -600,11 +614,11 @@ __device__ __forceinline__ bf16x8 l0_operand(const float* x, int lane) {
 //                                                                   S' = [P_w of the upper half | C_w of the upper half] = tile B,
 // with C_0 = Q (slot 8 = R[8], slot 9 = one) and C_1 = (1, 1), C_2 = C_3 = 0 (slots 10, 11 = ones, 12..15 = padding).
 // Same bf16 bits as l0_operand<1> / <2>.
+template <bool F16 = false>
 __device__ __forceinline__ void l0_operands_pair(const float* x, bf16x8& bA, bf16x8& bB) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  auto pk = [](float a, float b) { return __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)a, (__bf16)b}); };
-  const uint32_t c[4] = {pk(x[8], 1.0f), 0x3F803F80u, 0u, 0u};
+  auto pk = [](float a, float b) { return pack_pair<F16>(a, b); };
+  const uint32_t c[4] = {pk(x[8], 1.0f), F16 ? 0x3C003C00u : 0x3F803F80u, 0u, 0u};   // (1, 1) as two halves / two bf16
   uint32_t wa[4], wb[4];
 #pragma unroll
   for (int w = 0; w < 4; w++) {
@@ -622,7 +636,7 @@ __device__ __forceinline__ void l0_operands_pair(const float* x, bf16x8& bA, bf1
 // slice of tile Y's activation -- table lookups for about three values, the multiply-adds of the lookups issued two gaps
 // earlier, the packing of finished pairs -- and ONE weight-fragment read (five MFMAs ahead: the fragments of output tiles 1
 // and 2, then the next stage's first five into `ring`).  A sched_barrier closes every gap, so the emitted order is this one.
-template <bool WIDE>
+template <bool WIDE, bool F16 = false>
 __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const char* __restrict__ wnext, const Tile<SO3X_PREC_BF16>& inX,
                                            f32x16 (&accX)[3], const f32x16 (&accY)[3], Tile<SO3X_PREC_BF16>& curY, bf16x8 (&ring)[5],
                                            int lane, int h, const char* tab, uint32_t lt) {
@@ -637,7 +651,7 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
 #pragma unroll
   for (int g = 0; g < 15; g++) {
     const int to = g / 5, ks = g % 5;
-    accX[to] = mfma_bf16(ring[ks], inX.b[ks], ks == 0 ? zero16<SO3X_PREC_BF16>() : accX[to]);
+    accX[to] = mfma_op<F16>(ring[ks], inX.b[ks], ks == 0 ? zero16<SO3X_PREC_BF16>() : accX[to]);
     ring[ks] = g < 10 ? w[(g + 5) * 64 + lane] : wn[(g - 10) * 64 + lane];
 #pragma unroll
     for (int q = first_of(g); q < first_of(g + 1); q++) {
@@ -656,8 +670,7 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
     for (int j = 0; j < 16; j++) {
       const bool ready_now = 2 * j + 1 < first_of(g - LAG), ready_before = 2 * j + 1 < first_of(g - LAG - 1);
       if (ready_now && !ready_before) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        pk[j] = __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)val[2 * j], (__bf16)val[2 * j + 1]});
+        pk[j] = pack_pair<F16>(val[2 * j], val[2 * j + 1]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -665,15 +678,11 @@ __device__ __forceinline__ void stage_gaps(const char* __restrict__ wl, const ch
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int i = 0; i < 4; i++) curY.b[i] = __builtin_bit_cast(bf16x8, u32x4_t{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]});
-  bf16x8 p;
-#pragma unroll
-  for (int j = 0; j < 8; j++) p[j] = (__bf16)0.0f;
-  p[0] = (__bf16)(h ? 1.0f : val[32]);  // row 64 | the constant-one row 68
-  p[1] = (__bf16)(h ? 1.0f : 0.0f);     // row 69: the second constant one (carries the table offset)
-  curY.b[4] = p;
+  const float last8[8] = {h ? 1.0f : val[32], h ? 1.0f : 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row 64 | the constant ones of rows 68, 69
+  curY.b[4] = pack_octet<F16>(last8);
 }
 
-template <bool WIDE = false>
+template <bool WIDE = false, bool F16 = false>
 __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, const float* x, bf16x8 (&l0w)[3],
                                                   float* va, float* vb, int lane, uint32_t lt = 0,
                                                   const bf16x8* __restrict__ l0next = nullptr) {
@@ -685,9 +694,9 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   {  // layer 0 of both tiles from this timestep's three A fragments
     const bf16x8 w0 = l0w[0], w1 = l0w[1], w2 = l0w[2];
     bf16x8 bA, bB;
-    l0_operands_pair(x, bA, bB);
-    accA[0] = mfma_bf16(w0, bA, zero16<PREC>()); accA[1] = mfma_bf16(w1, bA, zero16<PREC>()); accA[2] = mfma_bf16(w2, bA, zero16<PREC>());
-    accB[0] = mfma_bf16(w0, bB, zero16<PREC>()); accB[1] = mfma_bf16(w1, bB, zero16<PREC>()); accB[2] = mfma_bf16(w2, bB, zero16<PREC>());
+    l0_operands_pair<F16>(x, bA, bB);
+    accA[0] = mfma_op<F16>(w0, bA, zero16<PREC>()); accA[1] = mfma_op<F16>(w1, bA, zero16<PREC>()); accA[2] = mfma_op<F16>(w2, bA, zero16<PREC>());
+    accB[0] = mfma_op<F16>(w0, bB, zero16<PREC>()); accB[1] = mfma_op<F16>(w1, bB, zero16<PREC>()); accB[2] = mfma_op<F16>(w2, bB, zero16<PREC>());
   }
   // the NEXT step's three layer-0 fragments go straight into the registers this step's six MFMAs have just read (an L2 round
   // trip that lands during the stages; no second set of twelve registers, no twelve moves per step)
@@ -699,7 +708,7 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
   // registers instead of waiting ~120 cycles for its first LDS reads behind the fence
   bf16x8 pre[5];
   prefetch_tile0(img + (size_t)frag_hidden<PREC, VAR>(1) * FB, lane, pre);
-  activate_bf16<true, WIDE>(accA, curA, h, tab, lt);
+  activate_bf16<true, WIDE, F16>(accA, curA, h, tab, lt);
   const char* wlast = img + (size_t)frag_last<PREC, VAR>() * FB;
   // Wave priority by phase (s_setprio): the six MFMA stages at 3, the output-layer stages
   // at 1, everything else of a step -- its top, layer 0, the all-vector reverse step -- at 0.  The two waves of a SIMD run
@@ -712,16 +721,16 @@ __device__ __forceinline__ void forward_pair_bf16(const char* __restrict__ img, 
     const char* wl = img + (size_t)frag_hidden<PREC, VAR>(l) * FB;
     const char* wnext = l < 3 ? img + (size_t)frag_hidden<PREC, VAR>(l + 1) * FB : wlast;
     __builtin_amdgcn_sched_barrier(0);
-    stage_gaps<WIDE>(wl, wl, curA, accA, accB, curB, pre, lane, h, tab, lt);     // MFMA A, layer l || activation B, layer l-1
-    stage_gaps<WIDE>(wl, wnext, curB, accB, accA, curA, pre, lane, h, tab, lt);  // MFMA B, layer l || activation A, layer l
+    stage_gaps<WIDE, F16>(wl, wl, curA, accA, accB, curB, pre, lane, h, tab, lt);     // MFMA A, layer l || activation B, layer l-1
+    stage_gaps<WIDE, F16>(wl, wnext, curB, accB, accA, curA, pre, lane, h, tab, lt);  // MFMA B, layer l || activation A, layer l
   }
   __builtin_amdgcn_s_setprio(1);
   f32x16 lastA[1], lastB[1];
   __builtin_amdgcn_sched_barrier(0);
-  mfma_layer_bf16<1>(wlast, curA, lastA, lane, pre);  // head A             ||
-  activate_bf16<true, WIDE>(accB, curB, h, tab, lt);            // activation B, layer 3 (head B below takes the SAME five fragments)
+  mfma_layer_bf16<1, F16>(wlast, curA, lastA, lane, pre);  // head A             ||
+  activate_bf16<true, WIDE, F16>(accB, curB, h, tab, lt);            // activation B, layer 3 (head B below takes the SAME five fragments)
   __builtin_amdgcn_sched_barrier(0);
-  mfma_layer_bf16<1>(wlast, curB, lastB, lane, pre);
+  mfma_layer_bf16<1, F16>(wlast, curB, lastB, lane, pre);
   __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = lastA[0][k]; vb[k] = lastB[0][k]; }
@@ -742,9 +751,10 @@ size_t image_bytes_rt(int precision, int variant);
 // want_image = false skips the forward image (the backward with a stash never reads it).
 // zero_word (optional): a device word the launch clears (the arrival ticket of a kernel that follows in the stream).
 // t_count > 0: only the per-timestep rows t_first .. t_first + t_count - 1 are built (a chain launch of a few steps reads no others).
+// f16: the bf16 images' 16-bit slots are filled with IEEE half bits instead (the chain kernel's f16-operand leg)
 int launch_prep(hipStream_t s, const float* params, int precision, int variant, int T, void* workspace, int nout = 3,
-                void* wt = nullptr, bool want_image = true, unsigned* zero_word = nullptr, int t_first = 0, int t_count = 0);
-int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace, int t_first = 0, int t_count = 0);
+                void* wt = nullptr, bool want_image = true, unsigned* zero_word = nullptr, int t_first = 0, int t_count = 0, bool f16 = false);
+int launch_prep_l0t(hipStream_t s, const float* params, int T, void* workspace, int t_first = 0, int t_count = 0, bool f16 = false);
 size_t beff_offset(int precision, int variant);
 // tables that follow the image for chain-layout variants: beff [T][96] fp32, then emb [T][56] fp32
 inline size_t emb_offset(int precision, int variant, int T) { return beff_offset(precision, variant) + (size_t)T * 96 * sizeof(float); }

@@ -429,38 +429,61 @@ k_bwd_dw_bf16(const __bf16* __restrict__ stash, int64_t nc, float* __restrict__ 
   write_slab(slabs, acc, wid, i, h, n_out);
 }
 
-// RED_PPB parameters x RED_GROUPS slab groups per block of 1024 threads: coalesced reads, every thread's loads independent
-// and in flight together -- the kernel is a latency chain, not a bandwidth problem (18 MB) -- fixed summation order
-// (deterministic).  64 x 16: 272 workgroups, ONE round on the chip (two 1024-thread workgroups per CU); 32 x 32 was 543
-// workgroups = one round and a 31-workgroup tail.
-constexpr int RED_PPB = 64, RED_GROUPS = 1024 / RED_PPB;
-__global__ void __launch_bounds__(1024)
-k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
-             const float* __restrict__ gscale = nullptr) {
-  __shared__ float part[RED_GROUPS][RED_PPB + 1];
-  const int p = threadIdx.x % RED_PPB, g = threadIdx.x / RED_PPB;
-  const int idx = blockIdx.x * RED_PPB + p;
-  float s = 0.0f;
-  if (idx < np) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+// Slab reduction.  A block = RED_COLS float4 columns (four consecutive parameters each: one 16-byte load per slab) x RED_GROUPS slab
+// groups; every thread's loads are independent and in flight together -- the kernel is a latency chain, not a bandwidth problem
+// (18 MB) -- and the summation order is FIXED: per element four running sums over the slabs of its group (b = g, g + 16, ...),
+// combined as (s0 + s1) + (s2 + s3), then the 16 groups in order.  (Round 4: 16-byte columns and 256-thread blocks instead of
+// 4-byte ones and 1,024 -- a quarter of the load instructions; the order per element, hence every bit, is round 2's.)
+constexpr int RED_COLS = 16, RED_GROUPS = 16, RED_THREADS = RED_COLS * RED_GROUPS;
+__host__ __device__ constexpr int red_blocks(int np) { return ((np + 3) / 4 + RED_COLS - 1) / RED_COLS; }
+static_assert(NPARAMS_MAX % 4 == 0, "slabs are read in 16-byte columns");
+__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ slabs, int nslabs, int np, float4 (*part)[RED_COLS + 1], int* col_out) {
+  const int c = threadIdx.x % RED_COLS, g = threadIdx.x / RED_COLS;
+  const int col = blockIdx.x * RED_COLS + c;
+  *col_out = col;
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+  if (4 * col < np) {
+    const float4* base = reinterpret_cast<const float4*>(slabs) + col;
+    constexpr size_t STRIDE4 = NPARAMS_MAX / 4;
+    float4 s0 = s, s1 = s, s2 = s, s3 = s;
+    auto add = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
     int b = g;
     for (; b + 3 * RED_GROUPS < nslabs; b += 4 * RED_GROUPS) {
-      s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
-      s1 += slabs[(size_t)(b + RED_GROUPS) * NPARAMS_MAX + idx];
-      s2 += slabs[(size_t)(b + 2 * RED_GROUPS) * NPARAMS_MAX + idx];
-      s3 += slabs[(size_t)(b + 3 * RED_GROUPS) * NPARAMS_MAX + idx];
+      add(s0, base[(size_t)b * STRIDE4]);
+      add(s1, base[(size_t)(b + RED_GROUPS) * STRIDE4]);
+      add(s2, base[(size_t)(b + 2 * RED_GROUPS) * STRIDE4]);
+      add(s3, base[(size_t)(b + 3 * RED_GROUPS) * STRIDE4]);
     }
-    for (; b < nslabs; b += RED_GROUPS) s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
-    s = (s0 + s1) + (s2 + s3);
+    for (; b < nslabs; b += RED_GROUPS) add(s0, base[(size_t)b * STRIDE4]);
+    s = float4{(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
   }
-  part[g][p] = s;
+  part[g][c] = s;
   __syncthreads();
-  if (g == 0 && idx < np) {
-    float t = 0.0f;
+  float4 t = {0.f, 0.f, 0.f, 0.f};
+  if (g == 0 && 4 * col < np) {
 #pragma unroll
-    for (int k = 0; k < RED_GROUPS; k++) t += part[k][p];
-    if (gscale) t *= gscale[0];
-    dparams[idx] = accumulate ? dparams[idx] + t : t;
+    for (int k = 0; k < RED_GROUPS; k++) { const float4 v = part[k][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+  }
+  return t;   // valid in the threads of group 0
+}
+
+__global__ void __launch_bounds__(RED_THREADS)
+k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
+             const float* __restrict__ gscale = nullptr) {
+  __shared__ float4 part[RED_GROUPS][RED_COLS + 1];
+  int col;
+  const float4 t4 = slab_sum4(slabs, nslabs, np, part, &col);
+  if (threadIdx.x / RED_COLS == 0) {
+    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+    const float gs = gscale ? gscale[0] : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = 4 * col + k;
+      if (idx < np) {
+        const float t = gscale ? tv[k] * gs : tv[k];
+        dparams[idx] = accumulate ? dparams[idx] + t : t;
+      }
+    }
   }
 }
 
@@ -468,53 +491,42 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
 // term): in a single process nothing sits between the slab reduction and the optimizer, and a 17,358-element update is all launch
 // latency (5 us of a 0.235 ms step).  Every block reads the step count before any block advances it (the last one to arrive does).
 struct AdamArgs { float* p; float* m; float* v; float* step; unsigned* ticket; float lr, beta1, beta2, eps, weight_decay, grad_scale; };
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(RED_THREADS)
 k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int np, const float* __restrict__ gscale,
                   AdamArgs ad) {
-  __shared__ float part[RED_GROUPS][RED_PPB + 1];
+  __shared__ float4 part[RED_GROUPS][RED_COLS + 1];
   __shared__ float sc[2];
-  const int p = threadIdx.x % RED_PPB, g = threadIdx.x / RED_PPB;
-  const int idx = blockIdx.x * RED_PPB + p;
-  if (threadIdx.x == 1023) {  // (a thread of the last group: the scalars are ready when the partial sums are)
+  if (threadIdx.x == RED_THREADS - 1) {  // (a thread of the last group: the scalars are ready when the partial sums are)
     const double k = (double)ad.step[0] + 1.0;
     const double bc1 = 1.0 - pow((double)ad.beta1, k), bc2 = 1.0 - pow((double)ad.beta2, k);
     sc[0] = (float)(-(double)ad.lr / bc1);
     sc[1] = (float)sqrt(bc2);
   }
-  float s = 0.0f;
-  if (idx < np) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = g;
-    for (; b + 3 * RED_GROUPS < nslabs; b += 4 * RED_GROUPS) {
-      s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
-      s1 += slabs[(size_t)(b + RED_GROUPS) * NPARAMS_MAX + idx];
-      s2 += slabs[(size_t)(b + 2 * RED_GROUPS) * NPARAMS_MAX + idx];
-      s3 += slabs[(size_t)(b + 3 * RED_GROUPS) * NPARAMS_MAX + idx];
-    }
-    for (; b < nslabs; b += RED_GROUPS) s0 += slabs[(size_t)b * NPARAMS_MAX + idx];
-    s = (s0 + s1) + (s2 + s3);
-  }
-  part[g][p] = s;
-  __syncthreads();
-  if (g == 0 && idx < np) {
-    float t = 0.0f;
-#pragma unroll
-    for (int k = 0; k < RED_GROUPS; k++) t += part[k][p];
-    if (gscale) t *= gscale[0];
-    dparams[idx] = t;
+  int col;
+  const float4 t4 = slab_sum4(slabs, nslabs, np, part, &col);
+  if (threadIdx.x / RED_COLS == 0) {
+    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+    const float gs = gscale ? gscale[0] : 1.0f;
     const float neg_step_size = sc[0], bc2_sqrt = sc[1];
-    float gi = t * ad.grad_scale;
-    const float pi = ad.p[idx];
-    if (ad.weight_decay != 0.0f) gi = fmaf(ad.weight_decay, pi, gi);
-    float mi = ad.m[idx], vi = ad.v[idx];
-    mi = mi + (1.0f - ad.beta1) * (gi - mi);
-    vi = vi * ad.beta2 + (1.0f - ad.beta2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
-    ad.p[idx] = pi + neg_step_size * (mi / denom);
-    ad.m[idx] = mi;
-    ad.v[idx] = vi;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = 4 * col + k;
+      if (idx >= np) continue;
+      const float t = gscale ? tv[k] * gs : tv[k];
+      dparams[idx] = t;
+      float gi = t * ad.grad_scale;
+      const float pi = ad.p[idx];
+      if (ad.weight_decay != 0.0f) gi = fmaf(ad.weight_decay, pi, gi);
+      float mi = ad.m[idx], vi = ad.v[idx];
+      mi = mi + (1.0f - ad.beta1) * (gi - mi);
+      vi = vi * ad.beta2 + (1.0f - ad.beta2) * gi * gi;
+      const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
+      ad.p[idx] = pi + neg_step_size * (mi / denom);
+      ad.m[idx] = mi;
+      ad.v[idx] = vi;
+    }
   }
-  if (threadIdx.x == 1023) {
+  if (threadIdx.x == RED_THREADS - 1) {
     const unsigned mine = __hip_atomic_fetch_add(ad.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (mine == gridDim.x - 1) {
       __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1028,7 +1040,7 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
     hipLaunchKernelGGL((k_bwd_fused<PREC, false>), dim3(gf), dim3(512), FUSED_LDS, s, (const void*)img, (const void*)wt, beff,
                        emb, R, t, t_stride, dout, slabs, n, zstash, h0, nout, T);
   if (!dparams) return check_launch();  // partial slabs only: launch_slab_reduce follows (so3x_train_bwd_reduce)
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
+  hipLaunchKernelGGL(k_bwd_reduce, dim3(red_blocks(nparams(nout))), dim3(RED_THREADS), 0, s, (const float*)slabs, gf, dparams, 0, nparams(nout),
                      gscale);
   return check_launch();
 }
@@ -1037,7 +1049,7 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
 inline int launch_slab_reduce(hipStream_t s, const float* slabs, int64_t n, int nout, float* dparams, const float* gscale) {
   const int64_t nt = (n + 31) / 32;
   const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, slabs, gf, dparams, 0, nparams(nout), gscale);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3(red_blocks(nparams(nout))), dim3(RED_THREADS), 0, s, slabs, gf, dparams, 0, nparams(nout), gscale);
   return check_launch();
 }
 
@@ -1088,7 +1100,7 @@ int launch_bwd(hipStream_t s, const float* params, const float* R, const int64_t
       hipLaunchKernelGGL(k_bwd_dw, dim3(g2), dim3(512), DW_LDS, s, (const float*)stash, nc, slabs, nout);
     else
       hipLaunchKernelGGL(k_bwd_dw_bf16, dim3(g2), dim3(512), DW_LDS, s, (const __bf16*)stash, nc, slabs, nout);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((nparams(nout) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, s, (const float*)slabs, g2, dparams,
+    hipLaunchKernelGGL(k_bwd_reduce, dim3(red_blocks(nparams(nout))), dim3(RED_THREADS), 0, s, (const float*)slabs, g2, dparams,
                        c0 > 0 ? 1 : 0, nparams(nout));
   }
   return check_launch();
@@ -1234,7 +1246,7 @@ int so3x_train_bwd_reduce_adam(so3x_stream_t s, int64_t n, int T, const float* g
   const int64_t nt = (n + 31) / 32;
   const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
   AdamArgs ad{params, exp_avg, exp_avg_sq, step, reinterpret_cast<unsigned*>(step + 1), lr, beta1, beta2, eps, weight_decay, grad_scale};
-  hipLaunchKernelGGL(k_bwd_reduce_adam, dim3((nparams(3) + RED_PPB - 1) / RED_PPB), dim3(1024), 0, (hipStream_t)s,
+  hipLaunchKernelGGL(k_bwd_reduce_adam, dim3(red_blocks(nparams(3))), dim3(RED_THREADS), 0, (hipStream_t)s,
                      reinterpret_cast<const float*>((const char*)workspace + L.slabs), gf, grad, nparams(3), gscale, ad);
   return check_launch();
 }

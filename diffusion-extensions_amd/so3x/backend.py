@@ -23,6 +23,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "so3x.h")
 
 PREC_F32 = 0
 PREC_BF16 = 1
+PREC_F16 = 2  # so3x_p_sample_chain only: the bf16 path with IEEE half operand bits (a labelled extra leg, round 4)
 N_PARAMS = 17358
 N_PARAMS_ROTMAT = 17556  # out_type="rotmat": Linear(65, 6) head (reference so3_train.py:21-22)
 SCHED_ROWS = 13

@@ -202,7 +202,7 @@ class SO3Diffusion(nn.Module):
         if net is not None and same:
             return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
                                      seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
-                                     precision=net.precision_code, guide_p=self._guide_p)
+                                     precision=getattr(net, "chain_precision_code", net.precision_code), guide_p=self._guide_p)
         tt = t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device, dtype=torch.long)
         predict = self.denoise_fn(x, tt)
         _, mean = _b.p_mean(self._sched, x, predict, tt if not same else t0)
@@ -229,7 +229,7 @@ class SO3Diffusion(nn.Module):
             _, trap_p = self._tables()
             off = _rng.next_offset(T)
             return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, T - 1, T, seed=_rng.seed(),
-                                     rng_offset=off, index_base=self.index_base, precision=net.precision_code,
+                                     rng_offset=off, index_base=self.index_base, precision=getattr(net, "chain_precision_code", net.precision_code),
                                      guide_p=self._guide_p)
         for i in reversed(range(T)):
             x = self.p_sample(x, torch.full((b,), i, device=device, dtype=torch.long))

@@ -71,12 +71,24 @@ class RotPredict(FlatParamsMixin, nn.Module):
         # SO3Diffusion passes its num_timesteps per call (forward's t_table argument); this attribute is the
         # default for direct calls and may be set by a caller that knows its timestep range.
         self.t_table = 0
+        # "f16": the reverse chain (so3x_p_sample_chain) runs its bf16 path with IEEE half operand bits (precision "bf16" only; a
+        # labelled extra leg of round 4 -- three more mantissa bits and one instruction less per activation; training is untouched)
+        self.chain_operands = None
         # the 17,358 (skewvec) / 17,556 (rotmat) parameters live in ONE flat buffer in state_dict order; the nn.Linear
         # parameters are views of it (so3x.flat): flat_data() / flat_params() / flat_grad()
         self._init_flat()
 
     @property
     def precision_code(self) -> int:
+        return _PRECISIONS[self.precision]
+
+    @property
+    def chain_precision_code(self) -> int:
+        """the precision argument of the reverse-chain kernel: this network's, or the f16-operand leg of the bf16 path"""
+        if self.chain_operands not in (None, "f16"):
+            raise ValueError("chain_operands must be None or 'f16'")
+        if self.chain_operands == "f16" and self.precision == "bf16":
+            return _b.PREC_F16
         return _PRECISIONS[self.precision]
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, t_table: int = None, raw: bool = False):

@@ -41,6 +41,8 @@ extern "C" {
 /* MLP operand precision: rotation state and rotation math are always fp32. */
 #define SO3X_PREC_F32 0  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)                 */
 #define SO3X_PREC_BF16 1 /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+#define SO3X_PREC_F16 2   /* so3x_p_sample_chain ONLY (round 4): the bf16 path with IEEE half operand bits -- a labelled extra leg,
+                          * not the headline precision (BASELINE config 3 names bf16); same workspace sizes as SO3X_PREC_BF16 */
 
 #define SO3X_KNOTS 1000      /* CDF knots, distributions.py:15                    */
 #define SO3X_TRAP 999        /* CDF row length, distributions.py:26-30            */

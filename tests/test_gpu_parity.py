@@ -512,8 +512,9 @@ def test_chain_fp32_vs_oracle_stepwise(mods, golden, net):
     assert maxabs(host(xd @ xd.transpose(-1, -2)), np.eye(3)[None]) < 1e-4
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "f16-leg"])
 @pytest.mark.parametrize("t", [5, 300, 700])
-def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
+def test_chain_bf16_step_vs_oracle(mods, golden, net, t, prec):
     """bf16-operand chain step vs the fp64 oracle with the same Philox noise.  Covers both MFMA tiles of a wave
     (lanes 0..31 / 32..63 take different operand-exchange paths) and ragged tails."""
     B = mods["B"]
@@ -524,7 +525,7 @@ def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
     params_np = O.flat_params(golden["score_mlp"])
     n = 200
     x0 = O.quat_to_rmat(np.random.default_rng(t).standard_normal((n, 4)).astype(np.float32))
-    out = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=1))
+    out = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=prec))
     coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
     v = O.mlp_fwd(params_np, x0, np.full(n, t), "f64")
     _, ref = O.p_mean(x0, v, *coef, "f64")
@@ -539,8 +540,9 @@ def test_chain_bf16_step_vs_oracle(mods, golden, net, t):
     assert abs(np.median(err[lanes < 32]) - np.median(err[lanes >= 32])) < 2e-3 * max(1.0, coef[1])
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "f16-leg"])
 @pytest.mark.parametrize("t", [950, 998, 999])
-def test_chain_bf16_step_vs_oracle_at_the_head_of_the_chain(mods, golden, net, t):
+def test_chain_bf16_step_vs_oracle_at_the_head_of_the_chain(mods, golden, net, t, prec):
     """the SHIPPED bf16 chain kernel (256-entry SiLU table, hardware v_sin / v_cos behind v_fract range
     reduction, layer-0 bias split into bf16 + remainder) step-wise against the f64 oracle with the same Philox noise where the
     reverse step is hardest: t >= 950, where x0hat = so3_scale(x_t, a_t) @ exp(-b_t v) scales a matrix log by up to 20291 and
@@ -559,7 +561,7 @@ def test_chain_bf16_step_vs_oracle_at_the_head_of_the_chain(mods, golden, net, t
     params_np = O.flat_params(golden["score_mlp"])
     n = 640 + 37   # ten full waves and a ragged one
     x0 = O.quat_to_rmat(np.random.default_rng(t).standard_normal((n, 4)).astype(np.float32))
-    out = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=1))
+    out = host(B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, dev(x0), t, 1, seed=9, rng_offset=7, precision=prec))
     coef = [float(sched[i][t]) for i in (6, 7, 10, 11)]
     v = O.mlp_fwd(params_np, x0, np.full(n, t), "f64")
     x0h, ref = O.p_mean(x0, v, *coef, "f64")
@@ -687,7 +689,7 @@ def test_chain_bf16_hardware_trig_at_the_head_of_the_chain(mods, net, monkeypatc
         x = hw
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16+f16-operand chain"])
 @pytest.mark.parametrize("fixture", ["chain_samples_trained", "chain_samples_T1000"])
 def test_G3_full_chain_two_sample_test_vs_reference(mods, golden, net, prec, fixture):
     """Gate G3: 4096 samples of the full 1000-step chain must be statistically
@@ -705,7 +707,8 @@ def test_G3_full_chain_two_sample_test_vs_reference(mods, golden, net, prec, fix
     if "net_0_weight" in g:
         mynet.load_state_dict({f"net.{l}.{k}": torch.from_numpy(g[f"net_{l}_{k}"]) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")})
     mynet = mynet.to(DEV)
-    mynet.precision = prec
+    mynet.precision = prec.split("+")[0]
+    mynet.chain_operands = "f16" if "f16" in prec else None   # round 4's extra leg: the bf16 chain with IEEE half operand bits
     proc = mods["diff"].SO3Diffusion(mynet, timesteps=1000).to(DEV)
     rng.manual_seed(2024)
     x = proc.p_sample_loop((m,))
