@@ -435,9 +435,10 @@ class TrainBuffers:
         self.n, self.T = int(n), int(T)
         self.device = device
         f32 = dict(dtype=torch.float32, device=device)
-        self.loss = torch.zeros((1,), **f32)
+        # (every kernel that fills these writes all of them: nothing to clear -- two fill launches less per eager step)
+        self.loss = torch.zeros((1,), **f32) if staged else torch.empty((1,), **f32)
         self.workspace = torch.empty((int(l.so3x_train_workspace_bytes(C.c_int64(self.n), C.c_int(self.T))),), dtype=torch.uint8, device=device)
-        self.grad = torch.zeros((N_PARAMS,), **f32)
+        self.grad = torch.zeros((N_PARAMS,), **f32) if staged else torch.empty((N_PARAMS,), **f32)
         self.x_t = self.t_used = self.dout = self.zstash = self.out = None
         if staged:
             self.x_t = torch.empty((self.n, 3, 3), **f32)
