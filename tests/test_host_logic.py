@@ -40,14 +40,16 @@ def test_no_oracle_or_cpu_fallback_in_product():
 
 def test_product_library_has_no_environment_switches():
     """libso3x.so reads no environment variable (getenv races with setenv, and an exported variable must never change
-    arithmetic) and ships ONE bf16 form of the chain kernel; the A/B forms live in libso3x_ab.so (-DSO3X_AB_BUILD), which
+    arithmetic) and ships ONE bf16 form of the chain kernel (plus its f16-operand leg, selected by the precision argument); the A/B forms live in libso3x_ab.so (-DSO3X_AB_BUILD), which
     only tools/ab and one parity test load by path."""
     dyn = subprocess.run(["nm", "-D", "--undefined-only", B.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in dyn
     syms = subprocess.run(["nm", B.LIB_PATH], capture_output=True, text=True, check=True).stdout  # mangled: I<PREC>E... = template args
     stubs = [l for l in syms.splitlines() if "__device_stub__k_p_sample_chainI" in l]
-    assert len(stubs) == 2, stubs   # <fp32 parity form>, <bf16 product form>
-    assert sum("k_p_sample_chainILi1E" in l for l in stubs) == 1
+    # <fp32 parity form>, <bf16 product form>, and (round 4) the product form's f16-operand leg -- a precision argument of the C ABI
+    # (SO3X_PREC_F16), not an environment switch
+    assert len(stubs) == 3, stubs
+    assert sum("k_p_sample_chainILi1ELb1ELb1ELb1ELb0E" in l for l in stubs) == 1 and sum("k_p_sample_chainILi1ELb1ELb1ELb1ELb1E" in l for l in stubs) == 1
     assert not any("k_train_fwdI" in l for l in syms.splitlines())   # the fused noising + forward experiment is A/B-only too
     ab = os.path.join(os.path.dirname(B.LIB_PATH), "libso3x_ab.so")
     assert os.path.exists(ab), "make -C csrc builds the A/B library beside the product one"

@@ -18,7 +18,8 @@ KNOWN = {
     "k_logprob_score": (16, "call frame of the out-of-line fp64 branch for an EXACT identity input (distributions.py:68-71); never "
                             "touched otherwise -- inlining the fp64 code would cost the streaming kernel a wave of occupancy"),
     "k_bwd_fused<1, false>": (512, "backward that recomputes the forward: kept for callers without a stash, not what training runs"),
-    "k_p_sample_chain<1, true, true, true, true>": (32, "the f16-operand LEG of the chain kernel (SO3X_PREC_F16, a labelled extra measured 8 % slower "
+    # (c++filt does not demangle this one: the key is the mangled prefix -- <bf16, FAST, PAIR, WIDE, F16 = true>)
+    "_ZN12_GLOBAL__N_116k_p_sample_chainILi1ELb1ELb1ELb1ELb1E": (32, "the f16-operand LEG of the chain kernel (SO3X_PREC_F16, a labelled extra measured 8 % slower "
                                                         "than the bf16 headline kernel: profiles/r04_ab_chain_f16_operands.json): 256 registers + 6 spilled dwords"),
     "k_bwd_stage<1, 1>": (64, "generic staged backward, bf16 with unbounded timesteps: parity / fallback path"),
 }
