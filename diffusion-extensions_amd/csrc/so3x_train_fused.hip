@@ -35,14 +35,22 @@ namespace {
 
 constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_TD, FB = frag_bytes<PREC>();
 constexpr int IMG = image_bytes<PREC, VAR>();                 // 53 fragments + the 4 KB (silu, silu') table
-constexpr int WTB = wt_bytes<PREC>();                         // transposed image: 48 fragments
 constexpr int REC_DW = 8;                                     // hand-over record of a sample: x_t as 5 bf16 pairs, target[3]
 constexpr int HAND_BYTES = 128 * REC_DW * 4 + 128 * 4;        // ... + the timesteps
-// LDS: the hand-over images FIRST -- their 150 distinct read / store addresses per round are (per-lane base) + constant, and a
-// DS instruction's offset field holds 16 bits: behind the 107 KB of weight images every one of them cost an address register
-// (60 VGPRs in the dW waves, beside 160 accumulators) -- then the hand-over records, the loss scratch, the two weight images
-constexpr int LDS_FIMG = 0, LDS_HAND = LDS_FIMG + 4 * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES, LDS_IMG = LDS_RED + 128;
-constexpr int LDS_WT = LDS_IMG + IMG, LDS_TOTAL = LDS_WT + WTB;
+// LDS: the hand-over images FIRST -- two per chain wave: image (p, w) at (4 p + w) FIMG_BYTES -- their 150 distinct read / store
+// addresses per round are (per-lane base) + constant, and a DS instruction's offset field holds 16 bits: behind the weight image
+// every one of them cost an address register (60 VGPRs in the dW waves, beside 160 accumulators) -- then the hand-over records,
+// the loss scratch and the hand-shake words, the forward's weight image.  The TRANSPOSED weight image (the A operands of
+// dH = W^T dZ, 48 KB) stays in global memory: it is the same for every workgroup and L2-resident, a layer's fragments are
+// fetched one layer ahead (so3x_train_fused's chain role), and its place in LDS went to the second set of images.
+#ifdef TF_DB
+constexpr bool DB = true;
+#else
+constexpr bool DB = false;
+#endif
+constexpr int WTB = wt_bytes<PREC>();                         // transposed image: 48 fragments
+constexpr int LDS_FIMG = 0, LDS_HAND = LDS_FIMG + (DB ? 8 : 4) * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES, LDS_IMG = LDS_RED + 256;
+constexpr int LDS_WT = LDS_IMG + IMG, LDS_TOTAL = LDS_WT + (DB ? 0 : WTB);
 static_assert(LDS_TOTAL <= 160 * 1024 && LDS_HAND % 16 == 0 && LDS_IMG % 16 == 0, "one workgroup per CU");
 
 __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
@@ -168,6 +176,79 @@ __device__ __forceinline__ void operand_of(const uint32_t (&hp)[17], Tile<PREC>&
   t.b[4] = __builtin_bit_cast(bf16x8, u32x4_t{hp[16], 0u, 0u, 0u});
 }
 
+// One hidden layer of the forward, MFMAs and activation as ONE stream: output tile 0's five MFMAs, then its sixteen activations
+// with the ten MFMAs of tiles 1 and 2 issued INTO the LDS round trips of its lookup groups (a lone wave waits ~100 cycles per group
+// there, and a 32-cycle MFMA issue slot is as good a use of the wait as any), then tiles 1 and 2's activations.  hidden_layer +
+// activate_td one after the other left the matrix pipe idle through 1.3 k cycles of activation and the wave idle through the
+// MFMAs' 0.5 k.
+__device__ __forceinline__ void hidden_fwd_td(const char* __restrict__ wl, const Tile<PREC>& in, f32x16 (&acc)[3], uint32_t (&hp)[17],
+                                              uint32_t (&dp)[17], int h, const char* tab, int lane) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+  constexpr int G = 4, NG = 8;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 a = zero16<PREC>();
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) a = mfma_bf16(w[ks * 64 + lane], in.b[ks], a);
+    acc[0] = a;
+  }
+  acc[1] = zero16<PREC>();
+  acc[2] = zero16<PREC>();
+  float4 e[2][G];
+  float u[2][G];
+  auto lookups = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+      const int q = G * g + i;
+      u[g & 1][i] = acc[q >> 4][q & 15];
+      const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[g & 1][i], 0u, 0u);  // round to nearest, saturated to 0..255
+      e[g & 1][i] = *reinterpret_cast<const float4*>(tab + idx * 16);
+    }
+  };
+  auto mm = [&](int m) {  // MFMA m of tiles 1, 2: (to, ks) = (1 + m / 5, m % 5)
+    const int to = 1 + m / 5, ks = m % 5;
+    acc[to] = mfma_bf16(w[((to * 5) + ks) * 64 + lane], in.b[ks], acc[to]);
+  };
+  __builtin_amdgcn_sched_barrier(0);
+  lookups(0);
+  float4 el;
+  float ul = 0.0f;
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    // tile 1 has to be complete in front of group 3's look-ahead (its values are group 4's), tile 2 in front of the last value
+    if (g == 0) { mm(0); mm(1); mm(2); }
+    if (g == 1) { mm(3); mm(4); mm(5); }
+    if (g == 2) { mm(6); mm(7); }
+    if (g == 3) { mm(8); mm(9); }
+    if (g + 1 < NG) lookups(g + 1);
+    else { ul = acc[2][0]; el = *reinterpret_cast<const float4*>(tab + __builtin_amdgcn_cvt_pk_u8_f32(ul, 0u, 0u) * 16); }
+#pragma unroll
+    for (int i = 0; i < G; i += 2) {
+      const float4 e0 = e[g & 1][i], e1 = e[g & 1][i + 1];
+      const float u0 = u[g & 1][i], u1 = u[g & 1][i + 1];
+      const int wd = (G * g + i) >> 1;
+      hp[wd] = pack_bf16x2(fmaf(e0.y, u0, e0.x), fmaf(e1.y, u1, e1.x));
+      dp[wd] = pack_f16x2(fmaf(e0.w, u0, e0.z), fmaf(e1.w, u1, e1.z));
+      asm volatile("" : "+v"(hp[wd]), "+v"(dp[wd]));   // (the packed words are the parked state: see activate_td)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  hp[16] = h ? 0x3F803F80u : pack_bf16x2(fmaf(el.y, ul, el.x), 0.0f);
+  dp[16] = h ? 0u : pack_f16x2(fmaf(el.w, ul, el.z), 0.0f);
+  asm volatile("" : "+v"(hp[16]), "+v"(dp[16]));
+}
+
+// the A operands of dH_L = W_L^T dZ_L, [to][ks], from the transposed image in global memory
+template <int L, int TO0, int TO1>
+__device__ __forceinline__ void fetch_wt(const void* __restrict__ gwt, bf16x8 (&wf)[15], int lane) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(gwt);
+  constexpr int KS = L < 4 ? 5 : 1;
+#pragma unroll
+  for (int to = TO0; to < TO1; to++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) wf[to * KS + ks] = w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane];
+}
+
 // ---- the dW waves: k_bwd_fused's dW role (so3x_mlp_bwd.hip) + the noising of the tiles ahead -----------------------------------
 struct Geo { int64_t n, ntiles, nchain, rounds; };
 // -DTF_STAMPS (timing build, tools/ab/fused_stamps.py; results of `out` destroyed): workgroup 0's chain wave 0 and dW wave 0 leave
@@ -179,6 +260,58 @@ struct Geo { int64_t n, ntiles, nchain, rounds; };
 #define TF_STAMP(role, k) do { } while (0)
 #endif
 constexpr int RING = 3;  // operand ring of the dW products: stages (image, k-step) in flight, 16 registers each
+
+// ---- hand-shakes per IMAGE instead of workgroup barriers (round 4, second half) -------------------------------------------------
+// With two s_barriers per layer the chain waves stored a layer's images (18 ds_write_b64 each, 25 cycles apiece through a wave's
+// LDS queue: tools/ab/lds_bench.hip), THEN the dW waves took their 64 transposed reads per layer (22 cycles apiece: 1.4 k), and
+// neither did the one while the other happened: 2.6 k cycles per layer.  Now a chain wave owns TWO images and alternates between
+// them from layer to layer -- layer index k = 4 - l goes to image p = (k + 1) & 1: [1 0 1 0 1], the same in every round, so the
+// parity is a compile-time constant everywhere -- and announces the n-th filling of image (w, p) as ready[w][p] = n + 1; the dW
+// waves walk the four waves' images in order, wait for each one's filling, and count themselves out of it behind their last
+// read (done[w][p] += 1); the chain wave refills an image once done[w][p] = 4 n.  So the chain waves run up to a layer ahead
+// of the dW waves instead of in lock-step with them.  handed[w] = the round whose records the wave's dW partner has put into
+// the hand-over buffer.  One wave's LDS operations are processed in issue order, so a flag written behind the data is seen
+// behind the data; the accesses are inline assembly with a memory clobber so that the compiler keeps that order too.  Every
+// wait gives up after ~0.1 s (a wrong result instead of a hung GPU).
+constexpr int LDS_READY = LDS_RED + 80, LDS_DONE = LDS_RED + 112, LDS_HANDED = LDS_RED + 144;   // [4][2], [4][2], [4] words
+static_assert(LDS_HANDED + 16 <= LDS_IMG, "the flags live behind the loss scratch");
+__device__ __forceinline__ constexpr int img_parity(int k) { return DB ? (k + 1) & 1 : 0; }
+// how many fillings image (w, img_parity(k)) has had in front of round rd's layer index k
+__device__ __forceinline__ uint32_t img_seq(int64_t rd, int k) {
+  if (!DB) return 5u * (uint32_t)rd + (uint32_t)k;
+  return img_parity(k) ? 3u * (uint32_t)rd + (uint32_t)(k >> 1) : 2u * (uint32_t)rd + (uint32_t)(k >> 1);
+}
+__device__ __forceinline__ uint32_t lds_peek(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void lds_wait_ge(uint32_t addr, uint32_t target) {
+  int spins = 0;
+  while ((int32_t)(lds_peek(addr) - target) < 0) {
+#ifndef TF_NOSLEEP
+    __builtin_amdgcn_s_sleep(1);
+#endif
+    if (++spins > (1 << 21)) break;
+  }
+}
+// The same wait with the word READ EARLY: `seen` was loaded (lds_early) some hundred cycles ahead, as an ordinary LDS load in
+// the wave's stream -- looking at it costs no drain of the wave's LDS queue (lds_peek's s_waitcnt lgkmcnt(0) does: in the dW
+// waves that emptied the operand ring in front of every image, ~200 cycles four times a layer).  A stale "not yet" falls back
+// to the polling loop; nothing that follows may be moved in front of the check (the empty asm is the compiler's fence).
+__device__ __forceinline__ uint32_t lds_early(const char* lds, uint32_t addr) {
+  return *reinterpret_cast<const volatile uint32_t*>(lds + addr);
+}
+__device__ __forceinline__ void lds_wait_ge_seen(uint32_t seen, uint32_t addr, uint32_t target) {
+  if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) - target) < 0) lds_wait_ge(addr, target);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_post(uint32_t addr, uint32_t val) {   // every lane writes the same word
+  asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(val) : "memory");
+}
+__device__ __forceinline__ void lds_count(uint32_t addr, int lane) {      // + 1, once per wave
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(1u) : "memory");
+}
 
 template <int DWI, bool EXPLICIT>
 __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t,
@@ -209,49 +342,46 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
   };
   Hand hd = pass(0);
   if (h == 0) hand_over(hd);
-  __syncthreads();  // P: round 0's samples are in the hand-over buffer
-  FimgReadLane RL = fimg_read_lane(lane);
+  __syncthreads();  // P: round 0's samples are in the hand-over buffer (the last workgroup barrier before the loss)
+  FimgReadLane RL = fimg_read_lane(lane), RH;  // RH: the same lane offsets into the second set of images (beyond an offset field)
   for (int64_t rd = 0; rd < g.rounds; rd++) {
     asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
+#pragma unroll
+    for (int i = 0; i < 4; i++) RH.off[i >> 1][i & 1] = RL.off[i >> 1][i & 1] + 4 * FIMG_BYTES;
+    asm volatile("" : "+v"(RH.off[0][0]), "+v"(RH.off[0][1]), "+v"(RH.off[1][0]), "+v"(RH.off[1][1]));
     if (DWI == 0) TF_STAMP(1, 0);
 #pragma unroll
     for (int l = 4; l >= 0; l--) {
-      __syncthreads();  // B1: images of layer l complete
-      if (DWI == 0) TF_STAMP(1, 2 + 3 * (4 - l));
+      const int P = img_parity(4 - l);
+      const uint32_t v = img_seq(rd, 4 - l) + 1u;   // the filling of the images (., P) this layer's products read
+      const FimgReadLane& RP = P ? RH : RL;
       if (l == 4) {
-        // the chain waves read round rd's records before this barrier and read round rd + 1's behind the round's last one
+        // the partner chain wave has read round rd's records once its forward is through, i.e. once its layer-4 image is out:
+        // then round rd + 1's go in, and the partner may take them in front of its layer-0 stores
+        lds_wait_ge(LDS_READY + 8 * DWI + 4 * P, v);
         if (h == (int)((rd & 1) ^ 1)) hand_over(hd);
+        lds_post(LDS_HANDED + 4 * DWI, (uint32_t)rd + 1u);
       }
+      if (DWI == 0) TF_STAMP(1, 2 + 3 * (4 - l));
       // The layer's products as EIGHT stages (image w, k-step ks) through a RING-slot operand ring: the transposed reads of
-      // stage s + RING - 1 are issued in front of the MFMAs of stage s.  Left to itself the compiler reused two operand registers for
-      // every MFMA -- read, s_waitcnt lgkmcnt(0), MFMA, 24 times per layer: an LDS round trip per MFMA, and this phase (not
-      // the chain waves' dH) was what every layer of the backward waited for.
-      if (l == 4) {
-        if (DWI < 3) {
-          bf16x8 ra[RING], rb[RING];
-          auto load4 = [&](int st) {
-            const char* im = fimg_all + (st >> 1) * FIMG_BYTES;
-            ra[st % RING] = fimg_frag(im, RL, 0, st & 1);
-            rb[st % RING] = fimg_frag(im, RL, 96 + 32 * DWI, st & 1);
-          };
-#pragma unroll
-          for (int st = 0; st < RING - 1; st++) load4(st);
-#pragma unroll
-          for (int st = 0; st < 8; st++) {
-            if (st + RING - 1 < 8) load4(st + RING - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[9] = mfma_bf16(ra[st % RING], rb[st % RING], acc[9]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      } else if (dw_row(DWI, l) != 3) {
-        const int to = dw_row(DWI, l), sl = dw_slot(DWI, l);
-        bf16x8 ra[RING], rb[RING][3];
+      // stage s + RING - 1 are issued in front of the MFMAs of stage s (left to itself the compiler reused two operand registers
+      // for every MFMA: an LDS round trip per MFMA).  An image's first stage waits for its version, its last counts the wave out.
+      if (l == 4 ? DWI < 3 : dw_row(DWI, l) != 3) {
+        const int to = l == 4 ? 0 : dw_row(DWI, l), sl = l == 4 ? 3 : dw_slot(DWI, l);
+        constexpr int NB = 3;
+        bf16x8 ra[RING], rb[RING][NB];
+        uint32_t seen = lds_early(lds, LDS_READY + 4 * P);   // image 0's word; image w + 1's is read behind image w's first stage
         auto load = [&](int st) {
+          if ((st & 1) == 0) lds_wait_ge_seen(seen, LDS_READY + 8 * (st >> 1) + 4 * P, v);
           const char* im = fimg_all + (st >> 1) * FIMG_BYTES;
-          ra[st % RING] = fimg_frag(im, RL, 32 * to, st & 1);
+          ra[st % RING] = fimg_frag(im, RP, 32 * to, st & 1);
+          if (l == 4) rb[st % RING][0] = fimg_frag(im, RP, 96 + 32 * DWI, st & 1);
+          else {
 #pragma unroll
-          for (int ti = 0; ti < 3; ti++) rb[st % RING][ti] = fimg_frag(im, RL, 96 + 32 * ti, st & 1);
+            for (int ti = 0; ti < 3; ti++) rb[st % RING][ti] = fimg_frag(im, RP, 96 + 32 * ti, st & 1);
+          }
+          if (st & 1) lds_count(LDS_DONE + 8 * (st >> 1) + 4 * P, lane);
+          else if (st < 6) seen = lds_early(lds, LDS_READY + 8 * ((st >> 1) + 1) + 4 * P);
         };
 #pragma unroll
         for (int st = 0; st < RING - 1; st++) load(st);
@@ -259,17 +389,25 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
         for (int st = 0; st < 8; st++) {
           if (st + RING - 1 < 8) load(st + RING - 1);
           __builtin_amdgcn_sched_barrier(0);
+          if (l == 4) acc[9] = mfma_bf16(ra[st % RING], rb[st % RING][0], acc[9]);
+          else {
 #pragma unroll
-          for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(ra[st % RING], rb[st % RING][ti], acc[3 * sl + ti]);
+            for (int ti = 0; ti < 3; ti++) acc[3 * sl + ti] = mfma_bf16(ra[st % RING], rb[st % RING][ti], acc[3 * sl + ti]);
+          }
           __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {  // the wave without a row in this layer: it still counts itself out of every image (once the image exists)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          lds_wait_ge(LDS_READY + 8 * w + 4 * P, v);
+          lds_count(LDS_DONE + 8 * w + 4 * P, lane);
         }
       }
       if (DWI == 0) TF_STAMP(1, 3 + 3 * (4 - l));
       // behind an even round's last products: the samples of rounds rd + 2, rd + 3 are drawn while the chain waves run the NEXT
-      // round's forward (which they start behind this layer's first barrier; the images are idle until their second)
+      // round's forward (the images are idle until its end)
       if (l == 0 && !(rd & 1)) hd = pass(rd + 2);
       if (DWI == 0 && l == 0) TF_STAMP(1, 1);
-      __syncthreads();  // B2: done with the images
       if (DWI == 0) TF_STAMP(1, 4 + 3 * (4 - l));
     }
   }
@@ -306,18 +444,21 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
               const uint4* __restrict__ h0_tab, NoiseArgs na, float* __restrict__ x_t_out, float* __restrict__ out,
               float* __restrict__ slabs, int64_t n, LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef TF_STAMPS
+  const uint64_t t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   char* img_lds = lds + LDS_IMG;
-  char* wt_lds = lds + LDS_WT;
   char* fimg_all = lds + LDS_FIMG;
   load_image(gimg, img_lds, IMG);
-  load_image(gwt, wt_lds, WTB);
-  for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  if (!DB) load_image(gwt, lds + LDS_WT, WTB);
+  for (int i = threadIdx.x; i < (DB ? 8 : 4) * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 20) reinterpret_cast<uint32_t*>(lds + LDS_READY)[threadIdx.x] = 0u;  // ready[4][2], done[4][2], handed[4]
   Geo g;
   g.n = n;
   g.ntiles = (n + 31) / 32;
   g.nchain = (int64_t)gridDim.x * 4;
-  g.rounds = (g.ntiles + g.nchain - 1) / g.nchain;  // uniform trip count: the barriers are block-wide
+  g.rounds = (g.ntiles + g.nchain - 1) / g.nchain;  // uniform trip count: every wave takes part in every round's hand-shakes
   uint64_t rng_offset = na.rng_offset;
   if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];  // device-resident part of the counter (hipGraph replays)
   __syncthreads();  // S0: images, tables
@@ -335,10 +476,10 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
     FimgStoreLane SL = fimg_store_lane(col);
     __syncthreads();  // P
     // A round's inputs: the samples the dW waves handed over (x_t as bf16 pairs, target, timestep) and the timestep's effective-bias
-    // row (nine 16-byte gathers from L2, per lane).  They are fetched a round AHEAD -- behind the round's last first barrier, while
-    // the dW waves take the layer-0 products -- so the row's L2 round trip (2.5 k cycles at the top of every round when it was
-    // fetched there) and the last barrier's wait (1.1 k) lie under the dW waves' work, and the forward starts on registers.
-    uint32_t xb[5];
+    // row (nine 16-byte gathers from L2, per lane).  They are fetched a round AHEAD -- behind the round's last image, while the dW
+    // waves take the layer-0 products -- so the row's L2 round trip (2.5 k cycles at the top of every round when it was fetched
+    // there) lies under the dW waves' work, and the forward starts on registers.
+    uint32_t xb[5], xbn[5];
     float tg[3];
     int tt;
     float4 bq[9];
@@ -347,7 +488,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
       //  load -- every element came back as element 0; so3x_mlp_bwd.hip's zstash_load_layer met the same bug)
       const uint4 r0 = *reinterpret_cast<const uint4*>(rec), r1 = *reinterpret_cast<const uint4*>(rec + 4);
       tt = *ht;
-      xb[0] = r0.x; xb[1] = r0.y; xb[2] = r0.z; xb[3] = r0.w; xb[4] = r1.x;
+      xbn[0] = r0.x; xbn[1] = r0.y; xbn[2] = r0.z; xbn[3] = r0.w; xbn[4] = r1.x;
       tg[0] = __uint_as_float(r1.y); tg[1] = __uint_as_float(r1.z); tg[2] = __uint_as_float(r1.w);
       const float* beff = beff_tab + (size_t)tt * 96;
 #pragma unroll
@@ -355,6 +496,8 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
     };
     load_top();
     for (int64_t rd = 0; rd < g.rounds; rd++) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) xb[i] = xbn[i];
       asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per round: no hoisting of the ~90 store addresses
       // ... and none of the 101 weight-fragment reads: the images are loop-invariant, and hoisted out of the round loop they
       // are 400 registers' worth of spills (seen: 2.4 KB of scratch per lane)
@@ -396,10 +539,12 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
       for (int l = 1; l < 4; l++) {
         Tile<PREC> cur;
         operand_of(hpk[l - 1], cur);
-        hidden_layer<PREC, 3>(img_lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, lane_r);
-        activate_td(acc, hpk[l], dpk[l], h, tab);
+        hidden_fwd_td(img_lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, hpk[l], dpk[l], h, tab, lane_r);
       }
       if (wid == 0) TF_STAMP(0, 3);
+      bf16x8 wf[15];  // W^T fragments of the dH that comes next (global memory, L2-resident: see the LDS layout above)
+      if (DB) fetch_wt<4, 0, 3>(gwt, wf, lane_r);
+      uint32_t seen_done = lds_early(lds, LDS_DONE + 8 * wid + 4 * img_parity(0));
       f32x16 last[1];
       {
         Tile<PREC> cur;
@@ -420,29 +565,83 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
         pdz[0] = pack_bf16x2(d0 * sc, d1 * sc);
         pdz[1] = pack_bf16x2(d2 * sc, 0.0f);
       }
-      // the previous round's LAST barrier, deferred to here: this round's forward ran beside the dW waves' layer-0 products of the
-      // previous one (it touches no image); the first image store below is what has to wait for them
-      if (rd > 0) __syncthreads();  // B2 of layer 0, round rd - 1
       uint4 hq[6];
-      // ---- backward:   [write images of layer l] B1 [dH_l, dZ_{l-1}] B2
+      // ---- backward, per layer index k = 4 - l:   wait until the dW waves are out of the image's previous filling (two layers
+      // back: never, in the steady state) -- the image's 18 stores INTERLEAVED with the MFMAs of dH_l = W_l^T dZ_l (both read
+      // the packed dZ_l; a wave's LDS queue takes a store per 25 cycles, the matrix pipe an MFMA per 32: one hides the other)
+      // -- announce the image -- dZ_{l-1} = dH_l * silu'(Z_{l-1}), with the next layer's W^T fragments in flight from L2
       f32x16 dh[3];
+      // (the dW waves' count for the image about to be refilled is read a phase ahead -- here in front of the head, below in front
+      //  of each layer's multiplies -- and looked at in front of the stores: no LDS round trip in the chain's critical path)
       if (wid == 0) TF_STAMP(0, 4);
 #pragma unroll
       for (int l = 4; l >= 0; l--) {
-#pragma unroll
-        for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 2 * c8 + h, pdz[2 * c8], pdz[2 * c8 + 1]);
-        fimg_store_pk(my_img, SL, 16 + h, h ? 0u : pdz[16], 0u);
+        const int P = img_parity(4 - l);
+        const uint32_t nfill = img_seq(rd, 4 - l);
+        char* img_p = my_img + P * 4 * FIMG_BYTES;
+        asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per layer: the ~20 store addresses are made where they are used
+        if (l == 0) {
+          // the next round's samples and bias row, IN FRONT of this round's last image: the row's L2 round trip (1 k cycles at the
+          // top of the forward when the gathers were issued behind the image) flies under the stores
+          lds_wait_ge(LDS_HANDED + 4 * wid, (uint32_t)rd + 1u);  // the partner put them in behind this round's first image
+          load_top();
+        }
+#ifndef TF_NODONE
+        lds_wait_ge_seen(seen_done, LDS_DONE + 8 * wid + 4 * P, 4u * nfill);
+#endif
+        if (wid == 0) TF_STAMP(0, 5 + 4 * (4 - l));
         if (l > 0) {
           const uint32_t (&ph)[17] = hpk[l - 1];  // H_l = silu(Z_{l-1}): the forward's operand bits
+          // the stores' addresses: chunk 2 C + h of this lane's row sits at rowbase + ((16 C + 8 h) ^ swizzle), and the swizzle
+          // touches bits 3..6 only -- eight bases sb[C & 7], the rest of C is an instruction offset (36 address operations
+          // per layer otherwise)
+          char* sb[8];
 #pragma unroll
-          for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(my_img, SL, 24 + 2 * c8 + h, ph[2 * c8], ph[2 * c8 + 1]);
-          fimg_store_pk(my_img, SL, 24 + 16 + h, ph[16], 0u);
+          for (int c = 0; c < 8; c++) sb[c] = img_p + SL.rowbase + (((2 * c + h) * 8) ^ SL.swz8);
+          auto put = [&](int C, uint32_t lo, uint32_t hi) { *reinterpret_cast<uint2*>(sb[C & 7] + (C >> 3) * 128) = uint2{lo, hi}; };
+          auto store = [&](int i) {  // store i of the image's 18: the dZ_l block (C = 0..8), then the H_l block (C = 12..20)
+            if (i < 8) put(i, pdz[2 * i], pdz[2 * i + 1]);
+            else if (i == 8) put(8, h ? 0u : pdz[16], 0u);
+            else if (i < 17) put(12 + i - 9, ph[2 * (i - 9)], ph[2 * (i - 9) + 1]);
+            else put(20, ph[16], 0u);
+          };
+          const int KS = l < 4 ? 5 : 1, NM = 3 * KS;
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          bf16x8 bop[5];
+#pragma unroll
+          for (int ks = 0; ks < 5; ks++) {
+            const u32x4 v = ks < 4 ? u32x4{pdz[4 * ks], pdz[4 * ks + 1], pdz[4 * ks + 2], pdz[4 * ks + 3]} : u32x4{pdz[16], 0u, 0u, 0u};
+            bop[ks] = __builtin_bit_cast(bf16x8, v);
+          }
+          // (LDS-resident W^T: a fragment is read three MFMAs ahead of its use, through a four-slot ring -- one wave's LDS operations
+          //  complete in order, so a read issued behind the stores would wait for them, and the MFMA for the read)
+          bf16x8 wring[4];
+          auto wread = [&](int m) {
+            wring[m & 3] = reinterpret_cast<const bf16x8*>(lds + LDS_WT)[(size_t)wt_frag<PREC>(l, m / KS, m % KS) * 64 + lane_r];
+          };
+          if (!DB) {
+#pragma unroll
+            for (int m = 0; m < 3 && m < NM; m++) wread(m);
+          }
+#pragma unroll
+          for (int m = 0; m < NM; m++) {
+            if (!DB && m + 3 < NM) wread(m + 3);
+#pragma unroll
+            for (int i = m * 18 / NM; i < (m + 1) * 18 / NM; i++) store(i);
+            __builtin_amdgcn_sched_barrier(0);
+            const int to = m / KS, ks = m % KS;
+            dh[to] = mfma_bf16(DB ? wf[m] : wring[m & 3], bop[ks], ks == 0 ? zero16<PREC>() : dh[to]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else {  // H_0 = the network input: [0..8] R, [9] one, [10..65] emb(t), zeros; the two lanes of a column split the row
+#pragma unroll
+          for (int c8 = 0; c8 < 8; c8++) fimg_store_pk(img_p, SL, 2 * c8 + h, pdz[2 * c8], pdz[2 * c8 + 1]);
+          fimg_store_pk(img_p, SL, 16 + h, h ? 0u : pdz[16], 0u);
           const uint32_t hd[24] = {hq[0].x, hq[0].y, hq[0].z, hq[0].w, hq[1].x, hq[1].y, hq[1].z, hq[1].w, hq[2].x, hq[2].y, hq[2].z, hq[2].w,
                                    hq[3].x, hq[3].y, hq[3].z, hq[3].w, hq[4].x, hq[4].y, hq[4].z, hq[4].w, hq[5].x, hq[5].y, hq[5].z, hq[5].w};
 #pragma unroll
           for (int c4 = 0; c4 < 12; c4++) {
-            const int ch0 = 24 + 12 * h + c4;  // chunk of the 4 consecutive input slots 48 h + 4 c4 ..
+            const int ch0 = 24 + 12 * (lane_r >> 5) + c4;  // chunk of the 4 consecutive input slots 48 h + 4 c4 .. (h from the opaque lane: no hoisting)
             uint32_t lo = hd[2 * c4], hi = hd[2 * c4 + 1];
             if (c4 < 3) {  // the lower half's first three chunks carry the rotation entries and the constant one
               const uint32_t plo = c4 == 0 ? xb[0] : (c4 == 1 ? xb[2] : xb[4]);
@@ -450,40 +649,43 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
               lo = h ? lo : plo;
               hi = h ? hi : phi;
             }
-            fimg_store_pk(my_img, SL, ch0, live ? lo : 0u, live ? hi : 0u);
+            fimg_store_pk(img_p, SL, ch0, live ? lo : 0u, live ? hi : 0u);
           }
         }
-        if (wid == 0) TF_STAMP(0, 5 + 4 * (4 - l));
-        __syncthreads();  // B1: images of layer l complete -- the dW waves consume them while this wave goes on
+        lds_post(LDS_READY + 8 * wid + 4 * P, nfill + 1u);
         if (wid == 0) TF_STAMP(0, 6 + 4 * (4 - l));
         if (l > 0) {
-          if (l == 4) dh_layer_pk<PREC, 4>(wt_lds, pdz, dh, lane_r);
-          if (l == 3) dh_layer_pk<PREC, 3>(wt_lds, pdz, dh, lane_r);
-          if (l == 2) dh_layer_pk<PREC, 2>(wt_lds, pdz, dh, lane_r);
-          if (l == 1) dh_layer_pk<PREC, 1>(wt_lds, pdz, dh, lane_r);
+          // the fragments of the NEXT dH: its first tile's ahead of the multiplies, the other two's behind them (dH's 48
+          // registers are free then) -- under the next wait, the next stores' addresses and the first tile's MFMAs
+          if (DB && l == 4) fetch_wt<3, 0, 1>(gwt, wf, lane_r);
+          if (DB && l == 3) fetch_wt<2, 0, 1>(gwt, wf, lane_r);
+          if (DB && l == 2) fetch_wt<1, 0, 1>(gwt, wf, lane_r);
+          seen_done = lds_early(lds, LDS_DONE + 8 * wid + 4 * img_parity(4 - l + 1));
           const uint32_t (&dp)[17] = dpk[l - 1];  // silu'(Z_{l-1}), parked by the forward
 #pragma unroll
           for (int r = 0; r < 16; r++) {
-            const float g0 = (r < 8 ? dh[0][2 * r] : dh[1][2 * r - 16]) * f16_lo(dp[r]);
-            const float g1 = (r < 8 ? dh[0][2 * r + 1] : dh[1][2 * r - 15]) * f16_hi(dp[r]);
+            // (as fused multiply-adds with a zero addend: v_fma_mix_f32 takes the f16 half as it is -- one instruction, not convert + multiply)
+            const float g0 = __builtin_fmaf(r < 8 ? dh[0][2 * r] : dh[1][2 * r - 16], f16_lo(dp[r]), 0.0f);
+            const float g1 = __builtin_fmaf(r < 8 ? dh[0][2 * r + 1] : dh[1][2 * r - 15], f16_hi(dp[r]), 0.0f);
             pdz[r] = pack_bf16x2(g0, g1);
           }
           pdz[16] = pack_bf16x2(h ? 0.0f : dh[2][0] * f16_lo(dp[16]), 0.0f);  // upper half of tile 2 / reg 0 = the constant-one row
+#pragma unroll
+          for (int r = 0; r < 17; r++) asm volatile("" : "+v"(pdz[r]));
+          if (DB && l == 4) fetch_wt<3, 1, 3>(gwt, wf, lane_r);
+          if (DB && l == 3) fetch_wt<2, 1, 3>(gwt, wf, lane_r);
+          if (DB && l == 2) fetch_wt<1, 1, 3>(gwt, wf, lane_r);
           // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them): six 16-byte gathers, two layers
           // ahead of their store
           if (l == 3) {
 #pragma unroll
             for (int i = 0; i < 6; i++) hq[i] = h0_tab[(size_t)tt * 12 + 6 * h + i];
           }
-        } else {
-          load_top();  // the next round's samples and bias row (the dW waves wrote the records behind this round's first barrier)
         }
         if (wid == 0) TF_STAMP(0, 7 + 4 * (4 - l));
-        if (l > 0) __syncthreads();  // B2: the dW waves are done with the images (layer 0's: at the top of the next round's backward)
         if (wid == 0) TF_STAMP(0, 8 + 4 * (4 - l));
       }
     }
-    __syncthreads();  // B2 of layer 0 of the last round
   } else {
     // ================================ dW waves =================================
     // distributions.py:42-43: column 0 == sample 0's eps.  With drawn timesteps that is GLOBAL sample 0's draw (Philox index 0,
@@ -533,6 +735,12 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
       if (la.rng_counter) la.rng_counter[0] += 1;  // every block read this step's offset at its start
     }
   }
+#ifdef TF_STAMPS
+  if (blockIdx.x == 0 && (wid == 0 || wid == 4) && lane == 0) {   // [role][round 63]: kernel entry / exit in shader ticks and in 100 MHz ticks
+    uint64_t* e = stamp_base + ((wid >> 2) * 64 + 63) * 32;
+    e[0] = t_entry; e[1] = __builtin_amdgcn_s_memtime(); e[2] = rt_entry; e[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 }  // namespace

@@ -28,28 +28,40 @@ l = C.CDLL(os.path.abspath(sys.argv[1]))
 l.so3x_train_workspace_bytes.restype = C.c_size_t
 ws = torch.empty(int(l.so3x_train_workspace_bytes(C.c_int64(n), C.c_int(T))), dtype=torch.uint8, device=DEV)
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(4):
     out.zero_()
+    ev0.record()
     rc = l.so3x_train_fused(C.c_void_p(torch.cuda.current_stream().cuda_stream), P(params), P(proc._sched), C.c_int(T), P(trap_q), P(proc._guide_q),
                             P(x0), None, None, C.c_int(1), None, None, C.c_uint64(1), C.c_uint64(it), None, C.c_int64(0), C.c_int64(n), P(loss), None,
                             P(out), P(ws), C.c_size_t(ws.numel()))
     assert rc == 0
+    ev1.record()
     torch.cuda.synchronize()
+    call_us = ev0.elapsed_time(ev1) * 1e3
 st = out.reshape(-1)[:2 * 2 * 64 * 32].view(torch.int64).cpu().numpy().reshape(2, 64, 32)
 rounds = 16
-names_c = ["top"] + ["l0+mfma", "act0", "hidden", "head+loss"] + sum([[f"store{l}", f"B1w{l}", f"dh{l}", f"B2w{l}"] for l in (4, 3, 2, 1, 0)], [])
-res = {}
+names_c = ["top"] + ["l0+mfma", "act0", "hidden", "head+loss"] + sum([[f"wait_done{l}", f"store{l}", f"dh{l}" if l else "wait_handed", f"end{l}"] for l in (4, 3, 2, 1, 0)], [])
+res = {"call_us_with_stamps": call_us}
 c = st[0, :rounds, :25].astype(np.float64)
 d = np.diff(c, axis=1)                     # phases 0->1 ... 23->24
 nxt = c[1:, 0] - c[:-1, 24]                # end of round -> next top
 res["chain_wave0_cycles_per_phase_median"] = {nm: float(np.median(d[1:-1, i])) for i, nm in enumerate(names_c[1:])}
 res["chain_round_cycles_median"] = float(np.median(c[2:, 0] - c[1:-1, 0]))
+e = st[:, 63, :4].astype(np.float64)
+res["kernel_ticks_entry_to_exit"] = [float(e[0, 1] - e[0, 0]), float(e[1, 1] - e[1, 0])]
+res["kernel_us_by_the_100MHz_clock"] = [float(e[0, 3] - e[0, 2]) / 100.0, float(e[1, 3] - e[1, 2]) / 100.0]
+res["shader_ticks_per_us"] = float(e[0, 1] - e[0, 0]) / (float(e[0, 3] - e[0, 2]) / 100.0)
+res["prologue_ticks_chain"] = float(c[0, 0] - e[0, 0])
+res["epilogue_ticks_chain"] = float(e[0, 1] - c[rounds - 1, 24])
 res["chain_between_rounds"] = float(np.median(nxt))
+res["chain_loop_span_cycles"] = float(c[rounds - 1, 24] - c[0, 0])
+res["chain_round_starts"] = [float(x - c[0, 0]) for x in c[:, 0]]
 res["chain_forward_cycles_by_round"] = [float(x) for x in (c[:, 4] - c[:, 0])]     # even rounds carry the dW waves' noise pass on the same SIMDs
 res["chain_backward_cycles_by_round"] = [float(x) for x in (c[:, 24] - c[:, 4])]
 w = st[1, :rounds, :17].astype(np.float64)
 order = [0] + sum([[2 + 3 * k, 3 + 3 * k, 4 + 3 * k] for k in range(4)], []) + [14, 15, 1, 16]   # ... B1(0), products(0), noise pass, B2(0)
-names_w = sum([[f"B1w{l}", f"mfma{l}", f"B2w{l}"] for l in (4, 3, 2, 1)], []) + ["B1w0", "mfma0", "noise", "B2w0"]
+names_w = sum([[f"hand{l}", f"products{l}", f"end{l}"] for l in (4, 3, 2, 1)], []) + ["hand0", "products0", "noise", "end0"]
 seq = w[:, order]
 dw = np.diff(seq, axis=1)
 res["dw_wave0_even_rounds"] = {nm: float(np.median(dw[2:-1:2, i])) for i, nm in enumerate(names_w)}
