@@ -37,20 +37,13 @@ constexpr int PREC = SO3X_PREC_BF16, VAR = GATHER_TD, FB = frag_bytes<PREC>();
 constexpr int IMG = image_bytes<PREC, VAR>();                 // 53 fragments + the 4 KB (silu, silu') table
 constexpr int REC_DW = 8;                                     // hand-over record of a sample: x_t as 5 bf16 pairs, target[3]
 constexpr int HAND_BYTES = 128 * REC_DW * 4 + 128 * 4;        // ... + the timesteps
-// LDS: the hand-over images FIRST -- two per chain wave: image (p, w) at (4 p + w) FIMG_BYTES -- their 150 distinct read / store
-// addresses per round are (per-lane base) + constant, and a DS instruction's offset field holds 16 bits: behind the weight image
-// every one of them cost an address register (60 VGPRs in the dW waves, beside 160 accumulators) -- then the hand-over records,
-// the loss scratch and the hand-shake words, the forward's weight image.  The TRANSPOSED weight image (the A operands of
-// dH = W^T dZ, 48 KB) stays in global memory: it is the same for every workgroup and L2-resident, a layer's fragments are
-// fetched one layer ahead (so3x_train_fused's chain role), and its place in LDS went to the second set of images.
-#ifdef TF_DB
-constexpr bool DB = true;
-#else
-constexpr bool DB = false;
-#endif
 constexpr int WTB = wt_bytes<PREC>();                         // transposed image: 48 fragments
-constexpr int LDS_FIMG = 0, LDS_HAND = LDS_FIMG + (DB ? 8 : 4) * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES, LDS_IMG = LDS_RED + 256;
-constexpr int LDS_WT = LDS_IMG + IMG, LDS_TOTAL = LDS_WT + (DB ? 0 : WTB);
+// LDS: the hand-over images FIRST -- their 150 distinct read / store addresses per round are (per-lane base) + constant, and a
+// DS instruction's offset field holds 16 bits: behind the 107 KB of weight images every one of them cost an address register
+// (60 VGPRs in the dW waves, beside 160 accumulators) -- then the hand-over records, the loss scratch and the hand-shake words,
+// the two weight images
+constexpr int LDS_FIMG = 0, LDS_HAND = LDS_FIMG + 4 * FIMG_BYTES, LDS_RED = LDS_HAND + HAND_BYTES, LDS_IMG = LDS_RED + 256;
+constexpr int LDS_WT = LDS_IMG + IMG, LDS_TOTAL = LDS_WT + WTB;
 static_assert(LDS_TOTAL <= 160 * 1024 && LDS_HAND % 16 == 0 && LDS_IMG % 16 == 0, "one workgroup per CU");
 
 __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
@@ -238,17 +231,6 @@ __device__ __forceinline__ void hidden_fwd_td(const char* __restrict__ wl, const
   asm volatile("" : "+v"(hp[16]), "+v"(dp[16]));
 }
 
-// the A operands of dH_L = W_L^T dZ_L, [to][ks], from the transposed image in global memory
-template <int L, int TO0, int TO1>
-__device__ __forceinline__ void fetch_wt(const void* __restrict__ gwt, bf16x8 (&wf)[15], int lane) {
-  const bf16x8* w = reinterpret_cast<const bf16x8*>(gwt);
-  constexpr int KS = L < 4 ? 5 : 1;
-#pragma unroll
-  for (int to = TO0; to < TO1; to++)
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) wf[to * KS + ks] = w[(size_t)wt_frag<PREC>(L, to, ks) * 64 + lane];
-}
-
 // ---- the dW waves: k_bwd_fused's dW role (so3x_mlp_bwd.hip) + the noising of the tiles ahead -----------------------------------
 struct Geo { int64_t n, ntiles, nchain, rounds; };
 // -DTF_STAMPS (timing build, tools/ab/fused_stamps.py; results of `out` destroyed): workgroup 0's chain wave 0 and dW wave 0 leave
@@ -262,25 +244,21 @@ struct Geo { int64_t n, ntiles, nchain, rounds; };
 constexpr int RING = 3;  // operand ring of the dW products: stages (image, k-step) in flight, 16 registers each
 
 // ---- hand-shakes per IMAGE instead of workgroup barriers (round 4, second half) -------------------------------------------------
-// With two s_barriers per layer the chain waves stored a layer's images (18 ds_write_b64 each, 25 cycles apiece through a wave's
-// LDS queue: tools/ab/lds_bench.hip), THEN the dW waves took their 64 transposed reads per layer (22 cycles apiece: 1.4 k), and
-// neither did the one while the other happened: 2.6 k cycles per layer.  Now a chain wave owns TWO images and alternates between
-// them from layer to layer -- layer index k = 4 - l goes to image p = (k + 1) & 1: [1 0 1 0 1], the same in every round, so the
-// parity is a compile-time constant everywhere -- and announces the n-th filling of image (w, p) as ready[w][p] = n + 1; the dW
-// waves walk the four waves' images in order, wait for each one's filling, and count themselves out of it behind their last
-// read (done[w][p] += 1); the chain wave refills an image once done[w][p] = 4 n.  So the chain waves run up to a layer ahead
-// of the dW waves instead of in lock-step with them.  handed[w] = the round whose records the wave's dW partner has put into
-// the hand-over buffer.  One wave's LDS operations are processed in issue order, so a flag written behind the data is seen
-// behind the data; the accesses are inline assembly with a memory clobber so that the compiler keeps that order too.  Every
-// wait gives up after ~0.1 s (a wrong result instead of a hung GPU).
-constexpr int LDS_READY = LDS_RED + 80, LDS_DONE = LDS_RED + 112, LDS_HANDED = LDS_RED + 144;   // [4][2], [4][2], [4] words
+// With two s_barriers per layer the chain waves stored a layer's images, THEN the dW waves took their 64 transposed reads per
+// layer, and neither did the one while the other happened.  Now a chain wave announces the n-th filling of ITS image as
+// ready[w] = n + 1 (n = 5 round + layer index); the dW waves walk the four waves' images in order, wait for each one's filling
+// and count themselves out of it behind their last read (done[w] += 1); the chain wave refills its image once done[w] = 4 n.
+// A chain wave whose image the dW waves have left goes on while they are still in its siblings'; the four fall into a
+// stagger.  handed[w] = the round whose records the wave's dW partner has put into the hand-over buffer.  One wave's LDS
+// operations are processed in issue order, so a flag written behind the data is seen behind the data; the accesses are inline
+// assembly with a memory clobber so that the compiler keeps that order too.  Every wait gives up after ~0.1 s (a wrong result
+// instead of a hung GPU).
+// (Tried and dropped, profiles/r04_ab_train_fused_sync.json: TWO images per chain wave, with the transposed weight image left in
+//  global memory to make room -- the chain waves ran a layer ahead, and lost more to the 15 L2 fetches per layer and wave than
+//  the decoupling gave: 156 us against 146.)
+constexpr int LDS_READY = LDS_RED + 80, LDS_DONE = LDS_RED + 96, LDS_HANDED = LDS_RED + 112;   // [4], [4], [4] words
 static_assert(LDS_HANDED + 16 <= LDS_IMG, "the flags live behind the loss scratch");
-__device__ __forceinline__ constexpr int img_parity(int k) { return DB ? (k + 1) & 1 : 0; }
-// how many fillings image (w, img_parity(k)) has had in front of round rd's layer index k
-__device__ __forceinline__ uint32_t img_seq(int64_t rd, int k) {
-  if (!DB) return 5u * (uint32_t)rd + (uint32_t)k;
-  return img_parity(k) ? 3u * (uint32_t)rd + (uint32_t)(k >> 1) : 2u * (uint32_t)rd + (uint32_t)(k >> 1);
-}
+__device__ __forceinline__ uint32_t img_seq(int64_t rd, int k) { return 5u * (uint32_t)rd + (uint32_t)k; }  // fillings in front of (rd, k)
 __device__ __forceinline__ uint32_t lds_peek(uint32_t addr) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
@@ -289,9 +267,7 @@ __device__ __forceinline__ uint32_t lds_peek(uint32_t addr) {
 __device__ __forceinline__ void lds_wait_ge(uint32_t addr, uint32_t target) {
   int spins = 0;
   while ((int32_t)(lds_peek(addr) - target) < 0) {
-#ifndef TF_NOSLEEP
     __builtin_amdgcn_s_sleep(1);
-#endif
     if (++spins > (1 << 21)) break;
   }
 }
@@ -317,8 +293,6 @@ template <int DWI, bool EXPLICIT>
 __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t,
                                               float* __restrict__ x_t_out, float* __restrict__ slabs, int lane, uint64_t* stamp_base = nullptr) {
   const char* fimg_all = lds + LDS_FIMG;
-  uint32_t* rec = reinterpret_cast<uint32_t*>(lds + LDS_HAND) + (DWI * 32 + (lane & 31)) * REC_DW;
-  int* ht = reinterpret_cast<int*>(lds + LDS_HAND + 128 * REC_DW * 4) + DWI * 32 + (lane & 31);
   const int col = lane & 31, h = lane >> 5;
   f32x16 acc[10];  // [3 slot + ti] for the hidden layers, [9] = the wave's tile of the output layer
 #pragma unroll
@@ -336,6 +310,10 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
     return noise_sample<EXPLICIT>(na, rng_offset, wrow_t, live ? s : g.n - 1, live, x_t_out);
   };
   auto hand_over = [&](const Hand& hd) {
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (the two record addresses are made here, not kept -- or spilled -- across the round loop)
+    uint32_t* rec = reinterpret_cast<uint32_t*>(lds + LDS_HAND) + (DWI * 32 + (lane_o & 31)) * REC_DW;
+    int* ht = reinterpret_cast<int*>(lds + LDS_HAND + 128 * REC_DW * 4) + DWI * 32 + (lane_o & 31);
     *reinterpret_cast<uint4*>(rec) = uint4{hd.xb[0], hd.xb[1], hd.xb[2], hd.xb[3]};
     *reinterpret_cast<uint4*>(rec + 4) = uint4{hd.xb[4], __float_as_uint(hd.tg[0]), __float_as_uint(hd.tg[1]), __float_as_uint(hd.tg[2])};
     *ht = hd.tt;
@@ -343,22 +321,17 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
   Hand hd = pass(0);
   if (h == 0) hand_over(hd);
   __syncthreads();  // P: round 0's samples are in the hand-over buffer (the last workgroup barrier before the loss)
-  FimgReadLane RL = fimg_read_lane(lane), RH;  // RH: the same lane offsets into the second set of images (beyond an offset field)
+  FimgReadLane RL = fimg_read_lane(lane);
   for (int64_t rd = 0; rd < g.rounds; rd++) {
     asm volatile("" : "+v"(RL.off[0][0]), "+v"(RL.off[0][1]), "+v"(RL.off[1][0]), "+v"(RL.off[1][1]));
-#pragma unroll
-    for (int i = 0; i < 4; i++) RH.off[i >> 1][i & 1] = RL.off[i >> 1][i & 1] + 4 * FIMG_BYTES;
-    asm volatile("" : "+v"(RH.off[0][0]), "+v"(RH.off[0][1]), "+v"(RH.off[1][0]), "+v"(RH.off[1][1]));
     if (DWI == 0) TF_STAMP(1, 0);
 #pragma unroll
     for (int l = 4; l >= 0; l--) {
-      const int P = img_parity(4 - l);
-      const uint32_t v = img_seq(rd, 4 - l) + 1u;   // the filling of the images (., P) this layer's products read
-      const FimgReadLane& RP = P ? RH : RL;
+      const uint32_t v = img_seq(rd, 4 - l) + 1u;   // the filling of the images this layer's products read
       if (l == 4) {
         // the partner chain wave has read round rd's records once its forward is through, i.e. once its layer-4 image is out:
         // then round rd + 1's go in, and the partner may take them in front of its layer-0 stores
-        lds_wait_ge(LDS_READY + 8 * DWI + 4 * P, v);
+        lds_wait_ge(LDS_READY + 4 * DWI, v);
         if (h == (int)((rd & 1) ^ 1)) hand_over(hd);
         lds_post(LDS_HANDED + 4 * DWI, (uint32_t)rd + 1u);
       }
@@ -370,18 +343,18 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
         const int to = l == 4 ? 0 : dw_row(DWI, l), sl = l == 4 ? 3 : dw_slot(DWI, l);
         constexpr int NB = 3;
         bf16x8 ra[RING], rb[RING][NB];
-        uint32_t seen = lds_early(lds, LDS_READY + 4 * P);   // image 0's word; image w + 1's is read behind image w's first stage
+        uint32_t seen = lds_early(lds, LDS_READY);   // image 0's word; image w + 1's is read behind image w's first stage
         auto load = [&](int st) {
-          if ((st & 1) == 0) lds_wait_ge_seen(seen, LDS_READY + 8 * (st >> 1) + 4 * P, v);
+          if ((st & 1) == 0) lds_wait_ge_seen(seen, LDS_READY + 4 * (st >> 1), v);
           const char* im = fimg_all + (st >> 1) * FIMG_BYTES;
-          ra[st % RING] = fimg_frag(im, RP, 32 * to, st & 1);
-          if (l == 4) rb[st % RING][0] = fimg_frag(im, RP, 96 + 32 * DWI, st & 1);
+          ra[st % RING] = fimg_frag(im, RL, 32 * to, st & 1);
+          if (l == 4) rb[st % RING][0] = fimg_frag(im, RL, 96 + 32 * DWI, st & 1);
           else {
 #pragma unroll
-            for (int ti = 0; ti < 3; ti++) rb[st % RING][ti] = fimg_frag(im, RP, 96 + 32 * ti, st & 1);
+            for (int ti = 0; ti < 3; ti++) rb[st % RING][ti] = fimg_frag(im, RL, 96 + 32 * ti, st & 1);
           }
-          if (st & 1) lds_count(LDS_DONE + 8 * (st >> 1) + 4 * P, lane);
-          else if (st < 6) seen = lds_early(lds, LDS_READY + 8 * ((st >> 1) + 1) + 4 * P);
+          if (st & 1) lds_count(LDS_DONE + 4 * (st >> 1), lane);
+          else if (st < 6) seen = lds_early(lds, LDS_READY + 4 * ((st >> 1) + 1));
         };
 #pragma unroll
         for (int st = 0; st < RING - 1; st++) load(st);
@@ -399,8 +372,8 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
       } else {  // the wave without a row in this layer: it still counts itself out of every image (once the image exists)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-          lds_wait_ge(LDS_READY + 8 * w + 4 * P, v);
-          lds_count(LDS_DONE + 8 * w + 4 * P, lane);
+          lds_wait_ge(LDS_READY + 4 * w, v);
+          lds_count(LDS_DONE + 4 * w, lane);
         }
       }
       if (DWI == 0) TF_STAMP(1, 3 + 3 * (4 - l));
@@ -411,6 +384,9 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
       if (DWI == 0) TF_STAMP(1, 4 + 3 * (4 - l));
     }
   }
+#ifdef TF_STAMPS
+  if (DWI == 0 && blockIdx.x == 0 && stamp_base && lane == 0) stamp_base[(64 + 63) * 32 + 4] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- slab: D-layout lane column = H feature (in), register rows = dZ feature (out)
   float* slab = slabs + (size_t)blockIdx.x * NPARAMS_MAX;
   int colw = col, hw = h;
@@ -436,6 +412,9 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
     for (int ti = 0; ti < 3; ti++) write_tile(acc[3 * dw_slot(DWI, l) + ti], l, dw_row(DWI, l), ti);
   }
   if (DWI < 3) write_tile(acc[9], 4, 0, DWI);
+#ifdef TF_STAMPS
+  if (DWI == 0 && blockIdx.x == 0 && stamp_base && lane == 0) stamp_base[(64 + 63) * 32 + 5] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <bool EXPLICIT>
@@ -449,11 +428,19 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
 #endif
   char* img_lds = lds + LDS_IMG;
   char* fimg_all = lds + LDS_FIMG;
-  load_image(gimg, img_lds, IMG);
-  if (!DB) load_image(gwt, lds + LDS_WT, WTB);
-  for (int i = threadIdx.x; i < (DB ? 8 : 4) * FIMG_BYTES / 16; i += blockDim.x) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
-  if (threadIdx.x < 20) reinterpret_cast<uint32_t*>(lds + LDS_READY)[threadIdx.x] = 0u;  // ready[4][2], done[4][2], handed[4]
+  // The chain waves bring the weight images into LDS and clear the hand-over images and the hand-shake words WHILE the dW waves
+  // draw round 0's and 1's samples (neither needs the other's result before the one barrier P below; 11 us of prologue with the
+  // two one after the other)
+  if (wid < 4) {
+    auto copy = [&](const void* src, char* dst, int bytes) {
+      for (int i = threadIdx.x; i < bytes / 16; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    };
+    copy(gimg, img_lds, IMG);
+    copy(gwt, lds + LDS_WT, WTB);
+    for (int i = threadIdx.x; i < 4 * FIMG_BYTES / 16; i += 256) reinterpret_cast<float4*>(fimg_all)[i] = float4{0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 12) reinterpret_cast<uint32_t*>(lds + LDS_READY)[threadIdx.x] = 0u;  // ready[4], done[4], handed[4]
+  }
   Geo g;
   g.n = n;
   g.ntiles = (n + 31) / 32;
@@ -461,7 +448,6 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
   g.rounds = (g.ntiles + g.nchain - 1) / g.nchain;  // uniform trip count: every wave takes part in every round's hand-shakes
   uint64_t rng_offset = na.rng_offset;
   if (na.rng_offset_dev) rng_offset += (uint64_t)na.rng_offset_dev[0];  // device-resident part of the counter (hipGraph replays)
-  __syncthreads();  // S0: images, tables
 #ifdef TF_STAMPS
   uint64_t* stamp_base = reinterpret_cast<uint64_t*>(out);
   out = nullptr;
@@ -474,7 +460,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
     const uint32_t* rec = reinterpret_cast<const uint32_t*>(lds + LDS_HAND) + (wid * 32 + col) * REC_DW;
     const int* ht = reinterpret_cast<const int*>(lds + LDS_HAND + 128 * REC_DW * 4) + wid * 32 + col;
     FimgStoreLane SL = fimg_store_lane(col);
-    __syncthreads();  // P
+    __syncthreads();  // P: the images and tables of this wave's siblings, round 0's samples of the dW waves
     // A round's inputs: the samples the dW waves handed over (x_t as bf16 pairs, target, timestep) and the timestep's effective-bias
     // row (nine 16-byte gathers from L2, per lane).  They are fetched a round AHEAD -- behind the round's last image, while the dW
     // waves take the layer-0 products -- so the row's L2 round trip (2.5 k cycles at the top of every round when it was fetched
@@ -542,9 +528,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
         hidden_fwd_td(img_lds + (size_t)frag_hidden<PREC, VAR>(l) * FB, cur, acc, hpk[l], dpk[l], h, tab, lane_r);
       }
       if (wid == 0) TF_STAMP(0, 3);
-      bf16x8 wf[15];  // W^T fragments of the dH that comes next (global memory, L2-resident: see the LDS layout above)
-      if (DB) fetch_wt<4, 0, 3>(gwt, wf, lane_r);
-      uint32_t seen_done = lds_early(lds, LDS_DONE + 8 * wid + 4 * img_parity(0));
+      uint32_t seen_done = lds_early(lds, LDS_DONE + 4 * wid);
       f32x16 last[1];
       {
         Tile<PREC> cur;
@@ -566,19 +550,17 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
         pdz[1] = pack_bf16x2(d2 * sc, 0.0f);
       }
       uint4 hq[6];
-      // ---- backward, per layer index k = 4 - l:   wait until the dW waves are out of the image's previous filling (two layers
-      // back: never, in the steady state) -- the image's 18 stores INTERLEAVED with the MFMAs of dH_l = W_l^T dZ_l (both read
-      // the packed dZ_l; a wave's LDS queue takes a store per 25 cycles, the matrix pipe an MFMA per 32: one hides the other)
-      // -- announce the image -- dZ_{l-1} = dH_l * silu'(Z_{l-1}), with the next layer's W^T fragments in flight from L2
+      // ---- backward, per layer index k = 4 - l:   wait until the dW waves are out of the image's previous filling -- the image's
+      // 18 stores INTERLEAVED with the MFMAs of dH_l = W_l^T dZ_l (both read the packed dZ_l; a wave's LDS queue takes a store
+      // per 25 cycles, the matrix pipe an MFMA per 32: one hides the other) -- announce the image -- dZ_{l-1} = dH_l * silu'(Z_{l-1})
       f32x16 dh[3];
       // (the dW waves' count for the image about to be refilled is read a phase ahead -- here in front of the head, below in front
       //  of each layer's multiplies -- and looked at in front of the stores: no LDS round trip in the chain's critical path)
       if (wid == 0) TF_STAMP(0, 4);
 #pragma unroll
       for (int l = 4; l >= 0; l--) {
-        const int P = img_parity(4 - l);
         const uint32_t nfill = img_seq(rd, 4 - l);
-        char* img_p = my_img + P * 4 * FIMG_BYTES;
+        char* img_p = my_img;
         asm volatile("" : "+v"(SL.rowbase), "+v"(SL.swz8));  // opaque per layer: the ~20 store addresses are made where they are used
         if (l == 0) {
           // the next round's samples and bias row, IN FRONT of this round's last image: the row's L2 round trip (1 k cycles at the
@@ -586,9 +568,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
           lds_wait_ge(LDS_HANDED + 4 * wid, (uint32_t)rd + 1u);  // the partner put them in behind this round's first image
           load_top();
         }
-#ifndef TF_NODONE
-        lds_wait_ge_seen(seen_done, LDS_DONE + 8 * wid + 4 * P, 4u * nfill);
-#endif
+        lds_wait_ge_seen(seen_done, LDS_DONE + 4 * wid, 4u * nfill);
         if (wid == 0) TF_STAMP(0, 5 + 4 * (4 - l));
         if (l > 0) {
           const uint32_t (&ph)[17] = hpk[l - 1];  // H_l = silu(Z_{l-1}): the forward's operand bits
@@ -619,18 +599,16 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
           auto wread = [&](int m) {
             wring[m & 3] = reinterpret_cast<const bf16x8*>(lds + LDS_WT)[(size_t)wt_frag<PREC>(l, m / KS, m % KS) * 64 + lane_r];
           };
-          if (!DB) {
 #pragma unroll
-            for (int m = 0; m < 3 && m < NM; m++) wread(m);
-          }
+          for (int m = 0; m < 3 && m < NM; m++) wread(m);
 #pragma unroll
           for (int m = 0; m < NM; m++) {
-            if (!DB && m + 3 < NM) wread(m + 3);
+            if (m + 3 < NM) wread(m + 3);
 #pragma unroll
             for (int i = m * 18 / NM; i < (m + 1) * 18 / NM; i++) store(i);
             __builtin_amdgcn_sched_barrier(0);
             const int to = m / KS, ks = m % KS;
-            dh[to] = mfma_bf16(DB ? wf[m] : wring[m & 3], bop[ks], ks == 0 ? zero16<PREC>() : dh[to]);
+            dh[to] = mfma_bf16(wring[m & 3], bop[ks], ks == 0 ? zero16<PREC>() : dh[to]);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {  // H_0 = the network input: [0..8] R, [9] one, [10..65] emb(t), zeros; the two lanes of a column split the row
@@ -652,15 +630,10 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
             fimg_store_pk(img_p, SL, ch0, live ? lo : 0u, live ? hi : 0u);
           }
         }
-        lds_post(LDS_READY + 8 * wid + 4 * P, nfill + 1u);
+        lds_post(LDS_READY + 4 * wid, nfill + 1u);
         if (wid == 0) TF_STAMP(0, 6 + 4 * (4 - l));
         if (l > 0) {
-          // the fragments of the NEXT dH: its first tile's ahead of the multiplies, the other two's behind them (dH's 48
-          // registers are free then) -- under the next wait, the next stores' addresses and the first tile's MFMAs
-          if (DB && l == 4) fetch_wt<3, 0, 1>(gwt, wf, lane_r);
-          if (DB && l == 3) fetch_wt<2, 0, 1>(gwt, wf, lane_r);
-          if (DB && l == 2) fetch_wt<1, 0, 1>(gwt, wf, lane_r);
-          seen_done = lds_early(lds, LDS_DONE + 8 * wid + 4 * img_parity(4 - l + 1));
+          seen_done = lds_early(lds, LDS_DONE + 4 * wid);
           const uint32_t (&dp)[17] = dpk[l - 1];  // silu'(Z_{l-1}), parked by the forward
 #pragma unroll
           for (int r = 0; r < 16; r++) {
@@ -671,10 +644,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
           }
           pdz[16] = pack_bf16x2(h ? 0.0f : dh[2][0] * f16_lo(dp[16]), 0.0f);  // upper half of tile 2 / reg 0 = the constant-one row
 #pragma unroll
-          for (int r = 0; r < 17; r++) asm volatile("" : "+v"(pdz[r]));
-          if (DB && l == 4) fetch_wt<3, 1, 3>(gwt, wf, lane_r);
-          if (DB && l == 3) fetch_wt<2, 1, 3>(gwt, wf, lane_r);
-          if (DB && l == 2) fetch_wt<1, 1, 3>(gwt, wf, lane_r);
+          for (int r = 0; r < 17; r++) asm volatile("" : "+v"(pdz[r]));  // (the packed words, not their fp32 sources, are what lives on)
           // this lane's 48 input slots of the layer-0 image (bf16 bits as the image wants them): six 16-byte gathers, two layers
           // ahead of their store
           if (l == 3) {

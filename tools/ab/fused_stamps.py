@@ -48,7 +48,8 @@ d = np.diff(c, axis=1)                     # phases 0->1 ... 23->24
 nxt = c[1:, 0] - c[:-1, 24]                # end of round -> next top
 res["chain_wave0_cycles_per_phase_median"] = {nm: float(np.median(d[1:-1, i])) for i, nm in enumerate(names_c[1:])}
 res["chain_round_cycles_median"] = float(np.median(c[2:, 0] - c[1:-1, 0]))
-e = st[:, 63, :4].astype(np.float64)
+e = st[:, 63, :6].astype(np.float64)
+res["dw_wave0_ticks_entry_to_first_round_to_slab_to_slab_done_to_exit"] = [float(st[1, 0, 0] - e[1, 0]), float(e[1, 4] - st[1, 0, 0]), float(e[1, 5] - e[1, 4]), float(e[1, 1] - e[1, 5])]
 res["kernel_ticks_entry_to_exit"] = [float(e[0, 1] - e[0, 0]), float(e[1, 1] - e[1, 0])]
 res["kernel_us_by_the_100MHz_clock"] = [float(e[0, 3] - e[0, 2]) / 100.0, float(e[1, 3] - e[1, 2]) / 100.0]
 res["shader_ticks_per_us"] = float(e[0, 1] - e[0, 0]) / (float(e[0, 3] - e[0, 2]) / 100.0)
