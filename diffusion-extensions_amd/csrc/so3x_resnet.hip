@@ -246,22 +246,27 @@ __device__ __forceinline__ void stream_begin(const char* __restrict__ gimg, char
 // sample column (lane & 31), valid in the lower lane half.  Block-collective (49 barriers).  `again` = another
 // forward() follows in this workgroup: its first two chunks are requested while this pass drains.
 // STASH (training): the layer inputs X_l (the packed bf16 operand registers, l = 0..6) and the pre-activations
-// Y_l = -log2(e) Z_l (l = 0..5) of this wave's 32 samples are dumped as they are, 32 B per lane per 32-row tile
-// ("native" layout [tile][column n][half h][16 bf16], 2 KiB per wave-tile, fully coalesced) for the backward kernels.
+// Y_l = -log2(e) Z_l (l = 0..5) of this wave's 32 samples are dumped as they are, 32 B per lane per 32-row tile, for the
+// backward kernels: layout [tile][part p][column n][half h][8 bf16] -- the lane's first 16 bytes in the tile's first KiB, its
+// second 16 in the second, so that EACH store instruction of a wave writes one contiguous KiB.  (Rounds 1-3 kept a lane's 32
+// bytes together, [tile][n][h][16 bf16]: every instruction then filled half of every cache line -- 4.1 TB/s of stores against
+// 5.6 for whole KiBs, tools/ab/store_pattern.hip -- and the training forward is store-bound: 1.09 -> 0.95 ms at 2^19 samples.
+// A deeper weight ring -- five chunks in flight, so that a store has 1.3 us instead of 0.5 to be acknowledged before the
+// in-order vmcnt wait for a chunk stalls on it -- changed nothing: 0.94 ms.)
 struct StashPtr { char* x; char* y; size_t layer_stride; };  // this wave's 16-KiB blocks of layer 0; +layer_stride per layer
 
 template <bool NT = false> __device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const uint32_t* p8) {
   asm volatile("" : "+v"(lane));  // per-lane store address formed at the store, not kept (or spilled) across the pass
-  u32x4* d = reinterpret_cast<u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 32);
+  u32x4* d = reinterpret_cast<u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 16);
   // NT = non-temporal stores.  Measured both ways: they keep the dumps from evicting the L2-resident weight image (training
   // forward alone 1.11 -> 0.97 ms at 2^19 samples), but the backward kernels that read the dumps next then find nothing
   // in the memory-side cache and the whole step got SLOWER (2.94 -> 3.2 ms, same box) -- off.
   if constexpr (NT) {
     __builtin_nontemporal_store(u32x4{p8[0], p8[1], p8[2], p8[3]}, d);
-    __builtin_nontemporal_store(u32x4{p8[4], p8[5], p8[6], p8[7]}, d + 1);
+    __builtin_nontemporal_store(u32x4{p8[4], p8[5], p8[6], p8[7]}, d + 64);
   } else {
     d[0] = u32x4{p8[0], p8[1], p8[2], p8[3]};
-    d[1] = u32x4{p8[4], p8[5], p8[6], p8[7]};
+    d[64] = u32x4{p8[4], p8[5], p8[6], p8[7]};
   }
 }
 // fp32 training path: the same dump with 16 fp32 per lane per tile (64 B per lane, 4 KiB per wave-tile, 32 KiB per block)
@@ -531,8 +536,8 @@ __global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict_
 }
 
 __device__ __forceinline__ void load_tile(const char* blk, int to, int lane, uint32_t* p8) {
-  const u32x4* s = reinterpret_cast<const u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 32);
-  const u32x4 a = s[0], b = s[1];
+  const u32x4* s = reinterpret_cast<const u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 16);
+  const u32x4 a = s[0], b = s[64];
   p8[0] = a.x; p8[1] = a.y; p8[2] = a.z; p8[3] = a.w; p8[4] = b.x; p8[5] = b.y; p8[6] = b.z; p8[7] = b.w;
 }
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
@@ -628,16 +633,19 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
 }
 
 // dW_l = sum over samples dZ_l^T X_l: one workgroup = one (layer, sample range); wave w owns output rows 32w..32w+31
-// x all 256 columns (8 accumulator tiles).  Per 32-sample block the two 16-KiB register dumps are copied to LDS as they
-// are and read back as MFMA operands with ds_read_b64_tr_b16 (K = the sample index): the quad (sample s, features
-// 4 fq .. 4 fq+3) of a dump sits at  (fq >> 3) 2048 + s 64 + (fq & 1) 32 + ((fq >> 1) & 3) 8.
+// x all 256 columns (8 accumulator tiles).  Per 32-sample block the two 16-KiB register dumps go to LDS by LDS-DMA, KiB by KiB
+// (a tile's second KiB 128 bytes further on, so that the two lane groups of a transposed read sit in different banks: a tile
+// takes DUMP_TILE bytes there), and are read back as MFMA operands with ds_read_b64_tr_b16 (K = the sample index): the quad
+// (sample s, features 4 fq .. 4 fq+3) of a dump, lane index 2 s + (fq & 1), quad j = (fq >> 1) & 3 of the lane's eight, sits at
+//   (fq >> 3) DUMP_TILE + (j >> 1) DUMP_PART1 + (2 s + (fq & 1)) 16 + (j & 1) 8.
+constexpr int DUMP_PART1 = 1024 + 128, DUMP_TILE = 2048 + 128, DUMP_LDS = 8 * DUMP_TILE;
 struct DumpReadLane { int off[2]; };  // [part]: samples +0 / +4
 __device__ __forceinline__ DumpReadLane dump_read_lane(int lane) {
   const int hh = lane >> 5, l32 = lane & 31, G = l32 >> 4, q = (l32 & 15) >> 2, pp = l32 & 3;
-  const int fq = 4 * G + pp;  // feature quad within the 32-feature tile
+  // feature quad within the 32-feature tile: fq = 4 G + pp, so j = (2 G + (pp >> 1)) & 3: j >> 1 = G, j & 1 = pp >> 1
   DumpReadLane L;
 #pragma unroll
-  for (int part = 0; part < 2; part++) L.off[part] = (8 * hh + q + 4 * part) * 64 + (fq & 1) * 32 + ((fq >> 1) & 3) * 8;
+  for (int part = 0; part < 2; part++) L.off[part] = (2 * (8 * hh + q + 4 * part) + (pp & 1)) * 16 + (pp >> 1) * 8 + G * DUMP_PART1;
   return L;
 }
 // operand = 8 bf16: samples 16 ks + 8 (lane >> 5) + 0..7 of feature 32 ft + (lane & 31)
@@ -645,7 +653,7 @@ __device__ __forceinline__ bf16x8 dump_frag(const char* img, const DumpReadLane&
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) s16x4* lds_p;
-  const int konst = ft * 2048 + ks * 1024;
+  const int konst = ft * DUMP_TILE + ks * 512;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[0]));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + konst + L.off[1]));
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -819,7 +827,7 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
   // The dumps go to LDS unchanged, which is what LDS-DMA does best: a 4-slot ring of [X | dZ] block pairs (4 x 32 KiB),
   // three blocks in flight per workgroup (96 KiB: the one-block-ahead register prefetch this replaces read at 3.7 TB/s,
   // 2/3 of the latency-bandwidth product), one raw barrier per block with counted vmcnt waits.
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // [slot 4][X 16 KiB | dZ 16 KiB]
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [slot 4][X | dZ], DUMP_LDS bytes each
   const int l = blockIdx.x / DW_SPLITS, split = blockIdx.x % DW_SPLITS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t per = (nblk32 + DW_SPLITS - 1) / DW_SPLITS;
@@ -836,13 +844,13 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
   auto issue = [&](int64_t blk, int slot) {
     const char* gx = xs + (size_t)blk * 16384 + (size_t)(2 * wave) * 1024 + lane * 16;
     const char* gd = ds + (size_t)blk * 16384 + (size_t)(2 * wave) * 1024 + lane * 16;
-    char* lx = lds + slot * 32768 + (2 * wave) * 1024;
+    char* lx = lds + slot * (2 * DUMP_LDS) + wave * DUMP_TILE;   // this wave brings tile `wave` of both dumps: its two KiBs
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(lx + i * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lx + i * DUMP_PART1), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gd + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(lx + 16384 + i * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lx + DUMP_LDS + i * DUMP_PART1), 16, 0, 0);
     }
   };
   for (int u = 0; u < 3; u++)
@@ -854,11 +862,11 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
     const int64_t younger = b1 - 1 - blk;
     if (younger >= 2) ring_sync<8>(); else if (younger == 1) ring_sync<4>(); else ring_sync<0>();
     if (blk + 3 < b1) issue(blk + 3, (slot + 3) & 3);  // the slot of block blk - 1: every wave is past it
-    const char* img = lds + slot * 32768;
+    const char* img = lds + slot * (2 * DUMP_LDS);
     if (!head || wave == 0) {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        const bf16x8 a = dump_frag(img + 16384, RL, wave, ks);
+        const bf16x8 a = dump_frag(img + DUMP_LDS, RL, wave, ks);
 #pragma unroll
         for (int tj = 0; tj < 8; tj++) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dump_frag(img, RL, tj, ks), acc[tj], 0, 0, 0);
       }
@@ -1034,8 +1042,8 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
     const int64_t ngroups = (n + 255) / 256;
     hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
                        dout, yd, ws + L.dz, L.layer_stride, n, n_out);
-    if ((rc = ensure_dyn_lds(attr_dw, reinterpret_cast<const void*>(&k_resnet_dw), 131072))) return rc;
-    hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 131072, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
+    if ((rc = ensure_dyn_lds(attr_dw, reinterpret_cast<const void*>(&k_resnet_dw), 8 * DUMP_LDS))) return rc;
+    hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 8 * DUMP_LDS, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
                        partial);
   } else {
     constexpr int PREC = SO3X_PREC_F32, LDS = RING * chunk_bytes<PREC>();

@@ -5,8 +5,8 @@ for p in (ROOT, os.path.join(ROOT, "diffusion-extensions_amd")):
     sys.path.insert(0, os.path.abspath(p))
 import torch
 from so3x import backend as B
-if len(sys.argv) > 1:
-    B.LIB_PATH = os.path.abspath(sys.argv[1])
+# (the operators come from libso3x_torch.so, which finds libso3x.so beside itself: to compare builds, copy one over
+#  diffusion-extensions_amd/libso3x.so on the GPU box between two runs of this script; the argument is only a label)
 dev = "cuda:0"
 torch.manual_seed(0)
 pw = torch.randn(B.N_PARAMS_RESNET, device=dev) * 0.06
