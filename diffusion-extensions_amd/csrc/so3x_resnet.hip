@@ -829,7 +829,7 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
   // 2/3 of the latency-bandwidth product), one raw barrier per block with counted vmcnt waits.
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [slot 4][X | dZ], DUMP_LDS bytes each
   const int l = blockIdx.x / DW_SPLITS, split = blockIdx.x % DW_SPLITS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1;
   const int64_t per = (nblk32 + DW_SPLITS - 1) / DW_SPLITS;
   const int64_t b0 = split * per, b1 = b0 + per < nblk32 ? b0 + per : nblk32;
   const char* xs = stash_x + l * layer_stride;
@@ -863,23 +863,61 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
     if (younger >= 2) ring_sync<8>(); else if (younger == 1) ring_sync<4>(); else ring_sync<0>();
     if (blk + 3 < b1) issue(blk + 3, (slot + 3) & 3);  // the slot of block blk - 1: every wave is past it
     const char* img = lds + slot * (2 * DUMP_LDS);
-    if (!head || wave == 0) {
+    // a wave's eight tiles are a 2 x 4 block of the layer's 8 x 8 -- output-row tiles 2 wi, 2 wi + 1 by input-column tiles
+    // 4 wj .. 4 wj + 3: six operand fragments per k-step for its eight MFMAs (one row of eight tiles took nine: the transposed
+    // reads, 4.5 x the block's bytes out of LDS, were what kept the loader from HBM's rate -- tools/ab/dma_streams.hip)
+    // The transposed reads are inline assembly with counted lgkmcnt waits, not the builtin: the compiler knows that LDS-DMA wrote
+    // this memory and put `s_waitcnt vmcnt(0)` in front of the first builtin read of every block -- draining the two younger block
+    // pairs still in flight, i.e. ONE pair in flight instead of three (4.1 TB/s; the loader alone reaches 6.2, tools/ab/dma_streams.hip).
+    // Both k-steps' 24 reads go out first, the first k-step's MFMAs start when its 12 have returned.
+    if (!head || wi == 0) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const uint32_t xb = (uint32_t)(uintptr_t)img + 4 * wj * DUMP_TILE, db = (uint32_t)(uintptr_t)img + DUMP_LDS + 2 * wi * DUMP_TILE;
+      const uint32_t x0 = xb + RL.off[0], x1 = xb + RL.off[1], d0 = db + RL.off[0], d1 = db + RL.off[1];
+      u32x2 fb[2][4][2], fa[2][2][2];  // [k-step][fragment][part: samples +0 / +4]
+#define SO3X_TR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        const bf16x8 a = dump_frag(img + DUMP_LDS, RL, wave, ks);
 #pragma unroll
-        for (int tj = 0; tj < 8; tj++) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dump_frag(img, RL, tj, ks), acc[tj], 0, 0, 0);
+        for (int c = 0; c < 4; c++) {
+          SO3X_TR(fb[ks][c][0], x0, c * DUMP_TILE + ks * 512);
+          SO3X_TR(fb[ks][c][1], x1, c * DUMP_TILE + ks * 512);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          SO3X_TR(fa[ks][r][0], d0, r * DUMP_TILE + ks * 512);
+          SO3X_TR(fa[ks][r][1], d1, r * DUMP_TILE + ks * 512);
+        }
+      }
+#undef SO3X_TR
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        if (ks == 0)
+          asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]), "+v"(fb[0][2][0]), "+v"(fb[0][2][1]),
+                       "+v"(fb[0][3][0]), "+v"(fb[0][3][1]), "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]), "+v"(fb[1][2][0]), "+v"(fb[1][2][1]),
+                       "+v"(fb[1][3][0]), "+v"(fb[1][3][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]));
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const u32x4 av = {fa[ks][r][0][0], fa[ks][r][0][1], fa[ks][r][1][0], fa[ks][r][1][1]};
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const u32x4 bv = {fb[ks][c][0][0], fb[ks][c][0][1], fb[ks][c][1][0], fb[ks][c][1][1]};
+            acc[4 * r + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[4 * r + c], 0, 0, 0);
+          }
+        }
       }
     }
     slot = (slot + 1) & 3;
   }
-  // partial[l][split][o][f], o = 32 wave + row(reg, h), f = 32 tj + (lane & 31)
+  // partial[l][split][o][f], o = 32 (2 wi + r) + row(reg, h), f = 32 (4 wj + c) + (lane & 31)
   float* P = partial + ((size_t)l * DW_SPLITS + split) * 65536;
   const int n32 = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int tj = 0; tj < 8; tj++)
+  for (int t = 0; t < 8; t++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) P[(32 * wave + row_of(r, h)) * 256 + 32 * tj + n32] = acc[tj][r];
+    for (int r = 0; r < 16; r++) P[(32 * (2 * wi + (t >> 2)) + row_of(r, h)) * 256 + 32 * (4 * wj + (t & 3)) + n32] = acc[t][r];
 }
 
 // fixed-order sum of the split partials into the flat gradient (state_dict order); column 255 = the bias
