@@ -423,7 +423,25 @@ def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
     ms = timed(tg.replay, 5)
     out["train_step"] = {"batch": nt, "ms_per_step": ms, "samples_per_s": nt / (ms * 1e-3), "operands": "bf16",
                          "algorithmic_TFLOPs": 3 * flop * nt / (ms * 1e-3) / 1e12, "optimizer": "so3x.optim.Adam",
+                         "frac_of_bf16_mfma_peak": 3 * flop * nt / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                          "mode": "one captured hipGraph per step (so3x.graphs.TrainStepGraph)", "finite": bool(torch.isfinite(tg.loss).item())}
+    # the step's two device calls timed apart (HIP events around the operators): what bounds each is the HBM traffic of the
+    # register dumps -- 512 B per sample, layer and stream (X_l: 7, Y_l: 6, dZ_l: 7) -- not the matrix pipe
+    tt = torch.randint(0, sched.shape[1], (nt,), device=dev)
+    dout = torch.randn(nt, 3, device=dev)
+    _, stash = B.resnet_fwd_stash(params, x0, tt, sched.shape[1], B.PREC_BF16)
+    ms_f = timed(lambda: B.resnet_fwd_stash(params, x0, tt, sched.shape[1], B.PREC_BF16), 5)
+    ms_b = timed(lambda: B.resnet_bwd(params, x0, tt, dout, sched.shape[1], B.PREC_BF16, stash=stash), 5)
+    kb = 512 * nt / 1e9   # GB per dumped stream
+    out["train_step"]["stages"] = {
+        "forward_with_dumps (k_resnet_fwd<bf16, stash>)": {
+            "ms": ms_f, "frac_of_bf16_mfma_peak": flop * nt / (ms_f * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "hbm_GB_written": 13 * kb, "hbm_TBps": 13 * kb / ms_f, "frac_of_hbm_peak": 13 * kb / ms_f / (HBM_PEAK_GBS / 1e3)},
+        "backward (k_resnet_bwd: dX chain, reads Y, writes dZ; k_resnet_dw: dW GEMM over samples, reads X and dZ; reduce)": {
+            "ms": ms_b, "frac_of_bf16_mfma_peak": 2 * flop * nt / (ms_b * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "hbm_GB_moved": 27 * kb, "hbm_TBps": 27 * kb / ms_b, "frac_of_hbm_peak": 27 * kb / ms_b / (HBM_PEAK_GBS / 1e3)},
+        "per_kernel_durations": "profiles/r04_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this script): k_resnet_fwd<1, true>, k_resnet_bwd, k_resnet_dw",
+        "streaming_rates_of_this_hardware_TBps": "fill 6.9, read 5.3-6.3, copy 5.4 (profiles/r04_hbm_rates.json, tools/ab/read_rate.hip)"}
     return out
 
 
