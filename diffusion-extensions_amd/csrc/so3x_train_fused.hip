@@ -251,8 +251,8 @@ constexpr int RING = 3;  // operand ring of the dW products: stages (image, k-st
 // A chain wave whose image the dW waves have left goes on while they are still in its siblings'; the four fall into a
 // stagger.  handed[w] = the round whose records the wave's dW partner has put into the hand-over buffer.  One wave's LDS
 // operations are processed in issue order, so a flag written behind the data is seen behind the data; the accesses are inline
-// assembly with a memory clobber so that the compiler keeps that order too.  Every wait gives up after ~0.1 s (a wrong result
-// instead of a hung GPU).
+// assembly with a memory clobber so that the compiler keeps that order too.  Every wait gives up after ~0.1 s and the
+// step then reports a NaN loss (a loud wrong result instead of a hung GPU).
 // (Tried and dropped, profiles/r04_ab_train_fused_sync.json: TWO images per chain wave, with the transposed weight image left in
 //  global memory to make room -- the chain waves ran a layer ahead, and lost more to the 15 L2 fetches per layer and wave than
 //  the decoupling gave: 156 us against 146.)
@@ -264,11 +264,13 @@ __device__ __forceinline__ uint32_t lds_peek(uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
-__device__ __forceinline__ void lds_wait_ge(uint32_t addr, uint32_t target) {
+// `gave_up` (wave-uniform, a scalar register): set when the wait ran out of patience after ~0.1 s -- the wave goes on (the words
+// carry absolute counts: one lost hand-shake does not take the later ones with it) and the step's loss comes out NaN.
+__device__ __forceinline__ void lds_wait_ge(uint32_t addr, uint32_t target, uint32_t& gave_up) {
   int spins = 0;
   while ((int32_t)(lds_peek(addr) - target) < 0) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 21)) break;
+    if (++spins > (1 << 21)) { gave_up = 1u; break; }
   }
 }
 // The same wait with the word READ EARLY: `seen` was loaded (lds_early) some hundred cycles ahead, as an ordinary LDS load in
@@ -278,8 +280,8 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t addr, uint32_t target) {
 __device__ __forceinline__ uint32_t lds_early(const char* lds, uint32_t addr) {
   return *reinterpret_cast<const volatile uint32_t*>(lds + addr);
 }
-__device__ __forceinline__ void lds_wait_ge_seen(uint32_t seen, uint32_t addr, uint32_t target) {
-  if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) - target) < 0) lds_wait_ge(addr, target);
+__device__ __forceinline__ void lds_wait_ge_seen(uint32_t seen, uint32_t addr, uint32_t target, uint32_t& gave_up) {
+  if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) - target) < 0) lds_wait_ge(addr, target, gave_up);
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_post(uint32_t addr, uint32_t val) {   // every lane writes the same word
@@ -291,7 +293,8 @@ __device__ __forceinline__ void lds_count(uint32_t addr, int lane) {      // + 1
 
 template <int DWI, bool EXPLICIT>
 __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const NoiseArgs& na, uint64_t rng_offset, int64_t wrow_t,
-                                              float* __restrict__ x_t_out, float* __restrict__ slabs, int lane, uint64_t* stamp_base = nullptr) {
+                                              float* __restrict__ x_t_out, float* __restrict__ slabs, int lane, uint32_t& gave_up,
+                                              uint64_t* stamp_base = nullptr) {
   const char* fimg_all = lds + LDS_FIMG;
   const int col = lane & 31, h = lane >> 5;
   f32x16 acc[10];  // [3 slot + ti] for the hidden layers, [9] = the wave's tile of the output layer
@@ -331,7 +334,7 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
       if (l == 4) {
         // the partner chain wave has read round rd's records once its forward is through, i.e. once its layer-4 image is out:
         // then round rd + 1's go in, and the partner may take them in front of its layer-0 stores
-        lds_wait_ge(LDS_READY + 4 * DWI, v);
+        lds_wait_ge(LDS_READY + 4 * DWI, v, gave_up);
         if (h == (int)((rd & 1) ^ 1)) hand_over(hd);
         lds_post(LDS_HANDED + 4 * DWI, (uint32_t)rd + 1u);
       }
@@ -345,7 +348,7 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
         bf16x8 ra[RING], rb[RING][NB];
         uint32_t seen = lds_early(lds, LDS_READY);   // image 0's word; image w + 1's is read behind image w's first stage
         auto load = [&](int st) {
-          if ((st & 1) == 0) lds_wait_ge_seen(seen, LDS_READY + 4 * (st >> 1), v);
+          if ((st & 1) == 0) lds_wait_ge_seen(seen, LDS_READY + 4 * (st >> 1), v, gave_up);
           const char* im = fimg_all + (st >> 1) * FIMG_BYTES;
           ra[st % RING] = fimg_frag(im, RL, 32 * to, st & 1);
           if (l == 4) rb[st % RING][0] = fimg_frag(im, RL, 96 + 32 * DWI, st & 1);
@@ -372,7 +375,7 @@ __device__ __forceinline__ void dw_role_fused(char* lds, const Geo& g, const Noi
       } else {  // the wave without a row in this layer: it still counts itself out of every image (once the image exists)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-          lds_wait_ge(LDS_READY + 4 * w, v);
+          lds_wait_ge(LDS_READY + 4 * w, v, gave_up);
           lds_count(LDS_DONE + 4 * w, lane);
         }
       }
@@ -453,6 +456,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
   out = nullptr;
 #endif
   float sq = 0.0f;
+  uint32_t gave_up = 0u;
   if (wid < 4) {
     // =============================== chain waves ===============================
     char* my_img = fimg_all + wid * FIMG_BYTES;
@@ -565,10 +569,10 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
         if (l == 0) {
           // the next round's samples and bias row, IN FRONT of this round's last image: the row's L2 round trip (1 k cycles at the
           // top of the forward when the gathers were issued behind the image) flies under the stores
-          lds_wait_ge(LDS_HANDED + 4 * wid, (uint32_t)rd + 1u);  // the partner put them in behind this round's first image
+          lds_wait_ge(LDS_HANDED + 4 * wid, (uint32_t)rd + 1u, gave_up);  // the partner put them in behind this round's first image
           load_top();
         }
-        lds_wait_ge_seen(seen_done, LDS_DONE + 4 * wid, 4u * nfill);
+        lds_wait_ge_seen(seen_done, LDS_DONE + 4 * wid, 4u * nfill, gave_up);
         if (wid == 0) TF_STAMP(0, 5 + 4 * (4 - l));
         if (l > 0) {
           const uint32_t (&ph)[17] = hpk[l - 1];  // H_l = silu(Z_{l-1}): the forward's operand bits
@@ -630,6 +634,9 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
             fimg_store_pk(img_p, SL, ch0, live ? lo : 0u, live ? hi : 0u);
           }
         }
+#ifdef TF_FAULT_TEST
+        if (!(blockIdx.x == 3 && wid == 1 && rd == 2 && l == 2))
+#endif
         lds_post(LDS_READY + 4 * wid, nfill + 1u);
         if (wid == 0) TF_STAMP(0, 6 + 4 * (4 - l));
         if (l > 0) {
@@ -669,13 +676,13 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
     switch (wid - 4) {
       case 0:
 #ifdef TF_STAMPS
-        dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, stamp_base); break;
+        dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, gave_up, stamp_base); break;
 #else
-        dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+        dw_role_fused<0, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, gave_up); break;
 #endif
-      case 1: dw_role_fused<1, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
-      case 2: dw_role_fused<2, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
-      default: dw_role_fused<3, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane); break;
+      case 1: dw_role_fused<1, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, gave_up); break;
+      case 2: dw_role_fused<2, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, gave_up); break;
+      default: dw_role_fused<3, EXPLICIT>(lds, g, na, rng_offset, wrow_t, x_t_out, slabs, lane, gave_up); break;
     }
   }
   // ---- the reported loss: per-block sums of squares combined by the last block to arrive, in a fixed tree (deterministic)
@@ -684,10 +691,12 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
   double v = (double)sq;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if (gave_up) v = __builtin_nan("");  // a hand-shake of this wave timed out: the step's loss says so
   if (lane == 0) wsum[wid] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double bs = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    // (the dW waves' entries are zeros -- or the NaN of a timed-out hand-shake: x + 0.0 * 0.0 is x, bit for bit)
+    const double bs = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + 0.0 * ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
     __hip_atomic_store(la.partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *is_last = last_block_arrives(la.ticket) ? 1 : 0;
   }

@@ -142,3 +142,51 @@ def test_one_kernel_step_at_the_shard_size_of_config_4(mods):
     assert int(ctr) == 18 and torch.equal(l3, loss) and torch.equal(g3, grad)                            # offset + counter = 17
     l4, _, t4, _, _ = _fused(B, proc, params, x0, seed=5, rng_offset=0, rng_counter=ctr)
     assert int(ctr) == 19 and not torch.equal(t4, t3)
+
+
+def test_a_lost_hand_shake_ends_in_a_nan_loss_not_in_a_hang(tmp_path):
+    """k_train_fused synchronises its waves through polled words in LDS; every poll gives up after ~0.1 s.  A build with ONE
+    announcement left out (-DTF_FAULT_TEST: workgroup 3, chain wave 1, round 2, layer 2) must come back -- in well under the
+    watchdog's patience -- with a NaN loss, and the regular build on the same inputs with a finite one.  (The variant is built here,
+    with tools/ab/build_variant.sh; no hipcc on the box = skipped.)"""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc here")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "ab", "build_variant.sh"), "tf_fault_test", "-DTF_FAULT_TEST", "so3x_train_fused.hip"],
+                       capture_output=True, text=True, timeout=600)
+    lib_path = os.path.join(root, "build", "libso3x_tf_fault_test.so")
+    if r.returncode or not os.path.exists(lib_path):
+        pytest.skip("the fault-injection variant did not build: " + r.stderr[-300:])
+    from so3x import backend as B
+    from so3x.diffusion import SO3Diffusion
+    from so3x.so3_train import RotPredict
+    torch.manual_seed(0)
+    n, T = 1 << 17, 1000
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = SO3Diffusion(net, timesteps=T).to(DEV)
+    trap_q, _ = proc._tables()
+    x0 = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
+    params = net.flat_data().clone()
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    out = {}
+    for name, path in (("regular", B.LIB_PATH), ("one announcement left out", lib_path)):
+        lib = C.CDLL(path)
+        lib.so3x_train_workspace_bytes.restype = C.c_size_t
+        ws = torch.empty(int(lib.so3x_train_workspace_bytes(C.c_int64(n), C.c_int(T))), dtype=torch.uint8, device=DEV)
+        loss = torch.zeros(1, device=DEV)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = lib.so3x_train_fused(C.c_void_p(torch.cuda.current_stream().cuda_stream), P(params), P(proc._sched), C.c_int(T), P(trap_q),
+                                  P(proc._guide_q), P(x0), None, None, C.c_int(1), None, None, C.c_uint64(1), C.c_uint64(0), None, C.c_int64(0),
+                                  C.c_int64(n), P(loss), None, None, P(ws), C.c_size_t(ws.numel()))
+        torch.cuda.synchronize()
+        out[name] = (rc, float(loss), time.perf_counter() - t0)
+    assert out["regular"][0] == 0 and np.isfinite(out["regular"][1])
+    rc, lossv, secs = out["one announcement left out"]
+    assert rc == 0 and np.isnan(lossv), out
+    assert secs < 5.0, out
