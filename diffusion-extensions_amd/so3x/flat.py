@@ -12,6 +12,21 @@ import torch
 
 __all__ = ["FlatParamsMixin"]
 
+# Every registration of a parameter or a submodule anywhere in the process bumps this counter (torch's global registration
+# hooks: `module.weight = nn.Parameter(...)`, `net[0] = nn.Linear(...)`, load_state_dict(assign=True) all go through them).
+# While it stands still, a network's cached parameter list IS its parameter list, and the per-step check (twice per training
+# step) is ten pointer comparisons instead of a walk over the module tree (~20 us of a 280-us host-bound step).
+_REGISTRATIONS = [0]
+
+
+def _registered(*_args, **_kwargs):
+    _REGISTRATIONS[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_registered)
+torch.nn.modules.module.register_module_module_registration_hook(_registered)
+
 
 class _FlatView(torch.autograd.Function):
     """The flat buffer as a differentiable function of the individual parameters (what torch.cat(params) would be, with
@@ -61,6 +76,7 @@ class FlatParamsMixin:
                 p.data = flat[off:off + n].view(p.shape)
                 off += n
         self._flat, self._flat_params, self._flat_grad = flat, params, None
+        self._flat_seen = -1       # the registration count at which the cached list was last compared with the module tree
 
     def _flat_ok(self):
         """the cached list IS the module's current parameters (identity: load_state_dict(assign=True) or any replacement of an
@@ -68,9 +84,20 @@ class FlatParamsMixin:
         f, ps = self._flat, self._flat_params
         if f is None or len(ps) == 0:
             return False
+        if getattr(self, "_flat_seen", -1) == _REGISTRATIONS[0]:
+            # nothing has been registered anywhere since the list was last checked against the tree: only a caller assigning
+            # p.data (which registers nothing) can have moved a parameter
+            off, base, es = 0, f.data_ptr(), f.element_size()
+            for p in ps:
+                if p.data_ptr() != base + es * off:
+                    return False
+                off += p.numel()
+            return True
+        seen = _REGISTRATIONS[0]
         cur = list(self.net.parameters())
         if len(cur) != len(ps) or any(a is not b for a, b in zip(cur, ps)):
             return False
+        self._flat_seen = seen
         off, es = 0, f.element_size()
         for p in ps:
             if p.device != f.device or p.dtype != f.dtype or not p.is_contiguous() or p.data_ptr() != f.data_ptr() + es * off:

@@ -10,7 +10,10 @@ dev = "cuda:0"
 torch.manual_seed(0)
 net = RotPredict(out_type="skewvec", precision="bf16").to(dev)
 proc = SO3Diffusion(net, timesteps=1000).to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=3e-4, fused=(len(sys.argv) > 1))
+from so3x import optim as so3x_optim
+which = sys.argv[1] if len(sys.argv) > 1 else "so3x"   # so3x | torch | torch-fused
+opt = (so3x_optim.Adam(net, lr=3e-4) if which == "so3x" else
+       torch.optim.Adam(net.parameters(), lr=3e-4, fused=(which == "torch-fused")))
 n = 1 << 12   # tiny batch: host-bound
 x0 = B.quat_to_rmat(torch.randn(n, 4, device=dev))
 def step():
@@ -28,4 +31,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28); st.sort_stats("tottime").print_stats(22)
