@@ -322,6 +322,38 @@ def test_score_network_parameters_live_in_one_flat_buffer(golden):
         assert torch.equal(torch.cat([p.grad.reshape(-1) for p in net.net.parameters()]), 2 * w)
 
 
+def test_flat_buffer_check_notices_replaced_parameters_and_modules():
+    """so3x.flat's per-step check is ten pointer comparisons while nothing has been registered anywhere in the process (torch's
+    global registration hooks); every way of re-homing a parameter must still be noticed: a new nn.Parameter on a layer, a replaced
+    layer, load_state_dict(assign=True), a caller assigning p.data -- flat_data() then adopts the parameters again and is current"""
+    from torch import nn
+    from so3x.so3_train import RotPredict
+    torch.manual_seed(0)
+
+    def current(net):
+        return torch.cat([p.detach().reshape(-1) for p in net.net.parameters()])
+
+    net = RotPredict(out_type="skewvec")
+    lin = next(m for m in net.net.modules() if isinstance(m, nn.Linear))
+    assert net._flat_ok() and net._flat_ok()                          # second call: the fast path
+    lin.weight = nn.Parameter(torch.randn_like(lin.weight))           # a new Parameter object on an old layer
+    assert not net._flat_ok()
+    assert torch.equal(net.flat_data(), current(net)) and net._flat_ok()
+    idx = next(i for i, m in enumerate(net.net) if isinstance(m, nn.Linear))
+    net.net[idx] = nn.Linear(net.net[idx].in_features, net.net[idx].out_features)   # a replaced layer
+    assert not net._flat_ok()
+    assert torch.equal(net.flat_data(), current(net)) and net._flat_ok()
+    sd = {k: torch.randn_like(v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)                               # parameters re-created from the given tensors
+    assert torch.equal(net.flat_data(), torch.cat([v.reshape(-1) for v in sd.values()])) and net._flat_ok()
+    p0 = next(net.net.parameters())
+    p0.data = torch.zeros_like(p0)                                     # registers nothing: the pointer check catches it
+    assert not net._flat_ok()
+    assert torch.equal(net.flat_data(), current(net)) and float(net.flat_data()[:p0.numel()].abs().sum()) == 0.0
+    other = RotPredict(out_type="skewvec")                             # registrations elsewhere only cost one full check
+    assert net._flat_ok() and other._flat_ok()
+
+
 def test_gradients_from_a_plain_torch_path_are_gathered():
     from so3x.so3_train import RotPredict
     net = RotPredict(out_type="skewvec")
