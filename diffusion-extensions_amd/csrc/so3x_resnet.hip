@@ -258,9 +258,10 @@ struct StashPtr { char* x; char* y; size_t layer_stride; };  // this wave's 16-K
 template <bool NT = false> __device__ __forceinline__ void stash_tile(char* blk, int to, int lane, const uint32_t* p8) {
   asm volatile("" : "+v"(lane));  // per-lane store address formed at the store, not kept (or spilled) across the pass
   u32x4* d = reinterpret_cast<u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 16);
-  // NT = non-temporal stores.  Measured both ways: they keep the dumps from evicting the L2-resident weight image (training
-  // forward alone 1.11 -> 0.97 ms at 2^19 samples), but the backward kernels that read the dumps next then find nothing
-  // in the memory-side cache and the whole step got SLOWER (2.94 -> 3.2 ms, same box) -- off.
+  // NT = non-temporal.  Every dump is written once and read once, 10 GB of them per step against a 768 KB weight image that every
+  // workgroup re-reads from L2: all dump stores, the dX chain's Y loads and the dW kernel's LDS-DMAs carry the hint (round 4, as a
+  // replayed graph at 2^19 samples, same box: X dumps 2.32 -> 2.12 ms, + Y and dZ dumps 2.07, + the Y loads 2.06, + the DMAs
+  // 2.03).  Round 2 had tried the stores alone, in the old lane-own-32-bytes layout, and seen the step get SLOWER (2.94 -> 3.2).
   if constexpr (NT) {
     __builtin_nontemporal_store(u32x4{p8[0], p8[1], p8[2], p8[3]}, d);
     __builtin_nontemporal_store(u32x4{p8[4], p8[5], p8[6], p8[7]}, d + 64);
@@ -304,7 +305,7 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
   auto stash_x = [&](const Operand<PREC>& o, int l) {
     if constexpr (STASH && PREC == SO3X_PREC_BF16) {
 #pragma unroll
-      for (int to = 0; to < 8; to++) stash_tile(sp.x + l * sp.layer_stride, to, lane, &o.hi[8 * to]);
+      for (int to = 0; to < 8; to++) stash_tile<true>(sp.x + l * sp.layer_stride, to, lane, &o.hi[8 * to]);
     } else if constexpr (STASH) {
 #pragma unroll
       for (int to = 0; to < 8; to++) stash_tile_f32(sp.x + l * sp.layer_stride, to, lane, &o.x[16 * to]);
@@ -315,7 +316,7 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
       uint32_t p8[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) p8[i] = pack2(a[2 * i], a[2 * i + 1]);
-      stash_tile(sp.y + l * sp.layer_stride, to, lane, p8);
+      stash_tile<true>(sp.y + l * sp.layer_stride, to, lane, p8);
     } else if constexpr (STASH) {
       float z[16];
 #pragma unroll
@@ -537,7 +538,7 @@ __global__ void __launch_bounds__(256) k_resnet_image_t(const float* __restrict_
 
 __device__ __forceinline__ void load_tile(const char* blk, int to, int lane, uint32_t* p8) {
   const u32x4* s = reinterpret_cast<const u32x4*>(blk + to * 2048 + (2 * (lane & 31) + (lane >> 5)) * 16);
-  const u32x4 a = s[0], b = s[64];
+  const u32x4 a = __builtin_nontemporal_load(s), b = __builtin_nontemporal_load(s + 64);  // read once (the comment at stash_tile)
   p8[0] = a.x; p8[1] = a.y; p8[2] = a.z; p8[3] = a.w; p8[4] = b.x; p8[5] = b.y; p8[6] = b.z; p8[7] = b.w;
 }
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
@@ -607,7 +608,7 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
           }
           dzop[8 * to + i] = pack2(g2[0], g2[1]);
         }
-        stash_tile(stash_dz + l * layer_stride + blk, to, lane, &dzop[8 * to]);
+        stash_tile<true>(stash_dz + l * layer_stride + blk, to, lane, &dzop[8 * to]);
       }
       // no drain here: vmcnt is in issue order, so the waits for this layer's Y loads have already retired every older DMA,
       // and the only operations still in flight are the last tile's two dZ stores -- the counted waits below absorb them
@@ -644,6 +645,7 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
 // takes DUMP_TILE bytes there), and are read back as MFMA operands with ds_read_b64_tr_b16 (K = the sample index): the quad
 // (sample s, features 4 fq .. 4 fq+3) of a dump, lane index 2 s + (fq & 1), quad j = (fq >> 1) & 3 of the lane's eight, sits at
 //   (fq >> 3) DUMP_TILE + (j >> 1) DUMP_PART1 + (2 s + (fq & 1)) 16 + (j & 1) 8.
+constexpr int DUMP_NT = 2;  // cache-policy bits of the dumps' LDS-DMA: non-temporal (read once; the comment at stash_tile)
 constexpr int DUMP_PART1 = 1024 + 128, DUMP_TILE = 2048 + 128, DUMP_LDS = 8 * DUMP_TILE;
 struct DumpReadLane { int off[2]; };  // [part]: samples +0 / +4
 __device__ __forceinline__ DumpReadLane dump_read_lane(int lane) {
@@ -854,9 +856,9 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(lx + i * DUMP_PART1), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lx + i * DUMP_PART1), 16, 0, DUMP_NT);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gd + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(lx + DUMP_LDS + i * DUMP_PART1), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lx + DUMP_LDS + i * DUMP_PART1), 16, 0, DUMP_NT);
     }
   };
   for (int u = 0; u < 3; u++)
