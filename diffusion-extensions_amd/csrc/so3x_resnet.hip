@@ -827,7 +827,11 @@ k_resnet_dw_f32(const char* __restrict__ stash_x, const char* __restrict__ stash
     for (int r = 0; r < 16; r++) P[(32 * wave + row_of(r, h)) * 256 + 32 * tj + m] = acc[tj][r];
 }
 
-constexpr int DW_SPLITS = 36;  // (6 + 1) layers x 36 sample ranges = 252 workgroups
+constexpr int DW_SPLITS = 36;  // fp32 path: (6 + 1) layers x 36 sample ranges = 252 workgroups
+// bf16 path: the output layer's dZ dump is ONE tile (2 KiB of a block's 16: rows 0..3, 8, 9 of tile 0 are the head's outputs), so a
+// head workgroup moves 18 KiB per block where a hidden layer's moves 32: 6 x 39 + 22 = 256 workgroups, 13.4 MB each at 2^19
+// samples (7 x 36 = 252 moved 14.6 MB each, the head's 36 reading 14 KiB of nothing per block)
+constexpr int DW_SPLITS_BODY = 39, DW_SPLITS_HEAD = 22, DW_GRID = NBLK * DW_SPLITS_BODY + DW_SPLITS_HEAD;
 
 __global__ void __launch_bounds__(512, 1)
 k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz, size_t layer_stride, int64_t nblk32,
@@ -836,9 +840,11 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
   // three blocks in flight per workgroup (96 KiB: the one-block-ahead register prefetch this replaces read at 3.7 TB/s,
   // 2/3 of the latency-bandwidth product), one raw barrier per block with counted vmcnt waits.
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [slot 4][X | dZ], DUMP_LDS bytes each
-  const int l = blockIdx.x / DW_SPLITS, split = blockIdx.x % DW_SPLITS;
+  const bool head = blockIdx.x >= NBLK * DW_SPLITS_BODY;  // output layer: only tile-row 0 carries a gradient
+  const int l = head ? NBLK : blockIdx.x / DW_SPLITS_BODY, split = head ? blockIdx.x - NBLK * DW_SPLITS_BODY : blockIdx.x % DW_SPLITS_BODY;
+  const int nsplit = head ? DW_SPLITS_HEAD : DW_SPLITS_BODY;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1;
-  const int64_t per = (nblk32 + DW_SPLITS - 1) / DW_SPLITS;
+  const int64_t per = (nblk32 + nsplit - 1) / nsplit;
   const int64_t b0 = split * per, b1 = b0 + per < nblk32 ? b0 + per : nblk32;
   const char* xs = stash_x + l * layer_stride;
   const char* ds = stash_dz + l * layer_stride;
@@ -848,7 +854,8 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
   for (int tj = 0; tj < 8; tj++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[tj][r] = 0.0f;
-  // 4 DMA pieces per wave and block: pieces 2 wave, 2 wave + 1 of each 16-KiB dump
+  // 4 DMA pieces per wave and block: pieces 2 wave, 2 wave + 1 of each 16-KiB dump (the head's dZ: tile 0 only, wave 0's two)
+  const bool dz_mine = !head || wave == 0;
   auto issue = [&](int64_t blk, int slot) {
     const char* gx = xs + (size_t)blk * 16384 + (size_t)(2 * wave) * 1024 + lane * 16;
     const char* gd = ds + (size_t)blk * 16384 + (size_t)(2 * wave) * 1024 + lane * 16;
@@ -857,18 +864,20 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
     for (int i = 0; i < 2; i++) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx + i * 1024),
                                        (__attribute__((address_space(3))) void*)(lx + i * DUMP_PART1), 16, 0, DUMP_NT);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gd + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(lx + DUMP_LDS + i * DUMP_PART1), 16, 0, DUMP_NT);
+      if (dz_mine)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gd + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(lx + DUMP_LDS + i * DUMP_PART1), 16, 0, DUMP_NT);
     }
   };
   for (int u = 0; u < 3; u++)
     if (b0 + u < b1) issue(b0 + u, u);
-  const bool head = l == NBLK;  // output layer: only tile-row 0 carries a gradient
   int slot = 0;
   for (int64_t blk = b0; blk < b1; blk++) {
-    // blocks younger than `blk` already requested: min(2, b1 - 1 - blk) -> that many x 4 DMAs may stay in flight
+    // blocks younger than `blk` already requested: min(2, b1 - 1 - blk) -> that many x 4 (2: a head wave without dZ pieces) of
+    // this wave's DMAs may stay in flight
     const int64_t younger = b1 - 1 - blk;
-    if (younger >= 2) ring_sync<8>(); else if (younger == 1) ring_sync<4>(); else ring_sync<0>();
+    if (dz_mine) { if (younger >= 2) ring_sync<8>(); else if (younger == 1) ring_sync<4>(); else ring_sync<0>(); }
+    else { if (younger >= 2) ring_sync<4>(); else if (younger == 1) ring_sync<2>(); else ring_sync<0>(); }
     if (blk + 3 < b1) issue(blk + 3, (slot + 3) & 3);  // the slot of block blk - 1: every wave is past it
     const char* img = lds + slot * (2 * DUMP_LDS);
     // a wave's eight tiles are a 2 x 4 block of the layer's 8 x 8 -- output-row tiles 2 wi, 2 wi + 1 by input-column tiles
@@ -920,7 +929,7 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
     slot = (slot + 1) & 3;
   }
   // partial[l][split][o][f], o = 32 (2 wi + r) + row(reg, h), f = 32 (4 wj + c) + (lane & 31)
-  float* P = partial + ((size_t)l * DW_SPLITS + split) * 65536;
+  float* P = partial + ((size_t)l * DW_SPLITS_BODY + split) * 65536;
   const int n32 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 8; t++)
@@ -929,17 +938,23 @@ k_resnet_dw(const char* __restrict__ stash_x, const char* __restrict__ stash_dz,
 }
 
 // fixed-order sum of the split partials into the flat gradient (state_dict order); column 255 = the bias
-__global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restrict__ partial, float* __restrict__ dparams, int nout) {
+// partial[(l * splits_body + split)][256][256]; the head's `splits_head` behind the hidden layers'
+__global__ void __launch_bounds__(256) k_resnet_dw_reduce(const float* __restrict__ partial, float* __restrict__ dparams, int nout,
+                                                          int splits_body, int splits_head) {
   const int l = blockIdx.y, o = blockIdx.x, f = threadIdx.x;
   const int rows = l < NBLK ? DW : nout;
   if (o >= rows || f >= 256) return;
   const int prow = l < NBLK ? o : row_of_head(o);  // the head's outputs sit in tile rows 0..3, 8, 9
-  const float* P = partial + (size_t)l * DW_SPLITS * 65536 + prow * 256 + f;
-  static_assert(DW_SPLITS % 4 == 0, "four interleaved partial sums");
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // independent chains: the 36 loads overlap (fixed order: deterministic)
-  for (int k = 0; k < DW_SPLITS; k += 4) {
+  const float* P = partial + (size_t)l * splits_body * 65536 + prow * 256 + f;
+  const int ns = l < NBLK ? splits_body : splits_head;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // independent chains: the loads overlap (fixed order: deterministic)
+  int k = 0;
+  for (; k + 3 < ns; k += 4) {
     s0 += P[(size_t)k * 65536]; s1 += P[(size_t)(k + 1) * 65536]; s2 += P[(size_t)(k + 2) * 65536]; s3 += P[(size_t)(k + 3) * 65536];
   }
+  if (k < ns) s0 += P[(size_t)k * 65536];
+  if (k + 1 < ns) s1 += P[(size_t)(k + 1) * 65536];
+  if (k + 2 < ns) s2 += P[(size_t)(k + 2) * 65536];
   const float s = (s0 + s1) + (s2 + s3);
   float* base = dparams + (size_t)l * LAYER_STRIDE;
   if (f < DW) base[o * DW + f] = s;
@@ -1012,7 +1027,7 @@ TrainLayout train_layout(int64_t n, int T, int precision) {
   L.y = L.x + 7 * L.layer_stride;
   L.dz = L.y + 6 * L.layer_stride;
   L.partial = L.dz + 7 * L.layer_stride;
-  L.end = L.partial + (size_t)7 * DW_SPLITS * 65536 * sizeof(float);
+  L.end = L.partial + (size_t)(DW_GRID > 7 * DW_SPLITS ? DW_GRID : 7 * DW_SPLITS) * 65536 * sizeof(float);
   return L;
 }
 
@@ -1089,7 +1104,7 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
     hipLaunchKernelGGL(k_resnet_bwd, dim3((int)(ngroups < cap_b ? ngroups : cap_b)), dim3(512), LDS, s, (const void*)(ws + L.img_t),
                        dout, yd, ws + L.dz, L.layer_stride, n, n_out);
     if ((rc = ensure_dyn_lds(attr_dw, reinterpret_cast<const void*>(&k_resnet_dw), 8 * DUMP_LDS))) return rc;
-    hipLaunchKernelGGL(k_resnet_dw, dim3(7 * DW_SPLITS), dim3(512), 8 * DUMP_LDS, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
+    hipLaunchKernelGGL(k_resnet_dw, dim3(DW_GRID), dim3(512), 8 * DUMP_LDS, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
                        partial);
   } else {
     constexpr int PREC = SO3X_PREC_F32, LDS = RING * chunk_bytes<PREC>();
@@ -1105,7 +1120,9 @@ int so3x_resnet_bwd(so3x_stream_t s_, const float* params, const float* R, const
     hipLaunchKernelGGL(k_resnet_dw_f32, dim3(7 * DW_SPLITS), dim3(512), 65536, s, xd, (const char*)(ws + L.dz), L.layer_stride, L.nblk32,
                        partial, DW_SPLITS);
   }
-  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, (const float*)partial, dparams, n_out);
+  const bool bf = precision == SO3X_PREC_BF16;
+  hipLaunchKernelGGL(k_resnet_dw_reduce, dim3(256, 7), dim3(256), 0, s, (const float*)partial, dparams, n_out,
+                     bf ? DW_SPLITS_BODY : DW_SPLITS, bf ? DW_SPLITS_HEAD : DW_SPLITS);
   return check_launch();
 }
 
