@@ -443,6 +443,8 @@ def wide_net_extra(B, torch, sched, trap_p, n=1 << 18, steps=50, reps=3):
             "ms": ms_b, "frac_of_bf16_mfma_peak": 2 * flop * nt / (ms_b * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             "hbm_GB_moved": 27 * kb, "hbm_TBps": 27 * kb / ms_b, "frac_of_hbm_peak": 27 * kb / ms_b / (HBM_PEAK_GBS / 1e3)},
         "per_kernel_durations": "profiles/r04_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this script): k_resnet_fwd<1, true>, k_resnet_bwd, k_resnet_dw",
+        "hbm_bytes_per_launch_pmc": {k: PMC.traffic(k, n=nt) for k in ("k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw")},
+        "pmc_source": PMC.source,
         "streaming_rates_of_this_hardware_TBps": "fill 6.9, read 5.3-6.3, copy 5.4 (profiles/r04_hbm_rates.json, tools/ab/read_rate.hip)"}
     return out
 

@@ -110,7 +110,11 @@ if lg:
             traffic["k_logprob_score:" + leg] = {"config": {"n": 1 << 20, "eps_input": leg}, "algorithmic_bytes_per_launch": nbytes << 20,
                                                  "fetch_size_kb": f_, "write_size_kb": w_, "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
 for k, cfg, alg in (("k_train_fused", {"n": 1 << 19}, 36 * (1 << 19) + 256 * 17556 * 4), ("k_rigid_move", {"structures": 4096, "residues": 256}, 96 * 4096 * 256), ("k_se3_q_sample_target", {"n": 1 << 20}, 128 << 20),
-                    ("k_q_sample_target", {"n": 1 << 19}, 92 << 19), ("k_mlp_fwd_stash", {"n": 1 << 19}, None), ("k_bwd_fused", {"n": 1 << 19}, None)):
+                    ("k_q_sample_target", {"n": 1 << 19}, 92 << 19), ("k_mlp_fwd_stash", {"n": 1 << 19}, None), ("k_bwd_fused", {"n": 1 << 19}, None),
+                    # the wide network's training kernels at 2^19 samples: 512 B per sample and dumped stream (X_l: 7, Y_l: 6, dZ_l: 6 + the head's one tile)
+                    ("k_resnet_fwd", {"n": 1 << 19, "what": "training forward: X and Y dumps written"}, 13 * 512 << 19),
+                    ("k_resnet_bwd", {"n": 1 << 19, "what": "dX chain: Y read, dZ written"}, (12 * 512 + 64) << 19),
+                    ("k_resnet_dw", {"n": 1 << 19, "what": "dW GEMM: X and dZ read"}, (13 * 512 + 64) << 19)):
     f_, w_ = mean("FETCH_SIZE", k), mean("WRITE_SIZE", k)
     if f_ is not None and w_ is not None:
         traffic[k] = {"config": cfg, "algorithmic_bytes_per_launch": alg, "fetch_size_kb": f_, "write_size_kb": w_,
