@@ -1,0 +1,89 @@
+// so3x_planenet.hpp -- parameter / workspace layout of the PlaneNet denoiser (reference models.py:185-210) shared by the
+// exact-fp32 form (so3x_planenet.hip) and the bf16 matrix-core form (so3x_planenet_bf16.hip).
+#pragma once
+#include "so3x_common.hpp"
+
+namespace so3x {
+namespace plane {
+
+// shape of one network
+struct Shape {
+  int64_t B, P;   // clouds, points per cloud
+  int d, H, L, F; // model width, heads, encoder layers, feed-forward width
+  int64_t N() const { return B * P; }
+  int dh() const { return d / H; }   // head width
+  int d2() const { return d / 2; }   // SIREN / time-embedding width
+};
+
+inline bool shape_ok(const Shape& s) {
+  return s.B >= 0 && s.P >= 1 && s.d >= 8 && s.H >= 1 && s.L >= 1 && s.F >= 1 && s.d % s.H == 0 && s.d % 4 == 0 && s.d <= 4096 &&
+         s.F <= 16384 && s.P <= (1 << 20) && s.B * s.P < (int64_t(1) << 31);
+}
+
+// Offsets (in floats) into the flat parameter buffer = state_dict order of the reference's module (models.py:186-196):
+// encoder.layers.{l}.{self_attn.in_proj_weight, in_proj_bias, self_attn.out_proj.weight, .bias, linear1.weight, .bias,
+// linear2.weight, .bias, norm1.weight, .bias, norm2.weight, .bias}, position_siren.{positional.weight, .bias, post_scale.weight,
+// .bias}, out_net.0.pool.0.{weight, bias}, out_net.0.lin.{weight, bias}, out_net.1.{weight, bias}.
+struct LayerOff { int64_t wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2; };
+struct ParamOff {
+  int64_t per_layer;
+  int64_t wp, bp, wps, bps, wpool, bpool, wlin, blin, wout, bout, total;
+  int d, F;
+  LayerOff layer(int l) const {
+    LayerOff o;
+    int64_t p = per_layer * l;
+    const int64_t dd = (int64_t)d * d;
+    o.wqkv = p; p += 3 * dd;
+    o.bqkv = p; p += 3 * d;
+    o.wo = p; p += dd;
+    o.bo = p; p += d;
+    o.w1 = p; p += (int64_t)F * d;
+    o.b1 = p; p += F;
+    o.w2 = p; p += (int64_t)d * F;
+    o.b2 = p; p += d;
+    o.g1 = p; p += d;
+    o.be1 = p; p += d;
+    o.g2 = p; p += d;
+    o.be2 = p; p += d;
+    return o;
+  }
+};
+inline ParamOff param_offsets(const Shape& s) {
+  ParamOff o;
+  o.d = s.d;
+  o.F = s.F;
+  const int64_t d = s.d, F = s.F, d2 = s.d / 2;
+  o.per_layer = 4 * d * d + 2 * d * F + 9 * d + F;
+  int64_t p = o.per_layer * s.L;
+  o.wp = p; p += d2 * 3;
+  o.bp = p; p += d2;
+  o.wps = p; p += d2 * d2;
+  o.bps = p; p += d2;
+  o.wpool = p; p += d;
+  o.bpool = p; p += 1;
+  o.wlin = p; p += d * d;
+  o.blin = p; p += d;
+  o.wout = p; p += 3 * d;
+  o.bout = p; p += 3;
+  o.total = p;
+  return o;
+}
+
+constexpr size_t kAlign = 256;
+inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+// sequential carve of a byte range
+struct Carve {
+  char* base;
+  size_t off = 0;
+  explicit Carve(void* b) : base(reinterpret_cast<char*>(b)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += up(count * sizeof(T));
+    return p;
+  }
+};
+
+}  // namespace plane
+}  // namespace so3x

@@ -386,6 +386,39 @@ Tensor rotate_cloud(const Tensor& rot, const Tensor& cloud, int64_t cloud_stride
   ok(so3x_rotate_cloud(strm(rot), F(dev(rot, "x")), F(dev(cloud, "data")), cloud_stride, Fm(out), rot.numel() / 9, P), "rotate_cloud");
   return out;
 }
+// PlaneNet (models.py:185-210): forward (+ the stash the backward reads when want_stash) and backward
+std::tuple<Tensor, Tensor, Tensor> planenet_fwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t dim, int64_t heads, int64_t layers,
+                                                int64_t ffn, int64_t precision, bool want_stash, bool want_encoding) {
+  GUARD(x);
+  TORCH_CHECK(x.dim() == 3 && x.size(2) == 3, "so3x: x must be [B, P, 3]");
+  const int64_t B = x.size(0), P = x.size(1);
+  TORCH_CHECK(t.numel() == B, "so3x: t must hold one timestep per cloud");
+  TORCH_CHECK(params.numel() == so3x_planenet_param_count((int)dim, (int)heads, (int)layers, (int)ffn), "so3x: params must hold ",
+              so3x_planenet_param_count((int)dim, (int)heads, (int)layers, (int)ffn), " values");
+  Tensor out = f32_like(x, {B, 3});
+  Tensor enc = f32_like(x, {want_encoding ? B : 0, P, dim});
+  const size_t wsb = so3x_planenet_workspace_bytes(B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision);
+  const size_t stb = want_stash ? so3x_planenet_stash_bytes(B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision) : 0;
+  TORCH_CHECK(B == 0 || wsb > 0, "so3x: planenet_fwd: this (dim, heads, layers, ffn, points, precision) is not supported");
+  Tensor ws = bytes(x, wsb), stash = bytes(x, stb);
+  ok(so3x_planenet_fwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), Fm(out), want_encoding && B ? Fm(enc) : nullptr,
+                       B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision, want_stash && B ? stash.mutable_data_ptr() : nullptr,
+                       ws.mutable_data_ptr(), ws.numel()),
+     "planenet_fwd");
+  return {out, stash, enc};
+}
+Tensor planenet_bwd(const Tensor& params, const Tensor& x, const Tensor& t, const Tensor& dout, const Tensor& stash, int64_t dim, int64_t heads,
+                    int64_t layers, int64_t ffn, int64_t precision) {
+  GUARD(x);
+  const int64_t B = x.size(0), P = x.size(1);
+  Tensor dparams = f32_like(x, {params.numel()});
+  Tensor ws = bytes(x, so3x_planenet_workspace_bytes(B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision));
+  ok(so3x_planenet_bwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), F(dev(dout, "dout")), Fm(dparams), B, P,
+                       (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision, dev(stash, "stash", at::kByte).const_data_ptr(),
+                       ws.mutable_data_ptr(), ws.numel()),
+     "planenet_bwd");
+  return dparams;
+}
 // wide residual score network (so3_lock_train.py:11-59)
 Tensor resnet_fwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t t_stride, int64_t n_out, int64_t precision, int64_t t_table) {
   GUARD(x);
@@ -614,6 +647,8 @@ TORCH_LIBRARY(so3x, m) {
         "float beta2, float eps, float weight_decay, float grad_scale) -> ()");
   m.def("rotate_cloud(Tensor rot, Tensor cloud, int cloud_stride, int P) -> Tensor");
   m.def("resnet_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> Tensor");
+  m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding) -> (Tensor, Tensor, Tensor)");
+  m.def("planenet_bwd(Tensor params, Tensor x, Tensor t, Tensor dout, Tensor stash, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
   m.def("resnet_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> (Tensor, Tensor)");
   m.def("resnet_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int n_out, int precision, int t_table, Tensor? stash) -> Tensor");
   m.def("resnet_p_sample_chain(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
@@ -674,6 +709,8 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("adam_step", adam_step);
   m.impl("rotate_cloud", rotate_cloud);
   m.impl("resnet_fwd", resnet_fwd);
+  m.impl("planenet_fwd", planenet_fwd);
+  m.impl("planenet_bwd", planenet_bwd);
   m.impl("resnet_fwd_stash", resnet_fwd_stash);
   m.impl("resnet_bwd", resnet_bwd);
   m.impl("resnet_p_sample_chain", resnet_p_sample_chain);

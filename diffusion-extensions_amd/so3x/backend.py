@@ -46,6 +46,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
+    "so3x_planenet_param_count", "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes", "so3x_planenet_fwd", "so3x_planenet_bwd",
     "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam", "so3x_train_fused",
 )
 
@@ -84,7 +85,10 @@ def lib():
                 l.so3x_resnet_stash_bytes.restype = C.c_size_t
                 l.so3x_prevstep_workspace_bytes.restype = C.c_size_t
                 l.so3x_train_workspace_bytes.restype = C.c_size_t
-                if l.so3x_abi_version() != 6:
+                l.so3x_planenet_workspace_bytes.restype = C.c_size_t
+                l.so3x_planenet_stash_bytes.restype = C.c_size_t
+                l.so3x_planenet_param_count.restype = C.c_int64
+                if l.so3x_abi_version() != 7:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -622,6 +626,38 @@ def resnet_p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None,
         return _call(ops().resnet_p_sample_chain, *args)
     _call(ops().resnet_p_sample_chain_out, *args, _out_like(out, x))
     return out
+
+
+# ----------------------------------------------------------------------------- PlaneNet (reference models.py:185-210)
+def planenet_param_count(dim, heads, layers, ffn=2048):
+    n = int(lib().so3x_planenet_param_count(C.c_int(dim), C.c_int(heads), C.c_int(layers), C.c_int(ffn)))
+    if n < 0:
+        raise ValueError(f"so3x: no PlaneNet with dim={dim}, heads={heads}, layers={layers}, ffn={ffn}")
+    return n
+
+
+def _planenet_in(params, x, t):
+    params = _dev(params, "params").reshape(-1)
+    x = _dev(x, "x")
+    if x.dim() != 3 or x.shape[-1] != 3:
+        raise ValueError("so3x: PlaneNet input must be [clouds, points, 3]")
+    tt = _dev(t, "t", torch.int64).reshape(-1)
+    if tt.numel() != x.shape[0]:
+        raise ValueError("so3x: PlaneNet needs one timestep per cloud")
+    return params, x, tt
+
+
+def planenet_fwd(params, x, t, dim, heads, layers, ffn=2048, precision=PREC_F32, want_stash=False, want_encoding=False):
+    """PlaneNet forward: (out [B, 3], stash for planenet_bwd or an empty tensor, encoder output [B, P, dim] or empty)"""
+    params, x, tt = _planenet_in(params, x, t)
+    return _call(ops().planenet_fwd, params, x, tt, int(dim), int(heads), int(layers), int(ffn), int(precision), bool(want_stash), bool(want_encoding))
+
+
+def planenet_bwd(params, x, t, dout, stash, dim, heads, layers, ffn=2048, precision=PREC_F32):
+    """d sum(out * dout) / d params (flat, state_dict order) from the stash planenet_fwd(want_stash=True) returned"""
+    params, x, tt = _planenet_in(params, x, t)
+    dout = _dev(dout, "dout").reshape(-1, 3)
+    return _call(ops().planenet_bwd, params, x, tt, dout, stash, int(dim), int(heads), int(layers), int(ffn), int(precision))
 
 
 # ----------------------------------------------------------------------------- SE(3) layer

@@ -54,7 +54,11 @@ class _FlatView(torch.autograd.Function):
 
 
 class FlatParamsMixin:
-    """Mixed into an nn.Module whose parameters of `self.net` live in one flat buffer."""
+    """Mixed into an nn.Module whose parameters of `self.net` (or of `self._flat_root()`, if the class overrides it) live in one
+    flat buffer."""
+
+    def _flat_root(self):
+        return self.net
 
     def _init_flat(self):
         self._flat = None          # the flat parameter buffer the nn.Parameters are views of
@@ -63,7 +67,7 @@ class FlatParamsMixin:
         self._flatten()
 
     def _flatten(self):
-        params = list(self.net.parameters())
+        params = list(self._flat_root().parameters())
         if not params:
             return
         dev, dt = params[0].device, params[0].dtype
@@ -94,7 +98,7 @@ class FlatParamsMixin:
                 off += p.numel()
             return True
         seen = _REGISTRATIONS[0]
-        cur = list(self.net.parameters())
+        cur = list(self._flat_root().parameters())
         if len(cur) != len(ps) or any(a is not b for a, b in zip(cur, ps)):
             return False
         self._flat_seen = seen

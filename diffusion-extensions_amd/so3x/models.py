@@ -6,6 +6,8 @@ import math
 import torch
 from torch import nn
 
+from .flat import FlatParamsMixin
+
 __all__ = ["SinusoidalPosEmb", "Siren", "ResLayer", "PointCloudProj", "PoolRN", "TransformerEnc2", "PlaneNet"]
 
 
@@ -102,23 +104,77 @@ class TransformerEnc2(nn.Module):
         return self.encoder(x.transpose(0, 1), src_key_padding_mask=src_key_padding_mask).transpose(0, 1)
 
 
-class PlaneNet(nn.Module):
+class _PlaneNetFn(torch.autograd.Function):
+    """autograd bridge of the PlaneNet kernels: only the parameters carry gradients (the point clouds are projections of the
+    noised pose, which needs none: reference diffusion.py:389-392)"""
+
+    @staticmethod
+    def forward(ctx, x, t, flat_params, cfg):
+        from . import backend as _b
+        out, stash, _ = _b.planenet_fwd(flat_params, x, t, *cfg, want_stash=True)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, t, flat_params, stash)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import backend as _b
+        x, t, flat_params, stash = ctx.saved_tensors
+        return None, None, _b.planenet_bwd(flat_params, x, t, dout.contiguous(), stash, *ctx.cfg), None
+
+
+class PlaneNet(FlatParamsMixin, nn.Module):
     """The point-cloud pose denoiser of the aircraft task (reference models.py:185-210): SIREN position encoding of every
     point (dim/2) next to the timestep's sinusoidal embedding (dim/2), a `layers`-deep nn.TransformerEncoder over the points,
     PoolRN over the points and a Linear to the 3 skew-vector components -- the `denoise_fn` of ProjectedSO3Diffusion with
-    PointCloudProj as the projection (aircraft_rotate.py:64-106).  Plain torch modules with the reference's state_dict keys
-    (the encoder runs on rocBLAS / MIOpen through torch; the diffusion around it is the fused kernels of this package).
+    PointCloudProj as the projection (aircraft_rotate.py:64-106).
+
+    The modules below exist for the reference's constructor order (same seed -> same initial weights) and its state_dict keys;
+    `forward` does not run them.  It runs the hand-written kernels of libso3x (so3x_planenet_fwd / so3x_planenet_bwd: embedding,
+    encoder layers with attention, pooling and head, forward and backward) on the flat parameter buffer the module parameters are
+    views of.  precision "fp32": every product on the exact-fp32 matrix-core instruction, any width; "bf16": the aircraft task's
+    shape (dim 512, 4 heads, points a multiple of 64) with bf16 operands and activations.  Dropout is NOT applied (the kernels are
+    nn.TransformerEncoderLayer's eval-mode arithmetic): `dropout` is the rate the torch modules are built with and must be 0
+    before a training-mode forward is accepted (the reference trains with torch's default 0.1, aircraft_rotate.py:66).
+    `forward_torch` runs the torch modules instead -- an explicit cross-check for tests, never taken implicitly.
+
     Returns [B, 3]: one prediction per cloud.  (The reference's forward ends in `out[..., 0, :]` on that [B, 3] tensor,
     models.py:210, i.e. it hands back sample 0's row only, and its pooling fails for batch != points -- see PoolRN.)"""
 
-    def __init__(self, dim=512, heads=4, layers=4):
+    def __init__(self, dim=512, heads=4, layers=4, precision="fp32", dropout=0.1):
         super().__init__()
-        self.encoder = nn.TransformerEncoder(nn.TransformerEncoderLayer(dim, heads), layers)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.encoder = nn.TransformerEncoder(nn.TransformerEncoderLayer(dim, heads, dropout=dropout), layers)
         self.position_siren = Siren(in_channels=3, out_channels=dim // 2, scale=30)
         self.time_embedding = SinusoidalPosEmb(dim // 2)
         self.out_net = nn.Sequential(PoolRN(dim), nn.Linear(dim, 3))
+        self.dim, self.heads, self.layers, self.precision, self.dropout = dim, heads, layers, precision, dropout
+        self.ffn = self.encoder.layers[0].linear1.out_features
+        self._init_flat()
 
-    def forward(self, x, t):
+    def _flat_root(self):
+        return self
+
+    @property
+    def cfg(self):
+        from . import backend as _b
+        return (self.dim, self.heads, self.layers, self.ffn, _b.PREC_BF16 if self.precision == "bf16" else _b.PREC_F32)
+
+    def forward(self, x, t, want_encoding=False):
+        from . import backend as _b
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("so3x: the PlaneNet kernels implement nn.TransformerEncoderLayer without dropout; build the network "
+                                      "with dropout=0 (or call .eval()) -- a silent fallback to torch's modules is not offered")
+        if want_encoding:
+            out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_encoding=True)
+            return out, enc
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _PlaneNetFn.apply(x, t, self.flat_params(), self.cfg)
+        return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg)[0]
+
+    def forward_torch(self, x, t):
+        """the same network through torch's own modules (any device): test infrastructure"""
         x_emb = self.position_siren(x)                                         # [B, P, dim/2]
         t_emb = self.time_embedding(t)                                         # [B, dim/2]
         t_in = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)

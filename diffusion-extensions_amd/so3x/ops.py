@@ -222,6 +222,19 @@ def _(rot, cloud, cloud_stride, P):
     return _f32(rot, rot.shape[:-2] + (P, 3))
 
 
+@register_fake("so3x::planenet_fwd")
+def _(params, x, t, dim, heads, layers, ffn, precision, want_stash, want_encoding):
+    B, P = x.shape[0], x.shape[1]
+    # an upper bound is all a fake needs: per token and layer 7 dim + ffn + heads * P floats
+    stash = (B * P * layers * (8 * dim + ffn + heads * P) * 4 + (1 << 20)) if want_stash else 0
+    return _f32(x, (B, 3)), x.new_empty((stash,), dtype=torch.uint8), _f32(x, (B if want_encoding else 0, P, dim))
+
+
+@register_fake("so3x::planenet_bwd")
+def _(params, x, t, dout, stash, dim, heads, layers, ffn, precision):
+    return _f32(x, (params.numel(),))
+
+
 @register_fake("so3x::resnet_fwd")
 def _(params, x, t, t_stride, n_out, precision, t_table):
     return _f32(x, x.shape[:-2] + (n_out,))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 6
+#define SO3X_ABI_VERSION 7
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -278,6 +278,37 @@ int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const
  * 525-573) feed their denoisers with: out[n][P][3] = cloud @ rot[n]^T.  cloud_stride 0: one cloud [P][3] for every rotation;
  * 3 P: one cloud per rotation, cloud[n][P][3] (how aircraft_rotate.py:104-106 calls it: a batch of shapes, one pose each). */
 int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int64_t cloud_stride, float* out, int64_t n, int64_t P);
+
+/* -------------------------------------------- PlaneNet: the point-cloud pose denoiser (8f row 4)
+ * models.PlaneNet (models.py:185-210), the denoise_fn ProjectedSO3Diffusion trains in aircraft_rotate.py:64-108:
+ *   x [B][P][3] points, t int64 [B]  ->
+ *   h0 = [ Siren(3 -> dim/2, scale 30): post_scale(sin(positional(x)))  (models.py:50-72)  ||  SinusoidalPosEmb(dim/2)(t)  (models.py:13-25) ]
+ *   `layers` x nn.TransformerEncoderLayer(dim, heads): post-norm, ReLU, feed-forward `ffn` (torch's default 2048), LayerNorm eps
+ *        1e-5, attention over the P points of one cloud, no mask; dropout OFF (eval-mode arithmetic: what the validation pass,
+ *        aircraft_rotate.py:113-117, and ProjectedSO3Diffusion.p_sample run)
+ *   PoolRN(dim) with every point unmasked (models.py:94-110)  ->  Linear(dim, 3)            -> out [B][3]
+ * params: the fp32 values in state_dict order -- encoder.layers.{l}.{self_attn.in_proj_weight, self_attn.in_proj_bias,
+ *   self_attn.out_proj.weight, self_attn.out_proj.bias, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight,
+ *   norm1.bias, norm2.weight, norm2.bias}, position_siren.{positional.weight, positional.bias, post_scale.weight, post_scale.bias},
+ *   out_net.0.pool.0.{weight, bias}, out_net.0.lin.{weight, bias}, out_net.1.{weight, bias}: so3x_planenet_param_count values.
+ * precision SO3X_PREC_F32: every product on the exact-fp32 MFMA, any (dim, heads, layers, ffn) with dim % heads == 0, dim % 4 == 0;
+ *           SO3X_PREC_BF16: bf16 operands / fp32 accumulate, activations kept in bf16; dim = 512, heads = 4 (head width 128),
+ *           ffn = 2048, P % 64 == 0 only (the aircraft task's shape), else SO3X_ERR_UNSUPPORTED.
+ * so3x_planenet_fwd: stash == NULL: inference (layer buffers reused inside the workspace).  stash != NULL
+ *   (so3x_planenet_stash_bytes): every layer's activations are kept there for so3x_planenet_bwd.  encoding_out (optional):
+ *   the encoder's output [B][P][dim] fp32 (parity tests).
+ * so3x_planenet_bwd: dparams[param_count] (overwritten) = d sum(out * dout) / d params for dout [B][3], from the stash the
+ *   forward wrote for the SAME params, x, t.  (The inputs carry no gradient: x is a projection of the noised pose,
+ *   diffusion.py:389-392.)  Deterministic: fixed-order reductions, no atomics.
+ * workspace: so3x_planenet_workspace_bytes covers either call. */
+int64_t so3x_planenet_param_count(int dim, int heads, int layers, int ffn);
+size_t so3x_planenet_workspace_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
+size_t so3x_planenet_stash_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
+int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, float* out, float* encoding_out, int64_t B,
+                      int64_t P, int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes);
+int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, const float* dout, float* dparams, int64_t B,
+                      int64_t P, int dim, int heads, int layers, int ffn, int precision, const void* stash, void* workspace,
+                      size_t workspace_bytes);
 
 /* ------------------------------------------------------- sample-quality statistics */
 /* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):

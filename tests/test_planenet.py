@@ -1,0 +1,177 @@
+"""PlaneNet on the hand-written kernels (reference models.py:185-210, aircraft_rotate.py:64-117):
+so3x_planenet_fwd / so3x_planenet_bwd against values the reference's own modules produced (tools/make_golden.py planenet).
+
+Two fixtures: `planenet.npz` -- a small network (dim 32, 4 heads, 2 layers) with its full state_dict, every intermediate and every
+parameter gradient; `planenet_full.npz` -- the aircraft task's own width (dim 512, 4 heads, 4 layers, 12.9 M parameters) at 24, 256
+and 2048 points, whose weights are rebuilt here from the same seeds (checksums in the fixture pin them)."""
+import numpy as np
+import pytest
+import torch
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def planenet_perturb(net, seed):
+    """tools/make_golden.py:planenet_perturb, verbatim: a seeded nudge of every parameter (a fresh nn.TransformerEncoder's layers
+    are deep copies of one layer; the nudge makes them differ)"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in sorted(net.named_parameters()):
+            p.add_(torch.randn(p.shape, generator=g) * (0.05 * float(p.abs().mean()) + 1e-3))
+
+
+def small_net(golden, precision="fp32"):
+    from so3x.models import PlaneNet
+    g = golden["planenet"]
+    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"]), precision=precision, dropout=0.0)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    assert list(net.state_dict().keys()) == list(sd.keys())                      # the reference's checkpoint keys, in its order
+    net.load_state_dict(sd)
+    return net, g
+
+
+def full_net(golden, precision):
+    from so3x.models import PlaneNet
+    g = golden["planenet_full"]
+    torch.manual_seed(21)
+    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"]), precision=precision, dropout=0.0)
+    planenet_perturb(net, 5)
+    for k, v in net.state_dict().items():                                       # the weights ARE the ones the fixture was made with
+        chk = g["chk_" + k]
+        v64 = v.double()
+        assert abs(float(v64.sum()) - chk[0]) <= 1e-9 * max(1.0, abs(chk[0])) and abs(float(v64.norm()) - chk[1]) <= 1e-9 * chk[1], k
+    return net, g
+
+
+# ------------------------------------------------------------------------------------------------ CPU: layout and host logic
+def test_flat_parameter_layout_is_the_state_dict_order(golden):
+    """the kernels address ONE flat buffer by offsets computed from (dim, heads, layers, ffn): the module's parameters must sit in
+    it in state_dict order, and the C library must agree about the count"""
+    from so3x import backend as B
+    net, g = small_net(golden)
+    flat = net.flat_data()
+    assert flat.numel() == sum(p.numel() for p in net.parameters()) == B.planenet_param_count(32, 4, 2, 2048)
+    off = 0
+    for k, v in net.state_dict().items():
+        assert torch.equal(flat[off:off + v.numel()].view(v.shape), v), k
+        assert v.data_ptr() == flat.data_ptr() + 4 * off, k
+        off += v.numel()
+    assert B.planenet_param_count(512, 4, 4) == 12_941_060
+    with pytest.raises(ValueError):
+        B.planenet_param_count(30, 4, 2)       # dim % heads != 0
+
+
+def test_torch_module_composition_is_the_reference(golden):
+    """forward_torch (the torch modules the state_dict keys come from) reproduces the reference's blocks: the fixture and the
+    module tree agree, so a kernel that matches the fixture matches the reference"""
+    net, g = small_net(golden)
+    net.eval()
+    with torch.no_grad():
+        out = net.forward_torch(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
+    assert np.abs(out.numpy() - g["out"]).max() < 1e-5
+
+
+def test_cpu_tensors_are_refused(golden):
+    from so3x.backend import So3xError
+    net, g = small_net(golden)
+    net.eval()
+    with pytest.raises(So3xError):
+        net(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
+
+
+def test_training_mode_with_dropout_is_refused():
+    from so3x.models import PlaneNet
+    net = PlaneNet(dim=32, heads=4, layers=1)      # torch's default dropout 0.1, as the reference builds it
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 8, 3), torch.zeros(1, dtype=torch.long))
+
+
+# ------------------------------------------------------------------------------------------------ GPU: fp32 form vs the reference
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.gpu
+def test_small_forward_vs_reference(golden):
+    net, g = small_net(golden)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        out, enc = net(dev(g["x"]), dev(g["t"], torch.int64), want_encoding=True)
+    # fp32 through a SIREN with |pre-activation| up to ~100 (ulp 7.6e-6) and two post-norm layers: the reference's own fp32 run
+    # sits this far from its float64 run (fixture: out64 / encoding64)
+    e_ref = max(np.abs(g["encoding"] - g["encoding64"]).max(), 1e-6)
+    assert np.abs(enc.cpu().numpy() - g["encoding64"]).max() < max(2e-5, 3 * e_ref)
+    assert np.abs(out.cpu().numpy() - g["out64"]).max() < max(1e-5, 3 * np.abs(g["out"] - g["out64"]).max())
+    assert np.abs(out.cpu().numpy() - g["out"]).max() < 2e-5
+    # the plain call returns the same numbers
+    with torch.no_grad():
+        assert torch.equal(net(dev(g["x"]), dev(g["t"], torch.int64)), out)
+
+
+@pytest.mark.gpu
+def test_small_backward_vs_reference_autograd(golden):
+    net, g = small_net(golden)
+    net = net.to(DEV).train()      # dropout 0: training mode is accepted
+    out = net(dev(g["x"]), dev(g["t"], torch.int64))
+    (out * dev(g["dout"])).sum().backward()
+    worst = {}
+    for k, p in net.named_parameters():
+        want = g["grad_" + k]
+        assert p.grad is not None and p.grad.shape == want.shape, k
+        worst[k] = rel(p.grad.cpu().numpy(), want)
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    assert not bad, bad
+    # deterministic: a second backward gives the same bits
+    flat1 = net.flat_grad().clone()
+    net.zero_grad(set_to_none=True)
+    (net(dev(g["x"]), dev(g["t"], torch.int64)) * dev(g["dout"])).sum().backward()
+    assert torch.equal(net.flat_grad(), flat1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [24, 256, 2048])
+def test_full_width_fp32_vs_reference(golden, P):
+    net, g = full_net(golden, "fp32")
+    net = net.to(DEV).train()
+    tag = f"P{P}_"
+    x, t, dout = dev(g[tag + "x"]), dev(g[tag + "t"], torch.int64), dev(g[tag + "dout"])
+    with torch.no_grad():
+        out_e, enc = net(x, t, want_encoding=True)
+    ends = torch.cat((enc[:, :4], enc[:, -4:]), 1).cpu().numpy()
+    assert np.abs(ends - g[tag + "encoding_ends"]).max() < 1e-4          # LayerNorm outputs, O(1) entries
+    assert np.abs(out_e.cpu().numpy() - g[tag + "out"]).max() < 2e-5
+    out = net(x, t)
+    assert torch.equal(out.detach(), out_e)
+    (out * dout).sum().backward()
+    for k, p in net.named_parameters():
+        gs, pick = g[tag + "gsum_" + k], g[tag + "gpick_" + k]
+        flat = p.grad.reshape(-1)
+        stride = max(1, flat.numel() // 64)
+        got = flat[::stride][:64].cpu().numpy()
+        scale = gs[1] / np.sqrt(flat.numel())                              # rms entry of this gradient
+        assert np.abs(got - pick).max() < 2e-3 * max(scale, np.abs(pick).max()), k
+        assert abs(float(flat.double().norm()) - gs[1]) < 1e-3 * gs[1], k
+
+
+@pytest.mark.gpu
+def test_ragged_and_empty_shapes(golden):
+    """points not a multiple of any tile, one cloud, zero clouds"""
+    from so3x import backend as B
+    net, g = small_net(golden)
+    net = net.to(DEV).eval()
+    cpu = small_net(golden)[0].eval()
+    gen = torch.Generator().manual_seed(3)
+    for Bn, P in ((1, 1), (3, 67), (2, 130)):
+        x = torch.randn(Bn, P, 3, generator=gen) * 0.5
+        t = torch.randint(0, 1000, (Bn,), generator=gen)
+        with torch.no_grad():
+            want = cpu.forward_torch(x, t)
+            got = net(x.to(DEV), t.to(DEV))
+        assert float((got.cpu() - want).abs().max()) < 3e-5, (Bn, P)
+    with torch.no_grad():
+        assert net(torch.zeros(0, 5, 3, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV)).shape == (0, 3)

@@ -99,7 +99,7 @@ def test_projected_se3_diffusion_matches_base_with_identity_projection():
 def _planenet(golden, device="cpu"):
     from so3x.models import PlaneNet
     g = golden["planenet"]
-    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"])).eval()
+    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"]), dropout=0.0).eval()
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
     assert set(net.state_dict().keys()) == set(sd.keys())                      # the reference's checkpoint keys
     net.load_state_dict(sd)
@@ -111,7 +111,7 @@ def test_planenet_blocks_vs_reference(golden):
     embedding -> TransformerEncoder -> PoolRN with an all-true [B, P] mask -> Linear): CPU, torch against torch"""
     net, g = _planenet(golden)
     with torch.no_grad():
-        out = net(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
+        out = net.forward_torch(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
         x_emb = net.position_siren(torch.from_numpy(g["x"]))
         t_in = torch.cat((x_emb, net.time_embedding(torch.from_numpy(g["t"]))[:, None, :].expand(x_emb.shape)), dim=2)
         enc = net.encoder(t_in.transpose(0, 1)).transpose(0, 1)
@@ -130,8 +130,8 @@ def test_planenet_blocks_vs_reference(golden):
 @pytest.mark.gpu
 def test_planenet_as_the_denoiser_of_projected_so3_diffusion(golden):
     """the aircraft task's wiring (aircraft_rotate.py:64-106): a batch of point clouds, one pose each, PointCloudProj as the
-    projection, PlaneNet as the denoiser of ProjectedSO3Diffusion -- the noising / target / posterior / noise steps are this
-    package's kernels, the transformer is torch's.  The network equals the reference's on the GPU too, per-sample clouds equal
+    projection, PlaneNet as the denoiser of ProjectedSO3Diffusion -- the noising / target / posterior / noise steps AND the
+    transformer (so3x_planenet_fwd / _bwd, through autograd) are this package's kernels.  The network equals the reference's on the GPU too, per-sample clouds equal
     torch.matmul's batching, a few Adam steps lower the loss, and the reverse loop returns rotations."""
     from so3x.diffusion import ProjectedSO3Diffusion
     from so3x.models import PointCloudProj

@@ -879,11 +879,37 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "orthogonalis
     orthogonalise_golden()
 
 
-def planenet_golden(B=6, P=24, dim=32, heads=4, layers=1):
+def planenet_perturb(net, seed):
+    """A seeded nudge of every parameter.  nn.TransformerEncoder deep-copies its layer, so all layers of a freshly built PlaneNet
+    start IDENTICAL (models.py:189-191); the nudge makes them differ, so that a kernel reading layer l's weights for layer m is
+    caught.  tests/test_planenet.py repeats this function verbatim to rebuild the same weights from the same seeds."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in sorted(net.named_parameters()):
+            p.add_(torch.randn(p.shape, generator=g) * (0.05 * float(p.abs().mean()) + 1e-3))
+
+
+def _planenet_run(net, x, t, dout):
+    """the reference's PlaneNet blocks in its own order (models.py:198-209) with an explicit all-true [B, P] pooling mask, eval
+    mode (no dropout), and the gradient of sum(out * dout) with respect to every parameter"""
+    B, P = x.shape[:2]
+    x_emb = net.position_siren(x)
+    t_emb = net.time_embedding(t)
+    t_in = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)
+    enc = net.encoder(t_in.transpose(0, 1)).transpose(0, 1)
+    pooled = net.out_net[0](enc, mask=torch.ones(B, P, dtype=torch.bool))
+    out = net.out_net[1](pooled)
+    names = [k for k, p in net.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad((out * dout).sum(), [p for _, p in net.named_parameters() if p.requires_grad])
+    return t_in.detach(), enc.detach(), pooled.detach(), out.detach(), dict(zip(names, grads))
+
+
+def planenet_golden(B=6, P=24, dim=32, heads=4, layers=2):
     """The reference's PlaneNet building blocks (models.py:94-110, 185-210) on a small cloud batch: its own submodules run in
     its own order, with the pooling given an explicit all-true mask of shape [B, P] (the default-mask branch of PoolRN only
     broadcasts for B == P, and PlaneNet.forward then keeps sample 0's row only: reference bugs, not reproduced).  Stores the
-    state_dict, the inputs, the encoder output and the [B, 3] prediction."""
+    state_dict, the inputs, the embedded input, the encoder output, the [B, 3] prediction, and -- for an upstream gradient `dout`
+    -- the gradient of every parameter (torch autograd, eval mode: TransformerEncoderLayer's dropout is off)."""
     _install_stubs()
     sys.path.insert(0, REF)
     import warnings
@@ -891,22 +917,62 @@ def planenet_golden(B=6, P=24, dim=32, heads=4, layers=1):
     import models as rmodels
     torch.manual_seed(21)
     net = rmodels.PlaneNet(dim=dim, heads=heads, layers=layers).eval()
+    planenet_perturb(net, 5)
     x = torch.randn(B, P, 3) * 0.5
     t = torch.randint(0, 1000, (B,))
-    with torch.no_grad():
-        x_emb = net.position_siren(x)
-        t_emb = net.time_embedding(t)
-        t_in = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)
-        enc = net.encoder(t_in.transpose(0, 1)).transpose(0, 1)
-        pooled = net.out_net[0](enc, mask=torch.ones(B, P, dtype=torch.bool))
-        out = net.out_net[1](pooled)
-    fix = {"x": npy(x), "t": npy(t), "encoding": npy(enc), "pooled": npy(pooled), "out": npy(out),
+    dout = torch.randn(B, 3)
+    t_in, enc, pooled, out, grads = _planenet_run(net, x, t, dout)
+    import copy
+    _, enc64, _, out64, _ = _planenet_run(copy.deepcopy(net).double(), x.double(), t, dout.double())   # the float64 run of the same weights
+    fix = {"x": npy(x), "t": npy(t), "dout": npy(dout), "embedded": npy(t_in), "encoding": npy(enc), "pooled": npy(pooled), "out": npy(out),
+           "encoding64": npy(enc64), "out64": npy(out64),
            "dim": np.int64(dim), "heads": np.int64(heads), "layers": np.int64(layers)}
     for k, v in net.state_dict().items():
         fix["sd_" + k] = npy(v)
+    for k, v in grads.items():
+        fix["grad_" + k] = npy(v)
     np.savez_compressed(os.path.join(OUT, "planenet.npz"), **fix)
     print("planenet.npz", os.path.getsize(os.path.join(OUT, "planenet.npz")) / 1024, "KB")
 
 
+def planenet_full_golden(dim=512, heads=4, layers=4, B=2, points=(24, 256, 2048)):
+    """The same at the aircraft task's own width (aircraft_rotate.py:32-47: dim 512, 4 heads, 4 layers; 12.6 M parameters = 50 MB,
+    too large to commit).  The weights are therefore REBUILT from seeds on both sides -- torch.manual_seed(21) default init of the
+    reference's constructor + planenet_perturb(net, 5); so3x.models.PlaneNet builds the same modules in the same order -- and the
+    fixture pins that with float64 checksums of every tensor.  Expected values: the [B, 3] outputs in full; of the encoder output
+    the first 4 and last 4 points of every cloud; of every parameter's gradient its float64 sum, its L2 norm and 64 entries at a
+    fixed stride."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import models as rmodels
+    torch.manual_seed(21)
+    net = rmodels.PlaneNet(dim=dim, heads=heads, layers=layers).eval()
+    planenet_perturb(net, 5)
+    fix = {"dim": np.int64(dim), "heads": np.int64(heads), "layers": np.int64(layers), "points": np.asarray(points, np.int64)}
+    for k, v in net.state_dict().items():
+        v64 = v.double()
+        fix["chk_" + k] = np.asarray([float(v64.sum()), float(v64.norm())], np.float64)
+    g = torch.Generator().manual_seed(77)
+    for P in points:
+        x = torch.randn(B, P, 3, generator=g) * 0.5
+        t = torch.randint(0, 1000, (B,), generator=g)
+        dout = torch.randn(B, 3, generator=g)
+        _, enc, pooled, out, grads = _planenet_run(net, x, t, dout)
+        tag = f"P{P}_"
+        fix.update({tag + "x": npy(x), tag + "t": npy(t), tag + "dout": npy(dout), tag + "out": npy(out), tag + "pooled": npy(pooled),
+                    tag + "encoding_ends": npy(torch.cat((enc[:, :4], enc[:, -4:]), 1))})
+        for k, v in grads.items():
+            flat = v.reshape(-1)
+            stride = max(1, flat.numel() // 64)
+            fix[tag + "gsum_" + k] = np.asarray([float(flat.double().sum()), float(flat.double().norm())], np.float64)
+            fix[tag + "gpick_" + k] = npy(flat[::stride][:64])
+        print("P", P, "out", out[0].tolist())
+    np.savez_compressed(os.path.join(OUT, "planenet_full.npz"), **fix)
+    print("planenet_full.npz", os.path.getsize(os.path.join(OUT, "planenet_full.npz")) / 1024, "KB")
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "planenet":
     planenet_golden()
+    planenet_full_golden()
