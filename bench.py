@@ -588,6 +588,68 @@ def se3_legs(B, torch, reps=20):
     return out
 
 
+def secondary_rooflines(line):
+    """The other kernels' rooflines in ONE place under `roofline` (the driver's record keeps `roofline` and `cpu_baseline` whole and
+    reduces every other key to its name): per leg the kernel, its bound, achieved / peak / frac, the launch time and the
+    algorithmic work per launch the rate is computed from -- enough to recompute every fraction from this object alone."""
+    def pick(d, *keys, **extra):
+        if not isinstance(d, dict) or "error" in d:
+            return {"error": (d or {}).get("error", "leg did not run") if isinstance(d, dict) else "leg did not run"}
+        out = {k: d[k] for k in keys if k in d}
+        out.update(extra)
+        return out
+    sec = {}
+    ig = line.get("igso3_eval")
+    if isinstance(ig, dict) and "error" not in ig:
+        sec["igso3_eval (BASELINE config 2, per-sample eps from the schedule)"] = pick(
+            ig, "kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "n", "bytes_per_eval", "traffic",
+            algorithmic_bytes_per_launch=ig["bytes_per_eval"] * ig["n"])
+        if "scalar_eps_0p5" in ig:
+            sc = ig["scalar_eps_0p5"]
+            sec["igso3_eval (config 2a, scalar eps = 0.5)"] = pick(sc, "kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "n", "bytes_per_eval")
+    elif ig is not None:
+        sec["igso3_eval"] = pick(ig)
+    tr = line.get("train_step")
+    if isinstance(tr, dict) and "error" not in tr:
+        sec["train_step (BASELINE config 4 per GPU), whole step"] = {
+            "bound": "mfma", "ms_per_step": tr.get("ms_per_step"), "batch_per_gpu": tr.get("batch_per_gpu"), "flop_per_sample": TRAIN_FLOP_PER_SAMPLE,
+            "achieved": tr.get("algorithmic_TFLOPs_per_gpu"), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": None if tr.get("algorithmic_TFLOPs_per_gpu") is None else tr["algorithmic_TFLOPs_per_gpu"] / BF16_MFMA_PEAK_TFLOPS,
+            "eager_python_loop_ms_per_step": tr.get("eager_python_loop_ms_per_step")}
+        sec["train_step kernel (k_train_fused)"] = pick(tr.get("kernel"), "kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_call",
+                                                         "flop_per_sample", "algorithmic_hbm_bytes_per_call", "traffic", "mfma_pipe_busy_frac_pmc")
+    elif tr is not None:
+        sec["train_step"] = pick(tr)
+    se = line.get("se3")
+    if isinstance(se, dict) and "error" not in se:
+        for k, v in se.items():
+            sec["se3." + k + " (BASELINE config 5 per GPU)"] = pick(v, "kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "traffic",
+                                                                      "bytes_per_residue", "bytes_per_frame", "n", "structures", "residues_per_structure")
+    elif se is not None:
+        sec["se3"] = pick(se)
+    wn = line.get("wide_net")
+    if isinstance(wn, dict) and "error" not in wn:
+        sec["wide_net.chain (255-wide residual network, reverse chain)"] = pick(wn.get("chain"), "kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                                "ms_per_launch", "batch", "steps_per_launch", "flop_per_sample_step")
+        ts = wn.get("train_step", {})
+        sec["wide_net.train_step"] = pick(ts, "batch", "ms_per_step", "algorithmic_TFLOPs", "frac_of_bf16_mfma_peak", bound="hbm (the design's register dumps) / mfma",
+                                          peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s")
+    elif wn is not None:
+        sec["wide_net"] = pick(wn)
+    pn = line.get("planenet")
+    if isinstance(pn, dict) and "error" not in pn:
+        for k, v in pn.items():
+            if isinstance(v, dict) and "frac" in v:
+                sec["planenet." + k] = pick(v, "kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "flop", "clouds", "points")
+    elif pn is not None:
+        sec["planenet"] = pick(pn)
+    el = line.get("external_loop")
+    if el is not None:
+        sec["external_loop (one p_sample call per reverse step, so3_test.py:28-31)"] = pick(el, "sample_steps_per_s", "ms_per_call", "calls", "batch",
+                                                                                          "vs_chain_kernel_rate")
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -621,6 +683,15 @@ def main():
     torch.manual_seed(0)
     net = RotPredict(out_type="skewvec", precision=args.precision)          # seed-0 default init (CPU generator)
     q = torch.randn(n, 4, generator=torch.Generator().manual_seed(ctx.rank))  # synthetic random quaternions
+    # the CPU baseline FIRST (rank 0 at N = 1 only; ~6 s of host work): every second after it is GPU work, so a driver that samples
+    # GPU utilisation during the run sees the GPU legs, not the host leg
+    cpu_leg = None
+    if not args.no_cpu_baseline and ctx.world_size == 1 and ctx.rank == 0:
+        try:
+            cpu_leg = cpu_baseline(T, net.flat_params_nograd().detach().cpu().numpy(), B.cosine_beta_schedule(T))
+        except Exception as e:  # report, never hide -- and never lose the GPU line to a host-side build problem
+            cpu_leg = {"error": repr(e)}
+    t_gpu_legs = time.perf_counter()
     net = net.to(dev)
     proc = SO3Diffusion(net, timesteps=T).to(dev)
     _, trap_p = proc._tables()
@@ -832,8 +903,10 @@ def main():
                 line["wide_net"] = wide_net_extra(B, torch, proc._sched, trap_p)
             except Exception as e:
                 line["wide_net"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and ctx.world_size == 1:  # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(T, params.cpu().numpy(), B.cosine_beta_schedule(T))
+        if cpu_leg is not None:
+            line["cpu_baseline"] = cpu_leg
+        line["roofline"]["secondary"] = secondary_rooflines(line)
+        line["gpu_legs_wall_seconds"] = time.perf_counter() - t_gpu_legs
         print(json.dumps(line), flush=True)
     parallel.finalize(ctx)
 

@@ -99,17 +99,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmP p) {
   }
 }
 
-struct Mat {  // a strided matrix view: element (i, j) at p[i * s0 + j * s1]
-  const float* p;
-  int64_t s0, s1;
-};
-inline Mat rowmajor(const float* p, int64_t ld) { return Mat{p, ld, 1}; }
-inline Mat transposed(const float* p, int64_t ld) { return Mat{p, 1, ld}; }   // view (i, j) = stored [j][i]
-
-// C = alpha A B (+ bias) ..., A: M x K, B: K x N
-inline int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f,
-                bool relu = false, bool accumulate = false, int nb0 = 1, int nb1 = 1, int64_t sA0 = 0, int64_t sA1 = 0, int64_t sB0 = 0,
-                int64_t sB1 = 0, int64_t sC0 = 0, int64_t sC1 = 0) {
+// C = alpha A B (+ bias) ..., A: M x K, B: K x N  (declared in so3x_planenet.hpp)
+int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, const float* bias, float alpha, bool relu, bool accumulate,
+         int nb0, int nb1, int64_t sA0, int64_t sA1, int64_t sB0, int64_t sB1, int64_t sC0, int64_t sC1) {
   if (M <= 0 || N <= 0 || nb0 * nb1 <= 0) return SO3X_OK;
   GemmP p{A.p, B.p, C, bias, M, N, K, A.s0, A.s1, B.s0, B.s1, ldc, nb1, sA0, sA1, sB0, sB1, sC0, sC1, alpha, relu ? 1 : 0, accumulate ? 1 : 0};
   const int gy = (M + GB - 1) / GB;
@@ -239,7 +231,6 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
 
 // column sums in a fixed order: part[chunk][c] = sum over the chunk's rows of X[row][c] (* xhat[row][c] when r/stats are given:
 // LayerNorm's d gamma), then k_colsum_final adds the chunks.  CH rows per chunk.
-constexpr int CH = 512;
 __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X, int64_t ld, int64_t rows, int cols, const float* __restrict__ r,
                                                      int64_t ldr, const float* __restrict__ stats, float* __restrict__ part) {
   __shared__ float red[4][64];
@@ -385,7 +376,6 @@ struct BwdBufs {
   float *dA, *dB, *dF, *dqkv, *dO, *dprobs, *ds, *dpooled, *dxs, *g, *part;
   size_t bytes;
 };
-inline int colsum_chunks(const Shape& s) { return (int)((s.N() + CH - 1) / CH) + 1; }
 inline BwdBufs carve_bwd(const Shape& s, void* mem) {
   BwdBufs b;
   Carve c(mem);
@@ -406,8 +396,8 @@ inline BwdBufs carve_bwd(const Shape& s, void* mem) {
   return b;
 }
 
-inline int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r = nullptr,
-                  int64_t ldr = 0, const float* stats = nullptr) {
+int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r, int64_t ldr,
+           const float* stats) {
   const int nch = (int)((rows + CH - 1) / CH);
   hipLaunchKernelGGL(k_colsum_part, dim3((cols + 63) / 64, nch), dim3(256), 0, s, X, ld, rows, cols, r, ldr, stats, part);
   hipLaunchKernelGGL(k_colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, part, nch, cols, out);

@@ -85,5 +85,22 @@ struct Carve {
   }
 };
 
+// ---- the exact-fp32 building blocks (so3x_planenet.hip) the bf16 form uses for its small products and reductions
+struct Mat {  // a strided matrix view: element (i, j) at p[i * s0 + j * s1]
+  const float* p;
+  int64_t s0, s1;
+};
+inline Mat rowmajor(const float* p, int64_t ld) { return Mat{p, ld, 1}; }
+inline Mat transposed(const float* p, int64_t ld) { return Mat{p, 1, ld}; }   // view (i, j) = stored [j][i]
+// C[z][m][n] = act(alpha * sum_k A[z](m, k) B[z](k, n) + bias[n] (+ C if accumulate)) on v_mfma_f32_32x32x2_f32; z = (z0 < nb0, z1 < nb1)
+int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f,
+         bool relu = false, bool accumulate = false, int nb0 = 1, int nb1 = 1, int64_t sA0 = 0, int64_t sA1 = 0, int64_t sB0 = 0,
+         int64_t sB1 = 0, int64_t sC0 = 0, int64_t sC1 = 0);
+// out[c] = sum over rows of X[row][c] (* xhat[row][c] when r / stats are given), fixed order; part: colsum_chunks x cols floats
+constexpr int CH = 512;
+inline int colsum_chunks(const Shape& s) { return (int)((s.N() + CH - 1) / CH) + 1; }
+int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r = nullptr,
+           int64_t ldr = 0, const float* stats = nullptr);
+
 }  // namespace plane
 }  // namespace so3x

@@ -1,14 +1,492 @@
-// so3x_planenet_bf16.hip -- the bf16 matrix-core form of the PlaneNet denoiser (placeholder until the kernels land).
+// so3x_planenet_bf16.hip -- the bf16 matrix-core form of the PlaneNet denoiser (reference models.py:185-210) at the aircraft
+// task's own shape: dim 512, 4 heads of 128, feed-forward 2048, points a multiple of 64 (aircraft_rotate.py:17-47).
+//
+// Data layout in HBM: activations token-major [tokens][width] in bf16 (tokens padded up to a multiple of 128 with zero rows;
+// rows never mix outside attention and pooling, which index real tokens only); LayerNorm statistics, attention log-sum-exp,
+// pooling weights and everything behind the pooling in fp32; the fp32 master parameters are converted to a bf16 image once per
+// call.  Kernels:
+//   k_gemm_bf16      C = A W^T (+ bias, ReLU, + residual) -- 128 x 128 x 64 tiles, 4 waves x (4 x 4) v_mfma_f32_16x16x32_bf16,
+//                    both operands K-contiguous, staged by LDS-DMA (global_load_lds_dwordx4) into two XOR-swizzled LDS buffers
+//                    (swizzle on the SOURCE address, conflict-free ds_read_b128), next tile in flight under the current one,
+//                    fp32 accumulators staged through LDS for whole-row stores, XCD-contiguous tile order.  MFMA-bound.
+//   k_attn_fwd       softmax(Q K^T / sqrt(128)) V per (cloud, head), flash style: 4 waves x 32 queries, 64-key tiles of K and V
+//                    by LDS-DMA (double-buffered), S^T = K Q^T on v_mfma_f32_32x32x16_bf16 so that a query's scores sit in one
+//                    lane pair (softmax without LDS), P^T fed to O^T = V^T P^T straight from the accumulator registers, V^T
+//                    operands by ds_read_b64_tr_b16.  Scores never touch HBM.  MFMA / VALU(exp) bound.
+//   k_ln_bf16        LayerNorm rows (HBM-bound: 2 B in + 2 B out per element).
+//   k_embed_bf16, k_pool_* : the SIREN / time embedding and PoolRN's weighted mean (HBM-bound).
 #include "so3x_planenet.hpp"
 
 namespace so3x {
 namespace plane {
-bool bf16_supported(const Shape&) { return false; }
-size_t bf16_workspace_bytes(const Shape&) { return 0; }
-size_t bf16_stash_bytes(const Shape&) { return 0; }
-int forward_bf16(hipStream_t, const Shape&, const float*, const float*, const int64_t*, float*, float*, void*, void*) { return SO3X_ERR_UNSUPPORTED; }
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define GLDS16(SRC, DST)                                                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                            \
+                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+
+constexpr int D = 512, HEADS = 4, DH = 128, FF = 2048, D2 = 256;
+
+bool bf16_supported(const Shape& s) { return s.d == D && s.H == HEADS && s.F == FF && s.P % 64 == 0 && s.P >= 64; }
+
+// ------------------------------------------------------------------------------------------------ fp32 -> bf16 image
+__global__ __launch_bounds__(256) void k_cvt_bf16(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(src)[i];
+  reinterpret_cast<bf16x4*>(dst)[i] = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+}
+__global__ __launch_bounds__(256) void k_cvt_f32(const bf16* __restrict__ src, float* __restrict__ dst, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const bf16x4 v = reinterpret_cast<const bf16x4*>(src)[i];
+  reinterpret_cast<float4*>(dst)[i] = float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// C[M][N] = act(A[M][K] W[N][K]^T + bias[N] (+ R[M][N])),  M % 128 == N % 128 == K % 64 == 0
+constexpr int BM = 128, BN = 128, BK = 64;
+
+template <bool RELU, bool RESID>
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
+                                                      const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
+                                                      int lda, int ldw, int ldc, int ldr) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (A tile 16 KB | W tile 16 KB); then the fp32 C tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN, nwg = ntn * (M / BM);
+  // XCD-contiguous tile order (workgroup ids round-robin over the 8 XCDs; bijective for any nwg): tiles that share an A panel
+  // run on one XCD and find it in that XCD's L2
+  const int bid = blockIdx.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = tile / ntn, tn = tile % ntn;
+  const bf16* Ag = A + (size_t)tm * BM * lda;
+  const bf16* Wg = W + (size_t)tn * BN * ldw;
+  // staging: wave w moves rows 32 w .. 32 w + 31 of both tiles, 8 rows (1 KB) per LDS-DMA instruction; LDS position (row, chunk c)
+  // holds the row's 16-byte chunk c ^ ((row >> 1) & 7)
+  const int srow = wave * 32 + (lane >> 3);
+  auto stage = [&](int kt, int buf) {
+    char* sa = smem + buf * 32768;
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = srow + i * 8;
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      GLDS16(Ag + (size_t)row * lda + kt * BK + ch * 8, sa + (wave * 32 + i * 8) * 128);
+      GLDS16(Wg + (size_t)row * ldw + kt * BK + ch * 8, sb + (wave * 32 + i * 8) * 128);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane >> 1) & 7;                       // ((row >> 1) & 7) of this lane's fragment rows (row = 16 x + (lane & 15))
+  const int arow = (wm * 64 + (lane & 15)) * 128, brow = (wn * 64 + (lane & 15)) * 128;
+  const int KT = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < KT; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed
+    __syncthreads();                                     // ... everyone's have, and everyone is done reading the other buffer
+    if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+    const char* sa = smem + (kt & 1) * 32768;
+    const char* sb = sa + 16384;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int choff = ((4 * s + (lane >> 4)) ^ fsw) << 4;
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        a[i] = *reinterpret_cast<const bf16x8*>(sa + arow + i * 2048 + choff);
+        b[i] = *reinterpret_cast<const bf16x8*>(sb + brow + i * 2048 + choff);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* sc = reinterpret_cast<float*>(smem);            // [128][128] fp32
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) sc[(wm * 64 + i * 16 + (lane >> 4) * 4 + e) * 128 + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
+  __syncthreads();
+  const int c4 = (tid & 31) * 4;
+  const float4 bv = *reinterpret_cast<const float4*>(bias + tn * BN + c4);
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const int row = it * 8 + (tid >> 5);
+    float4 v = *reinterpret_cast<const float4*>(sc + row * 128 + c4);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    const size_t grow = (size_t)tm * BM + row;
+    if constexpr (RESID) {
+      const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + grow * ldr + tn * BN + c4);
+      v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+    }
+    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<bf16x4*>(C + grow * ldc + tn * BN + c4) = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+  }
+}
+
+int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
+              int M, int N, int K, bool relu) {
+  if (M % BM || N % BN || K % BK) return SO3X_ERR_INVALID_ARG;
+  const dim3 grid((unsigned)((M / BM) * (N / BN))), block(256);
+  if (R) hipLaunchKernelGGL((k_gemm_bf16<false, true>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+  else if (relu) hipLaunchKernelGGL((k_gemm_bf16<true, false>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+  else hipLaunchKernelGGL((k_gemm_bf16<false, false>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+  return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ attention forward
+// LDS image of a [64 keys][128] bf16 tile: 256-byte rows, the row's 16-byte chunk c at position c ^ swz16(row) -- conflict-free for
+// the row reads of K (ds_read_b128) and for the transposed reads of V (ds_read_b64_tr_b16)
+__device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse, int P,
+                                                     float sc, float c2) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (K tile 16 KB | V tile 16 KB)
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  const size_t tok0 = (size_t)b * P;
+  // Q^T as the B operand of S^T = K Q^T: lane (r, h) holds Q[q0 + r][16 ks + 8 h .. + 8]
+  bf16x8 qf[8];
+  {
+    const int qr = q0 + r < P ? q0 + r : P - 1;            // (P % 128 == 64: the last block's upper two waves have no queries)
+    const bf16* qrow = qkv + (tok0 + qr) * (3 * D) + hd * DH + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+  }
+  const bf16* kbase = qkv + tok0 * (3 * D) + D + hd * DH;
+  const bf16* vbase = kbase + D;
+  auto stage = [&](int j, int buf) {
+    char* sk = smem + buf * 32768;
+    char* sv = sk + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int rowblk = (wave * 4 + i) * 4, row = rowblk + (lane >> 4);
+      const int ch = (lane & 15) ^ swz16(row);
+      const size_t off = (size_t)(j * 64 + row) * (3 * D) + ch * 8;
+      GLDS16(kbase + off, sk + rowblk * 256);
+      GLDS16(vbase + off, sv + rowblk * 256);
+    }
+  };
+  f32x16 ot[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) ot[dt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  // lane constants of the LDS reads
+  const int krd = r * 256, ksw = swz16(r);                                   // K rows kb * 32 + r: swz16 does not see kb * 32
+  const int g = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
+  const int vrow0 = (4 * h + q_) * 256, vsub = (p_ & 1) * 8, vclo = 2 * (g & 1) + (p_ >> 1);
+  const int nt = P / 64;
+  stage(0, 0);
+  for (int j = 0; j < nt; j++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (j + 1 < nt) stage(j + 1, (j + 1) & 1);
+    const char* sk = smem + (j & 1) * 32768;
+    const char* sv = sk + 16384;
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) st[kb][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + kb * 8192 + krd + (((2 * ks + h) ^ ksw) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+    // online softmax: this lane holds 32 of its query's 64 scores, lane ^ 32 the other 32
+    float mx = st[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) mx = fmaxf(mx, st[1][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+    const float mneg = -m_new * c2;
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][i], c2, mneg));
+        st[kb][i] = pv;
+        ps += pv;
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) ot[dt][i] *= alpha;
+    // O^T += V^T P^T: k-step s4 = keys 16 s4 .. 16 s4 + 15; the B operand is the accumulator registers 8 s' .. 8 s' + 7 as they sit
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const int kb = s4 >> 1, s1 = s4 & 1;
+      const bf16x8 pf = {(bf16)st[kb][8 * s1 + 0], (bf16)st[kb][8 * s1 + 1], (bf16)st[kb][8 * s1 + 2], (bf16)st[kb][8 * s1 + 3],
+                         (bf16)st[kb][8 * s1 + 4], (bf16)st[kb][8 * s1 + 5], (bf16)st[kb][8 * s1 + 6], (bf16)st[kb][8 * s1 + 7]};
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        // two 4-key x 16-column blocks per 16-lane group: keys 16 s4 + 4 h + (0..3) and + 8; columns 32 dt + 16 (g & 1) + (0..15)
+        const int c0 = ((((dt ^ q_) << 2) | (vclo ^ h)) << 4) + vsub;
+        const int c1 = ((((dt ^ q_) << 2) | (vclo ^ (h + 2))) << 4) + vsub;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sv + s4 * 4096 + vrow0 + c0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(sv + s4 * 4096 + vrow0 + 2048 + c1));
+        const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, ot[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (q0 >= P) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  bf16* orow = o + (tok0 + q0 + r) * D + hd * DH + 4 * h;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++)
+      *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * g4) = bf16x4{(bf16)(ot[dt][4 * g4] * inv), (bf16)(ot[dt][4 * g4 + 1] * inv),
+                                                                   (bf16)(ot[dt][4 * g4 + 2] * inv), (bf16)(ot[dt][4 * g4 + 3] * inv)};
+  if (lse && h == 0) lse[((size_t)b * HEADS + hd) * P + q0 + r] = m_run * sc + logf(l_tot);
+}
+
+// ------------------------------------------------------------------------------------------------ rows
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// y = LayerNorm(r) gamma + beta over 512-wide bf16 rows; stats[n] = (mean, rstd); one wave per row, 16 bytes per lane
+__global__ __launch_bounds__(256) void k_ln_bf16(const bf16* __restrict__ r, bf16* __restrict__ y, float* __restrict__ stats,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(r + row * D + lane * 8);
+  float x[8], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { x[i] = (float)v[i]; s += x[i]; }
+  const float mean = wave_sum(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { x[i] -= mean; q = fmaf(x[i], x[i], q); }
+  const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / D) + eps);
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 8), g1 = *reinterpret_cast<const float4*>(gamma + lane * 8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + lane * 8), b1 = *reinterpret_cast<const float4*>(beta + lane * 8 + 4);
+  const bf16x8 out = {(bf16)(x[0] * rstd * g0.x + b0.x), (bf16)(x[1] * rstd * g0.y + b0.y), (bf16)(x[2] * rstd * g0.z + b0.z),
+                      (bf16)(x[3] * rstd * g0.w + b0.w), (bf16)(x[4] * rstd * g1.x + b1.x), (bf16)(x[5] * rstd * g1.y + b1.y),
+                      (bf16)(x[6] * rstd * g1.z + b1.z), (bf16)(x[7] * rstd * g1.w + b1.w)};
+  *reinterpret_cast<bf16x8*>(y + row * D + lane * 8) = out;
+  if (stats && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+}
+
+// SIREN pre-activations / sines and the time embedding (fp32 arithmetic as the exact form's k_embed), bf16 out; rows >= N are zero
+__global__ __launch_bounds__(256) void k_embed_bf16(const float* __restrict__ x, const int64_t* __restrict__ t, const float* __restrict__ wp,
+                                                    const float* __restrict__ bp, float* __restrict__ pre, bf16* __restrict__ sn,
+                                                    bf16* __restrict__ h0, int64_t N, int64_t Npad, int64_t P, float neg_emb) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Npad * D2) return;
+  const int64_t n = idx / D2;
+  const int j = (int)(idx - n * D2);
+  if (n >= N) {
+    sn[idx] = (bf16)0.f;
+    h0[n * D + D2 + j] = (bf16)0.f;
+    return;
+  }
+  const float* xp = x + n * 3;
+  float a = bp[j];
+  a = fmaf(xp[0], wp[j * 3 + 0], a);
+  a = fmaf(xp[1], wp[j * 3 + 1], a);
+  a = fmaf(xp[2], wp[j * 3 + 2], a);
+  if (pre) pre[idx] = a;
+  sn[idx] = (bf16)sinf(a);
+  const int half = D2 / 2;
+  const int jj = j < half ? j : j - half;
+  const float f = (float)exp((double)((float)jj * neg_emb));
+  const float arg = (float)t[n / P] * f;
+  h0[n * D + D2 + j] = (bf16)(j < half ? sinf(arg) : cosf(arg));
+}
+
+// PoolRN on bf16 rows (models.py:94-110): w_p = sigmoid(x_p . wpool + bpool);  xs_b = sum_p w_p x_p / max(sum_p w_p, 1e-6)
+__global__ __launch_bounds__(256) void k_pool_logits_bf16(const bf16* __restrict__ x, const float* __restrict__ wpool, const float* __restrict__ bpool,
+                                                          float* __restrict__ w, int64_t N) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * D + lane * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s = fmaf((float)v[i], wpool[lane * 8 + i], s);
+  s = wave_sum(s) + bpool[0];
+  if (lane == 0) w[row] = 1.f / (1.f + expf(-s));
+}
+// grid (8 column blocks of 64, B clouds, PS point slices): partial weighted sums -> part[b][slice][0..511 | 512 = sum of weights]
+constexpr int PSLICE = 256;
+__global__ __launch_bounds__(256) void k_pool_part_bf16(const bf16* __restrict__ x, const float* __restrict__ w, float* __restrict__ part, int64_t P) {
+  __shared__ float red[4][64];
+  __shared__ float sred[4];
+  const int b = blockIdx.y, sl = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nsl = gridDim.z;
+  const int64_t p0 = (int64_t)sl * PSLICE, p1 = p0 + PSLICE < P ? p0 + PSLICE : P;
+  const bf16* xb = x + (int64_t)b * P * D;
+  const float* wb = w + (int64_t)b * P;
+  float acc = 0.f, sw = 0.f;
+  for (int64_t p = p0 + g; p < p1; p += 4) {
+    const float wv = wb[p];
+    sw += wv;
+    acc = fmaf(wv, (float)xb[p * D + c], acc);
+  }
+  red[g][lane] = acc;
+  if (lane == 0) sred[g] = sw;
+  __syncthreads();
+  if (g == 0) {
+    float* out = part + ((int64_t)b * nsl + sl) * (D + 1);
+    out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (blockIdx.x == 0 && lane == 0) out[D] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  }
+}
+__global__ __launch_bounds__(512) void k_pool_final(const float* __restrict__ part, int nsl, float* __restrict__ S, float* __restrict__ xs) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float* pb = part + (int64_t)b * nsl * (D + 1);
+  float tot = 0.f, v = 0.f;
+  for (int s = 0; s < nsl; s++) {
+    tot += pb[(int64_t)s * (D + 1) + D];
+    v += pb[(int64_t)s * (D + 1) + c];
+  }
+  xs[(int64_t)b * D + c] = v / fmaxf(tot, 1e-6f);
+  if (c == 0) S[b] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------ buffers
+inline int64_t padded_rows(const Shape& s) { return (s.N() + 127) / 128 * 128; }
+
+struct LayerB { bf16 *qkv, *o, *r1, *x1, *f, *r2; float *st1, *st2, *lse; };
+struct ActsB {
+  float* pre;              // [N][256] fp32 SIREN pre-activations (kept for the backward only)
+  bf16* sn;                // [Npad][256]
+  bf16* h[66];
+  LayerB layer[65];
+  float *w, *S, *xs, *pooled, *part;
+  size_t bytes;
+};
+inline ActsB carve_b(const Shape& s, void* mem, bool per_layer) {
+  ActsB a;
+  Carve c(mem);
+  const size_t Np = (size_t)padded_rows(s);
+  a.pre = per_layer ? c.take<float>((size_t)s.N() * D2) : nullptr;
+  a.sn = c.take<bf16>(Np * D2);
+  if (per_layer) {
+    for (int l = 0; l <= s.L; l++) a.h[l] = c.take<bf16>(Np * D);
+  } else {
+    bf16* h0 = c.take<bf16>(Np * D);
+    bf16* h1 = c.take<bf16>(Np * D);
+    for (int l = 0; l <= s.L; l++) a.h[l] = (l & 1) ? h1 : h0;
+  }
+  for (int l = 0; l < s.L; l++) {
+    if (l == 0 || per_layer) {
+      LayerB& k = a.layer[l];
+      k.qkv = c.take<bf16>(Np * 3 * D);
+      k.o = c.take<bf16>(Np * D);
+      k.r1 = c.take<bf16>(Np * D);
+      k.x1 = c.take<bf16>(Np * D);
+      k.f = c.take<bf16>(Np * FF);
+      k.r2 = c.take<bf16>(Np * D);
+      k.st1 = c.take<float>(Np * 2);
+      k.st2 = c.take<float>(Np * 2);
+      k.lse = c.take<float>((size_t)s.N() * HEADS);
+    } else {
+      a.layer[l] = a.layer[0];
+    }
+  }
+  a.w = c.take<float>((size_t)s.N());
+  a.S = c.take<float>((size_t)s.B);
+  a.xs = c.take<float>((size_t)s.B * D);
+  a.pooled = c.take<float>((size_t)s.B * D);
+  a.part = c.take<float>((size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1));
+  a.bytes = c.off;
+  return a;
+}
+
+// workspace = [bf16 image of the parameters][inference activations | backward scratch]
+inline size_t wimg_bytes(const Shape& s) { return up((size_t)param_offsets(s).total * sizeof(bf16)); }
+size_t bf16_stash_bytes(const Shape& s) { return carve_b(s, nullptr, true).bytes; }
+size_t bf16_workspace_bytes(const Shape& s) { return wimg_bytes(s) + carve_b(s, nullptr, false).bytes; }
+
+#define TRY(expr)                 \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__) return rc__;        \
+  } while (0)
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
+                 void* stash, void* workspace) {
+  const ParamOff po = param_offsets(sh);
+  const int64_t N = sh.N(), Np = padded_rows(sh), P = sh.P;
+  bf16* wimg = reinterpret_cast<bf16*>(workspace);
+  const ActsB a = stash ? carve_b(sh, stash, true) : carve_b(sh, reinterpret_cast<char*>(workspace) + wimg_bytes(sh), false);
+  // bf16 image of the weight matrices (everything up to the SIREN's post_scale weight; biases and LayerNorm vectors stay fp32)
+  const int64_t ncvt = (po.wps + (int64_t)D2 * D2 + 3) / 4;
+  hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks_for(ncvt, 256)), dim3(256), 0, s, prm, wimg, ncvt);
+  const float neg_emb = (float)(-(log(10000.0) / (D2 / 2 - 1)));
+  hipLaunchKernelGGL(k_embed_bf16, dim3(blocks_for(Np * D2, 256)), dim3(256), 0, s, x, t, prm + po.wp, prm + po.bp, a.pre, a.sn, a.h[0], N, Np, P, neg_emb);
+  TRY(check_launch());
+  TRY(gemm_bf16(s, a.sn, D2, wimg + po.wps, D2, a.h[0], D, prm + po.bps, nullptr, 0, (int)Np, D2, D2, false));   // post_scale -> h0[:, :256]
+  const float sc = 1.f / sqrtf((float)DH), c2 = sc * 1.4426950408889634f;
+  for (int l = 0; l < sh.L; l++) {
+    const LayerOff lo = po.layer(l);
+    const LayerB& k = a.layer[l];
+    const bf16* h = a.h[l];
+    TRY(gemm_bf16(s, h, D, wimg + lo.wqkv, D, k.qkv, 3 * D, prm + lo.bqkv, nullptr, 0, (int)Np, 3 * D, D, false));
+    hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)(P / 128 + (P % 128 ? 1 : 0)), HEADS, (unsigned)sh.B), dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2);
+    TRY(check_launch());
+    if (Np > N) {   // the pad rows of the attention output feed the next GEMM: keep them finite (zero)
+      hipError_t e = hipMemsetAsync(k.o + N * D, 0, (size_t)(Np - N) * D * sizeof(bf16), s);
+      if (e != hipSuccess) return (int)e;
+    }
+    TRY(gemm_bf16(s, k.o, D, wimg + lo.wo, D, k.r1, D, prm + lo.bo, h, D, (int)Np, D, D, false));
+    hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, k.r1, k.x1, k.st1, prm + lo.g1, prm + lo.be1, Np, 1e-5f);
+    TRY(gemm_bf16(s, k.x1, D, wimg + lo.w1, D, k.f, FF, prm + lo.b1, nullptr, 0, (int)Np, FF, D, true));
+    TRY(gemm_bf16(s, k.f, FF, wimg + lo.w2, FF, k.r2, D, prm + lo.b2, k.x1, D, (int)Np, D, FF, false));
+    hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, k.r2, a.h[l + 1], k.st2, prm + lo.g2, prm + lo.be2, Np, 1e-5f);
+    TRY(check_launch());
+  }
+  const bf16* enc = a.h[sh.L];
+  if (encoding_out) hipLaunchKernelGGL(k_cvt_f32, dim3(blocks_for(N * D / 4, 256)), dim3(256), 0, s, enc, encoding_out, N * D / 4);
+  const int nsl = (int)((P + PSLICE - 1) / PSLICE);
+  hipLaunchKernelGGL(k_pool_logits_bf16, dim3(blocks_for(N, 4)), dim3(256), 0, s, enc, prm + po.wpool, prm + po.bpool, a.w, N);
+  hipLaunchKernelGGL(k_pool_part_bf16, dim3(D / 64, (unsigned)sh.B, nsl), dim3(256), 0, s, enc, a.w, a.part, P);
+  hipLaunchKernelGGL(k_pool_final, dim3((unsigned)sh.B), dim3(D), 0, s, a.part, nsl, a.S, a.xs);
+  TRY(check_launch());
+  TRY(gemm(s, rowmajor(a.xs, D), transposed(prm + po.wlin, D), a.pooled, D, (int)sh.B, D, D, prm + po.blin));
+  TRY(gemm(s, rowmajor(a.pooled, D), transposed(prm + po.wout, D), out, 3, (int)sh.B, 3, D, prm + po.bout));
+  return SO3X_OK;
+}
+
 int backward_bf16(hipStream_t, const Shape&, const float*, const float*, const int64_t*, const float*, float*, const void*, void*) {
   return SO3X_ERR_UNSUPPORTED;
 }
+
 }  // namespace plane
 }  // namespace so3x

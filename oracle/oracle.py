@@ -406,14 +406,27 @@ _fast = None
 
 
 def p_sample_step_timed(params, sched, trap_p, x, t, axes, unif, out):
-    """so3o_p_sample_step_f32 of the TIMED build (libso3_oracle_fast.so: the same source compiled FAST_FLAGS ON THIS HOST -- the
-    GPU box's cores differ from the build container's, so it is (re)built where it runs) on preallocated, contiguous fp32
-    arrays: nothing but the C call inside the caller's timed region.  bench.py's cpu_baseline leg only; never a checker."""
-    global _fast
+    """so3o_p_sample_step_f32 of the TIMED build (the same source compiled FAST_FLAGS ON THIS HOST -- the GPU box's cores differ
+    from the build container's, so it is built where it runs) on preallocated, contiguous fp32 arrays: nothing but the C call
+    inside the caller's timed region.  bench.py's cpu_baseline leg only; never a checker.  The build goes to a per-process file
+    under the system's temporary directory (a read-only tree or two concurrent runs cannot break it); if no compiler is there,
+    the prebuilt -O2 checker library is timed instead and FAST_FLAGS says so."""
+    global _fast, FAST_FLAGS
     if _fast is None:
-        path = os.path.join(_HERE, "libso3_oracle_fast.so")
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libso3_oracle_fast.so"])
-        _fast = C.CDLL(path)
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), f"libso3_oracle_fast.{os.getpid()}.so")
+        try:
+            subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fPIC", "-fopenmp", "-fno-fast-math", "-Wall",
+                                   "-Wno-unused-function", "-shared", "-o", path, os.path.join(_HERE, "so3_oracle.c"), "-lm"])
+            _fast = C.CDLL(path)
+        except (OSError, subprocess.CalledProcessError) as e:
+            FAST_FLAGS = f"-O2 -ffp-contract=off (the prebuilt checker library: the -O3 -march=native build failed here: {e!r})"
+            _fast = lib()
+        finally:
+            try:
+                os.unlink(path)      # the mapping stays valid
+            except OSError:
+                pass
     T = sched.shape[1]
     k, _ = knots()
     fr = posemb_freqs()

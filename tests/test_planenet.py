@@ -175,3 +175,41 @@ def test_ragged_and_empty_shapes(golden):
         assert float((got.cpu() - want).abs().max()) < 3e-5, (Bn, P)
     with torch.no_grad():
         assert net(torch.zeros(0, 5, 3, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV)).shape == (0, 3)
+
+
+# ------------------------------------------------------------------------------------------------ GPU: bf16 form
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [256, 2048])
+def test_full_width_bf16_forward_vs_reference(golden, P):
+    """bf16 operands AND bf16 activations through four post-norm layers: 3e-2 of the output scale, and the
+    encoder output (LayerNorm rows, entries O(1)) within 6e-2 absolute with a median error far below"""
+    net, g = full_net(golden, "bf16")
+    net = net.to(DEV).eval()
+    tag = f"P{P}_"
+    x, t = dev(g[tag + "x"]), dev(g[tag + "t"], torch.int64)
+    with torch.no_grad():
+        out, enc = net(x, t, want_encoding=True)
+    want = g[tag + "out"]
+    assert np.abs(out.cpu().numpy() - want).max() < 3e-2 * max(1.0, np.abs(want).max())
+    ends = torch.cat((enc[:, :4], enc[:, -4:]), 1).cpu().numpy()
+    err = np.abs(ends - g[tag + "encoding_ends"])
+    assert err.max() < 1e-1 and np.median(err) < 1e-2, (err.max(), np.median(err))
+
+
+@pytest.mark.gpu
+def test_bf16_forward_matches_the_fp32_form_on_odd_shapes(golden):
+    """points = 64 and 192 (the last attention block half empty), token counts that are not a multiple of the GEMM tile (pad rows)"""
+    net32, _ = full_net(golden, "fp32")
+    net16, _ = full_net(golden, "bf16")
+    net32, net16 = net32.to(DEV).eval(), net16.to(DEV).eval()
+    gen = torch.Generator().manual_seed(11)
+    for Bn, P in ((1, 64), (3, 192), (5, 320)):
+        x = (torch.randn(Bn, P, 3, generator=gen) * 0.5).to(DEV)
+        t = torch.randint(0, 1000, (Bn,), generator=gen).to(DEV)
+        with torch.no_grad():
+            a, ea = net32(x, t, want_encoding=True)
+            b, eb = net16(x, t, want_encoding=True)
+        assert float((a - b).abs().max()) < 3e-2 * max(1.0, float(a.abs().max())), (Bn, P)
+        assert float((ea - eb).abs().max()) < 1e-1 and float((ea - eb).abs().median()) < 1e-2, (Bn, P)
+    with pytest.raises(Exception):
+        net16(torch.zeros(1, 24, 3, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))   # 24 points: not this form's shape
