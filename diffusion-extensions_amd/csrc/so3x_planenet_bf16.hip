@@ -138,9 +138,200 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
   }
 }
 
+// ---- the large-M form: 256 x 256 x 64 tiles, 8 waves (2 x 4, 128 x 64 of C each), PERSISTENT workgroups ------------------------
+// One workgroup per CU walks its tiles; the K-tiles of all its tiles form ONE stream through two 64 KB LDS buffers, each made of
+// four 16 KB half-tiles (A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255).  A K-tile is two phases of 32 MFMAs per
+// wave, each phase two halves with a raw barrier behind each:
+//     PA.H1  LDS reads: A(rows 0-63 of the wave's 128), W(all 64 of its columns); LDS-DMA: both A halves of K-tile u+1
+//     PA.H2  C rows 0-63 of the wave                                                  (32 MFMAs)
+//     PB.H1  LDS reads: A(rows 64-127); LDS-DMA: both W halves of K-tile u+2; `s_waitcnt vmcnt(4)`
+//     PB.H2  C rows 64-127
+// Waves 4-7 (row half wm = 1; wave w and w + 4 share a SIMD) run ONE barrier behind waves 0-3, so while one wave of a SIMD
+// computes, the other one fetches: the SIMD's matrix pipe alternates between them instead of idling while both wait for the LDS.
+// The one counted wait per K-tile leaves exactly the four pieces staged last (W of u+2) in flight and retires all of K-tile u+1; it
+// sits in PB.H1, so both groups have passed it, and a barrier, before either reads K-tile u+1 (a staged buffer is read one
+// barrier after the wait that retires it; a half-tile is re-staged at least one barrier after its last read).  The stream does
+// not stop at a tile boundary: the next tile's first K-tiles are in flight while this tile's accumulators are stored, so neither
+// the prologue latency nor the store tail is exposed.  Staging addresses are a scalar base per (tile, half, K-tile) plus a
+// per-lane offset fixed for the whole launch.
+// C^T = W A^T is what the MFMAs compute (W fragment as the A operand), so a lane holds 4 consecutive columns of one C row;
+// v_permlane16_swap pairs two 16-column tiles into 8 consecutive columns per lane: 16-byte stores, 64 contiguous bytes per row.
+constexpr int TB = 256;
+
+template <bool RELU, bool RESID>
+__global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
+                                                         const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
+                                                         int lda, int ldw, int ldc, int ldr) {
+  __shared__ __attribute__((aligned(16))) char smem[131072];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+  const int ntn = N / TB, ntiles = ntn * (M / TB), KT = K / 64;
+  // this workgroup's tiles: XCD x (workgroup ids round-robin over the 8 XCDs) owns a contiguous range of tiles, its workgroups take
+  // them round-robin -- at any time an XCD works on neighbouring tiles, which share their A panel through that XCD's L2
+  const int G = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qq = ntiles >> 3, rr = ntiles & 7;
+  const int x_start = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq, x_cnt = qq + (xcd < rr ? 1 : 0);
+  const int nlb = (G >> 3) + ((G & 7) > xcd ? 1 : 0), lb = bid >> 3;
+  const int nmine = lb < x_cnt ? (x_cnt - lb + nlb - 1) / nlb : 0;
+  if (nmine == 0) return;
+  // per-lane byte offsets of the two 1 KB pieces a wave moves per half-tile (rows 16 w + 8 i + (lane >> 3); the 16-byte chunk is
+  // the LDS position's chunk ^ ((row >> 1) & 7))
+  unsigned voa[2], vow[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = wave * 16 + i * 8 + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+    voa[i] = (unsigned)(row * lda + ch * 8) * 2u;
+    vow[i] = (unsigned)(row * ldw + ch * 8) * 2u;
+  }
+  // stream cursors: the A halves are staged one K-tile ahead, the W halves two
+  struct Cur { int it, kt; const char* pa; const char* pw; };
+  auto tile_base = [&](Cur& c) {
+    if (c.it < nmine) {
+      const int tile = x_start + lb + c.it * nlb, tm = tile / ntn, tn = tile - tm * ntn;
+      c.pa = reinterpret_cast<const char*>(A + (size_t)tm * TB * lda);
+      c.pw = reinterpret_cast<const char*>(W + (size_t)tn * TB * ldw);
+    }
+  };
+  auto advance = [&](Cur& c) {
+    if (++c.kt == KT) { c.kt = 0; c.it++; tile_base(c); }
+  };
+  auto stage_a = [&](const Cur& c, int par) {      // both A halves of the cursor's K-tile -> buffer `par`
+    if (c.it >= nmine) return;
+    char* dst = smem + par * 65536 + wave * 2048;
+    const char* src = c.pa + c.kt * 128;
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) GLDS16(src + (size_t)hh * 128 * lda * 2 + voa[i], dst + hh * 16384 + i * 1024);
+  };
+  auto stage_w = [&](const Cur& c, int par) {
+    if (c.it >= nmine) return;
+    char* dst = smem + par * 65536 + 32768 + wave * 2048;
+    const char* src = c.pw + c.kt * 128;
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) GLDS16(src + (size_t)hh * 128 * ldw * 2 + vow[i], dst + hh * 16384 + i * 1024);
+  };
+  f32x4 acc[2][4][2][2];   // [row half][16-row tile][column half][16-column tile]
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int d = 0; d < 2; d++) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane >> 1) & 7;
+  const int aoff = wm * 16384 + (lane & 15) * 128;                               // + rh * 8192 + mi * 2048
+  const int boff = 32768 + (wn >> 1) * 16384 + ((wn & 1) * 64 + (lane & 15)) * 128;   // + ch * 4096 + ni * 2048
+  const int ch0 = ((lane >> 4) ^ fsw) << 4, ch1 = ((4 + (lane >> 4)) ^ fsw) << 4;     // the two k-steps' 16-byte chunks
+  bf16x8 af[4][2], bfr[2][2][2];
+  auto load_a = [&](const char* buf, int rh) {
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) {
+      af[mi][0] = *reinterpret_cast<const bf16x8*>(buf + aoff + rh * 8192 + mi * 2048 + ch0);
+      af[mi][1] = *reinterpret_cast<const bf16x8*>(buf + aoff + rh * 8192 + mi * 2048 + ch1);
+    }
+  };
+  auto load_b = [&](const char* buf, int ch) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+      bfr[ch][ni][0] = *reinterpret_cast<const bf16x8*>(buf + boff + ch * 4096 + ni * 2048 + ch0);
+      bfr[ch][ni][1] = *reinterpret_cast<const bf16x8*>(buf + boff + ch * 4096 + ni * 2048 + ch1);
+    }
+  };
+#define SO3X_ROWS(RH)                                                                                                            \
+  do {                                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++) _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                             \
+    _Pragma("unroll") for (int mi = 0; mi < 4; mi++) _Pragma("unroll") for (int ni = 0; ni < 2; ni++)                             \
+        acc[RH][mi][c_][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c_][ni][s_], af[mi][s_], acc[RH][mi][c_][ni], 0, 0, 0);   \
+    __builtin_amdgcn_s_setprio(0);                                                                                               \
+  } while (0)
+#define SO3X_H1_END()                                  \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                      \
+  } while (0)
+  // prologue: K-tile 0 whole, the W halves of K-tile 1
+  Cur ca{0, 0, nullptr, nullptr}, cw{0, 0, nullptr, nullptr};
+  tile_base(ca);
+  tile_base(cw);
+  stage_a(ca, 0); advance(ca);
+  stage_w(cw, 0); advance(cw);
+  stage_w(cw, 1); advance(cw);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // (KT >= 2: the four pieces of W(1) are really there)
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  int par = 0;
+  for (int it = 0; it < nmine; it++) {
+    for (int kt = 0; kt < KT; kt++, par ^= 1) {
+      const char* buf = smem + par * 65536;
+      load_a(buf, 0); load_b(buf, 0); load_b(buf, 1);
+      stage_a(ca, par ^ 1); advance(ca);
+      SO3X_H1_END();
+      SO3X_ROWS(0);
+      __builtin_amdgcn_s_barrier();
+      load_a(buf, 1);
+      const bool more = cw.it < nmine;
+      stage_w(cw, par); advance(cw);
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SO3X_H1_END();
+      SO3X_ROWS(1);
+      __builtin_amdgcn_s_barrier();
+    }
+    // this tile's accumulators -> C (the next tile's first K-tiles are already on their way)
+    const int tile = x_start + lb + it * nlb, tm = tile / ntn, tn = tile - tm * ntn;
+    const int g = lane >> 4;
+    const int ncol = tn * TB + wn * 64 + (g & 1) * 16 + (g >> 1) * 8;        // + ch * 32: this lane's 8 columns after the swap
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+      const float4 bv0 = *reinterpret_cast<const float4*>(bias + ncol + ch * 32), bv1 = *reinterpret_cast<const float4*>(bias + ncol + ch * 32 + 4);
+#pragma unroll
+      for (int rh = 0; rh < 2; rh++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+          // odd 16-lane rows of X <-> even rows of Y: rows 0 / 2 keep X (their own columns 4 g' ..) and receive the next four from
+          // X's odd row; rows 1 / 3 receive Y's even row and keep Y.  (Inline asm: hipcc 7.2 folds the builtin form of this swap
+          // to a swap of zeros for accumulator elements 1..3.)
+          f32x4 X = acc[rh][mi][ch][0], Y = acc[rh][mi][ch][1];
+          acc[rh][mi][ch][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[rh][mi][ch][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                       "v_permlane16_swap_b32 %3, %7"
+                       : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]));
+          float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
+          v[0] += bv0.x; v[1] += bv0.y; v[2] += bv0.z; v[3] += bv0.w; v[4] += bv1.x; v[5] += bv1.y; v[6] += bv1.z; v[7] += bv1.w;
+          const size_t grow = (size_t)tm * TB + wm * 128 + rh * 64 + mi * 16 + (lane & 15);
+          if constexpr (RESID) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + grow * ldr + ncol + ch * 32);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] += (float)rv[e];
+          }
+          if constexpr (RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<bf16x8*>(C + grow * ldc + ncol + ch * 32) =
+              bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        }
+    }
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // the barrier the other group started with
+#undef SO3X_ROWS
+#undef SO3X_H1_END
+}
+
 int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
               int M, int N, int K, bool relu) {
   if (M % BM || N % BN || K % BK) return SO3X_ERR_INVALID_ARG;
+  if (M % TB == 0 && N % TB == 0 && K >= 128 && (M / TB) * (N / TB) >= 384) {   // enough 256 x 256 tiles to keep 256 persistent workgroups busy
+    const int ntiles = (M / TB) * (N / TB);
+    const dim3 g2((unsigned)(ntiles < 256 ? ntiles : 256)), b2(512);
+    if (R) hipLaunchKernelGGL((k_gemm256_bf16<false, true>), g2, b2, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+    else if (relu) hipLaunchKernelGGL((k_gemm256_bf16<true, false>), g2, b2, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+    else hipLaunchKernelGGL((k_gemm256_bf16<false, false>), g2, b2, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+    return check_launch();
+  }
   const dim3 grid((unsigned)((M / BM) * (N / BN))), block(256);
   if (R) hipLaunchKernelGGL((k_gemm_bf16<false, true>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
   else if (relu) hipLaunchKernelGGL((k_gemm_bf16<true, false>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);

@@ -213,3 +213,23 @@ def test_bf16_forward_matches_the_fp32_form_on_odd_shapes(golden):
         assert float((ea - eb).abs().max()) < 1e-1 and float((ea - eb).abs().median()) < 1e-2, (Bn, P)
     with pytest.raises(Exception):
         net16(torch.zeros(1, 24, 3, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))   # 24 points: not this form's shape
+
+
+@pytest.mark.gpu
+def test_bf16_large_batch_kernels_equal_the_small_batch_kernels(golden):
+    """65,536 tokens take the persistent 256 x 256-tile GEMM; the same clouds four at a time take the 128 x 128-tile one (the
+    form the fixtures pin).  Both sum every output element over k in the same order, so the encoder outputs must agree to the last
+    bf16 digit on almost every entry and the predictions to fp32 rounding."""
+    net, _ = full_net(golden, "bf16")
+    net = net.to(DEV).eval()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(32, 2048, 3, device=DEV, generator=gen) * 0.5
+    t = torch.randint(0, 1000, (32,), device=DEV, generator=gen)
+    with torch.no_grad():
+        big, ebig = net(x, t, want_encoding=True)
+        for i in range(0, 32, 8):
+            small, esmall = net(x[i:i + 4], t[i:i + 4], want_encoding=True)
+            assert float((big[i:i + 4] - small).abs().max()) < 1e-5, i
+            d = (ebig[i:i + 4] - esmall).abs()
+            assert float(d.max()) < 4e-2 and float((d > 0).float().mean()) < 1e-3, (i, float(d.max()), float((d > 0).float().mean()))
+    assert torch.isfinite(big).all()
