@@ -209,8 +209,12 @@ __global__ void __launch_bounds__((chain_threads<PREC, PAIR>()), (chain_threads<
 k_p_sample_chain(const void* __restrict__ gimg, const float* __restrict__ beff_tab, const bf16x8* __restrict__ l0t_tab,
                  const float* __restrict__ sched, int T, const float* __restrict__ trap_p,
                  const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
-                 int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
+                 const int64_t* __restrict__ t_dev, int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed,
                  uint64_t rng_offset, int64_t index_base, int64_t n, const char* __restrict__ cdf_rec, uint64_t* __restrict__ clk) {
+  if (t_dev) {  // the first timestep read on the device (the caller's `t` tensor: no host copy, no synchronisation), clamped into the tables
+    const int64_t tv = t_dev[0];
+    t_start = (int)(tv < n_steps - 1 ? n_steps - 1 : (tv > T - 1 ? T - 1 : tv));
+  }
   static_assert(!WIDE || (PAIR && PREC == SO3X_PREC_BF16), "the wide table belongs to the paired bf16 stream");
   static_assert(!F16 || WIDE, "the f16 operands are a leg of the shipped (paired, wide-table) stream");
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
@@ -344,8 +348,8 @@ inline int ab_env(const char* name, const char* value) {
 
 template <int PREC, bool FAST, bool PAIR, bool WIDE = false, bool F16 = false>
 int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
-                   const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
-                   uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
+                   const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, const int64_t* t_dev, int n_steps, const float* axes,
+                   const float* unif, uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n) {
   constexpr int IMG = image_bytes<PREC, CHAIN>() + (WIDE ? kWideTabBytes + kChainKnotsBytes + kChainRowBufBytes : 0);
   int max_blocks = 0;
   int threads = chain_threads_default<PREC>();
@@ -366,7 +370,7 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
   const int grid = (int)(want < max_blocks ? want : max_blocks);
   const bf16x8* l0t = PREC == SO3X_PREC_BF16 ? reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(ws) + l0t_offset(T)) : nullptr;
   hipLaunchKernelGGL((k_p_sample_chain<PREC, FAST, PAIR, WIDE, F16>), dim3(grid), dim3(threads), IMG, s, ws, beff, l0t, sched, T, trap_p, guide_p, x_in, x_out,
-                     t_start, n_steps, axes, unif, seed, rng_offset, index_base, n,
+                     t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, n,
                      staged_cdf ? reinterpret_cast<const char*>(ws) + cdf_offset(T) : nullptr,
                      reinterpret_cast<uint64_t*>(const_cast<char*>(reinterpret_cast<const char*>(ws)) +
                                                  (PREC == SO3X_PREC_BF16 ? clock_offset_bf16(T) : clock_offset_f32(T))));
@@ -375,9 +379,9 @@ int launch_chain_v(hipStream_t s, const void* ws, const float* beff, const float
 
 template <int PREC>
 int launch_chain(hipStream_t s, const void* ws, const float* beff, const float* sched, int T, const float* trap_p,
-                 const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
-                 uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, bool f16 = false) {
-#define SO3X_CHAIN_ARGS s, ws, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n
+                 const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, const int64_t* t_dev, int n_steps, const float* axes,
+                 const float* unif, uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, bool f16 = false) {
+#define SO3X_CHAIN_ARGS s, ws, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, n
   if constexpr (PREC == SO3X_PREC_BF16) {
     if (f16) return launch_chain_v<PREC, true, true, true, true>(SO3X_CHAIN_ARGS);
 #ifdef SO3X_AB_BUILD
@@ -458,6 +462,30 @@ size_t so3x_p_sample_clock_offset(int T, int precision) {
   return precision == SO3X_PREC_F32 ? clock_offset_f32(Tn) : clock_offset_bf16(Tn);
 }
 
+// the launch-independent state of the chain kernel for ALL T timesteps: weight image, per-timestep effective-bias rows and layer-0
+// fragments, CDF records
+static int prepare_steps(hipStream_t s, const float* params, int T, const float* trap_p, const uint16_t* guide_p, int precision, bool f16,
+                         void* workspace, int t_first, int n_steps) {
+  int rc = launch_prep(s, params, precision, CHAIN, T, workspace, 3, nullptr, true, nullptr, t_first, n_steps, f16);
+  if (rc) return rc;
+  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t(s, params, T, workspace, t_first, n_steps, f16))) return rc;
+  if (precision == SO3X_PREC_BF16) {  // the CDF records of these steps (LDS-DMA source of the chain kernel)
+    hipLaunchKernelGGL(k_prep_cdf, dim3(n_steps), dim3(256), 0, s, trap_p, guide_p, reinterpret_cast<char*>(workspace) + cdf_offset(T), t_first);
+    if ((rc = check_launch())) return rc;
+  }
+  return SO3X_OK;
+}
+static int run_steps(hipStream_t s, const float* sched, int T, const float* trap_p, const uint16_t* guide_p, const float* x_in, float* x_out,
+                     int t_start, const int64_t* t_dev, int n_steps, const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
+                     int64_t index_base, int64_t n, int precision, bool f16, void* workspace) {
+  const float* beff = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + beff_offset(precision, CHAIN));
+  if (precision == SO3X_PREC_F32)
+    return launch_chain<SO3X_PREC_F32>(s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, t_dev, n_steps, axes, unif, seed,
+                                       rng_offset, index_base, n);
+  return launch_chain<SO3X_PREC_BF16>(s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, t_dev, n_steps, axes, unif, seed,
+                                      rng_offset, index_base, n, f16);
+}
+
 int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_p,
                         const uint16_t* guide_p, const float* x_in, float* x_out, int t_start, int n_steps, const float* axes, const float* unif,
                         uint64_t seed, uint64_t rng_offset, int64_t index_base, int64_t n, int precision, void* workspace,
@@ -473,20 +501,32 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
   if (f16) precision = SO3X_PREC_BF16;
   // image + the per-timestep rows of the steps this launch runs (t_start - n_steps + 1 .. t_start)
   const int t_first = t_start - n_steps + 1;
-  int rc = launch_prep((hipStream_t)s, params, precision, CHAIN, T, workspace, 3, nullptr, true, nullptr, t_first, n_steps, f16);
-  if (rc) return rc;
-  if (precision == SO3X_PREC_BF16 && (rc = launch_prep_l0t((hipStream_t)s, params, T, workspace, t_first, n_steps, f16))) return rc;
-  if (precision == SO3X_PREC_BF16) {  // the CDF records of the steps this launch runs (LDS-DMA source of the chain kernel)
-    hipLaunchKernelGGL(k_prep_cdf, dim3(n_steps), dim3(256), 0, (hipStream_t)s, trap_p, guide_p,
-                       reinterpret_cast<char*>(workspace) + cdf_offset(T), t_first);
-    if ((rc = check_launch())) return rc;
-  }
-  const float* beff = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + beff_offset(precision, CHAIN));
-  if (precision == SO3X_PREC_F32)
-    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,
-                                       unif, seed, rng_offset, index_base, n);
-  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, beff, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes,
-                                      unif, seed, rng_offset, index_base, n, f16);
+  if (int rc = prepare_steps((hipStream_t)s, params, T, trap_p, guide_p, precision, f16, workspace, t_first, n_steps)) return rc;
+  return run_steps((hipStream_t)s, sched, T, trap_p, guide_p, x_in, x_out, t_start, nullptr, n_steps, axes, unif, seed, rng_offset, index_base, n,
+                   precision, f16, workspace);
+}
+
+int so3x_p_sample_prepare(so3x_stream_t s, const float* params, int T, const float* trap_p, const uint16_t* guide_p, int precision,
+                          void* workspace, size_t workspace_bytes) {
+  if (T <= 0 || !params || !trap_p) return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < so3x_p_sample_workspace_bytes(T, precision)) return SO3X_ERR_WORKSPACE;
+  const bool f16 = precision == SO3X_PREC_F16;
+  return prepare_steps((hipStream_t)s, params, T, trap_p, guide_p, f16 ? SO3X_PREC_BF16 : precision, f16, workspace, 0, T);
+}
+
+int so3x_p_sample_prepared(so3x_stream_t s, const float* sched, int T, const float* trap_p, const uint16_t* guide_p, const float* x_in,
+                           float* x_out, int t_start, const int64_t* t_dev, int n_steps, const float* axes, const float* unif, uint64_t seed,
+                           uint64_t rng_offset, int64_t index_base, int64_t n, int precision, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || T <= 0 || n_steps < 0 || n_steps > T || (n && (!sched || !trap_p || !x_in || !x_out)) || ((axes == nullptr) != (unif == nullptr)) ||
+      (axes && n_steps > 1) || (!t_dev && (t_start < 0 || t_start >= T || t_start - n_steps + 1 < 0)))
+    return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16 && precision != SO3X_PREC_F16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < so3x_p_sample_workspace_bytes(T, precision)) return SO3X_ERR_WORKSPACE;
+  if (n == 0 || n_steps == 0) return SO3X_OK;
+  const bool f16 = precision == SO3X_PREC_F16;
+  return run_steps((hipStream_t)s, sched, T, trap_p, guide_p, x_in, x_out, t_dev ? 0 : t_start, t_dev, n_steps, axes, unif, seed, rng_offset,
+                   index_base, n, f16 ? SO3X_PREC_BF16 : precision, f16, workspace);
 }
 
 }  // extern "C"

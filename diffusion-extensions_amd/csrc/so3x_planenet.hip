@@ -323,6 +323,44 @@ __global__ __launch_bounds__(256) void k_pool_bwd_tok(const float* __restrict__ 
   if (lane == 0) g[row] = gv;
 }
 
+// PoolRN's lin and the output Linear (models.py:100-109, 195-196): pooled = Wlin xs + blin -- one wave per output row, 32 rows per
+// workgroup, the row read as contiguous 256-byte pieces -- then out = Wout pooled + bout, one workgroup per cloud.  Exact fp32,
+// fixed summation order.
+__global__ __launch_bounds__(256) void k_head_lin(const float* __restrict__ xs, const float* __restrict__ wlin, const float* __restrict__ blin,
+                                                  float* __restrict__ pooled, int d) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xb = xs + (int64_t)b * d;
+  const int j0 = blockIdx.x * 32 + wave * 8;
+  float a[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) a[r] = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float xv = xb[c];
+#pragma unroll
+    for (int r = 0; r < 8; r++) a[r] = fmaf(wlin[(int64_t)(j0 + r < d ? j0 + r : d - 1) * d + c], xv, a[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const float v = wave_sum(a[r]);
+    if (lane == 0 && j0 + r < d) pooled[(int64_t)b * d + j0 + r] = v + blin[j0 + r];
+  }
+}
+__global__ __launch_bounds__(256) void k_head_out(const float* __restrict__ pooled, const float* __restrict__ wout, const float* __restrict__ bout,
+                                                  float* __restrict__ out, int d) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave >= 3) return;
+  float a = 0.f;
+  for (int c = lane; c < d; c += 64) a = fmaf(wout[(int64_t)wave * d + c], pooled[(int64_t)b * d + c], a);
+  a = wave_sum(a) + bout[wave];
+  if (lane == 0) out[(int64_t)b * 3 + wave] = a;
+}
+int head(hipStream_t s, const float* xs, const float* wlin, const float* blin, const float* wout, const float* bout, float* pooled, float* out,
+         int64_t B, int d) {
+  hipLaunchKernelGGL(k_head_lin, dim3((d + 31) / 32, (unsigned)B), dim3(256), 0, s, xs, wlin, blin, pooled, d);
+  hipLaunchKernelGGL(k_head_out, dim3((unsigned)B), dim3(256), 0, s, pooled, wout, bout, out, d);
+  return check_launch();
+}
+
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------------------------------------ buffers
@@ -451,8 +489,7 @@ int forward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* x
   hipLaunchKernelGGL(k_pool_logits, dim3(blocks_for(N, 4)), dim3(256), 0, s, enc, prm + po.wpool, prm + po.bpool, a.w, N, d);
   hipLaunchKernelGGL(k_pool_sum, dim3((d + 63) / 64, (unsigned)sh.B), dim3(256), 0, s, enc, a.w, a.S, a.xs, P, d);
   TRY(check_launch());
-  TRY(gemm(s, rowmajor(a.xs, d), transposed(prm + po.wlin, d), a.pooled, d, (int)sh.B, d, d, prm + po.blin));
-  TRY(gemm(s, rowmajor(a.pooled, d), transposed(prm + po.wout, d), out, 3, (int)sh.B, 3, d, prm + po.bout));
+  TRY(head(s, a.xs, prm + po.wlin, prm + po.blin, prm + po.wout, prm + po.bout, a.pooled, out, sh.B, d));
   return SO3X_OK;
 }
 

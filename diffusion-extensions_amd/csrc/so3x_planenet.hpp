@@ -101,6 +101,9 @@ constexpr int CH = 512;
 inline int colsum_chunks(const Shape& s) { return (int)((s.N() + CH - 1) / CH) + 1; }
 int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r = nullptr,
            int64_t ldr = 0, const float* stats = nullptr);
+// pooled[b] = Wlin xs[b] + blin, out[b] = Wout pooled[b] + bout: one workgroup per cloud
+int head(hipStream_t s, const float* xs, const float* wlin, const float* blin, const float* wout, const float* bout, float* pooled, float* out,
+         int64_t B, int d);
 
 }  // namespace plane
 }  // namespace so3x

@@ -15,24 +15,10 @@
 //                    operands by ds_read_b64_tr_b16.  Scores never touch HBM.  MFMA / VALU(exp) bound.
 //   k_ln_bf16        LayerNorm rows (HBM-bound: 2 B in + 2 B out per element).
 //   k_embed_bf16, k_pool_* : the SIREN / time embedding and PoolRN's weighted mean (HBM-bound).
-#include "so3x_planenet.hpp"
+#include "so3x_planenet_bf16.hpp"
 
 namespace so3x {
 namespace plane {
-
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-#define GLDS16(SRC, DST)                                                                                            \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                            \
-                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
-
-constexpr int D = 512, HEADS = 4, DH = 128, FF = 2048, D2 = 256;
 
 bool bf16_supported(const Shape& s) { return s.d == D && s.H == HEADS && s.F == FF && s.P % 64 == 0 && s.P >= 64; }
 
@@ -54,7 +40,7 @@ __global__ __launch_bounds__(256) void k_cvt_f32(const bf16* __restrict__ src, f
 // C[M][N] = act(A[M][K] W[N][K]^T + bias[N] (+ R[M][N])),  M % 128 == N % 128 == K % 64 == 0
 constexpr int BM = 128, BN = 128, BK = 64;
 
-template <bool RELU, bool RESID>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                       const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
                                                       int lda, int ldw, int ldc, int ldr) {
@@ -129,11 +115,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
     float4 v = *reinterpret_cast<const float4*>(sc + row * 128 + c4);
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     const size_t grow = (size_t)tm * BM + row;
-    if constexpr (RESID) {
+    if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
       const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + grow * ldr + tn * BN + c4);
-      v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+      if constexpr (EPI == EPI_RESID) {
+        v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+      } else {
+        v.x = (float)rv[0] > 0.f ? v.x : 0.f; v.y = (float)rv[1] > 0.f ? v.y : 0.f;
+        v.z = (float)rv[2] > 0.f ? v.z : 0.f; v.w = (float)rv[3] > 0.f ? v.w : 0.f;
+      }
     }
-    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if constexpr (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<bf16x4*>(C + grow * ldc + tn * BN + c4) = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
   }
 }
@@ -158,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
 // v_permlane16_swap pairs two 16-column tiles into 8 consecutive columns per lane: 16-byte stores, 64 contiguous bytes per row.
 constexpr int TB = 256;
 
-template <bool RELU, bool RESID>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                          const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
                                                          int lda, int ldw, int ldc, int ldr) {
@@ -302,12 +293,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
           float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
           v[0] += bv0.x; v[1] += bv0.y; v[2] += bv0.z; v[3] += bv0.w; v[4] += bv1.x; v[5] += bv1.y; v[6] += bv1.z; v[7] += bv1.w;
           const size_t grow = (size_t)tm * TB + wm * 128 + rh * 64 + mi * 16 + (lane & 15);
-          if constexpr (RESID) {
+          if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
             const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + grow * ldr + ncol + ch * 32);
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] += (float)rv[e];
+            for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? v[e] : 0.f);
           }
-          if constexpr (RELU) {
+          if constexpr (EPI == EPI_RELU) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
           }
@@ -321,29 +312,30 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
 #undef SO3X_H1_END
 }
 
-int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
-              int M, int N, int K, bool relu) {
-  if (M % BM || N % BN || K % BK) return SO3X_ERR_INVALID_ARG;
+template <int EPI>
+static int gemm_bf16_t(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
+                       int M, int N, int K) {
   if (M % TB == 0 && N % TB == 0 && K >= 128 && (M / TB) * (N / TB) >= 384) {   // enough 256 x 256 tiles to keep 256 persistent workgroups busy
     const int ntiles = (M / TB) * (N / TB);
-    const dim3 g2((unsigned)(ntiles < 256 ? ntiles : 256)), b2(512);
-    if (R) hipLaunchKernelGGL((k_gemm256_bf16<false, true>), g2, b2, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
-    else if (relu) hipLaunchKernelGGL((k_gemm256_bf16<true, false>), g2, b2, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
-    else hipLaunchKernelGGL((k_gemm256_bf16<false, false>), g2, b2, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
-    return check_launch();
+    hipLaunchKernelGGL((k_gemm256_bf16<EPI>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+  } else {
+    hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
   }
-  const dim3 grid((unsigned)((M / BM) * (N / BN))), block(256);
-  if (R) hipLaunchKernelGGL((k_gemm_bf16<false, true>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
-  else if (relu) hipLaunchKernelGGL((k_gemm_bf16<true, false>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
-  else hipLaunchKernelGGL((k_gemm_bf16<false, false>), grid, block, 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
   return check_launch();
+}
+int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
+              int M, int N, int K, int epi) {
+  if (M % BM || N % BN || K % BK || !bias || ((epi == EPI_RESID || epi == EPI_MASK) && !R)) return SO3X_ERR_INVALID_ARG;
+  switch (epi) {
+    case EPI_NONE: return gemm_bf16_t<EPI_NONE>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
+    case EPI_RELU: return gemm_bf16_t<EPI_RELU>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
+    case EPI_RESID: return gemm_bf16_t<EPI_RESID>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
+    case EPI_MASK: return gemm_bf16_t<EPI_MASK>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
+  }
+  return SO3X_ERR_INVALID_ARG;
 }
 
 // ------------------------------------------------------------------------------------------------ attention forward
-// LDS image of a [64 keys][128] bf16 tile: 256-byte rows, the row's 16-byte chunk c at position c ^ swz16(row) -- conflict-free for
-// the row reads of K (ds_read_b128) and for the transposed reads of V (ds_read_b64_tr_b16)
-__device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-
 __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse, int P,
                                                      float sc, float c2) {
   __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (K tile 16 KB | V tile 16 KB)
@@ -459,12 +451,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
 }
 
 // ------------------------------------------------------------------------------------------------ rows
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 // y = LayerNorm(r) gamma + beta over 512-wide bf16 rows; stats[n] = (mean, rstd); one wave per row, 16 bytes per lane
 __global__ __launch_bounds__(256) void k_ln_bf16(const bf16* __restrict__ r, bf16* __restrict__ y, float* __restrict__ stats,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows, float eps) {
@@ -492,31 +478,46 @@ __global__ __launch_bounds__(256) void k_ln_bf16(const bf16* __restrict__ r, bf1
   }
 }
 
-// SIREN pre-activations / sines and the time embedding (fp32 arithmetic as the exact form's k_embed), bf16 out; rows >= N are zero
-__global__ __launch_bounds__(256) void k_embed_bf16(const float* __restrict__ x, const int64_t* __restrict__ t, const float* __restrict__ wp,
-                                                    const float* __restrict__ bp, float* __restrict__ pre, bf16* __restrict__ sn,
-                                                    bf16* __restrict__ h0, int64_t N, int64_t Npad, int64_t P, float neg_emb) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Npad * D2) return;
-  const int64_t n = idx / D2;
-  const int j = (int)(idx - n * D2);
-  if (n >= N) {
-    sn[idx] = (bf16)0.f;
-    h0[n * D + D2 + j] = (bf16)0.f;
-    return;
-  }
-  const float* xp = x + n * 3;
-  float a = bp[j];
-  a = fmaf(xp[0], wp[j * 3 + 0], a);
-  a = fmaf(xp[1], wp[j * 3 + 1], a);
-  a = fmaf(xp[2], wp[j * 3 + 2], a);
-  if (pre) pre[idx] = a;
-  sn[idx] = (bf16)sinf(a);
-  const int half = D2 / 2;
-  const int jj = j < half ? j : j - half;
+// The time embedding of every cloud once (models.py:13-25; fp32 arithmetic as the exact form's k_embed): temb[b][j], j < 256
+__global__ __launch_bounds__(256) void k_temb(const int64_t* __restrict__ t, float* __restrict__ temb, float neg_emb) {
+  const int b = blockIdx.x, j = threadIdx.x, half = D2 / 2, jj = j < half ? j : j - half;
   const float f = (float)exp((double)((float)jj * neg_emb));
-  const float arg = (float)t[n / P] * f;
-  h0[n * D + D2 + j] = (bf16)(j < half ? sinf(arg) : cosf(arg));
+  const float arg = (float)t[b] * f;
+  temb[b * D2 + j] = j < half ? sinf(arg) : cosf(arg);
+}
+// SIREN pre-activations (exact fp32, kept for the backward) and their sines (hardware sine: |pre| stays below ~200, where
+// v_sin_f32 after the 1/2pi scaling is good to ~1e-5 -- two orders below the bf16 rounding of the result), the time embedding
+// copied next to them; 8 columns per thread, rows >= N zero
+__global__ __launch_bounds__(256) void k_embed_bf16(const float* __restrict__ x, const float* __restrict__ temb, const float* __restrict__ wp,
+                                                    const float* __restrict__ bp, float* __restrict__ pre, bf16* __restrict__ sn,
+                                                    bf16* __restrict__ h0, int64_t N, int64_t Npad, int64_t P) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Npad * (D2 / 8)) return;
+  const int64_t n = idx / (D2 / 8);
+  const int j0 = (int)(idx - n * (D2 / 8)) * 8;
+  bf16x8 sv, tv;
+  if (n >= N) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { sv[i] = (bf16)0.f; tv[i] = (bf16)0.f; }
+  } else {
+    const float x0 = x[n * 3], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
+    const float* te = temb + (n / P) * D2 + j0;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int j = j0 + i;
+      a[i] = fmaf(x2, wp[j * 3 + 2], fmaf(x1, wp[j * 3 + 1], fmaf(x0, wp[j * 3], bp[j])));
+      const float rev = a[i] * 0.15915494309189535f;
+      sv[i] = (bf16)__builtin_amdgcn_sinf(rev - floorf(rev));   // v_sin_f32 takes revolutions, |input| <= 256
+      tv[i] = (bf16)te[i];
+    }
+    if (pre) {
+      *reinterpret_cast<float4*>(pre + n * D2 + j0) = float4{a[0], a[1], a[2], a[3]};
+      *reinterpret_cast<float4*>(pre + n * D2 + j0 + 4) = float4{a[4], a[5], a[6], a[7]};
+    }
+  }
+  *reinterpret_cast<bf16x8*>(sn + n * D2 + j0) = sv;
+  *reinterpret_cast<bf16x8*>(h0 + n * D + D2 + j0) = tv;
 }
 
 // PoolRN on bf16 rows (models.py:94-110): w_p = sigmoid(x_p . wpool + bpool);  xs_b = sum_p w_p x_p / max(sum_p w_p, 1e-6)
@@ -533,7 +534,6 @@ __global__ __launch_bounds__(256) void k_pool_logits_bf16(const bf16* __restrict
   if (lane == 0) w[row] = 1.f / (1.f + expf(-s));
 }
 // grid (8 column blocks of 64, B clouds, PS point slices): partial weighted sums -> part[b][slice][0..511 | 512 = sum of weights]
-constexpr int PSLICE = 256;
 __global__ __launch_bounds__(256) void k_pool_part_bf16(const bf16* __restrict__ x, const float* __restrict__ w, float* __restrict__ part, int64_t P) {
   __shared__ float red[4][64];
   __shared__ float sred[4];
@@ -569,60 +569,7 @@ __global__ __launch_bounds__(512) void k_pool_final(const float* __restrict__ pa
   if (c == 0) S[b] = tot;
 }
 
-// ------------------------------------------------------------------------------------------------ buffers
-inline int64_t padded_rows(const Shape& s) { return (s.N() + 127) / 128 * 128; }
-
-struct LayerB { bf16 *qkv, *o, *r1, *x1, *f, *r2; float *st1, *st2, *lse; };
-struct ActsB {
-  float* pre;              // [N][256] fp32 SIREN pre-activations (kept for the backward only)
-  bf16* sn;                // [Npad][256]
-  bf16* h[66];
-  LayerB layer[65];
-  float *w, *S, *xs, *pooled, *part;
-  size_t bytes;
-};
-inline ActsB carve_b(const Shape& s, void* mem, bool per_layer) {
-  ActsB a;
-  Carve c(mem);
-  const size_t Np = (size_t)padded_rows(s);
-  a.pre = per_layer ? c.take<float>((size_t)s.N() * D2) : nullptr;
-  a.sn = c.take<bf16>(Np * D2);
-  if (per_layer) {
-    for (int l = 0; l <= s.L; l++) a.h[l] = c.take<bf16>(Np * D);
-  } else {
-    bf16* h0 = c.take<bf16>(Np * D);
-    bf16* h1 = c.take<bf16>(Np * D);
-    for (int l = 0; l <= s.L; l++) a.h[l] = (l & 1) ? h1 : h0;
-  }
-  for (int l = 0; l < s.L; l++) {
-    if (l == 0 || per_layer) {
-      LayerB& k = a.layer[l];
-      k.qkv = c.take<bf16>(Np * 3 * D);
-      k.o = c.take<bf16>(Np * D);
-      k.r1 = c.take<bf16>(Np * D);
-      k.x1 = c.take<bf16>(Np * D);
-      k.f = c.take<bf16>(Np * FF);
-      k.r2 = c.take<bf16>(Np * D);
-      k.st1 = c.take<float>(Np * 2);
-      k.st2 = c.take<float>(Np * 2);
-      k.lse = c.take<float>((size_t)s.N() * HEADS);
-    } else {
-      a.layer[l] = a.layer[0];
-    }
-  }
-  a.w = c.take<float>((size_t)s.N());
-  a.S = c.take<float>((size_t)s.B);
-  a.xs = c.take<float>((size_t)s.B * D);
-  a.pooled = c.take<float>((size_t)s.B * D);
-  a.part = c.take<float>((size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1));
-  a.bytes = c.off;
-  return a;
-}
-
-// workspace = [bf16 image of the parameters][inference activations | backward scratch]
-inline size_t wimg_bytes(const Shape& s) { return up((size_t)param_offsets(s).total * sizeof(bf16)); }
 size_t bf16_stash_bytes(const Shape& s) { return carve_b(s, nullptr, true).bytes; }
-size_t bf16_workspace_bytes(const Shape& s) { return wimg_bytes(s) + carve_b(s, nullptr, false).bytes; }
 
 #define TRY(expr)                 \
   do {                            \
@@ -641,25 +588,26 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
   const int64_t ncvt = (po.wps + (int64_t)D2 * D2 + 3) / 4;
   hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks_for(ncvt, 256)), dim3(256), 0, s, prm, wimg, ncvt);
   const float neg_emb = (float)(-(log(10000.0) / (D2 / 2 - 1)));
-  hipLaunchKernelGGL(k_embed_bf16, dim3(blocks_for(Np * D2, 256)), dim3(256), 0, s, x, t, prm + po.wp, prm + po.bp, a.pre, a.sn, a.h[0], N, Np, P, neg_emb);
+  hipLaunchKernelGGL(k_temb, dim3((unsigned)sh.B), dim3(D2), 0, s, t, a.temb, neg_emb);
+  hipLaunchKernelGGL(k_embed_bf16, dim3(blocks_for(Np * (D2 / 8), 256)), dim3(256), 0, s, x, a.temb, prm + po.wp, prm + po.bp, a.pre, a.sn, a.h[0], N, Np, P);
   TRY(check_launch());
-  TRY(gemm_bf16(s, a.sn, D2, wimg + po.wps, D2, a.h[0], D, prm + po.bps, nullptr, 0, (int)Np, D2, D2, false));   // post_scale -> h0[:, :256]
+  TRY(gemm_bf16(s, a.sn, D2, wimg + po.wps, D2, a.h[0], D, prm + po.bps, nullptr, 0, (int)Np, D2, D2, EPI_NONE));   // post_scale -> h0[:, :256]
   const float sc = 1.f / sqrtf((float)DH), c2 = sc * 1.4426950408889634f;
   for (int l = 0; l < sh.L; l++) {
     const LayerOff lo = po.layer(l);
     const LayerB& k = a.layer[l];
     const bf16* h = a.h[l];
-    TRY(gemm_bf16(s, h, D, wimg + lo.wqkv, D, k.qkv, 3 * D, prm + lo.bqkv, nullptr, 0, (int)Np, 3 * D, D, false));
+    TRY(gemm_bf16(s, h, D, wimg + lo.wqkv, D, k.qkv, 3 * D, prm + lo.bqkv, nullptr, 0, (int)Np, 3 * D, D, EPI_NONE));
     hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)(P / 128 + (P % 128 ? 1 : 0)), HEADS, (unsigned)sh.B), dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2);
     TRY(check_launch());
     if (Np > N) {   // the pad rows of the attention output feed the next GEMM: keep them finite (zero)
       hipError_t e = hipMemsetAsync(k.o + N * D, 0, (size_t)(Np - N) * D * sizeof(bf16), s);
       if (e != hipSuccess) return (int)e;
     }
-    TRY(gemm_bf16(s, k.o, D, wimg + lo.wo, D, k.r1, D, prm + lo.bo, h, D, (int)Np, D, D, false));
+    TRY(gemm_bf16(s, k.o, D, wimg + lo.wo, D, k.r1, D, prm + lo.bo, h, D, (int)Np, D, D, EPI_RESID));
     hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, k.r1, k.x1, k.st1, prm + lo.g1, prm + lo.be1, Np, 1e-5f);
-    TRY(gemm_bf16(s, k.x1, D, wimg + lo.w1, D, k.f, FF, prm + lo.b1, nullptr, 0, (int)Np, FF, D, true));
-    TRY(gemm_bf16(s, k.f, FF, wimg + lo.w2, FF, k.r2, D, prm + lo.b2, k.x1, D, (int)Np, D, FF, false));
+    TRY(gemm_bf16(s, k.x1, D, wimg + lo.w1, D, k.f, FF, prm + lo.b1, nullptr, 0, (int)Np, FF, D, EPI_RELU));
+    TRY(gemm_bf16(s, k.f, FF, wimg + lo.w2, FF, k.r2, D, prm + lo.b2, k.x1, D, (int)Np, D, FF, EPI_RESID));
     hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, k.r2, a.h[l + 1], k.st2, prm + lo.g2, prm + lo.be2, Np, 1e-5f);
     TRY(check_launch());
   }
@@ -670,13 +618,8 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
   hipLaunchKernelGGL(k_pool_part_bf16, dim3(D / 64, (unsigned)sh.B, nsl), dim3(256), 0, s, enc, a.w, a.part, P);
   hipLaunchKernelGGL(k_pool_final, dim3((unsigned)sh.B), dim3(D), 0, s, a.part, nsl, a.S, a.xs);
   TRY(check_launch());
-  TRY(gemm(s, rowmajor(a.xs, D), transposed(prm + po.wlin, D), a.pooled, D, (int)sh.B, D, D, prm + po.blin));
-  TRY(gemm(s, rowmajor(a.pooled, D), transposed(prm + po.wout, D), out, 3, (int)sh.B, 3, D, prm + po.bout));
+  TRY(head(s, a.xs, prm + po.wlin, prm + po.blin, prm + po.wout, prm + po.bout, a.pooled, out, sh.B, D));
   return SO3X_OK;
-}
-
-int backward_bf16(hipStream_t, const Shape&, const float*, const float*, const int64_t*, const float*, float*, const void*, void*) {
-  return SO3X_ERR_UNSUPPORTED;
 }
 
 }  // namespace plane

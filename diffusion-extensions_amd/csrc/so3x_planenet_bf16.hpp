@@ -1,0 +1,97 @@
+// so3x_planenet_bf16.hpp -- types, LDS-DMA helper, activation buffers and kernel launchers shared by the forward
+// (so3x_planenet_bf16.hip) and the backward (so3x_planenet_bf16_bwd.hip) of the bf16 form of PlaneNet.
+#pragma once
+#include "so3x_planenet.hpp"
+
+namespace so3x {
+namespace plane {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define GLDS16(SRC, DST)                                                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                            \
+                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+
+constexpr int D = 512, HEADS = 4, DH = 128, FF = 2048, D2 = 256;
+
+// LDS image of a [64 keys][128] bf16 tile: 256-byte rows, the row's 16-byte chunk c at position c ^ swz16(row) -- conflict-free for
+// the row reads of K (ds_read_b128) and for the transposed reads of V (ds_read_b64_tr_b16)
+__device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int PSLICE = 256;   // points per partial sum of the pooling reductions
+
+// ------------------------------------------------------------------------------------------------ buffers
+inline int64_t padded_rows(const Shape& s) { return (s.N() + 127) / 128 * 128; }
+
+struct LayerB { bf16 *qkv, *o, *r1, *x1, *f, *r2; float *st1, *st2, *lse; };
+struct ActsB {
+  float* pre;              // [N][256] fp32 SIREN pre-activations (kept for the backward only)
+  bf16* sn;                // [Npad][256]
+  bf16* h[66];
+  LayerB layer[65];
+  float *w, *S, *xs, *pooled, *part, *temb;
+  size_t bytes;
+};
+inline ActsB carve_b(const Shape& s, void* mem, bool per_layer) {
+  ActsB a;
+  Carve c(mem);
+  const size_t Np = (size_t)padded_rows(s);
+  a.pre = per_layer ? c.take<float>((size_t)s.N() * D2) : nullptr;
+  a.sn = c.take<bf16>(Np * D2);
+  if (per_layer) {
+    for (int l = 0; l <= s.L; l++) a.h[l] = c.take<bf16>(Np * D);
+  } else {
+    bf16* h0 = c.take<bf16>(Np * D);
+    bf16* h1 = c.take<bf16>(Np * D);
+    for (int l = 0; l <= s.L; l++) a.h[l] = (l & 1) ? h1 : h0;
+  }
+  for (int l = 0; l < s.L; l++) {
+    if (l == 0 || per_layer) {
+      LayerB& k = a.layer[l];
+      k.qkv = c.take<bf16>(Np * 3 * D);
+      k.o = c.take<bf16>(Np * D);
+      k.r1 = c.take<bf16>(Np * D);
+      k.x1 = c.take<bf16>(Np * D);
+      k.f = c.take<bf16>(Np * FF);
+      k.r2 = c.take<bf16>(Np * D);
+      k.st1 = c.take<float>(Np * 2);
+      k.st2 = c.take<float>(Np * 2);
+      k.lse = c.take<float>((size_t)s.N() * HEADS);
+    } else {
+      a.layer[l] = a.layer[0];
+    }
+  }
+  a.w = c.take<float>((size_t)s.N());
+  a.S = c.take<float>((size_t)s.B);
+  a.xs = c.take<float>((size_t)s.B * D);
+  a.pooled = c.take<float>((size_t)s.B * D);
+  a.part = c.take<float>((size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1));
+  a.temb = c.take<float>((size_t)s.B * D2);
+  a.bytes = c.off;
+  return a;
+}
+
+// workspace = [bf16 image of the parameters][inference activations | backward scratch]
+inline size_t wimg_bytes(const Shape& s) { return up((size_t)param_offsets(s).total * sizeof(bf16)); }
+
+
+// C[M][N] = epilogue(A[M][K] W[N][K]^T + bias[N]),  M % 128 == N % 128 == K % 64 == 0; every operand bf16 row-major, bias fp32
+//   EPI_NONE: C = acc + bias;  EPI_RELU: max(., 0);  EPI_RESID: + R[M][N];  EPI_MASK: (R[M][N] > 0) ? acc + bias : 0
+enum Epi { EPI_NONE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_MASK = 3 };
+int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
+              int M, int N, int K, int epi);
+
+}  // namespace plane
+}  // namespace so3x

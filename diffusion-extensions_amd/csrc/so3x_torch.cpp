@@ -251,6 +251,37 @@ void p_sample_chain_out(const Tensor& params, const Tensor& sched, const Tensor&
   chain_into(params, sched, trap_p, guide_p, x, out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision);
 }
 
+// prepared-state sampling (so3x_p_sample_prepare / so3x_p_sample_prepared): the preparation as a tensor the caller keeps
+Tensor p_sample_prepare(const Tensor& params, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, int64_t precision) {
+  GUARD(params);
+  const int T = (int)dev(sched, "sched").size(1);
+  Tensor ws = bytes(params, so3x_p_sample_workspace_bytes(T, (int)precision));
+  ok(so3x_p_sample_prepare(strm(params), F(dev(params, "params")), T, F(dev(trap_p, "trap_p")), Guide(guide_p), (int)precision,
+                           ws.mutable_data_ptr(), ws.numel()),
+     "p_sample_prepare");
+  return ws;
+}
+void p_sample_prepared_out(const Tensor& ws, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x, int64_t t_start,
+                           const optional<Tensor>& t_dev, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                           int64_t rng_offset, int64_t index_base, int64_t precision, Tensor& out) {
+  GUARD(x);
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(out.numel() == x.numel() && out.device() == x.device(), "so3x: out must match x");
+  ok(so3x_p_sample_prepared(strm(x), F(sched), T, F(dev(trap_p, "trap_p")), Guide(guide_p), F(dev(x, "x")), Fm(const_cast<Tensor&>(dev(out, "out"))),
+                            (int)t_start, t_dev.has_value() ? I64(dev(*t_dev, "t", at::kLong)) : nullptr, (int)n_steps, Fo(axes, "axes"), Fo(unif, "unif"),
+                            (uint64_t)seed, (uint64_t)rng_offset, index_base, x.numel() / 9, (int)precision,
+                            const_cast<Tensor&>(dev(ws, "workspace", at::kByte)).mutable_data_ptr(), ws.numel()),
+     "p_sample_prepared");
+}
+Tensor p_sample_prepared(const Tensor& ws, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x, int64_t t_start,
+                         const optional<Tensor>& t_dev, int64_t n_steps, const optional<Tensor>& axes, const optional<Tensor>& unif, int64_t seed,
+                         int64_t rng_offset, int64_t index_base, int64_t precision) {
+  GUARD(x);
+  Tensor out = at::empty_like(x);
+  p_sample_prepared_out(ws, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, precision, out);
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------- one training step
 // -> (loss[1], x_t, t, dout, zstash, workspace, out): everything so3x_train_bwd needs travels as tensors
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> train_fwd(
@@ -624,6 +655,9 @@ TORCH_LIBRARY(so3x, m) {
         "Tensor? unif, int seed, int rng_offset, Tensor? rng_offset_dev, int index_base, bool want_x_t, bool want_target, bool want_noise) "
         "-> (Tensor, Tensor, Tensor)");
   m.def("p_mean(Tensor sched, Tensor x, Tensor v, Tensor? t, int t_stride, int t_const, bool want_x0hat) -> (Tensor, Tensor)");
+  m.def("p_sample_prepare(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, int precision) -> Tensor");
+  m.def("p_sample_prepared(Tensor(a!) workspace, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, Tensor? t_dev, int n_steps, Tensor? axes, Tensor? unif, int seed, int rng_offset, int index_base, int precision) -> Tensor");
+  m.def("p_sample_prepared_out(Tensor(a!) workspace, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, Tensor? t_dev, int n_steps, Tensor? axes, Tensor? unif, int seed, int rng_offset, int index_base, int precision, Tensor(b!) out) -> ()");
   m.def("p_sample_chain(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
         "Tensor? unif, int seed, int rng_offset, int index_base, int precision) -> Tensor");
   m.def("p_sample_chain_out(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
@@ -696,6 +730,9 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("mlp_bwd", mlp_bwd);
   m.impl("q_sample_target", q_sample_target);
   m.impl("p_mean", p_mean);
+  m.impl("p_sample_prepare", p_sample_prepare);
+  m.impl("p_sample_prepared", p_sample_prepared);
+  m.impl("p_sample_prepared_out", p_sample_prepared_out);
   m.impl("p_sample_chain", p_sample_chain);
   m.impl("p_sample_chain_out", p_sample_chain_out);
   m.impl("train_fwd", train_fwd);

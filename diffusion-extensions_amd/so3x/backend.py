@@ -46,6 +46,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
+    "so3x_p_sample_prepare", "so3x_p_sample_prepared",
     "so3x_planenet_param_count", "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes", "so3x_planenet_fwd", "so3x_planenet_bwd",
     "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam", "so3x_train_fused",
 )
@@ -542,6 +543,33 @@ def p_mean(sched, x, v, t, want_x0hat=False):
     else:
         x0h, mean = _call(ops().p_mean, sched, x, v, None, 0, int(t), bool(want_x0hat))
     return (x0h if want_x0hat else None), mean
+
+
+def p_sample_prepare(params, sched, trap_p, precision=PREC_BF16, guide_p=None):
+    """everything the reverse-chain kernel derives from the parameters and the tables, for all T timesteps: a byte tensor to hand
+    to p_sample_prepared (valid until params / trap_p / guide_p change)"""
+    params = _dev(params, "params").reshape(-1)
+    if params.numel() != N_PARAMS:
+        raise ValueError(f"so3x: params must hold {N_PARAMS} values")
+    sched, trap_p = _dev(sched, "sched"), _dev(trap_p, "trap_p")
+    return _call(ops().p_sample_prepare, params, sched, trap_p, _guide(guide_p, trap_p, "guide_p"), int(precision))
+
+
+def p_sample_prepared(ws, sched, trap_p, x, t_start, n_steps, t_dev=None, axes=None, unif=None, seed=0, rng_offset=0, index_base=0,
+                      precision=PREC_BF16, out=None, guide_p=None):
+    """n_steps reverse steps from a prepared workspace: ONE launch.  t_dev (device int64, one element): the first timestep is read
+    on the device instead of from t_start."""
+    sched, trap_p = _dev(sched, "sched"), _dev(trap_p, "trap_p")
+    x = _rot_in(x, "x")
+    ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
+    un = _dev(unif, "unif").reshape(-1) if unif is not None else None
+    td = _dev(t_dev, "t", torch.int64).reshape(-1) if t_dev is not None else None
+    args = (ws, sched, trap_p, _guide(guide_p, trap_p, "guide_p"), x, int(t_start), td, int(n_steps), ax, un, _s64(seed), _s64(rng_offset),
+            int(index_base), int(precision))
+    if out is None:
+        return _call(ops().p_sample_prepared, *args)
+    _call(ops().p_sample_prepared_out, *args, _out_like(out, x))
+    return out
 
 
 def p_sample_chain(params, sched, trap_p, x, t_start, n_steps, axes=None, unif=None, seed=0, rng_offset=0, index_base=0,

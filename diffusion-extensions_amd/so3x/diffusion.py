@@ -125,6 +125,7 @@ class SO3Diffusion(nn.Module):
         self._trap_p = None  # rows for sigma_t = exp(0.5 * logvar_t)     (p_sample)
         self._guide_q = None  # search guide of the q rows (looked up per sample: t differs across the batch)
         self._guide_p = None  # and of the p rows (saves ~7 of the 10 bisection rounds of every reverse step)
+        self._prep = None     # (key, workspace): the reverse-chain kernel's prepared state for the current parameters
 
     # ------------------------------------------------------------------ tables
     def _tables(self):
@@ -135,6 +136,23 @@ class SO3Diffusion(nn.Module):
             self._guide_q = _b.igso3_build_guide(self._trap_q)
             self._guide_p = _b.igso3_build_guide(self._trap_p)
         return self._trap_q, self._trap_p
+
+    def _prepared(self, net):
+        """so3x_p_sample_prepare's workspace for the 65-wide network's CURRENT parameters (weight image, per-timestep rows, CDF
+        records for all T steps): built on first use and whenever the flat parameter buffer, its tensor version, the
+        out-of-band update epoch (graph replays), the precision or the tables change.  A p_sample call then is one kernel launch."""
+        from .flat import PARAM_EPOCH
+        _, trap_p = self._tables()
+        flat = net.flat_params_nograd()
+        prec = getattr(net, "chain_precision_code", net.precision_code)
+        key = (flat.data_ptr(), flat._version, PARAM_EPOCH[0], prec, trap_p.data_ptr(), self._guide_p.data_ptr(), flat.device)
+        if self._prep is None or self._prep[0] != key:
+            self._prep = (key, _b.p_sample_prepare(flat, self._sched, trap_p, prec, guide_p=self._guide_p))
+        return self._prep[1], prec
+
+    def invalidate_sampling_cache(self):
+        """for callers that rewrite the parameters behind torch's back (raw pointers, their own captured graphs)"""
+        self._prep = None
 
     def _fused_net(self, sampling=False):
         """the denoiser when it is one of the two score networks with fused kernels (so3_train / so3_lock_train RotPredict)"""
@@ -195,10 +213,22 @@ class SO3Diffusion(nn.Module):
         the noise scale is model_stdev[0] (t[0]'s) and the noise is skipped only when every t is 0; with all entries
         equal (the only way the reference's own loops call it) the step is ONE fused launch, with mixed entries the mean
         uses each sample's own coefficients (extract(), diffusion.py:291-306)."""
-        t0, same = self._shared_t(t)
-        _, trap_p = self._tables()
         net = self._fused_net(sampling=True)
+        _, trap_p = self._tables()
+        small = net is not None and getattr(net, "kind", "") != "resnet255"
+        if small and isinstance(t, torch.Tensor) and t.numel() == 1 and t.is_cuda and t.dtype == torch.int64:
+            # the (1,)-shaped t of the reference's own loop (so3_test.py:31): read by the kernel on the device -- no host copy of
+            # t, no synchronisation, ONE launch from the prepared state (the reference synchronises here, diffusion.py:320)
+            ws, prec = self._prepared(net)
+            off = _rng.next_offset(self.num_timesteps) if axes is None else 0
+            return _b.p_sample_prepared(ws, self._sched, trap_p, x, 0, 1, t_dev=t, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off,
+                                        index_base=self.index_base, precision=prec, guide_p=self._guide_p)
+        t0, same = self._shared_t(t)
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
+        if small and same:
+            ws, prec = self._prepared(net)
+            return _b.p_sample_prepared(ws, self._sched, trap_p, x, t0, 1, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off,
+                                        index_base=self.index_base, precision=prec, guide_p=self._guide_p)
         if net is not None and same:
             return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
                                      seed=_rng.seed(), rng_offset=off, index_base=self.index_base,

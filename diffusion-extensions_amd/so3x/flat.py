@@ -28,6 +28,16 @@ torch.nn.modules.module.register_module_parameter_registration_hook(_registered)
 torch.nn.modules.module.register_module_module_registration_hook(_registered)
 
 
+# Parameter updates torch cannot see: a replayed hipGraph (so3x.graphs.TrainStepGraph) rewrites the flat buffer without bumping its
+# tensor version.  Whoever does that calls params_changed_out_of_band(); caches derived from parameter values (the prepared
+# sampling state of SO3Diffusion) key on (tensor version, this epoch).
+PARAM_EPOCH = [0]
+
+
+def params_changed_out_of_band():
+    PARAM_EPOCH[0] += 1
+
+
 class _FlatView(torch.autograd.Function):
     """The flat buffer as a differentiable function of the individual parameters (what torch.cat(params) would be, with
     no copy either way).  backward: in the usual loop (`zero_grad(); loss.backward()`: every p.grad is None) the flat

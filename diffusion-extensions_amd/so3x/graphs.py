@@ -365,6 +365,8 @@ class TrainStepGraph:
         return self.loss
 
     def replay(self):
+        from .flat import params_changed_out_of_band
+        params_changed_out_of_band()   # the captured update rewrites the parameters without touching their tensor version
         if _hyper_of(self.optimizer) != self._hyper:
             raise RuntimeError("so3x: optimizer hyper-parameters changed after capture; they are kernel arguments frozen into the graph "
                                "-- build a new TrainStepGraph")
@@ -385,6 +387,8 @@ class TrainStepGraph:
         self._pending = True
 
     def flush(self):
+        from .flat import params_changed_out_of_band
+        params_changed_out_of_band()
         """pipelined form: run the outstanding reduction + all-reduce + optimizer update (a no-op otherwise).  After it the
         parameters are those of the eager loop after the same number of steps."""
         if not (self.pipelined and self._pending):

@@ -128,6 +128,22 @@ def _(sched, x, v, t, t_stride, t_const, want_x0hat):
     return _f32(x, x.shape if want_x0hat else (0, 3, 3)), _f32(x, x.shape)
 
 
+@register_fake("so3x::p_sample_prepare")
+def _(params, sched, trap_p, guide_p, precision):
+    T = sched.shape[1]
+    return params.new_empty((T * (4608 + 96 * 4 + 192 * 16) + (1 << 20),), dtype=torch.uint8)   # an upper bound is all a fake needs
+
+
+@register_fake("so3x::p_sample_prepared")
+def _(workspace, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, precision):
+    return _f32(x, x.shape)
+
+
+@register_fake("so3x::p_sample_prepared_out")
+def _(workspace, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, precision, out):
+    return None
+
+
 @register_fake("so3x::p_sample_chain")
 def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision):
     return _f32(x, x.shape)

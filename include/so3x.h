@@ -208,6 +208,21 @@ int so3x_p_sample_chain(so3x_stream_t s, const float* params, const float* sched
                         uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                         void* workspace, size_t workspace_bytes);
 
+/* The same in two calls, for callers that drive the chain ONE STEP PER CALL (so3_test.py:24-31: `R = process.p_sample(R, t)`
+ * in a Python loop; diffusion.py:335-336): everything so3x_p_sample_chain derives from the parameters and the tables -- weight
+ * image, per-timestep effective-bias rows and layer-0 fragments, CDF records -- depends on neither x nor t, so
+ *   so3x_p_sample_prepare   builds it ONCE for all T timesteps into `workspace` (so3x_p_sample_workspace_bytes), and
+ *   so3x_p_sample_prepared  runs n_steps reverse steps from that workspace: one kernel launch, no preparation.
+ * The caller re-prepares whenever params, trap_p or guide_p change (so3x.diffusion.SO3Diffusion keys a cache on the parameter
+ * buffer's version).  t_dev (optional, device int64[1]): the first timestep is READ ON THE DEVICE (clamped to
+ * [n_steps - 1, T - 1]) instead of taken from t_start -- the caller's `t` tensor goes straight through, with no host copy and no
+ * synchronisation (the reference's own loop synchronises every step, diffusion.py:320).  Other arguments as so3x_p_sample_chain. */
+int so3x_p_sample_prepare(so3x_stream_t s, const float* params, int T, const float* trap_p, const uint16_t* guide_p, int precision,
+                          void* workspace, size_t workspace_bytes);
+int so3x_p_sample_prepared(so3x_stream_t s, const float* sched, int T, const float* trap_p, const uint16_t* guide_p, const float* x_in,
+                           float* x_out, int t_start, const int64_t* t_dev, int n_steps, const float* axes, const float* unif, uint64_t seed,
+                           uint64_t rng_offset, int64_t index_base, int64_t n, int precision, void* workspace, size_t workspace_bytes);
+
 /* ------------------------------------------- wide residual score network (8f row 3) */
 /* so3_lock_train.RotPredict (so3_lock_train.py:11-59): d_model = 255, input
  * [R(9), sin(123), cos(123)] (models.py:13-25 with dim 246), six ResLayer(Linear(255,255)+SiLU) blocks

@@ -233,3 +233,62 @@ def test_bf16_large_batch_kernels_equal_the_small_batch_kernels(golden):
             d = (ebig[i:i + 4] - esmall).abs()
             assert float(d.max()) < 4e-2 and float((d > 0).float().mean()) < 1e-3, (i, float(d.max()), float((d > 0).float().mean()))
     assert torch.isfinite(big).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [256, 2048])
+def test_full_width_bf16_backward_vs_reference_autograd(golden, P):
+    """bf16 operands, activations AND activation gradients; parameter gradients accumulated in fp32.  Against the reference's
+    fp32 autograd: every parameter's gradient within 4 % in norm and its 64 sampled entries within 4 % of the larger of the
+    gradient's rms entry and the largest sampled entry (measured: 0.2-1.6 %)."""
+    net, g = full_net(golden, "bf16")
+    net = net.to(DEV).train()
+    tag = f"P{P}_"
+    x, t, dout = dev(g[tag + "x"]), dev(g[tag + "t"], torch.int64), dev(g[tag + "dout"])
+    out = net(x, t)
+    (out * dout).sum().backward()
+    bad = {}
+    for k, p in net.named_parameters():
+        gs, pick = g[tag + "gsum_" + k], g[tag + "gpick_" + k]
+        flat = p.grad.reshape(-1)
+        assert torch.isfinite(flat).all(), k
+        stride = max(1, flat.numel() // 64)
+        got = flat[::stride][:64].cpu().numpy()
+        scale = max(gs[1] / np.sqrt(flat.numel()), np.abs(pick).max())
+        norm = gs[1]
+        if k == "out_net.0.pool.0.bias":
+            # d bpool = sum_p e_p w_p (1 - w_p) with sum_p e_p w_p = 0 identically: a cancelling sum, whose bf16 noise does not
+            # cancel.  Its natural scale is the gradient of the pooling weight it sits beside (same sum, weighted by x_p = O(1)).
+            scale = norm = g[tag + "gsum_out_net.0.pool.0.weight"][1]
+        e_pick = float(np.abs(got - pick).max() / scale)
+        e_norm = abs(float(flat.double().norm()) - gs[1]) / norm
+        if e_pick > 4e-2 or e_norm > 4e-2:
+            bad[k] = (e_pick, e_norm)
+    assert not bad, bad
+    # deterministic: fixed-order reductions, no atomics
+    g1 = net.flat_grad().clone()
+    net.zero_grad(set_to_none=True)
+    (net(x, t) * dout).sum().backward()
+    assert torch.equal(net.flat_grad(), g1)
+
+
+@pytest.mark.gpu
+def test_bf16_backward_matches_the_fp32_form_on_odd_shapes(golden):
+    """pad rows (tokens not a multiple of 128) and a half-empty last attention block must not leak into any gradient"""
+    net32, _ = full_net(golden, "fp32")
+    net16, _ = full_net(golden, "bf16")
+    net32, net16 = net32.to(DEV).train(), net16.to(DEV).train()
+    gen = torch.Generator().manual_seed(12)
+    for Bn, P in ((1, 64), (3, 192)):
+        x = (torch.randn(Bn, P, 3, generator=gen) * 0.5).to(DEV)
+        t = torch.randint(0, 1000, (Bn,), generator=gen).to(DEV)
+        dout = torch.randn(Bn, 3, generator=gen).to(DEV)
+        for net in (net32, net16):
+            net.zero_grad(set_to_none=True)
+            (net(x, t) * dout).sum().backward()
+        ref = dict(net32.named_parameters())
+        for (k, a), (_, b) in zip(net32.named_parameters(), net16.named_parameters()):
+            # (the pooling bias' gradient is a cancelling sum: measured against the pooling weight's gradient, see above)
+            scale = ref["out_net.0.pool.0.weight"].grad.norm() if k == "out_net.0.pool.0.bias" else a.grad.norm()
+            rel = float((a.grad - b.grad).norm() / (scale + 1e-30))
+            assert rel < 5e-2 and torch.isfinite(b.grad).all(), (Bn, P, k, rel)

@@ -50,6 +50,22 @@ def main():
             fl = planenet_flop(Bn, P)
             rec = {"precision": prec, "clouds": Bn, "points": P, "forward_ms": ms, "forward_TFLOPs": fl / ms / 1e9,
                    "frac_of_bf16_peak": fl / ms / 1e9 / 2500.0, "flop": fl}
+            # one training evaluation: forward with the stash + backward (dX and dW of every product: 2 x the forward's flops;
+            # attention recomputes its probabilities: 2.5 x)
+            net.train()
+            dout = torch.randn(Bn, 3, device=dev)
+
+            def step():
+                net.zero_grad(set_to_none=True)
+                (net(x, t) * dout).sum().backward()
+            for _ in range(2):
+                step()
+            ms_t = min(timed(step, 5 if prec == "bf16" else 1) for _ in range(2))
+            attn = Bn * P * 4 * 4 * P * 512
+            fl_t = 3 * (fl - attn) + 3.5 * attn
+            rec.update({"train_eval_ms": ms_t, "train_eval_TFLOPs": fl_t / ms_t / 1e9, "train_eval_frac_of_bf16_peak": fl_t / ms_t / 1e9 / 2500.0,
+                        "train_eval_flop": fl_t})
+            net.eval()
             print(json.dumps(rec), flush=True)
 
 
