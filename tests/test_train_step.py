@@ -613,3 +613,102 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert "error" not in tr, tr
     assert tr["ranks"] == 8 and tr["global_batch"] == 8 * tr["batch_per_gpu"] and tr["finite"] and tr["one_kernel"]
     assert tr["allreduce_us"] > 0 and tr["mode"].startswith("captured hipGraphs with the eager all-reduce")
+
+
+# ---------------------------------------------------------------------------------------- prepared-state sampling (round 5)
+@pytest.mark.gpu
+def test_one_step_per_call_loop_equals_the_chain_and_never_goes_stale(mods):
+    """The reference's own way of driving the sampler -- one p_sample call per reverse step with a (1,)-shaped device t
+    (so3_test.py:24-31) -- runs from a prepared workspace that is cached across calls (so3x_p_sample_prepare /
+    so3x_p_sample_prepared, t read on the device).  It must (a) reproduce the one-launch chain bit for bit, (b) build the
+    preparation ONCE for the whole loop, (c) see every kind of parameter update: optimizer steps through the operator (tensor
+    version), captured-graph replays (out-of-band epoch), load_state_dict."""
+    from so3x import backend as B
+    from so3x.graphs import TrainStepGraph
+    torch.manual_seed(0)
+    net = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    T = 60
+    proc = mods["diff"].SO3Diffusion(net, timesteps=T).to(DEV)
+    x0 = mods["util"].quat_to_rmat(torch.randn(2048, 4, device=DEV))
+
+    def loop(x):
+        for i in reversed(range(T)):
+            x = proc.p_sample(x, torch.full((1,), i, device=DEV, dtype=torch.long))
+        return x
+
+    def chain(x):
+        _, trap_p = proc._tables()
+        return B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x, T - 1, T, seed=mods["rng"].seed(), rng_offset=0,
+                                precision=net.precision_code, guide_p=proc._guide_p)
+
+    calls = {"n": 0}
+    real = B.p_sample_prepare
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    B.p_sample_prepare = counting
+    try:
+        mods["rng"].manual_seed(9)
+        a = loop(x0)                      # every call draws offset o_k = k * T and the kernel adds t: distinct streams per step
+        assert calls["n"] == 1            # (b)
+        # (a): the same steps as separate one-step launches of the unprepared entry point, same offsets
+        mods["rng"].manual_seed(9)
+        x = x0
+        _, trap_p = proc._tables()
+        for k, i in enumerate(reversed(range(T))):
+            x = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x, i, 1, seed=mods["rng"].seed(), rng_offset=k * T,
+                                 precision=net.precision_code, guide_p=proc._guide_p)
+        assert torch.equal(a, x)
+        # int t and [B]-shaped t take the prepared path too and agree
+        mods["rng"].manual_seed(9)
+        b1 = proc.p_sample(x0, 17)
+        mods["rng"].manual_seed(9)
+        b2 = proc.p_sample(x0, torch.full((2048,), 17, device=DEV, dtype=torch.long))
+        mods["rng"].manual_seed(9)
+        b3 = proc.p_sample(x0, torch.full((1,), 17, device=DEV, dtype=torch.long))
+        assert torch.equal(b1, b2) and torch.equal(b1, b3) and calls["n"] == 1
+        # (c) optimizer step through the operator
+        opt = mods["optim"].Adam(net, lr=3e-2)
+        loss = proc(x0)
+        loss.backward()
+        opt.step()
+        mods["rng"].manual_seed(9)
+        c = proc.p_sample(x0, 17)
+        assert calls["n"] == 2 and float((c - b1).abs().max()) > 1e-4
+        mods["rng"].manual_seed(9)
+        _, trap_p = proc._tables()
+        want = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x0, 17, 1, seed=mods["rng"].seed(), rng_offset=0,
+                                precision=net.precision_code, guide_p=proc._guide_p)
+        assert torch.equal(c, want)
+        # (c) graph replays
+        del loss
+        opt.zero_grad(set_to_none=True)
+        g = TrainStepGraph(proc, opt, x0.shape, warmup=1)
+        for _ in range(3):
+            g.step(x0)
+        g.flush()
+        mods["rng"].manual_seed(9)
+        d = proc.p_sample(x0, 17)
+        mods["rng"].manual_seed(9)
+        want = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x0, 17, 1, seed=mods["rng"].seed(), rng_offset=0,
+                                precision=net.precision_code, guide_p=proc._guide_p)
+        assert torch.equal(d, want) and float((d - c).abs().max()) > 1e-4
+        # (c) load_state_dict
+        sd = {k: v * 0.5 for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
+        mods["rng"].manual_seed(9)
+        e = proc.p_sample(x0, 17)
+        mods["rng"].manual_seed(9)
+        want = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x0, 17, 1, seed=mods["rng"].seed(), rng_offset=0,
+                                precision=net.precision_code, guide_p=proc._guide_p)
+        assert torch.equal(e, want)
+    finally:
+        B.p_sample_prepare = real
+    # the device-side timestep is clamped into the tables, never read outside them
+    ws = B.p_sample_prepare(net.flat_params_nograd(), proc._sched, trap_p, net.precision_code, guide_p=proc._guide_p)
+    hi = B.p_sample_prepared(ws, proc._sched, trap_p, x0, 0, 1, t_dev=torch.full((1,), 10 ** 6, device=DEV, dtype=torch.long), seed=1,
+                             precision=net.precision_code, guide_p=proc._guide_p)
+    top = B.p_sample_prepared(ws, proc._sched, trap_p, x0, 0, 1, t_dev=torch.full((1,), T - 1, device=DEV, dtype=torch.long), seed=1,
+                              precision=net.precision_code, guide_p=proc._guide_p)
+    assert torch.equal(hi, top)
