@@ -469,10 +469,13 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ slabs, int
 
 __global__ void __launch_bounds__(RED_THREADS)
 k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int accumulate, int np,
-             const float* __restrict__ gscale = nullptr) {
+             const float* __restrict__ gscale = nullptr, const float* __restrict__ status = nullptr) {
   __shared__ float4 part[RED_GROUPS][RED_COLS + 1];
   int col;
   const float4 t4 = slab_sum4(slabs, nslabs, np, part, &col);
+  // status (the training step's loss): not finite = a hand-shake of the step's kernel gave up and its slabs are partial.  The
+  // gradient then is all NaN -- loud, and so3x_adam_step skips a non-finite gradient.
+  const bool bad = status != nullptr && !(fabsf(status[0]) <= 3.0e38f);
   if (threadIdx.x / RED_COLS == 0) {
     const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
     const float gs = gscale ? gscale[0] : 1.0f;
@@ -480,7 +483,7 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
     for (int k = 0; k < 4; k++) {
       const int idx = 4 * col + k;
       if (idx < np) {
-        const float t = gscale ? tv[k] * gs : tv[k];
+        const float t = bad ? __builtin_nanf("") : (gscale ? tv[k] * gs : tv[k]);
         dparams[idx] = accumulate ? dparams[idx] + t : t;
       }
     }
@@ -493,7 +496,7 @@ k_bwd_reduce(const float* __restrict__ slabs, int nslabs, float* __restrict__ dp
 struct AdamArgs { float* p; float* m; float* v; float* step; unsigned* ticket; float lr, beta1, beta2, eps, weight_decay, grad_scale; };
 __global__ void __launch_bounds__(RED_THREADS)
 k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict__ dparams, int np, const float* __restrict__ gscale,
-                  AdamArgs ad) {
+                  AdamArgs ad, const float* __restrict__ status) {
   __shared__ float4 part[RED_GROUPS][RED_COLS + 1];
   __shared__ float sc[2];
   if (threadIdx.x == RED_THREADS - 1) {  // (a thread of the last group: the scalars are ready when the partial sums are)
@@ -504,6 +507,8 @@ k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict
   }
   int col;
   const float4 t4 = slab_sum4(slabs, nslabs, np, part, &col);
+  // a step whose kernel gave up on a hand-shake (loss not finite): gradient NaN, parameters / moments / step count untouched
+  const bool bad = status != nullptr && !(fabsf(status[0]) <= 3.0e38f);
   if (threadIdx.x / RED_COLS == 0) {
     const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
     const float gs = gscale ? gscale[0] : 1.0f;
@@ -513,7 +518,8 @@ k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict
       const int idx = 4 * col + k;
       if (idx >= np) continue;
       const float t = gscale ? tv[k] * gs : tv[k];
-      dparams[idx] = t;
+      dparams[idx] = bad ? __builtin_nanf("") : t;
+      if (bad) continue;
       float gi = t * ad.grad_scale;
       const float pi = ad.p[idx];
       if (ad.weight_decay != 0.0f) gi = fmaf(ad.weight_decay, pi, gi);
@@ -530,7 +536,7 @@ k_bwd_reduce_adam(const float* __restrict__ slabs, int nslabs, float* __restrict
     const unsigned mine = __hip_atomic_fetch_add(ad.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (mine == gridDim.x - 1) {
       __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ad.step[0] = ad.step[0] + 1.0f;
+      if (!bad) ad.step[0] = ad.step[0] + 1.0f;
     }
   }
 }
@@ -722,6 +728,7 @@ k_mlp_fwd_stash(const void* __restrict__ gimg, const float* __restrict__ beff_ta
       __syncthreads();
       if (threadIdx.x == 0) {
         la.loss[0] = (float)((((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * la.inv_count);
+      if (la.status) la.status[0] = la.loss[0];
         if (la.rng_counter) la.rng_counter[0] += 1;  // every reader of this step's offset ran in an earlier launch
       }
     }
@@ -1046,10 +1053,11 @@ inline int launch_fused_bwd(hipStream_t s, const char* img, const char* wt, cons
 }
 
 // the fixed-order sum of the partial slabs k_bwd_fused left for n samples (same grid rule as launch_fused_bwd)
-inline int launch_slab_reduce(hipStream_t s, const float* slabs, int64_t n, int nout, float* dparams, const float* gscale) {
+inline int launch_slab_reduce(hipStream_t s, const float* slabs, int64_t n, int nout, float* dparams, const float* gscale,
+                              const float* status = nullptr) {
   const int64_t nt = (n + 31) / 32;
   const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3(red_blocks(nparams(nout))), dim3(RED_THREADS), 0, s, slabs, gf, dparams, 0, nparams(nout), gscale);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3(red_blocks(nparams(nout))), dim3(RED_THREADS), 0, s, slabs, gf, dparams, 0, nparams(nout), gscale, status);
   return check_launch();
 }
 
@@ -1189,6 +1197,7 @@ int so3x_train_net(so3x_stream_t s, const float* params, int T, const float* x_t
   LossArgs la;
   la.dout = dout; la.loss = loss;
   la.partial = reinterpret_cast<double*>(ws + L.partial);
+  la.status = reinterpret_cast<float*>(ws + L.ticket + 64);
   la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
   la.rng_counter = rng_counter;
   la.dscale = (float)(2.0 / (3.0 * (double)n));
@@ -1234,7 +1243,8 @@ int so3x_train_bwd_reduce(so3x_stream_t s, int64_t n, int T, const float* gscale
   if (n <= 0 || T <= 0 || !grad) return SO3X_ERR_INVALID_ARG;
   const TrainLayout L = train_layout(n, T);
   if (!workspace || workspace_bytes < L.end) return SO3X_ERR_WORKSPACE;
-  return launch_slab_reduce((hipStream_t)s, reinterpret_cast<const float*>((const char*)workspace + L.slabs), n, 3, grad, gscale);
+  return launch_slab_reduce((hipStream_t)s, reinterpret_cast<const float*>((const char*)workspace + L.slabs), n, 3, grad, gscale,
+                            reinterpret_cast<const float*>((const char*)workspace + L.ticket + 64));
 }
 
 int so3x_train_bwd_reduce_adam(so3x_stream_t s, int64_t n, int T, const float* gscale, float* grad, const void* workspace,
@@ -1247,7 +1257,8 @@ int so3x_train_bwd_reduce_adam(so3x_stream_t s, int64_t n, int T, const float* g
   const int gf = (int)((nt + 3) / 4 < DW_BLOCKS ? (nt + 3) / 4 : DW_BLOCKS);
   AdamArgs ad{params, exp_avg, exp_avg_sq, step, reinterpret_cast<unsigned*>(step + 1), lr, beta1, beta2, eps, weight_decay, grad_scale};
   hipLaunchKernelGGL(k_bwd_reduce_adam, dim3(red_blocks(nparams(3))), dim3(RED_THREADS), 0, (hipStream_t)s,
-                     reinterpret_cast<const float*>((const char*)workspace + L.slabs), gf, grad, nparams(3), gscale, ad);
+                     reinterpret_cast<const float*>((const char*)workspace + L.slabs), gf, grad, nparams(3), gscale, ad,
+                     reinterpret_cast<const float*>((const char*)workspace + L.ticket + 64));
   return check_launch();
 }
 

@@ -28,7 +28,12 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
   __syncthreads();
   const float neg_step_size = sc[0], bc2_sqrt = sc[1];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
+  // A gradient whose FIRST entry is not finite is the all-NaN gradient of a training step that gave up on a hand-shake
+  // (so3x_train_bwd_reduce poisons every entry, and a summed all-reduce keeps it that way on every rank): the whole update is
+  // skipped, step count included -- the parameters must not be written from partial slabs.  (torch.optim.Adam would propagate
+  // the NaN into the parameters; this is a deliberate deviation for that one case.)
+  const bool bad = !(fabsf(g[0]) <= 3.0e38f);
+  if (i < n && !bad) {
     float gi = g[i] * grad_scale;
     float pi = p[i];
     if (weight_decay != 0.0f) gi = fmaf(weight_decay, pi, gi);
@@ -45,7 +50,7 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
     const unsigned mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (mine == gridDim.x - 1) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      step[0] = step[0] + 1.0f;
+      if (!bad) step[0] = step[0] + 1.0f;
     }
   }
 }

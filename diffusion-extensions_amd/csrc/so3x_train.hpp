@@ -126,6 +126,8 @@ struct LossArgs {
   const float* target;   // [n][3] regression targets
   float* dout;           // [n][3] d loss / d out = 2 (out - target) / (3 n)
   float* loss;           // [1]
+  float* status;         // [1] inside the step's workspace: a copy of the loss for the kernels that consume the step's slabs -- a
+                         // non-finite value (a timed-out hand-shake) makes so3x_train_bwd_reduce{,_adam} leave everything untouched
   double* partial;       // [gridDim.x] per-block sums of squared differences
   unsigned* ticket;      // arrival ticket, zero between launches
   int64_t* rng_counter;  // optional: device-resident Philox offset of the noise draw, incremented once per step
@@ -150,7 +152,7 @@ inline TrainLayout train_layout(int64_t n, int T) {
   L.target = L.slabs + (size_t)DW_BLOCKS * NPARAMS_MAX * sizeof(float);
   L.partial = (L.target + (size_t)(n > 0 ? n : 0) * 3 * sizeof(float) + 255) & ~(size_t)255;
   L.ticket = L.partial + 512 * sizeof(double);
-  L.end = L.ticket + 256;
+  L.end = L.ticket + 256;   // (the ticket word at + 0, the step's status word -- LossArgs::status -- at + 64)
   return L;
 }
 

@@ -711,6 +711,7 @@ k_train_fused(const void* __restrict__ gimg, const void* __restrict__ gwt, const
     __syncthreads();
     if (threadIdx.x == 0) {
       la.loss[0] = (float)((((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * la.inv_count);
+      if (la.status) la.status[0] = la.loss[0];
       if (la.rng_counter) la.rng_counter[0] += 1;  // every block read this step's offset at its start
     }
   }
@@ -742,6 +743,7 @@ int so3x_train_fused(so3x_stream_t s, const float* params, const float* sched, i
   LossArgs la;
   la.target = nullptr; la.dout = nullptr; la.loss = loss;
   la.partial = reinterpret_cast<double*>(ws + L.partial);
+  la.status = reinterpret_cast<float*>(ws + L.ticket + 64);
   la.ticket = reinterpret_cast<unsigned*>(ws + L.ticket);
   la.rng_counter = counter;
   la.dscale = (float)(2.0 / (3.0 * (double)n));

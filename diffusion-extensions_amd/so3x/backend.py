@@ -512,6 +512,8 @@ def train_bwd_reduce(buf, gscale=None, grad=None):
 def train_bwd_reduce_adam(buf, params, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0, gscale=None):
     """stage 4 and the optimizer in ONE launch (single-process training): buf.grad = the reduced gradient, then torch.optim.Adam's
     update of `params` with it -- bit-identical to train_bwd_reduce followed by adam_step"""
+    from .flat import params_changed_out_of_band
+    params_changed_out_of_band()   # the parameters are rewritten through a raw pointer: caches keyed on their values must see it
     _call(ops().train_bwd_reduce_adam, buf.n, buf.T, _dev(gscale, "grad_output").reshape(1) if gscale is not None else None, buf.grad,
           buf.workspace, params, exp_avg, exp_avg_sq, step, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
           float(grad_scale))
@@ -520,6 +522,8 @@ def train_bwd_reduce_adam(buf, params, exp_avg, exp_avg_sq, step, lr, beta1, bet
 
 def adam_step(params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay=0.0, grad_scale=1.0):
     """torch.optim.Adam.step() on flat fp32 buffers, in place (so3x_adam_step); step: device float32 [2] = [count, scratch]"""
+    from .flat import params_changed_out_of_band
+    params_changed_out_of_band()   # the parameters are rewritten through a raw pointer: caches keyed on their values must see it
     for name, x in (("params", params), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq), ("step", step)):
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
             raise So3xError(f"so3x: adam_step needs contiguous fp32 device tensors ({name})")

@@ -139,13 +139,16 @@ class SO3Diffusion(nn.Module):
 
     def _prepared(self, net):
         """so3x_p_sample_prepare's workspace for the 65-wide network's CURRENT parameters (weight image, per-timestep rows, CDF
-        records for all T steps): built on first use and whenever the flat parameter buffer, its tensor version, the
+        records for all T steps): built on first use and whenever the flat parameter buffer, the parameters' tensor versions, the
         out-of-band update epoch (graph replays), the precision or the tables change.  A p_sample call then is one kernel launch."""
         from .flat import PARAM_EPOCH
         _, trap_p = self._tables()
         flat = net.flat_params_nograd()
         prec = getattr(net, "chain_precision_code", net.precision_code)
-        key = (flat.data_ptr(), flat._version, PARAM_EPOCH[0], prec, trap_p.data_ptr(), self._guide_p.data_ptr(), flat.device)
+        # (the nn.Parameters share the flat buffer's storage through `.data`, not its version counter: an in-place torch update
+        #  -- load_state_dict, torch.optim -- bumps THEIR versions)
+        key = (flat.data_ptr(), tuple(p._version for p in net._flat_params), PARAM_EPOCH[0], prec, trap_p.data_ptr(),
+               self._guide_p.data_ptr(), flat.device)
         if self._prep is None or self._prep[0] != key:
             self._prep = (key, _b.p_sample_prepare(flat, self._sched, trap_p, prec, guide_p=self._guide_p))
         return self._prep[1], prec

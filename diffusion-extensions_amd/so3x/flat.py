@@ -24,8 +24,16 @@ def _registered(*_args, **_kwargs):
     return None
 
 
-torch.nn.modules.module.register_module_parameter_registration_hook(_registered)
-torch.nn.modules.module.register_module_module_registration_hook(_registered)
+_HOOKED = [False]
+
+
+def _install_hooks():
+    """the process-global registration hooks, installed at the first flattening (not at import: a process that only imports
+    so3x pays nothing)"""
+    if not _HOOKED[0]:
+        torch.nn.modules.module.register_module_parameter_registration_hook(_registered)
+        torch.nn.modules.module.register_module_module_registration_hook(_registered)
+        _HOOKED[0] = True
 
 
 # Parameter updates torch cannot see: a replayed hipGraph (so3x.graphs.TrainStepGraph) rewrites the flat buffer without bumping its
@@ -77,6 +85,7 @@ class FlatParamsMixin:
         self._flatten()
 
     def _flatten(self):
+        _install_hooks()
         params = list(self._flat_root().parameters())
         if not params:
             return
@@ -90,6 +99,7 @@ class FlatParamsMixin:
                 p.data = flat[off:off + n].view(p.shape)
                 off += n
         self._flat, self._flat_params, self._flat_grad = flat, params, None
+        self._flat_owners = [(m, k, q) for m in self._flat_root().modules() for k, q in m._parameters.items() if q is not None]
         self._flat_seen = -1       # the registration count at which the cached list was last compared with the module tree
 
     def _flat_ok(self):
@@ -98,9 +108,12 @@ class FlatParamsMixin:
         f, ps = self._flat, self._flat_params
         if f is None or len(ps) == 0:
             return False
-        if getattr(self, "_flat_seen", -1) == _REGISTRATIONS[0]:
-            # nothing has been registered anywhere since the list was last checked against the tree: only a caller assigning
-            # p.data (which registers nothing) can have moved a parameter
+        if getattr(self, "_flat_seen", -1) == _REGISTRATIONS[0] and all(m._parameters.get(k) is q for m, k, q in self._flat_owners):
+            # nothing has been registered anywhere since the list was last checked against the tree, and every owning module
+            # still holds its parameter object under its name (torch's hooks do not fire for REMOVALS -- `del layer.weight`,
+            # `register_parameter(name, None)`, edits of `_parameters` -- which this identity check catches; removing a whole
+            # layer from the tree is not supported: the kernels are built for the network's fixed structure): only a caller
+            # assigning p.data (which registers nothing) can have moved a parameter
             off, base, es = 0, f.data_ptr(), f.element_size()
             for p in ps:
                 if p.data_ptr() != base + es * off:

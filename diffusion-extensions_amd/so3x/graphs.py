@@ -15,7 +15,9 @@ three launches per step with the prep), or slab reduction -> all-reduce -> Adam 
 kernel, so there is nothing left to run beside the tail: the kernel is ~90 us shorter than the three it replaces, which is more
 than the pipelined form below could hide.
 
-**Pipelined** (the default, in a data-parallel run, for the path BASELINE config 4 names: SO3Diffusion + the 65-wide
+**Pipelined** (round 3's default in a data-parallel run; since round 4 `pipeline=True` only -- "auto" takes the one-kernel step at
+every world size, a choice that rests on ONE-GPU timings and gloo dry runs: no multi-GPU node was available to any round, so
+which form wins over xGMI is unmeasured) for the path BASELINE config 4 names: SO3Diffusion + the 65-wide
 skew-vector RotPredict with bf16 operands + so3x.optim.Adam).  The step runs as its C-ABI stages (so3x_train_noise / _net / _bwd_partial / _bwd_reduce /
 so3x_adam_step, no autograd in between), and the graph boundary sits BEHIND THE FUSED BACKWARD instead of behind the optimizer:
 
@@ -85,8 +87,13 @@ class TrainStepGraph:
     """
 
     def __init__(self, process, optimizer, batch_shape, warmup=3, ctx=None, n_global=None, allreduce="auto", pipeline="auto",
-                 _inject_capture_failure=False, _assume_capturable=False):
+                 check_every=100, _inject_capture_failure=False, _assume_capturable=False):
         self.process, self.optimizer = process, optimizer
+        # every `check_every` calls of step() the loss is read back (one host synchronisation) and a non-finite value raises: the
+        # one-kernel step reports an abandoned LDS hand-shake (a hung partner wave) as a NaN loss, and although its consumers then
+        # leave parameters and optimizer state untouched (so3x_train_bwd_reduce{,_adam}, so3x_adam_step), a loop that never looks at
+        # the loss would train on nothing without noticing.  0 = never check.
+        self.check_every, self._steps = int(check_every), 0
         self.ctx = ctx
         self.world = 1 if ctx is None else ctx.world_size
         self.n_local = int(batch_shape[0])
@@ -100,13 +107,15 @@ class TrainStepGraph:
                     and self.n_local > 0 and all(p.requires_grad for p in self.net.net.parameters()))
         if pipeline is True and not eligible:
             raise ValueError("so3x: the pipelined step is built for SO3Diffusion(loss_type='skewvec', draw_t_in_kernel) + the 65-wide "
-                             "skew-vector RotPredict with bf16 operands + so3x.optim.Adam")
+                             "skew-vector RotPredict with bf16 operands + so3x.optim.Adam, with EVERY parameter trainable (a frozen "
+                             "parameter -- requires_grad False -- disqualifies it: the flat update would move it)")
         # "auto": pipelined where there is a collective to hide.  In a single process every kernel of the tail fills the chip
         # for its few microseconds, the noising kernel finds no free wave slots beside them, and the fork / join edges cost
         # ~2 us: measured 0.2430 vs 0.2402 ms per 2^19-sample step (bench.py train_step, round 3) -- so the serial form stays.
         if pipeline == "fused" and not eligible:
             raise ValueError("so3x: the one-kernel step is built for SO3Diffusion(loss_type='skewvec', draw_t_in_kernel) + the 65-wide "
-                             "skew-vector RotPredict with bf16 operands + so3x.optim.Adam")
+                             "skew-vector RotPredict with bf16 operands + so3x.optim.Adam, with EVERY parameter trainable (a frozen "
+                             "parameter -- requires_grad False -- disqualifies it: the flat update would move it)")
         # "auto": the one-kernel step (so3x_train_fused) wherever it applies -- measured 0.2066 against 0.2446 ms for the staged
         # launches at 2^19 samples in its first form (profiles/r04_ab_train_fused_v1.json)
         self.fused = bool(eligible and pipeline in ("auto", "fused") and getattr(process, "train_step_kernel", "fused") == "fused")
@@ -359,9 +368,17 @@ class TrainStepGraph:
         self.graph_head, self.graph_red, self.graph, self.graph_opt = head, red, rest, opt
 
     # ------------------------------------------------------------------ replay
+    def _check(self):
+        self._steps += 1
+        if self.check_every > 0 and self._steps % self.check_every == 0 and not bool(torch.isfinite(self.loss).all().item()):
+            raise _b.So3xError(f"so3x: the training step's loss is not finite after {self._steps} steps (loss = {float(self.loss)}): a "
+                               "hand-shake inside the one-kernel step gave up, or the data / parameters hold NaN; the update of such a "
+                               "step is skipped on the device")
+
     def step(self, x):
         self.x.copy_(x)
         self.replay()
+        self._check()
         return self.loss
 
     def replay(self):

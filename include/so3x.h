@@ -424,7 +424,7 @@ int so3x_adam_step(so3x_stream_t s, float* params, const float* grad, float* exp
  * process(truepos); loss.backward()` of so3_train.py:73-75 up to the per-workgroup partial dW slabs.  Noise draw, q_sample and
  * target (diffusion.py:339-355), network forward (so3_train.py:39-49), MSE and d loss / d out (diffusion.py:357), the dZ chain and
  * the dW products run per 32-sample tile inside one workgroup; x_t, target, timesteps, dout and the pre-activations never go
- * through HBM (a sample costs its 36 bytes of x0).  Same arguments and meaning as so3x_train_fwd, same draws bit for bit (Philox
+ * through HBM (a sample costs its 36 bytes of x0).  Same arguments and meaning as so3x_train_fwd, same Philox draws and timesteps bit for bit; x_t and the targets agree to fp32 rounding (fused multiply-adds contract differently in the two translation units), the network output to bf16-operand accuracy (Philox
  * keyed by (seed, index_base + i, rng_offset + *rng_counter); t == NULL: drawn in the kernel; quirk_col0 as there); rng_counter
  * is advanced by one when the call drew from it.  loss[0] = mean((out - target)^2).  The slabs land where
  * so3x_train_bwd_reduce / so3x_train_bwd_reduce_adam (same n, T, workspace) expect them: call one of those next for grad[17358].

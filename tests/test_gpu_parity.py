@@ -410,6 +410,10 @@ def test_p_sample_step_vs_golden_G2(mods, golden, net, tval):
     from conftest import reverse_step_bound
     lim = np.maximum(1e-5, 2 * ref_err)
     over = err > lim
+    # (the survey's 2 % / 40 % are RATES measured on many samples; this fixture has n = 64, where one binomial standard error is
+    #  1.75 % / 6.1 %: the budgets are the survey's rates plus at most one standard error -- 3 % = one sample, 45 % = 28 samples)
+    p_out = 0.40 if tval == 999 else 0.02
+    assert (0.45 if tval == 999 else 0.03) <= p_out + np.sqrt(p_out * (1 - p_out) / n) + 1e-9
     assert over.mean() <= (0.45 if tval == 999 else 0.03), (tval, over.mean())
     sch = host(proc._sched)
     coef = tuple(float(sch[i][tval]) for i in (6, 7, 10, 11))
@@ -1367,3 +1371,54 @@ def test_sharded_sampling_is_invariant_to_the_number_of_ranks(tmp_path):
     one = parallel.sharded_p_sample_loop(proc, 1001, parallel.Ctx(0, 1, 0, torch.device(DEV), False))
     assert torch.equal(one.cpu(), two)
     assert proc.index_base == 0
+
+
+@pytest.mark.parametrize("wrong", ["sigma_t x 1.15", "sigma_t x 0.87", "network output x 0.9", "network output x 1.1"])
+def test_G3_has_power_against_near_misses(mods, golden, net, wrong):
+    """Haar-uniform is the only alternative G3 was shown to reject.  Near misses -- the posterior noise scale
+    off by 15 %, the score network's output off by 10 % -- leave the kernel MMD far inside its acceptance bound (measured
+    4e-4 .. 8e-4 against a bound of 7.6e-2: the bound of util.py:289-299 is a worst-case one), so the chain-level gate gets a
+    second, sharper statistic: the median geodesic distance to the nearer training mode (so3_train.py:65-72).  The shipped bf16
+    chain reproduces the reference population's median within 6 % (measured 0.5-1.6 %; the bootstrap standard error of the
+    reference's own median is below 2 %); every near miss moves it by more than that, in the direction the error implies."""
+    import copy
+    from so3x import rng
+    g = golden["chain_samples_trained"]
+    ref = g["x_final"].astype(np.float64)
+    m = len(ref)
+    z90 = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+
+    def median_mode_distance(X):
+        d0 = O.rmat_dist(X, np.broadcast_to(z90, X.shape).copy(), "f64")
+        d1 = O.rmat_dist(X, np.broadcast_to(z90.T, X.shape).copy(), "f64")
+        return float(np.median(np.minimum(d0, d1)))
+
+    def chain(sig=1.0, vscale=1.0):
+        n2 = copy.deepcopy(net)
+        n2.load_state_dict({f"net.{l}.{k}": torch.from_numpy(g[f"net_{l}_{k}"]) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")})
+        n2 = n2.to(DEV)
+        n2.precision = "bf16"
+        with torch.no_grad():
+            n2.net[8].weight.mul_(vscale)
+            n2.net[8].bias.mul_(vscale)
+        proc = mods["diff"].SO3Diffusion(n2, timesteps=1000).to(DEV)
+        if sig != 1.0:
+            proc._tables()
+            proc._sched[12] *= sig
+            proc._trap_p = mods["B"].igso3_build_tables(proc._sched[12])
+            proc._guide_p = mods["B"].igso3_build_guide(proc._trap_p)
+        rng.manual_seed(2024)
+        return host(proc.p_sample_loop((m,))).astype(np.float64)
+
+    med_ref = median_mode_distance(ref)
+    boot = np.random.default_rng(0)
+    se = np.std([median_mode_distance(ref[boot.integers(0, m, m)]) for _ in range(40)]) / med_ref
+    assert se < 0.02, se                                                    # 6 % is at least three standard errors
+    shipped = median_mode_distance(chain())
+    assert abs(shipped - med_ref) < 0.06 * med_ref, (shipped, med_ref)
+    sig, vs = {"sigma_t x 1.15": (1.15, 1.0), "sigma_t x 0.87": (0.87, 1.0), "network output x 0.9": (1.0, 0.9), "network output x 1.1": (1.0, 1.1)}[wrong]
+    x = chain(sig, vs)
+    med = median_mode_distance(x)
+    wider = sig > 1.0 or vs < 1.0          # more noise, or a weaker pull towards the data: a wider population
+    assert (med - med_ref) * (1 if wider else -1) > 0.06 * med_ref, (wrong, med, med_ref)
+    assert O.MMD(x, ref) > 1.5 * O.MMD(chain(), ref)                       # the kernel statistic moves the same way, inside its loose bound

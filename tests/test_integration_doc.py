@@ -20,7 +20,8 @@ def _blocks():
 
 def test_integration_md_has_the_stubs():
     src = "\n".join(_blocks())
-    for name in ("def so3_scale", "def p_sample_loop", "def mlp_forward_for_training", "def mlp_backward", "def training_step_loss_and_grad"):
+    for name in ("def so3_scale", "def p_sample_loop", "def mlp_forward_for_training", "def mlp_backward", "def training_step_loss_and_grad",
+                 "def p_sample_prepare", "def p_sample(", "def planenet_forward_backward"):
         assert name in src
     compile(src.replace('ctypes.CDLL("diffusion-extensions_amd/libso3x.so")', "None"), "INTEGRATION.md", "exec")
 
@@ -39,7 +40,8 @@ def test_integration_md_stubs_run_and_agree_with_the_binding():
     finally:
         os.chdir(cwd)
     lib = ns["_lib"]
-    for f in ("so3x_mlp_stash_bytes", "so3x_mlp_workspace_bytes", "so3x_p_sample_workspace_bytes", "so3x_train_workspace_bytes"):
+    for f in ("so3x_mlp_stash_bytes", "so3x_mlp_workspace_bytes", "so3x_p_sample_workspace_bytes", "so3x_train_workspace_bytes",
+              "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes"):
         getattr(lib, f).restype = ctypes.c_size_t
     lib.so3x_error_string.restype = ctypes.c_char_p
     net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
@@ -65,3 +67,19 @@ def test_integration_md_stubs_run_and_agree_with_the_binding():
     xs = ns["p_sample_loop"](params, proc._sched, trap_p, x.clone(), 100, 5)
     eye = torch.eye(3, device=DEV)
     assert torch.isfinite(xs).all() and float((xs @ xs.transpose(-1, -2) - eye).abs().max()) < 1e-5
+    # round 5: one p_sample per call from the prepared state == the binding's; PlaneNet forward + backward == the module's
+    ws = ns["p_sample_prepare"](params, proc._sched, trap_p, 100)
+    tdev = torch.full((1,), 37, device=DEV, dtype=torch.long)
+    got = ns["p_sample"](ws, proc._sched, trap_p, x, tdev, 100, 5, 11)
+    want = B.p_sample_chain(params, proc._sched, trap_p, x, 37, 1, seed=5, rng_offset=11, precision=1)
+    assert torch.equal(got, want)
+    from so3x.models import PlaneNet
+    torch.manual_seed(1)
+    pn = PlaneNet(precision="bf16", dropout=0.0).to(DEV).train()
+    clouds = torch.randn(3, 128, 3, device=DEV) * 0.5
+    tt = torch.randint(0, 1000, (3,), device=DEV)
+    dout = torch.randn(3, 3, device=DEV)
+    out, dparams = ns["planenet_forward_backward"](pn.flat_data(), clouds, tt, dout)
+    ref = pn(clouds, tt)
+    (ref * dout).sum().backward()
+    assert torch.equal(out, ref.detach()) and torch.equal(dparams, pn.flat_grad())
