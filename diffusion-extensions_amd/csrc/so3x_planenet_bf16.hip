@@ -145,15 +145,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
 // not stop at a tile boundary: the next tile's first K-tiles are in flight while this tile's accumulators are stored, so neither
 // the prologue latency nor the store tail is exposed.  Staging addresses are a scalar base per (tile, half, K-tile) plus a
 // per-lane offset fixed for the whole launch.
-// C^T = W A^T is what the MFMAs compute (W fragment as the A operand), so a lane holds 4 consecutive columns of one C row;
-// v_permlane16_swap pairs two 16-column tiles into 8 consecutive columns per lane: 16-byte stores, 64 contiguous bytes per row.
+// C^T = W A^T is what the MFMAs compute (W fragment as the A operand), so a lane holds 4 consecutive columns of one C row: one
+// ds_write_b128 per tile into the epilogue's LDS transposition (below).
 constexpr int TB = 256;
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                          const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
                                                          int lda, int ldw, int ldc, int ldr) {
-  __shared__ __attribute__((aligned(16))) char smem[131072];
+  __shared__ __attribute__((aligned(16))) char smem[131072 + 32768];   // two K-tile buffers | 4 KB per wave for the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int ntn = N / TB, ntiles = ntn * (M / TB), KT = K / 64;
   // this workgroup's tiles: XCD x (workgroup ids round-robin over the 8 XCDs) owns a contiguous range of tiles, its workgroups take
@@ -254,57 +254,84 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
   int par = 0;
+  bool after_store = false;   // the K-tile right behind a tile's stores: its A halves were staged ahead of them (below)
   for (int it = 0; it < nmine; it++) {
     for (int kt = 0; kt < KT; kt++, par ^= 1) {
       const char* buf = smem + par * 65536;
       load_a(buf, 0); load_b(buf, 0); load_b(buf, 1);
-      stage_a(ca, par ^ 1); advance(ca);
+      if (!after_store) { stage_a(ca, par ^ 1); advance(ca); }
       SO3X_H1_END();
       SO3X_ROWS(0);
       __builtin_amdgcn_s_barrier();
       load_a(buf, 1);
       const bool more = cw.it < nmine;
       stage_w(cw, par); advance(cw);
-      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // vmcnt counts in issue order, stores included.  Behind a tile's 16 stores everything K-tile u+1 needs was issued BEFORE them
+      // (its A halves ahead of the epilogue, below), so they may stay in flight with the W pieces staged just now: a wait that
+      // had to retire them stalls every CU on the chip-wide burst of C at each tile boundary (measured: 25 % of the kernel).
+      if (after_store) {
+        if (more) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        after_store = false;
+      } else {
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       SO3X_H1_END();
       SO3X_ROWS(1);
       __builtin_amdgcn_s_barrier();
     }
-    // this tile's accumulators -> C (the next tile's first K-tiles are already on their way)
+    // this tile's accumulators -> C (the next tile's first K-tiles are already on their way).  Through a wave-private 4 KB of LDS,
+    // 16 rows at a time: the accumulators hold 4 consecutive columns of one row per lane (C^T = W A^T orientation) and go in as
+    // one ds_write_b128 per 16 x 16 tile (the 16-byte unit XORed with the row: conflict-free both ways); they come back as 8
+    // consecutive columns of a row per lane, so that one store instruction writes 8 rows x 128 contiguous bytes -- whole cache
+    // lines.  (Storing from the accumulator layout directly -- 16 rows x 64 bytes per instruction at the row stride of C -- ran the
+    // write side of a 8192^3 product at 0.5 TB/s: +35 % on the whole kernel.)
     const int tile = x_start + lb + it * nlb, tm = tile / ntn, tn = tile - tm * ntn;
-    const int g = lane >> 4;
-    const int ncol = tn * TB + wn * 64 + (g & 1) * 16 + (g >> 1) * 8;        // + ch * 32: this lane's 8 columns after the swap
+    // the A halves of K-tile u+2, normally staged in PA.H1 of K-tile u+1, go out NOW, ahead of the stores (their buffer is the one
+    // K-tile u just finished with: both groups are behind its last barrier)
+    stage_a(ca, par ^ 1); advance(ca);
+    after_store = true;
+    char* ep = smem + 131072 + wave * 4096;
+    const int g = lane >> 4, m_l = lane & 15, rrow = lane >> 3, c8 = lane & 7;
+    const int ncol = tn * TB + wn * 64 + c8 * 8;
+    const float4 bv0 = *reinterpret_cast<const float4*>(bias + ncol), bv1 = *reinterpret_cast<const float4*>(bias + ncol + 4);
+    // (the residual / mask rows are fetched one unit -- 8 rows x 128 bytes -- ahead: a load issued behind a store would make the
+    //  compiler's wait for it retire the store first)
+    const size_t row0 = (size_t)tm * TB + wm * 128;
+    bf16x8 rnext;
+    if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + rrow) * ldr + ncol);
 #pragma unroll
-    for (int ch = 0; ch < 2; ch++) {
-      const float4 bv0 = *reinterpret_cast<const float4*>(bias + ncol + ch * 32), bv1 = *reinterpret_cast<const float4*>(bias + ncol + ch * 32 + 4);
+    for (int c = 0; c < 8; c++) {      // 16-row chunks: rh = c >> 2, mi = c & 3
+      const int rh = c >> 2, mi = c & 3;
 #pragma unroll
-      for (int rh = 0; rh < 2; rh++)
+      for (int ch = 0; ch < 2; ch++)
 #pragma unroll
-        for (int mi = 0; mi < 4; mi++) {
-          // odd 16-lane rows of X <-> even rows of Y: rows 0 / 2 keep X (their own columns 4 g' ..) and receive the next four from
-          // X's odd row; rows 1 / 3 receive Y's even row and keep Y.  (Inline asm: hipcc 7.2 folds the builtin form of this swap
-          // to a swap of zeros for accumulator elements 1..3.)
-          f32x4 X = acc[rh][mi][ch][0], Y = acc[rh][mi][ch][1];
-          acc[rh][mi][ch][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[rh][mi][ch][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
-                       "v_permlane16_swap_b32 %3, %7"
-                       : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]));
-          float v[8] = {X[0], X[1], X[2], X[3], Y[0], Y[1], Y[2], Y[3]};
-          v[0] += bv0.x; v[1] += bv0.y; v[2] += bv0.z; v[3] += bv0.w; v[4] += bv1.x; v[5] += bv1.y; v[6] += bv1.z; v[7] += bv1.w;
-          const size_t grow = (size_t)tm * TB + wm * 128 + rh * 64 + mi * 16 + (lane & 15);
-          if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + grow * ldr + ncol + ch * 32);
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? v[e] : 0.f);
-          }
-          if constexpr (EPI == EPI_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-          }
-          *reinterpret_cast<bf16x8*>(C + grow * ldc + ncol + ch * 32) =
-              bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        for (int ni = 0; ni < 2; ni++) {
+          *reinterpret_cast<f32x4*>(ep + m_l * 256 + (((ch * 8 + ni * 4 + g) ^ m_l) << 4)) = acc[rh][mi][ch][ni];
+          acc[rh][mi][ch][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++) {
+        const int row = rrow + 8 * rr;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * c8) ^ row) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+        float v[8] = {lo[0] + bv0.x, lo[1] + bv0.y, lo[2] + bv0.z, lo[3] + bv0.w, hi[0] + bv1.x, hi[1] + bv1.y, hi[2] + bv1.z, hi[3] + bv1.w};
+        const size_t grow = row0 + c * 16 + row;
+        if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
+          const bf16x8 rv = rnext;
+          const int nu = 2 * c + rr + 1;                     // the next unit: rows 16 (nu >> 1) + rrow + 8 (nu & 1)
+          if (nu < 16) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + 16 * (nu >> 1) + rrow + 8 * (nu & 1)) * ldr + ncol);
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? v[e] : 0.f);
+        }
+        if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(C + grow * ldc + ncol) =
+            bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // the barrier the other group started with
@@ -371,6 +398,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
 #pragma unroll
     for (int i = 0; i < 16; i++) ot[dt][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  constexpr float RESCALE_LOG2 = 4.0f;
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
   // lane constants of the LDS reads
   const int krd = r * 256, ksw = swz16(r);                                   // K rows kb * 32 + r: swz16 does not see kb * 32
   const int g = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
@@ -394,37 +423,43 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
     }
-    // online softmax: this lane holds 32 of its query's 64 scores, lane ^ 32 the other 32
+    // online softmax: this lane holds 32 of its query's 64 scores, lane ^ 32 the other 32.  The running maximum is raised -- and
+    // O^T and the running sum rescaled -- only when some query of the wave outgrew it by more than 2^RESCALE_LOG2 (bf16 and fp32
+    // are floating point: probabilities up to 2^4 lose nothing); the branch is wave-uniform.
     float mx = st[0][0];
 #pragma unroll
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, st[0][i]);
 #pragma unroll
     for (int i = 0; i < 16; i++) mx = fmaxf(mx, st[1][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-    const float mneg = -m_new * c2;
-    m_run = m_new;
-    float ps = 0.f;
+    if (!__all((mx - m_run) * c2 <= RESCALE_LOG2)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) ot[dt][i] *= alpha;
+    }
+    const float mneg = -m_run * c2;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][i], c2, mneg));
-        st[kb][i] = pv;
-        ps += pv;
-      }
-    l_run = l_run * alpha + ps;
-#pragma unroll
-    for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) ot[dt][i] *= alpha;
+      for (int i = 0; i < 16; i++) st[kb][i] = __builtin_amdgcn_exp2f(fmaf(st[kb][i], c2, mneg));
     // O^T += V^T P^T: k-step s4 = keys 16 s4 .. 16 s4 + 15; the B operand is the accumulator registers 8 s' .. 8 s' + 7 as they sit
+    // The row sums ride on the matrix pipe too: a fifth "V^T tile" of ones gives sum_k P[k][q] in every accumulator row -- four
+    // MFMAs per tile instead of 64 vector adds (the vector port, not the matrix pipe, is this loop's bound), and the sum is of
+    // the bf16 probabilities the numerator uses.
+    f32x16 lt;
+#pragma unroll
+    for (int i = 0; i < 16; i++) lt[i] = 0.f;
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) {
       const int kb = s4 >> 1, s1 = s4 & 1;
       const bf16x8 pf = {(bf16)st[kb][8 * s1 + 0], (bf16)st[kb][8 * s1 + 1], (bf16)st[kb][8 * s1 + 2], (bf16)st[kb][8 * s1 + 3],
                          (bf16)st[kb][8 * s1 + 4], (bf16)st[kb][8 * s1 + 5], (bf16)st[kb][8 * s1 + 6], (bf16)st[kb][8 * s1 + 7]};
+      lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
 #pragma unroll
       for (int dt = 0; dt < 4; dt++) {
         // two 4-key x 16-column blocks per 16-lane group: keys 16 s4 + 4 h + (0..3) and + 8; columns 32 dt + 16 (g & 1) + (0..15)
@@ -436,9 +471,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, ot[dt], 0, 0, 0);
       }
     }
+    l_run += lt[0];
   }
   if (q0 >= P) return;
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = l_run;        // (the MFMA summed over all 64 keys of a tile: both lanes of a query hold the whole sum)
   const float inv = 1.f / l_tot;
   bf16* orow = o + (tok0 + q0 + r) * D + hd * DH + 4 * h;
 #pragma unroll

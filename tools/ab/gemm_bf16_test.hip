@@ -9,14 +9,16 @@
 using namespace so3x::plane;
 namespace so3x { namespace plane {   // the fp32 translation unit is not linked here
 int gemm(hipStream_t, Mat, Mat, float*, int64_t, int, int, int, const float*, float, bool, bool, int, int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t) { return 0; }
+int head(hipStream_t, const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int) { return 0; }
 } }
 __global__ void k_ref(const bf16* A, const bf16* W, float* C, const float* bias, const bf16* R, int M, int N, int K, int relu) {
   const int n = blockIdx.x * 16 + (threadIdx.x & 15), m = blockIdx.y * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
   for (int k = 0; k < K; k++) acc += (float)A[(size_t)m * K + k] * (float)W[(size_t)n * K + k];
   acc += bias[n];
-  if (R) acc += (float)R[(size_t)m * N + n];
-  if (relu) acc = fmaxf(acc, 0.f);
+  if (R && relu != 3) acc += (float)R[(size_t)m * N + n];
+  if (relu == 1) acc = fmaxf(acc, 0.f);
+  if (relu == 3) acc = (float)R[(size_t)m * N + n] > 0.f ? acc : 0.f;
   C[(size_t)m * N + n] = acc;
 }
 __global__ void k_fill(bf16* p, size_t n, unsigned seed) {
@@ -38,9 +40,9 @@ int main(int argc, char** argv) {
   std::vector<float> hb(N);
   for (int i = 0; i < N; i++) hb[i] = 0.01f * (i % 37);
   hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice);
-  k_ref<<<dim3(N / 16, M / 16), 256>>>(A, W, ref, bias, mode == 2 ? R : nullptr, M, N, K, mode == 1);
+  k_ref<<<dim3(N / 16, M / 16), 256>>>(A, W, ref, bias, mode >= 2 ? R : nullptr, M, N, K, mode);
   hipMemset(C, 0xff, (size_t)M * N * 2);
-  int rc = gemm_bf16(0, A, K, W, K, C, N, bias, mode == 2 ? R : nullptr, N, M, N, K, mode == 1);
+  int rc = gemm_bf16(0, A, K, W, K, C, N, bias, mode >= 2 ? R : nullptr, N, M, N, K, mode);
   hipDeviceSynchronize();
   printf("rc %d err %s\n", rc, hipGetErrorString(hipGetLastError()));
   std::vector<unsigned short> hc((size_t)M * N);
@@ -64,10 +66,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 256; i++) if (badcol[i]) printf(" %d", i); printf("\n");
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; i++) gemm_bf16(0, A, K, W, K, C, N, bias, mode == 2 ? R : nullptr, N, M, N, K, mode == 1);
+  for (int i = 0; i < 5; i++) gemm_bf16(0, A, K, W, K, C, N, bias, mode >= 2 ? R : nullptr, N, M, N, K, mode);
   hipEventRecord(e0);
   const int reps = 20;
-  for (int i = 0; i < reps; i++) gemm_bf16(0, A, K, W, K, C, N, bias, mode == 2 ? R : nullptr, N, M, N, K, mode == 1);
+  for (int i = 0; i < reps; i++) gemm_bf16(0, A, K, W, K, C, N, bias, mode >= 2 ? R : nullptr, N, M, N, K, mode);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   printf("time %.1f us  %.0f TFLOP/s (%.1f %% of 2.5 PF)\n", ms * 1e3, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 25.0);
