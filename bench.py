@@ -650,7 +650,9 @@ def planenet_leg(torch, reps=10):
         key = f"{Bn}x{P}"
         out["forward_" + key] = {"kernel": "so3x_planenet_fwd (bf16): k_gemm256_bf16 / k_gemm_bf16, k_attn_fwd, k_ln_bf16, ...", "bound": "mfma", "clouds": Bn,
                                  "points": P, "ms": ms, "flop": flop, "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": tf / BF16_MFMA_PEAK_TFLOPS, "timing": "HIP events around back-to-back operator calls"}
+                                 "frac": tf / BF16_MFMA_PEAK_TFLOPS, "timing": "HIP events around back-to-back operator calls",
+                                 "mfma_pipe_busy_frac_pmc": {k: pmc_mfma_busy(k) for k in ("k_gemm256_bf16", "k_gemm_bf16", "k_attn_fwd")},
+                                 "pmc_source": PMC.source}
         net.train()
         dout = torch.randn(Bn, 3, device=dev)
 

@@ -583,7 +583,8 @@ bool bf16_supported(const Shape& sh);
 size_t bf16_workspace_bytes(const Shape& sh);
 size_t bf16_stash_bytes(const Shape& sh);
 int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
-                 void* stash, void* workspace);
+                 void* stash, void* workspace, const void* prepared);
+int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg);
 int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, const float* dout, float* dprm,
                   const void* stash, void* workspace);
 } }
@@ -611,15 +612,33 @@ size_t so3x_planenet_workspace_bytes(int64_t B, int64_t P, int dim, int heads, i
   return f > b ? f : b;
 }
 
+size_t so3x_planenet_weights_bytes(int dim, int heads, int layers, int ffn, int precision) {
+  Shape sh{1, 64, dim, heads, layers, ffn};
+  if (!shape_ok(sh) || layers > 64 || precision != SO3X_PREC_BF16 || !bf16_supported(sh)) return 0;
+  return up((size_t)param_offsets(sh).total * 2);
+}
+
+int so3x_planenet_prepare(so3x_stream_t s, const float* params, int dim, int heads, int layers, int ffn, int precision, void* weights,
+                          size_t weights_bytes) {
+  Shape sh{1, 64, dim, heads, layers, ffn};
+  if (!shape_ok(sh) || layers > 64 || !params) return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (precision == SO3X_PREC_F32) return SO3X_OK;                       // the exact form reads the fp32 parameters as they are
+  if (!bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
+  if (!weights || weights_bytes < so3x_planenet_weights_bytes(dim, heads, layers, ffn, precision)) return SO3X_ERR_WORKSPACE;
+  return weights_bf16((hipStream_t)s, sh, params, weights);
+}
+
 int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, float* out, float* encoding_out, int64_t B, int64_t P,
-                      int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes) {
+                      int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes,
+                      const void* prepared_weights) {
   Shape sh{B, P, dim, heads, layers, ffn};
   if (!shape_ok(sh) || layers > 64 || (B && (!params || !x || !t || !out))) return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (precision == SO3X_PREC_BF16 && !bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
   if (B == 0) return SO3X_OK;
   if (!workspace || workspace_bytes < so3x_planenet_workspace_bytes(B, P, dim, heads, layers, ffn, precision)) return SO3X_ERR_WORKSPACE;
-  if (precision == SO3X_PREC_BF16) return forward_bf16((hipStream_t)s, sh, params, x, t, out, encoding_out, stash, workspace);
+  if (precision == SO3X_PREC_BF16) return forward_bf16((hipStream_t)s, sh, params, x, t, out, encoding_out, stash, workspace, prepared_weights);
   const Acts a = stash ? carve_acts(sh, stash, true) : carve_acts(sh, workspace, false);
   return forward_f32((hipStream_t)s, sh, params, x, t, out, encoding_out, a);
 }

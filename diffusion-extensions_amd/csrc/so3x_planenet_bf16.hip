@@ -473,16 +473,27 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
     }
     l_run += lt[0];
   }
-  if (q0 >= P) return;
   const float l_tot = l_run;        // (the MFMA summed over all 64 keys of a tile: both lanes of a query hold the whole sum)
   const float inv = 1.f / l_tot;
-  bf16* orow = o + (tok0 + q0 + r) * D + hd * DH + 4 * h;
+  // O^T (d in the registers, query on the lane) -> O rows through this wave's 8 KB of the (now idle) K / V buffers: 8-byte writes at
+  // [query][d] with the 16-byte unit XORed with the query, 16-byte reads of whole rows, so that a store instruction writes 4 rows
+  // x 256 contiguous bytes instead of 32 rows x 16
+  __syncthreads();
+  char* ob = smem + wave * 8192;
 #pragma unroll
   for (int dt = 0; dt < 4; dt++)
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++)
-      *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * g4) = bf16x4{(bf16)(ot[dt][4 * g4] * inv), (bf16)(ot[dt][4 * g4 + 1] * inv),
-                                                                   (bf16)(ot[dt][4 * g4 + 2] * inv), (bf16)(ot[dt][4 * g4 + 3] * inv)};
+      *reinterpret_cast<bf16x4*>(ob + r * 256 + (((4 * dt + g4) ^ (r & 15)) << 4) + 8 * h) =
+          bf16x4{(bf16)(ot[dt][4 * g4] * inv), (bf16)(ot[dt][4 * g4 + 1] * inv), (bf16)(ot[dt][4 * g4 + 2] * inv), (bf16)(ot[dt][4 * g4 + 3] * inv)};
+  __builtin_amdgcn_wave_barrier();
+  if (q0 >= P) return;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int qq = 4 * i + (lane >> 4), u = lane & 15;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ob + qq * 256 + ((u ^ (qq & 15)) << 4));
+    *reinterpret_cast<bf16x8*>(o + (tok0 + q0 + qq) * D + hd * DH + u * 8) = v;
+  }
   if (lse && h == 0) lse[((size_t)b * HEADS + hd) * P + q0 + r] = m_run * sc + logf(l_tot);
 }
 
@@ -556,42 +567,40 @@ __global__ __launch_bounds__(256) void k_embed_bf16(const float* __restrict__ x,
   *reinterpret_cast<bf16x8*>(h0 + n * D + D2 + j0) = tv;
 }
 
-// PoolRN on bf16 rows (models.py:94-110): w_p = sigmoid(x_p . wpool + bpool);  xs_b = sum_p w_p x_p / max(sum_p w_p, 1e-6)
-__global__ __launch_bounds__(256) void k_pool_logits_bf16(const bf16* __restrict__ x, const float* __restrict__ wpool, const float* __restrict__ bpool,
-                                                          float* __restrict__ w, int64_t N) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  const int lane = threadIdx.x & 63;
-  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * D + lane * 8);
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; i++) s = fmaf((float)v[i], wpool[lane * 8 + i], s);
-  s = wave_sum(s) + bpool[0];
-  if (lane == 0) w[row] = 1.f / (1.f + expf(-s));
-}
-// grid (8 column blocks of 64, B clouds, PS point slices): partial weighted sums -> part[b][slice][0..511 | 512 = sum of weights]
-__global__ __launch_bounds__(256) void k_pool_part_bf16(const bf16* __restrict__ x, const float* __restrict__ w, float* __restrict__ part, int64_t P) {
-  __shared__ float red[4][64];
-  __shared__ float sred[4];
-  const int b = blockIdx.y, sl = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nsl = gridDim.z;
+// PoolRN on bf16 rows (models.py:94-110): w_p = sigmoid(x_p . wpool + bpool);  xs_b = sum_p w_p x_p / max(sum_p w_p, 1e-6).
+// One pass over the encoder output: grid (B clouds, PS point slices of 256), a wave per row (16 bytes per lane), the row's weight
+// from a wave reduction, the weighted sum kept in 8 registers per lane; per workgroup part[b][slice][0..511 | 512 = sum of weights]
+__global__ __launch_bounds__(256) void k_pool_bf16(const bf16* __restrict__ x, const float* __restrict__ wpool, const float* __restrict__ bpool,
+                                                   float* __restrict__ w, float* __restrict__ part, int64_t P) {
+  __shared__ float red[4][D + 1];
+  const int b = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t p0 = (int64_t)sl * PSLICE, p1 = p0 + PSLICE < P ? p0 + PSLICE : P;
   const bf16* xb = x + (int64_t)b * P * D;
-  const float* wb = w + (int64_t)b * P;
-  float acc = 0.f, sw = 0.f;
-  for (int64_t p = p0 + g; p < p1; p += 4) {
-    const float wv = wb[p];
+  float* wb = w + (int64_t)b * P;
+  const float4 q0 = *reinterpret_cast<const float4*>(wpool + lane * 8), q1 = *reinterpret_cast<const float4*>(wpool + lane * 8 + 4);
+  const float wp[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  const float bias = bpool[0];
+  float acc[8], sw = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = 0.f;
+  for (int64_t p = p0 + wave; p < p1; p += 4) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + p * D + lane * 8);
+    float xv[8], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { xv[i] = (float)v[i]; s = fmaf(xv[i], wp[i], s); }
+    s = wave_sum(s) + bias;
+    const float wv = 1.f / (1.f + expf(-s));
+    if (lane == 0) wb[p] = wv;
     sw += wv;
-    acc = fmaf(wv, (float)xb[p * D + c], acc);
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = fmaf(wv, xv[i], acc[i]);
   }
-  red[g][lane] = acc;
-  if (lane == 0) sred[g] = sw;
+#pragma unroll
+  for (int i = 0; i < 8; i++) red[wave][lane * 8 + i] = acc[i];
+  if (lane == 0) red[wave][D] = sw;
   __syncthreads();
-  if (g == 0) {
-    float* out = part + ((int64_t)b * nsl + sl) * (D + 1);
-    out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    if (blockIdx.x == 0 && lane == 0) out[D] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-  }
+  float* out = part + ((int64_t)b * nsl + sl) * (D + 1);
+  for (int c = threadIdx.x; c <= D; c += 256) out[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 __global__ __launch_bounds__(512) void k_pool_final(const float* __restrict__ part, int nsl, float* __restrict__ S, float* __restrict__ xs) {
   const int b = blockIdx.x, c = threadIdx.x;
@@ -614,15 +623,21 @@ size_t bf16_stash_bytes(const Shape& s) { return carve_b(s, nullptr, true).bytes
   } while (0)
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// the bf16 image of the weight matrices (everything up to the SIREN's post_scale weight; biases and LayerNorm vectors stay fp32)
+int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg) {
+  const ParamOff po = param_offsets(sh);
+  const int64_t ncvt = (po.wps + (int64_t)D2 * D2 + 3) / 4;
+  hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks_for(ncvt, 256)), dim3(256), 0, s, prm, reinterpret_cast<bf16*>(wimg), ncvt);
+  return check_launch();
+}
+
 int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
-                 void* stash, void* workspace) {
+                 void* stash, void* workspace, const void* prepared) {
   const ParamOff po = param_offsets(sh);
   const int64_t N = sh.N(), Np = padded_rows(sh), P = sh.P;
-  bf16* wimg = reinterpret_cast<bf16*>(workspace);
+  const bf16* wimg = prepared ? reinterpret_cast<const bf16*>(prepared) : reinterpret_cast<const bf16*>(workspace);
   const ActsB a = stash ? carve_b(sh, stash, true) : carve_b(sh, reinterpret_cast<char*>(workspace) + wimg_bytes(sh), false);
-  // bf16 image of the weight matrices (everything up to the SIREN's post_scale weight; biases and LayerNorm vectors stay fp32)
-  const int64_t ncvt = (po.wps + (int64_t)D2 * D2 + 3) / 4;
-  hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks_for(ncvt, 256)), dim3(256), 0, s, prm, wimg, ncvt);
+  if (!prepared) TRY(weights_bf16(s, sh, prm, workspace));
   const float neg_emb = (float)(-(log(10000.0) / (D2 / 2 - 1)));
   hipLaunchKernelGGL(k_temb, dim3((unsigned)sh.B), dim3(D2), 0, s, t, a.temb, neg_emb);
   hipLaunchKernelGGL(k_embed_bf16, dim3(blocks_for(Np * (D2 / 8), 256)), dim3(256), 0, s, x, a.temb, prm + po.wp, prm + po.bp, a.pre, a.sn, a.h[0], N, Np, P);
@@ -650,8 +665,7 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
   const bf16* enc = a.h[sh.L];
   if (encoding_out) hipLaunchKernelGGL(k_cvt_f32, dim3(blocks_for(N * D / 4, 256)), dim3(256), 0, s, enc, encoding_out, N * D / 4);
   const int nsl = (int)((P + PSLICE - 1) / PSLICE);
-  hipLaunchKernelGGL(k_pool_logits_bf16, dim3(blocks_for(N, 4)), dim3(256), 0, s, enc, prm + po.wpool, prm + po.bpool, a.w, N);
-  hipLaunchKernelGGL(k_pool_part_bf16, dim3(D / 64, (unsigned)sh.B, nsl), dim3(256), 0, s, enc, a.w, a.part, P);
+  hipLaunchKernelGGL(k_pool_bf16, dim3((unsigned)sh.B, nsl), dim3(256), 0, s, enc, prm + po.wpool, prm + po.bpool, a.w, a.part, P);
   hipLaunchKernelGGL(k_pool_final, dim3((unsigned)sh.B), dim3(D), 0, s, a.part, nsl, a.S, a.xs);
   TRY(check_launch());
   TRY(head(s, a.xs, prm + po.wlin, prm + po.blin, prm + po.wout, prm + po.bout, a.pooled, out, sh.B, D));

@@ -418,8 +418,16 @@ Tensor rotate_cloud(const Tensor& rot, const Tensor& cloud, int64_t cloud_stride
   return out;
 }
 // PlaneNet (models.py:185-210): forward (+ the stash the backward reads when want_stash) and backward
+Tensor planenet_prepare(const Tensor& params, int64_t dim, int64_t heads, int64_t layers, int64_t ffn, int64_t precision) {
+  GUARD(params);
+  Tensor w = bytes(params, so3x_planenet_weights_bytes((int)dim, (int)heads, (int)layers, (int)ffn, (int)precision));
+  ok(so3x_planenet_prepare(strm(params), F(dev(params, "params")), (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision,
+                           w.numel() ? w.mutable_data_ptr() : nullptr, w.numel()),
+     "planenet_prepare");
+  return w;
+}
 std::tuple<Tensor, Tensor, Tensor> planenet_fwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t dim, int64_t heads, int64_t layers,
-                                                int64_t ffn, int64_t precision, bool want_stash, bool want_encoding) {
+                                                int64_t ffn, int64_t precision, bool want_stash, bool want_encoding, const optional<Tensor>& prepared) {
   GUARD(x);
   TORCH_CHECK(x.dim() == 3 && x.size(2) == 3, "so3x: x must be [B, P, 3]");
   const int64_t B = x.size(0), P = x.size(1);
@@ -434,7 +442,7 @@ std::tuple<Tensor, Tensor, Tensor> planenet_fwd(const Tensor& params, const Tens
   Tensor ws = bytes(x, wsb), stash = bytes(x, stb);
   ok(so3x_planenet_fwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), Fm(out), want_encoding && B ? Fm(enc) : nullptr,
                        B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision, want_stash && B ? stash.mutable_data_ptr() : nullptr,
-                       ws.mutable_data_ptr(), ws.numel()),
+                       ws.mutable_data_ptr(), ws.numel(), (prepared.has_value() && prepared->numel()) ? dev(*prepared, "prepared", at::kByte).const_data_ptr() : nullptr),
      "planenet_fwd");
   return {out, stash, enc};
 }
@@ -681,7 +689,8 @@ TORCH_LIBRARY(so3x, m) {
         "float beta2, float eps, float weight_decay, float grad_scale) -> ()");
   m.def("rotate_cloud(Tensor rot, Tensor cloud, int cloud_stride, int P) -> Tensor");
   m.def("resnet_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> Tensor");
-  m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding) -> (Tensor, Tensor, Tensor)");
+  m.def("planenet_prepare(Tensor params, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
+  m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding, Tensor? prepared) -> (Tensor, Tensor, Tensor)");
   m.def("planenet_bwd(Tensor params, Tensor x, Tensor t, Tensor dout, Tensor stash, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
   m.def("resnet_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> (Tensor, Tensor)");
   m.def("resnet_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int n_out, int precision, int t_table, Tensor? stash) -> Tensor");
@@ -746,6 +755,7 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("adam_step", adam_step);
   m.impl("rotate_cloud", rotate_cloud);
   m.impl("resnet_fwd", resnet_fwd);
+  m.impl("planenet_prepare", planenet_prepare);
   m.impl("planenet_fwd", planenet_fwd);
   m.impl("planenet_bwd", planenet_bwd);
   m.impl("resnet_fwd_stash", resnet_fwd_stash);

@@ -47,7 +47,7 @@ SYMBOLS = (
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
     "so3x_p_sample_prepare", "so3x_p_sample_prepared",
-    "so3x_planenet_param_count", "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes", "so3x_planenet_fwd", "so3x_planenet_bwd",
+    "so3x_planenet_weights_bytes", "so3x_planenet_prepare", "so3x_planenet_param_count", "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes", "so3x_planenet_fwd", "so3x_planenet_bwd",
     "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam", "so3x_train_fused",
 )
 
@@ -88,6 +88,7 @@ def lib():
                 l.so3x_train_workspace_bytes.restype = C.c_size_t
                 l.so3x_planenet_workspace_bytes.restype = C.c_size_t
                 l.so3x_planenet_stash_bytes.restype = C.c_size_t
+                l.so3x_planenet_weights_bytes.restype = C.c_size_t
                 l.so3x_planenet_param_count.restype = C.c_int64
                 if l.so3x_abi_version() != 7:
                     raise So3xError("so3x: ABI version mismatch")
@@ -679,10 +680,17 @@ def _planenet_in(params, x, t):
     return params, x, tt
 
 
-def planenet_fwd(params, x, t, dim, heads, layers, ffn=2048, precision=PREC_F32, want_stash=False, want_encoding=False):
+def planenet_prepare(params, dim, heads, layers, ffn=2048, precision=PREC_F32):
+    """the bf16 image of PlaneNet's weight matrices for planenet_fwd(prepared=...) (an empty tensor for the exact-fp32 form); valid
+    until the parameters change"""
+    return _call(ops().planenet_prepare, _dev(params, "params").reshape(-1), int(dim), int(heads), int(layers), int(ffn), int(precision))
+
+
+def planenet_fwd(params, x, t, dim, heads, layers, ffn=2048, precision=PREC_F32, want_stash=False, want_encoding=False, prepared=None):
     """PlaneNet forward: (out [B, 3], stash for planenet_bwd or an empty tensor, encoder output [B, P, dim] or empty)"""
     params, x, tt = _planenet_in(params, x, t)
-    return _call(ops().planenet_fwd, params, x, tt, int(dim), int(heads), int(layers), int(ffn), int(precision), bool(want_stash), bool(want_encoding))
+    return _call(ops().planenet_fwd, params, x, tt, int(dim), int(heads), int(layers), int(ffn), int(precision), bool(want_stash), bool(want_encoding),
+                 prepared)
 
 
 def planenet_bwd(params, x, t, dout, stash, dim, heads, layers, ffn=2048, precision=PREC_F32):

@@ -151,6 +151,7 @@ class PlaneNet(FlatParamsMixin, nn.Module):
         self.out_net = nn.Sequential(PoolRN(dim), nn.Linear(dim, 3))
         self.dim, self.heads, self.layers, self.precision, self.dropout = dim, heads, layers, precision, dropout
         self.ffn = self.encoder.layers[0].linear1.out_features
+        self._prep = None   # (key, bf16 weight image): inference reuses it while the parameters do not change
         self._init_flat()
 
     def _flat_root(self):
@@ -161,17 +162,28 @@ class PlaneNet(FlatParamsMixin, nn.Module):
         from . import backend as _b
         return (self.dim, self.heads, self.layers, self.ffn, _b.PREC_BF16 if self.precision == "bf16" else _b.PREC_F32)
 
+    def _prepared(self):
+        """the bf16 image of the weight matrices for the current parameters (so3x_planenet_prepare), rebuilt when any parameter's
+        tensor version, the out-of-band update epoch or the buffer changes (as SO3Diffusion's prepared sampling state)"""
+        from . import backend as _b
+        from .flat import PARAM_EPOCH
+        flat = self.flat_params_nograd()
+        key = (flat.data_ptr(), tuple(p._version for p in self._flat_params), PARAM_EPOCH[0], self.precision, flat.device)
+        if self._prep is None or self._prep[0] != key:
+            self._prep = (key, _b.planenet_prepare(flat, *self.cfg))
+        return self._prep[1]
+
     def forward(self, x, t, want_encoding=False):
         from . import backend as _b
         if self.training and self.dropout > 0:
             raise NotImplementedError("so3x: the PlaneNet kernels implement nn.TransformerEncoderLayer without dropout; build the network "
                                       "with dropout=0 (or call .eval()) -- a silent fallback to torch's modules is not offered")
         if want_encoding:
-            out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_encoding=True)
+            out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_encoding=True, prepared=self._prepared())
             return out, enc
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _PlaneNetFn.apply(x, t, self.flat_params(), self.cfg)
-        return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg)[0]
+        return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, prepared=self._prepared())[0]
 
     def forward_torch(self, x, t):
         """the same network through torch's own modules (any device): test infrastructure"""

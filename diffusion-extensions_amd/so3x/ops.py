@@ -238,8 +238,13 @@ def _(rot, cloud, cloud_stride, P):
     return _f32(rot, rot.shape[:-2] + (P, 3))
 
 
+@register_fake("so3x::planenet_prepare")
+def _(params, dim, heads, layers, ffn, precision):
+    return params.new_empty((2 * params.numel() + 256 if precision == 1 else 0,), dtype=torch.uint8)
+
+
 @register_fake("so3x::planenet_fwd")
-def _(params, x, t, dim, heads, layers, ffn, precision, want_stash, want_encoding):
+def _(params, x, t, dim, heads, layers, ffn, precision, want_stash, want_encoding, prepared):
     B, P = x.shape[0], x.shape[1]
     # an upper bound is all a fake needs: per token and layer 7 dim + ffn + heads * P floats
     stash = (B * P * layers * (8 * dim + ffn + heads * P) * 4 + (1 << 20)) if want_stash else 0

@@ -315,12 +315,20 @@ int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int
  * so3x_planenet_bwd: dparams[param_count] (overwritten) = d sum(out * dout) / d params for dout [B][3], from the stash the
  *   forward wrote for the SAME params, x, t.  (The inputs carry no gradient: x is a projection of the noised pose,
  *   diffusion.py:389-392.)  Deterministic: fixed-order reductions, no atomics.
- * workspace: so3x_planenet_workspace_bytes covers either call. */
+ * workspace: so3x_planenet_workspace_bytes covers either call.
+ * prepared_weights (optional, so3x_planenet_fwd): the bf16 form converts the weight matrices to a bf16 image on every call (25 MB,
+ *   ~15 us); a caller whose parameters did not change since (sampling: hundreds of calls per set of weights) builds the image once
+ *   with so3x_planenet_prepare (so3x_planenet_weights_bytes; 0 bytes / a no-op for the exact-fp32 form) and passes it here.
+ *   NULL = convert inside the call. */
 int64_t so3x_planenet_param_count(int dim, int heads, int layers, int ffn);
 size_t so3x_planenet_workspace_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
 size_t so3x_planenet_stash_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
+size_t so3x_planenet_weights_bytes(int dim, int heads, int layers, int ffn, int precision);
+int so3x_planenet_prepare(so3x_stream_t s, const float* params, int dim, int heads, int layers, int ffn, int precision, void* weights,
+                          size_t weights_bytes);
 int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, float* out, float* encoding_out, int64_t B,
-                      int64_t P, int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes);
+                      int64_t P, int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes,
+                      const void* prepared_weights);
 int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, const float* dout, float* dparams, int64_t B,
                       int64_t P, int dim, int heads, int layers, int ffn, int precision, const void* stash, void* workspace,
                       size_t workspace_bytes);

@@ -31,7 +31,8 @@ if trace:
                "n_100_step_launches": len(short)}, open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
 
 KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_se3_q_sample_target",
-           "k_q_sample_target", "k_rigid_move", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_reduce", "k_adam", "k_prep")
+           "k_q_sample_target", "k_rigid_move", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_reduce", "k_adam", "k_prep",
+           "k_gemm256_bf16", "k_gemm_bf16", "k_gemm_tn", "k_attn_fwd", "k_attn_bwd_dq", "k_attn_bwd_dkv", "k_ln_bf16", "k_ln_bwd_bf16")
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
 legs = {}  # counter -> the k_logprob_score dispatches at 2^20 evaluations in dispatch order, split into bench.py's three legs
 for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
@@ -123,7 +124,8 @@ for k, cfg, alg in (("k_train_fused", {"n": 1 << 19}, 36 * (1 << 19) + 256 * 175
 # executing (= MFMAs x 32 for v_mfma_f32_32x32x16_bf16, checked against SQ_INSTS_VALU_MFMA_MOPS_BF16); SQ_BUSY_CYCLES is
 # the kernel's duration in shader cycles counted once per shader engine (32 on this chip: 8 XCDs x 4).
 util = {}
-for k in ("k_p_sample_chain", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_q_sample_target"):
+for k in ("k_p_sample_chain", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_q_sample_target",
+          "k_gemm256_bf16", "k_gemm_bf16", "k_attn_fwd", "k_gemm_tn", "k_attn_bwd_dq", "k_attn_bwd_dkv"):
     busy, sqb = mean("SQ_VALU_MFMA_BUSY_CYCLES", k), mean("SQ_BUSY_CYCLES", k)
     if busy and sqb:
         util[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sqb, "simds": 1024, "shader_engines": 32,
