@@ -454,6 +454,40 @@ class TrainBuffers:
         if want_out:
             self.out = torch.empty((self.n, 3), **f32)
 
+    # The eager training loop's buffers (one so3x_train_fused evaluation each): the workspace -- slabs, tickets, weight images,
+    # a few MB -- is taken from a free list and handed back by the backward pass; the loss (returned to the caller) and the flat
+    # gradient (it becomes the parameters' .grad) are fresh tensors every time.
+    _free, _ws_bytes = {}, {}
+
+    @classmethod
+    def acquire(cls, n, T, device):
+        key = (int(n), int(T), device)
+        self = cls.__new__(cls)
+        self.n, self.T, self.device, self._key = key[0], key[1], device, key
+        self.loss = torch.empty((1,), dtype=torch.float32, device=device)
+        self.grad = None
+        free = cls._free.get(key)
+        if torch.cuda.is_current_stream_capturing():
+            free, self._key = None, None   # a captured step owns its workspace (graph-pool memory never enters the free list)
+        if free:
+            self.workspace = free.pop()
+        else:
+            nb = cls._ws_bytes.get(key[:2])
+            if nb is None:
+                nb = cls._ws_bytes[key[:2]] = int(lib().so3x_train_workspace_bytes(C.c_int64(self.n), C.c_int(self.T)))
+            self.workspace = torch.empty((nb,), dtype=torch.uint8, device=device)
+        self.x_t = self.t_used = self.dout = self.zstash = self.out = None
+        return self
+
+    @classmethod
+    def release(cls, buf):
+        key = getattr(buf, "_key", None)
+        if key is not None and buf.workspace is not None and not torch.cuda.is_current_stream_capturing():
+            free = cls._free.setdefault(key, [])
+            if len(free) < 4:
+                free.append(buf.workspace)
+            buf.workspace = None
+
 
 def train_noise(buf, sched, trap_q, x0, t=None, quirk_col0=True, axes=None, unif=None, seed=0, rng_offset=0, rng_counter=None,
                 index_base=0, guide_q=None):
@@ -506,6 +540,8 @@ def train_bwd_partial(buf):
 def train_bwd_reduce(buf, gscale=None, grad=None):
     """stage 4: fixed-order sum of the slabs (x gscale) -> the flat gradient (buf.grad unless another tensor is given)"""
     g = buf.grad if grad is None else grad
+    if g is None:
+        g = buf.grad = torch.empty((N_PARAMS,), dtype=torch.float32, device=buf.device)
     _call(ops().train_bwd_reduce, buf.n, buf.T, _dev(gscale, "grad_output").reshape(1) if gscale is not None else None, g, buf.workspace)
     return g
 

@@ -55,40 +55,116 @@ def noise_like(shape, device, repeat=False):
     return torch.randn(shape, device=device)
 
 
+class _FusedStep:
+    """One evaluation of the one-kernel training step: the buffers its backward half (the slab reduction) still has to read."""
+    __slots__ = ("buf", "net", "staged", "carry", "T", "n_params")
+
+    def direct_ok(self):
+        """`loss.backward()` may skip the autograd engine: nothing is accumulated, frozen or hooked, so the engine would do exactly
+        one thing -- call the slab reduction and hang its result on the parameters"""
+        if self.buf is None or torch.is_anomaly_enabled():
+            return False
+        for p in self.net._flat_params:
+            if p.grad is not None or not p.requires_grad or p._backward_hooks or p._post_accumulate_grad_hooks:
+                return False
+        return True
+
+    def run_direct(self):
+        net, buf = self.net, self.buf
+        self.buf = None
+        g, views = net._persistent_grad()
+        _b.train_bwd_reduce(buf, gscale=None, grad=g)
+        for p, v in zip(net._flat_params, views):
+            p.grad = v
+        net._flat_grad = g
+        _b.TrainBuffers.release(buf)
+
+
+class _DirectBackward:
+    """`loss.backward` of the training fast path's loss (an instance attribute of that ONE tensor: anything derived from it --
+    `loss * 2`, a sum with another loss -- is an ordinary tensor and differentiates through the engine).  The reference loop's
+    own `loss.backward()` (so3_train.py:71: no arguments, gradients cleared) runs the one launch the engine would have run,
+    without the engine's hand-over to its device thread (~130 us of host time on a 170-us step); every other call goes to
+    torch.Tensor.backward."""
+    __slots__ = ("step", "loss")
+
+    def __init__(self, loss, step):
+        # A strong reference (`proc(x).backward()`: the temporary must outlive the attribute fetch), hence a cycle through the
+        # tensor's __dict__ -- which the first call breaks; a loss nobody differentiates is left to the cycle collector.
+        self.step, self.loss = step, loss
+
+    def __call__(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        st, loss = self.step, self.loss
+        loss.__dict__.pop("backward", None)
+        if gradient is None and not retain_graph and not create_graph and inputs is None and st.direct_ok():
+            st.run_direct()
+            return None
+        return torch.Tensor.backward(loss, gradient, retain_graph, create_graph, inputs)
+
+
 class _FusedSkewvecLoss(torch.autograd.Function):
     """p_losses of loss_type="skewvec" for the 65-wide RotPredict with bf16 operands (reference diffusion.py:348-357).
     forward = so3x_train_fused: noise draw, q_sample, target, network forward, MSE AND the whole backward down to per-workgroup
     dW partial slabs in ONE kernel (nothing in the math needs the loss before the backward: d loss / d out is per sample);
     backward = so3x_train_bwd_reduce: the fixed-order sum of the slabs times the upstream gradient -> the FLAT parameter
-    gradient.  Only the parameters carry gradients.  `proc.train_step_kernel = "staged"` selects round 3's
-    form instead (so3x_train_fwd / so3x_train_bwd: three kernels with the pre-activations parked in HBM)."""
+    gradient, handed to the nn.Linear parameters as views (no copy; so3x.flat).  Only the parameters carry gradients
+    (SURVEY.md 3.1).  `proc.train_step_kernel = "staged"` selects round 3's form instead (so3x_train_fwd / so3x_train_bwd: three
+    kernels with the pre-activations parked in HBM)."""
 
     @staticmethod
-    def forward(ctx, flat, proc, x_start, t, axes, unif):
+    def forward(ctx, net, proc, x_start, t, axes, unif, *params):
+        flat = net._flat
         trap_q, _ = proc._tables()
         dev_rng = proc.rng_counter is not None and (axes is None or t is None)
         kw = dict(quirk_col0=proc.quirk_col0, axes=axes, unif=unif, seed=_rng.seed(),
                   rng_offset=0 if (dev_rng or (axes is not None and t is not None)) else _rng.next_offset(),
                   rng_counter=proc.rng_counter if dev_rng else None, index_base=proc.index_base, guide_q=proc._guide_q)
-        ctx.T, ctx.n_params = proc.num_timesteps, flat.numel()
-        if proc.train_step_kernel == "staged":
-            loss, ctx.carry, _ = _b.train_fwd(flat, proc._sched, trap_q, x_start, t, **kw)
-            ctx.buf = None
+        st = ctx.step = _FusedStep()
+        st.net, st.T, st.n_params, st.carry, st.buf = net, proc.num_timesteps, flat.numel(), None, None
+        st.staged = proc.train_step_kernel == "staged"
+        if st.staged:
+            loss, st.carry, _ = _b.train_fwd(flat, proc._sched, trap_q, x_start, t, **kw)
             return loss
-        buf = _b.TrainBuffers(x_start.numel() // 9, proc.num_timesteps, x_start.device, staged=False)
+        buf = _b.TrainBuffers.acquire(x_start.numel() // 9, proc.num_timesteps, x_start.device)
         _b.train_fused(buf, flat, proc._sched, trap_q, x_start, t, **kw)
-        ctx.buf = buf
+        st.buf = buf
         return buf.loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.buf is None:
-            grad = _b.train_bwd(ctx.carry, ctx.n_params, ctx.T, gscale=g)
-            ctx.carry = None
+        st = ctx.step
+        if st.staged:
+            if st.carry is None:
+                raise RuntimeError("so3x: this training step's buffers were already consumed by a backward pass")
+            grad = _b.train_bwd(st.carry, st.n_params, st.T, gscale=g)
+            st.carry = None
         else:
-            grad = _b.train_bwd_reduce(ctx.buf, gscale=g)
-            ctx.buf = None
-        return grad, None, None, None, None, None
+            if st.buf is None:
+                raise RuntimeError("so3x: this training step's buffers were already consumed by a backward pass")
+            grad = _b.train_bwd_reduce(st.buf, gscale=g)
+            _b.TrainBuffers.release(st.buf)
+            st.buf = None
+        net = st.net
+        params = net._flat_params
+        if all(p.grad is None and not p._backward_hooks and not p._post_accumulate_grad_hooks for p in params if p.requires_grad):
+            # the usual loop (nothing to accumulate into, no tensor hooks to feed): the flat gradient becomes the .grad views
+            net._install_flat_grad(grad)
+            return (None,) * (6 + len(params))
+        off, out = 0, []
+        for p in params:
+            out.append(grad[off:off + p.numel()].view_as(p) if p.requires_grad else None)
+            off += p.numel()
+        return (None,) * 6 + tuple(out)
+
+
+def _fused_loss(net, proc, x_start, t, axes, unif):
+    net._ensure_flat()
+    loss = _FusedSkewvecLoss.apply(net, proc, x_start, t, axes, unif, *net._flat_params)
+    step = loss.grad_fn.step if loss.grad_fn is not None else None
+    if step is None or step.staged:
+        return loss
+    loss.backward = _DirectBackward(loss, step)
+    return loss
 
 
 class SO3Diffusion(nn.Module):
@@ -284,7 +360,7 @@ class SO3Diffusion(nn.Module):
         trap_q, _ = self._tables()
         net = self._fused_net()
         if x_start.numel() > 0 and self._lean(noise):
-            return _FusedSkewvecLoss.apply(net.flat_params(), self, x_start, t, axes, unif)  # the training step's fast path
+            return _fused_loss(net, self, x_start, t, axes, unif)  # the training step's fast path
         dev_rng = self.rng_counter is not None and noise is None and axes is None
         prevstep = self.loss_type == "prevstep"
         x_noisy, target, _ = _b.q_sample_target(self._sched, trap_q, x_start, t, quirk_col0=self.quirk_col0, noise=noise,
@@ -312,7 +388,7 @@ class SO3Diffusion(nn.Module):
         net = self._fused_net()
         return (self.loss_type == "skewvec" and noise is None and type(self) is SO3Diffusion and isinstance(net, RotPredict)
                 and net.out_type == "skewvec" and net.precision == "bf16" and torch.is_grad_enabled()
-                and any(p.requires_grad for p in net.net.parameters()))
+                and any(p.requires_grad for p in (net._flat_params or net.net.parameters())))
 
     def forward(self, x, *args, **kwargs):
         """loss for a batch of rotations at random timesteps (reference diffusion.py:371-374).  On the training fast path
@@ -321,7 +397,7 @@ class SO3Diffusion(nn.Module):
         replayed hipGraph what the eager loop draws; set `draw_t_in_kernel = False` for torch.randint."""
         b = x.shape[0]
         if self.draw_t_in_kernel and b > 0 and not args and self._lean(kwargs.get("noise")) and set(kwargs) <= {"axes", "unif", "noise"}:
-            return _FusedSkewvecLoss.apply(self.denoise_fn.flat_params(), self, x, None, kwargs.get("axes"), kwargs.get("unif"))
+            return _fused_loss(self.denoise_fn, self, x, None, kwargs.get("axes"), kwargs.get("unif"))
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
         return self.p_losses(x, t, *args, **kwargs)
 

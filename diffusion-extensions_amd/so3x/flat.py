@@ -98,7 +98,7 @@ class FlatParamsMixin:
                 flat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = flat[off:off + n].view(p.shape)
                 off += n
-        self._flat, self._flat_params, self._flat_grad = flat, params, None
+        self._flat, self._flat_params, self._flat_grad, self._grad_cache = flat, params, None, None
         self._flat_owners = [(m, k, q) for m in self._flat_root().modules() for k, q in m._parameters.items() if q is not None]
         self._flat_seen = -1       # the registration count at which the cached list was last compared with the module tree
 
@@ -164,6 +164,21 @@ class FlatParamsMixin:
                 p.grad = dflat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         self._flat_grad = dflat
+
+    def _persistent_grad(self):
+        """(flat gradient buffer, its per-parameter views) for the training fast path's direct backward: allocated once per flat
+        buffer and rewritten by every such backward, like the gradients of a loop that runs zero_grad(set_to_none=False) -- ten
+        view constructions (~25 us of host time) less per step, and addresses a captured graph can rely on"""
+        c = getattr(self, "_grad_cache", None)
+        f = self._flat
+        if c is None or c[0] is not f or c[1].device != f.device:
+            g = torch.empty_like(f)
+            views, off = [], 0
+            for p in self._flat_params:
+                views.append(g[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            c = self._grad_cache = (f, g, views)
+        return c[1], c[2]
 
     def flat_grad(self):
         """the flat gradient if every parameter's .grad currently is a view of one flat tensor, else None"""

@@ -5,11 +5,16 @@ so3_train.py:64, so3_lock_train.py:70) -- as ONE launch on the score network's f
 Same hyper-parameters, defaults and update rule as torch.optim.Adam (amsgrad and maximize are not provided); pinned
 against torch's own results in tests/golden/adam.npz."""
 import torch
+import torch.optim.optimizer as _torch_optimizer
 
 from . import backend as _b
 from .flat import FlatParamsMixin
 
 __all__ = ["Adam"]
+
+
+def _global_step_hooks():
+    return getattr(_torch_optimizer, "_global_optimizer_pre_hooks", None) or getattr(_torch_optimizer, "_global_optimizer_post_hooks", None)
 
 
 class Adam(torch.optim.Optimizer):
@@ -51,21 +56,49 @@ class Adam(torch.optim.Optimizer):
     def step_count(self) -> int:
         return 0 if self._step is None else int(self._step[0].item())
 
-    @torch.no_grad()
     def step(self, closure=None):
+        """torch.optim.Adam.step().  Not wrapped by torch.optim.Optimizer's profiling hook (see `hooked` below): step pre/post
+        hooks registered on this optimizer (or globally) are honoured by taking torch's wrapper whenever any exists -- the common
+        case of none costs nothing (the wrapper and its record_function are ~25 us of a host-bound step)."""
+        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_step_hooks():
+            return self._hooked_step(closure)
+        return self._step_impl(closure)
+
+    step.hooked = True   # torch.optim.Optimizer._patch_step_function: leave this class's step as it is
+
+    def _hooked_step(self, closure=None):
+        fn = type(self).__dict__.get("_wrapped_step")
+        if fn is None:
+            fn = type(self)._wrapped_step = torch.optim.Optimizer.profile_hook_step(type(self)._step_impl)
+        return fn(self, closure)
+
+    def _step_impl(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        flat = self.net.flat_data()
-        grad = self.net.gather_flat_grad()
-        m, v, step = self._state(flat)
-        g = self.param_groups[0]
-        frozen = [(a, b, flat[a:b].clone(), m[a:b].clone(), v[a:b].clone()) for a, b in self._frozen_slices()]
-        _b.adam_step(flat, grad, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
-        for a, b, pf, pm, pv in frozen:
-            flat[a:b].copy_(pf); m[a:b].copy_(pm); v[a:b].copy_(pv)
+        with torch.no_grad():
+            flat = self.net.flat_data()
+            grad = self.net.gather_flat_grad()
+            m, v, step = self._state(flat)
+            g = self.param_groups[0]
+            frozen = [(a, b, flat[a:b].clone(), m[a:b].clone(), v[a:b].clone()) for a, b in self._frozen_slices()]
+            _b.adam_step(flat, grad, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
+            for a, b, pf, pm, pv in frozen:
+                flat[a:b].copy_(pf); m[a:b].copy_(pm); v[a:b].copy_(pv)
         return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        """torch.optim.Optimizer.zero_grad for the flat layout: with set_to_none (torch's default) ten attribute stores"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for p in self.net._flat_params:
+            p.grad = None
+        self.net._flat_grad = None
+        for group in self.param_groups:       # parameters handed in some other way (none in the reference's loops)
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.grad = None
 
     @torch.no_grad()
     def step_with_reduction(self, buf):

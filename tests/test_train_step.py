@@ -712,3 +712,55 @@ def test_one_step_per_call_loop_equals_the_chain_and_never_goes_stale(mods):
     top = B.p_sample_prepared(ws, proc._sched, trap_p, x0, 0, 1, t_dev=torch.full((1,), T - 1, device=DEV, dtype=torch.long), seed=1,
                               precision=net.precision_code, guide_p=proc._guide_p)
     assert torch.equal(hi, top)
+
+
+def test_direct_backward_is_the_engines_backward(mods):
+    """The reference loop's `loss.backward()` (so3_train.py:71) skips the autograd engine on the fast path; everything the engine
+    would have done still holds: the same gradient bit for bit, a second backward refused, derived losses and accumulation
+    through the engine, tensor hooks and optimizer step hooks honoured."""
+    B, rng = mods["B"], mods["rng"]
+    torch.manual_seed(3)
+    net = mods["train"].RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    proc = mods["diff"].SO3Diffusion(net, timesteps=1000).to(DEV)
+    x0 = B.quat_to_rmat(torch.randn(4096, 4, device=DEV))
+
+    def grads(how):
+        rng.manual_seed(11)
+        net.zero_grad(set_to_none=True)
+        loss = proc(x0)
+        assert "backward" in loss.__dict__ and "FusedSkewvecLoss" in type(loss.grad_fn).__name__
+        how(loss)
+        return float(loss), net.gather_flat_grad().clone()
+
+    l_direct, g_direct = grads(lambda l: l.backward())
+    l_engine, g_engine = grads(lambda l: l.backward(torch.ones((), device=DEV)))
+    assert l_direct == l_engine and torch.equal(g_direct, g_engine)
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
+    _, g_twice = grads(lambda l: (l * 2).backward())                 # a derived loss is a plain tensor: the engine's path
+    assert torch.equal(g_twice, 2 * g_direct)
+
+    rng.manual_seed(11)
+    net.zero_grad(set_to_none=True)
+    loss = proc(x0)
+    loss.backward()
+    with pytest.raises(RuntimeError, match="already consumed"):
+        loss.backward()
+    rng.manual_seed(11)
+    proc(x0).backward()                                               # no zero_grad: accumulated (through the engine)
+    assert torch.allclose(net.gather_flat_grad(), 2 * g_direct, rtol=1e-6, atol=0)
+
+    seen = []
+    h = net.net[0].weight.register_hook(lambda g: seen.append(g.shape))
+    _, g_hooked = grads(lambda l: l.backward())
+    h.remove()
+    assert seen == [net.net[0].weight.shape] and torch.equal(g_hooked, g_direct)
+
+    opt = mods["optim"].Adam(net, lr=1e-3)
+    calls = []
+    h = opt.register_step_post_hook(lambda o, a, k: calls.append("post"))
+    before = net.flat_data().clone()
+    opt.step()
+    h.remove()
+    assert calls == ["post"] and not torch.equal(before, net.flat_data())
+    opt.zero_grad()
+    assert all(p.grad is None for p in net.parameters()) and net.flat_grad() is None
