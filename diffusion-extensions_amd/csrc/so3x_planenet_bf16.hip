@@ -15,6 +15,8 @@
 //                    operands by ds_read_b64_tr_b16.  Scores never touch HBM.  MFMA / VALU(exp) bound.
 //   k_ln_bf16        LayerNorm rows (HBM-bound: 2 B in + 2 B out per element).
 //   k_embed_bf16, k_pool_* : the SIREN / time embedding and PoolRN's weighted mean (HBM-bound).
+#include <type_traits>
+
 #include "so3x_planenet_bf16.hpp"
 
 namespace so3x {
@@ -363,11 +365,20 @@ int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf1
 }
 
 // ------------------------------------------------------------------------------------------------ attention forward
+// LDS-DMA the compiler does not know about: 16 bytes per lane from `src` (per lane) to LDS `dst + 16 lane` (dst wave-uniform).  The
+// builtin form makes every LDS read whose address the compiler cannot bound -- the ds_read_b64_tr_b16 intrinsic's, i.e. all V^T
+// operands -- wait for `vmcnt(0)`: for the tile requested a few hundred cycles earlier.  Ordering is this file's own: one
+// `s_waitcnt vmcnt(0)` + barrier between a tile's DMA and its first read.
+__device__ __forceinline__ void glds16_asm(const void* src, const void* dst) {
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_cp)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(d) : "memory", "m0");
+}
 __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse, int P,
                                                      float sc, float c2) {
   __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (K tile 16 KB | V tile 16 KB)
   typedef __attribute__((address_space(3))) s16x4* lds_p;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
   const size_t tok0 = (size_t)b * P;
   // Q^T as the B operand of S^T = K Q^T: lane (r, h) holds Q[q0 + r][16 ks + 8 h .. + 8]
@@ -388,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
       const int rowblk = (wave * 4 + i) * 4, row = rowblk + (lane >> 4);
       const int ch = (lane & 15) ^ swz16(row);
       const size_t off = (size_t)(j * 64 + row) * (3 * D) + ch * 8;
-      GLDS16(kbase + off, sk + rowblk * 256);
-      GLDS16(vbase + off, sv + rowblk * 256);
+      glds16_asm(kbase + off, sk + rowblk * 256);
+      glds16_asm(vbase + off, sv + rowblk * 256);
     }
   };
   f32x16 ot[4];
@@ -406,11 +417,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
   const int vrow0 = (4 * h + q_) * 256, vsub = (p_ & 1) * 8, vclo = 2 * (g & 1) + (p_ >> 1);
   const int nt = P / 64;
   stage(0, 0);
-  for (int j = 0; j < nt; j++) {
+  // One tile; BUF is a compile-time constant (the loop below is unrolled by two): the compiler then sees that the tile it reads and
+  // the tile the LDS-DMA of stage(j + 1) writes are disjoint ranges of smem, and does not put a `vmcnt(0)` -- a wait for the DMA
+  // it has just issued -- in front of the V reads
+  auto tile = [&](int j, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (j + 1 < nt) stage(j + 1, (j + 1) & 1);
-    const char* sk = smem + (j & 1) * 32768;
+    if (j + 1 < nt) stage(j + 1, BUF ^ 1);
+    const char* sk = smem + BUF * 32768;
     const char* sv = sk + 16384;
     f32x16 st[2];
 #pragma unroll
@@ -423,6 +438,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
     }
+    // the K fragments six reads ahead of the MFMAs that take them (the scheduler's own order waits for every read in turn)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
     // online softmax: this lane holds 32 of its query's 64 scores, lane ^ 32 the other 32.  The running maximum is raised -- and
     // O^T and the running sum rescaled -- only when some query of the wave outgrew it by more than 2^RESCALE_LOG2 (bf16 and fp32
     // are floating point: probabilities up to 2^4 lose nothing); the branch is wave-uniform.
@@ -472,6 +495,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
       }
     }
     l_run += lt[0];
+  };
+  for (int j = 0; j < nt; j += 2) {
+    tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nt) tile(j + 1, std::integral_constant<int, 1>{});
   }
   const float l_tot = l_run;        // (the MFMA summed over all 64 keys of a tile: both lanes of a query hold the whole sum)
   const float inv = 1.f / l_tot;

@@ -22,6 +22,8 @@ ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--json")
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--batch-log2", type=int, default=20)
+ap.add_argument("--prepared", action="store_true", help="time so3x_p_sample_prepared (the one-call-per-step loop's launch) instead of the chain entry")
+ap.add_argument("--reps", type=int, default=1, help="launches per timed sample")
 ap.add_argument("variants", nargs="+")
 args = ap.parse_args()
 
@@ -66,6 +68,17 @@ def run(name, steps=None, t0=600, prec=1, xin=None):
     nb = lib.so3x_p_sample_workspace_bytes(C.c_int(1000), C.c_int(prec))
     ws = ws_cache.setdefault((path, prec), torch.zeros(nb, dtype=torch.uint8, device=dev))
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    if args.prepared:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if (path, prec, "prepared") not in ws_cache:
+            rc = lib.so3x_p_sample_prepare(st, P(params), C.c_int(1000), P(trap_p), P(proc._guide_p), C.c_int(prec), P(ws), C.c_size_t(nb))
+            assert rc == 0, (name, rc)
+            ws_cache[(path, prec, "prepared")] = True
+        rc = lib.so3x_p_sample_prepared(st, P(proc._sched), C.c_int(1000), P(trap_p), P(proc._guide_p), P(xi), P(out), C.c_int(t0), None,
+                                        C.c_int(args.steps if steps is None else steps), None, None, C.c_uint64(1), C.c_uint64(0), C.c_int64(0),
+                                        C.c_int64(xi.numel() // 9), C.c_int(prec), P(ws), C.c_size_t(nb))
+        assert rc == 0, (name, rc)
+        return out
     rc = lib.so3x_p_sample_chain(C.c_void_p(torch.cuda.current_stream().cuda_stream), P(params), P(proc._sched), C.c_int(1000), P(trap_p),
                                  P(proc._guide_p), P(xi), P(out), C.c_int(t0), C.c_int(args.steps if steps is None else steps), None, None,
                                  C.c_uint64(1), C.c_uint64(0), C.c_int64(0), C.c_int64(xi.numel() // 9), C.c_int(prec), P(ws), C.c_size_t(nb))
@@ -91,8 +104,11 @@ times, clocks = {k: [] for k in variants}, {k: [] for k in variants}
 for r in range(args.rounds):
     for name in variants:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); run(name); e1.record(); torch.cuda.synchronize()
-        times[name].append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(args.reps):
+            run(name)
+        e1.record(); torch.cuda.synchronize()
+        times[name].append(e0.elapsed_time(e1) / args.reps)
         clocks[name].append(clock_ghz(name))
 first = next(iter(variants))
 base20 = run(first, 20)
