@@ -365,15 +365,6 @@ int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf1
 }
 
 // ------------------------------------------------------------------------------------------------ attention forward
-// LDS-DMA the compiler does not know about: 16 bytes per lane from `src` (per lane) to LDS `dst + 16 lane` (dst wave-uniform).  The
-// builtin form makes every LDS read whose address the compiler cannot bound -- the ds_read_b64_tr_b16 intrinsic's, i.e. all V^T
-// operands -- wait for `vmcnt(0)`: for the tile requested a few hundred cycles earlier.  Ordering is this file's own: one
-// `s_waitcnt vmcnt(0)` + barrier between a tile's DMA and its first read.
-__device__ __forceinline__ void glds16_asm(const void* src, const void* dst) {
-  typedef __attribute__((address_space(3))) const char* lds_cp;
-  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_cp)dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(d) : "memory", "m0");
-}
 __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse, int P,
                                                      float sc, float c2) {
   __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (K tile 16 KB | V tile 16 KB)

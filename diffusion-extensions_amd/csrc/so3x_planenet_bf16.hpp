@@ -18,6 +18,22 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                            \
                                    (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
 
+// LDS-DMA the compiler does not know about: 16 (or 4) bytes per lane from `src` (per lane) to LDS `dst + 16 (4) lane` (dst
+// wave-uniform).  The builtin form makes every LDS read whose address the compiler cannot bound -- the ds_read_b64_tr_b16
+// intrinsic's, i.e. every transposed operand -- wait for `vmcnt(0)`: for the tile requested a few hundred cycles earlier, which
+// takes the prefetch out of a double-buffered loop.  Ordering is the kernel's own: one `s_waitcnt vmcnt(0)` + barrier between a
+// tile's DMA and its first read.
+__device__ __forceinline__ void glds16_asm(const void* src, const void* dst) {
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_cp)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(d) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4_asm(const void* src, const void* dst) {
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_cp)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(d) : "memory", "m0");
+}
+
 constexpr int D = 512, HEADS = 4, DH = 128, FF = 2048, D2 = 256;
 
 // LDS image of a [64 keys][128] bf16 tile: 256-byte rows, the row's 16-byte chunk c at position c ^ swz16(row) -- conflict-free for

@@ -38,8 +38,11 @@ static int cvt_t(hipStream_t s, const float* src, bf16* dst, int R, int C) {
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X
 // slab[split][n][k] = sum over the split's tokens of Y[tok][n0 + n] X[tok][k0 + k];  Nn % 128 == Kk % 128 == 0, tokens % 64 == 0
+// bpart (optional): the column sums of Y (the bias gradient of the same layer) ride along -- a ones vector as a fifth B operand
+// gives sum_tok Y[tok][n] in every column of a 16 x 16 accumulator; the k-tile index tk picks which 16-row block of its n range a
+// workgroup sums (every workgroup of a row of tiles reads the same Y tile), so the extra MFMA (1 per 16) is spread evenly.
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ Y, const bf16* __restrict__ X, float* __restrict__ slab, int T,
-                                                    int Nn, int Kk, int ldy, int ldx, int tok_per_split) {
+                                                    int Nn, int Kk, int ldy, int ldx, int tok_per_split, float* __restrict__ bpart) {
   __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (Y tile [64 tok][128] 16 KB | X tile 16 KB), swz16 images
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wk = wave & 1;
   const int nkt = Kk / 128, tn = blockIdx.x / nkt, tk = blockIdx.x % nkt, split = blockIdx.y;
@@ -54,8 +57,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ Y, 
     for (int i = 0; i < 4; i++) {
       const int rowblk = (wave * 4 + i) * 4, row = rowblk + (lane >> 4);
       const int ch = (lane & 15) ^ swz16(row);
-      GLDS16(Yg + (size_t)(j * 64 + row) * ldy + ch * 8, sy + rowblk * 256);
-      GLDS16(Xg + (size_t)(j * 64 + row) * ldx + ch * 8, sx + rowblk * 256);
+      glds16_asm(Yg + (size_t)(j * 64 + row) * ldy + ch * 8, sy + rowblk * 256);
+      glds16_asm(Xg + (size_t)(j * 64 + row) * ldx + ch * 8, sx + rowblk * 256);
     }
   };
   f32x4 acc[4][4];
@@ -63,6 +66,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ Y, 
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+  const int nke = nkt < 4 ? nkt : 4;
+  const bool sums = bpart != nullptr && wk == 0 && tk < nke;   // this wave sums the blocks i with i % nke == tk
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
   // transposed-read lane constants: the 16-lane group g reads tokens 8 g + (0..3) [+4] of a k-step, lane 4 q + p of the group
   // supplies row q, columns 4 p .. 4 p + 3 of the 16-column block
   const int g = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
@@ -95,7 +102,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ Y, 
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+      if (sums) {
+        if (nke == 4) {   // one block per workgroup: a[tk]
+          const bf16x8 at = tk == 0 ? a[0] : (tk == 1 ? a[1] : (tk == 2 ? a[2] : a[3]));
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, ones, accb, 0, 0, 0);
+        }
+      }
     }
+  }
+  if (sums && nke == 4 && (lane & 15) == 0) {
+    float* bo = bpart + (size_t)split * Nn + tn * 128 + wn * 64 + tk * 16 + g * 4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) bo[e] = accb[e];
   }
   float* out = slab + (size_t)split * Nn * Kk;
 #pragma unroll
@@ -106,9 +124,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ Y, 
       for (int e = 0; e < 4; e++)
         out[(size_t)(tn * 128 + wn * 64 + i * 16 + g * 4 + e) * Kk + tk * 128 + wk * 64 + jj * 16 + (lane & 15)] = acc[i][jj][e];
 }
-__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, int nsplit, int64_t n4, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
+__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, int nsplit, int64_t n4, float* __restrict__ out,
+                                                     const float* __restrict__ bpart, int nb4, float* __restrict__ bout) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) {   // the bias partials behind the matrix: the same fixed order over the splits
+    i -= n4;
+    if (i >= nb4) return;
+    float4 a = reinterpret_cast<const float4*>(bpart)[i];
+    for (int s = 1; s < nsplit; s++) {
+      const float4 v = reinterpret_cast<const float4*>(bpart + (size_t)s * nb4 * 4)[i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(bout)[i] = a;   // (parameter offsets are multiples of 4 floats: every matrix has a multiple of 4 rows)
+    return;
+  }
   float4 a = reinterpret_cast<const float4*>(slab)[i];
   for (int s = 1; s < nsplit; s++) {
     const float4 v = reinterpret_cast<const float4*>(slab + (size_t)s * n4 * 4)[i];
@@ -117,9 +146,14 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
   reinterpret_cast<float4*>(out)[i] = a;
 }
 constexpr int64_t SLAB_FLOATS = (int64_t)8 * FF * D;   // room for 8 slabs of the largest matrix (or 32 of a 512 x 512 one)
+constexpr int64_t BIAS_PART_FLOATS = (int64_t)32 * FF; // behind them: up to 32 splits of the widest bias
 // dW[Nn][Kk] (fp32, overwritten) = Y[:T][:Nn]^T X[:T][:Kk].  The token axis is cut into as many slabs as keep ~512 workgroups busy
 // (2 per CU) and fit the slab buffer; the cut depends on the shapes only, so the summation order is fixed.
-static int gemm_tn(hipStream_t s, const bf16* Y, int ldy, const bf16* X, int ldx, float* dW, int T, int Nn, int Kk, float* slab) {
+// dbias (optional, [Nn]) = the column sums of Y, from the same pass (Kk >= 512: four k-tiles to spread them over).
+static int gemm_tn(hipStream_t s, const bf16* Y, int ldy, const bf16* X, int ldx, float* dW, int T, int Nn, int Kk, float* slab,
+                   float* dbias = nullptr) {
+  if (dbias && Kk < 512) return SO3X_ERR_INVALID_ARG;
+  float* bpart = dbias ? slab + SLAB_FLOATS : nullptr;
   if (Nn % 128 || Kk % 128 || T % 64) return SO3X_ERR_INVALID_ARG;
   const int tiles = (Nn / 128) * (Kk / 128);
   int nsplit = (512 + tiles - 1) / tiles;
@@ -128,9 +162,10 @@ static int gemm_tn(hipStream_t s, const bf16* Y, int ldy, const bf16* X, int ldx
   if (nsplit > T / 64) nsplit = T / 64;
   if (nsplit < 1) nsplit = 1;
   const int per = ((T / 64 + nsplit - 1) / nsplit) * 64;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, nsplit), dim3(256), 0, s, Y, X, slab, T, Nn, Kk, ldy, ldx, per);
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, nsplit), dim3(256), 0, s, Y, X, slab, T, Nn, Kk, ldy, ldx, per, bpart);
   const int64_t n4 = (int64_t)Nn * Kk / 4;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, slab, nsplit, n4, dW);
+  const int nb4 = dbias ? Nn / 4 : 0;
+  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + nb4 + 255) / 256)), dim3(256), 0, s, slab, nsplit, n4, dW, bpart, nb4, dbias);
   return check_launch();
 }
 
@@ -188,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__
       const int rowblk = (wave * 4 + i) * 4, row = rowblk + (lane >> 4);
       const int ch = (lane & 15) ^ swz16(row);
       const size_t off = (size_t)(j * 64 + row) * (3 * D) + ch * 8;
-      GLDS16(kbase + off, sk + rowblk * 256);
-      GLDS16(vbase + off, sv + rowblk * 256);
+      glds16_asm(kbase + off, sk + rowblk * 256);
+      glds16_asm(vbase + off, sv + rowblk * 256);
     }
   };
   f32x16 dq[4];
@@ -287,15 +322,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
     for (int i = 0; i < 4; i++) {
       const int rowblk = (wave * 4 + i) * 4, row = rowblk + (lane >> 4);
       const int ch = (lane & 15) ^ swz16(row);
-      GLDS16(qbase + (size_t)(j * 64 + row) * (3 * D) + ch * 8, sq + rowblk * 256);
-      GLDS16(dbase + (size_t)(j * 64 + row) * D + ch * 8, sd + rowblk * 256);
+      glds16_asm(qbase + (size_t)(j * 64 + row) * (3 * D) + ch * 8, sq + rowblk * 256);
+      glds16_asm(dbase + (size_t)(j * 64 + row) * D + ch * 8, sd + rowblk * 256);
     }
     // the tile's 64 lse2 and 64 delta values by LDS-DMA too (4 bytes per lane: no register-destination load beside the DMA)
     char* sl = smem + 65536 + buf * 512;
-    if (wave == 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lrow + j * 64 + lane),
-                                                    (__attribute__((address_space(3))) void*)sl, 4, 0, 0);
-    if (wave == 1) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(drow + j * 64 + lane),
-                                                    (__attribute__((address_space(3))) void*)(sl + 256), 4, 0, 0);
+    if (wave == 0) glds4_asm(lrow + j * 64 + lane, sl);
+    if (wave == 1) glds4_asm(drow + j * 64 + lane, sl + 256);
   };
   f32x16 acc[4];   // dV^T or dK^T: [d][key]
 #pragma unroll
@@ -562,7 +595,7 @@ inline BwdB carve_bwd_b(const Shape& s, void* mem) {
   b.g = c.take<float>(N);
   b.dpooled = c.take<float>((size_t)s.B * D);
   b.dxs = c.take<float>((size_t)s.B * D);
-  b.slab = c.take<float>((size_t)SLAB_FLOATS);
+  b.slab = c.take<float>((size_t)(SLAB_FLOATS + BIAS_PART_FLOATS));
   size_t part = (size_t)colsum_chunks(s) * FF;                                        // column sums, <= 2048 wide
   const size_t lnp = (size_t)((Np + LNB_ROWS - 1) / LNB_ROWS) * 1024;                 // LayerNorm / embedding partials (64-row chunks)
   const size_t pool = (size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1);
@@ -632,19 +665,16 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
     hipLaunchKernelGGL(k_part_final, dim3(32), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g2);
     TRY(check_launch());
     // feed-forward: r2 = x1 + relu(x1 W1^T + b1) W2^T + b2
-    TRY(gemm_tn(s, dalt, D, k.f, FF, dprm + lo.w2, (int)Np, D, FF, w.slab));
-    TRY(colsum_bf16(s, dalt, D, N, D, dprm + lo.b2, w.part));
+    TRY(gemm_tn(s, dalt, D, k.f, FF, dprm + lo.w2, (int)Np, D, FF, w.slab, dprm + lo.b2));   // (+ d b2: rows >= N of every dY are zero)
     TRY(gemm_bf16(s, dalt, D, wT + lo.w2, D, w.dF, FF, w.zeros, k.f, FF, (int)Np, FF, D, EPI_MASK));          // dZ = (dr2 W2) o (f > 0)
-    TRY(gemm_tn(s, w.dF, FF, k.x1, D, dprm + lo.w1, (int)Np, FF, D, w.slab));
-    TRY(colsum_bf16(s, w.dF, FF, N, FF, dprm + lo.b1, w.part));
+    TRY(gemm_tn(s, w.dF, FF, k.x1, D, dprm + lo.w1, (int)Np, FF, D, w.slab, dprm + lo.b1));
     TRY(gemm_bf16(s, w.dF, FF, wT + lo.w1, FF, dcur, D, w.zeros, dalt, D, (int)Np, D, FF, EPI_RESID));        // dcur = d x1 = dr2 + dZ W1
     // norm1: dcur = d x1 -> dalt = d r1
     hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r1, k.st1, prm + lo.g1, dalt, w.part, Np);
     hipLaunchKernelGGL(k_part_final, dim3(32), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g1);
     TRY(check_launch());
     // attention block: r1 = h + softmax(Q K^T / sqrt(dh)) V Wo^T + bo
-    TRY(gemm_tn(s, dalt, D, k.o, D, dprm + lo.wo, (int)Np, D, D, w.slab));
-    TRY(colsum_bf16(s, dalt, D, N, D, dprm + lo.bo, w.part));
+    TRY(gemm_tn(s, dalt, D, k.o, D, dprm + lo.wo, (int)Np, D, D, w.slab, dprm + lo.bo));
     TRY(gemm_bf16(s, dalt, D, wT + lo.wo, D, w.dO, D, w.zeros, nullptr, 0, (int)Np, D, D, EPI_NONE));
     hipLaunchKernelGGL(k_attn_delta, dim3(blocks_for(N * HEADS, 16)), dim3(256), 0, s, k.o, w.dO, k.lse, w.delta, w.lse2, N, (int)P);
     const dim3 ag((unsigned)(P / 128 + (P % 128 ? 1 : 0)), HEADS, (unsigned)sh.B);
@@ -656,8 +686,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
       e = hipMemsetAsync(w.dqkv + N * 3 * D, 0, (size_t)(Np - N) * 3 * D * sizeof(bf16), s);
       if (e != hipSuccess) return (int)e;
     }
-    TRY(gemm_tn(s, w.dqkv, 3 * D, h, D, dprm + lo.wqkv, (int)Np, 3 * D, D, w.slab));
-    TRY(colsum_bf16(s, w.dqkv, 3 * D, N, 3 * D, dprm + lo.bqkv, w.part));
+    TRY(gemm_tn(s, w.dqkv, 3 * D, h, D, dprm + lo.wqkv, (int)Np, 3 * D, D, w.slab, dprm + lo.bqkv));
     TRY(gemm_bf16(s, w.dqkv, 3 * D, wT + lo.wqkv, 3 * D, dcur, D, w.zeros, dalt, D, (int)Np, D, 3 * D, EPI_RESID));   // dcur = d h = dr1 + dqkv Wqkv
   }
   // embedding: h0[:, :256] = sin(pre) Wps^T + bps, pre = x Wp^T + bp
