@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
   __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (K tile 16 KB | V tile 16 KB)
   typedef __attribute__((address_space(3))) s16x4* lds_p;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  int xt, hd, b;
+  attn_tile((P + 127) / 128, xt, hd, b);
+  const int q0 = xt * 128 + wave * 32;
   const size_t tok0 = (size_t)b * P;
   // Q^T as the B operand of S^T = K Q^T: lane (r, h) holds Q[q0 + r][16 ks + 8 h .. + 8]
   bf16x8 qf[8];
@@ -684,7 +686,7 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
     const LayerB& k = a.layer[l];
     const bf16* h = a.h[l];
     TRY(gemm_bf16(s, h, D, wimg + lo.wqkv, D, k.qkv, 3 * D, prm + lo.bqkv, nullptr, 0, (int)Np, 3 * D, D, EPI_NONE));
-    hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)(P / 128 + (P % 128 ? 1 : 0)), HEADS, (unsigned)sh.B), dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2);
+    hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)((P + 127) / 128 * HEADS * sh.B)), dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2);
     TRY(check_launch());
     if (Np > N) {   // the pad rows of the attention output feed the next GEMM: keep them finite (zero)
       hipError_t e = hipMemsetAsync(k.o + N * D, 0, (size_t)(Np - N) * D * sizeof(bf16), s);

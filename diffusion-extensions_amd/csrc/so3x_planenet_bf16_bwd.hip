@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__
                                                         const float* __restrict__ delta, bf16* __restrict__ dqkv, int P, float sc, float c2) {
   __shared__ __attribute__((aligned(16))) char smem[65536];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  int xt, hd, b;
+  attn_tile((P + 127) / 128, xt, hd, b);
+  const int q0 = xt * 128 + wave * 32;
   const size_t tok0 = (size_t)b * P;
   const int qr = q0 + r < P ? q0 + r : P - 1;
   bf16x8 qf[8], dof[8];
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
                                                          const float* __restrict__ delta, bf16* __restrict__ dqkv, int P, float sc, float c2) {
   __shared__ __attribute__((aligned(16))) char smem[65536 + 1024];   // 2 x (Q tile 16 KB | dO tile 16 KB) | 2 x (lse2[64] | delta[64])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, k0 = blockIdx.x * 128 + wave * 32;
+  int xt, hd, b;
+  attn_tile((P + 127) / 128, xt, hd, b);
+  const int k0 = xt * 128 + wave * 32;
   const size_t tok0 = (size_t)b * P;
   const int kr = k0 + r < P ? k0 + r : P - 1;
   bf16x8 kf[8], vf[WHICH ? 8 : 1];
@@ -445,19 +449,28 @@ __global__ __launch_bounds__(256) void k_ln_bwd_bf16(const bf16* __restrict__ dy
   __syncthreads();
   for (int c = threadIdx.x; c < 1024; c += 256) part[(int64_t)blockIdx.x * 1024 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
-// out[c] = sum over chunks of part[chunk][c], fixed order: 32 columns x 8 interleaved chunk groups per workgroup
+// out[c] = sum over chunks of part[chunk][c], fixed order: 8 columns x 32 interleaved chunk groups per workgroup, four chunks of
+// a group in flight (a thread's loads are each a round trip to L2: one after the other, 1024 chunks took 40 us)
 __global__ __launch_bounds__(256) void k_part_final(const float* __restrict__ part, int nchunks, int cols, int pitch, float* __restrict__ out) {
-  __shared__ float red[8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), gq = threadIdx.x >> 5;
-  float acc = 0.f;
-  if (c < cols)
-    for (int i = gq; i < nchunks; i += 8) acc += part[(int64_t)i * pitch + c];
-  red[gq][threadIdx.x & 31] = acc;
+  __shared__ float red[32][8];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7), gq = threadIdx.x >> 3;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int i = gq;
+    for (; i + 96 < nchunks; i += 128) {
+      a0 += part[(int64_t)i * pitch + c];
+      a1 += part[(int64_t)(i + 32) * pitch + c];
+      a2 += part[(int64_t)(i + 64) * pitch + c];
+      a3 += part[(int64_t)(i + 96) * pitch + c];
+    }
+    for (; i < nchunks; i += 32) a0 += part[(int64_t)i * pitch + c];
+  }
+  red[gq][threadIdx.x & 7] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (gq == 0 && c < cols) {
     float a = red[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < 8; k++) a += red[k][threadIdx.x];
+    for (int k = 1; k < 32; k++) a += red[k][threadIdx.x];
     out[c] = a;
   }
 }
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const bf16* __restrict__ X,
 static int colsum_bf16(hipStream_t s, const bf16* X, int64_t ld, int64_t rows, int cols, float* out, float* part) {
   const int nch = (int)((rows + CH - 1) / CH);
   hipLaunchKernelGGL(k_colsum_bf16, dim3((cols + 255) / 256, nch), dim3(256), 0, s, X, ld, rows, cols, part);
-  hipLaunchKernelGGL(k_part_final, dim3((cols + 31) / 32), dim3(256), 0, s, part, nch, cols, cols, out);
+  hipLaunchKernelGGL(k_part_final, dim3((cols + 7) / 8), dim3(256), 0, s, part, nch, cols, cols, out);
   return check_launch();
 }
 
@@ -650,7 +663,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
   hipLaunchKernelGGL(k_pool_bwd_tok_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, enc, a.w, a.S, a.xs, w.dxs, prm + po.wpool, w.dA, w.g, N, Np, P);
   const int nsl = (int)((P + PSLICE - 1) / PSLICE);
   hipLaunchKernelGGL(k_wsum_part_bf16, dim3(D / 64, (unsigned)sh.B, nsl), dim3(256), 0, s, enc, w.g, w.part, P);
-  hipLaunchKernelGGL(k_part_final, dim3((D + 1 + 31) / 32), dim3(256), 0, s, w.part, Bn * nsl, D + 1, D + 1, dprm + po.wpool);   // wpool[512] | bpool[1]
+  hipLaunchKernelGGL(k_part_final, dim3((D + 1 + 7) / 8), dim3(256), 0, s, w.part, Bn * nsl, D + 1, D + 1, dprm + po.wpool);   // wpool[512] | bpool[1]
   TRY(check_launch());
   const float sc = 1.f / sqrtf((float)DH), c2 = sc * 1.4426950408889634f;
   const int lnblk = (int)((Np + LNB_ROWS - 1) / LNB_ROWS);
@@ -662,7 +675,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
     const bf16* h = a.h[l];
     // norm2: dcur = d h_{l+1} -> dalt = d r2;  d gamma2 | d beta2 are adjacent in the parameter buffer
     hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r2, k.st2, prm + lo.g2, dalt, w.part, Np);
-    hipLaunchKernelGGL(k_part_final, dim3(32), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g2);
+    hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g2);
     TRY(check_launch());
     // feed-forward: r2 = x1 + relu(x1 W1^T + b1) W2^T + b2
     TRY(gemm_tn(s, dalt, D, k.f, FF, dprm + lo.w2, (int)Np, D, FF, w.slab, dprm + lo.b2));   // (+ d b2: rows >= N of every dY are zero)
@@ -671,13 +684,13 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
     TRY(gemm_bf16(s, w.dF, FF, wT + lo.w1, FF, dcur, D, w.zeros, dalt, D, (int)Np, D, FF, EPI_RESID));        // dcur = d x1 = dr2 + dZ W1
     // norm1: dcur = d x1 -> dalt = d r1
     hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r1, k.st1, prm + lo.g1, dalt, w.part, Np);
-    hipLaunchKernelGGL(k_part_final, dim3(32), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g1);
+    hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g1);
     TRY(check_launch());
     // attention block: r1 = h + softmax(Q K^T / sqrt(dh)) V Wo^T + bo
     TRY(gemm_tn(s, dalt, D, k.o, D, dprm + lo.wo, (int)Np, D, D, w.slab, dprm + lo.bo));
     TRY(gemm_bf16(s, dalt, D, wT + lo.wo, D, w.dO, D, w.zeros, nullptr, 0, (int)Np, D, D, EPI_NONE));
     hipLaunchKernelGGL(k_attn_delta, dim3(blocks_for(N * HEADS, 16)), dim3(256), 0, s, k.o, w.dO, k.lse, w.delta, w.lse2, N, (int)P);
-    const dim3 ag((unsigned)(P / 128 + (P % 128 ? 1 : 0)), HEADS, (unsigned)sh.B);
+    const dim3 ag((unsigned)((P + 127) / 128 * HEADS * sh.B));
     hipLaunchKernelGGL(k_attn_bwd_dq, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2);
     hipLaunchKernelGGL(k_attn_bwd_dkv<0>, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2);
     hipLaunchKernelGGL(k_attn_bwd_dkv<1>, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2);
@@ -695,7 +708,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
   TRY(gemm_bf16(s, dcur, D, wT + po.wps, D2, w.ds, D2, w.zeros, nullptr, 0, (int)Np, D2, D2, EPI_NONE));
   const int nch = (int)((N + ECH - 1) / ECH);
   hipLaunchKernelGGL(k_embed_bwd_part, dim3(nch), dim3(256), 0, s, w.ds, a.pre, x, N, w.part);
-  hipLaunchKernelGGL(k_part_final, dim3(32), dim3(256), 0, s, w.part, nch, 1024, 1024, w.slab);
+  hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, nch, 1024, 1024, w.slab);
   hipLaunchKernelGGL(k_embed_bwd_final, dim3(1), dim3(256), 0, s, w.slab, dprm + po.wp, dprm + po.bp);
   return check_launch();
 }

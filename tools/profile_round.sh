@@ -20,5 +20,29 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 100 > $out/pmc_$i.log 2>&1
 done
+# keep what tools/summarize_profiles.py reads, in a size gpurun copies back (<= 64 MiB for all of gpurun_out/): the counter files
+# with five columns and kernel names cut to 100 characters, the PMC passes' own kernel traces dropped
+python3 - "$out" <<'PY'
+import csv, glob, os, sys
+out = sys.argv[1]
+for f in glob.glob(os.path.join(out, "pmc_*", "*kernel_trace.csv")):
+    os.remove(f)
+keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value"]
+for f in glob.glob(os.path.join(out, "pmc_*", "*counter_collection.csv")):
+    rows = [{k: (r[k][:100] if k == "Kernel_Name" else r[k]) for k in keep} for r in csv.DictReader(open(f))]
+    with open(f, "w", newline="") as g:
+        w = csv.DictWriter(g, fieldnames=keep)
+        w.writeheader()
+        w.writerows(rows)
+for f in glob.glob(os.path.join(out, "stats", "*kernel_trace.csv")):
+    rows = list(csv.DictReader(open(f)))
+    cols = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size"]
+    cols = [c for c in cols if rows and c in rows[0]]
+    with open(f, "w", newline="") as g:
+        w = csv.DictWriter(g, fieldnames=cols)
+        w.writeheader()
+        w.writerows({c: (r[c][:100] if c == "Kernel_Name" else r[c]) for c in cols} for r in rows)
+PY
+du -sh $out
 ls $out $out/stats | head -30
 cat $out/bench_line.json | cut -c1-600
