@@ -728,7 +728,7 @@ def secondary_rooflines(line):
     el = line.get("external_loop")
     if el is not None:
         sec["external_loop (one p_sample call per reverse step, so3_test.py:28-31)"] = pick(el, "sample_steps_per_s", "ms_per_call", "calls", "batch",
-                                                                                          "vs_chain_kernel_rate")
+                                                                                          "vs_chain_kernel_rate", "at_batch_4M")
     return sec
 
 
@@ -996,6 +996,13 @@ def main():
             try:
                 el_leg = external_loop_leg(torch, proc, x, T)
                 el_leg["vs_chain_kernel_rate"] = el_leg["sample_steps_per_s"] / line["roofline"]["sample_steps_per_s"]
+                # the same loop on four times the batch: a launch's fixed costs (20-30 us: LDS image and table fill, the state's
+                # HBM round trip, first-chunk warm-up, tail; tools/ab/README.md round 5) against four times the work
+                x4 = torch.cat([x] * 4)
+                big = external_loop_leg(torch, proc, x4, T, calls=250)
+                el_leg["at_batch_4M"] = {k: big[k] for k in ("batch", "calls", "ms_per_call", "sample_steps_per_s", "finite")}
+                el_leg["at_batch_4M"]["vs_chain_kernel_rate"] = big["sample_steps_per_s"] / line["roofline"]["sample_steps_per_s"]
+                del x4
                 line["external_loop"] = el_leg
             except Exception as e:
                 line["external_loop"] = {"error": repr(e)}
