@@ -11,6 +11,7 @@
 // Activations are token-major [B*P][width] (the reference runs nn.TransformerEncoder sequence-first, [P][B][dim]; the
 // arithmetic per token is the same).
 #include "so3x_planenet.hpp"
+#include "so3x_math.hpp"
 
 namespace so3x {
 namespace plane {
@@ -256,9 +257,20 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
   out[c] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_relu_bwd(float* __restrict__ df, const float* __restrict__ f, int64_t n) {
+__global__ __launch_bounds__(256) void k_relu_bwd(float* __restrict__ df, const float* __restrict__ f, int64_t n, float scale) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n && !(f[i] > 0.f)) df[i] = 0.f;
+  if (i < n) df[i] = f[i] > 0.f ? df[i] * scale : 0.f;   // (scale = 1 / keep when the hidden activations were dropped out)
+}
+// dst[e] = keep(e) ? src[e] / (1 - p) : 0 over a flat array (src may be dst); eight elements per thread, one Philox call (Drop)
+__global__ __launch_bounds__(256) void k_dropout(const float* src, float* dst, int64_t n, uint32_t thr16, float inv_keep, uint64_t seed,
+                                                 uint64_t ctr_hi) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (8 * i >= n) return;
+  const Philox4 r = philox4x32_10(seed, (uint64_t)i, ctr_hi);
+  const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if (8 * i + j < n) dst[8 * i + j] = ((u[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) >= thr16 ? src[8 * i + j] * inv_keep : 0.f;
 }
 __global__ __launch_bounds__(256) void k_cos_mul(float* __restrict__ ds, const float* __restrict__ pre, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -449,8 +461,15 @@ int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, fl
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ forward plan (fp32)
+static int dropout(hipStream_t s, const Drop& dr, int layer, int site, const float* src, float* dst, int64_t n) {
+  hipLaunchKernelGGL(k_dropout, dim3(blocks_for((n + 7) / 8, 256)), dim3(256), 0, s, src, dst, n, dr.thr16(), dr.inv_keep(), dr.seed, dr.ctr_hi(layer, site));
+  return check_launch();
+}
+
+// dr.on(): a training-mode forward; `pd` = room for one layer's dropped-out probabilities ([B][H][P][P]; the stash keeps the
+// plain softmax, which its backward needs everywhere)
 int forward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
-                const Acts& a) {
+                const Acts& a, const Drop& dr, float* pd) {
   const ParamOff po = param_offsets(sh);
   const int64_t N = sh.N();
   const int d = sh.d, d2 = sh.d2(), H = sh.H, dh = sh.dh(), F = sh.F;
@@ -471,13 +490,21 @@ int forward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* x
              P * 3 * d, dh, P * 3 * d, dh, (int64_t)H * P * P, P * P));
     hipLaunchKernelGGL(k_softmax_rows, dim3(blocks_for(sh.B * H * P, 4)), dim3(256), 0, s, k.probs, sh.B * H * P, (int)P);
     TRY(check_launch());
-    TRY(gemm(s, rowmajor(k.probs, P), rowmajor(k.qkv + 2 * d, 3 * d), k.o, d, (int)P, dh, (int)P, nullptr, 1.f, false, false, (int)sh.B, H,
+    const float* pv = k.probs;
+    if (dr.on()) {
+      TRY(dropout(s, dr, l, DROP_ATTN, k.probs, pd, sh.B * H * P * P));
+      pv = pd;
+    }
+    TRY(gemm(s, rowmajor(pv, P), rowmajor(k.qkv + 2 * d, 3 * d), k.o, d, (int)P, dh, (int)P, nullptr, 1.f, false, false, (int)sh.B, H,
              (int64_t)H * P * P, P * P, P * 3 * d, dh, P * d, dh));
     TRY(gemm(s, rowmajor(k.o, d), transposed(prm + lo.wo, d), k.r1, d, (int)N, d, d, prm + lo.bo));
+    if (dr.on()) TRY(dropout(s, dr, l, DROP_BLOCK1, k.r1, k.r1, N * d));
     hipLaunchKernelGGL(k_add_ln, dim3(blocks_for(N, 4)), dim3(256), 0, s, h, k.r1, k.r1, k.x1, k.st1, prm + lo.g1, prm + lo.be1, N, d, 1e-5f);
     TRY(check_launch());
     TRY(gemm(s, rowmajor(k.x1, d), transposed(prm + lo.w1, d), k.f, F, (int)N, F, d, prm + lo.b1, 1.f, true));
+    if (dr.on()) TRY(dropout(s, dr, l, DROP_FFN, k.f, k.f, N * F));   // (the stash holds the dropped-out activations: what linear2 saw)
     TRY(gemm(s, rowmajor(k.f, F), transposed(prm + lo.w2, F), k.r2, d, (int)N, d, F, prm + lo.b2));
+    if (dr.on()) TRY(dropout(s, dr, l, DROP_BLOCK2, k.r2, k.r2, N * d));
     hipLaunchKernelGGL(k_add_ln, dim3(blocks_for(N, 4)), dim3(256), 0, s, k.x1, k.r2, k.r2, a.h[l + 1], k.st2, prm + lo.g2, prm + lo.be2, N, d, 1e-5f);
     TRY(check_launch());
   }
@@ -496,7 +523,7 @@ int forward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* x
 // ------------------------------------------------------------------------------------------------ backward plan (fp32)
 // dparams (overwritten) = d sum(out * dout) / d params, from the forward's per-layer buffers
 int backward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* x, const float* dout, float* dprm, const Acts& a,
-                 const BwdBufs& w) {
+                 const BwdBufs& w, const Drop& dr) {
   const ParamOff po = param_offsets(sh);
   const int64_t N = sh.N(), P = sh.P;
   const int d = sh.d, d2 = sh.d2(), H = sh.H, dh = sh.dh(), F = sh.F, Bn = (int)sh.B;
@@ -524,11 +551,16 @@ int backward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* 
     TRY(colsum(s, dcur, d, N, d, dprm + lo.be2, w.part));
     hipLaunchKernelGGL(k_ln_bwd, dim3(blocks_for(N, 4)), dim3(256), 0, s, dcur, k.r2, k.st2, prm + lo.g2, dalt, N, d);
     TRY(check_launch());
-    // dalt = d r2: flows to x1 (residual) and through linear2 / relu / linear1
-    TRY(gemm(s, transposed(dalt, d), rowmajor(k.f, F), dprm + lo.w2, F, d, F, (int)N));
-    TRY(colsum(s, dalt, d, N, d, dprm + lo.b2, w.part));
-    TRY(gemm(s, rowmajor(dalt, d), rowmajor(prm + lo.w2, F), w.dF, F, (int)N, F, d));
-    hipLaunchKernelGGL(k_relu_bwd, dim3(blocks_for(N * F, 256)), dim3(256), 0, s, w.dF, k.f, N * F);
+    // dalt = d r2: flows to x1 (residual) and through [dropout] linear2 / [dropout] relu / linear1
+    const float* dy2 = dalt;
+    if (dr.on()) {   // the feed-forward branch sees the gradient through its output dropout (w.dO is idle until the attention block)
+      TRY(dropout(s, dr, l, DROP_BLOCK2, dalt, w.dO, N * d));
+      dy2 = w.dO;
+    }
+    TRY(gemm(s, transposed(dy2, d), rowmajor(k.f, F), dprm + lo.w2, F, d, F, (int)N));
+    TRY(colsum(s, dy2, d, N, d, dprm + lo.b2, w.part));
+    TRY(gemm(s, rowmajor(dy2, d), rowmajor(prm + lo.w2, F), w.dF, F, (int)N, F, d));
+    hipLaunchKernelGGL(k_relu_bwd, dim3(blocks_for(N * F, 256)), dim3(256), 0, s, w.dF, k.f, N * F, dr.on() ? dr.inv_keep() : 1.f);
     TRY(check_launch());
     TRY(gemm(s, transposed(w.dF, F), rowmajor(k.x1, d), dprm + lo.w1, d, F, d, (int)N));
     TRY(colsum(s, w.dF, F, N, F, dprm + lo.b1, w.part));
@@ -538,17 +570,28 @@ int backward_f32(hipStream_t s, const Shape& sh, const float* prm, const float* 
     TRY(colsum(s, dalt, d, N, d, dprm + lo.be1, w.part));
     hipLaunchKernelGGL(k_ln_bwd, dim3(blocks_for(N, 4)), dim3(256), 0, s, dalt, k.r1, k.st1, prm + lo.g1, dcur, N, d);
     TRY(check_launch());
-    // dcur = d r1: flows to h (residual) and through out_proj / attention / in_proj
-    TRY(gemm(s, transposed(dcur, d), rowmajor(k.o, d), dprm + lo.wo, d, d, d, (int)N));
-    TRY(colsum(s, dcur, d, N, d, dprm + lo.bo, w.part));
-    TRY(gemm(s, rowmajor(dcur, d), rowmajor(prm + lo.wo, d), w.dO, d, (int)N, d, d));
+    // dcur = d r1: flows to h (residual) and through [dropout] out_proj / attention / in_proj
+    const float* dy1 = dcur;
+    if (dr.on()) {   // (w.dF is idle from here on)
+      TRY(dropout(s, dr, l, DROP_BLOCK1, dcur, w.dF, N * d));
+      dy1 = w.dF;
+    }
+    TRY(gemm(s, transposed(dy1, d), rowmajor(k.o, d), dprm + lo.wo, d, d, d, (int)N));
+    TRY(colsum(s, dy1, d, N, d, dprm + lo.bo, w.part));
+    TRY(gemm(s, rowmajor(dy1, d), rowmajor(prm + lo.wo, d), w.dO, d, (int)N, d, d));
     const int64_t sq = P * 3 * d, sp = (int64_t)H * P * P;
-    // dV = P^T dO
-    TRY(gemm(s, transposed(k.probs, P), rowmajor(w.dO, d), w.dqkv + 2 * d, 3 * d, (int)P, dh, (int)P, nullptr, 1.f, false, false, Bn, H, sp, P * P,
+    // dV = P^T dO (the dropped-out probabilities the forward multiplied V with, rebuilt in the buffer dP takes next)
+    const float* pv = k.probs;
+    if (dr.on()) {
+      TRY(dropout(s, dr, l, DROP_ATTN, k.probs, w.dprobs, sh.B * H * P * P));
+      pv = w.dprobs;
+    }
+    TRY(gemm(s, transposed(pv, P), rowmajor(w.dO, d), w.dqkv + 2 * d, 3 * d, (int)P, dh, (int)P, nullptr, 1.f, false, false, Bn, H, sp, P * P,
              P * d, dh, sq, dh));
-    // dP = dO V^T, dS = softmax'(P, dP) / sqrt(dh)
+    // dP = dO V^T [through the dropout], dS = softmax'(P, dP) / sqrt(dh)
     TRY(gemm(s, rowmajor(w.dO, d), transposed(k.qkv + 2 * d, 3 * d), w.dprobs, P, (int)P, (int)P, dh, nullptr, 1.f, false, false, Bn, H, P * d, dh,
              sq, dh, sp, P * P));
+    if (dr.on()) TRY(dropout(s, dr, l, DROP_ATTN, w.dprobs, w.dprobs, sh.B * H * P * P));
     hipLaunchKernelGGL(k_softmax_bwd, dim3(blocks_for(sh.B * H * P, 4)), dim3(256), 0, s, k.probs, w.dprobs, sh.B * H * P, (int)P, scale);
     TRY(check_launch());
     // dQ = dS K, dK = dS^T Q
@@ -631,23 +674,29 @@ int so3x_planenet_prepare(so3x_stream_t s, const float* params, int dim, int hea
 
 int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, float* out, float* encoding_out, int64_t B, int64_t P,
                       int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes,
-                      const void* prepared_weights) {
+                      const void* prepared_weights, float dropout_p, uint64_t seed, uint64_t rng_offset) {
   Shape sh{B, P, dim, heads, layers, ffn};
   if (!shape_ok(sh) || layers > 64 || (B && (!params || !x || !t || !out))) return SO3X_ERR_INVALID_ARG;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && !stash)) return SO3X_ERR_INVALID_ARG;   // dropout = a training forward
+  if (dropout_p > 0.f && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (precision == SO3X_PREC_BF16 && !bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
   if (B == 0) return SO3X_OK;
   if (!workspace || workspace_bytes < so3x_planenet_workspace_bytes(B, P, dim, heads, layers, ffn, precision)) return SO3X_ERR_WORKSPACE;
   if (precision == SO3X_PREC_BF16) return forward_bf16((hipStream_t)s, sh, params, x, t, out, encoding_out, stash, workspace, prepared_weights);
   const Acts a = stash ? carve_acts(sh, stash, true) : carve_acts(sh, workspace, false);
-  return forward_f32((hipStream_t)s, sh, params, x, t, out, encoding_out, a);
+  const Drop dr{dropout_p, seed, rng_offset};
+  // (with a stash the workspace is idle in the forward: the backward's dP buffer holds a layer's dropped-out probabilities)
+  return forward_f32((hipStream_t)s, sh, params, x, t, out, encoding_out, a, dr, dr.on() ? carve_bwd(sh, workspace).dprobs : nullptr);
 }
 
 int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, const float* dout, float* dparams, int64_t B,
                       int64_t P, int dim, int heads, int layers, int ffn, int precision, const void* stash, void* workspace,
-                      size_t workspace_bytes) {
+                      size_t workspace_bytes, float dropout_p, uint64_t seed, uint64_t rng_offset) {
   Shape sh{B, P, dim, heads, layers, ffn};
   if (!shape_ok(sh) || layers > 64 || !dparams || (B && (!params || !x || !t || !dout || !stash))) return SO3X_ERR_INVALID_ARG;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return SO3X_ERR_INVALID_ARG;
+  if (dropout_p > 0.f && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (precision == SO3X_PREC_BF16 && !bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
   if (B == 0) {
@@ -658,7 +707,7 @@ int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, cons
   if (precision == SO3X_PREC_BF16) return backward_bf16((hipStream_t)s, sh, params, x, t, dout, dparams, stash, workspace);
   const Acts a = carve_acts(sh, const_cast<void*>(stash), true);
   const BwdBufs w = carve_bwd(sh, workspace);
-  return backward_f32((hipStream_t)s, sh, params, x, dout, dparams, a, w);
+  return backward_f32((hipStream_t)s, sh, params, x, dout, dparams, a, w, Drop{dropout_p, seed, rng_offset});
 }
 
 }  // extern "C"

@@ -15,6 +15,23 @@ struct Shape {
   int d2() const { return d / 2; }   // SIREN / time-embedding width
 };
 
+// Dropout of a training-mode forward (nn.TransformerEncoderLayer's default p = 0.1, which the reference trains with:
+// aircraft_rotate.py:66 `net.train()`, models.py:190): four sites per layer -- the attention probabilities, the attention block's
+// output, the feed-forward's hidden activations, the feed-forward's output (torch/nn/modules/transformer.py).  Element e of site
+// s keeps its value (scaled by 1 / (1 - p)) iff 16-bit piece (e & 7) of Philox4x32-10(key = seed; counter = (e >> 3,
+// offset << 8 | s)) -- words x, y, z, w, low half first -- is >= p * 2^16 (eight decisions per call: a lane's eight consecutive
+// columns); the backward regenerates the same masks from (seed, offset).  torch's own mask stream cannot be reproduced
+// (it depends on its kernels' launch geometry); parity is against an emulation with THESE masks (tests/test_planenet.py).
+struct Drop {
+  float p;
+  uint64_t seed, offset;
+  bool on() const { return p > 0.f; }
+  uint32_t thr16() const { const double v = (double)p * 65536.0; return v >= 65535.0 ? 65535u : (uint32_t)v; }
+  float inv_keep() const { return 1.f / (1.f - p); }
+  uint64_t ctr_hi(int layer, int site) const { return (offset << 8) | (uint64_t)(4 * layer + site); }
+};
+enum { DROP_ATTN = 0, DROP_BLOCK1 = 1, DROP_FFN = 2, DROP_BLOCK2 = 3 };
+
 inline bool shape_ok(const Shape& s) {
   return s.B >= 0 && s.P >= 1 && s.d >= 8 && s.H >= 1 && s.L >= 1 && s.F >= 1 && s.d % s.H == 0 && s.d % 4 == 0 && s.d <= 4096 &&
          s.F <= 16384 && s.P <= (1 << 20) && s.B * s.P < (int64_t(1) << 31);

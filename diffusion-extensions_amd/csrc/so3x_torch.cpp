@@ -427,7 +427,8 @@ Tensor planenet_prepare(const Tensor& params, int64_t dim, int64_t heads, int64_
   return w;
 }
 std::tuple<Tensor, Tensor, Tensor> planenet_fwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t dim, int64_t heads, int64_t layers,
-                                                int64_t ffn, int64_t precision, bool want_stash, bool want_encoding, const optional<Tensor>& prepared) {
+                                                int64_t ffn, int64_t precision, bool want_stash, bool want_encoding, const optional<Tensor>& prepared,
+                                                double dropout_p, int64_t seed, int64_t rng_offset) {
   GUARD(x);
   TORCH_CHECK(x.dim() == 3 && x.size(2) == 3, "so3x: x must be [B, P, 3]");
   const int64_t B = x.size(0), P = x.size(1);
@@ -442,19 +443,20 @@ std::tuple<Tensor, Tensor, Tensor> planenet_fwd(const Tensor& params, const Tens
   Tensor ws = bytes(x, wsb), stash = bytes(x, stb);
   ok(so3x_planenet_fwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), Fm(out), want_encoding && B ? Fm(enc) : nullptr,
                        B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision, want_stash && B ? stash.mutable_data_ptr() : nullptr,
-                       ws.mutable_data_ptr(), ws.numel(), (prepared.has_value() && prepared->numel()) ? dev(*prepared, "prepared", at::kByte).const_data_ptr() : nullptr),
+                       ws.mutable_data_ptr(), ws.numel(), (prepared.has_value() && prepared->numel()) ? dev(*prepared, "prepared", at::kByte).const_data_ptr() : nullptr,
+                       (float)dropout_p, (uint64_t)seed, (uint64_t)rng_offset),
      "planenet_fwd");
   return {out, stash, enc};
 }
 Tensor planenet_bwd(const Tensor& params, const Tensor& x, const Tensor& t, const Tensor& dout, const Tensor& stash, int64_t dim, int64_t heads,
-                    int64_t layers, int64_t ffn, int64_t precision) {
+                    int64_t layers, int64_t ffn, int64_t precision, double dropout_p, int64_t seed, int64_t rng_offset) {
   GUARD(x);
   const int64_t B = x.size(0), P = x.size(1);
   Tensor dparams = f32_like(x, {params.numel()});
   Tensor ws = bytes(x, so3x_planenet_workspace_bytes(B, P, (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision));
   ok(so3x_planenet_bwd(strm(x), F(dev(params, "params")), F(dev(x, "x")), I64(dev(t, "t", at::kLong)), F(dev(dout, "dout")), Fm(dparams), B, P,
                        (int)dim, (int)heads, (int)layers, (int)ffn, (int)precision, dev(stash, "stash", at::kByte).const_data_ptr(),
-                       ws.mutable_data_ptr(), ws.numel()),
+                       ws.mutable_data_ptr(), ws.numel(), (float)dropout_p, (uint64_t)seed, (uint64_t)rng_offset),
      "planenet_bwd");
   return dparams;
 }
@@ -690,8 +692,8 @@ TORCH_LIBRARY(so3x, m) {
   m.def("rotate_cloud(Tensor rot, Tensor cloud, int cloud_stride, int P) -> Tensor");
   m.def("resnet_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> Tensor");
   m.def("planenet_prepare(Tensor params, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
-  m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding, Tensor? prepared) -> (Tensor, Tensor, Tensor)");
-  m.def("planenet_bwd(Tensor params, Tensor x, Tensor t, Tensor dout, Tensor stash, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
+  m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding, Tensor? prepared, float dropout_p, int seed, int rng_offset) -> (Tensor, Tensor, Tensor)");
+  m.def("planenet_bwd(Tensor params, Tensor x, Tensor t, Tensor dout, Tensor stash, int dim, int heads, int layers, int ffn, int precision, float dropout_p, int seed, int rng_offset) -> Tensor");
   m.def("resnet_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> (Tensor, Tensor)");
   m.def("resnet_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int n_out, int precision, int t_table, Tensor? stash) -> Tensor");
   m.def("resnet_p_sample_chain(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "

@@ -90,7 +90,7 @@ def lib():
                 l.so3x_planenet_stash_bytes.restype = C.c_size_t
                 l.so3x_planenet_weights_bytes.restype = C.c_size_t
                 l.so3x_planenet_param_count.restype = C.c_int64
-                if l.so3x_abi_version() != 7:
+                if l.so3x_abi_version() != 8:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
     return _lib
@@ -722,18 +722,22 @@ def planenet_prepare(params, dim, heads, layers, ffn=2048, precision=PREC_F32):
     return _call(ops().planenet_prepare, _dev(params, "params").reshape(-1), int(dim), int(heads), int(layers), int(ffn), int(precision))
 
 
-def planenet_fwd(params, x, t, dim, heads, layers, ffn=2048, precision=PREC_F32, want_stash=False, want_encoding=False, prepared=None):
-    """PlaneNet forward: (out [B, 3], stash for planenet_bwd or an empty tensor, encoder output [B, P, dim] or empty)"""
+def planenet_fwd(params, x, t, dim, heads, layers, ffn=2048, precision=PREC_F32, want_stash=False, want_encoding=False, prepared=None,
+                 dropout_p=0.0, seed=0, rng_offset=0):
+    """PlaneNet forward: (out [B, 3], stash for planenet_bwd or an empty tensor, encoder output [B, P, dim] or empty).
+    dropout_p > 0: the training-mode forward (needs want_stash; masks are a function of (seed, rng_offset), see so3x.h)"""
     params, x, tt = _planenet_in(params, x, t)
     return _call(ops().planenet_fwd, params, x, tt, int(dim), int(heads), int(layers), int(ffn), int(precision), bool(want_stash), bool(want_encoding),
-                 prepared)
+                 prepared, float(dropout_p), _s64(seed), _s64(rng_offset))
 
 
-def planenet_bwd(params, x, t, dout, stash, dim, heads, layers, ffn=2048, precision=PREC_F32):
-    """d sum(out * dout) / d params (flat, state_dict order) from the stash planenet_fwd(want_stash=True) returned"""
+def planenet_bwd(params, x, t, dout, stash, dim, heads, layers, ffn=2048, precision=PREC_F32, dropout_p=0.0, seed=0, rng_offset=0):
+    """d sum(out * dout) / d params (flat, state_dict order) from the stash planenet_fwd(want_stash=True) returned (and the SAME
+    dropout_p, seed, rng_offset)"""
     params, x, tt = _planenet_in(params, x, t)
     dout = _dev(dout, "dout").reshape(-1, 3)
-    return _call(ops().planenet_bwd, params, x, tt, dout, stash, int(dim), int(heads), int(layers), int(ffn), int(precision))
+    return _call(ops().planenet_bwd, params, x, tt, dout, stash, int(dim), int(heads), int(layers), int(ffn), int(precision), float(dropout_p),
+                 _s64(seed), _s64(rng_offset))
 
 
 # ----------------------------------------------------------------------------- SE(3) layer

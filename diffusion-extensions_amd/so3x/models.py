@@ -109,10 +109,10 @@ class _PlaneNetFn(torch.autograd.Function):
     noised pose, which needs none: reference diffusion.py:389-392)"""
 
     @staticmethod
-    def forward(ctx, x, t, flat_params, cfg):
+    def forward(ctx, x, t, flat_params, cfg, drop):
         from . import backend as _b
-        out, stash, _ = _b.planenet_fwd(flat_params, x, t, *cfg, want_stash=True)
-        ctx.cfg = cfg
+        out, stash, _ = _b.planenet_fwd(flat_params, x, t, *cfg, want_stash=True, dropout_p=drop[0], seed=drop[1], rng_offset=drop[2])
+        ctx.cfg, ctx.drop = cfg, drop
         ctx.save_for_backward(x, t, flat_params, stash)
         return out
 
@@ -120,7 +120,8 @@ class _PlaneNetFn(torch.autograd.Function):
     def backward(ctx, dout):
         from . import backend as _b
         x, t, flat_params, stash = ctx.saved_tensors
-        return None, None, _b.planenet_bwd(flat_params, x, t, dout.contiguous(), stash, *ctx.cfg), None
+        p, seed, off = ctx.drop
+        return None, None, _b.planenet_bwd(flat_params, x, t, dout.contiguous(), stash, *ctx.cfg, dropout_p=p, seed=seed, rng_offset=off), None, None
 
 
 class PlaneNet(FlatParamsMixin, nn.Module):
@@ -133,9 +134,10 @@ class PlaneNet(FlatParamsMixin, nn.Module):
     `forward` does not run them.  It runs the hand-written kernels of libso3x (so3x_planenet_fwd / so3x_planenet_bwd: embedding,
     encoder layers with attention, pooling and head, forward and backward) on the flat parameter buffer the module parameters are
     views of.  precision "fp32": every product on the exact-fp32 matrix-core instruction, any width; "bf16": the aircraft task's
-    shape (dim 512, 4 heads, points a multiple of 64) with bf16 operands and activations.  Dropout is NOT applied (the kernels are
-    nn.TransformerEncoderLayer's eval-mode arithmetic): `dropout` is the rate the torch modules are built with and must be 0
-    before a training-mode forward is accepted (the reference trains with torch's default 0.1, aircraft_rotate.py:66).
+    shape (dim 512, 4 heads, points a multiple of 64) with bf16 operands and activations.  `dropout` (torch's default 0.1, which
+    the reference trains with: aircraft_rotate.py:66) is applied in training mode at nn.TransformerEncoderLayer's four sites by
+    the exact-fp32 kernels, from counter-based masks keyed by (so3x.rng seed, a fresh offset per forward) that the backward
+    regenerates; the bf16 form has no dropout yet and refuses a training-mode forward with dropout > 0 rather than fall back to torch.
     `forward_torch` runs the torch modules instead -- an explicit cross-check for tests, never taken implicitly.
 
     Returns [B, 3]: one prediction per cloud.  (The reference's forward ends in `out[..., 0, :]` on that [B, 3] tensor,
@@ -175,14 +177,21 @@ class PlaneNet(FlatParamsMixin, nn.Module):
 
     def forward(self, x, t, want_encoding=False):
         from . import backend as _b
+        from . import rng as _rng
+        drop = (0.0, 0, 0)
         if self.training and self.dropout > 0:
-            raise NotImplementedError("so3x: the PlaneNet kernels implement nn.TransformerEncoderLayer without dropout; build the network "
-                                      "with dropout=0 (or call .eval()) -- a silent fallback to torch's modules is not offered")
+            if self.precision == "bf16":
+                raise NotImplementedError("so3x: the bf16 PlaneNet kernels have no dropout yet; train with precision='fp32' (dropout as in "
+                                          "the reference) or dropout=0 -- a silent fallback to torch's modules is not offered")
+            drop = (float(self.dropout), _rng.seed(), _rng.next_offset())   # a fresh mask set per training-mode forward
         if want_encoding:
-            out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_encoding=True, prepared=self._prepared())
+            out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_stash=drop[0] > 0, want_encoding=True,
+                                          prepared=None if drop[0] > 0 else self._prepared(), dropout_p=drop[0], seed=drop[1], rng_offset=drop[2])
             return out, enc
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _PlaneNetFn.apply(x, t, self.flat_params(), self.cfg)
+            return _PlaneNetFn.apply(x, t, self.flat_params(), self.cfg, drop)
+        if drop[0] > 0:   # a training-mode forward nobody differentiates: the same masks, the stash dropped
+            return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_stash=True, dropout_p=drop[0], seed=drop[1], rng_offset=drop[2])[0]
         return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, prepared=self._prepared())[0]
 
     def forward_torch(self, x, t):

@@ -244,7 +244,7 @@ def _(params, dim, heads, layers, ffn, precision):
 
 
 @register_fake("so3x::planenet_fwd")
-def _(params, x, t, dim, heads, layers, ffn, precision, want_stash, want_encoding, prepared):
+def _(params, x, t, dim, heads, layers, ffn, precision, want_stash, want_encoding, prepared, dropout_p, seed, rng_offset):
     B, P = x.shape[0], x.shape[1]
     # an upper bound is all a fake needs: per token and layer 7 dim + ffn + heads * P floats
     stash = (B * P * layers * (8 * dim + ffn + heads * P) * 4 + (1 << 20)) if want_stash else 0
@@ -252,7 +252,7 @@ def _(params, x, t, dim, heads, layers, ffn, precision, want_stash, want_encodin
 
 
 @register_fake("so3x::planenet_bwd")
-def _(params, x, t, dout, stash, dim, heads, layers, ffn, precision):
+def _(params, x, t, dout, stash, dim, heads, layers, ffn, precision, dropout_p, seed, rng_offset):
     return _f32(x, (params.numel(),))
 
 

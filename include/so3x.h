@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SO3X_ABI_VERSION 7
+#define SO3X_ABI_VERSION 8
 
 #define SO3X_OK 0
 #define SO3X_ERR_INVALID_ARG (-1)
@@ -299,8 +299,9 @@ int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int
  *   x [B][P][3] points, t int64 [B]  ->
  *   h0 = [ Siren(3 -> dim/2, scale 30): post_scale(sin(positional(x)))  (models.py:50-72)  ||  SinusoidalPosEmb(dim/2)(t)  (models.py:13-25) ]
  *   `layers` x nn.TransformerEncoderLayer(dim, heads): post-norm, ReLU, feed-forward `ffn` (torch's default 2048), LayerNorm eps
- *        1e-5, attention over the P points of one cloud, no mask; dropout OFF (eval-mode arithmetic: what the validation pass,
- *        aircraft_rotate.py:113-117, and ProjectedSO3Diffusion.p_sample run)
+ *        1e-5, attention over the P points of one cloud, no mask; dropout_p = 0: eval-mode arithmetic (the validation pass,
+ *        aircraft_rotate.py:113-117, and ProjectedSO3Diffusion.p_sample); dropout_p > 0: the training-mode forward the
+ *        reference trains with (aircraft_rotate.py:66 `net.train()` on nn.TransformerEncoderLayer's default p = 0.1), see below
  *   PoolRN(dim) with every point unmasked (models.py:94-110)  ->  Linear(dim, 3)            -> out [B][3]
  * params: the fp32 values in state_dict order -- encoder.layers.{l}.{self_attn.in_proj_weight, self_attn.in_proj_bias,
  *   self_attn.out_proj.weight, self_attn.out_proj.bias, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight,
@@ -319,7 +320,16 @@ int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int
  * prepared_weights (optional, so3x_planenet_fwd): the bf16 form converts the weight matrices to a bf16 image on every call (25 MB,
  *   ~15 us); a caller whose parameters did not change since (sampling: hundreds of calls per set of weights) builds the image once
  *   with so3x_planenet_prepare (so3x_planenet_weights_bytes; 0 bytes / a no-op for the exact-fp32 form) and passes it here.
- *   NULL = convert inside the call. */
+ *   NULL = convert inside the call.
+ * dropout_p in [0, 1), seed, rng_offset: with dropout_p > 0 (needs a stash: it is a training forward) the four dropout sites of
+ *   every encoder layer are active as in torch -- attention probabilities after the softmax, the attention block's output,
+ *   the feed-forward's hidden activations after the ReLU, the feed-forward's output; kept values scaled by 1 / (1 - p).  The
+ *   mask of flat element e of site s in layer l is 16-bit piece (e & 7) (words x, y, z, w; low half first) of
+ *   Philox4x32-10(key = seed, counter = (e >> 3, rng_offset << 8 | 4 l + s)) >= floor(p 2^16) (e: row-major index into
+ *   [B][heads][P][P] / [B P][dim] / [B P][ffn] / [B P][dim]):
+ *   a function of (seed, rng_offset) only, so so3x_planenet_bwd -- given the SAME three values -- regenerates it.  torch's own
+ *   mask stream depends on its kernels' launch geometry and cannot be matched; parity is against the reference's modules run
+ *   with these masks.  Exact-fp32 form; the bf16 form returns SO3X_ERR_UNSUPPORTED for dropout_p > 0. */
 int64_t so3x_planenet_param_count(int dim, int heads, int layers, int ffn);
 size_t so3x_planenet_workspace_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
 size_t so3x_planenet_stash_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
@@ -328,10 +338,10 @@ int so3x_planenet_prepare(so3x_stream_t s, const float* params, int dim, int hea
                           size_t weights_bytes);
 int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, float* out, float* encoding_out, int64_t B,
                       int64_t P, int dim, int heads, int layers, int ffn, int precision, void* stash, void* workspace, size_t workspace_bytes,
-                      const void* prepared_weights);
+                      const void* prepared_weights, float dropout_p, uint64_t seed, uint64_t rng_offset);
 int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, const float* dout, float* dparams, int64_t B,
                       int64_t P, int dim, int heads, int layers, int ffn, int precision, const void* stash, void* workspace,
-                      size_t workspace_bytes);
+                      size_t workspace_bytes, float dropout_p, uint64_t seed, uint64_t rng_offset);
 
 /* ------------------------------------------------------- sample-quality statistics */
 /* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/so3x.h but not exported"
     assert declared == set(B.SYMBOLS)
-    assert B.lib().so3x_abi_version() == 7
+    assert B.lib().so3x_abi_version() == 8
 
 
 def test_no_oracle_or_cpu_fallback_in_product():

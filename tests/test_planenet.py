@@ -83,12 +83,81 @@ def test_cpu_tensors_are_refused(golden):
         net(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
 
 
-def test_training_mode_with_dropout_is_refused():
+def test_bf16_training_mode_with_dropout_is_refused_not_rerouted():
+    """the exact-fp32 form applies the reference's training-mode dropout (GPU tests below); the bf16 form has none yet and says so
+    instead of running torch's modules"""
     from so3x.models import PlaneNet
-    net = PlaneNet(dim=32, heads=4, layers=1)      # torch's default dropout 0.1, as the reference builds it
+    net = PlaneNet(dim=32, heads=4, layers=1, precision="bf16")      # torch's default dropout 0.1, as the reference builds it
     net.train()
     with pytest.raises(NotImplementedError):
         net(torch.zeros(1, 8, 3), torch.zeros(1, dtype=torch.long))
+
+
+def philox4x32_10(seed, ctr_lo, ctr_hi):
+    """Philox4x32-10 as csrc/so3x_math.hpp runs it (key = seed, counter = (ctr_lo, ctr_hi)), vectorised over ctr_lo: four uint32 words"""
+    M = np.uint64(0xFFFFFFFF)
+    ctr_lo = np.asarray(ctr_lo, dtype=np.uint64)
+    k0, k1 = np.uint64(seed) & M, np.uint64(seed) >> np.uint64(32)
+    c0, c1 = ctr_lo & M, ctr_lo >> np.uint64(32)
+    c2 = np.full_like(c0, np.uint64(ctr_hi) & M)
+    c3 = np.full_like(c0, np.uint64(ctr_hi) >> np.uint64(32))
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & M, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & M
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return np.stack([c0, c1, c2, c3], axis=-1)
+
+
+def dropout_mask(n, p, seed, offset, layer, site):
+    """include/so3x.h: element e keeps its value iff 16-bit piece (e & 7) of Philox(seed; (e >> 3, offset << 8 | 4 layer + site)),
+    words in order, low half first, is >= floor(p 2^16)"""
+    thr = min(int(float(np.float32(p)) * 65536.0), 65535)
+    w = philox4x32_10(seed, np.arange((n + 7) // 8, dtype=np.uint64), (offset << 8) | (4 * layer + site))       # [calls, 4]
+    halves = np.stack([w & np.uint64(0xFFFF), w >> np.uint64(16)], axis=-1).reshape(-1)[:n]                        # x.lo, x.hi, y.lo, ...
+    return halves >= np.uint64(thr)
+
+
+def test_philox_known_answer():
+    """Random123's known-answer vectors for philox4x32-10: the emulation the dropout parity test rests on is the generator it says"""
+    out = philox4x32_10(0, [0], 0)[0]
+    assert [int(v) for v in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    full = (1 << 64) - 1
+    out = philox4x32_10(full, [full], full)[0]
+    assert [int(v) for v in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    m = dropout_mask(1 << 20, 0.1, 3, 7, 2, 1)
+    assert abs(float(m.mean()) - 0.9) < 2e-3
+
+
+def planenet_with_masks(net, x, t, masks, keep):
+    """PlaneNet's forward (reference models.py:198-210 over nn.TransformerEncoderLayer's post-norm arithmetic,
+    torch/nn/modules/transformer.py) in float64 on the CPU with GIVEN dropout masks: masks[l] = (attention [B, H, P, P],
+    block 1 [B, P, d], feed-forward [B, P, ffn], block 2 [B, P, d]) or None.  Test infrastructure."""
+    import torch.nn.functional as Fn
+    x_emb = net.position_siren(x)
+    t_emb = net.time_embedding(t)
+    h = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)
+    B, P, d = h.shape
+    H = net.heads
+    for l, layer in enumerate(net.encoder.layers):
+        ma, m1, mf, m2 = masks[l] if masks is not None else (None,) * 4
+        qkv = Fn.linear(h, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
+        q, k, v = (z.reshape(B, P, H, d // H).transpose(1, 2) for z in qkv.split(d, dim=2))
+        pr = torch.softmax(q @ k.transpose(2, 3) / (d // H) ** 0.5, dim=-1)
+        if ma is not None:
+            pr = pr * ma / keep
+        o = (pr @ v).transpose(1, 2).reshape(B, P, d)
+        y = layer.self_attn.out_proj(o)
+        if m1 is not None:
+            y = y * m1 / keep
+        x1 = layer.norm1(h + y)
+        f = torch.relu(layer.linear1(x1))
+        if mf is not None:
+            f = f * mf / keep
+        y2 = layer.linear2(f)
+        if m2 is not None:
+            y2 = y2 * m2 / keep
+        h = layer.norm2(x1 + y2)
+    return net.out_net(h)
 
 
 # ------------------------------------------------------------------------------------------------ GPU: fp32 form vs the reference
@@ -292,3 +361,58 @@ def test_bf16_backward_matches_the_fp32_form_on_odd_shapes(golden):
             scale = ref["out_net.0.pool.0.weight"].grad.norm() if k == "out_net.0.pool.0.bias" else a.grad.norm()
             rel = float((a.grad - b.grad).norm() / (scale + 1e-30))
             assert rel < 5e-2 and torch.isfinite(b.grad).all(), (Bn, P, k, rel)
+
+
+# ------------------------------------------------------------------------------------------------ GPU: training-mode dropout
+@pytest.mark.gpu
+def test_training_mode_dropout_vs_the_reference_arithmetic_with_the_same_masks(golden):
+    """The reference trains PlaneNet in training mode (aircraft_rotate.py:66) on nn.TransformerEncoderLayer's default dropout 0.1.
+    The kernels' masks are counter-based (include/so3x.h); torch's own stream cannot be matched, so parity is against the
+    reference's arithmetic in float64 WITH THESE MASKS: output and every parameter gradient.  Also: a manual_seed reproduces the
+    masks, consecutive forwards draw fresh ones, eval mode has none."""
+    import copy
+    from so3x import rng
+    from so3x.models import PlaneNet
+    g = golden["planenet"]
+    dim, heads, layers = int(g["dim"]), int(g["heads"]), int(g["layers"])
+    net = PlaneNet(dim=dim, heads=heads, layers=layers, precision="fp32", dropout=0.1)
+    net.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")})
+    ref = copy.deepcopy(net).double()
+    x64, t64 = torch.from_numpy(g["x"]).double(), torch.from_numpy(g["t"]).long()
+    Bn, P = x64.shape[0], x64.shape[1]
+    ref.eval()
+    with torch.no_grad():   # the emulation without masks IS the torch modules' eval forward
+        assert float((planenet_with_masks(ref, x64, t64, None, 1.0) - ref.forward_torch(x64, t64)).abs().max()) < 1e-12
+    net = net.to(DEV).train()
+    x, t = dev(g["x"]), dev(g["t"], torch.int64)
+    seed, p32 = 1234, float(np.float32(0.1))
+    keep = 1.0 - p32
+    rng.manual_seed(seed)                      # offset 0 for the next forward
+    out = net(x, t)
+    dout = torch.from_numpy(np.random.default_rng(0).standard_normal((Bn, 3))).to(DEV).float()
+    net.zero_grad(set_to_none=True)
+    (out * dout).sum().backward()
+    ffn = net.ffn
+    masks = []
+    for l in range(layers):
+        masks.append(tuple(torch.from_numpy(dropout_mask(n, 0.1, seed, 0, l, site).reshape(shape)).double()
+                           for site, (n, shape) in enumerate(((Bn * heads * P * P, (Bn, heads, P, P)), (Bn * P * dim, (Bn, P, dim)),
+                                                              (Bn * P * ffn, (Bn, P, ffn)), (Bn * P * dim, (Bn, P, dim))))))
+    ref.zero_grad(set_to_none=True)
+    out_ref = planenet_with_masks(ref, x64, t64, masks, keep)
+    (out_ref * dout.double().cpu()).sum().backward()
+    assert rel(out.detach().cpu().numpy(), out_ref.detach().numpy()) < 2e-5
+    no_mask = planenet_with_masks(ref, x64, t64, None, 1.0).detach().numpy()
+    assert rel(out.detach().cpu().numpy(), no_mask) > 1e-2           # (the masks do something: the test has power)
+    for (k, pk), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+        a, b = pk.grad.cpu().numpy(), pr.grad.numpy()
+        assert np.abs(a - b).max() <= 5e-4 * max(np.abs(b).max(), 1e-6) + 1e-7, k
+    # the same seed and offset: the same masks, bit for bit; the next forward: fresh ones; eval: none
+    rng.manual_seed(seed)
+    with torch.no_grad():
+        again = net(x, t)
+        other = net(x, t)
+    assert torch.equal(again, out.detach()) and not torch.equal(other, again)
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(x, t).cpu().numpy(), no_mask) < 2e-5
