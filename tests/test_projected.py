@@ -96,10 +96,10 @@ def test_projected_se3_diffusion_matches_base_with_identity_projection():
 
 
 # ------------------------------------------------------------------ PlaneNet (reference models.py:185-210)
-def _planenet(golden, device="cpu"):
+def _planenet(golden, device="cpu", dropout=0.0):
     from so3x.models import PlaneNet
     g = golden["planenet"]
-    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"]), dropout=0.0).eval()
+    net = PlaneNet(dim=int(g["dim"]), heads=int(g["heads"]), layers=int(g["layers"]), dropout=dropout).eval()
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
     assert set(net.state_dict().keys()) == set(sd.keys())                      # the reference's checkpoint keys
     net.load_state_dict(sd)
@@ -132,11 +132,12 @@ def test_planenet_as_the_denoiser_of_projected_so3_diffusion(golden):
     """the aircraft task's wiring (aircraft_rotate.py:64-106): a batch of point clouds, one pose each, PointCloudProj as the
     projection, PlaneNet as the denoiser of ProjectedSO3Diffusion -- the noising / target / posterior / noise steps AND the
     transformer (so3x_planenet_fwd / _bwd, through autograd) are this package's kernels.  The network equals the reference's on the GPU too, per-sample clouds equal
-    torch.matmul's batching, a few Adam steps lower the loss, and the reverse loop returns rotations."""
+    torch.matmul's batching, a few Adam steps lower the loss, and the reverse loop returns rotations.  The network is built and trained
+    as the reference does it: torch's default dropout 0.1, `net.train()` (aircraft_rotate.py:66) -- the kernels' own dropout."""
     from so3x.diffusion import ProjectedSO3Diffusion
     from so3x.models import PointCloudProj
     from so3x import backend as B
-    net, g = _planenet(golden, DEV)
+    net, g = _planenet(golden, DEV, dropout=0.1)
     with torch.no_grad():
         out = net(dev(g["x"]), dev(g["t"], torch.int64))
     assert float((out - dev(g["out"])).abs().max()) < 1e-4
@@ -163,7 +164,7 @@ def test_planenet_as_the_denoiser_of_projected_so3_diffusion(golden):
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
-    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0]
+    assert all(np.isfinite(losses)) and min(losses[-5:]) < 0.7 * losses[0]      # (a fresh dropout mask every step)
     net.eval()
     x = process.p_sample_loop((bsz,), proj)
     assert x.shape == (bsz, 3, 3) and torch.isfinite(x).all()
