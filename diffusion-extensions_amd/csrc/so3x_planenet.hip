@@ -626,10 +626,10 @@ bool bf16_supported(const Shape& sh);
 size_t bf16_workspace_bytes(const Shape& sh);
 size_t bf16_stash_bytes(const Shape& sh);
 int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
-                 void* stash, void* workspace, const void* prepared);
+                 void* stash, void* workspace, const void* prepared, const Drop& dr);
 int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg);
 int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, const float* dout, float* dprm,
-                  const void* stash, void* workspace);
+                  const void* stash, void* workspace, const Drop& dr);
 } }
 
 extern "C" {
@@ -678,14 +678,13 @@ int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, cons
   Shape sh{B, P, dim, heads, layers, ffn};
   if (!shape_ok(sh) || layers > 64 || (B && (!params || !x || !t || !out))) return SO3X_ERR_INVALID_ARG;
   if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && !stash)) return SO3X_ERR_INVALID_ARG;   // dropout = a training forward
-  if (dropout_p > 0.f && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (precision == SO3X_PREC_BF16 && !bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
   if (B == 0) return SO3X_OK;
   if (!workspace || workspace_bytes < so3x_planenet_workspace_bytes(B, P, dim, heads, layers, ffn, precision)) return SO3X_ERR_WORKSPACE;
-  if (precision == SO3X_PREC_BF16) return forward_bf16((hipStream_t)s, sh, params, x, t, out, encoding_out, stash, workspace, prepared_weights);
-  const Acts a = stash ? carve_acts(sh, stash, true) : carve_acts(sh, workspace, false);
   const Drop dr{dropout_p, seed, rng_offset};
+  if (precision == SO3X_PREC_BF16) return forward_bf16((hipStream_t)s, sh, params, x, t, out, encoding_out, stash, workspace, prepared_weights, dr);
+  const Acts a = stash ? carve_acts(sh, stash, true) : carve_acts(sh, workspace, false);
   // (with a stash the workspace is idle in the forward: the backward's dP buffer holds a layer's dropped-out probabilities)
   return forward_f32((hipStream_t)s, sh, params, x, t, out, encoding_out, a, dr, dr.on() ? carve_bwd(sh, workspace).dprobs : nullptr);
 }
@@ -696,7 +695,6 @@ int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, cons
   Shape sh{B, P, dim, heads, layers, ffn};
   if (!shape_ok(sh) || layers > 64 || !dparams || (B && (!params || !x || !t || !dout || !stash))) return SO3X_ERR_INVALID_ARG;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return SO3X_ERR_INVALID_ARG;
-  if (dropout_p > 0.f && precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (precision == SO3X_PREC_BF16 && !bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
   if (B == 0) {
@@ -704,7 +702,7 @@ int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, cons
     return e == hipSuccess ? SO3X_OK : (int)e;
   }
   if (!workspace || workspace_bytes < so3x_planenet_workspace_bytes(B, P, dim, heads, layers, ffn, precision)) return SO3X_ERR_WORKSPACE;
-  if (precision == SO3X_PREC_BF16) return backward_bf16((hipStream_t)s, sh, params, x, t, dout, dparams, stash, workspace);
+  if (precision == SO3X_PREC_BF16) return backward_bf16((hipStream_t)s, sh, params, x, t, dout, dparams, stash, workspace, Drop{dropout_p, seed, rng_offset});
   const Acts a = carve_acts(sh, const_cast<void*>(stash), true);
   const BwdBufs w = carve_bwd(sh, workspace);
   return backward_f32((hipStream_t)s, sh, params, x, dout, dparams, a, w, Drop{dropout_p, seed, rng_offset});

@@ -42,10 +42,10 @@ __global__ __launch_bounds__(256) void k_cvt_f32(const bf16* __restrict__ src, f
 // C[M][N] = act(A[M][K] W[N][K]^T + bias[N] (+ R[M][N])),  M % 128 == N % 128 == K % 64 == 0
 constexpr int BM = 128, BN = 128, BK = 64;
 
-template <int EPI>
+template <int EPI, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                       const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
-                                                      int lda, int ldw, int ldc, int ldr) {
+                                                      int lda, int ldw, int ldc, int ldr, const GemmDrop gd) {
   __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (A tile 16 KB | W tile 16 KB); then the fp32 C tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int ntn = N / BN, nwg = ntn * (M / BM);
@@ -117,16 +117,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
     float4 v = *reinterpret_cast<const float4*>(sc + row * 128 + c4);
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     const size_t grow = (size_t)tm * BM + row;
+    if constexpr (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if constexpr (DROP && (EPI == EPI_RELU || EPI == EPI_RESID)) {
+      {   // (four columns per thread: one half of a call's eight flags)
+        const uint64_t e = (uint64_t)grow * N + tn * BN + c4;
+        const uint32_t m = drop_keep8(gd.seed, e >> 3, gd.ctr_hi, gd.thr16) >> (c4 & 4);
+        v.x = m & 1 ? v.x * gd.scale : 0.f; v.y = m & 2 ? v.y * gd.scale : 0.f;
+        v.z = m & 4 ? v.z * gd.scale : 0.f; v.w = m & 8 ? v.w * gd.scale : 0.f;
+      }
+    }
     if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
       const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + grow * ldr + tn * BN + c4);
       if constexpr (EPI == EPI_RESID) {
         v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
       } else {
-        v.x = (float)rv[0] > 0.f ? v.x : 0.f; v.y = (float)rv[1] > 0.f ? v.y : 0.f;
-        v.z = (float)rv[2] > 0.f ? v.z : 0.f; v.w = (float)rv[3] > 0.f ? v.w : 0.f;
+        const float ms = DROP ? gd.scale : 1.f;
+        v.x = (float)rv[0] > 0.f ? v.x * ms : 0.f; v.y = (float)rv[1] > 0.f ? v.y * ms : 0.f;
+        v.z = (float)rv[2] > 0.f ? v.z * ms : 0.f; v.w = (float)rv[3] > 0.f ? v.w * ms : 0.f;
       }
     }
-    if constexpr (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<bf16x4*>(C + grow * ldc + tn * BN + c4) = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
   }
 }
@@ -151,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
 // ds_write_b128 per tile into the epilogue's LDS transposition (below).
 constexpr int TB = 256;
 
-template <int EPI>
+template <int EPI, bool DROP>
 __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                          const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
-                                                         int lda, int ldw, int ldc, int ldr) {
+                                                         int lda, int ldw, int ldc, int ldr, const GemmDrop gd) {
   __shared__ __attribute__((aligned(16))) char smem[131072 + 32768];   // two K-tile buffers | 4 KB per wave for the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int ntn = N / TB, ntiles = ntn * (M / TB), KT = K / 64;
@@ -319,16 +328,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
         const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * c8 + 1) ^ row) << 4));
         float v[8] = {lo[0] + bv0.x, lo[1] + bv0.y, lo[2] + bv0.z, lo[3] + bv0.w, hi[0] + bv1.x, hi[1] + bv1.y, hi[2] + bv1.z, hi[3] + bv1.w};
         const size_t grow = row0 + c * 16 + row;
+        if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (DROP && (EPI == EPI_RELU || EPI == EPI_RESID)) {
+          {   // training-mode dropout: this lane's eight columns are one call's eight flags
+            const uint32_t m = drop_keep8(gd.seed, ((uint64_t)grow * N + ncol) >> 3, gd.ctr_hi, gd.thr16);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (m >> e) & 1 ? v[e] * gd.scale : 0.f;
+          }
+        }
         if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
           const bf16x8 rv = rnext;
           const int nu = 2 * c + rr + 1;                     // the next unit: rows 16 (nu >> 1) + rrow + 8 (nu & 1)
           if (nu < 16) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + 16 * (nu >> 1) + rrow + 8 * (nu & 1)) * ldr + ncol);
 #pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? v[e] : 0.f);
-        }
-        if constexpr (EPI == EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? (DROP ? v[e] * gd.scale : v[e]) : 0.f);
         }
         *reinterpret_cast<bf16x8*>(C + grow * ldc + ncol) =
             bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
@@ -341,33 +357,42 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
 #undef SO3X_H1_END
 }
 
-template <int EPI>
+template <int EPI, bool DROP>
 static int gemm_bf16_t(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
-                       int M, int N, int K) {
+                       int M, int N, int K, const GemmDrop& gd) {
   if (M % TB == 0 && N % TB == 0 && K >= 128 && (M / TB) * (N / TB) >= 384) {   // enough 256 x 256 tiles to keep 256 persistent workgroups busy
     const int ntiles = (M / TB) * (N / TB);
-    hipLaunchKernelGGL((k_gemm256_bf16<EPI>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+    hipLaunchKernelGGL((k_gemm256_bf16<EPI, DROP>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
   } else {
-    hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr);
+    hipLaunchKernelGGL((k_gemm_bf16<EPI, DROP>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
   }
   return check_launch();
 }
 int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
-              int M, int N, int K, int epi) {
+              int M, int N, int K, int epi, GemmDrop gd) {
   if (M % BM || N % BN || K % BK || !bias || ((epi == EPI_RESID || epi == EPI_MASK) && !R)) return SO3X_ERR_INVALID_ARG;
+  // (the dropout forms are their own instantiations: the plain epilogues stay exactly the code they were)
+  const bool drop = epi == EPI_MASK ? gd.scale != 1.f : gd.thr16 != 0;
+#define SO3X_GEMM_CASE(E) \
+  case E: return drop ? gemm_bf16_t<E, true>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, gd) : gemm_bf16_t<E, false>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, gd)
   switch (epi) {
-    case EPI_NONE: return gemm_bf16_t<EPI_NONE>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
-    case EPI_RELU: return gemm_bf16_t<EPI_RELU>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
-    case EPI_RESID: return gemm_bf16_t<EPI_RESID>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
-    case EPI_MASK: return gemm_bf16_t<EPI_MASK>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K);
+    case EPI_NONE: return gemm_bf16_t<EPI_NONE, false>(s, A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, gd);
+    SO3X_GEMM_CASE(EPI_RELU);
+    SO3X_GEMM_CASE(EPI_RESID);
+    SO3X_GEMM_CASE(EPI_MASK);
   }
+#undef SO3X_GEMM_CASE
   return SO3X_ERR_INVALID_ARG;
 }
 
 // ------------------------------------------------------------------------------------------------ attention forward
+// DROP: training-mode dropout of the probabilities (torch: after the softmax).  The keep bits of this wave's 32 queries x the tile's
+// 64 keys (maskq, so3x_planenet_bf16.hpp) arrive by one more LDS-DMA per wave and tile; the row sums (the softmax's denominator)
+// take the plain probabilities, O^T the kept ones, and the 1 / keep goes into the final normalisation.
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse, int P,
-                                                     float sc, float c2) {
-  __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (K tile 16 KB | V tile 16 KB)
+                                                     float sc, float c2, const uint32_t* __restrict__ maskq, float inv_keep) {
+  __shared__ __attribute__((aligned(16))) char smem[65536 + (DROP ? 2048 : 0)];   // 2 x (K tile 16 KB | V tile 16 KB) [| 2 x 4 waves x 64 mask words]
   typedef __attribute__((address_space(3))) s16x4* lds_p;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   int xt, hd, b;
@@ -384,6 +409,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
   }
   const bf16* kbase = qkv + tok0 * (3 * D) + D + hd * DH;
   const bf16* vbase = kbase + D;
+  const uint32_t* mrow = nullptr;   // lane (r, h): word 2 j + h of query r's row of keep bits
+  if constexpr (DROP) mrow = maskq + (((size_t)b * HEADS + hd) * P + (q0 + r < P ? q0 + r : P - 1)) * (P / 32) + h;
   auto stage = [&](int j, int buf) {
     char* sk = smem + buf * 32768;
     char* sv = sk + 16384;
@@ -395,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
       glds16_asm(kbase + off, sk + rowblk * 256);
       glds16_asm(vbase + off, sv + rowblk * 256);
     }
+    if constexpr (DROP) glds4_asm(mrow + 2 * j, smem + 65536 + buf * 1024 + wave * 256);
   };
   f32x16 ot[4];
 #pragma unroll
@@ -470,12 +498,25 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
     f32x16 lt;
 #pragma unroll
     for (int i = 0; i < 16; i++) lt[i] = 0.f;
+    uint32_t wsh[2] = {0u, 0u};   // accumulator register i = key (i & 3) + 8 (i >> 2) + 4 h of its 32-key block: bit i' of word >> 4 h
+    if constexpr (DROP) {
+      const uint32_t* mw = reinterpret_cast<const uint32_t*>(smem + 65536 + BUF * 1024 + wave * 256);
+      wsh[0] = mw[r] >> (4 * h);
+      wsh[1] = mw[r + 32] >> (4 * h);
+    }
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) {
       const int kb = s4 >> 1, s1 = s4 & 1;
-      const bf16x8 pf = {(bf16)st[kb][8 * s1 + 0], (bf16)st[kb][8 * s1 + 1], (bf16)st[kb][8 * s1 + 2], (bf16)st[kb][8 * s1 + 3],
-                         (bf16)st[kb][8 * s1 + 4], (bf16)st[kb][8 * s1 + 5], (bf16)st[kb][8 * s1 + 6], (bf16)st[kb][8 * s1 + 7]};
+      bf16x8 pf = {(bf16)st[kb][8 * s1 + 0], (bf16)st[kb][8 * s1 + 1], (bf16)st[kb][8 * s1 + 2], (bf16)st[kb][8 * s1 + 3],
+                   (bf16)st[kb][8 * s1 + 4], (bf16)st[kb][8 * s1 + 5], (bf16)st[kb][8 * s1 + 6], (bf16)st[kb][8 * s1 + 7]};
       lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lt, 0, 0, 0);
+      if constexpr (DROP) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int i = 8 * s1 + e;
+          pf[e] = (wsh[kb] >> ((i & 3) + 8 * (i >> 2))) & 1u ? pf[e] : (bf16)0.f;
+        }
+      }
 #pragma unroll
       for (int dt = 0; dt < 4; dt++) {
         // two 4-key x 16-column blocks per 16-lane group: keys 16 s4 + 4 h + (0..3) and + 8; columns 32 dt + 16 (g & 1) + (0..15)
@@ -494,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
     if (j + 1 < nt) tile(j + 1, std::integral_constant<int, 1>{});
   }
   const float l_tot = l_run;        // (the MFMA summed over all 64 keys of a tile: both lanes of a query hold the whole sum)
-  const float inv = 1.f / l_tot;
+  const float inv = (DROP ? inv_keep : 1.f) / l_tot;
   // O^T (d in the registers, query on the lane) -> O rows through this wave's 8 KB of the (now idle) K / V buffers: 8-byte writes at
   // [query][d] with the 16-byte unit XORed with the query, 16-byte reads of whole rows, so that a store instruction writes 4 rows
   // x 256 contiguous bytes instead of 32 rows x 16
@@ -515,6 +556,35 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(const bf16* __restrict__ qk
     *reinterpret_cast<bf16x8*>(o + (tok0 + q0 + qq) * D + hd * DH + u * 8) = v;
   }
   if (lse && h == 0) lse[((size_t)b * HEADS + hd) * P + q0 + r] = m_run * sc + logf(l_tot);
+}
+
+// The attention dropout's keep bits of one layer in both layouts (LayerB): one wave per 64 queries x 64 keys, lane = query; element
+// e = ((b H + h) P + q) P + k of the site (Drop), eight consecutive keys per Philox call; the transposed words by 64 ballots.
+__global__ __launch_bounds__(256) void k_attn_mask(uint32_t* __restrict__ maskq, uint32_t* __restrict__ maskk, int P, uint32_t thr16, uint64_t seed,
+                                                   uint64_t ctr_hi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, qt = blockIdx.x, bh = blockIdx.y;
+  const int q = qt * 64 + lane, wpr = P / 32;
+  for (int kt = wave; kt < P / 64; kt += 4) {
+    const uint64_t c0 = ((((uint64_t)bh * P + q) * P) + (uint64_t)kt * 64) >> 3;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      lo |= drop_keep8(seed, c0 + u, ctr_hi, thr16) << (8 * u);
+      hi |= drop_keep8(seed, c0 + 4 + u, ctr_hi, thr16) << (8 * u);
+    }
+    uint32_t* rq = maskq + ((size_t)bh * P + q) * wpr + 2 * kt;
+    rq[0] = lo;
+    rq[1] = hi;
+    unsigned long long mine = 0;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; kk++) {
+      const unsigned long long bal = __ballot((((kk < 32 ? lo : hi) >> (kk & 31)) & 1u) != 0u);
+      if (lane == kk) mine = bal;
+    }
+    uint32_t* rk = maskk + ((size_t)bh * P + kt * 64 + lane) * wpr + 2 * qt;
+    rk[0] = (uint32_t)mine;
+    rk[1] = (uint32_t)(mine >> 32);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ rows
@@ -669,7 +739,7 @@ int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg) {
 }
 
 int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
-                 void* stash, void* workspace, const void* prepared) {
+                 void* stash, void* workspace, const void* prepared, const Drop& dr) {
   const ParamOff po = param_offsets(sh);
   const int64_t N = sh.N(), Np = padded_rows(sh), P = sh.P;
   const bf16* wimg = prepared ? reinterpret_cast<const bf16*>(prepared) : reinterpret_cast<const bf16*>(workspace);
@@ -686,16 +756,23 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
     const LayerB& k = a.layer[l];
     const bf16* h = a.h[l];
     TRY(gemm_bf16(s, h, D, wimg + lo.wqkv, D, k.qkv, 3 * D, prm + lo.bqkv, nullptr, 0, (int)Np, 3 * D, D, EPI_NONE));
-    hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)((P + 127) / 128 * HEADS * sh.B)), dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2);
+    const dim3 ag((unsigned)((P + 127) / 128 * HEADS * sh.B));
+    if (dr.on()) {   // (a training forward: the stash is there)
+      hipLaunchKernelGGL(k_attn_mask, dim3((unsigned)(P / 64), (unsigned)(sh.B * HEADS)), dim3(256), 0, s, k.maskq, k.maskk, (int)P, dr.thr16(), dr.seed,
+                         dr.ctr_hi(l, DROP_ATTN));
+      hipLaunchKernelGGL(k_attn_fwd<true>, ag, dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2, k.maskq, dr.inv_keep());
+    } else {
+      hipLaunchKernelGGL(k_attn_fwd<false>, ag, dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2, (const uint32_t*)nullptr, 1.f);
+    }
     TRY(check_launch());
     if (Np > N) {   // the pad rows of the attention output feed the next GEMM: keep them finite (zero)
       hipError_t e = hipMemsetAsync(k.o + N * D, 0, (size_t)(Np - N) * D * sizeof(bf16), s);
       if (e != hipSuccess) return (int)e;
     }
-    TRY(gemm_bf16(s, k.o, D, wimg + lo.wo, D, k.r1, D, prm + lo.bo, h, D, (int)Np, D, D, EPI_RESID));
+    TRY(gemm_bf16(s, k.o, D, wimg + lo.wo, D, k.r1, D, prm + lo.bo, h, D, (int)Np, D, D, EPI_RESID, gemm_drop(dr, l, DROP_BLOCK1)));
     hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, k.r1, k.x1, k.st1, prm + lo.g1, prm + lo.be1, Np, 1e-5f);
-    TRY(gemm_bf16(s, k.x1, D, wimg + lo.w1, D, k.f, FF, prm + lo.b1, nullptr, 0, (int)Np, FF, D, EPI_RELU));
-    TRY(gemm_bf16(s, k.f, FF, wimg + lo.w2, FF, k.r2, D, prm + lo.b2, k.x1, D, (int)Np, D, FF, EPI_RESID));
+    TRY(gemm_bf16(s, k.x1, D, wimg + lo.w1, D, k.f, FF, prm + lo.b1, nullptr, 0, (int)Np, FF, D, EPI_RELU, gemm_drop(dr, l, DROP_FFN)));
+    TRY(gemm_bf16(s, k.f, FF, wimg + lo.w2, FF, k.r2, D, prm + lo.b2, k.x1, D, (int)Np, D, FF, EPI_RESID, gemm_drop(dr, l, DROP_BLOCK2)));
     hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, k.r2, a.h[l + 1], k.st2, prm + lo.g2, prm + lo.be2, Np, 1e-5f);
     TRY(check_launch());
   }

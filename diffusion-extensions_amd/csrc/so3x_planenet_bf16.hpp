@@ -2,6 +2,7 @@
 // (so3x_planenet_bf16.hip) and the backward (so3x_planenet_bf16_bwd.hip) of the bf16 form of PlaneNet.
 #pragma once
 #include "so3x_planenet.hpp"
+#include "so3x_math.hpp"
 
 namespace so3x {
 namespace plane {
@@ -32,6 +33,16 @@ __device__ __forceinline__ void glds4_asm(const void* src, const void* dst) {
   typedef __attribute__((address_space(3))) const char* lds_cp;
   const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_cp)dst);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(d) : "memory", "m0");
+}
+
+// keep bits of the eight elements 8 c .. 8 c + 7 of a dropout site: bit j = piece j (words x, y, z, w; low half first) >= thr16
+__device__ __forceinline__ uint32_t drop_keep8(uint64_t seed, uint64_t c, uint64_t ctr_hi, uint32_t thr16) {
+  const Philox4 r = philox4x32_10(seed, c, ctr_hi);
+  const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) m |= (((u[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) >= thr16 ? 1u : 0u) << j;
+  return m;
 }
 
 constexpr int D = 512, HEADS = 4, DH = 128, FF = 2048, D2 = 256;
@@ -65,7 +76,10 @@ constexpr int PSLICE = 256;   // points per partial sum of the pooling reduction
 // ------------------------------------------------------------------------------------------------ buffers
 inline int64_t padded_rows(const Shape& s) { return (s.N() + 127) / 128 * 128; }
 
-struct LayerB { bf16 *qkv, *o, *r1, *x1, *f, *r2; float *st1, *st2, *lse; };
+// maskq / maskk (training stash only): the attention dropout's keep bits of a layer, [B][H][P][P / 32] words -- bit (k & 31) of word
+// k >> 5 in row q of maskq, and the transpose (bit of q in row k) in maskk: the kernels with the query on the lane read the
+// one, those with the key on the lane the other (written by k_attn_mask when a forward runs with dropout)
+struct LayerB { bf16 *qkv, *o, *r1, *x1, *f, *r2; float *st1, *st2, *lse; uint32_t *maskq, *maskk; };
 struct ActsB {
   float* pre;              // [N][256] fp32 SIREN pre-activations (kept for the backward only)
   bf16* sn;                // [Npad][256]
@@ -99,6 +113,11 @@ inline ActsB carve_b(const Shape& s, void* mem, bool per_layer) {
       k.st1 = c.take<float>(Np * 2);
       k.st2 = c.take<float>(Np * 2);
       k.lse = c.take<float>((size_t)s.N() * HEADS);
+      k.maskq = k.maskk = nullptr;
+      if (per_layer) {
+        k.maskq = c.take<uint32_t>((size_t)s.B * HEADS * s.P * (s.P / 32));
+        k.maskk = c.take<uint32_t>((size_t)s.B * HEADS * s.P * (s.P / 32));
+      }
     } else {
       a.layer[l] = a.layer[0];
     }
@@ -120,8 +139,19 @@ inline size_t wimg_bytes(const Shape& s) { return up((size_t)param_offsets(s).to
 // C[M][N] = epilogue(A[M][K] W[N][K]^T + bias[N]),  M % 128 == N % 128 == K % 64 == 0; every operand bf16 row-major, bias fp32
 //   EPI_NONE: C = acc + bias;  EPI_RELU: max(., 0);  EPI_RESID: + R[M][N];  EPI_MASK: (R[M][N] > 0) ? acc + bias : 0
 enum Epi { EPI_NONE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_MASK = 3 };
+// Training-mode dropout inside an epilogue (Drop, so3x_planenet.hpp; the element index is row * N + column of the LOGICAL [M][N]
+// matrix): EPI_RELU and EPI_RESID drop (and rescale by `scale` = 1 / keep) the value acc + bias [after the ReLU] -- EPI_RESID before
+// the residual is added --, EPI_MASK multiplies what passes by `scale`.  thr16 == 0 and scale == 1: the plain epilogues.
+struct GemmDrop {
+  uint32_t thr16 = 0;
+  float scale = 1.f;
+  uint64_t seed = 0, ctr_hi = 0;
+};
+inline GemmDrop gemm_drop(const Drop& dr, int layer, int site) {
+  return dr.on() ? GemmDrop{dr.thr16(), dr.inv_keep(), dr.seed, dr.ctr_hi(layer, site)} : GemmDrop{};
+}
 int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
-              int M, int N, int K, int epi);
+              int M, int N, int K, int epi, GemmDrop gd = GemmDrop{});
 
 }  // namespace plane
 }  // namespace so3x

@@ -194,10 +194,14 @@ __global__ __launch_bounds__(256) void k_attn_delta(const bf16* __restrict__ o, 
 
 // dQ: one wave = 32 queries (lane pair per query, as the forward), 64-key tiles of K and V by LDS-DMA.
 //   S^T = K Q^T, P^T = exp(S^T / sqrt(dh) - lse_q), dP^T = V dO^T, dS^T = P^T (dP^T - delta_q) / sqrt(dh), dQ^T += K^T dS^T
+// DROP (all three kernels): the forward ran with dropout on the probabilities; dP is masked and rescaled (dQ, dK), P is masked and
+// dV rescaled -- keep bits from the forward's maskq (query on the lane) / maskk (key on the lane), staged per tile like the operands
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__ qkv, const bf16* __restrict__ dO, const float* __restrict__ lse2v,
-                                                        const float* __restrict__ delta, bf16* __restrict__ dqkv, int P, float sc, float c2) {
-  __shared__ __attribute__((aligned(16))) char smem[65536];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+                                                        const float* __restrict__ delta, bf16* __restrict__ dqkv, int P, float sc, float c2,
+                                                        const uint32_t* __restrict__ maskq, float inv_keep) {
+  __shared__ __attribute__((aligned(16))) char smem[65536 + (DROP ? 2048 : 0)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   int xt, hd, b;
   attn_tile((P + 127) / 128, xt, hd, b);
   const int q0 = xt * 128 + wave * 32;
@@ -217,6 +221,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__
   const float dl = delta[((size_t)b * HEADS + hd) * P + qr];
   const bf16* kbase = qkv + tok0 * (3 * D) + D + hd * DH;
   const bf16* vbase = kbase + D;
+  const uint32_t* mrow = nullptr;
+  if constexpr (DROP) mrow = maskq + (((size_t)b * HEADS + hd) * P + qr) * (P / 32) + h;
   auto stage = [&](int j, int buf) {
     char* sk = smem + buf * 32768;
     char* sv = sk + 16384;
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__
       glds16_asm(kbase + off, sk + rowblk * 256);
       glds16_asm(vbase + off, sv + rowblk * 256);
     }
+    if constexpr (DROP) glds4_asm(mrow + 2 * j, smem + 65536 + buf * 1024 + wave * 256);
   };
   f32x16 dq[4];
 #pragma unroll
@@ -258,12 +265,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__
       }
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++)
+    for (int kb = 0; kb < 2; kb++) {
+      uint32_t wsh = 0u;
+      if constexpr (DROP) wsh = reinterpret_cast<const uint32_t*>(smem + 65536 + (j & 1) * 1024 + wave * 256)[r + 32 * kb] >> (4 * h);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][i], c2, -lse2));
-        st[kb][i] = pv * (dp[kb][i] - dl) * sc;
+        float dpv = dp[kb][i];
+        if constexpr (DROP) dpv = (wsh >> ((i & 3) + 8 * (i >> 2))) & 1u ? dpv * inv_keep : 0.f;
+        st[kb][i] = pv * (dpv - dl) * sc;
       }
+    }
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) {
       const int kb = s4 >> 1, s1 = s4 & 1;
@@ -296,11 +308,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16* __restrict__
 //   dV^T += dO^T P, dK^T += Q^T dS    (A operands = transposed reads of the same dO / Q tiles, B = the accumulators as they sit)
 // (One launch per output: holding dK^T AND dV^T -- 128 accumulator registers -- beside both operand sets does not fit 256 registers;
 //  WHICH = 0: dV, from S and P only; WHICH = 1: dK, from S, dP and dS.)
-template <int WHICH>
+template <int WHICH, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict__ qkv, const bf16* __restrict__ dO, const float* __restrict__ lse2v,
-                                                         const float* __restrict__ delta, bf16* __restrict__ dqkv, int P, float sc, float c2) {
-  __shared__ __attribute__((aligned(16))) char smem[65536 + 1024];   // 2 x (Q tile 16 KB | dO tile 16 KB) | 2 x (lse2[64] | delta[64])
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+                                                         const float* __restrict__ delta, bf16* __restrict__ dqkv, int P, float sc, float c2,
+                                                         const uint32_t* __restrict__ maskk, float inv_keep) {
+  // 2 x (Q tile 16 KB | dO tile 16 KB) | 2 x (lse2[64] | delta[64]) [| 2 x 4 waves x 64 mask words]
+  __shared__ __attribute__((aligned(16))) char smem[65536 + 1024 + (DROP ? 2048 : 0)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   int xt, hd, b;
   attn_tile((P + 127) / 128, xt, hd, b);
   const int k0 = xt * 128 + wave * 32;
@@ -319,6 +333,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
   const bf16* dbase = dO + tok0 * D + hd * DH;
   const float* lrow = lse2v + ((size_t)b * HEADS + hd) * P;
   const float* drow = delta + ((size_t)b * HEADS + hd) * P;
+  const uint32_t* mrow = nullptr;   // lane (r, h): word 2 j + h of key r's row of keep bits (one bit per query)
+  if constexpr (DROP) mrow = maskk + (((size_t)b * HEADS + hd) * P + kr) * (P / 32) + h;
   auto stage = [&](int j, int buf) {
     char* sq = smem + buf * 32768;
     char* sd = sq + 16384;
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
     char* sl = smem + 65536 + buf * 512;
     if (wave == 0) glds4_asm(lrow + j * 64 + lane, sl);
     if (wave == 1) glds4_asm(drow + j * 64 + lane, sl + 256);
+    if constexpr (DROP) glds4_asm(mrow + 2 * j, smem + 65536 + 1024 + buf * 1024 + wave * 256);
   };
   f32x16 acc[4];   // dV^T or dK^T: [d][key]
 #pragma unroll
@@ -363,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
         if constexpr (WHICH == 1) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(sd + off), vf[ks], dp, 0, 0, 0);
       }
       // accumulator register i = query row (i & 3) + 8 (i >> 2) + 4 h of the block: its lse / delta from the tile's LDS copy
+      uint32_t wsh = 0u;
+      if constexpr (DROP) wsh = reinterpret_cast<const uint32_t*>(smem + 65536 + 1024 + (j & 1) * 1024 + wave * 256)[r + 32 * qb] >> (4 * h);
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         const float4 l4 = *reinterpret_cast<const float4*>(sl + qb * 32 + 8 * g4 + 4 * h);
@@ -372,7 +391,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
         for (int e = 0; e < 4; e++) {
           const int i = 4 * g4 + e;
           const float pv = __builtin_amdgcn_exp2f(fmaf(s_[i], c2, -lv[e]));
-          s_[i] = WHICH == 1 ? pv * (dp[i] - dv[e]) * sc : pv;    // dS or P: the B operand of the accumulation below
+          bool keep = true;
+          if constexpr (DROP) keep = (wsh >> ((i & 3) + 8 * (i >> 2))) & 1u;
+          if constexpr (WHICH == 1) s_[i] = pv * ((DROP ? (keep ? dp[i] * inv_keep : 0.f) : dp[i]) - dv[e]) * sc;   // dS
+          else s_[i] = keep ? pv : 0.f;                                                                            // (kept) P
         }
       }
 #pragma unroll
@@ -395,20 +417,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
   }
   if (k0 >= P) return;
   bf16* krow = dqkv + (tok0 + k0 + r) * (3 * D) + (WHICH == 1 ? D : 2 * D) + hd * DH + 4 * h;
+  const float os = (DROP && WHICH == 0) ? inv_keep : 1.f;   // dV = (kept P / keep)^T dO
 #pragma unroll
   for (int dt = 0; dt < 4; dt++)
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++)
       *reinterpret_cast<bf16x4*>(krow + 32 * dt + 8 * g4) =
-          bf16x4{(bf16)acc[dt][4 * g4], (bf16)acc[dt][4 * g4 + 1], (bf16)acc[dt][4 * g4 + 2], (bf16)acc[dt][4 * g4 + 3]};
+          bf16x4{(bf16)(acc[dt][4 * g4] * os), (bf16)(acc[dt][4 * g4 + 1] * os), (bf16)(acc[dt][4 * g4 + 2] * os), (bf16)(acc[dt][4 * g4 + 3] * os)};
 }
 
 // ------------------------------------------------------------------------------------------------ rows and reductions
 // LayerNorm backward over 512-wide bf16 rows: dr = rstd (dy gamma - mean(dy gamma) - xhat mean(dy gamma xhat)); per workgroup (64
 // rows) the partial column sums part[blk][0..511] = sum dy xhat (d gamma), part[blk][512..1023] = sum dy (d beta)
 constexpr int LNB_ROWS = 64;
+// drm (optional): dr through the dropout of the block whose output the LayerNorm's input added to its residual (the gradient that
+// block sees; dr itself goes on along the residual)
 __global__ __launch_bounds__(256) void k_ln_bwd_bf16(const bf16* __restrict__ dy, const bf16* __restrict__ r, const float* __restrict__ stats,
-                                                     const float* __restrict__ gamma, bf16* __restrict__ dr, float* __restrict__ part, int64_t rows) {
+                                                     const float* __restrict__ gamma, bf16* __restrict__ dr, float* __restrict__ part, int64_t rows,
+                                                     bf16* __restrict__ drm, const GemmDrop gd) {
   __shared__ float red[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 8), g1 = *reinterpret_cast<const float4*>(gamma + lane * 8 + 4);
@@ -437,9 +463,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd_bf16(const bf16* __restrict__ dy
     c1 = wave_sum(c1) * (1.f / D);
     c2 = wave_sum(c2) * (1.f / D);
     bf16x8 out;
+    float ov[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = (bf16)(rstd * (gy[i] - c1 - xh[i] * c2));
+    for (int i = 0; i < 8; i++) { ov[i] = rstd * (gy[i] - c1 - xh[i] * c2); out[i] = (bf16)ov[i]; }
     *reinterpret_cast<bf16x8*>(dr + row * D + lane * 8) = out;
+    if (drm) {
+      const uint32_t m = drop_keep8(gd.seed, (uint64_t)row * (D / 8) + lane, gd.ctr_hi, gd.thr16);
+#pragma unroll
+      for (int i = 0; i < 8; i++) out[i] = (m >> i) & 1u ? (bf16)(ov[i] * gd.scale) : (bf16)0.f;
+      *reinterpret_cast<bf16x8*>(drm + row * D + lane * 8) = out;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -589,7 +622,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_final(const float* __restrict
 
 // ------------------------------------------------------------------------------------------------ scratch and the plan
 struct BwdB {
-  bf16 *dA, *dB, *dF, *dqkv, *dO, *ds;
+  bf16 *dA, *dB, *dF, *dqkv, *dO, *ds, *dM;
   float *delta, *lse2, *g, *dpooled, *dxs, *slab, *part, *zeros;
   size_t bytes;
 };
@@ -603,6 +636,7 @@ inline BwdB carve_bwd_b(const Shape& s, void* mem) {
   b.dqkv = c.take<bf16>(Np * 3 * D);
   b.dO = c.take<bf16>(Np * D);
   b.ds = c.take<bf16>(Np * D2);
+  b.dM = c.take<bf16>(Np * D);   // a block's output gradient behind its dropout (training with dropout)
   b.delta = c.take<float>(N * HEADS);
   b.lse2 = c.take<float>(N * HEADS);
   b.g = c.take<float>(N);
@@ -633,7 +667,7 @@ size_t bf16_workspace_bytes(const Shape& s) {
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t*, const float* dout, float* dprm,
-                  const void* stash, void* workspace) {
+                  const void* stash, void* workspace, const Drop& dr) {
   const ParamOff po = param_offsets(sh);
   const int64_t N = sh.N(), Np = padded_rows(sh), P = sh.P;
   const int Bn = (int)sh.B;
@@ -674,26 +708,39 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
     const LayerB& k = a.layer[l];
     const bf16* h = a.h[l];
     // norm2: dcur = d h_{l+1} -> dalt = d r2;  d gamma2 | d beta2 are adjacent in the parameter buffer
-    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r2, k.st2, prm + lo.g2, dalt, w.part, Np);
+    bf16* const dM = dr.on() ? w.dM : nullptr;
+    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r2, k.st2, prm + lo.g2, dalt, w.part, Np, dM, gemm_drop(dr, l, DROP_BLOCK2));
     hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g2);
     TRY(check_launch());
-    // feed-forward: r2 = x1 + relu(x1 W1^T + b1) W2^T + b2
-    TRY(gemm_tn(s, dalt, D, k.f, FF, dprm + lo.w2, (int)Np, D, FF, w.slab, dprm + lo.b2));   // (+ d b2: rows >= N of every dY are zero)
-    TRY(gemm_bf16(s, dalt, D, wT + lo.w2, D, w.dF, FF, w.zeros, k.f, FF, (int)Np, FF, D, EPI_MASK));          // dZ = (dr2 W2) o (f > 0)
+    // feed-forward: r2 = x1 + [dropout] (relu(x1 W1^T + b1) [dropout]) W2^T + b2; dy2 = the gradient behind the output dropout
+    const bf16* dy2 = dr.on() ? w.dM : dalt;
+    GemmDrop relu_scale;   // the hidden activations' dropout: f is stored dropped out, so (f > 0) is "active and kept"
+    relu_scale.scale = dr.on() ? dr.inv_keep() : 1.f;
+    TRY(gemm_tn(s, dy2, D, k.f, FF, dprm + lo.w2, (int)Np, D, FF, w.slab, dprm + lo.b2));   // (+ d b2: rows >= N of every dY are zero)
+    TRY(gemm_bf16(s, dy2, D, wT + lo.w2, D, w.dF, FF, w.zeros, k.f, FF, (int)Np, FF, D, EPI_MASK, relu_scale));   // dZ = (dy2 W2) o (f > 0)
     TRY(gemm_tn(s, w.dF, FF, k.x1, D, dprm + lo.w1, (int)Np, FF, D, w.slab, dprm + lo.b1));
     TRY(gemm_bf16(s, w.dF, FF, wT + lo.w1, FF, dcur, D, w.zeros, dalt, D, (int)Np, D, FF, EPI_RESID));        // dcur = d x1 = dr2 + dZ W1
     // norm1: dcur = d x1 -> dalt = d r1
-    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r1, k.st1, prm + lo.g1, dalt, w.part, Np);
+    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r1, k.st1, prm + lo.g1, dalt, w.part, Np, dM, gemm_drop(dr, l, DROP_BLOCK1));
     hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g1);
     TRY(check_launch());
-    // attention block: r1 = h + softmax(Q K^T / sqrt(dh)) V Wo^T + bo
-    TRY(gemm_tn(s, dalt, D, k.o, D, dprm + lo.wo, (int)Np, D, D, w.slab, dprm + lo.bo));
-    TRY(gemm_bf16(s, dalt, D, wT + lo.wo, D, w.dO, D, w.zeros, nullptr, 0, (int)Np, D, D, EPI_NONE));
+    // attention block: r1 = h + [dropout] (softmax(Q K^T / sqrt(dh)) [dropout] V Wo^T + bo)
+    const bf16* dy1 = dr.on() ? w.dM : dalt;
+    TRY(gemm_tn(s, dy1, D, k.o, D, dprm + lo.wo, (int)Np, D, D, w.slab, dprm + lo.bo));
+    TRY(gemm_bf16(s, dy1, D, wT + lo.wo, D, w.dO, D, w.zeros, nullptr, 0, (int)Np, D, D, EPI_NONE));
     hipLaunchKernelGGL(k_attn_delta, dim3(blocks_for(N * HEADS, 16)), dim3(256), 0, s, k.o, w.dO, k.lse, w.delta, w.lse2, N, (int)P);
     const dim3 ag((unsigned)((P + 127) / 128 * HEADS * sh.B));
-    hipLaunchKernelGGL(k_attn_bwd_dq, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2);
-    hipLaunchKernelGGL(k_attn_bwd_dkv<0>, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2);
-    hipLaunchKernelGGL(k_attn_bwd_dkv<1>, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2);
+    if (dr.on()) {
+      const float ik = dr.inv_keep();
+      hipLaunchKernelGGL(k_attn_bwd_dq<true>, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2, k.maskq, ik);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<0, true>), ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2, k.maskk, ik);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<1, true>), ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2, k.maskk, ik);
+    } else {
+      const uint32_t* nm = nullptr;
+      hipLaunchKernelGGL(k_attn_bwd_dq<false>, ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2, nm, 1.f);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<0, false>), ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2, nm, 1.f);
+      hipLaunchKernelGGL((k_attn_bwd_dkv<1, false>), ag, dim3(256), 0, s, k.qkv, w.dO, w.lse2, w.delta, w.dqkv, (int)P, sc, c2, nm, 1.f);
+    }
     TRY(check_launch());
     if (Np > N) {
       e = hipMemsetAsync(w.dqkv + N * 3 * D, 0, (size_t)(Np - N) * 3 * D * sizeof(bf16), s);

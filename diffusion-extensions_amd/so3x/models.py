@@ -136,8 +136,8 @@ class PlaneNet(FlatParamsMixin, nn.Module):
     views of.  precision "fp32": every product on the exact-fp32 matrix-core instruction, any width; "bf16": the aircraft task's
     shape (dim 512, 4 heads, points a multiple of 64) with bf16 operands and activations.  `dropout` (torch's default 0.1, which
     the reference trains with: aircraft_rotate.py:66) is applied in training mode at nn.TransformerEncoderLayer's four sites by
-    the exact-fp32 kernels, from counter-based masks keyed by (so3x.rng seed, a fresh offset per forward) that the backward
-    regenerates; the bf16 form has no dropout yet and refuses a training-mode forward with dropout > 0 rather than fall back to torch.
+    the kernels of either precision, from counter-based masks keyed by (so3x.rng seed, a fresh offset per forward) that the
+    backward regenerates -- the two precisions draw the SAME masks.
     `forward_torch` runs the torch modules instead -- an explicit cross-check for tests, never taken implicitly.
 
     Returns [B, 3]: one prediction per cloud.  (The reference's forward ends in `out[..., 0, :]` on that [B, 3] tensor,
@@ -180,9 +180,6 @@ class PlaneNet(FlatParamsMixin, nn.Module):
         from . import rng as _rng
         drop = (0.0, 0, 0)
         if self.training and self.dropout > 0:
-            if self.precision == "bf16":
-                raise NotImplementedError("so3x: the bf16 PlaneNet kernels have no dropout yet; train with precision='fp32' (dropout as in "
-                                          "the reference) or dropout=0 -- a silent fallback to torch's modules is not offered")
             drop = (float(self.dropout), _rng.seed(), _rng.next_offset())   # a fresh mask set per training-mode forward
         if want_encoding:
             out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_stash=drop[0] > 0, want_encoding=True,

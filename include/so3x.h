@@ -329,7 +329,8 @@ int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int
  *   [B][heads][P][P] / [B P][dim] / [B P][ffn] / [B P][dim]):
  *   a function of (seed, rng_offset) only, so so3x_planenet_bwd -- given the SAME three values -- regenerates it.  torch's own
  *   mask stream depends on its kernels' launch geometry and cannot be matched; parity is against the reference's modules run
- *   with these masks.  Exact-fp32 form; the bf16 form returns SO3X_ERR_UNSUPPORTED for dropout_p > 0. */
+ *   with these masks.  Both precisions draw the same masks (the bf16 form applies them in its GEMM epilogues and, through keep
+ *   bits one kernel writes into the stash per layer, inside its attention kernels). */
 int64_t so3x_planenet_param_count(int dim, int heads, int layers, int ffn);
 size_t so3x_planenet_workspace_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);
 size_t so3x_planenet_stash_bytes(int64_t B, int64_t P, int dim, int heads, int layers, int ffn, int precision);

@@ -83,16 +83,6 @@ def test_cpu_tensors_are_refused(golden):
         net(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
 
 
-def test_bf16_training_mode_with_dropout_is_refused_not_rerouted():
-    """the exact-fp32 form applies the reference's training-mode dropout (GPU tests below); the bf16 form has none yet and says so
-    instead of running torch's modules"""
-    from so3x.models import PlaneNet
-    net = PlaneNet(dim=32, heads=4, layers=1, precision="bf16")      # torch's default dropout 0.1, as the reference builds it
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 8, 3), torch.zeros(1, dtype=torch.long))
-
-
 def philox4x32_10(seed, ctr_lo, ctr_hi):
     """Philox4x32-10 as csrc/so3x_math.hpp runs it (key = seed, counter = (ctr_lo, ctr_hi)), vectorised over ctr_lo: four uint32 words"""
     M = np.uint64(0xFFFFFFFF)
@@ -416,3 +406,41 @@ def test_training_mode_dropout_vs_the_reference_arithmetic_with_the_same_masks(g
     net.eval()
     with torch.no_grad():
         assert rel(net(x, t).cpu().numpy(), no_mask) < 2e-5
+
+
+@pytest.mark.gpu
+def test_bf16_dropout_draws_the_masks_of_the_fp32_form(golden):
+    """Training mode at the aircraft task's width: the bf16 kernels (dropout in the GEMM epilogues, keep bits inside the attention
+    kernels) against the exact-fp32 kernels -- pinned above on the reference's arithmetic -- on the SAME (seed, offset): output and
+    every parameter gradient to bf16 accuracy, on a small-batch shape (128-wide tiles), on one with pad rows, and at 24 x 2048
+    points, where every product runs on the persistent 256-wide kernel (its own epilogue code)."""
+    from so3x import rng
+    net32, _ = full_net(golden, "fp32")
+    net16, _ = full_net(golden, "bf16")
+    for net in (net32, net16):
+        net.dropout = 0.1
+    net32, net16 = net32.to(DEV).train(), net16.to(DEV).train()
+    gen = torch.Generator().manual_seed(13)
+    for Bn, P in ((2, 128), (3, 192), (24, 2048)):
+        x = (torch.randn(Bn, P, 3, generator=gen) * 0.5).to(DEV)
+        t = torch.randint(0, 1000, (Bn,), generator=gen).to(DEV)
+        dout = torch.randn(Bn, 3, generator=gen).to(DEV)
+        outs = []
+        for net in (net32, net16):
+            rng.manual_seed(99)
+            net.zero_grad(set_to_none=True)
+            out = net(x, t)
+            (out * dout).sum().backward()
+            outs.append(out.detach())
+        net32.eval()
+        with torch.no_grad():
+            plain = net32(x, t)
+        net32.train()
+        scale = float(outs[0].abs().max())
+        assert float((outs[0] - outs[1]).abs().max()) < 3e-2 * scale
+        assert float((outs[0] - plain).abs().max()) > 4 * float((outs[0] - outs[1]).abs().max())      # (the dropout is visible: the check has power)
+        ref = dict(net32.named_parameters())
+        for (k, a), (_, b) in zip(net32.named_parameters(), net16.named_parameters()):
+            sc_ = ref["out_net.0.pool.0.weight"].grad.norm() if k == "out_net.0.pool.0.bias" else a.grad.norm()
+            rel_ = float((a.grad - b.grad).norm() / (sc_ + 1e-30))
+            assert rel_ < 5e-2 and torch.isfinite(b.grad).all(), (Bn, P, k, rel_)
