@@ -623,6 +623,7 @@ using namespace so3x::plane;
 namespace so3x { namespace plane {
 // so3x_planenet_bf16.hip
 bool bf16_supported(const Shape& sh);
+size_t bf16_weights_bytes(const Shape& sh);
 size_t bf16_workspace_bytes(const Shape& sh);
 size_t bf16_stash_bytes(const Shape& sh);
 int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
@@ -658,7 +659,7 @@ size_t so3x_planenet_workspace_bytes(int64_t B, int64_t P, int dim, int heads, i
 size_t so3x_planenet_weights_bytes(int dim, int heads, int layers, int ffn, int precision) {
   Shape sh{1, 64, dim, heads, layers, ffn};
   if (!shape_ok(sh) || layers > 64 || precision != SO3X_PREC_BF16 || !bf16_supported(sh)) return 0;
-  return up((size_t)param_offsets(sh).total * 2);
+  return bf16_weights_bytes(sh);
 }
 
 int so3x_planenet_prepare(so3x_stream_t s, const float* params, int dim, int heads, int layers, int ffn, int precision, void* weights,

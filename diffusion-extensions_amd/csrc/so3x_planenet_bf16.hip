@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
 // ds_write_b128 per tile into the epilogue's LDS transposition (below).
 constexpr int TB = 256;
 
-template <int EPI, bool DROP>
+template <int EPI, bool DROP, int LNM = LN_NONE>
 __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                          const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
-                                                         int lda, int ldw, int ldc, int ldr, const GemmDrop gd) {
+                                                         int lda, int ldw, int ldc, int ldr, const GemmDrop gd, const GemmLN ln = GemmLN{}) {
+  constexpr int NST = LNM >= LN_STAT ? 32 : 16;   // stores per wave and tile (the statistics are one more per 8-row unit)
   __shared__ __attribute__((aligned(16))) char smem[131072 + 32768];   // two K-tile buffers | 4 KB per wave for the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int ntn = N / TB, ntiles = ntn * (M / TB), KT = K / 64;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
       // (its A halves ahead of the epilogue, below), so they may stay in flight with the W pieces staged just now: a wait that
       // had to retire them stalls every CU on the chip-wide burst of C at each tile boundary (measured: 25 % of the kernel).
       if (after_store) {
-        if (more) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST + 4) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
         after_store = false;
       } else {
         if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -310,6 +311,26 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
     const size_t row0 = (size_t)tm * TB + wm * 128;
     bf16x8 rnext;
     if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + rrow) * ldr + ncol);
+    // LayerNorm folded in (GemmLN): the per-column vectors of this lane's eight columns, the rows' statistics one unit ahead
+    float sv[8], gv[8], ev[8];
+    if constexpr (LNM == LN_A) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ln.svec + ncol), a1 = *reinterpret_cast<const float4*>(ln.svec + ncol + 4);
+      sv[0] = a0.x; sv[1] = a0.y; sv[2] = a0.z; sv[3] = a0.w; sv[4] = a1.x; sv[5] = a1.y; sv[6] = a1.z; sv[7] = a1.w;
+    }
+    if constexpr (LNM == LN_RESID) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ln.gamma + ncol), a1 = *reinterpret_cast<const float4*>(ln.gamma + ncol + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(ln.beta + ncol), b1 = *reinterpret_cast<const float4*>(ln.beta + ncol + 4);
+      gv[0] = a0.x; gv[1] = a0.y; gv[2] = a0.z; gv[3] = a0.w; gv[4] = a1.x; gv[5] = a1.y; gv[6] = a1.z; gv[7] = a1.w;
+      ev[0] = b0.x; ev[1] = b0.y; ev[2] = b0.z; ev[3] = b0.w; ev[4] = b1.x; ev[5] = b1.y; ev[6] = b1.z; ev[7] = b1.w;
+    }
+    // the statistics of this wave's 128 rows: ONE load per tile (lane l: rows l and 64 + l), handed to the lanes that need a row by
+    // ds_bpermute -- a load per 8-row unit sits behind that unit's C store in the vmcnt order, and waiting for it retires the
+    // store (measured: +2 us per tile)
+    float2 st_lo = {0.f, 1.f}, st_hi = {0.f, 1.f};
+    if constexpr (LNM == LN_A || LNM == LN_RESID) {
+      st_lo = *reinterpret_cast<const float2*>(ln.rowstat + 2 * (row0 + lane));
+      st_hi = *reinterpret_cast<const float2*>(ln.rowstat + 2 * (row0 + 64 + lane));
+    }
 #pragma unroll
     for (int c = 0; c < 8; c++) {      // 16-row chunks: rh = c >> 2, mi = c & 3
       const int rh = c >> 2, mi = c & 3;
@@ -328,6 +349,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
         const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * c8 + 1) ^ row) << 4));
         float v[8] = {lo[0] + bv0.x, lo[1] + bv0.y, lo[2] + bv0.z, lo[3] + bv0.w, hi[0] + bv1.x, hi[1] + bv1.y, hi[2] + bv1.z, hi[3] + bv1.w};
         const size_t grow = row0 + c * 16 + row;
+        const int nu = 2 * c + rr + 1;                       // the next unit: rows 16 (nu >> 1) + rrow + 8 (nu & 1)
+        float2 stc = {0.f, 1.f};
+        if constexpr (LNM == LN_A || LNM == LN_RESID) {
+          const int src = (c * 16 + row) & 63;               // row c * 16 + row of the wave's 128: lane src, low or high half by c
+          stc.x = __shfl(c >= 4 ? st_hi.x : st_lo.x, src);
+          stc.y = __shfl(c >= 4 ? st_hi.y : st_lo.y, src);
+        }
+        if constexpr (LNM == LN_A) {   // v = rstd (r W'^T) - rstd mean s + c   (bias = c)
+          const float acc8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const float bc[8] = {bv0.x, bv0.y, bv0.z, bv0.w, bv1.x, bv1.y, bv1.z, bv1.w};
+          const float nrm = -stc.y * stc.x;
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = fmaf(stc.y, acc8[e], fmaf(nrm, sv[e], bc[e]));
+        }
         if constexpr (EPI == EPI_RELU) {
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
@@ -341,10 +376,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
         }
         if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
           const bf16x8 rv = rnext;
-          const int nu = 2 * c + rr + 1;                     // the next unit: rows 16 (nu >> 1) + rrow + 8 (nu & 1)
           if (nu < 16) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + 16 * (nu >> 1) + rrow + 8 * (nu & 1)) * ldr + ncol);
+          if constexpr (LNM == LN_RESID) {   // the residual operand is the un-normalised row: its LayerNorm here
 #pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? (DROP ? v[e] * gd.scale : v[e]) : 0.f);
+            for (int e = 0; e < 8; e++) v[e] += fmaf(((float)rv[e] - stc.x) * stc.y, gv[e], ev[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = EPI == EPI_RESID ? v[e] + (float)rv[e] : ((float)rv[e] > 0.f ? (DROP ? v[e] * gd.scale : v[e]) : 0.f);
+          }
+        }
+        if constexpr (LNM >= LN_STAT) {   // this row's sum and sum of squares over the wave's 64 columns (8 lanes x 8)
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+          s1 = sum8(s1);
+          s2 = sum8(s2);
+          if (c8 == 0) *reinterpret_cast<float2*>(ln.stat_part + ((grow * 8 + tn * 4 + wn) << 1)) = float2{s1, s2};
         }
         *reinterpret_cast<bf16x8*>(C + grow * ldc + ncol) =
             bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
@@ -383,6 +430,27 @@ int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf1
   }
 #undef SO3X_GEMM_CASE
   return SO3X_ERR_INVALID_ARG;
+}
+
+bool gemm_bf16_ln_ok(int M, int N, int K) { return M % TB == 0 && N % TB == 0 && K % BK == 0 && K >= 128 && (M / TB) * (N / TB) >= 384; }
+// the LayerNorm-folded forms (GemmLN): the persistent kernel only; stat_part needs N == 512 (two column tiles x four waves)
+int gemm_bf16_ln(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
+                 int M, int N, int K, int epi, int lnm, GemmLN ln) {
+  if (!gemm_bf16_ln_ok(M, N, K) || !bias || (epi == EPI_RESID && !R)) return SO3X_ERR_INVALID_ARG;
+  if ((lnm == LN_A || lnm == LN_RESID) && !ln.rowstat) return SO3X_ERR_INVALID_ARG;
+  if (lnm >= LN_STAT && (N != 2 * TB || !ln.stat_part)) return SO3X_ERR_INVALID_ARG;
+  const int ntiles = (M / TB) * (N / TB);
+  const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
+  const GemmDrop gd{};
+#define SO3X_LN_LAUNCH(E, L) \
+  hipLaunchKernelGGL((k_gemm256_bf16<E, false, L>), grid, dim3(512), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd, ln)
+  if (epi == EPI_NONE && lnm == LN_A) SO3X_LN_LAUNCH(EPI_NONE, LN_A);
+  else if (epi == EPI_RELU && lnm == LN_A) SO3X_LN_LAUNCH(EPI_RELU, LN_A);
+  else if (epi == EPI_RESID && lnm == LN_STAT) SO3X_LN_LAUNCH(EPI_RESID, LN_STAT);
+  else if (epi == EPI_RESID && lnm == LN_RESID) SO3X_LN_LAUNCH(EPI_RESID, LN_RESID);
+  else return SO3X_ERR_INVALID_ARG;
+#undef SO3X_LN_LAUNCH
+  return check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ attention forward
@@ -730,11 +798,59 @@ size_t bf16_stash_bytes(const Shape& s) { return carve_b(s, nullptr, true).bytes
   } while (0)
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// W'[n][k] = bf16(W[n][k] gamma[k]), s[n] = sum_k W'[n][k] (of the ROUNDED values: what the matrix core multiplies), c[n] = sum_k
+// W[n][k] beta[k] + bias[n]; 512-wide rows, one wave per row (GemmLN)
+__global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 const float* __restrict__ bias, bf16* __restrict__ Wf, float* __restrict__ sv, float* __restrict__ cv,
+                                                 int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* w = W + (size_t)row * D + lane * 8;
+  float s1 = 0.f, c1 = 0.f;
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    o[i] = (bf16)(w[i] * gamma[lane * 8 + i]);
+    s1 += (float)o[i];
+    c1 = fmaf(w[i], beta[lane * 8 + i], c1);
+  }
+  *reinterpret_cast<bf16x8*>(Wf + (size_t)row * D + lane * 8) = o;
+  s1 = wave_sum(s1);
+  c1 = wave_sum(c1);
+  if (lane == 0) { sv[row] = s1; cv[row] = c1 + bias[row]; }
+}
+// (mean, rstd) of every row from the eight partial (sum, sum of squares) pairs a LN_STAT epilogue left
+__global__ __launch_bounds__(256) void k_ln_stats_final(const float* __restrict__ part, float* __restrict__ stats, int64_t rows, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float4* p = reinterpret_cast<const float4*>(part + row * 16);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const float4 v = p[i]; s1 += v.x + v.z; s2 += v.y + v.w; }
+  const float mean = s1 * (1.f / D), var = fmaxf(s2 * (1.f / D) - mean * mean, 0.f);
+  *reinterpret_cast<float2*>(stats + row * 2) = float2{mean, 1.f / sqrtf(var + eps)};
+}
+
+size_t bf16_weights_bytes(const Shape& s) { return wimg_bytes(s); }
+
 // the bf16 image of the weight matrices (everything up to the SIREN's post_scale weight; biases and LayerNorm vectors stay fp32)
+// and the LayerNorm-folded copies of linear1 / in_proj with their vectors (wimg_bytes)
 int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg) {
   const ParamOff po = param_offsets(sh);
   const int64_t ncvt = (po.wps + (int64_t)D2 * D2 + 3) / 4;
   hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks_for(ncvt, 256)), dim3(256), 0, s, prm, reinterpret_cast<bf16*>(wimg), ncvt);
+  char* base = reinterpret_cast<char*>(wimg);
+  for (int l = 0; l < sh.L; l++) {
+    const LayerOff lo = po.layer(l);
+    const FoldOff fo = fold_off(sh, l);
+    hipLaunchKernelGGL(k_fold_ln, dim3(FF / 4), dim3(256), 0, s, prm + lo.w1, prm + lo.g1, prm + lo.be1, prm + lo.b1, reinterpret_cast<bf16*>(base + fo.w1),
+                       reinterpret_cast<float*>(base + fo.s1), reinterpret_cast<float*>(base + fo.c1), FF);
+    if (l > 0) {
+      const LayerOff lp = po.layer(l - 1);
+      hipLaunchKernelGGL(k_fold_ln, dim3(3 * D / 4), dim3(256), 0, s, prm + lo.wqkv, prm + lp.g2, prm + lp.be2, prm + lo.bqkv,
+                         reinterpret_cast<bf16*>(base + fo.wqkv), reinterpret_cast<float*>(base + fo.sq), reinterpret_cast<float*>(base + fo.cq), 3 * D);
+    }
+  }
   return check_launch();
 }
 
@@ -751,7 +867,55 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
   TRY(check_launch());
   TRY(gemm_bf16(s, a.sn, D2, wimg + po.wps, D2, a.h[0], D, prm + po.bps, nullptr, 0, (int)Np, D2, D2, EPI_NONE));   // post_scale -> h0[:, :256]
   const float sc = 1.f / sqrtf((float)DH), c2 = sc * 1.4426950408889634f;
-  for (int l = 0; l < sh.L; l++) {
+  // Inference at large token counts: the LayerNorms folded into the products around them (GemmLN) -- a.h[l + 1] then holds the
+  // UN-normalised r2 of layer l with its statistics in st2, x1 is never formed, and only the last layer's output is normalised
+  // (for the pooling).  Training (stash), dropout and small token counts take the plain sequence below.
+  const bool folded = !stash && !dr.on() && gemm_bf16_ln_ok((int)Np, D, D) && gemm_bf16_ln_ok((int)Np, D, FF);
+  const char* wbase = reinterpret_cast<const char*>(wimg);
+  for (int l = 0; folded && l < sh.L; l++) {
+    const LayerOff lo = po.layer(l);
+    const LayerB& k = a.layer[l];
+    const bf16* h = a.h[l];           // l == 0: the embedding; else r2 of layer l - 1 (statistics: st2 of that layer)
+    const FoldOff fo = fold_off(sh, l);
+    const unsigned sblocks = blocks_for(Np, 256);
+    GemmLN prev;                      // the LayerNorm between layer l - 1 and this one
+    if (l > 0) {
+      const LayerOff lp = po.layer(l - 1);
+      prev.rowstat = a.layer[l - 1].st2;
+      prev.svec = reinterpret_cast<const float*>(wbase + fo.sq);
+      prev.gamma = prm + lp.g2;
+      prev.beta = prm + lp.be2;
+    }
+    prev.stat_part = a.stat_part;
+    if (l == 0) TRY(gemm_bf16(s, h, D, wimg + lo.wqkv, D, k.qkv, 3 * D, prm + lo.bqkv, nullptr, 0, (int)Np, 3 * D, D, EPI_NONE));
+    else TRY(gemm_bf16_ln(s, h, D, reinterpret_cast<const bf16*>(wbase + fo.wqkv), D, k.qkv, 3 * D, reinterpret_cast<const float*>(wbase + fo.cq), nullptr, 0,
+                          (int)Np, 3 * D, D, EPI_NONE, LN_A, prev));
+    hipLaunchKernelGGL(k_attn_fwd<false>, dim3((unsigned)((P + 127) / 128 * HEADS * sh.B)), dim3(256), 0, s, k.qkv, k.o, k.lse, (int)P, sc, c2,
+                       (const uint32_t*)nullptr, 1.f);
+    TRY(check_launch());
+    if (Np > N) {
+      hipError_t e = hipMemsetAsync(k.o + N * D, 0, (size_t)(Np - N) * D * sizeof(bf16), s);
+      if (e != hipSuccess) return (int)e;
+    }
+    TRY(gemm_bf16_ln(s, k.o, D, wimg + lo.wo, D, k.r1, D, prm + lo.bo, h, D, (int)Np, D, D, EPI_RESID, l == 0 ? LN_STAT : LN_RESID, prev));
+    hipLaunchKernelGGL(k_ln_stats_final, dim3(sblocks), dim3(256), 0, s, a.stat_part, k.st1, Np, 1e-5f);
+    GemmLN n1;                        // norm1 of this layer: folded into linear1, recomputed as linear2's residual
+    n1.rowstat = k.st1;
+    n1.svec = reinterpret_cast<const float*>(wbase + fo.s1);
+    n1.gamma = prm + lo.g1;
+    n1.beta = prm + lo.be1;
+    n1.stat_part = a.stat_part;
+    TRY(gemm_bf16_ln(s, k.r1, D, reinterpret_cast<const bf16*>(wbase + fo.w1), D, k.f, FF, reinterpret_cast<const float*>(wbase + fo.c1), nullptr, 0, (int)Np,
+                     FF, D, EPI_RELU, LN_A, n1));
+    TRY(gemm_bf16_ln(s, k.f, FF, wimg + lo.w2, FF, a.h[l + 1], D, prm + lo.b2, k.r1, D, (int)Np, D, FF, EPI_RESID, LN_RESID, n1));
+    hipLaunchKernelGGL(k_ln_stats_final, dim3(sblocks), dim3(256), 0, s, a.stat_part, k.st2, Np, 1e-5f);
+    TRY(check_launch());
+    if (l == sh.L - 1) {              // the encoder's output itself: normalised in place
+      hipLaunchKernelGGL(k_ln_bf16, dim3(blocks_for(Np, 4)), dim3(256), 0, s, a.h[l + 1], a.h[l + 1], (float*)nullptr, prm + lo.g2, prm + lo.be2, Np, 1e-5f);
+      TRY(check_launch());
+    }
+  }
+  for (int l = 0; !folded && l < sh.L; l++) {
     const LayerOff lo = po.layer(l);
     const LayerB& k = a.layer[l];
     const bf16* h = a.h[l];

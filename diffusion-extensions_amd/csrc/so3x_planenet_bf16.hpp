@@ -65,6 +65,14 @@ __device__ __forceinline__ void attn_tile(int nxt, int& xt, int& hd, int& b) {
 // the row reads of K (ds_read_b128) and for the transposed reads of V (ds_read_b64_tr_b16)
 __device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+// sum over the 8 lanes that share lane >> 3 (every one of them gets it), on the vector ALU's data-parallel primitives: quad_perm
+// [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror -- three full-rate instructions where __shfl_xor is three LDS round trips
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm 1,0,3,2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm 2,3,0,1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -86,6 +94,7 @@ struct ActsB {
   bf16* h[66];
   LayerB layer[65];
   float *w, *S, *xs, *pooled, *part, *temb;
+  float* stat_part;        // [Npad][8][2] row sums / sums of squares of a residual product's output (LayerNorm-folded inference)
   size_t bytes;
 };
 inline ActsB carve_b(const Shape& s, void* mem, bool per_layer) {
@@ -128,12 +137,31 @@ inline ActsB carve_b(const Shape& s, void* mem, bool per_layer) {
   a.pooled = c.take<float>((size_t)s.B * D);
   a.part = c.take<float>((size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1));
   a.temb = c.take<float>((size_t)s.B * D2);
+  a.stat_part = c.take<float>(Np * 16);
   a.bytes = c.off;
   return a;
 }
 
 // workspace = [bf16 image of the parameters][inference activations | backward scratch]
-inline size_t wimg_bytes(const Shape& s) { return up((size_t)param_offsets(s).total * sizeof(bf16)); }
+// The weight image: the plain bf16 copy of the parameters, then what the LayerNorm-folded inference path reads (GemmLN): per layer
+// W1' = W1 gamma1 [F][D] and Wqkv' = Wqkv gamma2 of the PREVIOUS layer [3 D][D] as bf16 (layer 0's slot unused), then the fp32
+// vectors s1[F], c1[F], sq[3 D], cq[3 D] (s = row sums of the bf16 W', c = W beta + bias).
+inline size_t wimg_plain_bytes(const Shape& s) { return up((size_t)param_offsets(s).total * sizeof(bf16)); }
+struct FoldOff { size_t w1, wqkv, s1, c1, sq, cq; };   // byte offsets from the image base
+inline FoldOff fold_off(const Shape& s, int l) {
+  const size_t mats = ((size_t)FF * D + (size_t)3 * D * D) * sizeof(bf16), vecs = ((size_t)2 * FF + 6 * D) * sizeof(float);
+  FoldOff o;
+  o.w1 = wimg_plain_bytes(s) + (size_t)l * mats;
+  o.wqkv = o.w1 + (size_t)FF * D * sizeof(bf16);
+  o.s1 = wimg_plain_bytes(s) + (size_t)s.L * mats + (size_t)l * vecs;
+  o.c1 = o.s1 + FF * sizeof(float);
+  o.sq = o.c1 + FF * sizeof(float);
+  o.cq = o.sq + 3 * D * sizeof(float);
+  return o;
+}
+inline size_t wimg_bytes(const Shape& s) {
+  return up(wimg_plain_bytes(s) + (size_t)s.L * (((size_t)FF * D + (size_t)3 * D * D) * sizeof(bf16) + ((size_t)2 * FF + 6 * D) * sizeof(float)));
+}
 
 
 // C[M][N] = epilogue(A[M][K] W[N][K]^T + bias[N]),  M % 128 == N % 128 == K % 64 == 0; every operand bf16 row-major, bias fp32
@@ -152,6 +180,27 @@ inline GemmDrop gemm_drop(const Drop& dr, int layer, int site) {
 }
 int gemm_bf16(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
               int M, int N, int K, int epi, GemmDrop gd = GemmDrop{});
+
+// LayerNorm folded into the products around it (inference, large token counts: the persistent 256-wide kernel only).  With
+// r the un-normalised row, (mean, rstd) its statistics, y = (r - mean) rstd gamma + beta:
+//   LN_A     the product's A operand is r instead of y: y W^T = rstd (r W'^T) - rstd mean s + c  with  W' = W gamma (per column),
+//            s = W' 1, c = W beta + bias -- a row scale and a rank-one correction in the epilogue (`bias` = c, `svec` = s, `rowstat`);
+//   LN_STAT  (EPI_RESID) the output rows' sum and sum of squares over this wave's 64 columns go to stat_part[row][8][2] (a tiny
+//            kernel turns the eight partials into (mean, rstd));
+//   LN_RESID LN_STAT + the residual operand is r: its y is recomputed in the epilogue from rowstat, gamma, beta.
+// The normalised rows are then never written or read: k_ln_bf16 -- 128 MB of HBM traffic per LayerNorm at 32 x 2048 points --
+// drops out of the forward (section 4 of DESIGN.md).
+enum { LN_NONE = 0, LN_A = 1, LN_STAT = 2, LN_RESID = 3 };
+struct GemmLN {
+  const float* rowstat = nullptr;   // [M][2] (mean, rstd) of the rows of A (LN_A) or of R (LN_RESID)
+  const float* svec = nullptr;      // [N]  LN_A
+  const float* gamma = nullptr;     // [N]  LN_RESID
+  const float* beta = nullptr;      // [N]  LN_RESID
+  float* stat_part = nullptr;       // [M][8][2]  LN_STAT, LN_RESID
+};
+bool gemm_bf16_ln_ok(int M, int N, int K);
+int gemm_bf16_ln(hipStream_t s, const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, const float* bias, const bf16* R, int ldr,
+                 int M, int N, int K, int epi, int lnm, GemmLN ln);
 
 }  // namespace plane
 }  // namespace so3x

@@ -284,8 +284,11 @@ def test_bf16_large_batch_kernels_equal_the_small_batch_kernels(golden):
     gen = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn(32, 2048, 3, device=DEV, generator=gen) * 0.5
     t = torch.randint(0, 1000, (32,), device=DEV, generator=gen)
+    from so3x import backend as B
     with torch.no_grad():
-        big, ebig = net(x, t, want_encoding=True)
+        # (with a stash: the plain kernel sequence -- without one, inference at this size folds its LayerNorms, which is a different
+        #  rounding and has its own test below)
+        big, _, ebig = B.planenet_fwd(net.flat_data(), x, t, *net.cfg, want_stash=True, want_encoding=True)
         for i in range(0, 32, 8):
             small, esmall = net(x[i:i + 4], t[i:i + 4], want_encoding=True)
             assert float((big[i:i + 4] - small).abs().max()) < 1e-5, i
@@ -444,3 +447,30 @@ def test_bf16_dropout_draws_the_masks_of_the_fp32_form(golden):
             sc_ = ref["out_net.0.pool.0.weight"].grad.norm() if k == "out_net.0.pool.0.bias" else a.grad.norm()
             rel_ = float((a.grad - b.grad).norm() / (sc_ + 1e-30))
             assert rel_ < 5e-2 and torch.isfinite(b.grad).all(), (Bn, P, k, rel_)
+
+
+@pytest.mark.gpu
+def test_layernorm_folded_inference_equals_the_plain_sequence(golden):
+    """At large token counts the bf16 inference forward folds every LayerNorm into the products around it (row scale + rank-one
+    correction in the consumer's epilogue, statistics from the producer's, the residual's LayerNorm recomputed where it is added):
+    same network, same clouds as the plain kernel sequence -- which a forward that keeps a stash still runs -- and as the exact
+    fp32 form, to bf16 accuracy; the prepared weight image and the per-call one agree bit for bit."""
+    from so3x import backend as B
+    net16, _ = full_net(golden, "bf16")
+    net32, _ = full_net(golden, "fp32")
+    net16, net32 = net16.to(DEV).eval(), net32.to(DEV).eval()
+    gen = torch.Generator().manual_seed(17)
+    Bn, P = 24, 2048                               # 49152 tokens: every product on the persistent 256-wide kernel
+    x = (torch.randn(Bn, P, 3, generator=gen) * 0.5).to(DEV)
+    t = torch.randint(0, 1000, (Bn,), generator=gen).to(DEV)
+    flat = net16.flat_data()
+    with torch.no_grad():
+        folded = net16(x, t)                                                     # prepared image, no stash: the folded path
+        folded_unprepared = B.planenet_fwd(flat, x, t, *net16.cfg)[0]             # the image built inside the call
+        plain = B.planenet_fwd(flat, x, t, *net16.cfg, want_stash=True)[0]        # a stash: the plain sequence
+        exact = net32(x, t)
+    assert torch.equal(folded, folded_unprepared)
+    scale = float(exact.abs().max())
+    assert float((folded - plain).abs().max()) < 2e-2 * scale and not torch.equal(folded, plain)
+    assert float((folded - exact).abs().max()) < 3e-2 * scale
+    assert float((plain - exact).abs().max()) < 3e-2 * scale
