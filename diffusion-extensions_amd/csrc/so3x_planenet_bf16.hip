@@ -306,11 +306,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
     const int g = lane >> 4, m_l = lane & 15, rrow = lane >> 3, c8 = lane & 7;
     const int ncol = tn * TB + wn * 64 + c8 * 8;
     const float4 bv0 = *reinterpret_cast<const float4*>(bias + ncol), bv1 = *reinterpret_cast<const float4*>(bias + ncol + 4);
-    // (the residual / mask rows are fetched one unit -- 8 rows x 128 bytes -- ahead: a load issued behind a store would make the
-    //  compiler's wait for it retire the store first)
     const size_t row0 = (size_t)tm * TB + wm * 128;
-    bf16x8 rnext;
-    if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + rrow) * ldr + ncol);
+    // (the residual / mask rows are fetched FOUR units -- 8 rows x 128 bytes each -- ahead: vmcnt retires in issue order, so the
+    //  wait for a load issued d units ago also retires every C store older than that; at d = 1 that was the store just issued
+    //  (measured, same box: 152 -> 143 us on the 512 x 2048 residual product, 243 -> 215 us on the 2048 x 512 ReLU-mask one; all 16
+    //  units up front costs the short-K products a bubble at every tile start))
+    constexpr int SO3X_RQ = 4;
+    bf16x8 rq[SO3X_RQ];   // unit u's rows sit in rq[u % SO3X_RQ]
+    if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
+#pragma unroll
+      for (int u = 0; u < SO3X_RQ; u++) rq[u] = *reinterpret_cast<const bf16x8*>(R + (row0 + 16 * (u >> 1) + rrow + 8 * (u & 1)) * ldr + ncol);
+    }
     // LayerNorm folded in (GemmLN): the per-column vectors of this lane's eight columns, the rows' statistics one unit ahead
     float sv[8], gv[8], ev[8];
     if constexpr (LNM == LN_A) {
@@ -375,8 +381,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256_bf16(const bf16* __restrict_
           }
         }
         if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
-          const bf16x8 rv = rnext;
-          if (nu < 16) rnext = *reinterpret_cast<const bf16x8*>(R + (row0 + 16 * (nu >> 1) + rrow + 8 * (nu & 1)) * ldr + ncol);
+          const int cu = 2 * c + rr, fu = cu + SO3X_RQ;     // this unit, the unit fetched now
+          const bf16x8 rv = rq[cu % SO3X_RQ];
+          if (fu < 16) rq[cu % SO3X_RQ] = *reinterpret_cast<const bf16x8*>(R + (row0 + 16 * (fu >> 1) + rrow + 8 * (fu & 1)) * ldr + ncol);
           if constexpr (LNM == LN_RESID) {   // the residual operand is the un-normalised row: its LayerNorm here
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] += fmaf(((float)rv[e] - stc.x) * stc.y, gv[e], ev[e]);
