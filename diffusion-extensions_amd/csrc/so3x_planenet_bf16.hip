@@ -111,7 +111,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
   __syncthreads();
   const int c4 = (tid & 31) * 4;
   const float4 bv = *reinterpret_cast<const float4*>(bias + tn * BN + c4);
-#pragma unroll 4
+  // the residual / mask values of this thread's 16 rows, all requested before the first C store (a load issued behind a store
+  // cannot be waited for without retiring the store: vmcnt counts in issue order)
+  bf16x4 rall[16];
+  if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      rall[it] = *reinterpret_cast<const bf16x4*>(R + ((size_t)tm * BM + it * 8 + (tid >> 5)) * ldr + tn * BN + c4);
+  }
+#pragma unroll
   for (int it = 0; it < 16; it++) {
     const int row = it * 8 + (tid >> 5);
     float4 v = *reinterpret_cast<const float4*>(sc + row * 128 + c4);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
       }
     }
     if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
-      const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + grow * ldr + tn * BN + c4);
+      const bf16x4 rv = rall[it];
       if constexpr (EPI == EPI_RESID) {
         v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
       } else {
