@@ -79,7 +79,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-constexpr int PSLICE = 256;   // points per partial sum of the pooling reductions
+constexpr int PSLICE = 64;    // points per partial sum of the pooling reductions (32 clouds x 256 points: 128 workgroups, not 32)
 
 // ------------------------------------------------------------------------------------------------ buffers
 inline int64_t padded_rows(const Shape& s) { return (s.N() + 127) / 128 * 128; }
