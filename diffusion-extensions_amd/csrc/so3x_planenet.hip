@@ -628,7 +628,7 @@ size_t bf16_workspace_bytes(const Shape& sh);
 size_t bf16_stash_bytes(const Shape& sh);
 int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, float* out, float* encoding_out,
                  void* stash, void* workspace, const void* prepared, const Drop& dr);
-int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg);
+int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg, bool fold);
 int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* x, const int64_t* t, const float* dout, float* dprm,
                   const void* stash, void* workspace, const Drop& dr);
 } }
@@ -670,7 +670,7 @@ int so3x_planenet_prepare(so3x_stream_t s, const float* params, int dim, int hea
   if (precision == SO3X_PREC_F32) return SO3X_OK;                       // the exact form reads the fp32 parameters as they are
   if (!bf16_supported(sh)) return SO3X_ERR_UNSUPPORTED;
   if (!weights || weights_bytes < so3x_planenet_weights_bytes(dim, heads, layers, ffn, precision)) return SO3X_ERR_WORKSPACE;
-  return weights_bf16((hipStream_t)s, sh, params, weights);
+  return weights_bf16((hipStream_t)s, sh, params, weights, true);
 }
 
 int so3x_planenet_fwd(so3x_stream_t s, const float* params, const float* x, const int64_t* t, float* out, float* encoding_out, int64_t B, int64_t P,

@@ -850,12 +850,12 @@ size_t bf16_weights_bytes(const Shape& s) { return wimg_bytes(s); }
 
 // the bf16 image of the weight matrices (everything up to the SIREN's post_scale weight; biases and LayerNorm vectors stay fp32)
 // and the LayerNorm-folded copies of linear1 / in_proj with their vectors (wimg_bytes)
-int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg) {
+int weights_bf16(hipStream_t s, const Shape& sh, const float* prm, void* wimg, bool fold) {
   const ParamOff po = param_offsets(sh);
   const int64_t ncvt = (po.wps + (int64_t)D2 * D2 + 3) / 4;
   hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks_for(ncvt, 256)), dim3(256), 0, s, prm, reinterpret_cast<bf16*>(wimg), ncvt);
   char* base = reinterpret_cast<char*>(wimg);
-  for (int l = 0; l < sh.L; l++) {
+  for (int l = 0; fold && l < sh.L; l++) {   // (only the LayerNorm-folded inference path reads these: a training forward skips them)
     const LayerOff lo = po.layer(l);
     const FoldOff fo = fold_off(sh, l);
     hipLaunchKernelGGL(k_fold_ln, dim3(FF / 4), dim3(256), 0, s, prm + lo.w1, prm + lo.g1, prm + lo.be1, prm + lo.b1, reinterpret_cast<bf16*>(base + fo.w1),
@@ -875,17 +875,17 @@ int forward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float* 
   const int64_t N = sh.N(), Np = padded_rows(sh), P = sh.P;
   const bf16* wimg = prepared ? reinterpret_cast<const bf16*>(prepared) : reinterpret_cast<const bf16*>(workspace);
   const ActsB a = stash ? carve_b(sh, stash, true) : carve_b(sh, reinterpret_cast<char*>(workspace) + wimg_bytes(sh), false);
-  if (!prepared) TRY(weights_bf16(s, sh, prm, workspace));
+  // Inference at large token counts: the LayerNorms folded into the products around them (GemmLN) -- a.h[l + 1] then holds the
+  // UN-normalised r2 of layer l with its statistics in st2, x1 is never formed, and only the last layer's output is normalised
+  // (for the pooling).  Training (stash), dropout and small token counts take the plain sequence below.
+  const bool folded = !stash && !dr.on() && gemm_bf16_ln_ok((int)Np, D, D) && gemm_bf16_ln_ok((int)Np, D, FF);
+  if (!prepared) TRY(weights_bf16(s, sh, prm, workspace, folded));
   const float neg_emb = (float)(-(log(10000.0) / (D2 / 2 - 1)));
   hipLaunchKernelGGL(k_temb, dim3((unsigned)sh.B), dim3(D2), 0, s, t, a.temb, neg_emb);
   hipLaunchKernelGGL(k_embed_bf16, dim3(blocks_for(Np * (D2 / 8), 256)), dim3(256), 0, s, x, a.temb, prm + po.wp, prm + po.bp, a.pre, a.sn, a.h[0], N, Np, P);
   TRY(check_launch());
   TRY(gemm_bf16(s, a.sn, D2, wimg + po.wps, D2, a.h[0], D, prm + po.bps, nullptr, 0, (int)Np, D2, D2, EPI_NONE));   // post_scale -> h0[:, :256]
   const float sc = 1.f / sqrtf((float)DH), c2 = sc * 1.4426950408889634f;
-  // Inference at large token counts: the LayerNorms folded into the products around them (GemmLN) -- a.h[l + 1] then holds the
-  // UN-normalised r2 of layer l with its statistics in st2, x1 is never formed, and only the last layer's output is normalised
-  // (for the pooling).  Training (stash), dropout and small token counts take the plain sequence below.
-  const bool folded = !stash && !dr.on() && gemm_bf16_ln_ok((int)Np, D, D) && gemm_bf16_ln_ok((int)Np, D, FF);
   const char* wbase = reinterpret_cast<const char*>(wimg);
   for (int l = 0; folded && l < sh.L; l++) {
     const LayerOff lo = po.layer(l);

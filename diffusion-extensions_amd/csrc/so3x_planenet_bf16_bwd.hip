@@ -21,19 +21,27 @@ namespace plane {
 typedef __attribute__((address_space(3))) s16x4* lds_p;
 
 // ------------------------------------------------------------------------------------------------ transposed weight image
-// dst[c][r] = bf16(src[r][c]), src fp32 [R][C]; 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void k_cvt_bf16_t(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C) {
+// dst[c][r] = bf16(src[r][c]) for every weight matrix the dX products need, in ONE launch (17 launches of a few microseconds
+// each were 4 % of a training evaluation at 32 x 256): 32 x 32 tiles through LDS, the matrix of a block from a table
+struct TposeTab {
+  int n;
+  int tile0[18];      // first block of matrix i (tile0[n] = all blocks)
+  int64_t off[17];    // element offset of the matrix in the parameter buffer = in the transposed image
+  int R[17], C[17];
+};
+__global__ __launch_bounds__(256) void k_cvt_bf16_t(const float* __restrict__ prm, bf16* __restrict__ wT, const TposeTab tab) {
   __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  int m = 0;
+  while (m + 1 < tab.n && (int)blockIdx.x >= tab.tile0[m + 1]) m++;
+  const int R = tab.R[m], C = tab.C[m], tb = blockIdx.x - tab.tile0[m];
+  const float* src = prm + tab.off[m];
+  bf16* dst = wT + tab.off[m];
+  const int c0 = (tb % (C / 32)) * 32, r0 = (tb / (C / 32)) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int i = 0; i < 4; i++) tile[ty + 8 * i][tx] = src[(size_t)(r0 + ty + 8 * i) * C + c0 + tx];
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; i++) dst[(size_t)(c0 + ty + 8 * i) * R + r0 + tx] = (bf16)tile[tx][ty + 8 * i];
-}
-static int cvt_t(hipStream_t s, const float* src, bf16* dst, int R, int C) {
-  hipLaunchKernelGGL(k_cvt_bf16_t, dim3(C / 32, R / 32), dim3(256), 0, s, src, dst, R, C);
-  return check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X
@@ -429,12 +437,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16* __restrict_
 // ------------------------------------------------------------------------------------------------ rows and reductions
 // LayerNorm backward over 512-wide bf16 rows: dr = rstd (dy gamma - mean(dy gamma) - xhat mean(dy gamma xhat)); per workgroup (64
 // rows) the partial column sums part[blk][0..511] = sum dy xhat (d gamma), part[blk][512..1023] = sum dy (d beta)
-constexpr int LNB_ROWS = 64;
+// rows per workgroup: 64 at large token counts (fewer partial rows to add up), 16 below 32768 tokens (a wave's rows are a serial
+// chain of load -> two wave reductions -> store: 128 workgroups x 16 rows per wave took 18 us for 8 MB at 32 x 256)
+inline int lnb_rows(int64_t Np) { return Np >= 32768 ? 64 : 16; }
 // drm (optional): dr through the dropout of the block whose output the LayerNorm's input added to its residual (the gradient that
 // block sees; dr itself goes on along the residual)
 __global__ __launch_bounds__(256) void k_ln_bwd_bf16(const bf16* __restrict__ dy, const bf16* __restrict__ r, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, bf16* __restrict__ dr, float* __restrict__ part, int64_t rows,
-                                                     bf16* __restrict__ drm, const GemmDrop gd) {
+                                                     bf16* __restrict__ drm, const GemmDrop gd, int LNB_ROWS) {
   __shared__ float red[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 8), g1 = *reinterpret_cast<const float4*>(gamma + lane * 8 + 4);
@@ -644,7 +654,7 @@ inline BwdB carve_bwd_b(const Shape& s, void* mem) {
   b.dxs = c.take<float>((size_t)s.B * D);
   b.slab = c.take<float>((size_t)(SLAB_FLOATS + BIAS_PART_FLOATS));
   size_t part = (size_t)colsum_chunks(s) * FF;                                        // column sums, <= 2048 wide
-  const size_t lnp = (size_t)((Np + LNB_ROWS - 1) / LNB_ROWS) * 1024;                 // LayerNorm / embedding partials (64-row chunks)
+  const size_t lnp = (size_t)((Np + lnb_rows(Np) - 1) / lnb_rows(Np)) * 1024;       // LayerNorm / embedding partials
   const size_t pool = (size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1);
   if (lnp > part) part = lnp;
   if (pool > part) part = pool;
@@ -678,14 +688,26 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
   hipError_t e = hipMemsetAsync(w.zeros, 0, FF * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   // transposed bf16 images of the weights the dX products need
-  for (int l = 0; l < sh.L; l++) {
-    const LayerOff lo = po.layer(l);
-    TRY(cvt_t(s, prm + lo.wqkv, wT + lo.wqkv, 3 * D, D));
-    TRY(cvt_t(s, prm + lo.wo, wT + lo.wo, D, D));
-    TRY(cvt_t(s, prm + lo.w1, wT + lo.w1, FF, D));
-    TRY(cvt_t(s, prm + lo.w2, wT + lo.w2, D, FF));
+  if (4 * sh.L + 1 > 17) return SO3X_ERR_UNSUPPORTED;   // (the bf16 form is the 4-layer aircraft network)
+  {
+    TposeTab tab;
+    tab.n = 0;
+    int blocks = 0;
+    auto add = [&](int64_t off, int R, int C) {
+      tab.tile0[tab.n] = blocks;
+      tab.off[tab.n] = off; tab.R[tab.n] = R; tab.C[tab.n] = C;
+      blocks += (R / 32) * (C / 32);
+      tab.n++;
+    };
+    for (int l = 0; l < sh.L; l++) {
+      const LayerOff lo = po.layer(l);
+      add(lo.wqkv, 3 * D, D); add(lo.wo, D, D); add(lo.w1, FF, D); add(lo.w2, D, FF);
+    }
+    add(po.wps, D2, D2);
+    tab.tile0[tab.n] = blocks;
+    hipLaunchKernelGGL(k_cvt_bf16_t, dim3((unsigned)blocks), dim3(256), 0, s, prm, wT, tab);
+    TRY(check_launch());
   }
-  TRY(cvt_t(s, prm + po.wps, wT + po.wps, D2, D2));
   const bf16* enc = a.h[sh.L];
   // head and pooling (fp32, a few rows)
   TRY(gemm(s, transposed(dout, 3), rowmajor(a.pooled, D), dprm + po.wout, D, 3, D, Bn));
@@ -700,7 +722,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
   hipLaunchKernelGGL(k_part_final, dim3((D + 1 + 7) / 8), dim3(256), 0, s, w.part, Bn * nsl, D + 1, D + 1, dprm + po.wpool);   // wpool[512] | bpool[1]
   TRY(check_launch());
   const float sc = 1.f / sqrtf((float)DH), c2 = sc * 1.4426950408889634f;
-  const int lnblk = (int)((Np + LNB_ROWS - 1) / LNB_ROWS);
+  const int LNB_ROWS = lnb_rows(Np), lnblk = (int)((Np + LNB_ROWS - 1) / LNB_ROWS);
   bf16* dcur = w.dA;
   bf16* dalt = w.dB;
   for (int l = sh.L - 1; l >= 0; l--) {
@@ -709,7 +731,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
     const bf16* h = a.h[l];
     // norm2: dcur = d h_{l+1} -> dalt = d r2;  d gamma2 | d beta2 are adjacent in the parameter buffer
     bf16* const dM = dr.on() ? w.dM : nullptr;
-    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r2, k.st2, prm + lo.g2, dalt, w.part, Np, dM, gemm_drop(dr, l, DROP_BLOCK2));
+    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r2, k.st2, prm + lo.g2, dalt, w.part, Np, dM, gemm_drop(dr, l, DROP_BLOCK2), LNB_ROWS);
     hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g2);
     TRY(check_launch());
     // feed-forward: r2 = x1 + [dropout] (relu(x1 W1^T + b1) [dropout]) W2^T + b2; dy2 = the gradient behind the output dropout
@@ -721,7 +743,7 @@ int backward_bf16(hipStream_t s, const Shape& sh, const float* prm, const float*
     TRY(gemm_tn(s, w.dF, FF, k.x1, D, dprm + lo.w1, (int)Np, FF, D, w.slab, dprm + lo.b1));
     TRY(gemm_bf16(s, w.dF, FF, wT + lo.w1, FF, dcur, D, w.zeros, dalt, D, (int)Np, D, FF, EPI_RESID));        // dcur = d x1 = dr2 + dZ W1
     // norm1: dcur = d x1 -> dalt = d r1
-    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r1, k.st1, prm + lo.g1, dalt, w.part, Np, dM, gemm_drop(dr, l, DROP_BLOCK1));
+    hipLaunchKernelGGL(k_ln_bwd_bf16, dim3(lnblk), dim3(256), 0, s, dcur, k.r1, k.st1, prm + lo.g1, dalt, w.part, Np, dM, gemm_drop(dr, l, DROP_BLOCK1), LNB_ROWS);
     hipLaunchKernelGGL(k_part_final, dim3(128), dim3(256), 0, s, w.part, lnblk, 1024, 1024, dprm + lo.g1);
     TRY(check_launch());
     // attention block: r1 = h + [dropout] (softmax(Q K^T / sqrt(dh)) [dropout] V Wo^T + bo)
