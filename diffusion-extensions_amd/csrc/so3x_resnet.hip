@@ -447,8 +447,12 @@ __global__ void __launch_bounds__(64 * n_waves<PREC>(), 1)
 k_resnet_chain(const void* __restrict__ gimg, const float* __restrict__ x0tab, const float* __restrict__ sched, int T,
                const float* __restrict__ trap_p, const uint16_t* __restrict__ guide_p, const float* __restrict__ x_in, float* __restrict__ x_out, int t_start,
                int n_steps, const float* __restrict__ axes, const float* __restrict__ unif, uint64_t seed, uint64_t rng_offset,
-               int64_t index_base, int64_t n) {
+               int64_t index_base, int64_t n, const int64_t* __restrict__ t_dev) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
+  if (t_dev) {  // the first timestep read on the device (the caller's `t` tensor: no host copy, no synchronisation), clamped into the tables
+    const int64_t tv = t_dev[0];
+    t_start = (int)(tv < n_steps - 1 ? n_steps - 1 : (tv > T - 1 ? T - 1 : tv));
+  }
   constexpr int NW = n_waves<PREC>();
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: what derives from it lives in SGPRs
@@ -1003,7 +1007,7 @@ template <int PREC>
 int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const float* trap_p, const uint16_t* guide_p,
                  const float* x_in, float* x_out,
                  int t_start, int n_steps, const float* axes, const float* unif, uint64_t seed, uint64_t rng_offset,
-                 int64_t index_base, int64_t n) {
+                 int64_t index_base, int64_t n, const int64_t* t_dev = nullptr) {
   constexpr int LDS = lds_bytes<PREC, false>(), THREADS = 64 * n_waves<PREC>();
   static PerDevice caps;
   int cap = 0;
@@ -1011,7 +1015,7 @@ int launch_chain(hipStream_t s, const void* ws, const float* sched, int T, const
   const int64_t ngroups = (n + THREADS / 2 - 1) / (THREADS / 2);
   const float* tab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + image_bytes<PREC>());
   hipLaunchKernelGGL((k_resnet_chain<PREC>), dim3((int)(ngroups < cap ? ngroups : cap)), dim3(THREADS), LDS, s, ws, tab, sched, T,
-                     trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n);
+                     trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed, rng_offset, index_base, n, t_dev);
   return check_launch();
 }
 
@@ -1164,6 +1168,34 @@ int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float
                                        seed, rng_offset, index_base, n);
   return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif,
                                       seed, rng_offset, index_base, n);
+}
+
+// The same in two calls for callers that drive the chain one step per call (so3_lock_test.py:24-31), as so3x_p_sample_prepare /
+// so3x_p_sample_prepared do for the 65-wide network: the weight image and the [T][256] input-row table depend on the parameters only.
+int so3x_resnet_p_sample_prepare(so3x_stream_t s, const float* params, int T, int precision, void* workspace, size_t workspace_bytes) {
+  if (T <= 0 || !params) return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ws_bytes(precision, T)) return SO3X_ERR_WORKSPACE;
+  return precision == SO3X_PREC_F32 ? prep<SO3X_PREC_F32>((hipStream_t)s, params, T, workspace) : prep<SO3X_PREC_BF16>((hipStream_t)s, params, T, workspace);
+}
+
+int so3x_resnet_p_sample_prepared(so3x_stream_t s, const float* sched, int T, const float* trap_p, const uint16_t* guide_p, const float* x_in,
+                                  float* x_out, int t_start, const int64_t* t_dev, int n_steps, const float* axes, const float* unif, uint64_t seed,
+                                  uint64_t rng_offset, int64_t index_base, int64_t n, int precision, const void* workspace,
+                                  size_t workspace_bytes) {
+  if (n < 0 || T <= 0 || n_steps < 0 || (n && (!sched || !trap_p || !x_in || !x_out)) || ((axes == nullptr) != (unif == nullptr)) ||
+      (axes && n_steps > 1))
+    return SO3X_ERR_INVALID_ARG;
+  if (!t_dev && (t_start < 0 || t_start >= T || t_start - n_steps + 1 < 0)) return SO3X_ERR_INVALID_ARG;
+  if (t_dev && n_steps > T) return SO3X_ERR_INVALID_ARG;
+  if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ws_bytes(precision, T)) return SO3X_ERR_WORKSPACE;
+  if (n == 0 || n_steps == 0) return SO3X_OK;
+  if (precision == SO3X_PREC_F32)
+    return launch_chain<SO3X_PREC_F32>((hipStream_t)s, workspace, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed,
+                                       rng_offset, index_base, n, t_dev);
+  return launch_chain<SO3X_PREC_BF16>((hipStream_t)s, workspace, sched, T, trap_p, guide_p, x_in, x_out, t_start, n_steps, axes, unif, seed,
+                                      rng_offset, index_base, n, t_dev);
 }
 
 }  // extern "C"

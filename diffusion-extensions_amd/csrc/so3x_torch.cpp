@@ -282,6 +282,34 @@ Tensor p_sample_prepared(const Tensor& ws, const Tensor& sched, const Tensor& tr
   return out;
 }
 
+// the same for the 255-wide residual network (so3x_resnet_p_sample_prepare / _prepared)
+Tensor resnet_p_sample_prepare(const Tensor& params, int64_t T, int64_t precision) {
+  GUARD(params);
+  Tensor ws = bytes(params, so3x_resnet_workspace_bytes((int)precision, (int)T));
+  ok(so3x_resnet_p_sample_prepare(strm(params), F(dev(params, "params")), (int)T, (int)precision, ws.mutable_data_ptr(), ws.numel()), "resnet_p_sample_prepare");
+  return ws;
+}
+void resnet_p_sample_prepared_out(const Tensor& ws, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                                  int64_t t_start, const optional<Tensor>& t_dev, int64_t n_steps, const optional<Tensor>& axes,
+                                  const optional<Tensor>& unif, int64_t seed, int64_t rng_offset, int64_t index_base, int64_t precision, Tensor& out) {
+  GUARD(x);
+  const int T = (int)dev(sched, "sched").size(1);
+  TORCH_CHECK(out.numel() == x.numel() && out.device() == x.device(), "so3x: out must match x");
+  ok(so3x_resnet_p_sample_prepared(strm(x), F(sched), T, F(dev(trap_p, "trap_p")), Guide(guide_p), F(dev(x, "x")), Fm(const_cast<Tensor&>(dev(out, "out"))),
+                                   (int)t_start, t_dev.has_value() ? I64(dev(*t_dev, "t", at::kLong)) : nullptr, (int)n_steps, Fo(axes, "axes"),
+                                   Fo(unif, "unif"), (uint64_t)seed, (uint64_t)rng_offset, index_base, x.numel() / 9, (int)precision,
+                                   dev(ws, "workspace", at::kByte).const_data_ptr(), ws.numel()),
+     "resnet_p_sample_prepared");
+}
+Tensor resnet_p_sample_prepared(const Tensor& ws, const Tensor& sched, const Tensor& trap_p, const optional<Tensor>& guide_p, const Tensor& x,
+                                int64_t t_start, const optional<Tensor>& t_dev, int64_t n_steps, const optional<Tensor>& axes,
+                                const optional<Tensor>& unif, int64_t seed, int64_t rng_offset, int64_t index_base, int64_t precision) {
+  GUARD(x);
+  Tensor out = at::empty_like(x);
+  resnet_p_sample_prepared_out(ws, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, precision, out);
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------- one training step
 // -> (loss[1], x_t, t, dout, zstash, workspace, out): everything so3x_train_bwd needs travels as tensors
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> train_fwd(
@@ -666,6 +694,9 @@ TORCH_LIBRARY(so3x, m) {
         "-> (Tensor, Tensor, Tensor)");
   m.def("p_mean(Tensor sched, Tensor x, Tensor v, Tensor? t, int t_stride, int t_const, bool want_x0hat) -> (Tensor, Tensor)");
   m.def("p_sample_prepare(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, int precision) -> Tensor");
+  m.def("resnet_p_sample_prepare(Tensor params, int T, int precision) -> Tensor");
+  m.def("resnet_p_sample_prepared(Tensor workspace, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, Tensor? t_dev, int n_steps, Tensor? axes, Tensor? unif, int seed, int rng_offset, int index_base, int precision) -> Tensor");
+  m.def("resnet_p_sample_prepared_out(Tensor workspace, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, Tensor? t_dev, int n_steps, Tensor? axes, Tensor? unif, int seed, int rng_offset, int index_base, int precision, Tensor(b!) out) -> ()");
   m.def("p_sample_prepared(Tensor(a!) workspace, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, Tensor? t_dev, int n_steps, Tensor? axes, Tensor? unif, int seed, int rng_offset, int index_base, int precision) -> Tensor");
   m.def("p_sample_prepared_out(Tensor(a!) workspace, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, Tensor? t_dev, int n_steps, Tensor? axes, Tensor? unif, int seed, int rng_offset, int index_base, int precision, Tensor(b!) out) -> ()");
   m.def("p_sample_chain(Tensor params, Tensor sched, Tensor trap_p, Tensor? guide_p, Tensor x, int t_start, int n_steps, Tensor? axes, "
@@ -742,6 +773,9 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("q_sample_target", q_sample_target);
   m.impl("p_mean", p_mean);
   m.impl("p_sample_prepare", p_sample_prepare);
+  m.impl("resnet_p_sample_prepare", resnet_p_sample_prepare);
+  m.impl("resnet_p_sample_prepared", resnet_p_sample_prepared);
+  m.impl("resnet_p_sample_prepared_out", resnet_p_sample_prepared_out);
   m.impl("p_sample_prepared", p_sample_prepared);
   m.impl("p_sample_prepared_out", p_sample_prepared_out);
   m.impl("p_sample_chain", p_sample_chain);

@@ -46,7 +46,7 @@ SYMBOLS = (
     "so3x_six2rmat", "so3x_six2rmat_bwd", "so3x_log_rmat_bwd", "so3x_rmat_dist_bwd", "so3x_prevstep_workspace_bytes",
     "so3x_prevstep_loss", "so3x_prevstep_loss6",
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
-    "so3x_p_sample_prepare", "so3x_p_sample_prepared",
+    "so3x_p_sample_prepare", "so3x_p_sample_prepared", "so3x_resnet_p_sample_prepare", "so3x_resnet_p_sample_prepared",
     "so3x_planenet_weights_bytes", "so3x_planenet_prepare", "so3x_planenet_param_count", "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes", "so3x_planenet_fwd", "so3x_planenet_bwd",
     "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam", "so3x_train_fused",
 )
@@ -596,10 +596,15 @@ def p_sample_prepare(params, sched, trap_p, precision=PREC_BF16, guide_p=None):
     return _call(ops().p_sample_prepare, params, sched, trap_p, _guide(guide_p, trap_p, "guide_p"), int(precision))
 
 
+def resnet_p_sample_prepare(params, T, precision=PREC_BF16):
+    """p_sample_prepare for the 255-wide residual network (so3x_resnet_p_sample_prepare): its weight image + input-row table"""
+    return _call(ops().resnet_p_sample_prepare, _dev(params, "params").reshape(-1), int(T), int(precision))
+
+
 def p_sample_prepared(ws, sched, trap_p, x, t_start, n_steps, t_dev=None, axes=None, unif=None, seed=0, rng_offset=0, index_base=0,
-                      precision=PREC_BF16, out=None, guide_p=None):
+                      precision=PREC_BF16, out=None, guide_p=None, wide=False):
     """n_steps reverse steps from a prepared workspace: ONE launch.  t_dev (device int64, one element): the first timestep is read
-    on the device instead of from t_start."""
+    on the device instead of from t_start.  wide: the workspace is resnet_p_sample_prepare's (the 255-wide network)."""
     sched, trap_p = _dev(sched, "sched"), _dev(trap_p, "trap_p")
     x = _rot_in(x, "x")
     ax = _dev(axes, "axes").reshape(-1, 3) if axes is not None else None
@@ -608,8 +613,8 @@ def p_sample_prepared(ws, sched, trap_p, x, t_start, n_steps, t_dev=None, axes=N
     args = (ws, sched, trap_p, _guide(guide_p, trap_p, "guide_p"), x, int(t_start), td, int(n_steps), ax, un, _s64(seed), _s64(rng_offset),
             int(index_base), int(precision))
     if out is None:
-        return _call(ops().p_sample_prepared, *args)
-    _call(ops().p_sample_prepared_out, *args, _out_like(out, x))
+        return _call(ops().resnet_p_sample_prepared if wide else ops().p_sample_prepared, *args)
+    _call(ops().resnet_p_sample_prepared_out if wide else ops().p_sample_prepared_out, *args, _out_like(out, x))
     return out
 
 

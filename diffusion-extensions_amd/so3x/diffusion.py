@@ -226,7 +226,9 @@ class SO3Diffusion(nn.Module):
         key = (flat.data_ptr(), tuple(p._version for p in net._flat_params), PARAM_EPOCH[0], prec, trap_p.data_ptr(),
                self._guide_p.data_ptr(), flat.device)
         if self._prep is None or self._prep[0] != key:
-            self._prep = (key, _b.p_sample_prepare(flat, self._sched, trap_p, prec, guide_p=self._guide_p))
+            wide = getattr(net, "kind", "") == "resnet255"
+            self._prep = (key, _b.resnet_p_sample_prepare(flat, self.num_timesteps, prec) if wide
+                          else _b.p_sample_prepare(flat, self._sched, trap_p, prec, guide_p=self._guide_p))
         return self._prep[1], prec
 
     def invalidate_sampling_cache(self):
@@ -294,20 +296,21 @@ class SO3Diffusion(nn.Module):
         uses each sample's own coefficients (extract(), diffusion.py:291-306)."""
         net = self._fused_net(sampling=True)
         _, trap_p = self._tables()
-        small = net is not None and getattr(net, "kind", "") != "resnet255"
+        wide = net is not None and getattr(net, "kind", "") == "resnet255"
+        small = net is not None      # (either fused score network: one launch from its prepared state)
         if small and isinstance(t, torch.Tensor) and t.numel() == 1 and t.is_cuda and t.dtype == torch.int64:
             # the (1,)-shaped t of the reference's own loop (so3_test.py:31): read by the kernel on the device -- no host copy of
             # t, no synchronisation, ONE launch from the prepared state (the reference synchronises here, diffusion.py:320)
             ws, prec = self._prepared(net)
             off = _rng.next_offset(self.num_timesteps) if axes is None else 0
             return _b.p_sample_prepared(ws, self._sched, trap_p, x, 0, 1, t_dev=t, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off,
-                                        index_base=self.index_base, precision=prec, guide_p=self._guide_p)
+                                        index_base=self.index_base, precision=prec, guide_p=self._guide_p, wide=wide)
         t0, same = self._shared_t(t)
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
         if small and same:
             ws, prec = self._prepared(net)
             return _b.p_sample_prepared(ws, self._sched, trap_p, x, t0, 1, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off,
-                                        index_base=self.index_base, precision=prec, guide_p=self._guide_p)
+                                        index_base=self.index_base, precision=prec, guide_p=self._guide_p, wide=wide)
         if net is not None and same:
             return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
                                      seed=_rng.seed(), rng_offset=off, index_base=self.index_base,

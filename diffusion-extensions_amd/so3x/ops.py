@@ -144,6 +144,21 @@ def _(workspace, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif,
     return None
 
 
+@register_fake("so3x::resnet_p_sample_prepare")
+def _(params, T, precision):
+    return params.new_empty((4 * params.numel() + T * 1024 + (1 << 20),), dtype=torch.uint8)   # an upper bound is all a fake needs
+
+
+@register_fake("so3x::resnet_p_sample_prepared")
+def _(workspace, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, precision):
+    return _f32(x, x.shape)
+
+
+@register_fake("so3x::resnet_p_sample_prepared_out")
+def _(workspace, sched, trap_p, guide_p, x, t_start, t_dev, n_steps, axes, unif, seed, rng_offset, index_base, precision, out):
+    return None
+
+
 @register_fake("so3x::p_sample_chain")
 def _(params, sched, trap_p, guide_p, x, t_start, n_steps, axes, unif, seed, rng_offset, index_base, precision):
     return _f32(x, x.shape)

@@ -257,6 +257,15 @@ int so3x_resnet_p_sample_chain(so3x_stream_t s, const float* params, const float
                                int n_steps, const float* axes, const float* unif, uint64_t seed,
                                uint64_t rng_offset, int64_t index_base, int64_t n, int precision,
                                void* workspace, size_t workspace_bytes);
+/* The same in two calls, as so3x_p_sample_prepare / so3x_p_sample_prepared for the 65-wide network (so3_lock_test.py:24-31 drives
+ * the chain one `p_sample` per call): the weight image and the [T][256] input-row table are built once per set of parameters
+ * (workspace = so3x_resnet_workspace_bytes(precision, T)); t_dev (optional, device int64[1]): the first timestep read on the
+ * device, clamped to [n_steps - 1, T - 1]. */
+int so3x_resnet_p_sample_prepare(so3x_stream_t s, const float* params, int T, int precision, void* workspace, size_t workspace_bytes);
+int so3x_resnet_p_sample_prepared(so3x_stream_t s, const float* sched, int T, const float* trap_p, const uint16_t* guide_p, const float* x_in,
+                                  float* x_out, int t_start, const int64_t* t_dev, int n_steps, const float* axes, const float* unif, uint64_t seed,
+                                  uint64_t rng_offset, int64_t index_base, int64_t n, int precision, const void* workspace,
+                                  size_t workspace_bytes);
 
 /* ------------------------------------------------------ SE(3) = SO(3) x R^3 layer */
 /* SE3Diffusion.q_sample + the two p_losses targets (diffusion.py:496-513) fused with the

@@ -424,3 +424,51 @@ def test_wide_net_training_with_this_stack_reaches_the_reference_trained_populat
     mmd = O.MMD(mine, ref)
     print(f"[wide trained here] MMD {mmd:.2e} (bound {thr:.2e})")
     assert not np.isnan(mine).any() and mmd < thr, (mmd, thr)
+
+
+@pytest.mark.gpu
+def test_wide_one_step_per_call_loop_runs_from_a_prepared_state(B):
+    """so3_lock_test.py:24-31 drives the 255-wide network's sampler one `p_sample` per reverse step with a (1,)-shaped device t: as
+    for the small network, every call is one launch from a cached preparation (so3x_resnet_p_sample_prepare / _prepared, t read on
+    the device) -- bit-identical to one-step launches of the unprepared entry, prepared once, rebuilt when the parameters change."""
+    from so3x import rng
+    from so3x.diffusion import SO3Diffusion
+    from so3x.so3_lock_train import RotPredict
+    torch.manual_seed(0)
+    net = RotPredict(out_type="skewvec", precision="bf16").to(DEV)
+    T = 40
+    proc = SO3Diffusion(net, timesteps=T).to(DEV)
+    x0 = B.quat_to_rmat(torch.randn(1000, 4, device=DEV))
+    calls = {"n": 0}
+    real = B.resnet_p_sample_prepare
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    B.resnet_p_sample_prepare = counting
+    try:
+        rng.manual_seed(4)
+        x = x0
+        for i in reversed(range(T)):
+            x = proc.p_sample(x, torch.full((1,), i, device=DEV, dtype=torch.long))
+        assert calls["n"] == 1
+        rng.manual_seed(4)
+        y = x0
+        _, trap_p = proc._tables()
+        prec = getattr(net, "chain_precision_code", net.precision_code)
+        for k, i in enumerate(reversed(range(T))):
+            y = B.resnet_p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, y, i, 1, seed=rng.seed(), rng_offset=k * T, precision=prec,
+                                        guide_p=proc._guide_p)
+        assert torch.equal(x, y) and torch.isfinite(x).all()
+        rng.manual_seed(4)
+        a = proc.p_sample(x0, 7)
+        rng.manual_seed(4)
+        b = proc.p_sample(x0, torch.full((1,), 7, device=DEV, dtype=torch.long))
+        assert torch.equal(a, b) and calls["n"] == 1
+        with torch.no_grad():
+            net.net[0].layer[0].weight.mul_(1.5)          # an in-place torch update: the parameters' versions move
+        rng.manual_seed(4)
+        c = proc.p_sample(x0, 7)
+        assert calls["n"] == 2 and not torch.equal(a, c)
+    finally:
+        B.resnet_p_sample_prepare = real
