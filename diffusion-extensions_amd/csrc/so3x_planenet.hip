@@ -1,5 +1,5 @@
 // so3x_planenet.hip -- the PlaneNet point-cloud denoiser (reference models.py:185-210: SIREN position encoding || sinusoidal time
-// embedding -> `layers` x nn.TransformerEncoderLayer(dim, heads) [post-norm, ReLU, feed-forward 2048, eval mode] -> PoolRN ->
+// embedding -> `layers` x nn.TransformerEncoderLayer(dim, heads) [post-norm, ReLU, feed-forward 2048; eval mode, or training mode with its dropout] -> PoolRN ->
 // Linear(dim, 3)), forward and backward, as hand-written kernels.
 //
 // This file: the EXACT-FP32 form (SO3X_PREC_F32) for any (dim, heads, layers, ffn) and the host-side plan both precisions share.
