@@ -741,6 +741,39 @@ def secondary_rooflines(line):
     return sec
 
 
+def flat_roofline_keys(line):
+    """The other legs' headline numbers as FLAT SCALAR members of `roofline` (the driver's record keeps only scalar members of that
+    object; the nested `secondary` repeats them with everything needed to recompute each one).  A leg that did not run gives None."""
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d if isinstance(d, (int, float)) and not isinstance(d, bool) else None
+    ig, tr, se, wn, pn, el, pt = (line.get(k) for k in ("igso3_eval", "train_step", "se3", "wide_net", "planenet", "external_loop", "protnet"))
+    flat = {
+        "cfg2_hbm_frac": get(ig, "frac"), "cfg2_ms": get(ig, "ms"), "cfg2_hbm_frac_at_2p24": get(ig, "at_n_2p24", "frac"),
+        "cfg2_traffic_bytes": get(ig, "traffic"),
+        "cfg4_step_ms": get(tr, "ms_per_step"),
+        "cfg4_step_frac": None if get(tr, "algorithmic_TFLOPs_per_gpu") is None else get(tr, "algorithmic_TFLOPs_per_gpu") / BF16_MFMA_PEAK_TFLOPS,
+        "cfg4_kernel_frac": get(tr, "kernel", "frac"), "cfg4_kernel_ms": get(tr, "kernel", "ms_per_call"),
+        "cfg4_kernel_traffic_bytes": get(tr, "kernel", "traffic"), "cfg4_eager_loop_ms": get(tr, "eager_python_loop_ms_per_step"),
+        "cfg5_rigid_frac": get(se, "rigid_move", "frac"), "cfg5_noise_frac": get(se, "se3_q_sample_target", "frac"),
+        "cfg5_protnet_fwd_frac": get(pt, "forward", "frac"), "cfg5_protnet_fwd_ms": get(pt, "forward", "ms"),
+        "cfg5_protnet_train_frac": get(pt, "train_eval", "frac"), "cfg5_protnet_train_ms": get(pt, "train_eval", "ms"),
+        "wide_chain_frac": get(wn, "chain", "frac"), "wide_train_step_ms": get(wn, "train_step", "ms_per_step"),
+        "wide_train_step_frac": get(wn, "train_step", "frac_of_bf16_mfma_peak"),
+        "planenet_fwd_256_frac": get(pn, "forward_32x256", "frac"), "planenet_fwd_256_ms": get(pn, "forward_32x256", "ms"),
+        "planenet_train_256_frac": get(pn, "train_eval_32x256", "frac"), "planenet_train_256_ms": get(pn, "train_eval_32x256", "ms"),
+        "planenet_fwd_2048_frac": get(pn, "forward_32x2048", "frac"), "planenet_fwd_2048_ms": get(pn, "forward_32x2048", "ms"),
+        "planenet_train_2048_frac": get(pn, "train_eval_32x2048", "frac"), "planenet_train_2048_ms": get(pn, "train_eval_32x2048", "ms"),
+        "planenet_train_2048_dropout_ms": get(pn, "train_eval_32x2048", "ms_with_dropout_0.1"),
+        "external_loop_ratio": get(el, "vs_chain_kernel_rate"), "external_loop_ms_per_call": get(el, "ms_per_call"),
+        "full_chain_sample_steps_per_s": get(line.get("full_chain"), "sample_steps_per_s"),
+    }
+    return flat
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -837,9 +870,17 @@ def main():
     # A SIMD serves two waves: port cycles of one wave-step / SIMD cycles per wave-step (live time x live clock).
     port = None
     iv = pmc_counter("k_p_sample_chain", "SQ_INSTS_VALU")
-    if prec == B.PREC_BF16 and clock_ghz and iv and isa_mix("chain"):
+    # sanity gate on the quoted profile: a 100-step launch of this kernel issues ~1,100 vector instructions per 64-sample wave-step.
+    # A value outside [500, 3000] means the profile's counters belong to another launch shape (round 5: one-step launches summarised
+    # as 100-step ones gave 14) -- then NOTHING PMC-derived is quoted for this kernel.
+    n_valu_profile = None if not iv else iv / ((1 << 20) // 64 * 100)              # the profile's shape: 2^20 samples, 100 steps per launch
+    pmc_chain_ok = n_valu_profile is not None and 500.0 <= n_valu_profile <= 3000.0
+    pmc_chain_note = ("ok: %.0f vector instructions per wave-step in the profile" % n_valu_profile) if pmc_chain_ok else (
+        "withheld: no fresh profile" if n_valu_profile is None else
+        "withheld: the profile implies %.1f vector instructions per wave-step, outside [500, 3000] -- its counters are not a 100-step launch's" % n_valu_profile)
+    if prec == B.PREC_BF16 and clock_ghz and pmc_chain_ok and isa_mix("chain"):
         wave_steps = ((n + 63) // 64) * RL_STEPS
-        n_valu = iv / ((1 << 20) // 64 * 100)              # the profile's shape: 2^20 samples, 100 steps per launch
+        n_valu = n_valu_profile
         mix = isa_mix("chain") or {}
         n_mfma, n_trans = mix.get("mfma_per_wave_step"), mix.get("trans_per_wave_step")   # tools/count_isa.py on the step loop
         port_cycles = (n_valu - n_mfma - n_trans) * 4 + n_trans * 8 + n_mfma * 8
@@ -853,7 +894,7 @@ def main():
     # ISSUED matrix work: the PMC count of bf16 MFMA "MOPS" per launch of the profiled shape (x 512 flop each: the padded 96-row
     # tiles and the fifth k-step included) over THIS run's launch time -- the other way to read "40 % MFMA utilisation"
     mops = pmc_counter("k_p_sample_chain", "SQ_INSTS_VALU_MFMA_MOPS_BF16")
-    issued_tflops = None if (not mops or n != (1 << 20) or prec != B.PREC_BF16) else mops * 512.0 / (ms_per_launch * 1e-3) / 1e12
+    issued_tflops = None if (not mops or not pmc_chain_ok or n != (1 << 20) or prec != B.PREC_BF16) else mops * 512.0 / (ms_per_launch * 1e-3) / 1e12
 
     # ---- the f16-operand LEG of the same kernel (SO3X_PREC_F16): a labelled extra beside the bf16 headline -- what
     #      "config 3 names bf16" costs or buys -- same shape, three launches, HIP events.  Never the headline.
@@ -931,9 +972,10 @@ def main():
                          "issued_TFLOPs": issued_tflops,
                          "pmc_source": PMC.source, "silu": "256-entry secant table (max abs error 1.3e-4), bf16 chain kernel",
                          "f16_operand_leg": f16_leg,
-                         "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=RL_STEPS, precision=args.precision),
-                         "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_p_sample_chain"),
-                         "valu_busy_frac_pmc": pmc_valu_busy("k_p_sample_chain"),
+                         "pmc_sanity": pmc_chain_note,
+                         "traffic": pmc_traffic("k_p_sample_chain", batch=n, steps_per_launch=RL_STEPS, precision=args.precision) if pmc_chain_ok else None,
+                         "mfma_pipe_busy_frac_pmc": pmc_mfma_busy("k_p_sample_chain") if pmc_chain_ok else None,
+                         "valu_busy_frac_pmc": pmc_valu_busy("k_p_sample_chain") if pmc_chain_ok else None,
                          "in_kernel_clock_ghz": clock_ghz,
                          "valu_port_bound_frac": None if port is None else port["frac"], "valu_port_accounting": port,
                          "launches": RL_LAUNCHES, "steps_per_launch": RL_STEPS, "ms_per_launch": ms_per_launch,
@@ -1017,6 +1059,7 @@ def main():
                 line["external_loop"] = {"error": repr(e)}
         if cpu_leg is not None:
             line["cpu_baseline"] = cpu_leg
+        line["roofline"].update(flat_roofline_keys(line))     # flat scalars first: what the driver's record keeps
         line["roofline"]["secondary"] = secondary_rooflines(line)
         line["gpu_legs_wall_seconds"] = time.perf_counter() - t_gpu_legs
         print(json.dumps(line), flush=True)

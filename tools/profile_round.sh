@@ -21,22 +21,31 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 100 > $out/pmc_$i.log 2>&1
 done
 # keep what tools/summarize_profiles.py reads, in a size gpurun copies back (<= 64 MiB for all of gpurun_out/): the counter files
-# with five columns and kernel names cut to 100 characters, the PMC passes' own kernel traces dropped
+# with seven columns and kernel names cut to 100 characters, the PMC passes' own kernel traces cut to three columns
 python3 - "$out" <<'PY'
 import csv, glob, os, sys
 out = sys.argv[1]
+# the PMC passes' kernel traces shrink to (dispatch id, start, end): tools/summarize_profiles.py joins them to the counters to tell
+# a kernel's launch shapes apart by DURATION (k_p_sample_chain runs with 1, 100 and 1000 steps per launch on the same grid)
 for f in glob.glob(os.path.join(out, "pmc_*", "*kernel_trace.csv")):
-    os.remove(f)
-keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    rows = list(csv.DictReader(open(f)))
+    cols = [c for c in ("Dispatch_Id", "Start_Timestamp", "End_Timestamp") if rows and c in rows[0]]
+    with open(f, "w", newline="") as g:
+        w = csv.DictWriter(g, fieldnames=cols)
+        w.writeheader()
+        w.writerows({c: r[c] for c in cols} for r in rows)
+keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
 for f in glob.glob(os.path.join(out, "pmc_*", "*counter_collection.csv")):
-    rows = [{k: (r[k][:100] if k == "Kernel_Name" else r[k]) for k in keep} for r in csv.DictReader(open(f))]
+    rows = list(csv.DictReader(open(f)))
+    keep = [k for k in keep if rows and k in rows[0]]
+    rows = [{k: (r[k][:100] if k == "Kernel_Name" else r[k]) for k in keep} for r in rows]
     with open(f, "w", newline="") as g:
         w = csv.DictWriter(g, fieldnames=keep)
         w.writeheader()
         w.writerows(rows)
 for f in glob.glob(os.path.join(out, "stats", "*kernel_trace.csv")):
     rows = list(csv.DictReader(open(f)))
-    cols = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size"]
+    cols = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size", "Grid_Size_X", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size"]
     cols = [c for c in cols if rows and c in rows[0]]
     with open(f, "w", newline="") as g:
         w = csv.DictWriter(g, fieldnames=cols)

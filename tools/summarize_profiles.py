@@ -19,21 +19,57 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line.json"))
 shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 
-# per-dispatch durations of the headline kernel from the kernel trace: bench.py launches it with 100 steps (ramp, warm-up, timed
-# region, roofline leg) and once with all 1000 (full_chain), so the stats file's plain average mixes two shapes
+# k_p_sample_chain runs in bench.py with THREE launch shapes on the same grid: 100 steps per launch (ramp, warm-up, timed region,
+# roofline leg), 1000 (full_chain) and ONE (external_loop: 1000 calls -- the majority of its dispatches since round 5).  A dispatch's
+# shape is read off its DURATION: steps ~ duration / (55 ns x samples / 2^20 ... per step), binned on a log scale.  Never "the
+# majority", never a plain median over all dispatches of the grid (round 5's summary did that and priced one-step counters as a
+# 100-step launch).
+CHAIN_MS_PER_STEP_AT_2P20 = 0.055   # measured, any round; the bins below are a factor 3 wide on each side, PMC-pass inflation fits
+
+
+def chain_steps_class(dur_ms, grid):
+    if dur_ms is None or not grid:
+        return None
+    est = dur_ms / (CHAIN_MS_PER_STEP_AT_2P20 * grid / float(1 << 20))
+    if est < 12:
+        return 1
+    if 30 <= est <= 320:
+        return 100
+    if est > 320:
+        return 1000
+    return None     # 12..30 steps: the chain's tail cuts and tools' odd step counts; quoted nowhere
+
+
+def chain_is_bf16(kname):
+    """k_p_sample_chain<PREC, FAST, PAIR, WIDE, F16>: the headline is PREC = 1 (SO3X_PREC_BF16) with F16 = false"""
+    import re
+    m = re.search(r"k_p_sample_chainILi(\d)E(?:Lb\dE){3}Lb(\d)E", kname) or re.search(r"k_p_sample_chain<(\d), \w+, \w+, \w+, (\w+)>", kname)
+    return bool(m) and m.group(1) == "1" and m.group(2) in ("0", "false")
+
+
 trace = glob.glob(os.path.join(src, "stats", "*kernel_trace.csv"))
 if trace:
-    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace[0])) if "k_p_sample_chain" in r["Kernel_Name"]]
-    short = sorted(d for d in durs if d < 3 * min(durs))
-    json.dump({"what": "k_p_sample_chain dispatch durations (ms) under rocprofv3 --kernel-trace, same command as the bench line",
-               "dispatches": len(durs), "ms_all": [round(d, 4) for d in durs],
-               "ms_100_step_launches_median": statistics.median(short), "ms_100_step_launches_mean": sum(short) / len(short),
-               "n_100_step_launches": len(short)}, open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
+    recs = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0) or (1 << 20))
+            for r in csv.DictReader(open(trace[0])) if "k_p_sample_chain" in r["Kernel_Name"]]
+    by = collections.defaultdict(list)
+    for d, g in recs:
+        by[chain_steps_class(d, g) if g == (1 << 20) else "other_grid"].append(d)
+    hundred = sorted(by.get(100, []))
+    json.dump({"what": "k_p_sample_chain dispatch durations (ms) under rocprofv3 --kernel-trace, same command as the bench line; launches classified "
+                       "by duration into 1 / 100 / 1000 steps per launch (tools/summarize_profiles.py:chain_steps_class)",
+               "dispatches": len(recs), "dispatches_by_steps_per_launch": {str(k): len(v) for k, v in by.items()},
+               "ms_100_step_launches_median": statistics.median(hundred) if hundred else None,
+               "ms_100_step_launches_mean": sum(hundred) / len(hundred) if hundred else None, "n_100_step_launches": len(hundred),
+               "ms_100_step_launches": [round(d, 4) for d in hundred],
+               "ms_one_step_launches_median": statistics.median(by[1]) if by.get(1) else None,
+               "ms_1000_step_launches": [round(d, 3) for d in by.get(1000, [])]},
+              open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
 
 KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_se3_q_sample_target",
            "k_q_sample_target", "k_rigid_move", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_reduce", "k_adam", "k_prep",
            "k_gemm256_bf16", "k_gemm_bf16", "k_gemm_tn", "k_attn_fwd", "k_attn_bwd_dq", "k_attn_bwd_dkv", "k_ln_bf16", "k_ln_bwd_bf16")
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
+unclassified = collections.Counter()   # counter -> k_p_sample_chain dispatches without a duration (dropped)
 legs = {}  # counter -> the k_logprob_score dispatches at 2^20 evaluations in dispatch order, split into bench.py's three legs
 for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
     f = glob.glob(os.path.join(d, "*counter_collection.csv"))
@@ -41,13 +77,29 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
         continue
     disp = collections.defaultdict(float)
     meta = {}
+    dur = {}   # dispatch id -> ms, from the counter file's own timestamps or the pass's kernel trace (tools/profile_round.sh keeps both)
+    for tf in glob.glob(os.path.join(d, "*kernel_trace.csv")):
+        for r in csv.DictReader(open(tf)):
+            if "Dispatch_Id" in r and "End_Timestamp" in r:
+                dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     for r in csv.DictReader(open(f[0])):
         key = (r["Dispatch_Id"], r["Counter_Name"])
         disp[key] += float(r["Counter_Value"])
         meta[r["Dispatch_Id"]] = (r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0))
+        if r.get("End_Timestamp") and r["Dispatch_Id"] not in dur:
+            dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     for (did, cname), v in disp.items():
         kname, grid = meta[did]
         short = next((k for k in KERNELS if k in kname), None)
+        if short == "k_p_sample_chain":
+            # the launch shape by duration; a dispatch whose duration is unknown is NOT counted (no guess by majority)
+            cls = chain_steps_class(dur.get(did), grid)
+            unclassified[cname] += cls is None
+            if cls is None:
+                continue
+            short = {1: "k_p_sample_chain:1step", 100: "k_p_sample_chain", 1000: "k_p_sample_chain:1000step"}[cls]
+            if not chain_is_bf16(kname):      # the f16 / fp32 operand instantiations: their own rows
+                short += ":not_bf16"
         if short:
             per.setdefault(cname, {}).setdefault((short, grid), []).append(v)
     # bench.py times k_logprob_score at 2^20 evaluations on three inputs, in this order: eps from the schedule (config 2b),
@@ -67,8 +119,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
 rows = []
 for cname, ks in sorted(per.items()):
     for (k, grid), vals in sorted(ks.items()):
-        # "mean" = the MEDIAN over the dispatches: bench.py also launches the chain kernel once for a whole 1000-step chain and a
-        # few times with other step counts; the 100-step launches are the majority and the median is one of them
+        # "mean" = the MEDIAN over the dispatches of ONE launch shape (k_p_sample_chain's shapes are separate rows, see above)
         rows.append({"counter": cname, "kernel": k, "grid_size": grid, "dispatches": len(vals), "mean": statistics.median(vals),
                      "min": min(vals), "max": max(vals)})
 with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
@@ -97,11 +148,16 @@ spl = int(line["roofline"]["steps_per_launch"])
 traffic = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --no-cpu-baseline --steps 300 "
                    f"--warmup 100` ({tag}); counters are KB per dispatch; FETCH_SIZE is doubled (gfx950 reports half of wide "
                    "streaming reads, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is"}
-fs, wsz = mean("FETCH_SIZE", "k_p_sample_chain"), mean("WRITE_SIZE", "k_p_sample_chain")
+fs, wsz = mean("FETCH_SIZE", "k_p_sample_chain", 1 << 20), mean("WRITE_SIZE", "k_p_sample_chain", 1 << 20)
 if fs is not None and wsz is not None:
     traffic["k_p_sample_chain"] = {"config": {"batch": n, "steps_per_launch": spl, "precision": line["dtype"]},
                                    "fetch_size_kb": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": int((2 * fs + wsz) * 1024),
-                                   "algorithmic_bytes_per_launch": 72 * n}
+                                   "algorithmic_bytes_per_launch": 72 * n,
+                                   "dispatches_in_the_median": next(r["dispatches"] for r in rows if r["counter"] == "FETCH_SIZE" and r["kernel"] == "k_p_sample_chain" and r["grid_size"] == 1 << 20)}
+fs1, wsz1 = mean("FETCH_SIZE", "k_p_sample_chain:1step", 1 << 20), mean("WRITE_SIZE", "k_p_sample_chain:1step", 1 << 20)
+if fs1 is not None and wsz1 is not None:   # the one-call-per-step loop's launches (bench.py external_loop): their own record
+    traffic["k_p_sample_chain:1step"] = {"config": {"batch": n, "steps_per_launch": 1, "precision": line["dtype"]}, "fetch_size_kb": fs1,
+                                         "write_size_kb": wsz1, "hbm_bytes_per_launch": int((2 * fs1 + wsz1) * 1024), "algorithmic_bytes_per_launch": 72 * n}
 lg = [r for r in rows if r["counter"] == "FETCH_SIZE" and r["kernel"] == "k_logprob_score"]
 if lg:
     small = min(lg, key=lambda r: r["grid_size"])
@@ -164,7 +220,7 @@ try:
 except OSError:
     prof_digest = None
 git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-traffic["_meta"] = {"tag": tag, "csrc_sha256": prof_digest, "csrc_sha256_at_summary": digest(ROOT), "git": git,
+traffic["_meta"] = {"chain_dispatches_without_a_duration_dropped": dict(unclassified), "tag": tag, "csrc_sha256": prof_digest, "csrc_sha256_at_summary": digest(ROOT), "git": git,
                     "note": "csrc_sha256 = tools/csrc_digest.py on the GPU box at profile time; bench.py quotes PMC fields only while it matches"}
 # instruction mix of the chain kernel's step loop, from the same sources (no GPU needed): what bench.py's vector-port accounting
 # takes its MFMA / transcendental counts from
