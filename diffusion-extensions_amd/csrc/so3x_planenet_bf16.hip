@@ -22,7 +22,8 @@
 namespace so3x {
 namespace plane {
 
-bool bf16_supported(const Shape& s) { return s.d == D && s.H == HEADS && s.F == FF && s.P % 64 == 0 && s.P >= 64; }
+// (layers <= 4: the backward's transpose table holds 4 layers' matrices + the head -- refused here, before a forward builds a stash)
+bool bf16_supported(const Shape& s) { return s.d == D && s.H == HEADS && s.F == FF && s.P % 64 == 0 && s.P >= 64 && s.L <= 4; }
 
 // ------------------------------------------------------------------------------------------------ fp32 -> bf16 image
 __global__ __launch_bounds__(256) void k_cvt_bf16(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n4) {

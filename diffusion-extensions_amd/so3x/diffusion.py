@@ -201,7 +201,8 @@ class SO3Diffusion(nn.Module):
         self._trap_p = None  # rows for sigma_t = exp(0.5 * logvar_t)     (p_sample)
         self._guide_q = None  # search guide of the q rows (looked up per sample: t differs across the batch)
         self._guide_p = None  # and of the p rows (saves ~7 of the 10 bisection rounds of every reverse step)
-        self._prep = None     # (key, workspace): the reverse-chain kernel's prepared state for the current parameters
+        from .flat import PreparedCache
+        self._prep = PreparedCache()   # the reverse-chain kernel's prepared state for the current parameters
 
     # ------------------------------------------------------------------ tables
     def _tables(self):
@@ -213,10 +214,12 @@ class SO3Diffusion(nn.Module):
             self._guide_p = _b.igso3_build_guide(self._trap_p)
         return self._trap_q, self._trap_p
 
-    def _prepared(self, net):
+    def _prepared(self, net, check=False):
         """so3x_p_sample_prepare's workspace for the 65-wide network's CURRENT parameters (weight image, per-timestep rows, CDF
         records for all T steps): built on first use and whenever the flat parameter buffer, the parameters' tensor versions, the
-        out-of-band update epoch (graph replays), the precision or the tables change.  A p_sample call then is one kernel launch."""
+        out-of-band update epoch (graph replays), the precision or the tables change -- and, for writes torch's versions do not see
+        (`p.data`, EMA), when the buffer's fingerprint no longer matches (so3x.flat.PreparedCache: compared at chain starts, after
+        idle gaps, on train() / eval() switches and every 256 calls).  A p_sample call then is one kernel launch."""
         from .flat import PARAM_EPOCH
         _, trap_p = self._tables()
         flat = net.flat_params_nograd()
@@ -225,15 +228,19 @@ class SO3Diffusion(nn.Module):
         #  -- load_state_dict, torch.optim -- bumps THEIR versions)
         key = (flat.data_ptr(), tuple(p._version for p in net._flat_params), PARAM_EPOCH[0], prec, trap_p.data_ptr(),
                self._guide_p.data_ptr(), flat.device)
-        if self._prep is None or self._prep[0] != key:
-            wide = getattr(net, "kind", "") == "resnet255"
-            self._prep = (key, _b.resnet_p_sample_prepare(flat, self.num_timesteps, prec) if wide
-                          else _b.p_sample_prepare(flat, self._sched, trap_p, prec, guide_p=self._guide_p))
-        return self._prep[1], prec
+        wide = getattr(net, "kind", "") == "resnet255"
+        ws = self._prep.get(key, flat, lambda: _b.resnet_p_sample_prepare(flat, self.num_timesteps, prec) if wide
+                            else _b.p_sample_prepare(flat, self._sched, trap_p, prec, guide_p=self._guide_p), check=check)
+        return ws, prec
 
     def invalidate_sampling_cache(self):
-        """for callers that rewrite the parameters behind torch's back (raw pointers, their own captured graphs)"""
-        self._prep = None
+        """for callers that rewrite the parameters behind torch's back (`p.data` writes, raw pointers, their own captured graphs)
+        and want the next p_sample to see it unconditionally"""
+        self._prep.invalidate()
+
+    def train(self, mode=True):
+        self._prep.check_next()      # a mode switch usually brackets a weight update: the next p_sample compares fingerprints
+        return super().train(mode)
 
     def _fused_net(self, sampling=False):
         """the denoiser when it is one of the two score networks with fused kernels (so3_train / so3_lock_train RotPredict)"""
@@ -308,13 +315,9 @@ class SO3Diffusion(nn.Module):
         t0, same = self._shared_t(t)
         off = _rng.next_offset(self.num_timesteps) if axes is None else 0
         if small and same:
-            ws, prec = self._prepared(net)
+            ws, prec = self._prepared(net, check=t0 == self.num_timesteps - 1)   # a chain's first step: compare fingerprints
             return _b.p_sample_prepared(ws, self._sched, trap_p, x, t0, 1, axes=axes, unif=unif, seed=_rng.seed(), rng_offset=off,
                                         index_base=self.index_base, precision=prec, guide_p=self._guide_p, wide=wide)
-        if net is not None and same:
-            return self._chain_fn(net)(net.flat_params_nograd(), self._sched, trap_p, x, t0, 1, axes=axes, unif=unif,
-                                     seed=_rng.seed(), rng_offset=off, index_base=self.index_base,
-                                     precision=getattr(net, "chain_precision_code", net.precision_code), guide_p=self._guide_p)
         tt = t if isinstance(t, torch.Tensor) else torch.full((1,), t0, device=x.device, dtype=torch.long)
         predict = self.denoise_fn(x, tt)
         _, mean = _b.p_mean(self._sched, x, predict, tt if not same else t0)

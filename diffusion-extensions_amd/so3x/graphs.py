@@ -404,10 +404,10 @@ class TrainStepGraph:
         self._pending = True
 
     def flush(self):
-        from .flat import params_changed_out_of_band
-        params_changed_out_of_band()
         """pipelined form: run the outstanding reduction + all-reduce + optimizer update (a no-op otherwise).  After it the
         parameters are those of the eager loop after the same number of steps."""
+        from .flat import params_changed_out_of_band
+        params_changed_out_of_band()
         if not (self.pipelined and self._pending):
             return
         if self.mode == "in_graph":

@@ -153,7 +153,8 @@ class PlaneNet(FlatParamsMixin, nn.Module):
         self.out_net = nn.Sequential(PoolRN(dim), nn.Linear(dim, 3))
         self.dim, self.heads, self.layers, self.precision, self.dropout = dim, heads, layers, precision, dropout
         self.ffn = self.encoder.layers[0].linear1.out_features
-        self._prep = None   # (key, bf16 weight image): inference reuses it while the parameters do not change
+        from .flat import PreparedCache
+        self._prep = PreparedCache(every=64)   # the bf16 weight image: inference reuses it while the parameters do not change
         self._init_flat()
 
     def _flat_root(self):
@@ -166,14 +167,21 @@ class PlaneNet(FlatParamsMixin, nn.Module):
 
     def _prepared(self):
         """the bf16 image of the weight matrices for the current parameters (so3x_planenet_prepare), rebuilt when any parameter's
-        tensor version, the out-of-band update epoch or the buffer changes (as SO3Diffusion's prepared sampling state)"""
+        tensor version, the out-of-band update epoch or the buffer changes, and when the buffer's fingerprint does (writes through
+        `p.data`: so3x.flat.PreparedCache, as SO3Diffusion's prepared sampling state)"""
         from . import backend as _b
         from .flat import PARAM_EPOCH
         flat = self.flat_params_nograd()
         key = (flat.data_ptr(), tuple(p._version for p in self._flat_params), PARAM_EPOCH[0], self.precision, flat.device)
-        if self._prep is None or self._prep[0] != key:
-            self._prep = (key, _b.planenet_prepare(flat, *self.cfg))
-        return self._prep[1]
+        return self._prep.get(key, flat, lambda: _b.planenet_prepare(flat, *self.cfg))
+
+    def invalidate_prepared(self):
+        """for callers that rewrite the parameters behind torch's back and want the next forward to see it unconditionally"""
+        self._prep.invalidate()
+
+    def train(self, mode=True):
+        self._prep.check_next()      # train() / eval() usually bracket a weight update: the next inference compares fingerprints
+        return super().train(mode)
 
     def forward(self, x, t, want_encoding=False):
         from . import backend as _b

@@ -318,7 +318,8 @@ int so3x_rotate_cloud(so3x_stream_t s, const float* rot, const float* cloud, int
  *   out_net.0.pool.0.{weight, bias}, out_net.0.lin.{weight, bias}, out_net.1.{weight, bias}: so3x_planenet_param_count values.
  * precision SO3X_PREC_F32: every product on the exact-fp32 MFMA, any (dim, heads, layers, ffn) with dim % heads == 0, dim % 4 == 0;
  *           SO3X_PREC_BF16: bf16 operands / fp32 accumulate, activations kept in bf16; dim = 512, heads = 4 (head width 128),
- *           ffn = 2048, P % 64 == 0 only (the aircraft task's shape), else SO3X_ERR_UNSUPPORTED.
+ *           ffn = 2048, P % 64 == 0, layers <= 4 only (the aircraft task's shape), else SO3X_ERR_UNSUPPORTED -- from the
+ *           forward already, so that no stash is built for a backward that would refuse it.
  * so3x_planenet_fwd: stash == NULL: inference (layer buffers reused inside the workspace).  stash != NULL
  *   (so3x_planenet_stash_bytes): every layer's activations are kept there for so3x_planenet_bwd.  encoding_out (optional):
  *   the encoder's output [B][P][dim] fp32 (parity tests).

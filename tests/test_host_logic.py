@@ -411,3 +411,37 @@ def test_bench_gpus_n_starts_its_own_ranks_without_touching_a_gpu():
     assert r.returncode != 0
     assert (r.stdout + r.stderr).count("needs an MI355X") == 2, r.stdout + r.stderr   # both ranks started, met, and refused
     assert "needs torch.distributed.run" not in r.stdout + r.stderr
+
+
+def test_prepared_cache_sees_writes_that_tensor_versions_miss():
+    """so3x.flat.PreparedCache: the cheap key misses `p.data` writes; the buffer's fingerprint finds them when a
+    comparison is due (on request, after check_next(), after an idle gap, every N hits) -- and an unchanged buffer never rebuilds."""
+    import time
+    from so3x.flat import PreparedCache
+    flat = torch.arange(1000, dtype=torch.float32)
+    built = []
+    c = PreparedCache(every=4, idle_s=1e9)
+    build = lambda: built.append(1) or len(built)   # noqa: E731
+    assert c.get("k", flat, build) == 1 and c.get("k", flat, build) == 1
+    flat.data.mul_(2.0)                              # invisible to the key
+    assert c.get("k", flat, build) == 1              # no comparison due: stale (hit 2 of 4)
+    assert c.get("k", flat, build, check=True) == 2  # on request
+    flat.data.add_(1.0)
+    c.check_next()
+    assert c.get("k", flat, build) == 3              # armed by a mode switch
+    flat.data.add_(1.0)
+    assert [c.get("k", flat, build) for _ in range(4)][-1] == 4   # every 4th hit
+    assert c.get("k2", flat, build) == 5             # a new key rebuilds as before
+    c.invalidate()
+    assert c.get("k2", flat, build) == 6
+    n = len(built)
+    for _ in range(20):
+        c.get("k2", flat, build, check=True)
+    assert len(built) == n                           # unchanged values: comparisons never rebuild
+    c2 = PreparedCache(every=10 ** 9, idle_s=0.01)
+    c2.get("k", flat, build)
+    flat.data.add_(1.0)
+    time.sleep(0.03)
+    m = len(built)
+    c2.get("k", flat, build)
+    assert len(built) == m + 1                       # idle gap

@@ -703,6 +703,33 @@ def test_one_step_per_call_loop_equals_the_chain_and_never_goes_stale(mods):
         want = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x0, 17, 1, seed=mods["rng"].seed(), rng_offset=0,
                                 precision=net.precision_code, guide_p=proc._guide_p)
         assert torch.equal(e, want)
+        # (d) a write torch's version counters do NOT see (EMA / weight averaging through `p.data`): found by the buffer's
+        # fingerprint at the next chain start, after train() / eval(), after an idle gap, or on request
+        built = calls["n"]
+        for p_ in net.parameters():
+            p_.data.mul_(0.9)
+        mods["rng"].manual_seed(9)
+        f = proc.p_sample(x0, torch.full((1,), T - 1, device=DEV, dtype=torch.long).item())   # host-known t = T - 1: a chain start
+        mods["rng"].manual_seed(9)
+        want = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x0, T - 1, 1, seed=mods["rng"].seed(), rng_offset=0,
+                                precision=net.precision_code, guide_p=proc._guide_p)
+        assert calls["n"] == built + 1 and torch.equal(f, want)
+        for p_ in net.parameters():
+            p_.data.mul_(0.9)
+        proc.eval()                                                      # the mode switch arms the comparison for the next call
+        mods["rng"].manual_seed(9)
+        g_ = proc.p_sample(x0, torch.full((1,), 17, device=DEV, dtype=torch.long))
+        mods["rng"].manual_seed(9)
+        want = B.p_sample_chain(net.flat_params_nograd(), proc._sched, trap_p, x0, 17, 1, seed=mods["rng"].seed(), rng_offset=0,
+                                precision=net.precision_code, guide_p=proc._guide_p)
+        assert calls["n"] == built + 2 and torch.equal(g_, want)
+        for p_ in net.parameters():
+            p_.data.mul_(0.9)
+        proc.invalidate_sampling_cache()
+        proc.p_sample(x0, 17)
+        assert calls["n"] == built + 3
+        proc.p_sample(x0, 16)                                            # unchanged parameters: no rebuild, whatever was compared
+        assert calls["n"] == built + 3
     finally:
         B.p_sample_prepare = real
     # the device-side timestep is clamped into the tables, never read outside them
