@@ -161,36 +161,50 @@ class Pmc:
     profile time).  When they are not, nothing is quoted: a stale profile must not price a new kernel."""
 
     def __init__(self):
-        self.data, self.meta, self.fresh = {}, {}, False
+        self.data, self.meta, self.fresh, self.fresh_units = {}, {}, False, {}
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 self.data = json.load(f)
             self.meta = self.data.get("_meta", {})
             sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from csrc_digest import digest
+            from csrc_digest import digest, unit_digests, kernel_unit
+            self._kernel_unit = kernel_unit
             self.fresh = bool(self.meta.get("csrc_sha256")) and self.meta["csrc_sha256"] == digest(ROOT)
+            # per translation unit: a kernel's counters stay quotable while ITS unit (and the headers it includes) is unchanged
+            now, then = unit_digests(ROOT), self.meta.get("csrc_sha256_by_unit") or {}
+            self.fresh_units = {u: then.get(u) == h for u, h in now.items()}
         except (OSError, ValueError, ImportError):
             pass
+
+    def is_fresh(self, kernel):
+        if self.fresh:
+            return True
+        unit = self._kernel_unit(kernel) if self.data else None
+        return bool(unit) and self.fresh_units.get(unit, False)
 
     @property
     def source(self):
         if not self.data:
             return "none: profiles/pmc_traffic.json missing"
         tag = f"committed profile {self.meta.get('tag', '?')} (profiles/pmc_traffic.json, summarised at git {self.meta.get('git', '?')})"
-        return tag + (": kernel sources unchanged since it was taken" if self.fresh else
+        if self.fresh:
+            return tag + ": kernel sources unchanged since it was taken"
+        stale = sorted(u for u, ok in self.fresh_units.items() if not ok)
+        return tag + (": units changed since it was taken: " + ", ".join(stale) + " -- PMC-derived fields of THEIR kernels withheld"
+                      if self.fresh_units and len(stale) < len(self.fresh_units) else
                       ": STALE -- the kernel sources changed since it was taken; PMC-derived fields withheld")
 
     def traffic(self, kernel, **match):
         """HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md + WRITE_SIZE), only when the
         profiled configuration matches this run"""
-        rec = self.data.get(kernel) if self.fresh else None
+        rec = self.data.get(kernel) if self.is_fresh(kernel) else None
         if rec and all(rec.get("config", {}).get(k) == v for k, v in match.items()):
             return rec["hbm_bytes_per_launch"]
         return None
 
     def counter(self, kernel, name):
         try:
-            return self.data["mfma_utilisation"][kernel][name] if self.fresh else None
+            return self.data["mfma_utilisation"][kernel][name] if self.is_fresh(kernel) else None
         except KeyError:
             return None
 
@@ -215,7 +229,7 @@ def isa_mix(name):
     written by tools/summarize_profiles.py), or None when the sources changed since"""
     try:
         with open(os.path.join(ROOT, "profiles", f"{PMC.meta.get('tag', 'r04')}_{name}_isa_mix.json")) as f:
-            return json.load(f) if PMC.fresh else None
+            return json.load(f) if PMC.is_fresh("k_p_sample_chain") else None
     except (OSError, ValueError):
         return None
 

@@ -214,14 +214,18 @@ traffic["mfma_utilisation"] = util
 # summary was made; bench.py withholds every PMC-derived field once the kernel sources no longer match
 import subprocess
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from csrc_digest import digest
+from csrc_digest import digest, unit_digests
 try:
-    prof_digest = open(os.path.join(src, "csrc_sha256.txt")).read().strip()
+    raw = open(os.path.join(src, "csrc_sha256.txt")).read().strip()
+    rec = json.loads(raw) if raw.startswith("{") else {"all": raw, "units": None}
 except OSError:
-    prof_digest = None
+    rec = {"all": None, "units": None}
+prof_digest = rec["all"]
 git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-traffic["_meta"] = {"chain_dispatches_without_a_duration_dropped": dict(unclassified), "tag": tag, "csrc_sha256": prof_digest, "csrc_sha256_at_summary": digest(ROOT), "git": git,
-                    "note": "csrc_sha256 = tools/csrc_digest.py on the GPU box at profile time; bench.py quotes PMC fields only while it matches"}
+traffic["_meta"] = {"chain_dispatches_without_a_duration_dropped": dict(unclassified), "tag": tag, "csrc_sha256": prof_digest,
+                    "csrc_sha256_by_unit": rec["units"], "csrc_sha256_at_summary": digest(ROOT), "git": git,
+                    "note": "csrc_sha256 / csrc_sha256_by_unit = tools/csrc_digest.py on the GPU box at profile time; bench.py quotes a kernel's "
+                            "PMC fields only while the digest of the translation unit that kernel is compiled from still matches"}
 # instruction mix of the chain kernel's step loop, from the same sources (no GPU needed): what bench.py's vector-port accounting
 # takes its MFMA / transcendental counts from
 try:
