@@ -19,25 +19,25 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line.json"))
 shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 
-# k_p_sample_chain runs in bench.py with THREE launch shapes on the same grid: 100 steps per launch (ramp, warm-up, timed region,
-# roofline leg), 1000 (full_chain) and ONE (external_loop: 1000 calls -- the majority of its dispatches since round 5).  A dispatch's
-# shape is read off its DURATION: steps ~ duration / (55 ns x samples / 2^20 ... per step), binned on a log scale.  Never "the
-# majority", never a plain median over all dispatches of the grid (round 5's summary did that and priced one-step counters as a
+# k_p_sample_chain runs in bench.py with FOUR launch shapes on the same (persistent) grid: 100 steps per launch at 2^20 samples
+# (ramp, warm-up, timed region, roofline leg), 1000 steps (full_chain), ONE step at 2^20 (external_loop: 1000 calls -- the majority
+# of its dispatches since round 5) and one step at 2^22 (external_loop.at_batch_4M).  The grid is the same for all of them (one
+# workgroup per CU), so a dispatch's shape is read off its DURATION, in bins a factor > 2 apart (55 us per step at 2^20 samples):
+#   < 0.15 ms: 1 step, 2^20 | 0.15 - 1 ms: 1 step, 2^22 | 2.5 - 15 ms: 100 steps | > 30 ms: 1000 steps | else: not counted.
+# Never "the majority", never a plain median over all dispatches (round 5's summary did that and priced one-step counters as a
 # 100-step launch).
-CHAIN_MS_PER_STEP_AT_2P20 = 0.055   # measured, any round; the bins below are a factor 3 wide on each side, PMC-pass inflation fits
-
-
-def chain_steps_class(dur_ms, grid):
-    if dur_ms is None or not grid:
+def chain_steps_class(dur_ms, grid=None):
+    if dur_ms is None:
         return None
-    est = dur_ms / (CHAIN_MS_PER_STEP_AT_2P20 * grid / float(1 << 20))
-    if est < 12:
+    if dur_ms < 0.15:
         return 1
-    if 30 <= est <= 320:
+    if dur_ms < 1.0:
+        return "1@4M"
+    if 2.5 <= dur_ms <= 15.0:
         return 100
-    if est > 320:
+    if dur_ms > 30.0:
         return 1000
-    return None     # 12..30 steps: the chain's tail cuts and tools' odd step counts; quoted nowhere
+    return None
 
 
 def chain_is_bf16(kname):
@@ -53,7 +53,7 @@ if trace:
             for r in csv.DictReader(open(trace[0])) if "k_p_sample_chain" in r["Kernel_Name"]]
     by = collections.defaultdict(list)
     for d, g in recs:
-        by[chain_steps_class(d, g) if g == (1 << 20) else "other_grid"].append(d)
+        by[chain_steps_class(d)].append(d)
     hundred = sorted(by.get(100, []))
     json.dump({"what": "k_p_sample_chain dispatch durations (ms) under rocprofv3 --kernel-trace, same command as the bench line; launches classified "
                        "by duration into 1 / 100 / 1000 steps per launch (tools/summarize_profiles.py:chain_steps_class)",
@@ -97,7 +97,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
             unclassified[cname] += cls is None
             if cls is None:
                 continue
-            short = {1: "k_p_sample_chain:1step", 100: "k_p_sample_chain", 1000: "k_p_sample_chain:1000step"}[cls]
+            short = {1: "k_p_sample_chain:1step", "1@4M": "k_p_sample_chain:1step_4M", 100: "k_p_sample_chain", 1000: "k_p_sample_chain:1000step"}[cls]
             if not chain_is_bf16(kname):      # the f16 / fp32 operand instantiations: their own rows
                 short += ":not_bf16"
         if short:
@@ -148,13 +148,13 @@ spl = int(line["roofline"]["steps_per_launch"])
 traffic = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --no-cpu-baseline --steps 300 "
                    f"--warmup 100` ({tag}); counters are KB per dispatch; FETCH_SIZE is doubled (gfx950 reports half of wide "
                    "streaming reads, MI355X_MICROARCH.md HBM section), WRITE_SIZE as is"}
-fs, wsz = mean("FETCH_SIZE", "k_p_sample_chain", 1 << 20), mean("WRITE_SIZE", "k_p_sample_chain", 1 << 20)
+fs, wsz = mean("FETCH_SIZE", "k_p_sample_chain"), mean("WRITE_SIZE", "k_p_sample_chain")
 if fs is not None and wsz is not None:
     traffic["k_p_sample_chain"] = {"config": {"batch": n, "steps_per_launch": spl, "precision": line["dtype"]},
                                    "fetch_size_kb": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": int((2 * fs + wsz) * 1024),
                                    "algorithmic_bytes_per_launch": 72 * n,
-                                   "dispatches_in_the_median": next(r["dispatches"] for r in rows if r["counter"] == "FETCH_SIZE" and r["kernel"] == "k_p_sample_chain" and r["grid_size"] == 1 << 20)}
-fs1, wsz1 = mean("FETCH_SIZE", "k_p_sample_chain:1step", 1 << 20), mean("WRITE_SIZE", "k_p_sample_chain:1step", 1 << 20)
+                                   "dispatches_in_the_median": max(r["dispatches"] for r in rows if r["counter"] == "FETCH_SIZE" and r["kernel"] == "k_p_sample_chain")}
+fs1, wsz1 = mean("FETCH_SIZE", "k_p_sample_chain:1step"), mean("WRITE_SIZE", "k_p_sample_chain:1step")
 if fs1 is not None and wsz1 is not None:   # the one-call-per-step loop's launches (bench.py external_loop): their own record
     traffic["k_p_sample_chain:1step"] = {"config": {"batch": n, "steps_per_launch": 1, "precision": line["dtype"]}, "fetch_size_kb": fs1,
                                          "write_size_kb": wsz1, "hbm_bytes_per_launch": int((2 * fs1 + wsz1) * 1024), "algorithmic_bytes_per_launch": 72 * n}
