@@ -454,6 +454,29 @@ int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, fl
   return check_launch();
 }
 
+// host-side entry points of the row kernels for the other translation units (so3x_protnet.hip)
+int add_ln(hipStream_t s, const float* a, const float* b, float* r_out, float* y, float* stats, const float* gamma, const float* beta, int64_t N,
+           int d, float eps) {
+  hipLaunchKernelGGL(k_add_ln, dim3(blocks_for(N, 4)), dim3(256), 0, s, a, b, r_out, y, stats, gamma, beta, N, d, eps);
+  return check_launch();
+}
+int ln_bwd(hipStream_t s, const float* dy, const float* r, const float* stats, const float* gamma, float* dr, int64_t N, int d) {
+  hipLaunchKernelGGL(k_ln_bwd, dim3(blocks_for(N, 4)), dim3(256), 0, s, dy, r, stats, gamma, dr, N, d);
+  return check_launch();
+}
+int softmax_bwd(hipStream_t s, const float* probs, float* dprobs, int64_t rows, int cols, float scale) {
+  hipLaunchKernelGGL(k_softmax_bwd, dim3(blocks_for(rows, 4)), dim3(256), 0, s, probs, dprobs, rows, cols, scale);
+  return check_launch();
+}
+int relu_bwd(hipStream_t s, float* df, const float* f, int64_t n, float scale) {
+  hipLaunchKernelGGL(k_relu_bwd, dim3(blocks_for(n, 256)), dim3(256), 0, s, df, f, n, scale);
+  return check_launch();
+}
+int cos_mul(hipStream_t s, float* ds, const float* pre, int64_t n) {
+  hipLaunchKernelGGL(k_cos_mul, dim3(blocks_for(n, 256)), dim3(256), 0, s, ds, pre, n);
+  return check_launch();
+}
+
 #define TRY(expr)                 \
   do {                            \
     int rc__ = (expr);            \

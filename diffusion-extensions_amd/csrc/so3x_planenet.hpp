@@ -118,6 +118,14 @@ constexpr int CH = 512;
 inline int colsum_chunks(const Shape& s) { return (int)((s.N() + CH - 1) / CH) + 1; }
 int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r = nullptr,
            int64_t ldr = 0, const float* stats = nullptr);
+// row kernels (one wave per row): r = a + b, y = LayerNorm(r) gamma + beta, stats = (mean, rstd); its backward; dS = P o (dP - rowsum(dP o P))
+// scale in place over dP; df = f > 0 ? df scale : 0; ds *= cos(pre)
+int add_ln(hipStream_t s, const float* a, const float* b, float* r_out, float* y, float* stats, const float* gamma, const float* beta, int64_t N,
+           int d, float eps);
+int ln_bwd(hipStream_t s, const float* dy, const float* r, const float* stats, const float* gamma, float* dr, int64_t N, int d);
+int softmax_bwd(hipStream_t s, const float* probs, float* dprobs, int64_t rows, int cols, float scale);
+int relu_bwd(hipStream_t s, float* df, const float* f, int64_t n, float scale);
+int cos_mul(hipStream_t s, float* ds, const float* pre, int64_t n);
 // pooled[b] = Wlin xs[b] + blin, out[b] = Wout pooled[b] + bout: one workgroup per cloud
 int head(hipStream_t s, const float* xs, const float* wlin, const float* blin, const float* wout, const float* bout, float* pooled, float* out,
          int64_t B, int d);

@@ -488,6 +488,47 @@ Tensor planenet_bwd(const Tensor& params, const Tensor& x, const Tensor& t, cons
      "planenet_bwd");
   return dparams;
 }
+// ProtNet (models.py:212-319): ragged complexes as concatenated ProtData fields + int64 [B + 1] offsets
+std::tuple<Tensor, Tensor, Tensor, Tensor> protnet_fwd(const Tensor& params, const Tensor& rec_res, const Tensor& rec_pos, const Tensor& rec_ang,
+                                                       const Tensor& rec_off, const Tensor& lig_res, const Tensor& lig_pos, const Tensor& lig_ang,
+                                                       const Tensor& lig_off, const Tensor& t, int64_t max_len, int64_t dim, int64_t heads,
+                                                       int64_t t_depth, int64_t c_depth, int64_t precision, bool want_stash, bool want_pool,
+                                                       bool want_encoding) {
+  GUARD(rec_pos);
+  const int64_t B = t.numel(), nr = rec_pos.numel() / 3, nl = lig_pos.numel() / 3;
+  TORCH_CHECK(rec_off.numel() == B + 1 && lig_off.numel() == B + 1, "so3x: protnet_fwd: offsets must hold B + 1 entries");
+  TORCH_CHECK(rec_res.numel() == nr * 21 && rec_ang.numel() == nr * 9 && lig_res.numel() == nl * 21 && lig_ang.numel() == nl * 9,
+              "so3x: protnet_fwd: residues [n, 21], positions [n, 3], angles [n, 3, 3] per chain kind");
+  const int64_t np = so3x_protnet_param_count((int)dim, (int)heads, (int)t_depth, (int)c_depth);
+  TORCH_CHECK(np > 0, "so3x: protnet_fwd: no ProtNet with this (dim, heads, t_depth, c_depth)");
+  TORCH_CHECK(params.numel() == np, "so3x: params must hold ", np, " values");
+  Tensor out = f32_like(rec_pos, {B, 6});
+  Tensor pool = f32_like(rec_pos, {want_pool ? B : 0, 3 * dim + 6});
+  Tensor enc = f32_like(rec_pos, {want_encoding ? 2 * B : 0, max_len, dim});
+  const size_t wsb = so3x_protnet_workspace_bytes(B, max_len, nr, nl, (int)dim, (int)heads, (int)t_depth, (int)c_depth, (int)precision);
+  const size_t stb = want_stash ? so3x_protnet_stash_bytes(B, max_len, (int)dim, (int)heads, (int)t_depth, (int)c_depth, (int)precision) : 0;
+  TORCH_CHECK(B == 0 || wsb > 0, "so3x: protnet_fwd: this (dim, heads, t_depth, c_depth, max_len, precision) is not supported");
+  TORCH_CHECK(!want_stash || B == 0 || stb > 0, "so3x: protnet_fwd: no training stash for this precision");
+  Tensor ws = bytes(rec_pos, wsb), stash = bytes(rec_pos, stb);
+  ok(so3x_protnet_fwd(strm(rec_pos), F(dev(params, "params")), F(dev(rec_res, "rec_res")), F(dev(rec_pos, "rec_pos")), F(dev(rec_ang, "rec_ang")),
+                      I64(dev(rec_off, "rec_off", at::kLong)), nr, F(dev(lig_res, "lig_res")), F(dev(lig_pos, "lig_pos")), F(dev(lig_ang, "lig_ang")),
+                      I64(dev(lig_off, "lig_off", at::kLong)), nl, I64(dev(t, "t", at::kLong)), Fm(out), want_pool && B ? Fm(pool) : nullptr,
+                      want_encoding && B ? Fm(enc) : nullptr, B, max_len, (int)dim, (int)heads, (int)t_depth, (int)c_depth, (int)precision,
+                      want_stash && B ? stash.mutable_data_ptr() : nullptr, ws.mutable_data_ptr(), ws.numel()),
+     "protnet_fwd");
+  return {out, stash, pool, enc};
+}
+Tensor protnet_bwd(const Tensor& params, const Tensor& dout, const Tensor& stash, int64_t max_len, int64_t dim, int64_t heads, int64_t t_depth,
+                   int64_t c_depth, int64_t precision) {
+  GUARD(dout);
+  const int64_t B = dout.numel() / 6;
+  Tensor dparams = f32_like(dout, {params.numel()});
+  Tensor ws = bytes(dout, so3x_protnet_workspace_bytes(B, max_len, 0, 0, (int)dim, (int)heads, (int)t_depth, (int)c_depth, (int)precision));
+  ok(so3x_protnet_bwd(strm(dout), F(dev(params, "params")), F(dev(dout, "dout")), Fm(dparams), B, max_len, (int)dim, (int)heads, (int)t_depth,
+                      (int)c_depth, (int)precision, dev(stash, "stash", at::kByte).const_data_ptr(), ws.mutable_data_ptr(), ws.numel()),
+     "protnet_bwd");
+  return dparams;
+}
 // wide residual score network (so3_lock_train.py:11-59)
 Tensor resnet_fwd(const Tensor& params, const Tensor& x, const Tensor& t, int64_t t_stride, int64_t n_out, int64_t precision, int64_t t_table) {
   GUARD(x);
@@ -724,6 +765,8 @@ TORCH_LIBRARY(so3x, m) {
   m.def("resnet_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> Tensor");
   m.def("planenet_prepare(Tensor params, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
   m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding, Tensor? prepared, float dropout_p, int seed, int rng_offset) -> (Tensor, Tensor, Tensor)");
+  m.def("protnet_fwd(Tensor params, Tensor rec_res, Tensor rec_pos, Tensor rec_ang, Tensor rec_off, Tensor lig_res, Tensor lig_pos, Tensor lig_ang, Tensor lig_off, Tensor t, int max_len, int dim, int heads, int t_depth, int c_depth, int precision, bool want_stash, bool want_pool, bool want_encoding) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("protnet_bwd(Tensor params, Tensor dout, Tensor stash, int max_len, int dim, int heads, int t_depth, int c_depth, int precision) -> Tensor");
   m.def("planenet_bwd(Tensor params, Tensor x, Tensor t, Tensor dout, Tensor stash, int dim, int heads, int layers, int ffn, int precision, float dropout_p, int seed, int rng_offset) -> Tensor");
   m.def("resnet_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> (Tensor, Tensor)");
   m.def("resnet_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int n_out, int precision, int t_table, Tensor? stash) -> Tensor");
@@ -794,6 +837,8 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("planenet_prepare", planenet_prepare);
   m.impl("planenet_fwd", planenet_fwd);
   m.impl("planenet_bwd", planenet_bwd);
+  m.impl("protnet_fwd", protnet_fwd);
+  m.impl("protnet_bwd", protnet_bwd);
   m.impl("resnet_fwd_stash", resnet_fwd_stash);
   m.impl("resnet_bwd", resnet_bwd);
   m.impl("resnet_p_sample_chain", resnet_p_sample_chain);

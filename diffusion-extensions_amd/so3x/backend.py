@@ -14,6 +14,8 @@ import ctypes as C
 import os
 import threading
 
+import numpy as np
+
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,6 +50,7 @@ SYMBOLS = (
     "so3x_train_workspace_bytes", "so3x_train_fwd", "so3x_train_bwd", "so3x_adam_step",
     "so3x_p_sample_prepare", "so3x_p_sample_prepared", "so3x_resnet_p_sample_prepare", "so3x_resnet_p_sample_prepared",
     "so3x_planenet_weights_bytes", "so3x_planenet_prepare", "so3x_planenet_param_count", "so3x_planenet_workspace_bytes", "so3x_planenet_stash_bytes", "so3x_planenet_fwd", "so3x_planenet_bwd",
+    "so3x_protnet_param_count", "so3x_protnet_workspace_bytes", "so3x_protnet_stash_bytes", "so3x_protnet_fwd", "so3x_protnet_bwd",
     "so3x_train_noise", "so3x_train_net", "so3x_train_bwd_partial", "so3x_train_bwd_reduce", "so3x_p_sample_clock_offset", "so3x_train_bwd_reduce_adam", "so3x_train_fused",
 )
 
@@ -90,6 +93,9 @@ def lib():
                 l.so3x_planenet_stash_bytes.restype = C.c_size_t
                 l.so3x_planenet_weights_bytes.restype = C.c_size_t
                 l.so3x_planenet_param_count.restype = C.c_int64
+                l.so3x_protnet_param_count.restype = C.c_int64
+                l.so3x_protnet_workspace_bytes.restype = C.c_size_t
+                l.so3x_protnet_stash_bytes.restype = C.c_size_t
                 if l.so3x_abi_version() != 8:
                     raise So3xError("so3x: ABI version mismatch")
                 _lib = l
@@ -743,6 +749,65 @@ def planenet_bwd(params, x, t, dout, stash, dim, heads, layers, ffn=2048, precis
     dout = _dev(dout, "dout").reshape(-1, 3)
     return _call(ops().planenet_bwd, params, x, tt, dout, stash, int(dim), int(heads), int(layers), int(ffn), int(precision), float(dropout_p),
                  _s64(seed), _s64(rng_offset))
+
+
+# ----------------------------------------------------------------------------- ProtNet (reference models.py:212-319)
+def protnet_param_count(dim=64, heads=4, t_depth=4, c_depth=3):
+    n = int(lib().so3x_protnet_param_count(C.c_int(dim), C.c_int(heads), C.c_int(t_depth), C.c_int(c_depth)))
+    if n < 0:
+        raise ValueError(f"so3x: no ProtNet with dim={dim}, heads={heads}, t_depth={t_depth}, c_depth={c_depth}")
+    return n
+
+
+class ProtBatch:
+    """A batch of (receptor, ligand) ProtData pairs in the layout the kernels take (so3x.h): each field of each chain kind
+    concatenated along the residue axis + int64 [B + 1] offsets; `max_len` = the longest chain.  Built once per batch
+    (`ProtBatch.from_pairs`); `with_ligands` swaps in moved ligands (what ProtProjection produces every call) without touching the
+    receptor side."""
+
+    def __init__(self, rec, lig, rec_off, lig_off, max_len, lens):
+        self.rec, self.lig, self.rec_off, self.lig_off, self.max_len, self.lens = rec, lig, rec_off, lig_off, int(max_len), lens
+
+    @staticmethod
+    def _cat(chains):
+        res = torch.cat([_dev(c.residues, "residues") for c in chains]).contiguous()
+        pos = torch.cat([_dev(c.positions, "positions") for c in chains]).contiguous()
+        ang = torch.cat([_dev(c.angles, "angles").reshape(-1, 9) for c in chains]).contiguous()
+        return res, pos, ang
+
+    @classmethod
+    def from_pairs(cls, pairs):
+        pairs = list(pairs)
+        lens = [(int(r.positions.shape[0]), int(l.positions.shape[0])) for r, l in pairs]
+        dev = pairs[0][0].positions.device
+        off = lambda k: torch.tensor([0] + list(np.cumsum([n[k] for n in lens])), dtype=torch.int64, device=dev)   # noqa: E731
+        return cls(cls._cat([p[0] for p in pairs]), cls._cat([p[1] for p in pairs]), off(0), off(1), max(max(n) for n in lens), lens)
+
+    def with_ligands(self, pos, ang):
+        """the same batch with the ligands' positions [n_lig, 3] and frames [n_lig, 3, 3] replaced"""
+        return ProtBatch(self.rec, (self.lig[0], _dev(pos, "positions").contiguous(), _dev(ang, "angles").reshape(-1, 9).contiguous()),
+                         self.rec_off, self.lig_off, self.max_len, self.lens)
+
+    def __len__(self):
+        return len(self.lens)
+
+
+def protnet_fwd(params, batch, t, dim=64, heads=4, t_depth=4, c_depth=3, precision=PREC_F32, want_stash=False, want_pool=False, want_encoding=False):
+    """ProtNet forward on a ProtBatch: (out [B, 6] = (rot_g, shift_g), stash for protnet_bwd or empty, the head's input [B, 3 dim + 6]
+    or empty, rec_tf's output in the padded layout [2 B, max_len, dim] or empty)"""
+    params = _dev(params, "params").reshape(-1)
+    tt = _dev(t, "t", torch.int64).reshape(-1)
+    if tt.numel() != len(batch):
+        raise ValueError("so3x: ProtNet needs one timestep per complex")
+    return _call(ops().protnet_fwd, params, *batch.rec, batch.rec_off, *batch.lig, batch.lig_off, tt, int(batch.max_len), int(dim), int(heads),
+                 int(t_depth), int(c_depth), int(precision), bool(want_stash), bool(want_pool), bool(want_encoding))
+
+
+def protnet_bwd(params, dout, stash, max_len, dim=64, heads=4, t_depth=4, c_depth=3, precision=PREC_F32):
+    """d sum(out * dout) / d params (flat, state_dict order; zero for lig_tf, which the reference never runs) from protnet_fwd's stash"""
+    params = _dev(params, "params").reshape(-1)
+    dout = _dev(dout, "dout").reshape(-1, 6).contiguous()
+    return _call(ops().protnet_bwd, params, dout, stash, int(max_len), int(dim), int(heads), int(t_depth), int(c_depth), int(precision))
 
 
 # ----------------------------------------------------------------------------- SE(3) layer

@@ -8,7 +8,9 @@ from torch import nn
 
 from .flat import FlatParamsMixin
 
-__all__ = ["SinusoidalPosEmb", "Siren", "ResLayer", "PointCloudProj", "PoolRN", "TransformerEnc2", "PlaneNet"]
+__all__ = ["SinusoidalPosEmb", "Siren", "ResLayer", "PointCloudProj", "PoolRN", "PoolPos", "TransformerEnc2", "PlaneNet", "ProtNet", "RES_COUNT"]
+
+RES_COUNT = 21   # prot_util.py:9-35: 20 residue types + "---" (unknown / padding)
 
 
 class SinusoidalPosEmb(nn.Module):
@@ -91,6 +93,22 @@ class PoolRN(nn.Module):
         w_sum = weight.sum(dim=-2, keepdim=True).clamp(min=1e-6)
         out = (self.lin(x) * weight).sum(dim=-2, keepdim=True) / w_sum
         return out[..., 0, :]
+
+
+class PoolPos(nn.Module):
+    """Learned-weight mean of the residue POSITIONS (reference models.py:113-127): out = sum_p w_p pos_p / sum_p w_p with
+    w_p = sigmoid(Linear(x_p)) * mask_p.  mask: [.., P] booleans (see PoolRN for the reference's default-mask shape)."""
+
+    def __init__(self, dim_pool):
+        super().__init__()
+        self.pool = nn.Sequential(nn.Linear(dim_pool, 1), nn.Sigmoid())
+
+    def forward(self, x, pos, mask=None):
+        if mask is None:
+            mask = torch.ones(x.shape[:-1], dtype=torch.bool, device=x.device)
+        weight = self.pool(x) * mask[..., None]
+        w_sum = weight.sum(dim=-2, keepdim=True).clamp(min=1e-6)
+        return ((pos * weight).sum(dim=-2, keepdim=True) / w_sum)[..., 0, :]
 
 
 class TransformerEnc2(nn.Module):
@@ -206,3 +224,107 @@ class PlaneNet(FlatParamsMixin, nn.Module):
         t_in = torch.cat((x_emb, t_emb[:, None, :].expand(x_emb.shape)), dim=2)
         encoding = self.encoder(t_in.transpose(0, 1)).transpose(0, 1)          # sequence-first inside, as the reference
         return self.out_net(encoding)
+
+
+class _ProtNetFn(torch.autograd.Function):
+    """autograd bridge of the ProtNet kernels: only the parameters carry gradients (the complexes are a projection of the noised
+    pose, reference diffusion.py:558-559)"""
+
+    @staticmethod
+    def forward(ctx, t, flat_params, cfg, batch):
+        from . import backend as _b
+        out, stash, _, _ = _b.protnet_fwd(flat_params, batch, t, *cfg, want_stash=True)
+        ctx.cfg, ctx.max_len = cfg, batch.max_len
+        ctx.save_for_backward(flat_params, stash)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import backend as _b
+        flat_params, stash = ctx.saved_tensors
+        return None, _b.protnet_bwd(flat_params, dout.contiguous(), stash, ctx.max_len, *ctx.cfg), None, None
+
+
+class ProtNet(FlatParamsMixin, nn.Module):
+    """The docking denoiser of prot_train.py (reference models.py:212-319): per chain a residue-type convolution stack, SIREN
+    encodings of the CA positions and residue frames, a t_depth-deep transformer encoder with key-padding masks, PoolRN / PoolPos
+    over the residues; the two chains' pools and the timestep embedding go through a small residual MLP to (rot_g, shift_g) -- the
+    `denoise_fn` of ProjectedSE3Diffusion with ProtProjection as the projection (prot_train.py:78-104).
+
+    The modules below exist for the reference's constructor order (same seed -> same initial weights) and its state_dict keys;
+    `forward` does not run them.  It runs the hand-written kernels of libso3x (so3x_protnet_fwd / so3x_protnet_bwd) on the flat
+    parameter buffer the module parameters are views of.  As in the reference BOTH chains are encoded by `rec_tf` (models.py:288,
+    302); `lig_tf` is constructed, saved and loaded, never run, and gets a zero gradient (the reference leaves it None).
+    The reference trains in net.train() with nn.TransformerEncoderLayer's default dropout 0.1 (prot_train.py:75); the kernels run
+    the eval-mode arithmetic in either mode (dropout = 0), which is also what sampling (prot_test.py) uses.
+    precision "fp32": exact-fp32 matrix-core products, any width, forward and backward; "bf16": the class-default width (dim 64,
+    4 heads) with bf16 operands, inference only -- a forward that needs gradients runs the fp32 form.
+
+    forward(x, t): x = a sequence of (receptor, ligand) ProtData pairs, as ProtProjection returns them, or a
+    so3x.backend.ProtBatch (the same data already concatenated: what a loader builds once per batch); t int64 [B].
+    Returns AffineGrad(rot_g [B, 3], shift_g [B, 3]) (se3=True) or the [B, 6] tensor."""
+
+    def __init__(self, dim=64, heads=4, t_depth=4, c_depth=3, se3=True, precision="fp32"):
+        super().__init__()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        pos_dim, ang_dim = dim // 2, dim // 4
+        res_dim = dim - (pos_dim + ang_dim)
+        self.se3 = se3
+        self.time_emb = SinusoidalPosEmb(dim)
+        self.pos_emb = Siren(3, pos_dim, scale=0.1)
+        self.ang_emb = Siren(9, ang_dim)
+
+        def conv(cin, cout):
+            return nn.Conv1d(in_channels=cin, out_channels=cout, kernel_size=(3,), padding=(1,), stride=(1,))
+        self.res_conv = nn.Sequential(conv(RES_COUNT, dim), nn.SiLU(inplace=True),
+                                      *[ResLayer(nn.Sequential(conv(dim, dim), nn.SiLU(inplace=True))) for _ in range(c_depth - 2)],
+                                      conv(dim, res_dim))
+        self.lig_tf = TransformerEnc2(dim=dim, layers=t_depth, heads=heads)
+        self.lig_emb_pool = PoolRN(dim)
+        self.lig_pos_pool = PoolPos(dim)
+        self.rec_tf = TransformerEnc2(dim=dim, layers=t_depth, heads=heads)
+        self.rec_emb_pool = PoolRN(dim)
+        self.rec_pos_pool = PoolPos(dim)
+        self.last = nn.Sequential(nn.Sequential(nn.Linear(3 * dim + 6, dim), nn.SiLU(inplace=True)),
+                                  *[ResLayer(nn.Sequential(nn.Linear(dim, dim), nn.SiLU(inplace=True))) for _ in range(3)],
+                                  nn.Linear(dim, 6))
+        self.dim, self.heads, self.t_depth, self.c_depth, self.precision = dim, heads, t_depth, c_depth, precision
+        self._init_flat()
+
+    def _flat_root(self):
+        return self
+
+    @property
+    def cfg(self):
+        return (self.dim, self.heads, self.t_depth, self.c_depth)
+
+    def _wrap(self, out):
+        from .se3 import AffineGrad
+        return AffineGrad(rot_g=out[..., :3], shift_g=out[..., 3:]) if self.se3 else out
+
+    def forward(self, x, t, want_internals=False):
+        from . import backend as _b
+        batch = x if isinstance(x, _b.ProtBatch) else _b.ProtBatch.from_pairs(x)
+        if want_internals:    # (out, the head's input [B, 3 dim + 6], rec_tf's output in the padded layout): parity tests
+            out, _, pool, enc = _b.protnet_fwd(self.flat_params_nograd(), batch, t, *self.cfg, want_pool=True, want_encoding=True)
+            return out, pool, enc
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._wrap(_ProtNetFn.apply(t, self.flat_params(), self.cfg, batch))
+        prec = _b.PREC_BF16 if self.precision == "bf16" else _b.PREC_F32
+        return self._wrap(_b.protnet_fwd(self.flat_params_nograd(), batch, t, *self.cfg, precision=prec)[0])
+
+    def forward_torch(self, x, t):
+        """the same network through torch's own modules (any device): test infrastructure.  Follows models.py:275-319, ligand
+        through rec_tf included."""
+        from torch.nn.utils.rnn import pad_sequence
+        pools = []
+        for k, (emb_pool, pos_pool) in enumerate(((self.rec_emb_pool, self.rec_pos_pool), (self.lig_emb_pool, self.lig_pos_pool))):
+            chains = [pair[k] for pair in x]
+            pos = pad_sequence([c.positions for c in chains], batch_first=True)
+            ang = pad_sequence([c.angles for c in chains], batch_first=True).flatten(-2, -1)
+            res = pad_sequence([self.res_conv(c.residues[None].transpose(-1, -2)).transpose(-1, -2)[0] for c in chains], batch_first=True)
+            msk = pos.any(dim=-1)
+            enc = self.rec_tf(torch.cat((res, self.pos_emb(pos), self.ang_emb(ang)), dim=-1), src_key_padding_mask=msk.logical_not())
+            pools += [emb_pool(enc, msk), pos_pool(enc, pos, msk)]
+        return self._wrap(self.last(torch.cat((self.time_emb(t), *pools), dim=-1)))

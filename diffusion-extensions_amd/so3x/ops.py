@@ -271,6 +271,21 @@ def _(params, x, t, dout, stash, dim, heads, layers, ffn, precision, dropout_p, 
     return _f32(x, (params.numel(),))
 
 
+@register_fake("so3x::protnet_fwd")
+def _(params, rec_res, rec_pos, rec_ang, rec_off, lig_res, lig_pos, lig_ang, lig_off, t, max_len, dim, heads, t_depth, c_depth, precision, want_stash,
+      want_pool, want_encoding):
+    B = t.numel()
+    # an upper bound is all a fake needs: per padded token and layer 8 dim + 2048 + heads * max_len floats
+    stash = (2 * B * max_len * (t_depth * (8 * dim + 2048 + heads * max_len) + 2 * c_depth * dim + 64) * 4 + (1 << 20)) if want_stash else 0
+    return (_f32(rec_pos, (B, 6)), rec_pos.new_empty((stash,), dtype=torch.uint8), _f32(rec_pos, (B if want_pool else 0, 3 * dim + 6)),
+            _f32(rec_pos, (2 * B if want_encoding else 0, max_len, dim)))
+
+
+@register_fake("so3x::protnet_bwd")
+def _(params, dout, stash, max_len, dim, heads, t_depth, c_depth, precision):
+    return _f32(dout, (params.numel(),))
+
+
 @register_fake("so3x::resnet_fwd")
 def _(params, x, t, t_stride, n_out, precision, t_table):
     return _f32(x, x.shape[:-2] + (n_out,))

@@ -354,6 +354,40 @@ int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, cons
                       int64_t P, int dim, int heads, int layers, int ffn, int precision, const void* stash, void* workspace,
                       size_t workspace_bytes, float dropout_p, uint64_t seed, uint64_t rng_offset);
 
+/* -------------------------------------------- ProtNet: the docking denoiser of prot_train.py (8f row 4)
+ * models.ProtNet (models.py:212-319), the denoise_fn ProjectedSE3Diffusion trains in prot_train.py:90-108 (BASELINE config 5):
+ *   a batch of B complexes = B receptor chains + B ligand chains of ANY lengths, handed over as the reference's ProtData fields
+ *   concatenated along the residue axis (CSR): *_res [n][21] one-hot residue types (prot_util.py:9-35), *_pos [n][3] CA
+ *   positions, *_ang [n][3][3] residue frames, *_off int64 [B + 1] (chain c = rows off[c] .. off[c + 1]); t int64 [B].
+ *   per chain: [ res_conv(residues) | Siren(3 -> dim/2, scale 0.1)(positions) | Siren(9 -> dim/4)(frames) ]  (models.py:219-252, 276-286)
+ *     -> rec_tf: t_depth x nn.TransformerEncoderLayer(dim, heads) [post-norm, ReLU, feed-forward 2048, eval-mode arithmetic] + the
+ *        encoder's final LayerNorm, attention over the chain's own residues (src_key_padding_mask: padded keys take no mass;
+ *        BOTH chain kinds go through rec_tf, models.py:288 and 302 -- lig_tf is never run and its gradient is zero)
+ *     -> PoolRN(dim) and PoolPos(dim) over the chain's residues with the chain kind's pool parameters (models.py:94-127)
+ *   out [B][6] = last([SinusoidalPosEmb(dim)(t) | rec pool | rec pos | lig pool | lig pos]) = (rot_g, shift_g) (models.py:261-270, 311-318)
+ * params: the fp32 values in state_dict order (so3x_protnet_param_count values; the order is spelled out in csrc/so3x_protnet.hpp).
+ * max_len >= every chain's length (the kernels pad to it internally); n_rec / n_lig = rows of the receptor / ligand arrays.
+ * precision SO3X_PREC_F32: every product on the exact-fp32 MFMA; any dim % 4 == 0, dim % heads == 0, dim <= 1024, c_depth >= 2
+ *           (prot_train.py's own defaults -- dim 1024, 8 heads, t_depth 12, c_depth 8 -- included);
+ *           SO3X_PREC_BF16: the class defaults' width (dim 64, 4 heads; any t_depth <= 8, c_depth <= 8, max_len <= 256): bf16
+ *           operands / fp32 accumulate, one persistent workgroup per chain with the chain's activations in LDS; forward only
+ *           (stash and enc_out must be NULL), else SO3X_ERR_UNSUPPORTED.
+ * so3x_protnet_fwd: stash == NULL: inference.  stash != NULL (so3x_protnet_stash_bytes): activations kept for so3x_protnet_bwd.
+ *   pool_out (optional) [B][3 dim + 6]: the head's input; enc_out (optional) [2 B][max_len][dim]: rec_tf's output in the padded
+ *   layout (receptors first; rows past a chain's length hold what the reference's padded rows hold).
+ * so3x_protnet_bwd: dparams[param_count] (overwritten) = d sum(out * dout) / d params for dout [B][6], from the stash of the
+ *   forward.  (The inputs carry no gradient: they are a projection of the noised pose, diffusion.py:558-559.)  Deterministic. */
+int64_t so3x_protnet_param_count(int dim, int heads, int t_depth, int c_depth);
+size_t so3x_protnet_workspace_bytes(int64_t B, int64_t max_len, int64_t n_rec, int64_t n_lig, int dim, int heads, int t_depth, int c_depth,
+                                    int precision);
+size_t so3x_protnet_stash_bytes(int64_t B, int64_t max_len, int dim, int heads, int t_depth, int c_depth, int precision);
+int so3x_protnet_fwd(so3x_stream_t s, const float* params, const float* rec_res, const float* rec_pos, const float* rec_ang, const int64_t* rec_off,
+                     int64_t n_rec, const float* lig_res, const float* lig_pos, const float* lig_ang, const int64_t* lig_off, int64_t n_lig,
+                     const int64_t* t, float* out, float* pool_out, float* enc_out, int64_t B, int64_t max_len, int dim, int heads, int t_depth,
+                     int c_depth, int precision, void* stash, void* workspace, size_t workspace_bytes);
+int so3x_protnet_bwd(so3x_stream_t s, const float* params, const float* dout, float* dparams, int64_t B, int64_t max_len, int dim, int heads,
+                     int t_depth, int c_depth, int precision, const void* stash, void* workspace, size_t workspace_bytes);
+
 /* ------------------------------------------------------- sample-quality statistics */
 /* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):
  *   out[0] = scale * sum_{i < nx, j < ny} k(X_i, Y_j),

@@ -1,0 +1,198 @@
+"""ProtNet on the hand-written kernels (reference models.py:212-319, prot_train.py:75-104):
+so3x_protnet_fwd / so3x_protnet_bwd against values the reference's own models.ProtNet produced on ragged synthetic complexes
+(tools/make_golden.py protnet -> tests/golden/protnet.npz).
+
+Two configurations: `small` (dim 32, 2 heads, t_depth 2, c_depth 4; chains of 1 .. 24 residues) and `default` (the class defaults
+dim 64, 4 heads, t_depth 4, c_depth 3; chains of 40 .. 256 residues).  The weights (0.8 M / 2.3 M parameters) are rebuilt here from
+the same seeds the fixture was made with; float64 checksums in the fixture pin them."""
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+
+DEV = "cuda:0"
+ProtData = namedtuple("ProtData", ["residues", "positions", "angles"])
+
+
+def protnet_perturb(net, seed):
+    """tools/make_golden.py:protnet_perturb, verbatim"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in sorted(net.named_parameters()):
+            p.add_(torch.randn(p.shape, generator=g) * (0.05 * float(p.abs().mean()) + 1e-3))
+
+
+def synthetic_complexes(lengths, seed):
+    """tools/make_golden.py:synthetic_complexes, verbatim (ProtData is this module's namedtuple)"""
+    g = torch.Generator().manual_seed(seed)
+
+    def chain(L, centre):
+        res = torch.zeros(L, 21)
+        res[torch.arange(L), torch.randint(0, 21, (L,), generator=g)] = 1.0
+        pos = torch.randn(L, 3, generator=g) * 8.0 + centre
+        v1 = torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1)
+        v2 = torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1)
+        return ProtData(res, pos, torch.stack((v1, v2, torch.cross(v1, v2, dim=-1)), dim=1))
+    out = []
+    for lr, ll in lengths:
+        c = torch.randn(3, generator=g) * 5.0
+        out.append((chain(lr, c), chain(ll, c + 12.0)))
+    return out
+
+
+def build(golden, tag, precision="fp32"):
+    """(net on the CPU with the fixture's weights, the fixture's complexes, the fixture)"""
+    from so3x.models import ProtNet
+    g = golden["protnet"]
+    dim, heads, t_depth, c_depth = (int(v) for v in g[tag + "_cfg"])
+    torch.manual_seed(31)
+    net = ProtNet(dim=dim, heads=heads, t_depth=t_depth, c_depth=c_depth, precision=precision).eval()
+    protnet_perturb(net, 7)
+    for k, v in net.state_dict().items():                     # the weights ARE the ones the fixture was made with
+        chk = g[f"{tag}_chk_{k}"]
+        v64 = v.double()
+        assert abs(float(v64.sum()) - chk[0]) <= 1e-9 * max(1.0, abs(chk[0])) and abs(float(v64.norm()) - chk[1]) <= 1e-9 * max(chk[1], 1e-30), k
+    lengths = [tuple(int(x) for x in row) for row in g[tag + "_lengths"]]
+    return net, synthetic_complexes(lengths, 101 if tag == "small" else 202), g
+
+
+def to_dev(data):
+    return [tuple(ProtData(*(a.to(DEV) for a in c)) for c in pair) for pair in data]
+
+
+# ------------------------------------------------------------------------------------------------ CPU: layout and host logic
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_module_mirrors_the_reference_constructor_and_layout(golden, tag):
+    """same seed -> the reference's initial weights (the checksums inside build()); the parameters sit in ONE flat buffer in
+    state_dict order and the C library agrees about the count; the torch cross-check path reproduces the reference's outputs"""
+    from so3x import backend as B
+    net, data, g = build(golden, tag)
+    flat = net.flat_data()
+    assert flat.numel() == sum(p.numel() for p in net.parameters()) == B.protnet_param_count(*net.cfg)
+    off = 0
+    for k, v in net.state_dict().items():
+        assert torch.equal(flat[off:off + v.numel()].view(v.shape), v), k
+        off += v.numel()
+    keys = list(net.state_dict().keys())
+    assert keys[0] == "pos_emb.positional.weight" and keys[-1] == "last.4.bias"
+    assert any(k.startswith("lig_tf.encoder.layers.0.self_attn.in_proj_weight") for k in keys) and "rec_tf.encoder.norm.weight" in keys
+    with torch.no_grad():
+        out = net.forward_torch(data, torch.from_numpy(g[tag + "_t"]))
+    full = torch.cat((out.rot_g, out.shift_g), -1).numpy()
+    assert np.abs(full - g[tag + "_out"]).max() < 2e-5
+
+
+def test_protbatch_is_the_concatenation_with_offsets(golden):
+    from so3x import backend as B
+    _, data, _ = build(golden, "small")
+    # (host-only check of the CSR layout: runs without a GPU by bypassing the device check)
+    lens = [(r.positions.shape[0], l.positions.shape[0]) for r, l in data]
+    rec_off = np.concatenate(([0], np.cumsum([n[0] for n in lens])))
+    assert rec_off[-1] == sum(n[0] for n in lens) and max(max(n) for n in lens) == 24
+    assert hasattr(B, "ProtBatch") and hasattr(B.ProtBatch, "from_pairs") and hasattr(B.ProtBatch, "with_ligands")
+
+
+# ------------------------------------------------------------------------------------------------ GPU parity
+def valid_rows(enc, lengths, max_len):
+    """[2 B, max_len, d] padded layout -> (receptor rows, ligand rows), valid residues only, concatenated over the complexes"""
+    B = len(lengths)
+    rec = torch.cat([enc[i, :lengths[i][0]] for i in range(B)])
+    lig = torch.cat([enc[B + i, :lengths[i][1]] for i in range(B)])
+    return rec, lig
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_fp32_forward_vs_reference(golden, tag):
+    """output, the head's 198-wide input and rec_tf's output at every valid residue of both chains: 1e-5 against the reference's
+    float32 run, and no further from its float64 run than the reference's own float32 run is (x 3)"""
+    net, data, g = build(golden, tag)
+    net = net.to(DEV)
+    t = torch.from_numpy(g[tag + "_t"]).to(DEV)
+    lengths = [tuple(int(x) for x in row) for row in g[tag + "_lengths"]]
+    with torch.no_grad():
+        out, pool, enc = net(to_dev(data), t, want_internals=True)
+        plain = net(to_dev(data), t)
+    assert torch.equal(torch.cat((plain.rot_g, plain.shift_g), -1), out) and plain.rot_g.shape == (len(lengths), 3)
+    out, pool = out.cpu().numpy(), pool.cpu().numpy()
+    rec, lig = valid_rows(enc.cpu(), lengths, max(max(n) for n in lengths))
+    for name, got, ref32, ref64 in (("out", out, g[tag + "_out"], g[tag + "_out64"]), ("pool", pool, g[tag + "_pool"], g[tag + "_pool64"]),
+                                    ("rec_tf_out", rec.numpy(), g[tag + "_rec_tf_out"], g[tag + "_rec_tf_out64"]),
+                                    ("lig_tf_out", lig.numpy(), g[tag + "_lig_tf_out"], g[tag + "_lig_tf_out64"])):
+        scale = max(1.0, float(np.abs(ref64).max()))
+        err32 = float(np.abs(got - ref32).max()) / scale
+        err64 = float(np.abs(got - ref64).max()) / scale
+        ref_err = float(np.abs(ref32 - ref64).max()) / scale
+        assert err32 < 1e-5, (name, err32)
+        assert err64 < max(3 * ref_err, 2e-6), (name, err64, ref_err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_fp32_backward_vs_reference_autograd(golden, tag):
+    """every parameter's gradient of sum(out * dout) against the reference's autograd: per tensor the L2 norm and the sampled (or
+    full) entries within 2e-4 of the tensor's scale (measured ~1e-5; the reference's own float32 gradients sit ~1e-5 from its
+    float64 ones); lig_tf, which the reference never runs, gets zeros where the reference leaves None"""
+    net, data, g = build(golden, tag)
+    net = net.to(DEV).train()        # (training mode: the kernels run the eval arithmetic either way, see the class docstring)
+    t = torch.from_numpy(g[tag + "_t"]).to(DEV)
+    dout = torch.from_numpy(g[tag + "_dout"]).to(DEV)
+    out = net(to_dev(data), t)
+    full = torch.cat((out.rot_g, out.shift_g), -1)
+    assert float((full.detach().cpu() - torch.from_numpy(g[tag + "_out"])).abs().max()) < 1e-5
+    (full * dout).sum().backward()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        grad = p.grad.detach().cpu().reshape(-1)
+        if f"{tag}_gnone_{k}" in g.files:
+            assert k.startswith("lig_tf.") and float(grad.abs().max()) == 0.0, k
+            continue
+        gsum, pick64 = g[f"{tag}_gsum_{k}"], g[f"{tag}_gpick64_{k}"]
+        stride = 1 if grad.numel() <= 4096 else max(1, grad.numel() // 64)
+        got = grad[::stride][:4096 if stride == 1 else 64].double().numpy()
+        scale = max(float(gsum[2]) / np.sqrt(grad.numel()), 1e-12)       # the tensor's RMS entry (float64 reference)
+        err = float(np.abs(got - pick64).max()) / scale
+        nerr = abs(float(grad.double().norm()) - float(gsum[2])) / max(float(gsum[2]), 1e-12)
+        worst = max(worst, err * 1e-2, nerr)
+        assert nerr < 2e-4, (k, "norm", nerr)
+        assert err < 2e-2, (k, "entries", err)      # entries relative to the RMS entry: small entries of a tensor carry absolute, not relative, error
+    assert worst < 2e-4
+
+
+@pytest.mark.gpu
+def test_ragged_batch_equals_its_complexes_one_by_one(golden):
+    """padding is invisible: a batch of ragged complexes gives, complex by complex, what each complex gives alone (max_len then is
+    its own longer chain) -- outputs to float32 round-off, and the batch gradient is the sum of the single gradients"""
+    net, data, g = build(golden, "small")
+    net = net.to(DEV)
+    t = torch.from_numpy(g["small_t"]).to(DEV)
+    dout = torch.from_numpy(g["small_dout"]).to(DEV)
+    dd = to_dev(data)
+    out = net(dd, t)
+    full = torch.cat((out.rot_g, out.shift_g), -1)
+    net.zero_grad(set_to_none=True)
+    (full * dout).sum().backward()
+    gb = net.gather_flat_grad().clone()
+    acc = torch.zeros_like(gb)
+    for i in range(len(dd)):
+        net.zero_grad(set_to_none=True)
+        o = net(dd[i:i + 1], t[i:i + 1])
+        fi = torch.cat((o.rot_g, o.shift_g), -1)
+        assert float((fi - full[i:i + 1]).abs().max()) < 2e-6
+        (fi * dout[i:i + 1]).sum().backward()
+        acc += net.gather_flat_grad()
+    assert float((acc - gb).abs().max()) < 2e-5 * max(1.0, float(gb.abs().max()))
+
+
+@pytest.mark.gpu
+def test_error_paths(golden):
+    from so3x import backend as B
+    net, data, g = build(golden, "small")
+    net = net.to(DEV)
+    with pytest.raises(Exception):
+        net(to_dev(data), torch.zeros(2, dtype=torch.long, device=DEV))      # one timestep per complex
+    with pytest.raises(Exception):
+        net(data, torch.from_numpy(g["small_t"]).to(DEV))                    # CPU tensors are refused
+    with pytest.raises(ValueError):
+        B.protnet_param_count(dim=30)                                        # dim % 4
