@@ -177,11 +177,14 @@ k_se3_p_noise(const float* __restrict__ trap_row, float sigma, float shift_scale
 //   pos' = (pos - mean) R^T + mean + shift,  frames' = frames R^T.   48 B in + 48 B out per residue.
 __global__ void __launch_bounds__(kBlock)
 k_rigid_move(const float* __restrict__ rot, const float* __restrict__ shift, const float* __restrict__ pos,
-             const float* __restrict__ frames, float* __restrict__ out_pos, float* __restrict__ out_frames, int64_t L) {
+             const float* __restrict__ frames, float* __restrict__ out_pos, float* __restrict__ out_frames, int64_t L,
+             const int64_t* __restrict__ off) {   // off != nullptr: ragged structures, structure s = rows off[s] .. off[s + 1]
   __shared__ float red[3][kBlock / 64];
   __shared__ float mean_s[3];
   const int64_t s = blockIdx.x;
-  const float* p = pos + s * L * 3;
+  const int64_t row0 = off ? off[s] : s * L;
+  if (off) L = off[s + 1] - row0;
+  const float* p = pos + row0 * 3;
   float acc[3] = {0.f, 0.f, 0.f};
   for (int64_t i = threadIdx.x; i < L; i += kBlock) { acc[0] += p[i * 3]; acc[1] += p[i * 3 + 1]; acc[2] += p[i * 3 + 2]; }
 #pragma unroll
@@ -204,14 +207,14 @@ k_rigid_move(const float* __restrict__ rot, const float* __restrict__ shift, con
   for (int j = 0; j < 3; j++) sh[j] = shift[s * 3 + j];
   for (int64_t i = threadIdx.x; i < L; i += kBlock) {
     const float d0 = p[i * 3] - mu[0], d1 = p[i * 3 + 1] - mu[1], d2 = p[i * 3 + 2] - mu[2];
-    float* o = out_pos + (s * L + i) * 3;
+    float* o = out_pos + (row0 + i) * 3;
 #pragma unroll
     for (int j = 0; j < 3; j++) o[j] = d0 * R[3 * j] + d1 * R[3 * j + 1] + d2 * R[3 * j + 2] + mu[j] + sh[j];  // (p - mu) @ R^T
     if (frames) {
       float f[9], fo[9];
-      load_rot9(frames, s * L + i, f);
+      load_rot9(frames, row0 + i, f);
       mul33_bt(f, R, fo);
-      store_rot9(out_frames, s * L + i, fo);
+      store_rot9(out_frames, row0 + i, fo);
     }
   }
 }
@@ -308,7 +311,17 @@ int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const
     return SO3X_ERR_INVALID_ARG;
   if (S == 0) return SO3X_OK;
   hipLaunchKernelGGL(k_rigid_move, dim3((unsigned)S), dim3(kBlock), 0, (hipStream_t)s, rot, shift, pos, frames, out_pos,
-                     out_frames, L);
+                     out_frames, L, (const int64_t*)nullptr);
+  return check_launch();
+}
+
+int so3x_rigid_move_ragged(so3x_stream_t s, const float* rot, const float* shift, const float* pos, const float* frames, const int64_t* off,
+                           float* out_pos, float* out_frames, int64_t S) {
+  if (S < 0 || S > 0x7fffffff || (S && (!rot || !shift || !pos || !out_pos || !off)) || ((frames == nullptr) != (out_frames == nullptr)))
+    return SO3X_ERR_INVALID_ARG;
+  if (S == 0) return SO3X_OK;
+  hipLaunchKernelGGL(k_rigid_move, dim3((unsigned)S), dim3(kBlock), 0, (hipStream_t)s, rot, shift, pos, frames, out_pos,
+                     out_frames, (int64_t)0, off);
   return check_launch();
 }
 

@@ -635,6 +635,17 @@ std::tuple<Tensor, Tensor> rigid_move(const Tensor& rot, const Tensor& shift, co
      "rigid_move");
   return {out_pos, out_fr};
 }
+std::tuple<Tensor, Tensor> rigid_move_ragged(const Tensor& rot, const Tensor& shift, const Tensor& pos, const optional<Tensor>& frames, const Tensor& off) {
+  GUARD(rot);
+  const int64_t S = rot.numel() / 9;
+  TORCH_CHECK(off.numel() == S + 1, "so3x: rigid_move_ragged: offsets must hold one entry per structure + 1");
+  Tensor out_pos = at::empty_like(dev(pos, "positions"));
+  Tensor out_fr = frames.has_value() ? at::empty_like(dev(*frames, "angles")) : f32_like(rot, {0, 3, 3});
+  ok(so3x_rigid_move_ragged(strm(rot), F(dev(rot, "transf.rot")), F(dev(shift, "transf.shift")), F(pos), Fo(frames, "angles"),
+                            I64(dev(off, "offsets", at::kLong)), Fm(out_pos), frames.has_value() ? Fm(out_fr) : nullptr, S),
+     "rigid_move_ragged");
+  return {out_pos, out_fr};
+}
 // statistics
 Tensor kernel_sum(const Tensor& X, const Tensor& Y, int64_t kind, double scale) {
   GUARD(X);
@@ -781,6 +792,7 @@ TORCH_LIBRARY(so3x, m) {
   m.def("se3_p_noise(Tensor trap_row, float sigma, float shift_scale, Tensor mean_rot, Tensor mean_shift, Tensor? axes, Tensor? unif, "
         "Tensor? znorm, int seed, int rng_offset, int index_base, bool shared_rot) -> (Tensor, Tensor)");
   m.def("rigid_move(Tensor rot, Tensor shift, Tensor pos, Tensor? frames) -> (Tensor, Tensor)");
+  m.def("rigid_move_ragged(Tensor rot, Tensor shift, Tensor pos, Tensor? frames, Tensor off) -> (Tensor, Tensor)");
   m.def("kernel_sum(Tensor X, Tensor Y, int kind, float scale) -> Tensor");
   m.def("six2rmat(Tensor x6) -> Tensor");
   m.def("six2rmat_bwd(Tensor x6, Tensor dR) -> Tensor");
@@ -847,6 +859,7 @@ TORCH_LIBRARY_IMPL(so3x, CUDA, m) {
   m.impl("se3_p_mean", se3_p_mean);
   m.impl("se3_p_noise", se3_p_noise);
   m.impl("rigid_move", rigid_move);
+  m.impl("rigid_move_ragged", rigid_move_ragged);
   m.impl("kernel_sum", kernel_sum);
   m.impl("six2rmat", six2rmat);
   m.impl("six2rmat_bwd", six2rmat_bwd);

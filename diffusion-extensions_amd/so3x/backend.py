@@ -41,7 +41,7 @@ SYMBOLS = (
     "so3x_igso3_logprob_score", "so3x_mlp_workspace_bytes", "so3x_mlp_fwd", "so3x_mlp_bwd", "so3x_mlp_stash_bytes",
     "so3x_mlp_fwd_stash",
     "so3x_q_sample_target", "so3x_p_mean", "so3x_p_mean_t", "so3x_p_sample_workspace_bytes", "so3x_p_sample_chain",
-    "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move", "so3x_rotate_cloud",
+    "so3x_se3_q_sample_target", "so3x_se3_p_mean", "so3x_se3_p_noise", "so3x_rigid_move", "so3x_rigid_move_ragged", "so3x_rotate_cloud",
     "so3x_kernel_sum_workspace_bytes", "so3x_kernel_sum", "so3x_mse_workspace_bytes", "so3x_mse_loss", "so3x_mse_grad",
     "so3x_resnet_workspace_bytes", "so3x_resnet_fwd", "so3x_resnet_p_sample_chain",
     "so3x_resnet_train_workspace_bytes", "so3x_resnet_bwd", "so3x_resnet_stash_bytes", "so3x_resnet_fwd_stash",
@@ -858,6 +858,18 @@ def rigid_move(rot, shift, pos, frames=None):
     pos = _dev(pos, "positions")
     fr = _dev(frames, "angles") if frames is not None else None
     out_pos, out_fr = _call(ops().rigid_move, rot, shift, pos, fr)
+    return out_pos, (out_fr if fr is not None else None)
+
+
+def rigid_move_ragged(rot, shift, pos, frames, off):
+    """S structures of different lengths, concatenated: rot [S,3,3], shift [S,3], pos [n,3], frames [n,3,3] (or [n,9]) or None,
+    off int64 [S + 1]; every structure moves about ITS OWN centroid (move_prot, prot_util.py:73-81)"""
+    rot = _rot_in(rot, "transf.rot")
+    S = rot.numel() // 9
+    shift = _dev(shift, "transf.shift").reshape(S, 3)
+    pos = _dev(pos, "positions")
+    fr = _dev(frames, "angles") if frames is not None else None
+    out_pos, out_fr = _call(ops().rigid_move_ragged, rot, shift, pos, fr, _dev(off, "offsets", torch.int64))
     return out_pos, (out_fr if fr is not None else None)
 
 

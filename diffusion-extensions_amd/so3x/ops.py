@@ -334,6 +334,11 @@ def _(rot, shift, pos, frames):
     return _f32(pos, pos.shape), _f32(pos, frames.shape if frames is not None else (0, 3, 3))
 
 
+@register_fake("so3x::rigid_move_ragged")
+def _(rot, shift, pos, frames, off):
+    return _f32(pos, pos.shape), _f32(pos, frames.shape if frames is not None else (0, 3, 3))
+
+
 @register_fake("so3x::kernel_sum")
 def _(X, Y, kind, scale):
     return _f32(X, (1,))

@@ -106,7 +106,10 @@ def move_prots(transf: AffineT, proteins) -> list:
 class ProtProjection(nn.Module):
     """Projection of ProjectedSE3Diffusion for docking data (reference prot_util.py:102-117): `data` is a sequence of
     (receptor, ligand) ProtData pairs; the i-th transform moves the i-th ligand, the receptor stays.  se3=False takes
-    [n, 6] = (Euler angles, shift) instead of an AffineT."""
+    [n, 6] = (Euler angles, shift) instead of an AffineT.
+    `data` may also be a so3x.backend.ProtBatch (the same pairs already concatenated with offsets, what a loader builds once per
+    batch): then all ligands move in ONE launch (so3x_rigid_move_ragged) and the result is a ProtBatch again -- the form
+    ProtNet takes without re-concatenating ~6 B small tensors per call."""
 
     def __init__(self, data, se3=True):
         super().__init__()
@@ -119,6 +122,10 @@ class ProtProjection(nn.Module):
         else:
             from .util import euler_to_rmat
             tfs = AffineT(euler_to_rmat(*torch.unbind(transforms[..., :3], -1)), transforms[..., 3:])
+        if isinstance(self.data, _b.ProtBatch):
+            n = len(self.data)
+            pos, ang = _b.rigid_move_ragged(tfs.rot[:n], tfs.shift[:n], self.data.lig[1], self.data.lig[2], self.data.lig_off)
+            return self.data.with_ligands(pos, ang)
         return [(pair[0], move_prot(tfs[i], pair[1])) for i, pair in enumerate(self.data)]
 
 

@@ -297,6 +297,10 @@ int so3x_se3_p_noise(so3x_stream_t s, const float* trap_row, float sigma, float 
  * pos' = (pos - mean_L(pos)) R^T + mean + shift, frames' = frames R^T (frames may be NULL). */
 int so3x_rigid_move(so3x_stream_t s, const float* rot, const float* shift, const float* pos,
                     const float* frames, float* out_pos, float* out_frames, int64_t S, int64_t L);
+/* the same for S structures of DIFFERENT lengths concatenated along the residue axis: structure c = rows off[c] .. off[c + 1]
+ * (off int64 [S + 1]) -- what ProtProjection (prot_util.py:102-117) does to the ligands of a batch, one move_prot each, in ONE launch */
+int so3x_rigid_move_ragged(so3x_stream_t s, const float* rot, const float* shift, const float* pos, const float* frames, const int64_t* off,
+                           float* out_pos, float* out_frames, int64_t S);
 
 /* PointCloudProj (models.py:75-91, so3 = True): the projection the Projected*Diffusion variants (diffusion.py:377-429,
  * 525-573) feed their denoisers with: out[n][P][3] = cloud @ rot[n]^T.  cloud_stride 0: one cloud [P][3] for every rotation;
