@@ -46,7 +46,7 @@ struct ParamOff {
   int64_t per_layer;
   int64_t wp, bp, wps, bps, wpool, bpool, wlin, blin, wout, bout, total;
   int d, F;
-  LayerOff layer(int l) const {
+  __host__ __device__ LayerOff layer(int l) const {
     LayerOff o;
     int64_t p = per_layer * l;
     const int64_t dd = (int64_t)d * d;

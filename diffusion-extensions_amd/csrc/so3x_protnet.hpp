@@ -45,7 +45,7 @@ struct POff {
   Pool lig, rec;
   int64_t w0, b0, wr[3], br[3], wout, bout, total;
   int d, F;
-  LayerOff layer(const Tf& tf, int l) const {
+  __host__ __device__ LayerOff layer(const Tf& tf, int l) const {
     plane::ParamOff o;
     o.d = d;
     o.F = F;

@@ -1,8 +1,849 @@
-// so3x_protnet_bf16.hip -- placeholder while the exact-fp32 form is brought up (replaced by the bf16 matrix-core form)
+// so3x_protnet_bf16.hip -- ProtNet (reference models.py:212-319) at the class-default width (dim 64, 4 heads of 16, feed-forward
+// 2048), bf16 operands / fp32 accumulate on the gfx950 matrix cores, forward.  What ProjectedSE3Diffusion's reverse chain runs
+// 1000 times per sample (prot_test.py) and BASELINE config 5's batch (4096 complexes x 256 residues) is priced on.
+//
+// Design (MI355X-first, not the padded [2 B][max_len] tensors of the reference): the residues of all chains live COMPACTLY in one
+// token-major stream x [n_rec + n_lig][64] bf16 (128 B per residue) -- no padded rows exist, so the key-padding mask of the
+// reference (models.py:288) is simply the chain's own length.  Per encoder layer two launches:
+//   k_attn  one workgroup per CHAIN (<= 256 residues: 4 waves x 64 queries): QKV projection, the chain's K and V^T in LDS (69 KB),
+//           softmax(Q K^T) V per head with the scores in registers (16-wide heads: 16x16x16 / 16x16x32 MFMAs whose accumulator
+//           layout IS the next product's operand layout), out-projection, residual, LayerNorm 1.
+//   k_ffn   token-parallel, chain-agnostic (84 % of the network's flops): 512-token blocks, each wave keeps its 64 tokens' input as
+//           MFMA operands in registers, the 2 x 256 KB of W1 / W2 stream through LDS in 16 KB chunks by LDS-DMA (double-buffered,
+//           swizzled image: conflict-free ds_read_b128), the 2048 hidden activations never leave registers (ReLU'd accumulators
+//           of the first product are the second product's B operand), residual, LayerNorm 2.
+// Around them: k_embed (per chain: the Conv1d stack as three row-shifted MFMA products over an LDS halo buffer, the two SIRENs on
+// the vector ALU), k_poolb (final LayerNorm + PoolRN / PoolPos sums per chain), and the 198 -> 64 -> 6 head on the exact-fp32
+// products of so3x_protnet.hip (B rows: nothing to gain).
+//
+// Storage order of a 64-wide activation row: within every group of 16 features, position p holds feature sigma(p) =
+// 4 (p >> 3) + (p & 3) + 8 ((p >> 2) & 1).  That is the order in which a lane of v_mfma_f32_32x32x16_bf16 holds its accumulator rows
+// (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a lane's 8 accumulators of a 16-group are 16 contiguous bytes of the row, and
+// the same 16 bytes are its B-operand fragment of the next product -- no lane movement, no LDS (the weight images' K order absorbs
+// the permutation).
 #include "so3x_protnet.hpp"
-namespace so3x { namespace prot {
-bool bf16_supported(const Dims&) { return false; }
-size_t bf16_workspace_bytes(const Dims&, int64_t, int64_t) { return 0; }
-int forward_bf16(hipStream_t, const Dims&, const float*, const float*, const float*, const float*, const int64_t*, int64_t, const float*, const float*,
-                 const float*, const int64_t*, int64_t, const int64_t*, float*, float*, void*) { return SO3X_ERR_UNSUPPORTED; }
-} }
+#include "so3x_math.hpp"
+
+namespace so3x {
+namespace prot {
+
+using plane::gemm;
+using plane::Mat;
+using plane::rowmajor;
+using plane::transposed;
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TRY(expr)                 \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__) return rc__;        \
+  } while (0)
+
+constexpr int DM = 64, NH = 4, DH = 16, FF = 2048;
+constexpr int MAXL = 256;                 // residues per chain the attention kernel holds in LDS
+constexpr float LOG2E = 1.4426950408889634f;
+
+__host__ __device__ inline int sigma16(int p) { return 4 * (p >> 3) + (p & 3) + 8 * ((p >> 2) & 1); }          // position -> feature
+__host__ __device__ inline int sigma16_inv(int f) { return 8 * ((f >> 2) & 1) + (f & 3) + 4 * (f >> 3); }      // feature -> position
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * sigm(x); }
+
+__device__ __forceinline__ void glds16(const void* src, const void* dst) {   // LDS-DMA: 16 B per lane to dst + 16 lane (dst wave-uniform)
+  typedef __attribute__((address_space(3))) const char* lds_cp;
+  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_cp)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory", "m0");
+}
+
+// ------------------------------------------------------------------------------------------------ the weight image
+// One bf16 / fp32 image per forward, built from the flat fp32 parameters (state_dict order) by k_image:
+//   per encoder layer l of rec_tf:
+//     qkv   [192][64] bf16: row i = in_proj row i (q rows and bias pre-scaled by log2(e) / sqrt(16)); K order = storage order
+//     wo    [64][64] bf16: K position 32 ks + 8 kq + j = head (2 ks + (j >> 2)), feature 4 kq + (j & 3)  (the order in which a lane
+//           of the 16x16x32 out-projection holds two heads' normalised outputs)
+//     ffn   32 chunks of [W1c 64 x 64 | W2c 64 x 64 | b1c 64 fp32] = 16,640 B: W1c row r = hidden unit 64 c + r, K order = storage
+//           order; W2c row o = output feature o, K position = sigma-order of the chunk's hidden units; both with the 16-byte chunk
+//           q of row r stored at q ^ (r & 7) (swizzle: conflict-free ds_read_b128 of 32 rows x one chunk)
+//     vec   fp32 [bqkv 192 | bo 64 | g1 64 | be1 64 | b2 64 | g2 64 | be2 64]   (natural feature order)
+//   conv layer i: 3 taps x [cout][KP] bf16 (KP = 32 for the 21 residue types, else 64; natural order) + bias fp32
+struct Img {
+  size_t qkv, wo, ffn, vec, per_layer;   // byte offsets inside a layer's slab
+  size_t conv[8], convb[8], layers, total;
+  int kp[8], cout[8];
+};
+constexpr size_t CHUNK_BYTES = 64 * 64 * 2 * 2 + 64 * 4;   // 16,640
+constexpr int NCHUNK = FF / 64;
+constexpr int VEC_FLOATS = 192 + 6 * 64;
+inline Img image_layout(const Dims& s) {
+  Img im;
+  size_t p = 0;
+  for (int i = 0; i < s.Cd; i++) {
+    im.kp[i] = i == 0 ? 32 : 64;
+    im.cout[i] = i == s.Cd - 1 ? s.rd() : 64;
+    im.conv[i] = p; p += (size_t)3 * im.cout[i] * im.kp[i] * 2;
+    im.convb[i] = p; p += plane::up((size_t)im.cout[i] * 4);
+    p = plane::up(p);
+  }
+  im.layers = p;
+  size_t q = 0;
+  im.qkv = q; q += 192 * 64 * 2;
+  im.wo = q; q += 64 * 64 * 2;
+  im.ffn = q; q += NCHUNK * CHUNK_BYTES;
+  im.vec = q; q += plane::up(VEC_FLOATS * 4);
+  im.per_layer = plane::up(q);
+  im.total = p + im.per_layer * s.T;
+  return im;
+}
+
+__global__ __launch_bounds__(256) void k_image(const float* __restrict__ prm, char* __restrict__ img, const POff po, const Img im, int T, int Cd) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  // convolutions
+  for (int i = 0; i < Cd; i++) {
+    const int cin = po.cin[i], cout = po.cout[i], kp = im.kp[i];
+    bf16* w = reinterpret_cast<bf16*>(img + im.conv[i]);
+    for (int64_t e = tid; e < (int64_t)3 * cout * kp; e += nth) {
+      const int k = (int)(e % kp), co = (int)((e / kp) % cout), tap = (int)(e / ((int64_t)kp * cout));
+      w[e] = (bf16)(k < cin ? prm[po.cw[i] + ((int64_t)co * cin + k) * 3 + tap] : 0.f);
+    }
+    float* b = reinterpret_cast<float*>(img + im.convb[i]);
+    for (int64_t e = tid; e < cout; e += nth) b[e] = prm[po.cb[i] + e];
+  }
+  const float qs = LOG2E * 0.25f;   // 1 / sqrt(16), and exp2 instead of exp in the softmax
+  for (int l = 0; l < T; l++) {
+    const LayerOff lo = po.layer(po.rec_tf, l);
+    char* slab = img + im.layers + im.per_layer * l;
+    bf16* qkv = reinterpret_cast<bf16*>(slab + im.qkv);
+    for (int64_t e = tid; e < 192 * 64; e += nth) {
+      const int p = (int)(e & 63), i = (int)(e >> 6);
+      const int f = 16 * (p >> 4) + sigma16(p & 15);
+      qkv[e] = (bf16)(prm[lo.wqkv + (int64_t)i * 64 + f] * (i < 64 ? qs : 1.f));
+    }
+    bf16* wo = reinterpret_cast<bf16*>(slab + im.wo);
+    for (int64_t e = tid; e < 64 * 64; e += nth) {
+      const int p = (int)(e & 63), i = (int)(e >> 6);
+      const int ks = p >> 5, kq = (p >> 3) & 3, j = p & 7;
+      const int f = 16 * (2 * ks + (j >> 2)) + 4 * kq + (j & 3);
+      wo[e] = (bf16)prm[lo.wo + (int64_t)i * 64 + f];
+    }
+    char* ffn = slab + im.ffn;
+    for (int64_t e = tid; e < (int64_t)NCHUNK * 64 * 64; e += nth) {
+      const int c = (int)(e >> 12), r = (int)((e >> 6) & 63), p = (int)(e & 63);
+      const int q = p >> 3, j = p & 7;
+      const int slot = ((q ^ (r & 7)) << 3) + j;                      // swizzled position inside the 128-byte row
+      bf16* w1 = reinterpret_cast<bf16*>(ffn + (size_t)c * CHUNK_BYTES);
+      bf16* w2 = w1 + 64 * 64;
+      const int f = 16 * (p >> 4) + sigma16(p & 15);                  // W1: K = input feature in storage order
+      w1[r * 64 + slot] = (bf16)prm[lo.w1 + (int64_t)(64 * c + r) * 64 + f];
+      const int hu = 64 * c + 16 * (p >> 4) + sigma16(p & 15);        // W2: K = hidden unit of the chunk in accumulator order
+      w2[r * 64 + slot] = (bf16)prm[lo.w2 + (int64_t)r * FF + hu];
+    }
+    for (int64_t e = tid; e < FF; e += nth)
+      reinterpret_cast<float*>(ffn + (size_t)(e >> 6) * CHUNK_BYTES + 64 * 64 * 4)[e & 63] = prm[lo.b1 + e];
+    float* vec = reinterpret_cast<float*>(slab + im.vec);
+    for (int64_t e = tid; e < VEC_FLOATS; e += nth) {
+      float v;
+      if (e < 192) v = prm[lo.bqkv + e] * (e < 64 ? qs : 1.f);
+      else if (e < 256) v = prm[lo.bo + e - 192];
+      else if (e < 320) v = prm[lo.g1 + e - 256];
+      else if (e < 384) v = prm[lo.be1 + e - 320];
+      else if (e < 448) v = prm[lo.b2 + e - 384];
+      else if (e < 512) v = prm[lo.g2 + e - 448];
+      else v = prm[lo.be2 + e - 512];
+      vec[e] = v;
+    }
+  }
+}
+
+// chain table: start row of every chain in the compact stream and its length (s < B: receptor rows first, then the ligands)
+__global__ __launch_bounds__(256) void k_chains(const int64_t* __restrict__ roff, const int64_t* __restrict__ loff, int64_t n_rec, int* __restrict__ start,
+                                                int* __restrict__ len, int64_t B) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= 2 * B) return;
+  const bool lig = s >= B;
+  const int64_t c = lig ? s - B : s;
+  const int64_t* off = lig ? loff : roff;
+  start[s] = (int)(off[c] + (lig ? n_rec : 0));
+  const int64_t L = off[c + 1] - off[c];
+  len[s] = (int)(L < MAXL ? L : MAXL);
+}
+
+// ------------------------------------------------------------------------------------------------ k_embed
+// One workgroup (256 threads) per chain.  LDS: two halo buffers [MAXL + 2][72] bf16 (144-byte rows) for the convolution stack's
+// ping-pong, the residues as [MAXL + 2][40] bf16 (80-byte rows, 21 types zero-padded to 32), SIREN weights in fp32.
+// Conv1d(k 3, pad 1) = sum over 3 taps of W_tap x[l + tap - 1]: out^T[16 features x 16 residues] += W_tap[16 x 32] x_tap^T[32 x 16]
+// on v_mfma_f32_16x16x32_bf16, whose accumulator (lane = residue, 4 consecutive features) is written back as one 8-byte LDS store.
+constexpr int ERS = 72, RRS = 40;   // row strides in bf16 elements
+constexpr int EMB_LDS = ((MAXL + 2) * ERS * 2 + (MAXL + 2) * RRS) * 2 + (32 * 3 + 32 + 32 * 32 + 32 + 16 * 9 + 16 + 16 * 16 + 16) * 4;
+
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ prm, const char* __restrict__ img, const POff po, const Img im, int Cd,
+                                               const float* __restrict__ rres, const float* __restrict__ rpos, const float* __restrict__ rang,
+                                               const float* __restrict__ lres, const float* __restrict__ lpos, const float* __restrict__ lang,
+                                               const int* __restrict__ start, const int* __restrict__ len, int64_t B, int64_t n_rec,
+                                               bf16* __restrict__ x) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* bufA = reinterpret_cast<bf16*>(smem);
+  bf16* bufB = bufA + (MAXL + 2) * ERS;
+  bf16* resb = bufB + (MAXL + 2) * ERS;
+  float* sw = reinterpret_cast<float*>(resb + (MAXL + 2) * RRS);
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = len[s], row0 = start[s];
+  const bool lig = s >= B;
+  const int64_t src0 = lig ? row0 - n_rec : row0;
+  const float* res = lig ? lres : rres;
+  const float* pos = lig ? lpos : rpos;
+  const float* ang = lig ? lang : rang;
+  // zero both halo buffers' halo rows and stage the residues (rows >= L zero)
+  for (int i = tid; i < (MAXL + 2) * RRS; i += 256) {
+    const int r = i / RRS, c = i - r * RRS;
+    const int l = r - 1;
+    resb[i] = (bf16)((l >= 0 && l < L && c < RES) ? res[(src0 + l) * RES + c] : 0.f);
+  }
+  for (int i = tid; i < (MAXL + 2) * ERS; i += 256) bufA[i] = bufB[i] = (bf16)0.f;
+  // SIREN weights: [wpp 96 | bpp 32 | wpps 1024 | bpps 32 | wap 144 | bap 16 | waps 256 | baps 16]
+  for (int i = tid; i < 96; i += 256) sw[i] = prm[po.wpp + i];
+  for (int i = tid; i < 32; i += 256) { sw[96 + i] = prm[po.bpp + i]; sw[1152 + i] = prm[po.bpps + i]; }
+  for (int i = tid; i < 1024; i += 256) sw[128 + i] = prm[po.wpps + i];
+  for (int i = tid; i < 144; i += 256) sw[1184 + i] = prm[po.wap + i];
+  for (int i = tid; i < 16; i += 256) { sw[1328 + i] = prm[po.bap + i]; sw[1600 + i] = prm[po.baps + i]; }
+  for (int i = tid; i < 256; i += 256) sw[1344 + i] = prm[po.waps + i];
+  __syncthreads();
+  const int q = lane & 15, g = lane >> 4;
+  const int tok0 = wave * 64;          // this wave's 64 residues: 4 tiles of 16
+  const int ntile = L <= tok0 ? 0 : ((L - tok0 + 15) >> 4) < 4 ? ((L - tok0 + 15) >> 4) : 4;
+  float resid[4][4][4];                // [tile][feature tile][r]: the ResLayers' running x (fp32)
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) resid[t][ft][r] = 0.f;
+  const bf16* in = resb;
+  int in_rs = RRS;
+  bf16* out = bufA;
+  for (int i = 0; i < Cd; i++) {
+    const int kp = im.kp[i], cout = im.cout[i], ksteps = kp >> 5, ftiles = cout >> 4;
+    const bf16* w = reinterpret_cast<const bf16*>(img + im.conv[i]);
+    const float* bias = reinterpret_cast<const float*>(img + im.convb[i]);
+    const bool last = i == Cd - 1;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (t >= ntile) continue;
+      const int tok = tok0 + 16 * t + q;
+#pragma unroll
+      for (int ft = 0; ft < 4; ft++) {
+        if (ft >= ftiles) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < 3; tap++)
+          for (int ks = 0; ks < ksteps; ks++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w + ((size_t)tap * cout + 16 * ft + q) * kp + 32 * ks + 8 * g);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(in + (tok + tap) * in_rs + 32 * ks + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+          }
+        // lane (residue q, g): features 16 ft + 4 g + r
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = acc[r] + bias[16 * ft + 4 * g + r];
+        const bool ok = tok < L;
+        if (last) {
+          // res_emb -> x[:, features 0 .. 15] (group 0), storage positions sigma^-1(4 g + r) = {0, 8, 4, 12}[g] + r
+          if (ok) {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(x + (int64_t)(row0 + tok) * DM + sigma16_inv(4 * g)) = o;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float a = silu(v[r]);
+            resid[t][ft][r] = i == 0 ? a : resid[t][ft][r] + a;
+            v[r] = ok ? resid[t][ft][r] : 0.f;
+          }
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(out + (tok + 1) * ERS + 16 * ft + 4 * g) = o;
+        }
+      }
+    }
+    __syncthreads();
+    in = out;
+    in_rs = ERS;
+    out = out == bufA ? bufB : bufA;
+  }
+  // SIRENs, one residue per thread: pos_emb -> features 16 .. 47 (groups 1, 2), ang_emb -> features 48 .. 63 (group 3)
+  const int tok = tid;
+  if (tok < L) {
+    const float* pp = pos + (src0 + tok) * 3;
+    const float* aa = ang + (src0 + tok) * 9;
+    float sn[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) sn[j] = sinf(fmaf(pp[2], sw[3 * j + 2], fmaf(pp[1], sw[3 * j + 1], fmaf(pp[0], sw[3 * j], sw[96 + j]))));
+    bf16* xo = x + (int64_t)(row0 + tok) * DM;
+    for (int grp = 0; grp < 2; grp++) {
+      float o[16];
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        const int f = 16 * grp + sigma16(p);
+        float a = sw[1152 + f];
+#pragma unroll
+        for (int j = 0; j < 32; j++) a = fmaf(sn[j], sw[128 + f * 32 + j], a);
+        o[p] = a;
+      }
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int p = 0; p < 8; p++) { o0[p] = (bf16)o[p]; o1[p] = (bf16)o[8 + p]; }
+      *reinterpret_cast<bf16x8*>(xo + 16 * (1 + grp)) = o0;
+      *reinterpret_cast<bf16x8*>(xo + 16 * (1 + grp) + 8) = o1;
+    }
+    float sa[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      float a = sw[1328 + j];
+#pragma unroll
+      for (int c = 0; c < 9; c++) a = fmaf(aa[c], sw[1184 + 9 * j + c], a);
+      sa[j] = sinf(a);
+    }
+    float o[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      const int f = sigma16(p);
+      float a = sw[1600 + f];
+#pragma unroll
+      for (int j = 0; j < 16; j++) a = fmaf(sa[j], sw[1344 + f * 16 + j], a);
+      o[p] = a;
+    }
+    bf16x8 o0, o1;
+#pragma unroll
+    for (int p = 0; p < 8; p++) { o0[p] = (bf16)o[p]; o1[p] = (bf16)o[8 + p]; }
+    *reinterpret_cast<bf16x8*>(xo + 48) = o0;
+    *reinterpret_cast<bf16x8*>(xo + 56) = o1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_attn
+// One workgroup (256 threads = 4 waves x 64 queries) per chain.  LDS: K [MAXL][68] bf16 (136-byte rows: the 16 keys x 8 bytes a
+// 16x16x16 A-operand read takes fall in distinct banks), V^T [64][264] bf16 (528-byte rows, the same for its 16 features x 8 bytes).
+constexpr int KRS = 68, VRS = 264;
+constexpr int ATT_LDS = (MAXL * KRS + DM * VRS) * 2;
+
+__global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf16* __restrict__ y, const char* __restrict__ slab, const Img im,
+                                                 const int* __restrict__ start, const int* __restrict__ len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vt = Ks + MAXL * KRS;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = len[s], row0 = start[s];
+  const int q = lane & 15, g = lane >> 4;
+  const bf16* wqkv = reinterpret_cast<const bf16*>(slab + im.qkv);
+  const bf16* wo = reinterpret_cast<const bf16*>(slab + im.wo);
+  const float* vec = reinterpret_cast<const float*>(slab + im.vec);
+  const int tok0 = wave * 64;
+  const int ntile = L <= tok0 ? 0 : ((L - tok0 + 15) >> 4) < 4 ? ((L - tok0 + 15) >> 4) : 4;
+  // this wave's input rows as 16x16x32 operand fragments: lane (residue q, kq = g) holds 8 consecutive storage positions
+  const int L32 = (L + 31) & ~31;       // K / V tiles are produced up to the last key chunk's end (finite values at the masked keys)
+  const int nkv = L32 <= tok0 ? 0 : ((L32 - tok0) >> 4) < 4 ? ((L32 - tok0) >> 4) : 4;
+  bf16x8 xf[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int tok = tok0 + 16 * t + q;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = (bf16)0.f;
+      if (t < ntile && tok < L) v = *reinterpret_cast<const bf16x8*>(x + (int64_t)(row0 + tok) * DM + 32 * ks + 8 * g);
+      xf[t][ks] = v;
+    }
+  }
+  // K (rows 64 .. 127 of in_proj) and V (rows 128 .. 191) of this wave's residues -> LDS
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    if (t >= nkv) continue;
+    const int tok = tok0 + 16 * t;
+#pragma unroll
+    for (int ft = 0; ft < 4; ft++) {
+      f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const bf16x8 wk = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(64 + 16 * ft + q) * 64 + 32 * ks + 8 * g);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(128 + 16 * ft + q) * 64 + 32 * ks + 8 * g);
+        ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk, xf[t][ks], ak, 0, 0, 0);   // K^T: lane (residue q, g): features 16 ft + 4 g + r
+        av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t][ks], wv, av, 0, 0, 0);   // V:   lane (feature q, g): residues tok + 4 g + r
+      }
+      bf16x4 ok, ov;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        ok[r] = (bf16)(ak[r] + vec[64 + 16 * ft + 4 * g + r]);
+        ov[r] = (bf16)(av[r] + vec[128 + 16 * ft + q]);
+      }
+      *reinterpret_cast<bf16x4*>(Ks + (tok + q) * KRS + 16 * ft + 4 * g) = ok;
+      *reinterpret_cast<bf16x4*>(Vt + (16 * ft + q) * VRS + tok + 4 * g) = ov;
+    }
+  }
+  __syncthreads();
+  // attention of this wave's queries over the chain's keys, one head at a time
+  const int nchunk = (L + 31) >> 5;
+  bf16x4 ob[4][4];       // [query tile][head]: the normalised head outputs, lane (query q, g): head features 4 g + r
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    bf16x4 qf[4];        // Q_h^T as the B operand of the 16x16x16 score product: lane (query q, kq = g): features 16 h + 4 g + j
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+      if (t < ntile) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(16 * h + q) * 64 + 32 * ks + 8 * g);
+          aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, xf[t][ks], aq, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) qf[t][r] = (bf16)(aq[r] + vec[16 * h + 4 * g + r]);
+    }
+    f32x4 oacc[4];
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mrun[t] = -INFINITY;
+      lrun[t] = 0.f;
+    }
+    for (int c = 0; c < nchunk; c++) {
+      const int key0 = 32 * c;
+      // K_h rows of the chunk's two 16-key tiles (A operands: lane (key q, kq = g): features 16 h + 4 g + j) and V_h^T (A operand of
+      // the 16x16x32 product: lane (feature q, kq = g): keys key0 + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3})
+      const s16x4 k0 = *reinterpret_cast<const s16x4*>(Ks + (key0 + q) * KRS + 16 * h + 4 * g);
+      const s16x4 k1 = *reinterpret_cast<const s16x4*>(Ks + (key0 + 16 + q) * KRS + 16 * h + 4 * g);
+      const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vt + (16 * h + q) * VRS + key0 + 4 * g);
+      const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vt + (16 * h + q) * VRS + key0 + 16 + 4 * g);
+      bf16x8 vf;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
+      const bool tail = key0 + 32 > L;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (t >= ntile) continue;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), s0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
+        s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), s1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
+        if (tail) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            if (key0 + 4 * g + r >= L) s0[r] = -INFINITY;
+            if (key0 + 16 + 4 * g + r >= L) s1[r] = -INFINITY;
+          }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun[t], mx);          // (a chunk always holds at least one real key: mnew is finite)
+        const float resc = exp2f(mrun[t] - mnew);
+        mrun[t] = mnew;
+        bf16x8 pf;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float p0 = exp2f(s0[r] - mnew), p1 = exp2f(s1[r] - mnew);
+          ps += p0 + p1;
+          pf[r] = (bf16)p0;
+          pf[4 + r] = (bf16)p1;
+        }
+        lrun[t] = lrun[t] * resc + ps;
+#pragma unroll
+        for (int r = 0; r < 4; r++) oacc[t][r] *= resc;
+        // O_h^T[feature][query] += V_h^T[feature][32 keys] P^T[32 keys][query]: lane (query q, g): head features 4 g + r
+        oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      float l = lrun[t];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) ob[t][h][r] = (bf16)(oacc[t][r] * inv);
+    }
+  }
+  // out-projection (16x16x32, K = two heads per step), residual, LayerNorm 1 -> y in storage order
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    if (t >= ntile) continue;
+    const int tok = tok0 + 16 * t + q;
+    bf16x8 of[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { of[ks][j] = ob[t][2 * ks][j]; of[ks][4 + j] = ob[t][2 * ks + 1][j]; }
+    float v[4][4];
+    float sum = 0.f;
+    const bool ok = tok < L;
+    const bf16* xr = x + (int64_t)(row0 + (ok ? tok : 0)) * DM;
+#pragma unroll
+    for (int ft = 0; ft < 4; ft++) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wo + (size_t)(16 * ft + q) * 64 + 32 * ks + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, of[ks], acc, 0, 0, 0);      // lane (residue q, g): features 16 ft + 4 g + r
+      }
+      const bf16x4 xr4 = *reinterpret_cast<const bf16x4*>(xr + 16 * ft + sigma16_inv(4 * g));
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        v[ft][r] = acc[r] + vec[192 + 16 * ft + 4 * g + r] + (float)xr4[r];
+        sum += v[ft][r];
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.f / 64.f);
+    float var = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float u = v[ft][r] - mean;
+        var = fmaf(u, u, var);
+      }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + 1e-5f);
+    if (ok) {
+      bf16* yo = y + (int64_t)(row0 + tok) * DM;
+#pragma unroll
+      for (int ft = 0; ft < 4; ft++) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int f = 16 * ft + 4 * g + r;
+          o[r] = (bf16)((v[ft][r] - mean) * rstd * vec[256 + f] + vec[320 + f]);
+        }
+        *reinterpret_cast<bf16x4*>(yo + 16 * ft + sigma16_inv(4 * g)) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_ffn
+// x1 -> LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2), 512 residues per workgroup iteration (8 waves x 64), persistent workgroups.
+constexpr int FFN_LDS = 2 * (int)CHUNK_BYTES;
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int qchunk) {   // the swizzled image's 16-byte chunk `qchunk` of `row`
+  return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((qchunk ^ (row & 7)) << 4));
+}
+
+__global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* __restrict__ y, const char* __restrict__ slab, const Img im, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const char* ffn = slab + im.ffn;
+  const float* vec = reinterpret_cast<const float*>(slab + im.vec);
+  const int64_t nblocks = (n + 511) / 512;
+  auto dma = [&](int chunk, int buf) {     // 16,640 bytes = 1040 x 16: lanes 0 .. 511 twice + 16 lanes of wave 0
+    const char* src = ffn + (size_t)chunk * CHUNK_BYTES;
+    char* dst = smem + buf * CHUNK_BYTES;
+    glds16(src + tid * 16, dst + wave * 1024);
+    glds16(src + 8192 + tid * 16, dst + 8192 + wave * 1024);
+    if (wave == 0 && lane < 16) glds16(src + 16384 + lane * 16, dst + 16384);
+  };
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t tok_base = blk * 512 + wave * 64;
+    // the wave's 64 residues as B operands: xb[token tile][16-feature group]: lane (token c32, hh): storage positions 16 g + 8 hh ..
+    bf16x8 xb[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int64_t tok = tok_base + 32 * tt + c32;
+#pragma unroll
+      for (int gi = 0; gi < 4; gi++) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (bf16)0.f;
+        if (tok < n) v = *reinterpret_cast<const bf16x8*>(x1 + tok * DM + 16 * gi + 8 * hh);
+        xb[tt][gi] = v;
+      }
+    }
+    f32x16 yacc[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int ot = 0; ot < 2; ot++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) yacc[tt][ot][r] = 0.f;
+    __syncthreads();        // every wave is done with both buffers of the previous block
+    dma(0, 0);
+    for (int c = 0; c < NCHUNK; c++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();      // chunk c has landed for everybody; everybody is done with chunk c - 1's buffer
+      if (c + 1 < NCHUNK) dma(c + 1, (c + 1) & 1);
+      const char* w1 = smem + (c & 1) * CHUNK_BYTES;
+      const char* w2 = w1 + 64 * 64 * 2;
+      const float* b1 = reinterpret_cast<const float*>(w2 + 64 * 64 * 2);
+#pragma unroll
+      for (int ht = 0; ht < 2; ht++) {
+        bf16x8 a1[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) a1[gi] = lds_frag(w1, 32 * ht + c32, 2 * gi + hh);
+        f32x16 bias;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1 + 32 * ht + 8 * r4 + 4 * hh);
+#pragma unroll
+          for (int r = 0; r < 4; r++) bias[4 * r4 + r] = b4[r];
+        }
+        bf16x8 hb[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          f32x16 h = bias;
+#pragma unroll
+          for (int gi = 0; gi < 4; gi++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[gi], xb[tt][gi], h, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            hb[tt][0][r] = (bf16)fmaxf(h[r], 0.f);
+            hb[tt][1][r] = (bf16)fmaxf(h[8 + r], 0.f);
+          }
+        }
+#pragma unroll
+        for (int ot = 0; ot < 2; ot++)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++) {
+            const bf16x8 a2 = lds_frag(w2, 32 * ot + c32, 4 * ht + 2 * s2 + hh);
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) yacc[tt][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hb[tt][s2], yacc[tt][ot], 0, 0, 0);
+          }
+      }
+    }
+    // + b2 + residual, LayerNorm 2, store.  Lane (token c32, hh) holds features 32 ot + (r & 3) + 8 (r >> 2) + 4 hh = storage positions
+    // 16 (2 ot + (r >> 3)) + 8 hh + (r & 7) of its row: the same elements as xb[tt][2 ot + (r >> 3)][r & 7].
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int64_t tok = tok_base + 32 * tt + c32;
+      float sum = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < 2; ot++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int f = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float v = yacc[tt][ot][r] + vec[384 + f] + (float)xb[tt][2 * ot + (r >> 3)][r & 7];
+          yacc[tt][ot][r] = v;
+          sum += v;
+        }
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.f / 64.f);
+      float var = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < 2; ot++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float u = yacc[tt][ot][r] - mean;
+          var = fmaf(u, u, var);
+        }
+      var += __shfl_xor(var, 32);
+      const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + 1e-5f);
+      if (tok < n) {
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int r = 8 * (gi & 1) + j, ot = gi >> 1;
+            const int f = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            o[j] = (bf16)((yacc[tt][ot][r] - mean) * rstd * vec[448 + f] + vec[512 + f]);
+          }
+          *reinterpret_cast<bf16x8*>(y + tok * DM + 16 * gi + 8 * hh) = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_poolb
+// Per chain: the encoder's final LayerNorm, then PoolRN's and PoolPos's weighted sums (models.py:94-127) -- as k_pool of the exact
+// form, from the bf16 stream.  One residue per thread for the norm and the two logits, one (feature, quarter) per thread for the sums.
+__global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const float* __restrict__ prm, const POff po, const float* __restrict__ rpos,
+                                               const float* __restrict__ lpos, const int* __restrict__ start, const int* __restrict__ len, int64_t B,
+                                               int64_t n_rec, float* __restrict__ xs, float* __restrict__ pv, float* __restrict__ enc_dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float (*xn)[65] = reinterpret_cast<float (*)[65]>(smem);
+  float* we = reinterpret_cast<float*>(smem) + MAXL * 65;
+  float* wp = we + MAXL;
+  float (*pp)[3] = reinterpret_cast<float (*)[3]>(wp + MAXL);
+  float (*part)[64] = reinterpret_cast<float (*)[64]>(wp + MAXL + MAXL * 3);
+  float (*tail)[8] = reinterpret_cast<float (*)[8]>(wp + MAXL + MAXL * 3 + 4 * 64);
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int L = len[s], row0 = start[s];
+  const bool lig = s >= B;
+  const Pool q = lig ? po.lig : po.rec;
+  const float* pos = lig ? lpos : rpos;
+  const int64_t src0 = lig ? row0 - n_rec : row0;
+  if (tid < L) {
+    const bf16* xr = x + (int64_t)(row0 + tid) * DM;
+    float v[64];
+    float sum = 0.f;
+#pragma unroll
+    for (int gi = 0; gi < 8; gi++) {
+      const bf16x8 u = *reinterpret_cast<const bf16x8*>(xr + 8 * gi);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int p = 8 * gi + j;
+        v[p] = (float)u[j];
+        sum += v[p];
+      }
+    }
+    const float mean = sum * (1.f / 64.f);
+    float var = 0.f;
+#pragma unroll
+    for (int p = 0; p < 64; p++) var = fmaf(v[p] - mean, v[p] - mean, var);
+    const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + 1e-5f);
+    float a = prm[q.bpool], b = prm[q.bppool];
+#pragma unroll
+    for (int p = 0; p < 64; p++) {
+      const int f = 16 * (p >> 4) + sigma16(p & 15);
+      const float u = (v[p] - mean) * rstd * prm[po.rec_tf.gF + f] + prm[po.rec_tf.bF + f];
+      xn[tid][f] = u;
+      a = fmaf(u, prm[q.wpool + f], a);
+      b = fmaf(u, prm[q.wppool + f], b);
+      if (enc_dbg) enc_dbg[(int64_t)(row0 + tid) * DM + f] = u;
+    }
+    we[tid] = sigm(a);
+    wp[tid] = sigm(b);
+    pp[tid][0] = pos[(src0 + tid) * 3];
+    pp[tid][1] = pos[(src0 + tid) * 3 + 1];
+    pp[tid][2] = pos[(src0 + tid) * 3 + 2];
+  }
+  __syncthreads();
+  const int c = tid & 63, qu = tid >> 6;
+  float acc = 0.f, se = 0.f, sp = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+  for (int l = qu; l < L; l += 4) {
+    acc = fmaf(we[l], xn[l][c], acc);
+    if (c == 0) {
+      se += we[l];
+      sp += wp[l];
+      p0 = fmaf(wp[l], pp[l][0], p0);
+      p1 = fmaf(wp[l], pp[l][1], p1);
+      p2 = fmaf(wp[l], pp[l][2], p2);
+    }
+  }
+  part[qu][c] = acc;
+  if (c == 0) {
+    tail[qu][0] = se;
+    tail[qu][1] = sp;
+    tail[qu][2] = p0;
+    tail[qu][3] = p1;
+    tail[qu][4] = p2;
+  }
+  __syncthreads();
+  const float tse = (tail[0][0] + tail[1][0]) + (tail[2][0] + tail[3][0]), tsp = (tail[0][1] + tail[1][1]) + (tail[2][1] + tail[3][1]);
+  const float ce = fmaxf(tse, 1e-6f), cp = fmaxf(tsp, 1e-6f);
+  if (tid < 64) xs[(int64_t)s * DM + tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / ce;
+  if (tid < 3) {
+    const int64_t b = lig ? s - B : s;
+    const int j = 2 + tid;
+    pv[b * (3 * DM + 6) + (lig ? 3 * DM + 3 : 2 * DM) + tid] = ((tail[0][j] + tail[1][j]) + (tail[2][j] + tail[3][j])) / cp;
+  }
+}
+
+// SinusoidalPosEmb(64)(t) -> pv[b][0 .. 64) (as k_time_emb of the exact form)
+__global__ __launch_bounds__(256) void k_time_embb(const int64_t* __restrict__ t, float* __restrict__ pv, int64_t B, float neg_emb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * DM) return;
+  const int64_t b = i / DM;
+  const int j = (int)(i - b * DM), jj = j < 32 ? j : j - 32;
+  const float f = (float)exp((double)((float)jj * neg_emb));
+  const float arg = (float)t[b] * f;
+  pv[b * (3 * DM + 6) + j] = j < 32 ? sinf(arg) : cosf(arg);
+}
+__global__ __launch_bounds__(256) void k_silu_res(const float* __restrict__ z, const float* res, float* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (res ? res[i] : 0.f) + silu(z[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ host
+bool bf16_supported(const Dims& s) { return s.d == DM && s.H == NH && s.F == FF && s.T <= 8 && s.Cd <= 8 && s.Lp <= MAXL; }
+
+struct WsB {
+  char* img;
+  int *start, *len;
+  bf16 *xa, *xb;
+  float *xs, *pv, *hz, *ha, *hb;
+  size_t bytes;
+};
+static WsB carve_ws(const Dims& s, int64_t n, void* mem) {
+  WsB w;
+  Carve c(mem);
+  w.img = c.take<char>(image_layout(s).total);
+  w.start = c.take<int>((size_t)s.S());
+  w.len = c.take<int>((size_t)s.S());
+  w.xa = c.take<bf16>((size_t)(n + 512) * DM);
+  w.xb = c.take<bf16>((size_t)(n + 512) * DM);
+  w.xs = c.take<float>((size_t)s.S() * DM);
+  w.pv = c.take<float>((size_t)s.B * s.pw());
+  w.hz = c.take<float>((size_t)s.B * DM);
+  w.ha = c.take<float>((size_t)s.B * DM);
+  w.hb = c.take<float>((size_t)s.B * DM);
+  w.bytes = c.off;
+  return w;
+}
+size_t bf16_workspace_bytes(const Dims& s, int64_t n_rec, int64_t n_lig) { return carve_ws(s, n_rec + n_lig, nullptr).bytes; }
+
+constexpr int POOL_LDS = (MAXL * 65 + MAXL * 2 + MAXL * 3 + 4 * 64 + 4 * 8) * 4;
+static PerDevice g_embed, g_attn, g_ffn, g_pool;
+
+int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* rres, const float* rpos, const float* rang, const int64_t* roff,
+                 int64_t n_rec, const float* lres, const float* lpos, const float* lang, const int64_t* loff, int64_t n_lig, const int64_t* t,
+                 float* out, float* pool_out, void* workspace) {
+  const POff po = param_offsets(s);
+  const Img im = image_layout(s);
+  const int64_t n = n_rec + n_lig, S = s.S(), B = s.B;
+  const WsB w = carve_ws(s, n, workspace);
+  TRY(ensure_dyn_lds(g_embed, (const void*)k_embed, EMB_LDS));
+  TRY(ensure_dyn_lds(g_attn, (const void*)k_attn, ATT_LDS));
+  TRY(ensure_dyn_lds(g_pool, (const void*)k_poolb, POOL_LDS));
+  int cap = 256;
+  TRY(resident_blocks(g_ffn, (const void*)k_ffn, 512, FFN_LDS, &cap));
+  hipLaunchKernelGGL(k_image, dim3(512), dim3(256), 0, st, prm, w.img, po, im, s.T, s.Cd);
+  hipLaunchKernelGGL(k_chains, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, roff, loff, n_rec, w.start, w.len, B);
+  hipLaunchKernelGGL(k_embed, dim3((unsigned)S), dim3(256), EMB_LDS, st, prm, w.img, po, im, s.Cd, rres, rpos, rang, lres, lpos, lang, w.start, w.len, B,
+                     n_rec, w.xa);
+  TRY(check_launch());
+  const int64_t nblocks = (n + 511) / 512;
+  const unsigned fgrid = (unsigned)(nblocks < cap ? nblocks : cap);
+  for (int l = 0; l < s.T; l++) {
+    const char* slab = w.img + im.layers + im.per_layer * l;
+    hipLaunchKernelGGL(k_attn, dim3((unsigned)S), dim3(256), ATT_LDS, st, w.xa, w.xb, slab, im, w.start, w.len);
+    hipLaunchKernelGGL(k_ffn, dim3(fgrid), dim3(512), FFN_LDS, st, w.xb, w.xa, slab, im, n);
+    TRY(check_launch());
+  }
+  const float neg_emb = (float)(-(log(10000.0) / (DM / 2 - 1)));
+  hipLaunchKernelGGL(k_time_embb, dim3((unsigned)((B * DM + 255) / 256)), dim3(256), 0, st, t, w.pv, B, neg_emb);
+  hipLaunchKernelGGL(k_poolb, dim3((unsigned)S), dim3(256), POOL_LDS, st, w.xa, prm, po, rpos, lpos, w.start, w.len, B, n_rec, w.xs, w.pv, (float*)nullptr);
+  TRY(check_launch());
+  const int d = DM, pw = s.pw();
+  TRY(gemm(st, rowmajor(w.xs, d), transposed(prm + po.rec.wlin, d), w.pv + d, pw, (int)B, d, d, prm + po.rec.blin));
+  TRY(gemm(st, rowmajor(w.xs + B * d, d), transposed(prm + po.lig.wlin, d), w.pv + 2 * d + 3, pw, (int)B, d, d, prm + po.lig.blin));
+  if (pool_out) {
+    hipError_t e = hipMemcpyAsync(pool_out, w.pv, (size_t)B * pw * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  // last: Linear SiLU, 3 x [x + SiLU(Linear(x))], Linear -- exact fp32 (B rows)
+  const unsigned hb = (unsigned)((B * d + 255) / 256);
+  TRY(gemm(st, rowmajor(w.pv, pw), transposed(prm + po.w0, pw), w.hz, d, (int)B, d, pw, prm + po.b0));
+  hipLaunchKernelGGL(k_silu_res, dim3(hb), dim3(256), 0, st, w.hz, (const float*)nullptr, w.ha, B * d);
+  float* cur = w.ha;
+  float* nxt = w.hb;
+  for (int i = 0; i < 3; i++) {
+    TRY(gemm(st, rowmajor(cur, d), transposed(prm + po.wr[i], d), w.hz, d, (int)B, d, d, prm + po.br[i]));
+    hipLaunchKernelGGL(k_silu_res, dim3(hb), dim3(256), 0, st, w.hz, cur, nxt, B * d);
+    float* tmp = cur;
+    cur = nxt;
+    nxt = tmp;
+  }
+  TRY(check_launch());
+  TRY(gemm(st, rowmajor(cur, d), transposed(prm + po.wout, d), out, 6, (int)B, 6, d, prm + po.bout));
+  return SO3X_OK;
+}
+
+}  // namespace prot
+}  // namespace so3x

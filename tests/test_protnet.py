@@ -282,3 +282,50 @@ def test_projected_se3_diffusion_training_step_with_protnet(golden):
     assert torch.isfinite(x.rot).all() and torch.isfinite(x.shift).all()
     full = proc(true_pos, ProtProjection(dd))        # the reference's own call form (prot_train.py:104)
     assert torch.isfinite(full)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 form (inference)
+@pytest.mark.gpu
+def test_bf16_forward_vs_reference(golden):
+    """the class-default width on the bf16 matrix-core kernels (compact ragged token stream, one workgroup per chain for the
+    attention block, token-parallel fused feed-forward): output and the head's 198-wide input within 3e-2 of the reference's float64
+    run, relative to the tensor's largest entry (measured ~5e-3); the exact-fp32 form on the same inputs sits 1e-5 away"""
+    from so3x import backend as B
+    net, data, g = build(golden, "default", precision="bf16")
+    net = net.to(DEV)
+    t = torch.from_numpy(g["default_t"]).to(DEV)
+    batch = B.ProtBatch.from_pairs(to_dev(data))
+    with torch.no_grad():
+        out = net(batch, t)
+        _, _, pool, _ = B.protnet_fwd(net.flat_params_nograd(), batch, t, *net.cfg, precision=B.PREC_BF16, want_pool=True)
+    full = torch.cat((out.rot_g, out.shift_g), -1).cpu().numpy()
+    for name, got, ref in (("out", full, g["default_out64"]), ("pool", pool.cpu().numpy(), g["default_pool64"])):
+        assert np.isfinite(got).all(), name
+        err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
+        assert err < 3e-2, (name, err)
+    # pooled positions are weighted means of fp32 inputs: tighter than the bf16 features
+    d = 64
+    for sl in (slice(2 * d, 2 * d + 3), slice(3 * d + 3, 3 * d + 6)):
+        ref = g["default_pool64"][:, sl]
+        assert float(np.abs(pool.cpu().numpy()[:, sl] - ref).max()) < 2e-2 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_bf16_ragged_batch_equals_its_complexes_one_by_one(golden):
+    """the compact stream has no padded rows: a batch gives complex by complex what each complex gives alone, BIT FOR BIT (a chain's
+    arithmetic does not depend on its neighbours: same kernels, same order of operations per chain)"""
+    from so3x import backend as B
+    net, data, g = build(golden, "default", precision="bf16")
+    net = net.to(DEV)
+    t = torch.from_numpy(g["default_t"]).to(DEV)
+    dd = to_dev(data)
+    with torch.no_grad():
+        full = net(dd, t)
+        for i in range(len(dd)):
+            one = net(dd[i:i + 1], t[i:i + 1])
+            assert torch.equal(one.rot_g, full.rot_g[i:i + 1]) and torch.equal(one.shift_g, full.shift_g[i:i + 1]), i
+    with pytest.raises(Exception):       # the bf16 form is the class-default width only
+        from so3x.models import ProtNet
+        small = ProtNet(dim=32, heads=2, t_depth=2, c_depth=4, precision="bf16").to(DEV)
+        with torch.no_grad():
+            small(to_dev(build(golden, "small")[1]), torch.zeros(5, dtype=torch.long, device=DEV))
