@@ -693,6 +693,85 @@ def planenet_leg(torch, reps=10):
     return out
 
 
+def protnet_leg(torch, complexes=4096, rec_len=198, lig_len=58, reps=10):
+    """BASELINE config 5's denoiser: ProtNet (reference models.py:212-319, prot_train.py:75-104) at 4096 complexes x 256 residues (a
+    198-residue receptor + a 58-residue ligand each: the BPTI docking set's typical split), class-default widths.  `forward`: the bf16
+    matrix-core form (what ProjectedSE3Diffusion's reverse chain runs per step).  `train_eval`: forward with stash + backward in the
+    exact-fp32 form (the form that has a backward) on 256 complexes, priced against the exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32:
+    256 flop / clk / CU = 157 TFLOP/s).  Algorithmic flops: every multiply-add of the Conv1d / Linear layers and of attention's two
+    products over each chain's OWN length, x 2 (backward: x 2 more; attention x 2.5: the exact form keeps its probabilities)."""
+    from so3x import backend as B
+    from so3x.models import ProtNet
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(1)
+
+    def make(n):
+        def chains(L):
+            res = torch.zeros(n * L, 21, device=dev)
+            res[torch.arange(n * L, device=dev), torch.randint(0, 21, (n * L,), device=dev, generator=g)] = 1.0
+            pos = torch.randn(n * L, 3, device=dev, generator=g) * 8.0
+            ang = B.quat_to_rmat(torch.randn(n * L, 4, device=dev, generator=g)).reshape(n * L, 9)
+            return (res, pos, ang), torch.arange(0, n * L + 1, L, device=dev, dtype=torch.int64)
+        rec, roff = chains(rec_len)
+        lig, loff = chains(lig_len)
+        return B.ProtBatch(rec, lig, roff, loff, max(rec_len, lig_len), [(rec_len, lig_len)] * n), torch.randint(0, 1000, (n,), device=dev, generator=g)
+
+    def flops(n, dim=64, t_depth=4, c_depth=3, ffn=2048):
+        lin = attn = 0
+        for L in (rec_len, lig_len):
+            conv = 21 * dim * 3 + (c_depth - 2) * dim * dim * 3 + dim * (dim - dim // 2 - dim // 4) * 3
+            siren = 3 * (dim // 2) + (dim // 2) ** 2 + 9 * (dim // 4) + (dim // 4) ** 2
+            lin += 2 * n * L * (conv + siren + t_depth * (4 * dim * dim + 2 * dim * ffn) + 2 * dim)
+            attn += 2 * n * L * t_depth * 2 * L * dim
+        return lin, attn
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    torch.manual_seed(0)
+    net = ProtNet(precision="bf16").to(dev).eval()
+    batch, t = make(complexes)
+    with torch.no_grad():
+        for _ in range(2):
+            out = net(batch, t)
+        ms = min(timed(lambda: net(batch, t), reps) for _ in range(3))
+    lin, attn = flops(complexes)
+    tf = (lin + attn) / ms / 1e9
+    res = {"forward": {"kernel": "so3x_protnet_fwd (bf16): k_embed, 4 x (k_attn, k_ffn), k_poolb, head", "bound": "mfma", "complexes": complexes,
+                       "residues": complexes * (rec_len + lig_len), "chain_lengths": [rec_len, lig_len], "ms": ms, "flop": lin + attn, "achieved": tf,
+                       "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_MFMA_PEAK_TFLOPS, "finite": bool(torch.isfinite(out.rot_g).all()),
+                       "timing": "HIP events around back-to-back module calls"}}
+    n_t = 256
+    tb, tt = make(n_t)
+    net.train()
+    dout = torch.randn(n_t, 6, device=dev)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        o = net(tb, tt)
+        (torch.cat((o.rot_g, o.shift_g), -1) * dout).sum().backward()
+    step()
+    ms_t = min(timed(step, 3) for _ in range(2))
+    lin_t, attn_t = flops(n_t)
+    fl_t = 3 * lin_t + 3.5 * attn_t
+    FP32_MFMA_PEAK = 157.0
+    res["train_eval"] = {"kernel": "so3x_protnet_fwd (stash) + so3x_protnet_bwd, exact-fp32 form", "bound": "mfma (fp32)", "complexes": n_t,
+                         "residues": n_t * (rec_len + lig_len), "ms": ms_t, "flop": fl_t, "achieved": fl_t / ms_t / 1e9, "peak": FP32_MFMA_PEAK,
+                         "unit": "TFLOP/s", "frac": fl_t / ms_t / 1e9 / FP32_MFMA_PEAK,
+                         "note": "the exact-fp32 form pads every chain to the longest one and keeps [chains][heads][L][L] probabilities: the parity "
+                                 "form, not a throughput form; a bf16 backward is not built",
+                         "timing": "HIP events; through autograd (zero_grad, forward, backward)"}
+    return res
+
+
 def secondary_rooflines(line):
     """The other kernels' rooflines in ONE place under `roofline` (the driver's record keeps `roofline` and `cpu_baseline` whole and
     reduces every other key to its name): per leg the kernel, its bound, achieved / peak / frac, the launch time and the
@@ -748,6 +827,12 @@ def secondary_rooflines(line):
                 sec["planenet." + k] = pick(v, "kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "flop", "clouds", "points", "ms_with_dropout_0.1")
     elif pn is not None:
         sec["planenet"] = pick(pn)
+    pt = line.get("protnet")
+    if isinstance(pt, dict) and "error" not in pt:
+        for k, v in pt.items():
+            sec["protnet." + k + " (BASELINE config 5's denoiser)"] = pick(v, "kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "flop", "complexes", "residues")
+    elif pt is not None:
+        sec["protnet"] = pick(pt)
     el = line.get("external_loop")
     if el is not None:
         sec["external_loop (one p_sample call per reverse step, so3_test.py:28-31)"] = pick(el, "sample_steps_per_s", "ms_per_call", "calls", "batch",
@@ -1058,6 +1143,10 @@ def main():
                 line["planenet"] = planenet_leg(torch)
             except Exception as e:
                 line["planenet"] = {"error": repr(e)}
+            try:
+                line["protnet"] = protnet_leg(torch)
+            except Exception as e:
+                line["protnet"] = {"error": repr(e)}
             try:
                 el_leg = external_loop_leg(torch, proc, x, T)
                 el_leg["vs_chain_kernel_rate"] = el_leg["sample_steps_per_s"] / line["roofline"]["sample_steps_per_s"]

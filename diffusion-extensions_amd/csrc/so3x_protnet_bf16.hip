@@ -54,6 +54,51 @@ __host__ __device__ inline int sigma16_inv(int f) { return 8 * ((f >> 2) & 1) + 
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float silu(float x) { return x * sigm(x); }
+// sin on the hardware unit (v_sin_f32 takes revolutions): |x| stays below ~40 in both SIRENs (weights ~0.14 x coordinates of tens of
+// Angstrom; unit frames), where x / (2 pi) keeps 1e-6 of a revolution -- well inside the bf16 features' own rounding
+__device__ __forceinline__ float fast_sin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)); }
+
+// max without the IEEE canonicalisation pass fmaxf costs (a second v_max_f32 per value): the median of (a, b, +inf), one v_med3_f32.
+// (Not inline asm: an asm statement reading an MFMA's result escapes the compiler's MFMA -> VALU wait-state insertion.)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
+// reductions over the four lanes (q, q + 16, q + 32, q + 48) that share a 16x16 accumulator column, on the vector ALU
+// (v_permlane16_swap / v_permlane32_swap: no LDS round trip as __shfl_xor's ds_bpermute takes); every one of the four gets the result
+__device__ __forceinline__ float quad_max(float v) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = vmax(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+  const uint32_t w = __builtin_bit_cast(uint32_t, v);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return vmax(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, a[1]);
+  const uint32_t w = __builtin_bit_cast(uint32_t, v);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+}
+__device__ __forceinline__ float half_sum(float v) {    // over lanes l, l ^ 32
+  const uint32_t w = __builtin_bit_cast(uint32_t, v);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+}
+// ReLU of eight bf16 values on their BITS: a negative float is a negative int16 (sign bit), so v_pk_max_i16 against zero is max(x, 0)
+// for two values per instruction (fmaxf on the fp32 accumulators costs two v_max_f32 per value under IEEE rules: canonicalise + max)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {          // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ uint32_t relu_pk(uint32_t w) {                  // one v_pk_max_i16
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+}
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: 2^x, flushes below 2^-126 (a zero weight)
 
 __device__ __forceinline__ void glds16(const void* src, const void* dst) {   // LDS-DMA: 16 B per lane to dst + 16 lane (dst wave-uniform)
   typedef __attribute__((address_space(3))) const char* lds_cp;
@@ -67,9 +112,10 @@ __device__ __forceinline__ void glds16(const void* src, const void* dst) {   // 
 //     qkv   [192][64] bf16: row i = in_proj row i (q rows and bias pre-scaled by log2(e) / sqrt(16)); K order = storage order
 //     wo    [64][64] bf16: K position 32 ks + 8 kq + j = head (2 ks + (j >> 2)), feature 4 kq + (j & 3)  (the order in which a lane
 //           of the 16x16x32 out-projection holds two heads' normalised outputs)
-//     ffn   32 chunks of [W1c 64 x 64 | W2c 64 x 64 | b1c 64 fp32] = 16,640 B: W1c row r = hidden unit 64 c + r, K order = storage
+//     ffn   32 chunks of [W1c 64 x 64 | W2c 64 x 64 | b1c 64 fp32, twice] = 16,896 B: W1c row r = hidden unit 64 c + r, K order = storage
 //           order; W2c row o = output feature o, K position = sigma-order of the chunk's hidden units; both with the 16-byte chunk
-//           q of row r stored at q ^ (r & 7) (swizzle: conflict-free ds_read_b128 of 32 rows x one chunk)
+//           q of row r stored at q ^ ((r >> 1) & 7) (swizzle: 16 consecutive rows x one chunk = 16 distinct 16-byte bank groups of the
+//           256-byte LDS line: conflict-free ds_read_b128)
 //     vec   fp32 [bqkv 192 | bo 64 | g1 64 | be1 64 | b2 64 | g2 64 | be2 64]   (natural feature order)
 //   conv layer i: 3 taps x [cout][KP] bf16 (KP = 32 for the 21 residue types, else 64; natural order) + bias fp32
 struct Img {
@@ -77,7 +123,7 @@ struct Img {
   size_t conv[8], convb[8], layers, total;
   int kp[8], cout[8];
 };
-constexpr size_t CHUNK_BYTES = 64 * 64 * 2 * 2 + 64 * 4;   // 16,640
+constexpr size_t CHUNK_BYTES = 64 * 64 * 2 * 2 + 2 * 64 * 4;   // 16,896 (the bias twice: see k_ffn)
 constexpr int NCHUNK = FF / 64;
 constexpr int VEC_FLOATS = 192 + 6 * 64;
 inline Img image_layout(const Dims& s) {
@@ -135,7 +181,7 @@ __global__ __launch_bounds__(256) void k_image(const float* __restrict__ prm, ch
     for (int64_t e = tid; e < (int64_t)NCHUNK * 64 * 64; e += nth) {
       const int c = (int)(e >> 12), r = (int)((e >> 6) & 63), p = (int)(e & 63);
       const int q = p >> 3, j = p & 7;
-      const int slot = ((q ^ (r & 7)) << 3) + j;                      // swizzled position inside the 128-byte row
+      const int slot = ((q ^ ((r >> 1) & 7)) << 3) + j;               // swizzled position inside the 128-byte row
       bf16* w1 = reinterpret_cast<bf16*>(ffn + (size_t)c * CHUNK_BYTES);
       bf16* w2 = w1 + 64 * 64;
       const int f = 16 * (p >> 4) + sigma16(p & 15);                  // W1: K = input feature in storage order
@@ -143,8 +189,10 @@ __global__ __launch_bounds__(256) void k_image(const float* __restrict__ prm, ch
       const int hu = 64 * c + 16 * (p >> 4) + sigma16(p & 15);        // W2: K = hidden unit of the chunk in accumulator order
       w2[r * 64 + slot] = (bf16)prm[lo.w2 + (int64_t)r * FF + hu];
     }
-    for (int64_t e = tid; e < FF; e += nth)
-      reinterpret_cast<float*>(ffn + (size_t)(e >> 6) * CHUNK_BYTES + 64 * 64 * 4)[e & 63] = prm[lo.b1 + e];
+    for (int64_t e = tid; e < 2 * FF; e += nth) {   // [b1c | b1c]: each token tile's accumulators are LOADED from their own copy
+      const int64_t hu = e >> 1;
+      reinterpret_cast<float*>(ffn + (size_t)(hu >> 6) * CHUNK_BYTES + 64 * 64 * 4)[64 * (e & 1) + (hu & 63)] = prm[lo.b1 + hu];
+    }
     float* vec = reinterpret_cast<float*>(slab + im.vec);
     for (int64_t e = tid; e < VEC_FLOATS; e += nth) {
       float v;
@@ -179,32 +227,106 @@ __global__ __launch_bounds__(256) void k_chains(const int64_t* __restrict__ roff
 // Conv1d(k 3, pad 1) = sum over 3 taps of W_tap x[l + tap - 1]: out^T[16 features x 16 residues] += W_tap[16 x 32] x_tap^T[32 x 16]
 // on v_mfma_f32_16x16x32_bf16, whose accumulator (lane = residue, 4 consecutive features) is written back as one 8-byte LDS store.
 constexpr int ERS = 72, RRS = 40;   // row strides in bf16 elements
-constexpr int EMB_LDS = ((MAXL + 2) * ERS * 2 + (MAXL + 2) * RRS) * 2 + (32 * 3 + 32 + 32 * 32 + 32 + 16 * 9 + 16 + 16 * 16 + 16) * 4;
+constexpr int EMB_LDS = (MAXL + 2) * ERS * 2 * 2 + (32 * 3 + 32 + 32 * 32 + 32 + 16 * 9 + 16 + 16 * 16 + 16) * 4;   // 80,768: two workgroups per CU
 
-__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ prm, const char* __restrict__ img, const POff po, const Img im, int Cd,
-                                               const float* __restrict__ rres, const float* __restrict__ rpos, const float* __restrict__ rang,
-                                               const float* __restrict__ lres, const float* __restrict__ lpos, const float* __restrict__ lang,
-                                               const int* __restrict__ start, const int* __restrict__ len, int64_t B, int64_t n_rec,
-                                               bf16* __restrict__ x) {
+// One convolution layer for this wave's tiles.  KS = k-steps of 32 input channels (1: the residue types, 2: 64 channels), FT = output
+// tiles of 16 channels (4, or 1 for the last layer's 16).  Per output tile the weights -- 3 taps x KS operand fragments, straight from
+// the image in L2 -- are loaded once into registers and reused over the wave's four residue tiles: no global access between the
+// MFMAs of a tile, only its own LDS operand reads.
+template <int KS, int FT, bool FIRST, bool LAST>
+__device__ __forceinline__ void conv_layer(const bf16* __restrict__ w, const float* __restrict__ bias, const bf16* in, int in_rs, bf16* out,
+                                           bf16* __restrict__ x, int row0, int tok0, int ntile, int L, int q, int g, float (&resid)[4][4][4]) {
+  constexpr int KP = 32 * KS, CO = 16 * FT;
+#pragma unroll
+  for (int ft = 0; ft < FT; ft++) {
+    bf16x8 wf[3][KS];
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) wf[tap][ks] = *reinterpret_cast<const bf16x8*>(w + ((size_t)tap * CO + 16 * ft + q) * KP + 32 * ks + 8 * g);
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bv[r] = bias[16 * ft + 4 * g + r];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (t >= ntile) continue;
+      const int tok = tok0 + 16 * t + q;
+      const bool ok = tok < L;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(in + (tok + tap) * in_rs + 32 * ks + 8 * g);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][ks], bfr, acc, 0, 0, 0);
+        }
+      // lane (residue q, g): channels 16 ft + 4 g + r
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[r] + bv[r];
+      if (LAST) {
+        // res_emb -> x[:, features 0 .. 15] (group 0), storage positions sigma^-1(4 g + r) = {0, 8, 4, 12}[g] + r
+        if (ok) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(x + (int64_t)(row0 + tok) * DM + sigma16_inv(4 * g)) = o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float a = silu(v[r]);
+          resid[t][ft][r] = FIRST ? a : resid[t][ft][r] + a;
+          v[r] = ok ? resid[t][ft][r] : 0.f;
+        }
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(out + (tok + 1) * ERS + 16 * ft + 4 * g) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm, const char* __restrict__ img, const POff po, const Img im, int Cd,
+                                                  const float* __restrict__ rres, const float* __restrict__ rpos, const float* __restrict__ rang,
+                                                  const float* __restrict__ lres, const float* __restrict__ lpos, const float* __restrict__ lang,
+                                                  const int* __restrict__ start, const int* __restrict__ len, int64_t B, int64_t n_rec,
+                                                  bf16* __restrict__ x) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* bufA = reinterpret_cast<bf16*>(smem);
   bf16* bufB = bufA + (MAXL + 2) * ERS;
-  bf16* resb = bufB + (MAXL + 2) * ERS;
-  float* sw = reinterpret_cast<float*>(resb + (MAXL + 2) * RRS);
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16* resb = bufB;                    // the residue one-hots live in bufB until layer 0 has read them (layer 1 is the first to write bufB)
+  float* sw = reinterpret_cast<float*>(bufB + (MAXL + 2) * ERS);
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile counts below are wave-uniform)
   const int L = len[s], row0 = start[s];
   const bool lig = s >= B;
   const int64_t src0 = lig ? row0 - n_rec : row0;
   const float* res = lig ? lres : rres;
   const float* pos = lig ? lpos : rpos;
   const float* ang = lig ? lang : rang;
-  // zero both halo buffers' halo rows and stage the residues (rows >= L zero)
-  for (int i = tid; i < (MAXL + 2) * RRS; i += 256) {
-    const int r = i / RRS, c = i - r * RRS;
+  const int Lr = (L + 15) & ~15;        // the tile-rounded length: layers write rows 1 .. Lr of their output buffer (masked beyond L)
+  // stage the residues: one row (residue l = r - 1) per thread, 21 floats -> 32 bf16 (+ 8 unused); halo rows and rows >= L zero.
+  // Of bufA only the rows a layer does not write but its successor reads must be zeroed: row 0 and row Lr + 1.
+  for (int r = tid; r < MAXL + 2; r += 256) {
     const int l = r - 1;
-    resb[i] = (bf16)((l >= 0 && l < L && c < RES) ? res[(src0 + l) * RES + c] : 0.f);
+    float v[24];
+#pragma unroll
+    for (int c = 0; c < 24; c++) v[c] = 0.f;
+    if (l >= 0 && l < L) {
+#pragma unroll
+      for (int c = 0; c < RES; c++) v[c] = res[(src0 + l) * RES + c];
+    }
+    bf16x8 o[4];
+#pragma unroll
+    for (int c = 0; c < 24; c++) o[c >> 3][c & 7] = (bf16)v[c];
+#pragma unroll
+    for (int c = 0; c < 8; c++) o[3][c] = (bf16)0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) *reinterpret_cast<bf16x8*>(resb + r * RRS + 8 * k) = o[k];
   }
-  for (int i = tid; i < (MAXL + 2) * ERS; i += 256) bufA[i] = bufB[i] = (bf16)0.f;
+  if (tid < 18) {     // 2 rows x 144 bytes
+    bf16x8 z;
+#pragma unroll
+    for (int c = 0; c < 8; c++) z[c] = (bf16)0.f;
+    *reinterpret_cast<bf16x8*>(bufA + (tid < 9 ? 0 : (Lr + 1)) * ERS + 8 * (tid % 9)) = z;
+  }
   // SIREN weights: [wpp 96 | bpp 32 | wpps 1024 | bpps 32 | wap 144 | bap 16 | waps 256 | baps 16]
   for (int i = tid; i < 96; i += 256) sw[i] = prm[po.wpp + i];
   for (int i = tid; i < 32; i += 256) { sw[96 + i] = prm[po.bpp + i]; sw[1152 + i] = prm[po.bpps + i]; }
@@ -216,63 +338,28 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ prm, co
   const int q = lane & 15, g = lane >> 4;
   const int tok0 = wave * 64;          // this wave's 64 residues: 4 tiles of 16
   const int ntile = L <= tok0 ? 0 : ((L - tok0 + 15) >> 4) < 4 ? ((L - tok0 + 15) >> 4) : 4;
-  float resid[4][4][4];                // [tile][feature tile][r]: the ResLayers' running x (fp32)
+  float resid[4][4][4];                // [tile][channel tile][r]: the ResLayers' running x (fp32)
+  bf16* cur = bufA;                    // layer i >= 1 reads `cur`, writes the other buffer
+  conv_layer<1, 4, true, false>(reinterpret_cast<const bf16*>(img + im.conv[0]), reinterpret_cast<const float*>(img + im.convb[0]), resb, RRS, bufA, x,
+                                row0, tok0, ntile, L, q, g, resid);
+  __syncthreads();
+  // bufB held the residues: now that layer 0 has read them, zero ITS two rows that no layer writes and layer 2 reads (any thread may
+  // do this while layer 1 runs: the next barrier orders it before layer 2)
+  if (tid < 18) {
+    bf16x8 z;
 #pragma unroll
-  for (int t = 0; t < 4; t++)
-#pragma unroll
-    for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) resid[t][ft][r] = 0.f;
-  const bf16* in = resb;
-  int in_rs = RRS;
-  bf16* out = bufA;
-  for (int i = 0; i < Cd; i++) {
-    const int kp = im.kp[i], cout = im.cout[i], ksteps = kp >> 5, ftiles = cout >> 4;
-    const bf16* w = reinterpret_cast<const bf16*>(img + im.conv[i]);
-    const float* bias = reinterpret_cast<const float*>(img + im.convb[i]);
-    const bool last = i == Cd - 1;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      if (t >= ntile) continue;
-      const int tok = tok0 + 16 * t + q;
-#pragma unroll
-      for (int ft = 0; ft < 4; ft++) {
-        if (ft >= ftiles) continue;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int tap = 0; tap < 3; tap++)
-          for (int ks = 0; ks < ksteps; ks++) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w + ((size_t)tap * cout + 16 * ft + q) * kp + 32 * ks + 8 * g);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(in + (tok + tap) * in_rs + 32 * ks + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-          }
-        // lane (residue q, g): features 16 ft + 4 g + r
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = acc[r] + bias[16 * ft + 4 * g + r];
-        const bool ok = tok < L;
-        if (last) {
-          // res_emb -> x[:, features 0 .. 15] (group 0), storage positions sigma^-1(4 g + r) = {0, 8, 4, 12}[g] + r
-          if (ok) {
-            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(x + (int64_t)(row0 + tok) * DM + sigma16_inv(4 * g)) = o;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float a = silu(v[r]);
-            resid[t][ft][r] = i == 0 ? a : resid[t][ft][r] + a;
-            v[r] = ok ? resid[t][ft][r] : 0.f;
-          }
-          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *reinterpret_cast<bf16x4*>(out + (tok + 1) * ERS + 16 * ft + 4 * g) = o;
-        }
-      }
-    }
-    __syncthreads();
-    in = out;
-    in_rs = ERS;
-    out = out == bufA ? bufB : bufA;
+    for (int c = 0; c < 8; c++) z[c] = (bf16)0.f;
+    *reinterpret_cast<bf16x8*>(bufB + (tid < 9 ? 0 : (Lr + 1)) * ERS + 8 * (tid % 9)) = z;
   }
+  for (int i = 1; i < Cd - 1; i++) {
+    bf16* nxt = cur == bufA ? bufB : bufA;
+    conv_layer<2, 4, false, false>(reinterpret_cast<const bf16*>(img + im.conv[i]), reinterpret_cast<const float*>(img + im.convb[i]), cur, ERS, nxt, x,
+                                   row0, tok0, ntile, L, q, g, resid);
+    __syncthreads();
+    cur = nxt;
+  }
+  conv_layer<2, 1, false, true>(reinterpret_cast<const bf16*>(img + im.conv[Cd - 1]), reinterpret_cast<const float*>(img + im.convb[Cd - 1]), cur, ERS,
+                                nullptr, x, row0, tok0, ntile, L, q, g, resid);
   // SIRENs, one residue per thread: pos_emb -> features 16 .. 47 (groups 1, 2), ang_emb -> features 48 .. 63 (group 3)
   const int tok = tid;
   if (tok < L) {
@@ -280,7 +367,7 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ prm, co
     const float* aa = ang + (src0 + tok) * 9;
     float sn[32];
 #pragma unroll
-    for (int j = 0; j < 32; j++) sn[j] = sinf(fmaf(pp[2], sw[3 * j + 2], fmaf(pp[1], sw[3 * j + 1], fmaf(pp[0], sw[3 * j], sw[96 + j]))));
+    for (int j = 0; j < 32; j++) sn[j] = fast_sin(fmaf(pp[2], sw[3 * j + 2], fmaf(pp[1], sw[3 * j + 1], fmaf(pp[0], sw[3 * j], sw[96 + j]))));
     bf16* xo = x + (int64_t)(row0 + tok) * DM;
     for (int grp = 0; grp < 2; grp++) {
       float o[16];
@@ -304,7 +391,7 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ prm, co
       float a = sw[1328 + j];
 #pragma unroll
       for (int c = 0; c < 9; c++) a = fmaf(aa[c], sw[1184 + 9 * j + c], a);
-      sa[j] = sinf(a);
+      sa[j] = fast_sin(a);
     }
     float o[16];
 #pragma unroll
@@ -334,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Ks = reinterpret_cast<bf16*>(smem);
   bf16* Vt = Ks + MAXL * KRS;
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile counts below are wave-uniform)
   const int L = len[s], row0 = start[s];
   const int q = lane & 15, g = lane >> 4;
   const bf16* wqkv = reinterpret_cast<const bf16*>(slab + im.qkv);
@@ -403,14 +490,17 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
 #pragma unroll
       for (int r = 0; r < 4; r++) qf[t][r] = (bf16)(aq[r] + vec[16 * h + 4 * g + r]);
     }
-    f32x4 oacc[4];
-    float mrun[4], lrun[4];
+    f32x4 oacc[4], lacc[4];   // lacc: the softmax denominators, on the matrix pipe too: ones[16 x 32 keys] P^T -> every row = sum over the keys
+    float mrun[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       mrun[t] = -INFINITY;
-      lrun[t] = 0.f;
     }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = (bf16)1.f;
     for (int c = 0; c < nchunk; c++) {
       const int key0 = 32 * c;
       // K_h rows of the chunk's two 16-key tiles (A operands: lane (key q, kq = g): features 16 h + 4 g + j) and V_h^T (A operand of
@@ -422,47 +512,46 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
       bf16x8 vf;
 #pragma unroll
       for (int j = 0; j < 4; j++) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
-      const bool tail = key0 + 32 > L;
+      // the key-padding mask as the score products' C operand: 0 at the chain's keys, -inf past its end (one pair per chunk, shared
+      // by the four query tiles)
+      f32x4 c0, c1;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        if (t >= ntile) continue;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-        s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), s0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
-        s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), s1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
-        if (tail) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            if (key0 + 4 * g + r >= L) s0[r] = -INFINITY;
-            if (key0 + 16 + 4 * g + r >= L) s1[r] = -INFINITY;
-          }
-        }
-        float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mnew = fmaxf(mrun[t], mx);          // (a chunk always holds at least one real key: mnew is finite)
-        const float resc = exp2f(mrun[t] - mnew);
+      for (int r = 0; r < 4; r++) {
+        c0[r] = key0 + 4 * g + r >= L ? -INFINITY : 0.f;
+        c1[r] = key0 + 16 + 4 * g + r >= L ? -INFINITY : 0.f;
+      }
+      auto unit = [&](int t) __attribute__((always_inline)) {
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), c0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), c1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
+        const float mx = quad_max(vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax(s1[2], s1[3])));
+        const float mnew = vmax(mrun[t], mx);           // (a chunk always holds at least one real key: mnew is finite)
+        const float resc = ex2(mrun[t] - mnew);
         mrun[t] = mnew;
-        bf16x8 pf;
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float p0 = exp2f(s0[r] - mnew), p1 = exp2f(s1[r] - mnew);
-          ps += p0 + p1;
-          pf[r] = (bf16)p0;
-          pf[4 + r] = (bf16)p1;
-        }
-        lrun[t] = lrun[t] * resc + ps;
-#pragma unroll
-        for (int r = 0; r < 4; r++) oacc[t][r] *= resc;
-        // O_h^T[feature][query] += V_h^T[feature][32 keys] P^T[32 keys][query]: lane (query q, g): head features 4 g + r
+        const f32x4 d0 = s0 - mnew, d1 = s1 - mnew;     // (vector form: two v_pk_add_f32 each)
+        u32x4 pw;
+        pw[0] = pack_bf16(ex2(d0[0]), ex2(d0[1]));
+        pw[1] = pack_bf16(ex2(d0[2]), ex2(d0[3]));
+        pw[2] = pack_bf16(ex2(d1[0]), ex2(d1[1]));
+        pw[3] = pack_bf16(ex2(d1[2]), ex2(d1[3]));
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        oacc[t] *= resc;
+        lacc[t] *= resc;
+        // O_h^T[feature][query] += V_h^T[feature][32 keys] P^T[32 keys][query]: lane (query q, g): head features 4 g + r; the row sums likewise
         oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[t], 0, 0, 0);
+        lacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc[t], 0, 0, 0);
+      };
+      if (ntile == 4) {      // (the common case, branch-free: the four tiles' chains interleave)
+#pragma unroll
+        for (int t = 0; t < 4; t++) unit(t);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          if (t < ntile) unit(t);
       }
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      float l = lrun[t];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
+      const float l = lacc[t][0];
       const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; r++) ob[t][h][r] = (bf16)(oacc[t][r] * inv);
@@ -497,8 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
         sum += v[ft][r];
       }
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = quad_sum(sum);
     const float mean = sum * (1.f / 64.f);
     float var = 0.f;
 #pragma unroll
@@ -508,8 +596,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
         const float u = v[ft][r] - mean;
         var = fmaf(u, u, var);
       }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
+    var = quad_sum(var);
     const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + 1e-5f);
     if (ok) {
       bf16* yo = y + (int64_t)(row0 + tok) * DM;
@@ -529,25 +616,26 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
 
 // ------------------------------------------------------------------------------------------------ k_ffn
 // x1 -> LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2), 512 residues per workgroup iteration (8 waves x 64), persistent workgroups.
-constexpr int FFN_LDS = 2 * (int)CHUNK_BYTES;
+constexpr int FFN_NBUF = 3;        // chunk c + 2 is in flight while chunk c is multiplied
+constexpr int FFN_LDS = FFN_NBUF * (int)CHUNK_BYTES;
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int qchunk) {   // the swizzled image's 16-byte chunk `qchunk` of `row`
-  return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((qchunk ^ (row & 7)) << 4));
+  return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((qchunk ^ ((row >> 1) & 7)) << 4));
 }
 
 __global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* __restrict__ y, const char* __restrict__ slab, const Img im, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c32 = lane & 31, hh = lane >> 5;
   const char* ffn = slab + im.ffn;
   const float* vec = reinterpret_cast<const float*>(slab + im.vec);
   const int64_t nblocks = (n + 511) / 512;
-  auto dma = [&](int chunk, int buf) {     // 16,640 bytes = 1040 x 16: lanes 0 .. 511 twice + 16 lanes of wave 0
+  auto dma = [&](int chunk, int buf) {     // 16,896 bytes = 1056 x 16: lanes 0 .. 511 twice + 32 lanes of wave 0
     const char* src = ffn + (size_t)chunk * CHUNK_BYTES;
     char* dst = smem + buf * CHUNK_BYTES;
     glds16(src + tid * 16, dst + wave * 1024);
     glds16(src + 8192 + tid * 16, dst + 8192 + wave * 1024);
-    if (wave == 0 && lane < 16) glds16(src + 16384 + lane * 16, dst + 16384);
+    if (wave == 0 && lane < 32) glds16(src + 16384 + lane * 16, dst + 16384);
   };
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t tok_base = blk * 512 + wave * 64;
@@ -572,13 +660,23 @@ __global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* 
       for (int ot = 0; ot < 2; ot++)
 #pragma unroll
         for (int r = 0; r < 16; r++) yacc[tt][ot][r] = 0.f;
-    __syncthreads();        // every wave is done with both buffers of the previous block
+    __syncthreads();        // every wave is done with the previous block's buffers
     dma(0, 0);
+    dma(1, 1);
+    int buf = 0;
+#pragma unroll 1
     for (int c = 0; c < NCHUNK; c++) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();      // chunk c has landed for everybody; everybody is done with chunk c - 1's buffer
-      if (c + 1 < NCHUNK) dma(c + 1, (c + 1) & 1);
-      const char* w1 = smem + (c & 1) * CHUNK_BYTES;
+      // chunk c has landed when at most chunk c + 1's requests (2 per wave, 3 for wave 0) are still out: LDS-DMA completes in order
+      if (c + 1 < NCHUNK) {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();      // ... for everybody; and everybody is done with chunk c - 1, whose buffer chunk c + 2 takes
+      if (c + 2 < NCHUNK) dma(c + 2, buf + 2 >= FFN_NBUF ? buf + 2 - FFN_NBUF : buf + 2);
+      const char* w1 = smem + buf * CHUNK_BYTES;
+      buf = buf + 1 == FFN_NBUF ? 0 : buf + 1;
       const char* w2 = w1 + 64 * 64 * 2;
       const float* b1 = reinterpret_cast<const float*>(w2 + 64 * 64 * 2);
 #pragma unroll
@@ -586,24 +684,28 @@ __global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* 
         bf16x8 a1[4];
 #pragma unroll
         for (int gi = 0; gi < 4; gi++) a1[gi] = lds_frag(w1, 32 * ht + c32, 2 * gi + hh);
-        f32x16 bias;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1 + 32 * ht + 8 * r4 + 4 * hh);
-#pragma unroll
-          for (int r = 0; r < 4; r++) bias[4 * r4 + r] = b4[r];
-        }
         bf16x8 hb[2][2];
 #pragma unroll
         for (int tt = 0; tt < 2; tt++) {
-          f32x16 h = bias;
+          // the accumulators start as the bias, read from LDS per token tile (two copies in the image: one tile's read cannot be
+          // merged with the other's into a register copy -- 16 v_mov per tile were a quarter of the loop's vector instructions)
+          f32x16 h;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1 + 64 * tt + 32 * ht + 8 * r4 + 4 * hh);
+#pragma unroll
+            for (int r = 0; r < 4; r++) h[4 * r4 + r] = b4[r];
+          }
 #pragma unroll
           for (int gi = 0; gi < 4; gi++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[gi], xb[tt][gi], h, 0, 0, 0);
+          u32x4 t0, t1;
 #pragma unroll
-          for (int r = 0; r < 8; r++) {
-            hb[tt][0][r] = (bf16)fmaxf(h[r], 0.f);
-            hb[tt][1][r] = (bf16)fmaxf(h[8 + r], 0.f);
+          for (int r = 0; r < 4; r++) {
+            t0[r] = relu_pk(pack_bf16(h[2 * r], h[2 * r + 1]));
+            t1[r] = relu_pk(pack_bf16(h[8 + 2 * r], h[9 + 2 * r]));
           }
+          hb[tt][0] = __builtin_bit_cast(bf16x8, t0);
+          hb[tt][1] = __builtin_bit_cast(bf16x8, t1);
         }
 #pragma unroll
         for (int ot = 0; ot < 2; ot++)
@@ -630,7 +732,7 @@ __global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* 
           yacc[tt][ot][r] = v;
           sum += v;
         }
-      sum += __shfl_xor(sum, 32);
+      sum = half_sum(sum);
       const float mean = sum * (1.f / 64.f);
       float var = 0.f;
 #pragma unroll
@@ -640,7 +742,7 @@ __global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* 
           const float u = yacc[tt][ot][r] - mean;
           var = fmaf(u, u, var);
         }
-      var += __shfl_xor(var, 32);
+      var = half_sum(var);
       const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + 1e-5f);
       if (tok < n) {
 #pragma unroll
@@ -672,12 +774,18 @@ __global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const
   float (*pp)[3] = reinterpret_cast<float (*)[3]>(wp + MAXL);
   float (*part)[64] = reinterpret_cast<float (*)[64]>(wp + MAXL + MAXL * 3);
   float (*tail)[8] = reinterpret_cast<float (*)[8]>(wp + MAXL + MAXL * 3 + 4 * 64);
+  float* cst = wp + MAXL + MAXL * 3 + 4 * 64 + 4 * 8;      // [gamma | beta | wpool | wppool] in STORAGE order (position p: feature sigma)
   const int s = blockIdx.x, tid = threadIdx.x;
   const int L = len[s], row0 = start[s];
   const bool lig = s >= B;
   const Pool q = lig ? po.lig : po.rec;
   const float* pos = lig ? lpos : rpos;
   const int64_t src0 = lig ? row0 - n_rec : row0;
+  {
+    const int p = tid & 63, f = 16 * (p >> 4) + sigma16(p & 15), which = tid >> 6;
+    cst[tid] = prm[(which == 0 ? po.rec_tf.gF : which == 1 ? po.rec_tf.bF : which == 2 ? q.wpool : q.wppool) + f];
+  }
+  __syncthreads();
   if (tid < L) {
     const bf16* xr = x + (int64_t)(row0 + tid) * DM;
     float v[64];
@@ -687,9 +795,8 @@ __global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const
       const bf16x8 u = *reinterpret_cast<const bf16x8*>(xr + 8 * gi);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const int p = 8 * gi + j;
-        v[p] = (float)u[j];
-        sum += v[p];
+        v[8 * gi + j] = (float)u[j];
+        sum += v[8 * gi + j];
       }
     }
     const float mean = sum * (1.f / 64.f);
@@ -700,12 +807,11 @@ __global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const
     float a = prm[q.bpool], b = prm[q.bppool];
 #pragma unroll
     for (int p = 0; p < 64; p++) {
-      const int f = 16 * (p >> 4) + sigma16(p & 15);
-      const float u = (v[p] - mean) * rstd * prm[po.rec_tf.gF + f] + prm[po.rec_tf.bF + f];
-      xn[tid][f] = u;
-      a = fmaf(u, prm[q.wpool + f], a);
-      b = fmaf(u, prm[q.wppool + f], b);
-      if (enc_dbg) enc_dbg[(int64_t)(row0 + tid) * DM + f] = u;
+      const float u = (v[p] - mean) * rstd * cst[p] + cst[64 + p];
+      xn[tid][p] = u;                                  // (storage order: the column sums below undo it when they write xs)
+      a = fmaf(u, cst[128 + p], a);
+      b = fmaf(u, cst[192 + p], b);
+      if (enc_dbg) enc_dbg[(int64_t)(row0 + tid) * DM + 16 * (p >> 4) + sigma16(p & 15)] = u;
     }
     we[tid] = sigm(a);
     wp[tid] = sigm(b);
@@ -737,7 +843,7 @@ __global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const
   __syncthreads();
   const float tse = (tail[0][0] + tail[1][0]) + (tail[2][0] + tail[3][0]), tsp = (tail[0][1] + tail[1][1]) + (tail[2][1] + tail[3][1]);
   const float ce = fmaxf(tse, 1e-6f), cp = fmaxf(tsp, 1e-6f);
-  if (tid < 64) xs[(int64_t)s * DM + tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / ce;
+  if (tid < 64) xs[(int64_t)s * DM + 16 * (tid >> 4) + sigma16(tid & 15)] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / ce;
   if (tid < 3) {
     const int64_t b = lig ? s - B : s;
     const int j = 2 + tid;
@@ -788,7 +894,7 @@ static WsB carve_ws(const Dims& s, int64_t n, void* mem) {
 }
 size_t bf16_workspace_bytes(const Dims& s, int64_t n_rec, int64_t n_lig) { return carve_ws(s, n_rec + n_lig, nullptr).bytes; }
 
-constexpr int POOL_LDS = (MAXL * 65 + MAXL * 2 + MAXL * 3 + 4 * 64 + 4 * 8) * 4;
+constexpr int POOL_LDS = (MAXL * 65 + MAXL * 2 + MAXL * 3 + 4 * 64 + 4 * 8 + 256) * 4;
 static PerDevice g_embed, g_attn, g_ffn, g_pool;
 
 int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* rres, const float* rpos, const float* rang, const int64_t* roff,
