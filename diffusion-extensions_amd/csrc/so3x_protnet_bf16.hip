@@ -8,7 +8,7 @@
 //   k_attn  one workgroup per CHAIN (<= 256 residues: 4 waves x 64 queries): QKV projection, the chain's K and V^T in LDS (69 KB),
 //           softmax(Q K^T) V per head with the scores in registers (16-wide heads: 16x16x16 / 16x16x32 MFMAs whose accumulator
 //           layout IS the next product's operand layout), out-projection, residual, LayerNorm 1.
-//   k_ffn   token-parallel, chain-agnostic (84 % of the network's flops): 512-token blocks, each wave keeps its 64 tokens' input as
+//   k_ffn   token-parallel, chain-agnostic (84 % of the network's flops): 256-token blocks, each wave keeps its 64 tokens' input as
 //           MFMA operands in registers, the 2 x 256 KB of W1 / W2 stream through LDS in 16 KB chunks by LDS-DMA (double-buffered,
 //           swizzled image: conflict-free ds_read_b128), the 2048 hidden activations never leave registers (ReLU'd accumulators
 //           of the first product are the second product's B operand), residual, LayerNorm 2.
@@ -120,7 +120,7 @@ __device__ __forceinline__ void glds16(const void* src, const void* dst) {   // 
 //   conv layer i: 3 taps x [cout][KP] bf16 (KP = 32 for the 21 residue types, else 64; natural order) + bias fp32
 struct Img {
   size_t qkv, wo, ffn, vec, per_layer;   // byte offsets inside a layer's slab
-  size_t conv[8], convb[8], layers, total;
+  size_t conv[8], convb[8], sir, layers, total;   // sir: [post_scale of pos_emb 32 x 32 | of ang_emb 16 x 16] bf16, natural order
   int kp[8], cout[8];
 };
 constexpr size_t CHUNK_BYTES = 64 * 64 * 2 * 2 + 2 * 64 * 4;   // 16,896 (the bias twice: see k_ffn)
@@ -136,6 +136,7 @@ inline Img image_layout(const Dims& s) {
     im.convb[i] = p; p += plane::up((size_t)im.cout[i] * 4);
     p = plane::up(p);
   }
+  im.sir = p; p += plane::up((32 * 32 + 16 * 16) * 2);
   im.layers = p;
   size_t q = 0;
   im.qkv = q; q += 192 * 64 * 2;
@@ -159,6 +160,11 @@ __global__ __launch_bounds__(256) void k_image(const float* __restrict__ prm, ch
     }
     float* b = reinterpret_cast<float*>(img + im.convb[i]);
     for (int64_t e = tid; e < cout; e += nth) b[e] = prm[po.cb[i] + e];
+  }
+  {
+    bf16* sir = reinterpret_cast<bf16*>(img + im.sir);
+    for (int64_t e = tid; e < 32 * 32; e += nth) sir[e] = (bf16)prm[po.wpps + e];
+    for (int64_t e = tid; e < 16 * 16; e += nth) sir[1024 + e] = (bf16)prm[po.waps + e];
   }
   const float qs = LOG2E * 0.25f;   // 1 / sqrt(16), and exp2 instead of exp in the softmax
   for (int l = 0; l < T; l++) {
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void k_chains(const int64_t* __restrict__ roff
 // Conv1d(k 3, pad 1) = sum over 3 taps of W_tap x[l + tap - 1]: out^T[16 features x 16 residues] += W_tap[16 x 32] x_tap^T[32 x 16]
 // on v_mfma_f32_16x16x32_bf16, whose accumulator (lane = residue, 4 consecutive features) is written back as one 8-byte LDS store.
 constexpr int ERS = 72, RRS = 40;   // row strides in bf16 elements
-constexpr int EMB_LDS = (MAXL + 2) * ERS * 2 * 2 + (32 * 3 + 32 + 32 * 32 + 32 + 16 * 9 + 16 + 16 * 16 + 16) * 4;   // 80,768: two workgroups per CU
+constexpr int EMB_LDS = (MAXL + 2) * ERS * 2 * 2;   // 74,304: two workgroups per CU
 
 // One convolution layer for this wave's tiles.  KS = k-steps of 32 input channels (1: the residue types, 2: 64 channels), FT = output
 // tiles of 16 channels (4, or 1 for the last layer's 16).  Per output tile the weights -- 3 taps x KS operand fragments, straight from
@@ -237,16 +243,30 @@ template <int KS, int FT, bool FIRST, bool LAST>
 __device__ __forceinline__ void conv_layer(const bf16* __restrict__ w, const float* __restrict__ bias, const bf16* in, int in_rs, bf16* out,
                                            bf16* __restrict__ x, int row0, int tok0, int ntile, int L, int q, int g, float (&resid)[4][4][4]) {
   constexpr int KP = 32 * KS, CO = 16 * FT;
-#pragma unroll
-  for (int ft = 0; ft < FT; ft++) {
-    bf16x8 wf[3][KS];
+  // the weights of output tile ft + 1 are requested (L2, ~1 us away) before tile ft is multiplied: one round trip per layer is
+  // exposed instead of one per tile
+  bf16x8 wn[3][KS];
+  float bn[4];
+  auto fetch = [&](int ft) __attribute__((always_inline)) {
 #pragma unroll
     for (int tap = 0; tap < 3; tap++)
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) wf[tap][ks] = *reinterpret_cast<const bf16x8*>(w + ((size_t)tap * CO + 16 * ft + q) * KP + 32 * ks + 8 * g);
+      for (int ks = 0; ks < KS; ks++) wn[tap][ks] = *reinterpret_cast<const bf16x8*>(w + ((size_t)tap * CO + 16 * ft + q) * KP + 32 * ks + 8 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) bn[r] = bias[16 * ft + 4 * g + r];
+  };
+  fetch(0);
+#pragma unroll
+  for (int ft = 0; ft < FT; ft++) {
+    bf16x8 wf[3][KS];
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) bv[r] = bias[16 * ft + 4 * g + r];
+    for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) wf[tap][ks] = wn[tap][ks];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bv[r] = bn[r];
+    if (ft + 1 < FT) fetch(ft + 1);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       if (t >= ntile) continue;
@@ -293,7 +313,6 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
   bf16* bufA = reinterpret_cast<bf16*>(smem);
   bf16* bufB = bufA + (MAXL + 2) * ERS;
   bf16* resb = bufB;                    // the residue one-hots live in bufB until layer 0 has read them (layer 1 is the first to write bufB)
-  float* sw = reinterpret_cast<float*>(bufB + (MAXL + 2) * ERS);
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile counts below are wave-uniform)
   const int L = len[s], row0 = start[s];
   const bool lig = s >= B;
@@ -327,13 +346,6 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
     for (int c = 0; c < 8; c++) z[c] = (bf16)0.f;
     *reinterpret_cast<bf16x8*>(bufA + (tid < 9 ? 0 : (Lr + 1)) * ERS + 8 * (tid % 9)) = z;
   }
-  // SIREN weights: [wpp 96 | bpp 32 | wpps 1024 | bpps 32 | wap 144 | bap 16 | waps 256 | baps 16]
-  for (int i = tid; i < 96; i += 256) sw[i] = prm[po.wpp + i];
-  for (int i = tid; i < 32; i += 256) { sw[96 + i] = prm[po.bpp + i]; sw[1152 + i] = prm[po.bpps + i]; }
-  for (int i = tid; i < 1024; i += 256) sw[128 + i] = prm[po.wpps + i];
-  for (int i = tid; i < 144; i += 256) sw[1184 + i] = prm[po.wap + i];
-  for (int i = tid; i < 16; i += 256) { sw[1328 + i] = prm[po.bap + i]; sw[1600 + i] = prm[po.baps + i]; }
-  for (int i = tid; i < 256; i += 256) sw[1344 + i] = prm[po.waps + i];
   __syncthreads();
   const int q = lane & 15, g = lane >> 4;
   const int tok0 = wave * 64;          // this wave's 64 residues: 4 tiles of 16
@@ -360,53 +372,75 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
   }
   conv_layer<2, 1, false, true>(reinterpret_cast<const bf16*>(img + im.conv[Cd - 1]), reinterpret_cast<const float*>(img + im.convb[Cd - 1]), cur, ERS,
                                 nullptr, x, row0, tok0, ntile, L, q, g, resid);
-  // SIRENs, one residue per thread: pos_emb -> features 16 .. 47 (groups 1, 2), ang_emb -> features 48 .. 63 (group 3)
-  const int tok = tid;
-  if (tok < L) {
-    const float* pp = pos + (src0 + tok) * 3;
-    const float* aa = ang + (src0 + tok) * 9;
-    float sn[32];
+  // SIRENs (models.py:50-72): emb = post_scale(sin(positional(v))).  Per 16-residue tile the lane (residue q, g) evaluates 8 of the 32
+  // position sines (k = 8 g ..) and 4 of the 16 frame sines (k = 4 g ..) -- exactly its B-operand fragment of the post_scale product
+  // out^T[16 features x 16 residues] = W[16 x K] sin^T[K x 16] (16x16x32 for the positions, 16x16x16 for the frames); the products'
+  // accumulators (4 consecutive features of a residue) go out as 8-byte stores: pos_emb -> features 16 .. 47, ang_emb -> 48 .. 63.
+  {
+    float wp[8][3], bp8[8], wa[4][9], ba4[4];
 #pragma unroll
-    for (int j = 0; j < 32; j++) sn[j] = fast_sin(fmaf(pp[2], sw[3 * j + 2], fmaf(pp[1], sw[3 * j + 1], fmaf(pp[0], sw[3 * j], sw[96 + j]))));
-    bf16* xo = x + (int64_t)(row0 + tok) * DM;
-    for (int grp = 0; grp < 2; grp++) {
-      float o[16];
+    for (int j = 0; j < 8; j++) {
 #pragma unroll
-      for (int p = 0; p < 16; p++) {
-        const int f = 16 * grp + sigma16(p);
-        float a = sw[1152 + f];
+      for (int c = 0; c < 3; c++) wp[j][c] = prm[po.wpp + 3 * (8 * g + j) + c];
+      bp8[j] = prm[po.bpp + 8 * g + j];
+    }
 #pragma unroll
-        for (int j = 0; j < 32; j++) a = fmaf(sn[j], sw[128 + f * 32 + j], a);
-        o[p] = a;
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int c = 0; c < 9; c++) wa[j][c] = prm[po.wap + 9 * (4 * g + j) + c];
+      ba4[j] = prm[po.bap + 4 * g + j];
+    }
+    const bf16* sir = reinterpret_cast<const bf16*>(img + im.sir);
+    const bf16x8 wps0 = *reinterpret_cast<const bf16x8*>(sir + (size_t)q * 32 + 8 * g);
+    const bf16x8 wps1 = *reinterpret_cast<const bf16x8*>(sir + (size_t)(16 + q) * 32 + 8 * g);
+    const s16x4 was = *reinterpret_cast<const s16x4*>(sir + 1024 + (size_t)q * 16 + 4 * g);
+    float bo[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      bo[0][r] = prm[po.bpps + 4 * g + r];
+      bo[1][r] = prm[po.bpps + 16 + 4 * g + r];
+      bo[2][r] = prm[po.baps + 4 * g + r];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (t >= ntile) continue;
+      const int tok = tok0 + 16 * t + q;
+      const bool ok = tok < L;
+      const float* pp = pos + (src0 + (ok ? tok : 0)) * 3;
+      const float* aa = ang + (src0 + (ok ? tok : 0)) * 9;
+      const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+      float av[9];
+#pragma unroll
+      for (int c = 0; c < 9; c++) av[c] = aa[c];
+      u32x4 sp;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        sp[j] = pack_bf16(fast_sin(fmaf(p2, wp[2 * j][2], fmaf(p1, wp[2 * j][1], fmaf(p0, wp[2 * j][0], bp8[2 * j])))),
+                          fast_sin(fmaf(p2, wp[2 * j + 1][2], fmaf(p1, wp[2 * j + 1][1], fmaf(p0, wp[2 * j + 1][0], bp8[2 * j + 1])))));
+      float sa[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float a = ba4[j];
+#pragma unroll
+        for (int c = 0; c < 9; c++) a = fmaf(av[c], wa[j][c], a);
+        sa[j] = fast_sin(a);
       }
-      bf16x8 o0, o1;
-#pragma unroll
-      for (int p = 0; p < 8; p++) { o0[p] = (bf16)o[p]; o1[p] = (bf16)o[8 + p]; }
-      *reinterpret_cast<bf16x8*>(xo + 16 * (1 + grp)) = o0;
-      *reinterpret_cast<bf16x8*>(xo + 16 * (1 + grp) + 8) = o1;
+      const uint32_t sa01 = pack_bf16(sa[0], sa[1]), sa23 = pack_bf16(sa[2], sa[3]);
+      const bf16x8 spf = __builtin_bit_cast(bf16x8, sp);
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const s16x4 saf = __builtin_bit_cast(s16x4, u32x2{sa01, sa23});
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wps0, spf, z, 0, 0, 0);
+      const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wps1, spf, z, 0, 0, 0);
+      const f32x4 e2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(was, saf, z, 0, 0, 0);
+      if (ok) {
+        bf16* xo = x + (int64_t)(row0 + tok) * DM + sigma16_inv(4 * g);
+        typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2s*>(xo + 16) = u32x2s{pack_bf16(e0[0] + bo[0][0], e0[1] + bo[0][1]), pack_bf16(e0[2] + bo[0][2], e0[3] + bo[0][3])};
+        *reinterpret_cast<u32x2s*>(xo + 32) = u32x2s{pack_bf16(e1[0] + bo[1][0], e1[1] + bo[1][1]), pack_bf16(e1[2] + bo[1][2], e1[3] + bo[1][3])};
+        *reinterpret_cast<u32x2s*>(xo + 48) = u32x2s{pack_bf16(e2[0] + bo[2][0], e2[1] + bo[2][1]), pack_bf16(e2[2] + bo[2][2], e2[3] + bo[2][3])};
+      }
     }
-    float sa[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      float a = sw[1328 + j];
-#pragma unroll
-      for (int c = 0; c < 9; c++) a = fmaf(aa[c], sw[1184 + 9 * j + c], a);
-      sa[j] = fast_sin(a);
-    }
-    float o[16];
-#pragma unroll
-    for (int p = 0; p < 16; p++) {
-      const int f = sigma16(p);
-      float a = sw[1600 + f];
-#pragma unroll
-      for (int j = 0; j < 16; j++) a = fmaf(sa[j], sw[1344 + f * 16 + j], a);
-      o[p] = a;
-    }
-    bf16x8 o0, o1;
-#pragma unroll
-    for (int p = 0; p < 8; p++) { o0[p] = (bf16)o[p]; o1[p] = (bf16)o[8 + p]; }
-    *reinterpret_cast<bf16x8*>(xo + 48) = o0;
-    *reinterpret_cast<bf16x8*>(xo + 56) = o1;
   }
 }
 
@@ -615,30 +649,39 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
 }
 
 // ------------------------------------------------------------------------------------------------ k_ffn
-// x1 -> LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2), 512 residues per workgroup iteration (8 waves x 64), persistent workgroups.
+// x1 -> LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2), 256 residues per workgroup iteration (4 waves x 64), persistent workgroups, TWO per CU:
+// the chunk barrier then joins one wave per SIMD, and a workgroup waiting at it leaves the matrix pipes to its neighbour (an
+// 8-wave workgroup stalled the whole CU at every chunk: measured 472 us per layer at 4096 x 256 against this form's 3xx).
+constexpr int FFN_THREADS = 256, FFN_TOK = FFN_THREADS;
 constexpr int FFN_NBUF = 3;        // chunk c + 2 is in flight while chunk c is multiplied
 constexpr int FFN_LDS = FFN_NBUF * (int)CHUNK_BYTES;
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int qchunk) {   // the swizzled image's 16-byte chunk `qchunk` of `row`
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_NOLDS)       // timing ablation: operands made up in registers
+  bf16x8 v;
+  for (int j = 0; j < 8; j++) v[j] = (bf16)(float)(row + qchunk + j);
+  asm volatile("" : "+v"(v));
+  return v;
+#endif
   return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((qchunk ^ ((row >> 1) & 7)) << 4));
 }
 
-__global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* __restrict__ y, const char* __restrict__ slab, const Img im, int64_t n) {
+__global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__ x1, bf16* __restrict__ y, const char* __restrict__ slab, const Img im, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c32 = lane & 31, hh = lane >> 5;
   const char* ffn = slab + im.ffn;
   const float* vec = reinterpret_cast<const float*>(slab + im.vec);
-  const int64_t nblocks = (n + 511) / 512;
-  auto dma = [&](int chunk, int buf) {     // 16,896 bytes = 1056 x 16: lanes 0 .. 511 twice + 32 lanes of wave 0
+  const int64_t nblocks = (n + FFN_TOK - 1) / FFN_TOK;
+  auto dma = [&](int chunk, int buf) {     // 16,896 bytes = 1056 x 16: lanes 0 .. 255 four times + 32 lanes of wave 0
     const char* src = ffn + (size_t)chunk * CHUNK_BYTES;
     char* dst = smem + buf * CHUNK_BYTES;
-    glds16(src + tid * 16, dst + wave * 1024);
-    glds16(src + 8192 + tid * 16, dst + 8192 + wave * 1024);
+#pragma unroll
+    for (int k = 0; k < 4; k++) glds16(src + 4096 * k + tid * 16, dst + 4096 * k + wave * 1024);
     if (wave == 0 && lane < 32) glds16(src + 16384 + lane * 16, dst + 16384);
   };
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int64_t tok_base = blk * 512 + wave * 64;
+    const int64_t tok_base = blk * FFN_TOK + wave * 64;
     // the wave's 64 residues as B operands: xb[token tile][16-feature group]: lane (token c32, hh): storage positions 16 g + 8 hh ..
     bf16x8 xb[2][4];
 #pragma unroll
@@ -666,55 +709,81 @@ __global__ __launch_bounds__(512) void k_ffn(const bf16* __restrict__ x1, bf16* 
     int buf = 0;
 #pragma unroll 1
     for (int c = 0; c < NCHUNK; c++) {
-      // chunk c has landed when at most chunk c + 1's requests (2 per wave, 3 for wave 0) are still out: LDS-DMA completes in order
+      // chunk c has landed when at most chunk c + 1's requests (4 per wave, 5 for wave 0) are still out: LDS-DMA completes in order
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_NOSYNC)     // timing ablation: no chunk hand-over at all (stale weights)
+      if (c > 0) goto compute;
+#endif
       if (c + 1 < NCHUNK) {
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();      // ... for everybody; and everybody is done with chunk c - 1, whose buffer chunk c + 2 takes
       if (c + 2 < NCHUNK) dma(c + 2, buf + 2 >= FFN_NBUF ? buf + 2 - FFN_NBUF : buf + 2);
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_NOSYNC)
+    compute:
+#endif
       const char* w1 = smem + buf * CHUNK_BYTES;
       buf = buf + 1 == FFN_NBUF ? 0 : buf + 1;
       const char* w2 = w1 + 64 * 64 * 2;
       const float* b1 = reinterpret_cast<const float*>(w2 + 64 * 64 * 2);
-#pragma unroll
-      for (int ht = 0; ht < 2; ht++) {
-        bf16x8 a1[4];
+      // Source order = issue order wanted: every LDS operand read is requested one phase before the MFMAs that take it (the W2
+      // fragments before the ReLU / pack block, the next half's W1 fragments and bias before the second product), so that a wave
+      // never sits on an LDS round trip with its partner wave doing the same.
+      bf16x8 a1[4];
+      f32x16 h[2];
+      auto load_w1 = [&](int ht) __attribute__((always_inline)) {
 #pragma unroll
         for (int gi = 0; gi < 4; gi++) a1[gi] = lds_frag(w1, 32 * ht + c32, 2 * gi + hh);
-        bf16x8 hb[2][2];
 #pragma unroll
-        for (int tt = 0; tt < 2; tt++) {
-          // the accumulators start as the bias, read from LDS per token tile (two copies in the image: one tile's read cannot be
-          // merged with the other's into a register copy -- 16 v_mov per tile were a quarter of the loop's vector instructions)
-          f32x16 h;
+        for (int tt = 0; tt < 2; tt++)     // the accumulators start as the bias, read per token tile from its own copy (no register copy)
 #pragma unroll
           for (int r4 = 0; r4 < 4; r4++) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1 + 64 * tt + 32 * ht + 8 * r4 + 4 * hh);
 #pragma unroll
-            for (int r = 0; r < 4; r++) h[4 * r4 + r] = b4[r];
+            for (int r = 0; r < 4; r++) h[tt][4 * r4 + r] = b4[r];
           }
+      };
+      load_w1(0);
 #pragma unroll
-          for (int gi = 0; gi < 4; gi++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[gi], xb[tt][gi], h, 0, 0, 0);
-          u32x4 t0, t1;
+      for (int ht = 0; ht < 2; ht++) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            t0[r] = relu_pk(pack_bf16(h[2 * r], h[2 * r + 1]));
-            t1[r] = relu_pk(pack_bf16(h[8 + 2 * r], h[9 + 2 * r]));
-          }
-          hb[tt][0] = __builtin_bit_cast(bf16x8, t0);
-          hb[tt][1] = __builtin_bit_cast(bf16x8, t1);
-        }
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+          for (int gi = 0; gi < 4; gi++) h[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[gi], xb[tt][gi], h[tt], 0, 0, 0);
+        bf16x8 a2[2][2];
 #pragma unroll
         for (int ot = 0; ot < 2; ot++)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; s2++) {
-            const bf16x8 a2 = lds_frag(w2, 32 * ot + c32, 4 * ht + 2 * s2 + hh);
+          for (int s2 = 0; s2 < 2; s2++) a2[ot][s2] = lds_frag(w2, 32 * ot + c32, 4 * ht + 2 * s2 + hh);
+        bf16x8 hb[2][2];
 #pragma unroll
-            for (int tt = 0; tt < 2; tt++) yacc[tt][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hb[tt][s2], yacc[tt][ot], 0, 0, 0);
+        for (int tt = 0; tt < 2; tt++) {
+          u32x4 t0, t1;
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_NORELU)      // timing ablation: the accumulators' first words as they are
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            t0[r] = __builtin_bit_cast(uint32_t, h[tt][r]);
+            t1[r] = __builtin_bit_cast(uint32_t, h[tt][8 + r]);
           }
+#else
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            t0[r] = relu_pk(pack_bf16(h[tt][2 * r], h[tt][2 * r + 1]));
+            t1[r] = relu_pk(pack_bf16(h[tt][8 + 2 * r], h[tt][9 + 2 * r]));
+          }
+#endif
+          hb[tt][0] = __builtin_bit_cast(bf16x8, t0);
+          hb[tt][1] = __builtin_bit_cast(bf16x8, t1);
+        }
+        if (ht == 0) load_w1(1);
+#pragma unroll
+        for (int ot = 0; ot < 2; ot++)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) yacc[tt][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ot][s2], hb[tt][s2], yacc[tt][ot], 0, 0, 0);
       }
     }
     // + b2 + residual, LayerNorm 2, store.  Lane (token c32, hh) holds features 32 ot + (r & 3) + 8 (r >> 2) + 4 hh = storage positions
@@ -908,18 +977,18 @@ int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* r
   TRY(ensure_dyn_lds(g_attn, (const void*)k_attn, ATT_LDS));
   TRY(ensure_dyn_lds(g_pool, (const void*)k_poolb, POOL_LDS));
   int cap = 256;
-  TRY(resident_blocks(g_ffn, (const void*)k_ffn, 512, FFN_LDS, &cap));
+  TRY(resident_blocks(g_ffn, (const void*)k_ffn, FFN_THREADS, FFN_LDS, &cap));
   hipLaunchKernelGGL(k_image, dim3(512), dim3(256), 0, st, prm, w.img, po, im, s.T, s.Cd);
   hipLaunchKernelGGL(k_chains, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, roff, loff, n_rec, w.start, w.len, B);
   hipLaunchKernelGGL(k_embed, dim3((unsigned)S), dim3(256), EMB_LDS, st, prm, w.img, po, im, s.Cd, rres, rpos, rang, lres, lpos, lang, w.start, w.len, B,
                      n_rec, w.xa);
   TRY(check_launch());
-  const int64_t nblocks = (n + 511) / 512;
+  const int64_t nblocks = (n + FFN_TOK - 1) / FFN_TOK;
   const unsigned fgrid = (unsigned)(nblocks < cap ? nblocks : cap);
   for (int l = 0; l < s.T; l++) {
     const char* slab = w.img + im.layers + im.per_layer * l;
     hipLaunchKernelGGL(k_attn, dim3((unsigned)S), dim3(256), ATT_LDS, st, w.xa, w.xb, slab, im, w.start, w.len);
-    hipLaunchKernelGGL(k_ffn, dim3(fgrid), dim3(512), FFN_LDS, st, w.xb, w.xa, slab, im, n);
+    hipLaunchKernelGGL(k_ffn, dim3(fgrid), dim3(FFN_THREADS), FFN_LDS, st, w.xb, w.xa, slab, im, n);
     TRY(check_launch());
   }
   const float neg_emb = (float)(-(log(10000.0) / (DM / 2 - 1)));
