@@ -1095,3 +1095,42 @@ def protnet_golden():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "protnet":
     protnet_golden()
+
+
+def p_sample_steps_large(n=1024):
+    """The G2 RATE fixture: the teacher-forced reverse-step quantities of main()'s `p_sample_steps.npz` at n = 1024
+    samples per timestep, so that the survey's outlier budgets (2 % for t <= 998, 40 % at t = 999) apply as RATES
+    without a small-sample margin.  Same network (the weights of score_mlp.npz), same reference calls (diffusion.py:291-313).  Stored:
+    x, and per t the fp32 network output v, the reference's fp32 posterior mean, and the float64 mean / x0hat with v teacher-forced."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    import util as rutil
+    import diffusion as rdiff
+    import so3_train as rtrain
+    g = np.load(os.path.join(OUT, "score_mlp.npz"))
+    net = rtrain.RotPredict(out_type="skewvec")
+    net.load_state_dict({f"net.{l}.{k}": torch.from_numpy(g[f"net_{l}_{k}"]) for l in (0, 2, 4, 6, 8) for k in ("weight", "bias")})
+    proc = rdiff.SO3Diffusion(net, timesteps=1000, loss_type="skewvec")
+    proc64 = rdiff.SO3Diffusion(lambda x, t: None, timesteps=1000, loss_type="skewvec").double()
+    torch.manual_seed(1077)
+    xs = rutil.quat_to_rmat(torch.randn(n, 4))
+    ps = {"x": npy(xs)}
+    for tval in (0, 1, 50, 500, 950, 998, 999):
+        tt = torch.full((n,), tval, dtype=torch.long)
+        pre = f"t{tval}_"
+        with torch.no_grad():
+            v = net(xs, tt)
+            x0hat = proc.predict_start_from_noise(xs, tt, v)
+            mean, _, _ = proc.q_posterior(x0hat, xs, tt)
+            x0hat64f = proc64.predict_start_from_noise(xs.double(), tt, v.double())
+            mean64f, _, _ = proc64.q_posterior(x0hat64f, xs.double(), tt)
+        ps[pre + "v"], ps[pre + "mean"], ps[pre + "mean_64f"], ps[pre + "x0hat_64f"] = npy(v), npy(mean), npy(mean64f), npy(x0hat64f)
+    np.savez_compressed(os.path.join(OUT, "p_sample_steps_n1024.npz"), **ps)
+    print("p_sample_steps_n1024.npz", os.path.getsize(os.path.join(OUT, "p_sample_steps_n1024.npz")) / 1024, "KB")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "p_sample_steps_large":
+    p_sample_steps_large()
