@@ -32,6 +32,7 @@ struct GemmP {
   int64_t sA0, sA1, sB0, sB1, sC0, sC1;
   float alpha;
   int relu, accumulate;
+  int kc;   // > 0: split-K -- batch index z0 is the K-chunk [z0 kc, min(K, (z0 + 1) kc)); the chunks' partial products go to C + z0 sC0
 };
 
 constexpr int GB = 64, GK = 16, GPAD = 68;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmP p) {
   const float* A = p.A + z0 * p.sA0 + z1 * p.sA1;
   const float* B = p.B + z0 * p.sB0 + z1 * p.sB1;
   float* C = p.C + z0 * p.sC0 + z1 * p.sC1;
+  const int Kn = p.kc > 0 ? (p.K - z0 * p.kc < p.kc ? p.K - z0 * p.kc : p.kc) : p.K;   // this workgroup's extent of K
   const bool a_kfast = p.sak == 1, b_nfast = p.sbn == 1;
   int am[4], ak[4], bn[4], bk[4];
 #pragma unroll
@@ -58,23 +60,23 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int gm = m0 + am[i], gk = k0 + ak[i];
-      ra[i] = (gm < p.M && gk < p.K) ? A[gm * p.sam + gk * p.sak] : 0.f;
+      ra[i] = (gm < p.M && gk < Kn) ? A[gm * p.sam + gk * p.sak] : 0.f;
       const int gn = n0 + bn[i], gk2 = k0 + bk[i];
-      rb[i] = (gn < p.N && gk2 < p.K) ? B[gk2 * p.sbk + gn * p.sbn] : 0.f;
+      rb[i] = (gn < p.N && gk2 < Kn) ? B[gk2 * p.sbk + gn * p.sbn] : 0.f;
     }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0.f;
   fetch(0);
-  for (int k0 = 0; k0 < p.K; k0 += GK) {
+  for (int k0 = 0; k0 < Kn; k0 += GK) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       As[ak[i]][am[i]] = ra[i];
       Bs[bk[i]][bn[i]] = rb[i];
     }
     __syncthreads();
-    if (k0 + GK < p.K) fetch(k0 + GK);
+    if (k0 + GK < Kn) fetch(k0 + GK);
 #pragma unroll
     for (int kk = 0; kk < GK / 2; kk++) {
       const float a = As[2 * kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -104,10 +106,37 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmP p) {
 int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, const float* bias, float alpha, bool relu, bool accumulate,
          int nb0, int nb1, int64_t sA0, int64_t sA1, int64_t sB0, int64_t sB1, int64_t sC0, int64_t sC1) {
   if (M <= 0 || N <= 0 || nb0 * nb1 <= 0) return SO3X_OK;
-  GemmP p{A.p, B.p, C, bias, M, N, K, A.s0, A.s1, B.s0, B.s1, ldc, nb1, sA0, sA1, sB0, sB1, sC0, sC1, alpha, relu ? 1 : 0, accumulate ? 1 : 0};
+  GemmP p{A.p, B.p, C, bias, M, N, K, A.s0, A.s1, B.s0, B.s1, ldc, nb1, sA0, sA1, sB0, sB1, sC0, sC1, alpha, relu ? 1 : 0, accumulate ? 1 : 0, 0};
   const int gy = (M + GB - 1) / GB;
   if (gy > 65535 || nb0 * nb1 > 65535) return SO3X_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_gemm_f32, dim3((N + GB - 1) / GB, gy, nb0 * nb1), dim3(256), 0, s, p);
+  return check_launch();
+}
+
+// C = A B for a SMALL M x N and a LONG K (a weight gradient: K = every token of the batch): as gemm() the launch would be a handful of
+// workgroups walking all of K (dW of a 64-wide layer: ONE workgroup).  Here K is cut into chunks, one workgroup per (tile, chunk)
+// writes its partial product to slab[chunk][M][N], and k_splitk_sum adds the chunks in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ slab, int nchunk, int64_t mn, int N, float* __restrict__ C, int64_t ldc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn) return;
+  float acc = 0.f;
+  for (int z = 0; z < nchunk; z++) acc += slab[(int64_t)z * mn + i];
+  C[(i / N) * ldc + i % N] = acc;
+}
+int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats) {
+  if (M <= 0 || N <= 0) return SO3X_OK;
+  const int64_t tiles = (int64_t)((M + GB - 1) / GB) * ((N + GB - 1) / GB), mn = (int64_t)M * N;
+  int nch = (int)(1024 / tiles);                                   // ~4 workgroups per CU
+  if ((int64_t)nch * 512 > K) nch = K / 512;                       // ... of at least 512 of K each
+  if ((size_t)nch * (size_t)mn > slab_floats) nch = (int)(slab_floats / (size_t)mn);
+  if (nch < 2) return gemm(s, A, B, C, ldc, M, N, K);
+  const int kc = ((K + nch - 1) / nch + GK - 1) / GK * GK;
+  nch = (K + kc - 1) / kc;
+  GemmP p{A.p, B.p, slab, nullptr, M, N, K, A.s0, A.s1, B.s0, B.s1, N, 1, (int64_t)kc * A.s1, 0, (int64_t)kc * B.s0, 0, mn, 0, 1.f, 0, 0, kc};
+  const int gy = (M + GB - 1) / GB;
+  if (gy > 65535 || nch > 65535) return SO3X_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gemm_f32, dim3((N + GB - 1) / GB, gy, nch), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, slab, nch, mn, N, C, ldc);
   return check_launch();
 }
 

@@ -113,6 +113,9 @@ inline Mat transposed(const float* p, int64_t ld) { return Mat{p, 1, ld}; }   //
 int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f,
          bool relu = false, bool accumulate = false, int nb0 = 1, int nb1 = 1, int64_t sA0 = 0, int64_t sA1 = 0, int64_t sB0 = 0,
          int64_t sB1 = 0, int64_t sC0 = 0, int64_t sC1 = 0);
+// the same product (no bias / activation) for a small M x N and a long K, cut over K into slab[chunk][M][N] partials summed in a
+// fixed order: what a weight gradient over all tokens needs to fill the chip (falls back to gemm() when K is short)
+int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats);
 // out[c] = sum over rows of X[row][c] (* xhat[row][c] when r / stats are given), fixed order; part: colsum_chunks x cols floats
 constexpr int CH = 512;
 inline int colsum_chunks(const Shape& s) { return (int)((s.N() + CH - 1) / CH) + 1; }

@@ -26,6 +26,7 @@ namespace prot {
 
 using plane::colsum;
 using plane::gemm;
+using plane::gemm_splitk;
 using plane::Mat;
 using plane::rowmajor;
 using plane::transposed;
@@ -360,8 +361,8 @@ inline Acts carve_acts(const Dims& s, void* mem, bool per_layer) {
 }
 
 struct BwdBufs {
-  float *dA, *dB, *dF, *dqkv, *dO, *dprobs, *dsp, *dsa, *dzh, *dxc, *gE, *gP, *dxs, *dpv, *dh0, *dh1, *dhz, *wtmp, *part;
-  size_t bytes;
+  float *dA, *dB, *dF, *dqkv, *dO, *dprobs, *dsp, *dsa, *dzh, *dxc, *gE, *gP, *dxs, *dpv, *dh0, *dh1, *dhz, *wtmp, *part, *slab;
+  size_t bytes, slab_floats;
 };
 inline int part_chunks(const Dims& s) { return (int)((s.R() + plane::CH - 1) / plane::CH) + 1; }
 inline BwdBufs carve_bwd(const Dims& s, void* mem) {
@@ -388,6 +389,9 @@ inline BwdBufs carve_bwd(const Dims& s, void* mem) {
   b.wtmp = c.take<float>((size_t)3 * d * (d > RES ? d : RES));
   const size_t widest = (size_t)(s.F > 3 * s.d ? s.F : 3 * s.d);
   b.part = c.take<float>((size_t)part_chunks(s) * widest);
+  // split-K partials of the weight gradients (plane::gemm_splitk): room for 32 chunks of the largest one, at least 8 M floats
+  b.slab_floats = (size_t)32 * s.F * d > ((size_t)8 << 20) ? (size_t)32 * s.F * d : ((size_t)8 << 20);
+  b.slab = c.take<float>(b.slab_floats);
   b.bytes = c.off;
   return b;
 }
@@ -483,7 +487,8 @@ static int conv_bwd(hipStream_t st, const Dims& s, const float* xh, int cin, con
                     float* dx, bool accumulate_dx, const BwdBufs& w) {
   const int64_t R = s.R();
   for (int k = 0; k < 3; k++)   // dW[:, :, k] = sum over rows r of dz[r] (x) x[r + k - 1] (rows 0 and R - 1 of dzh are halo rows: zero)
-    TRY(gemm(st, transposed(dzh + cout, cout), Mat{xh + (int64_t)k * cin, cin, 1}, w.wtmp + (int64_t)k * cout * cin, cin, cout, cin, (int)(R - 2)));
+    TRY(gemm_splitk(st, transposed(dzh + cout, cout), Mat{xh + (int64_t)k * cin, cin, 1}, w.wtmp + (int64_t)k * cout * cin, cin, cout, cin, (int)(R - 2),
+                    w.slab, w.slab_floats));
   hipLaunchKernelGGL(k_conv_w_scatter, dim3(nblk((int64_t)cout * cin * 3, 256)), dim3(256), 0, st, w.wtmp, dW, cout, cin);
   TRY(check_launch());
   TRY(colsum(st, dzh + cout, cout, R - 2, cout, db, w.part));
@@ -534,9 +539,9 @@ int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* d
   for (int kind = 0; kind < 2; kind++) {
     const Pool& q = kind ? po.lig : po.rec;
     const float* x = a.enc + kind * NB * d;
-    TRY(gemm(st, Mat{w.gE + kind * NB, 0, 1}, rowmajor(x, d), dprm + q.wpool, d, 1, d, (int)NB));
+    TRY(gemm_splitk(st, Mat{w.gE + kind * NB, 0, 1}, rowmajor(x, d), dprm + q.wpool, d, 1, d, (int)NB, w.slab, w.slab_floats));
     TRY(colsum(st, w.gE + kind * NB, 1, NB, 1, dprm + q.bpool, w.part));
-    TRY(gemm(st, Mat{w.gP + kind * NB, 0, 1}, rowmajor(x, d), dprm + q.wppool, d, 1, d, (int)NB));
+    TRY(gemm_splitk(st, Mat{w.gP + kind * NB, 0, 1}, rowmajor(x, d), dprm + q.wppool, d, 1, d, (int)NB, w.slab, w.slab_floats));
     TRY(colsum(st, w.gP + kind * NB, 1, NB, 1, dprm + q.bppool, w.part));
   }
   // the encoder's final norm
@@ -554,18 +559,18 @@ int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* d
     TRY(colsum(st, dcur, d, N, d, dprm + lo.g2, w.part, k.r2, d, k.st2));
     TRY(colsum(st, dcur, d, N, d, dprm + lo.be2, w.part));
     TRY(plane::ln_bwd(st, dcur, k.r2, k.st2, prm + lo.g2, dalt, N, d));
-    TRY(gemm(st, transposed(dalt, d), rowmajor(k.f, F), dprm + lo.w2, F, d, F, (int)N));
+    TRY(gemm_splitk(st, transposed(dalt, d), rowmajor(k.f, F), dprm + lo.w2, F, d, F, (int)N, w.slab, w.slab_floats));
     TRY(colsum(st, dalt, d, N, d, dprm + lo.b2, w.part));
     TRY(gemm(st, rowmajor(dalt, d), rowmajor(prm + lo.w2, F), w.dF, F, (int)N, F, d));
     TRY(plane::relu_bwd(st, w.dF, k.f, N * F, 1.f));
-    TRY(gemm(st, transposed(w.dF, F), rowmajor(k.x1, d), dprm + lo.w1, d, F, d, (int)N));
+    TRY(gemm_splitk(st, transposed(w.dF, F), rowmajor(k.x1, d), dprm + lo.w1, d, F, d, (int)N, w.slab, w.slab_floats));
     TRY(colsum(st, w.dF, F, N, F, dprm + lo.b1, w.part));
     TRY(gemm(st, rowmajor(w.dF, F), rowmajor(prm + lo.w1, d), dalt, d, (int)N, d, F, nullptr, 1.f, false, true));   // dalt = d x1
     // norm1 over r1 = h + attn(h)
     TRY(colsum(st, dalt, d, N, d, dprm + lo.g1, w.part, k.r1, d, k.st1));
     TRY(colsum(st, dalt, d, N, d, dprm + lo.be1, w.part));
     TRY(plane::ln_bwd(st, dalt, k.r1, k.st1, prm + lo.g1, dcur, N, d));
-    TRY(gemm(st, transposed(dcur, d), rowmajor(k.o, d), dprm + lo.wo, d, d, d, (int)N));
+    TRY(gemm_splitk(st, transposed(dcur, d), rowmajor(k.o, d), dprm + lo.wo, d, d, d, (int)N, w.slab, w.slab_floats));
     TRY(colsum(st, dcur, d, N, d, dprm + lo.bo, w.part));
     TRY(gemm(st, rowmajor(dcur, d), rowmajor(prm + lo.wo, d), w.dO, d, (int)N, d, d));
     const int64_t sq = Lp * 3 * d, sp = (int64_t)H * Lp * Lp;
@@ -579,23 +584,23 @@ int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* d
              Lp * Lp, sq, dh, sq, dh));
     TRY(gemm(st, transposed(w.dprobs, Lp), rowmajor(k.qkv, 3 * d), w.dqkv + d, 3 * d, (int)Lp, dh, (int)Lp, nullptr, 1.f, false, false, (int)S, H, sp,
              Lp * Lp, sq, dh, sq, dh));
-    TRY(gemm(st, transposed(w.dqkv, 3 * d), rowmajor(h, d), dprm + lo.wqkv, d, 3 * d, d, (int)N));
+    TRY(gemm_splitk(st, transposed(w.dqkv, 3 * d), rowmajor(h, d), dprm + lo.wqkv, d, 3 * d, d, (int)N, w.slab, w.slab_floats));
     TRY(colsum(st, w.dqkv, 3 * d, N, 3 * d, dprm + lo.bqkv, w.part));
     TRY(gemm(st, rowmajor(w.dqkv, 3 * d), rowmajor(prm + lo.wqkv, d), dcur, d, (int)N, d, 3 * d, nullptr, 1.f, false, true));   // dcur = d h
   }
   // dcur = d [res_emb | pos_emb | ang_emb]
   // SIREN embeddings: emb = sin(x Wp^T + bp) Wps^T + bps
-  TRY(gemm(st, transposed(dcur + rd, d), rowmajor(a.snp, pd), dprm + po.wpps, pd, pd, pd, (int)N));
+  TRY(gemm_splitk(st, transposed(dcur + rd, d), rowmajor(a.snp, pd), dprm + po.wpps, pd, pd, pd, (int)N, w.slab, w.slab_floats));
   TRY(colsum(st, dcur + rd, d, N, pd, dprm + po.bpps, w.part));
   TRY(gemm(st, rowmajor(dcur + rd, d), rowmajor(prm + po.wpps, pd), w.dsp, pd, (int)N, pd, pd));
   TRY(plane::cos_mul(st, w.dsp, a.prep, N * pd));
-  TRY(gemm(st, transposed(w.dsp, pd), rowmajor(a.pos, 3), dprm + po.wpp, 3, pd, 3, (int)N));
+  TRY(gemm_splitk(st, transposed(w.dsp, pd), rowmajor(a.pos, 3), dprm + po.wpp, 3, pd, 3, (int)N, w.slab, w.slab_floats));
   TRY(colsum(st, w.dsp, pd, N, pd, dprm + po.bpp, w.part));
-  TRY(gemm(st, transposed(dcur + rd + pd, d), rowmajor(a.sna, ad), dprm + po.waps, ad, ad, ad, (int)N));
+  TRY(gemm_splitk(st, transposed(dcur + rd + pd, d), rowmajor(a.sna, ad), dprm + po.waps, ad, ad, ad, (int)N, w.slab, w.slab_floats));
   TRY(colsum(st, dcur + rd + pd, d, N, ad, dprm + po.baps, w.part));
   TRY(gemm(st, rowmajor(dcur + rd + pd, d), rowmajor(prm + po.waps, ad), w.dsa, ad, (int)N, ad, ad));
   TRY(plane::cos_mul(st, w.dsa, a.prea, N * ad));
-  TRY(gemm(st, transposed(w.dsa, ad), rowmajor(a.ang, 9), dprm + po.wap, 9, ad, 9, (int)N));
+  TRY(gemm_splitk(st, transposed(w.dsa, ad), rowmajor(a.ang, 9), dprm + po.wap, 9, ad, 9, (int)N, w.slab, w.slab_floats));
   TRY(colsum(st, w.dsa, ad, N, ad, dprm + po.bap, w.part));
   // residue convolutions, last to first; dzh's halo rows stay zero (memset once: every k_silu_bwd_halo writes rows 1 .. Lp only)
   if ((e = hipMemsetAsync(w.dzh, 0, (size_t)s.R() * d * sizeof(float), st)) != hipSuccess) return (int)e;
