@@ -122,84 +122,6 @@ class TransformerEnc2(nn.Module):
         return self.encoder(x.transpose(0, 1), src_key_padding_mask=src_key_padding_mask).transpose(0, 1)
 
 
-class _GraphCache:
-    """hipGraph replay of a fixed launch sequence (a PlaneNet forward is ~45 launches, a training evaluation ~150: at the aircraft
-    task's own 32 x 256 points the kernels are shorter than the launches, and the host -- not the GPU -- set the pace).  One graph
-    per key (shapes and the parameter buffers' addresses), captured on first use after two warm-up runs; later calls copy the inputs
-    into the graph's static buffers and replay.  The outputs are the graph's static buffers: callers copy what must outlive the next
-    replay.  Never used while the caller itself is capturing, and bounded (oldest entry dropped)."""
-
-    def __init__(self, limit=8):
-        self.entries, self.limit = {}, limit
-
-    @staticmethod
-    def usable(*tensors):
-        return all(t.is_cuda for t in tensors) and not torch.cuda.is_current_stream_capturing()
-
-    def run(self, key, inputs, fn):
-        e = self.entries.get(key)
-        if e is None:
-            static = [t.clone() for t in inputs]
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    fn(*static)
-            cur.wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs = fn(*static)
-            if len(self.entries) >= self.limit:
-                self.entries.pop(next(iter(self.entries)))
-            e = self.entries[key] = (g, static, outs)
-        g, static, outs = e
-        for d, src in zip(static, inputs):
-            d.copy_(src)
-        g.replay()
-        return outs
-
-    def clear(self):
-        self.entries.clear()
-
-    def __deepcopy__(self, memo):       # graphs are bound to their buffers: a copied module captures its own
-        return _GraphCache(self.limit)
-
-    def __reduce__(self):
-        return (_GraphCache, (self.limit,))
-
-
-class _PlaneNetGraphFn(torch.autograd.Function):
-    """_PlaneNetFn with both halves replayed from captured graphs (no dropout: its (seed, offset) are launch arguments).  The stash
-    is the forward graph's static buffer: `net._stash_busy` marks it until the backward has read it, and a second forward in between
-    (gradient accumulation over two batches, a validation pass under grad) takes the eager path instead."""
-
-    @staticmethod
-    def forward(ctx, x, t, flat_params, net):
-        from . import backend as _b
-        cfg = net.cfg
-        key = ("train_fwd", tuple(x.shape), flat_params.data_ptr(), cfg)
-        out, stash = net._graphs.run(key, (x, t), lambda xs, ts: _b.planenet_fwd(flat_params, xs, ts, *cfg, want_stash=True)[:2])
-        import weakref
-        ctx.net, ctx.key = net, key
-        net._stash_busy = True
-        weakref.finalize(ctx, setattr, net, "_stash_busy", False)   # (a forward whose graph is dropped without a backward frees the stash too)
-        ctx.save_for_backward(flat_params)
-        return out.clone()
-
-    @staticmethod
-    def backward(ctx, dout):
-        from . import backend as _b
-        net = ctx.net
-        (flat_params,) = ctx.saved_tensors
-        _, (xs, ts), (_, stash) = net._graphs.entries[ctx.key]
-        cfg = net.cfg
-        bkey = ("train_bwd",) + ctx.key[1:]
-        (dparams,) = net._graphs.run(bkey, (dout.contiguous(),), lambda d: (_b.planenet_bwd(flat_params, xs, ts, d, stash, *cfg),))
-        net._stash_busy = False
-        return None, None, dparams.clone(), None
-
-
 class _PlaneNetFn(torch.autograd.Function):
     """autograd bridge of the PlaneNet kernels: only the parameters carry gradients (the point clouds are projections of the
     noised pose, which needs none: reference diffusion.py:389-392)"""
@@ -251,9 +173,6 @@ class PlaneNet(FlatParamsMixin, nn.Module):
         self.ffn = self.encoder.layers[0].linear1.out_features
         from .flat import PreparedCache
         self._prep = PreparedCache(every=64)   # the bf16 weight image: inference reuses it while the parameters do not change
-        self._graphs = _GraphCache()           # captured launch sequences (use_graphs): see _GraphCache
-        self._stash_busy = False
-        self.use_graphs = precision == "bf16"  # the exact-fp32 form is the parity form: launched eagerly
         self._init_flat()
 
     def _flat_root(self):
@@ -292,20 +211,11 @@ class PlaneNet(FlatParamsMixin, nn.Module):
             out, _, enc = _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_stash=drop[0] > 0, want_encoding=True,
                                           prepared=None if drop[0] > 0 else self._prepared(), dropout_p=drop[0], seed=drop[1], rng_offset=drop[2])
             return out, enc
-        graphs = self.use_graphs and _GraphCache.usable(x, t)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if graphs and drop[0] == 0 and not self._stash_busy and all(p.requires_grad for p in self.parameters()):
-                return _PlaneNetGraphFn.apply(x, t if t.dtype == torch.int64 else t.long(), self.flat_params(), self)
             return _PlaneNetFn.apply(x, t, self.flat_params(), self.cfg, drop)
         if drop[0] > 0:   # a training-mode forward nobody differentiates: the same masks, the stash dropped
             return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, want_stash=True, dropout_p=drop[0], seed=drop[1], rng_offset=drop[2])[0]
-        flat, prep = self.flat_params_nograd(), self._prepared()
-        if graphs:
-            key = ("fwd", tuple(x.shape), flat.data_ptr(), prep.data_ptr() if prep is not None and prep.numel() else 0, self.cfg)
-            (out,) = self._graphs.run(key, (x, t if t.dtype == torch.int64 else t.long()),
-                                      lambda xs, ts: (_b.planenet_fwd(flat, xs, ts, *self.cfg, prepared=prep)[0],))
-            return out.clone()
-        return _b.planenet_fwd(flat, x, t, *self.cfg, prepared=prep)[0]
+        return _b.planenet_fwd(self.flat_params_nograd(), x, t, *self.cfg, prepared=self._prepared())[0]
 
     def forward_torch(self, x, t):
         """the same network through torch's own modules (any device): test infrastructure"""
