@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_chains(const int64_t* __restrict__ roff
 // Conv1d(k 3, pad 1) = sum over 3 taps of W_tap x[l + tap - 1]: out^T[16 features x 16 residues] += W_tap[16 x 32] x_tap^T[32 x 16]
 // on v_mfma_f32_16x16x32_bf16, whose accumulator (lane = residue, 4 consecutive features) is written back as one 8-byte LDS store.
 constexpr int ERS = 72, RRS = 40;   // row strides in bf16 elements
-constexpr int EMB_LDS = (MAXL + 2) * ERS * 2 * 2;   // 74,304: two workgroups per CU
+constexpr int EMB_LDS = (MAXL + 2) * ERS * 2 * 2 + 336 * 4;   // 75,648: two workgroups per CU
 
 // One convolution layer for this wave's tiles.  KS = k-steps of 32 input channels (1: the residue types, 2: 64 channels), FT = output
 // tiles of 16 channels (4, or 1 for the last layer's 16).  Per output tile the weights -- 3 taps x KS operand fragments, straight from
@@ -241,12 +241,13 @@ constexpr int EMB_LDS = (MAXL + 2) * ERS * 2 * 2;   // 74,304: two workgroups pe
 // MFMAs of a tile, only its own LDS operand reads.
 template <int KS, int FT, bool FIRST, bool LAST>
 __device__ __forceinline__ void conv_layer(const bf16* __restrict__ w, const float* __restrict__ bias, const bf16* in, int in_rs, bf16* out,
-                                           bf16* __restrict__ x, int row0, int tok0, int ntile, int L, int q, int g, float (&resid)[4][4][4]) {
+                                           bf16* __restrict__ x, int row0, int tok0, int ntile, int L, int q, int g, float (&resid)[4][4][4],
+                                           bf16x8 (&wn)[3][2], float (&bn)[4], const bf16* __restrict__ wnext, const float* __restrict__ bnext,
+                                           int ks_next, int co_next) {
   constexpr int KP = 32 * KS, CO = 16 * FT;
-  // the weights of output tile ft + 1 are requested (L2, ~1 us away) before tile ft is multiplied: one round trip per layer is
-  // exposed instead of one per tile
-  bf16x8 wn[3][KS];
-  float bn[4];
+  // On entry wn / bn hold output tile 0's weights (requested by the previous layer -- or the kernel's prologue -- BEFORE its closing
+  // barrier: the L2 round trip, ~1 us, overlaps the wait).  The weights of tile ft + 1 are requested before tile ft is multiplied, and
+  // the next layer's tile 0 before this layer returns.
   auto fetch = [&](int ft) __attribute__((always_inline)) {
 #pragma unroll
     for (int tap = 0; tap < 3; tap++)
@@ -255,7 +256,6 @@ __device__ __forceinline__ void conv_layer(const bf16* __restrict__ w, const flo
 #pragma unroll
     for (int r = 0; r < 4; r++) bn[r] = bias[16 * ft + 4 * g + r];
   };
-  fetch(0);
 #pragma unroll
   for (int ft = 0; ft < FT; ft++) {
     bf16x8 wf[3][KS];
@@ -266,7 +266,18 @@ __device__ __forceinline__ void conv_layer(const bf16* __restrict__ w, const flo
       for (int ks = 0; ks < KS; ks++) wf[tap][ks] = wn[tap][ks];
 #pragma unroll
     for (int r = 0; r < 4; r++) bv[r] = bn[r];
-    if (ft + 1 < FT) fetch(ft + 1);
+    if (ft + 1 < FT) {
+      fetch(ft + 1);
+    } else if (wnext) {      // tile 0 of the next layer (its K extent and width may differ)
+      const int kpn = 32 * ks_next;
+#pragma unroll
+      for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+          if (ks < ks_next) wn[tap][ks] = *reinterpret_cast<const bf16x8*>(wnext + ((size_t)tap * co_next + q) * kpn + 32 * ks + 8 * g);
+#pragma unroll
+      for (int r = 0; r < 4; r++) bn[r] = bnext[4 * g + r];
+    }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       if (t >= ntile) continue;
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
   bf16* bufA = reinterpret_cast<bf16*>(smem);
   bf16* bufB = bufA + (MAXL + 2) * ERS;
   bf16* resb = bufB;                    // the residue one-hots live in bufB until layer 0 has read them (layer 1 is the first to write bufB)
+  float* sw = reinterpret_cast<float*>(bufB + (MAXL + 2) * ERS);   // SIREN constants [wpp 96 | bpp 32 | wap 144 | bap 16 | bpps 32 | baps 16]
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile counts below are wave-uniform)
   const int L = len[s], row0 = start[s];
   const bool lig = s >= B;
@@ -321,6 +333,16 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
   const float* pos = lig ? lpos : rpos;
   const float* ang = lig ? lang : rang;
   const int Lr = (L + 15) & ~15;        // the tile-rounded length: layers write rows 1 .. Lr of their output buffer (masked beyond L)
+  const int q = lane & 15, g = lane >> 4;
+  bf16x8 wn[3][2];                      // the next output tile's conv weights, always one L2 round trip ahead (conv_layer)
+  float bn[4];
+  {
+    const bf16* w0 = reinterpret_cast<const bf16*>(img + im.conv[0]);
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++) wn[tap][0] = *reinterpret_cast<const bf16x8*>(w0 + ((size_t)tap * 64 + q) * 32 + 8 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) bn[r] = reinterpret_cast<const float*>(img + im.convb[0])[4 * g + r];
+  }
   // stage the residues: one row (residue l = r - 1) per thread, 21 floats -> 32 bf16 (+ 8 unused); halo rows and rows >= L zero.
   // Of bufA only the rows a layer does not write but its successor reads must be zeroed: row 0 and row Lr + 1.
   for (int r = tid; r < MAXL + 2; r += 256) {
@@ -340,6 +362,8 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
 #pragma unroll
     for (int k = 0; k < 4; k++) *reinterpret_cast<bf16x8*>(resb + r * RRS + 8 * k) = o[k];
   }
+  for (int i = tid; i < 336; i += 256)
+    sw[i] = prm[i < 96 ? po.wpp + i : i < 128 ? po.bpp + i - 96 : i < 272 ? po.wap + i - 128 : i < 288 ? po.bap + i - 272 : i < 320 ? po.bpps + i - 288 : po.baps + i - 320];
   if (tid < 18) {     // 2 rows x 144 bytes
     bf16x8 z;
 #pragma unroll
@@ -347,13 +371,16 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
     *reinterpret_cast<bf16x8*>(bufA + (tid < 9 ? 0 : (Lr + 1)) * ERS + 8 * (tid % 9)) = z;
   }
   __syncthreads();
-  const int q = lane & 15, g = lane >> 4;
   const int tok0 = wave * 64;          // this wave's 64 residues: 4 tiles of 16
   const int ntile = L <= tok0 ? 0 : ((L - tok0 + 15) >> 4) < 4 ? ((L - tok0 + 15) >> 4) : 4;
   float resid[4][4][4];                // [tile][channel tile][r]: the ResLayers' running x (fp32)
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_EMB_NOCONV)
+  if (L >= 0) return;
+#endif
   bf16* cur = bufA;                    // layer i >= 1 reads `cur`, writes the other buffer
-  conv_layer<1, 4, true, false>(reinterpret_cast<const bf16*>(img + im.conv[0]), reinterpret_cast<const float*>(img + im.convb[0]), resb, RRS, bufA, x,
-                                row0, tok0, ntile, L, q, g, resid);
+  auto cw = [&](int i) { return reinterpret_cast<const bf16*>(img + im.conv[i]); };
+  auto cb = [&](int i) { return reinterpret_cast<const float*>(img + im.convb[i]); };
+  conv_layer<1, 4, true, false>(cw(0), cb(0), resb, RRS, bufA, x, row0, tok0, ntile, L, q, g, resid, wn, bn, cw(1), cb(1), 2, im.cout[1]);
   __syncthreads();
   // bufB held the residues: now that layer 0 has read them, zero ITS two rows that no layer writes and layer 2 reads (any thread may
   // do this while layer 1 runs: the next barrier orders it before layer 2)
@@ -365,13 +392,14 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
   }
   for (int i = 1; i < Cd - 1; i++) {
     bf16* nxt = cur == bufA ? bufB : bufA;
-    conv_layer<2, 4, false, false>(reinterpret_cast<const bf16*>(img + im.conv[i]), reinterpret_cast<const float*>(img + im.convb[i]), cur, ERS, nxt, x,
-                                   row0, tok0, ntile, L, q, g, resid);
+    conv_layer<2, 4, false, false>(cw(i), cb(i), cur, ERS, nxt, x, row0, tok0, ntile, L, q, g, resid, wn, bn, cw(i + 1), cb(i + 1), 2, im.cout[i + 1]);
     __syncthreads();
     cur = nxt;
   }
-  conv_layer<2, 1, false, true>(reinterpret_cast<const bf16*>(img + im.conv[Cd - 1]), reinterpret_cast<const float*>(img + im.convb[Cd - 1]), cur, ERS,
-                                nullptr, x, row0, tok0, ntile, L, q, g, resid);
+  conv_layer<2, 1, false, true>(cw(Cd - 1), cb(Cd - 1), cur, ERS, nullptr, x, row0, tok0, ntile, L, q, g, resid, wn, bn, nullptr, nullptr, 0, 0);
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_EMB_NOSIREN)
+  return;
+#endif
   // SIRENs (models.py:50-72): emb = post_scale(sin(positional(v))).  Per 16-residue tile the lane (residue q, g) evaluates 8 of the 32
   // position sines (k = 8 g ..) and 4 of the 16 frame sines (k = 4 g ..) -- exactly its B-operand fragment of the post_scale product
   // out^T[16 features x 16 residues] = W[16 x K] sin^T[K x 16] (16x16x32 for the positions, 16x16x16 for the frames); the products'
@@ -381,14 +409,14 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
 #pragma unroll
     for (int j = 0; j < 8; j++) {
 #pragma unroll
-      for (int c = 0; c < 3; c++) wp[j][c] = prm[po.wpp + 3 * (8 * g + j) + c];
-      bp8[j] = prm[po.bpp + 8 * g + j];
+      for (int c = 0; c < 3; c++) wp[j][c] = sw[3 * (8 * g + j) + c];
+      bp8[j] = sw[96 + 8 * g + j];
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
 #pragma unroll
-      for (int c = 0; c < 9; c++) wa[j][c] = prm[po.wap + 9 * (4 * g + j) + c];
-      ba4[j] = prm[po.bap + 4 * g + j];
+      for (int c = 0; c < 9; c++) wa[j][c] = sw[128 + 9 * (4 * g + j) + c];
+      ba4[j] = sw[272 + 4 * g + j];
     }
     const bf16* sir = reinterpret_cast<const bf16*>(img + im.sir);
     const bf16x8 wps0 = *reinterpret_cast<const bf16x8*>(sir + (size_t)q * 32 + 8 * g);
@@ -397,21 +425,30 @@ __global__ __launch_bounds__(256, 2) void k_embed(const float* __restrict__ prm,
     float bo[3][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      bo[0][r] = prm[po.bpps + 4 * g + r];
-      bo[1][r] = prm[po.bpps + 16 + 4 * g + r];
-      bo[2][r] = prm[po.baps + 4 * g + r];
+      bo[0][r] = sw[288 + 4 * g + r];
+      bo[1][r] = sw[304 + 4 * g + r];
+      bo[2][r] = sw[320 + 4 * g + r];
+    }
+    // all four tiles' coordinates and frames first (12 floats per lane and tile, clamped rows): ONE round trip to memory, not four
+    float pin[4][3], ain[4][9];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int tok = tok0 + 16 * t + q;
+      const int64_t row = src0 + (tok < L ? tok : (L > 0 ? L - 1 : 0));
+#pragma unroll
+      for (int c = 0; c < 3; c++) pin[t][c] = pos[row * 3 + c];
+#pragma unroll
+      for (int c = 0; c < 9; c++) ain[t][c] = ang[row * 9 + c];
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       if (t >= ntile) continue;
       const int tok = tok0 + 16 * t + q;
       const bool ok = tok < L;
-      const float* pp = pos + (src0 + (ok ? tok : 0)) * 3;
-      const float* aa = ang + (src0 + (ok ? tok : 0)) * 9;
-      const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+      const float p0 = pin[t][0], p1 = pin[t][1], p2 = pin[t][2];
       float av[9];
 #pragma unroll
-      for (int c = 0; c < 9; c++) av[c] = aa[c];
+      for (int c = 0; c < 9; c++) av[c] = ain[t][c];
       u32x4 sp;
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -465,7 +502,11 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
   const int ntile = L <= tok0 ? 0 : ((L - tok0 + 15) >> 4) < 4 ? ((L - tok0 + 15) >> 4) : 4;
   // this wave's input rows as 16x16x32 operand fragments: lane (residue q, kq = g) holds 8 consecutive storage positions
   const int L32 = (L + 31) & ~31;       // K / V tiles are produced up to the last key chunk's end (finite values at the masked keys)
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_ATT_NOKV)      // timing ablation: K / V not produced
+  const int nkv = 0;
+#else
   const int nkv = L32 <= tok0 ? 0 : ((L32 - tok0) >> 4) < 4 ? ((L32 - tok0) >> 4) : 4;
+#endif
   bf16x8 xf[4][2];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
@@ -479,63 +520,124 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
       xf[t][ks] = v;
     }
   }
-  // K (rows 64 .. 127 of in_proj) and V (rows 128 .. 191) of this wave's residues -> LDS
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    if (t >= nkv) continue;
-    const int tok = tok0 + 16 * t;
+  // K (rows 64 .. 127 of in_proj) and V (rows 128 .. 191) of this wave's residues -> LDS.  The 16 weight fragments and the biases are
+  // loaded ONCE, ahead of the tile loop (the image sits in L2, ~1 us away: a load in front of every product made this phase 180 us
+  // of the kernel's 530 at 4096 x 256: tools/ab/ab_protnet_libs.py).
+  if (nkv > 0) {
+    bf16x8 wkf[4][2], wvf[4][2];
+    float bk[4][4], bv[4];
 #pragma unroll
     for (int ft = 0; ft < 4; ft++) {
-      f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        const bf16x8 wk = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(64 + 16 * ft + q) * 64 + 32 * ks + 8 * g);
-        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(128 + 16 * ft + q) * 64 + 32 * ks + 8 * g);
-        ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk, xf[t][ks], ak, 0, 0, 0);   // K^T: lane (residue q, g): features 16 ft + 4 g + r
-        av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t][ks], wv, av, 0, 0, 0);   // V:   lane (feature q, g): residues tok + 4 g + r
+        wkf[ft][ks] = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(64 + 16 * ft + q) * 64 + 32 * ks + 8 * g);
+        wvf[ft][ks] = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(128 + 16 * ft + q) * 64 + 32 * ks + 8 * g);
       }
-      bf16x4 ok, ov;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + 64 + 16 * ft + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        ok[r] = (bf16)(ak[r] + vec[64 + 16 * ft + 4 * g + r]);
-        ov[r] = (bf16)(av[r] + vec[128 + 16 * ft + q]);
+      for (int r = 0; r < 4; r++) bk[ft][r] = b4[r];
+      bv[ft] = vec[128 + 16 * ft + q];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (t >= nkv) continue;
+      const int tok = tok0 + 16 * t;
+#pragma unroll
+      for (int ft = 0; ft < 4; ft++) {
+        f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wkf[ft][ks], xf[t][ks], ak, 0, 0, 0);   // K^T: lane (residue q, g): features 16 ft + 4 g + r
+          av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t][ks], wvf[ft][ks], av, 0, 0, 0);   // V:   lane (feature q, g): residues tok + 4 g + r
+        }
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(Ks + (tok + q) * KRS + 16 * ft + 4 * g) =
+            u32x2{pack_bf16(ak[0] + bk[ft][0], ak[1] + bk[ft][1]), pack_bf16(ak[2] + bk[ft][2], ak[3] + bk[ft][3])};
+        *reinterpret_cast<u32x2*>(Vt + (16 * ft + q) * VRS + tok + 4 * g) =
+            u32x2{pack_bf16(av[0] + bv[ft], av[1] + bv[ft]), pack_bf16(av[2] + bv[ft], av[3] + bv[ft])};
       }
-      *reinterpret_cast<bf16x4*>(Ks + (tok + q) * KRS + 16 * ft + 4 * g) = ok;
-      *reinterpret_cast<bf16x4*>(Vt + (16 * ft + q) * VRS + tok + 4 * g) = ov;
     }
   }
   __syncthreads();
   // attention of this wave's queries over the chain's keys, one head at a time
-  const int nchunk = (L + 31) >> 5;
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_ATT_NOHEADS)   // timing ablation: no score / softmax / PV work
+  const int nchunk = 0;
+#else
+  const int nchunk = ntile ? (L + 31) >> 5 : 0;     // (a wave without queries multiplies nothing)
+#endif
   bf16x4 ob[4][4];       // [query tile][head]: the normalised head outputs, lane (query q, g): head features 4 g + r
+  bf16x8 wqf[NH][2];     // the query rows of in_proj and their bias, all heads, loaded once (as the K / V fragments above)
+  f32x4 bq[NH];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) wqf[h][ks] = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(16 * h + q) * 64 + 32 * ks + 8 * g);
+    bq[h] = *reinterpret_cast<const f32x4*>(vec + 16 * h + 4 * g);
+  }
 #pragma unroll
   for (int h = 0; h < NH; h++) {
     bf16x4 qf[4];        // Q_h^T as the B operand of the 16x16x16 score product: lane (query q, kq = g): features 16 h + 4 g + j
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+      f32x4 aq = bq[h];
       if (t < ntile) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-          const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(16 * h + q) * 64 + 32 * ks + 8 * g);
-          aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, xf[t][ks], aq, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 2; ks++) aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wqf[h][ks], xf[t][ks], aq, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) qf[t][r] = (bf16)(aq[r] + vec[16 * h + 4 * g + r]);
+      for (int r = 0; r < 4; r++) qf[t][r] = (bf16)aq[r];
     }
+    // Softmax in TWO passes over the keys, both on the matrix pipe's spare time (it idles ~90 % of this kernel; the vector ALU is what
+    // it waits for).  Pass 1: the scores once for the exact row maxima (4 max per 32 keys and query; one cross-lane reduction per
+    // tile at the end).  Pass 2: the scores again with C = -max (- inf at masked keys): the product's result IS s - max, so a key costs
+    // one v_exp_f32 and half a pack -- no running maximum, no rescaling of the accumulators, no subtraction (the one-pass online form
+    // spent ~50 vector instructions per 32 keys and query tile; this one ~17).
     f32x4 oacc[4], lacc[4];   // lacc: the softmax denominators, on the matrix pipe too: ones[16 x 32 keys] P^T -> every row = sum over the keys
-    float mrun[4];
+    float mloc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       lacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mrun[t] = -INFINITY;
+      mloc[t] = -INFINITY;
     }
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; j++) ones[j] = (bf16)1.f;
-    for (int c = 0; c < nchunk; c++) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto key_mask = [&](int key0, f32x4& c0, f32x4& c1) __attribute__((always_inline)) {   // 0 at the chain's keys, -inf past its end
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        c0[r] = key0 + 4 * g + r >= L ? -INFINITY : 0.f;
+        c1[r] = key0 + 16 + 4 * g + r >= L ? -INFINITY : 0.f;
+      }
+    };
+    for (int c = 0; c < nchunk; c++) {      // pass 1
+      const int key0 = 32 * c;
+      const s16x4 k0 = *reinterpret_cast<const s16x4*>(Ks + (key0 + q) * KRS + 16 * h + 4 * g);
+      const s16x4 k1 = *reinterpret_cast<const s16x4*>(Ks + (key0 + 16 + q) * KRS + 16 * h + 4 * g);
+      f32x4 c0 = zero4, c1 = zero4;
+      if (key0 + 32 > L) key_mask(key0, c0, c1);
+      auto unit1 = [&](int t) __attribute__((always_inline)) {
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), c0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), c1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
+        mloc[t] = vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax3(s1[2], s1[3], mloc[t]));
+      };
+      if (ntile == 4) {      // (the common case, branch-free: the four tiles' chains interleave)
+#pragma unroll
+        for (int t = 0; t < 4; t++) unit1(t);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          if (t < ntile) unit1(t);
+      }
+    }
+    f32x4 cm[4];                            // -max of the tile's queries (every chunk holds a real key: finite), as the C operand
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float m = -quad_max(mloc[t]);
+      cm[t] = f32x4{m, m, m, m};
+    }
+    for (int c = 0; c < nchunk; c++) {      // pass 2
       const int key0 = 32 * c;
       // K_h rows of the chunk's two 16-key tiles (A operands: lane (key q, kq = g): features 16 h + 4 g + j) and V_h^T (A operand of
       // the 16x16x32 product: lane (feature q, kq = g): keys key0 + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3})
@@ -546,41 +648,29 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
       bf16x8 vf;
 #pragma unroll
       for (int j = 0; j < 4; j++) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
-      // the key-padding mask as the score products' C operand: 0 at the chain's keys, -inf past its end (one pair per chunk, shared
-      // by the four query tiles)
-      f32x4 c0, c1;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        c0[r] = key0 + 4 * g + r >= L ? -INFINITY : 0.f;
-        c1[r] = key0 + 16 + 4 * g + r >= L ? -INFINITY : 0.f;
-      }
-      auto unit = [&](int t) __attribute__((always_inline)) {
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), c0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), c1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
-        const float mx = quad_max(vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax(s1[2], s1[3])));
-        const float mnew = vmax(mrun[t], mx);           // (a chunk always holds at least one real key: mnew is finite)
-        const float resc = ex2(mrun[t] - mnew);
-        mrun[t] = mnew;
-        const f32x4 d0 = s0 - mnew, d1 = s1 - mnew;     // (vector form: two v_pk_add_f32 each)
+      const bool tail = key0 + 32 > L;
+      f32x4 m0 = zero4, m1 = zero4;
+      if (tail) key_mask(key0, m0, m1);
+      auto unit2 = [&](int t) __attribute__((always_inline)) {
+        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), tail ? cm[t] + m0 : cm[t], 0, 0, 0);
+        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), tail ? cm[t] + m1 : cm[t], 0, 0, 0);
         u32x4 pw;
         pw[0] = pack_bf16(ex2(d0[0]), ex2(d0[1]));
         pw[1] = pack_bf16(ex2(d0[2]), ex2(d0[3]));
         pw[2] = pack_bf16(ex2(d1[0]), ex2(d1[1]));
         pw[3] = pack_bf16(ex2(d1[2]), ex2(d1[3]));
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-        oacc[t] *= resc;
-        lacc[t] *= resc;
         // O_h^T[feature][query] += V_h^T[feature][32 keys] P^T[32 keys][query]: lane (query q, g): head features 4 g + r; the row sums likewise
         oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[t], 0, 0, 0);
         lacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc[t], 0, 0, 0);
       };
-      if (ntile == 4) {      // (the common case, branch-free: the four tiles' chains interleave)
+      if (ntile == 4) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) unit(t);
+        for (int t = 0; t < 4; t++) unit2(t);
       } else {
 #pragma unroll
         for (int t = 0; t < 4; t++)
-          if (t < ntile) unit(t);
+          if (t < ntile) unit2(t);
       }
     }
 #pragma unroll
@@ -591,7 +681,17 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
       for (int r = 0; r < 4; r++) ob[t][h][r] = (bf16)(oacc[t][r] * inv);
     }
   }
-  // out-projection (16x16x32, K = two heads per step), residual, LayerNorm 1 -> y in storage order
+  // out-projection (16x16x32, K = two heads per step), residual, LayerNorm 1 -> y in storage order; weights and row constants first
+  bf16x8 wof[4][2];
+  f32x4 bo4[4], g14[4], be14[4];
+#pragma unroll
+  for (int ft = 0; ft < 4; ft++) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) wof[ft][ks] = *reinterpret_cast<const bf16x8*>(wo + (size_t)(16 * ft + q) * 64 + 32 * ks + 8 * g);
+    bo4[ft] = *reinterpret_cast<const f32x4*>(vec + 192 + 16 * ft + 4 * g);
+    g14[ft] = *reinterpret_cast<const f32x4*>(vec + 256 + 16 * ft + 4 * g);
+    be14[ft] = *reinterpret_cast<const f32x4*>(vec + 320 + 16 * ft + 4 * g);
+  }
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     if (t >= ntile) continue;
@@ -607,16 +707,13 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
     const bf16* xr = x + (int64_t)(row0 + (ok ? tok : 0)) * DM;
 #pragma unroll
     for (int ft = 0; ft < 4; ft++) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = bo4[ft];
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wo + (size_t)(16 * ft + q) * 64 + 32 * ks + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, of[ks], acc, 0, 0, 0);      // lane (residue q, g): features 16 ft + 4 g + r
-      }
+      for (int ks = 0; ks < 2; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wof[ft][ks], of[ks], acc, 0, 0, 0);   // lane (residue q, g): features 16 ft + 4 g + r
       const bf16x4 xr4 = *reinterpret_cast<const bf16x4*>(xr + 16 * ft + sigma16_inv(4 * g));
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        v[ft][r] = acc[r] + vec[192 + 16 * ft + 4 * g + r] + (float)xr4[r];
+        v[ft][r] = acc[r] + (float)xr4[r];
         sum += v[ft][r];
       }
     }
@@ -638,10 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
       for (int ft = 0; ft < 4; ft++) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int f = 16 * ft + 4 * g + r;
-          o[r] = (bf16)((v[ft][r] - mean) * rstd * vec[256 + f] + vec[320 + f]);
-        }
+        for (int r = 0; r < 4; r++) o[r] = (bf16)((v[ft][r] - mean) * rstd * g14[ft][r] + be14[ft][r]);
         *reinterpret_cast<bf16x4*>(yo + 16 * ft + sigma16_inv(4 * g)) = o;
       }
     }
@@ -891,6 +985,7 @@ __global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const
   __syncthreads();
   const int c = tid & 63, qu = tid >> 6;
   float acc = 0.f, se = 0.f, sp = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll 8
   for (int l = qu; l < L; l += 4) {
     acc = fmaf(we[l], xn[l][c], acc);
     if (c == 0) {
