@@ -484,6 +484,10 @@ int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, fl
 }
 
 // host-side entry points of the row kernels for the other translation units (so3x_protnet.hip)
+int dropout_apply(hipStream_t s, const Drop& dr, int layer, int site, const float* src, float* dst, int64_t n) {
+  hipLaunchKernelGGL(k_dropout, dim3(blocks_for((n + 7) / 8, 256)), dim3(256), 0, s, src, dst, n, dr.thr16(), dr.inv_keep(), dr.seed, dr.ctr_hi(layer, site));
+  return check_launch();
+}
 int add_ln(hipStream_t s, const float* a, const float* b, float* r_out, float* y, float* stats, const float* gamma, const float* beta, int64_t N,
            int d, float eps) {
   hipLaunchKernelGGL(k_add_ln, dim3(blocks_for(N, 4)), dim3(256), 0, s, a, b, r_out, y, stats, gamma, beta, N, d, eps);

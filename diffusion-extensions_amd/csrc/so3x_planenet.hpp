@@ -123,6 +123,8 @@ int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, fl
            int64_t ldr = 0, const float* stats = nullptr);
 // row kernels (one wave per row): r = a + b, y = LayerNorm(r) gamma + beta, stats = (mean, rstd); its backward; dS = P o (dP - rowsum(dP o P))
 // scale in place over dP; df = f > 0 ? df scale : 0; ds *= cos(pre)
+// dst[e] = keep(e) ? src[e] / (1 - p) : 0 over a flat array (src may be dst): dropout site `site` of layer `layer` (Drop)
+int dropout_apply(hipStream_t s, const Drop& dr, int layer, int site, const float* src, float* dst, int64_t n);
 int add_ln(hipStream_t s, const float* a, const float* b, float* r_out, float* y, float* stats, const float* gamma, const float* beta, int64_t N,
            int d, float eps);
 int ln_bwd(hipStream_t s, const float* dy, const float* r, const float* stats, const float* gamma, float* dr, int64_t N, int d);

@@ -25,6 +25,12 @@ namespace so3x {
 namespace prot {
 
 using plane::colsum;
+using plane::Drop;
+using plane::dropout_apply;
+using plane::DROP_ATTN;
+using plane::DROP_BLOCK1;
+using plane::DROP_BLOCK2;
+using plane::DROP_FFN;
 using plane::gemm;
 using plane::gemm_splitk;
 using plane::Mat;
@@ -407,7 +413,7 @@ static int conv_fwd(hipStream_t st, const Dims& s, const float* xh, int cin, con
 
 int forward_f32(hipStream_t st, const Dims& s, const float* prm, const float* rres, const float* rpos, const float* rang, const int64_t* roff,
                 const float* lres, const float* lpos, const float* lang, const int64_t* loff, const int64_t* t, float* out, float* pool_out,
-                float* enc_out, const Acts& a) {
+                float* enc_out, const Acts& a, const Drop& dr, float* pdrop) {
   const POff po = param_offsets(s);
   const int64_t N = s.N(), S = s.S(), Lp = s.Lp, B = s.B;
   const int d = s.d, H = s.H, dh = s.dh(), F = s.F, pd = s.pd(), ad = s.ad(), rd = s.rd(), pw = s.pw();
@@ -448,12 +454,22 @@ int forward_f32(hipStream_t st, const Dims& s, const float* prm, const float* rr
              Lp * 3 * d, dh, Lp * 3 * d, dh, (int64_t)H * Lp * Lp, Lp * Lp));
     hipLaunchKernelGGL(k_softmax_masked, dim3(nblk(S * H * Lp, 4)), dim3(256), 0, st, k.probs, a.len, S * H * Lp, (int)Lp, (int64_t)H * Lp);
     TRY(check_launch());
-    TRY(gemm(st, rowmajor(k.probs, Lp), rowmajor(k.qkv + 2 * d, 3 * d), k.o, d, (int)Lp, dh, (int)Lp, nullptr, 1.f, false, false, (int)S, H,
+    // dr.on(): the training-mode forward -- nn.TransformerEncoderLayer's four dropout sites (so3x.h); `pdrop` holds the layer's
+    // dropped-out probabilities (the stash keeps the plain softmax, which its backward needs at dropped positions too)
+    const float* pv = k.probs;
+    if (dr.on()) {
+      TRY(dropout_apply(st, dr, l, DROP_ATTN, k.probs, pdrop, S * H * Lp * Lp));
+      pv = pdrop;
+    }
+    TRY(gemm(st, rowmajor(pv, Lp), rowmajor(k.qkv + 2 * d, 3 * d), k.o, d, (int)Lp, dh, (int)Lp, nullptr, 1.f, false, false, (int)S, H,
              (int64_t)H * Lp * Lp, Lp * Lp, Lp * 3 * d, dh, Lp * d, dh));
     TRY(gemm(st, rowmajor(k.o, d), transposed(prm + lo.wo, d), k.r1, d, (int)N, d, d, prm + lo.bo));
+    if (dr.on()) TRY(dropout_apply(st, dr, l, DROP_BLOCK1, k.r1, k.r1, N * d));
     TRY(plane::add_ln(st, h, k.r1, k.r1, k.x1, k.st1, prm + lo.g1, prm + lo.be1, N, d, 1e-5f));
     TRY(gemm(st, rowmajor(k.x1, d), transposed(prm + lo.w1, d), k.f, F, (int)N, F, d, prm + lo.b1, 1.f, true));
+    if (dr.on()) TRY(dropout_apply(st, dr, l, DROP_FFN, k.f, k.f, N * F));   // (the stash holds the dropped-out activations: what linear2 saw)
     TRY(gemm(st, rowmajor(k.f, F), transposed(prm + lo.w2, F), k.r2, d, (int)N, d, F, prm + lo.b2));
+    if (dr.on()) TRY(dropout_apply(st, dr, l, DROP_BLOCK2, k.r2, k.r2, N * d));
     TRY(plane::add_ln(st, k.x1, k.r2, k.r2, a.h[l + 1], k.st2, prm + lo.g2, prm + lo.be2, N, d, 1e-5f));
   }
   TRY(plane::add_ln(st, a.h[s.T], nullptr, nullptr, a.enc, a.stF, prm + po.rec_tf.gF, prm + po.rec_tf.bF, N, d, 1e-5f));   // encoder.norm
@@ -500,7 +516,7 @@ static int conv_bwd(hipStream_t st, const Dims& s, const float* xh, int cin, con
 }
 
 // dprm (overwritten; lig_tf's slice zero: the reference never runs it) = d sum(out * dout) / d params
-int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* dout, float* dprm, const Acts& a, const BwdBufs& w) {
+int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* dout, float* dprm, const Acts& a, const BwdBufs& w, const Drop& dr) {
   const POff po = param_offsets(s);
   const int64_t N = s.N(), S = s.S(), Lp = s.Lp, B = s.B, NB = B * Lp;
   const int d = s.d, H = s.H, dh = s.dh(), F = s.F, pd = s.pd(), ad = s.ad(), rd = s.rd(), pw = s.pw(), Bn = (int)B;
@@ -559,10 +575,16 @@ int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* d
     TRY(colsum(st, dcur, d, N, d, dprm + lo.g2, w.part, k.r2, d, k.st2));
     TRY(colsum(st, dcur, d, N, d, dprm + lo.be2, w.part));
     TRY(plane::ln_bwd(st, dcur, k.r2, k.st2, prm + lo.g2, dalt, N, d));
-    TRY(gemm_splitk(st, transposed(dalt, d), rowmajor(k.f, F), dprm + lo.w2, F, d, F, (int)N, w.slab, w.slab_floats));
-    TRY(colsum(st, dalt, d, N, d, dprm + lo.b2, w.part));
-    TRY(gemm(st, rowmajor(dalt, d), rowmajor(prm + lo.w2, F), w.dF, F, (int)N, F, d));
-    TRY(plane::relu_bwd(st, w.dF, k.f, N * F, 1.f));
+    // dalt = d r2: flows to x1 (residual) and through [dropout] linear2 / [dropout] relu / linear1
+    const float* dy2 = dalt;
+    if (dr.on()) {   // the feed-forward branch sees the gradient through its output dropout (w.dO is idle until the attention block)
+      TRY(dropout_apply(st, dr, l, DROP_BLOCK2, dalt, w.dO, N * d));
+      dy2 = w.dO;
+    }
+    TRY(gemm_splitk(st, transposed(dy2, d), rowmajor(k.f, F), dprm + lo.w2, F, d, F, (int)N, w.slab, w.slab_floats));
+    TRY(colsum(st, dy2, d, N, d, dprm + lo.b2, w.part));
+    TRY(gemm(st, rowmajor(dy2, d), rowmajor(prm + lo.w2, F), w.dF, F, (int)N, F, d));
+    TRY(plane::relu_bwd(st, w.dF, k.f, N * F, dr.on() ? dr.inv_keep() : 1.f));
     TRY(gemm_splitk(st, transposed(w.dF, F), rowmajor(k.x1, d), dprm + lo.w1, d, F, d, (int)N, w.slab, w.slab_floats));
     TRY(colsum(st, w.dF, F, N, F, dprm + lo.b1, w.part));
     TRY(gemm(st, rowmajor(w.dF, F), rowmajor(prm + lo.w1, d), dalt, d, (int)N, d, F, nullptr, 1.f, false, true));   // dalt = d x1
@@ -570,15 +592,28 @@ int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* d
     TRY(colsum(st, dalt, d, N, d, dprm + lo.g1, w.part, k.r1, d, k.st1));
     TRY(colsum(st, dalt, d, N, d, dprm + lo.be1, w.part));
     TRY(plane::ln_bwd(st, dalt, k.r1, k.st1, prm + lo.g1, dcur, N, d));
-    TRY(gemm_splitk(st, transposed(dcur, d), rowmajor(k.o, d), dprm + lo.wo, d, d, d, (int)N, w.slab, w.slab_floats));
-    TRY(colsum(st, dcur, d, N, d, dprm + lo.bo, w.part));
-    TRY(gemm(st, rowmajor(dcur, d), rowmajor(prm + lo.wo, d), w.dO, d, (int)N, d, d));
+    // dcur = d r1: flows to h (residual) and through [dropout] out_proj / attention / in_proj
+    const float* dy1 = dcur;
+    if (dr.on()) {   // (w.dF is idle from here on)
+      TRY(dropout_apply(st, dr, l, DROP_BLOCK1, dcur, w.dF, N * d));
+      dy1 = w.dF;
+    }
+    TRY(gemm_splitk(st, transposed(dy1, d), rowmajor(k.o, d), dprm + lo.wo, d, d, d, (int)N, w.slab, w.slab_floats));
+    TRY(colsum(st, dy1, d, N, d, dprm + lo.bo, w.part));
+    TRY(gemm(st, rowmajor(dy1, d), rowmajor(prm + lo.wo, d), w.dO, d, (int)N, d, d));
     const int64_t sq = Lp * 3 * d, sp = (int64_t)H * Lp * Lp;
-    // dV = P^T dO; dP = dO V^T; dS = softmax'(P, dP) / sqrt(dh) (zero at masked keys: P = 0 there); dQ = dS K; dK = dS^T Q
-    TRY(gemm(st, transposed(k.probs, Lp), rowmajor(w.dO, d), w.dqkv + 2 * d, 3 * d, (int)Lp, dh, (int)Lp, nullptr, 1.f, false, false, (int)S, H, sp,
+    // dV = P^T dO (with dropout: the dropped-out probabilities the forward multiplied V with, rebuilt in the buffer dP takes next);
+    // dP = dO V^T [through the dropout]; dS = softmax'(P, dP) / sqrt(dh) (zero at masked keys: P = 0 there); dQ = dS K; dK = dS^T Q
+    const float* pv = k.probs;
+    if (dr.on()) {
+      TRY(dropout_apply(st, dr, l, DROP_ATTN, k.probs, w.dprobs, S * H * Lp * Lp));
+      pv = w.dprobs;
+    }
+    TRY(gemm(st, transposed(pv, Lp), rowmajor(w.dO, d), w.dqkv + 2 * d, 3 * d, (int)Lp, dh, (int)Lp, nullptr, 1.f, false, false, (int)S, H, sp,
              Lp * Lp, Lp * d, dh, sq, dh));
     TRY(gemm(st, rowmajor(w.dO, d), transposed(k.qkv + 2 * d, 3 * d), w.dprobs, Lp, (int)Lp, (int)Lp, dh, nullptr, 1.f, false, false, (int)S, H, Lp * d,
              dh, sq, dh, sp, Lp * Lp));
+    if (dr.on()) TRY(dropout_apply(st, dr, l, DROP_ATTN, w.dprobs, w.dprobs, S * H * Lp * Lp));
     TRY(plane::softmax_bwd(st, k.probs, w.dprobs, S * H * Lp, (int)Lp, scale));
     TRY(gemm(st, rowmajor(w.dprobs, Lp), rowmajor(k.qkv + d, 3 * d), w.dqkv, 3 * d, (int)Lp, dh, (int)Lp, nullptr, 1.f, false, false, (int)S, H, sp,
              Lp * Lp, sq, dh, sq, dh));
@@ -664,9 +699,11 @@ size_t so3x_protnet_workspace_bytes(int64_t B, int64_t max_len, int64_t n_rec, i
 int so3x_protnet_fwd(so3x_stream_t st, const float* params, const float* rec_res, const float* rec_pos, const float* rec_ang, const int64_t* rec_off,
                      int64_t n_rec, const float* lig_res, const float* lig_pos, const float* lig_ang, const int64_t* lig_off, int64_t n_lig,
                      const int64_t* t, float* out, float* pool_out, float* enc_out, int64_t B, int64_t max_len, int dim, int heads, int t_depth,
-                     int c_depth, int precision, void* stash, void* workspace, size_t workspace_bytes) {
+                     int c_depth, int precision, void* stash, void* workspace, size_t workspace_bytes, float dropout_p, uint64_t seed,
+                     uint64_t rng_offset) {
   Dims s{B, max_len, dim, heads, t_depth, c_depth, 2048};
   if (!dims_ok(s) || n_rec < 0 || n_lig < 0) return SO3X_ERR_INVALID_ARG;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && (!stash || precision != SO3X_PREC_F32))) return SO3X_ERR_INVALID_ARG;   // dropout = a training forward
   if (B && (!params || !rec_res || !rec_pos || !rec_ang || !rec_off || !lig_res || !lig_pos || !lig_ang || !lig_off || !t || !out)) return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
   if (precision == SO3X_PREC_BF16 && (!bf16_supported(s) || stash || enc_out)) return SO3X_ERR_UNSUPPORTED;   // (the bf16 form is the inference form)
@@ -675,13 +712,17 @@ int so3x_protnet_fwd(so3x_stream_t st, const float* params, const float* rec_res
   if (precision == SO3X_PREC_BF16)
     return forward_bf16((hipStream_t)st, s, params, rec_res, rec_pos, rec_ang, rec_off, n_rec, lig_res, lig_pos, lig_ang, lig_off, n_lig, t, out, pool_out, workspace);
   const Acts a = stash ? carve_acts(s, stash, true) : carve_acts(s, workspace, false);
-  return forward_f32((hipStream_t)st, s, params, rec_res, rec_pos, rec_ang, rec_off, lig_res, lig_pos, lig_ang, lig_off, t, out, pool_out, enc_out, a);
+  const Drop dr{dropout_p, seed, rng_offset};
+  // (with a stash the workspace is idle in the forward: the backward's dP buffer holds a layer's dropped-out probabilities)
+  return forward_f32((hipStream_t)st, s, params, rec_res, rec_pos, rec_ang, rec_off, lig_res, lig_pos, lig_ang, lig_off, t, out, pool_out, enc_out, a, dr,
+                     dr.on() ? carve_bwd(s, workspace).dprobs : nullptr);
 }
 
 int so3x_protnet_bwd(so3x_stream_t st, const float* params, const float* dout, float* dparams, int64_t B, int64_t max_len, int dim, int heads,
-                     int t_depth, int c_depth, int precision, const void* stash, void* workspace, size_t workspace_bytes) {
+                     int t_depth, int c_depth, int precision, const void* stash, void* workspace, size_t workspace_bytes, float dropout_p,
+                     uint64_t seed, uint64_t rng_offset) {
   Dims s{B, max_len, dim, heads, t_depth, c_depth, 2048};
-  if (!dims_ok(s) || !dparams || (B && (!params || !dout || !stash))) return SO3X_ERR_INVALID_ARG;
+  if (!dims_ok(s) || !dparams || (B && (!params || !dout || !stash)) || !(dropout_p >= 0.f && dropout_p < 1.f)) return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32) return SO3X_ERR_UNSUPPORTED;
   if (B == 0) {
     hipError_t e = hipMemsetAsync(dparams, 0, (size_t)param_offsets(s).total * sizeof(float), (hipStream_t)st);
@@ -690,7 +731,7 @@ int so3x_protnet_bwd(so3x_stream_t st, const float* params, const float* dout, f
   if (!workspace || workspace_bytes < so3x_protnet_workspace_bytes(B, max_len, 0, 0, dim, heads, t_depth, c_depth, precision)) return SO3X_ERR_WORKSPACE;
   const Acts a = carve_acts(s, const_cast<void*>(stash), true);
   const BwdBufs w = carve_bwd(s, workspace);
-  return backward_f32((hipStream_t)st, s, params, dout, dparams, a, w);
+  return backward_f32((hipStream_t)st, s, params, dout, dparams, a, w, Drop{dropout_p, seed, rng_offset});
 }
 
 }  // extern "C"

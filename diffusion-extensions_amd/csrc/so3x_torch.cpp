@@ -493,7 +493,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> protnet_fwd(const Tensor& params, con
                                                        const Tensor& rec_off, const Tensor& lig_res, const Tensor& lig_pos, const Tensor& lig_ang,
                                                        const Tensor& lig_off, const Tensor& t, int64_t max_len, int64_t dim, int64_t heads,
                                                        int64_t t_depth, int64_t c_depth, int64_t precision, bool want_stash, bool want_pool,
-                                                       bool want_encoding) {
+                                                       bool want_encoding, double dropout_p, int64_t seed, int64_t rng_offset) {
   GUARD(rec_pos);
   const int64_t B = t.numel(), nr = rec_pos.numel() / 3, nl = lig_pos.numel() / 3;
   TORCH_CHECK(rec_off.numel() == B + 1 && lig_off.numel() == B + 1, "so3x: protnet_fwd: offsets must hold B + 1 entries");
@@ -514,18 +514,20 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> protnet_fwd(const Tensor& params, con
                       I64(dev(rec_off, "rec_off", at::kLong)), nr, F(dev(lig_res, "lig_res")), F(dev(lig_pos, "lig_pos")), F(dev(lig_ang, "lig_ang")),
                       I64(dev(lig_off, "lig_off", at::kLong)), nl, I64(dev(t, "t", at::kLong)), Fm(out), want_pool && B ? Fm(pool) : nullptr,
                       want_encoding && B ? Fm(enc) : nullptr, B, max_len, (int)dim, (int)heads, (int)t_depth, (int)c_depth, (int)precision,
-                      want_stash && B ? stash.mutable_data_ptr() : nullptr, ws.mutable_data_ptr(), ws.numel()),
+                      want_stash && B ? stash.mutable_data_ptr() : nullptr, ws.mutable_data_ptr(), ws.numel(), (float)dropout_p, (uint64_t)seed,
+                      (uint64_t)rng_offset),
      "protnet_fwd");
   return {out, stash, pool, enc};
 }
 Tensor protnet_bwd(const Tensor& params, const Tensor& dout, const Tensor& stash, int64_t max_len, int64_t dim, int64_t heads, int64_t t_depth,
-                   int64_t c_depth, int64_t precision) {
+                   int64_t c_depth, int64_t precision, double dropout_p, int64_t seed, int64_t rng_offset) {
   GUARD(dout);
   const int64_t B = dout.numel() / 6;
   Tensor dparams = f32_like(dout, {params.numel()});
   Tensor ws = bytes(dout, so3x_protnet_workspace_bytes(B, max_len, 0, 0, (int)dim, (int)heads, (int)t_depth, (int)c_depth, (int)precision));
   ok(so3x_protnet_bwd(strm(dout), F(dev(params, "params")), F(dev(dout, "dout")), Fm(dparams), B, max_len, (int)dim, (int)heads, (int)t_depth,
-                      (int)c_depth, (int)precision, dev(stash, "stash", at::kByte).const_data_ptr(), ws.mutable_data_ptr(), ws.numel()),
+                      (int)c_depth, (int)precision, dev(stash, "stash", at::kByte).const_data_ptr(), ws.mutable_data_ptr(), ws.numel(), (float)dropout_p,
+                      (uint64_t)seed, (uint64_t)rng_offset),
      "protnet_bwd");
   return dparams;
 }
@@ -776,8 +778,8 @@ TORCH_LIBRARY(so3x, m) {
   m.def("resnet_fwd(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> Tensor");
   m.def("planenet_prepare(Tensor params, int dim, int heads, int layers, int ffn, int precision) -> Tensor");
   m.def("planenet_fwd(Tensor params, Tensor x, Tensor t, int dim, int heads, int layers, int ffn, int precision, bool want_stash, bool want_encoding, Tensor? prepared, float dropout_p, int seed, int rng_offset) -> (Tensor, Tensor, Tensor)");
-  m.def("protnet_fwd(Tensor params, Tensor rec_res, Tensor rec_pos, Tensor rec_ang, Tensor rec_off, Tensor lig_res, Tensor lig_pos, Tensor lig_ang, Tensor lig_off, Tensor t, int max_len, int dim, int heads, int t_depth, int c_depth, int precision, bool want_stash, bool want_pool, bool want_encoding) -> (Tensor, Tensor, Tensor, Tensor)");
-  m.def("protnet_bwd(Tensor params, Tensor dout, Tensor stash, int max_len, int dim, int heads, int t_depth, int c_depth, int precision) -> Tensor");
+  m.def("protnet_fwd(Tensor params, Tensor rec_res, Tensor rec_pos, Tensor rec_ang, Tensor rec_off, Tensor lig_res, Tensor lig_pos, Tensor lig_ang, Tensor lig_off, Tensor t, int max_len, int dim, int heads, int t_depth, int c_depth, int precision, bool want_stash, bool want_pool, bool want_encoding, float dropout_p, int seed, int rng_offset) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("protnet_bwd(Tensor params, Tensor dout, Tensor stash, int max_len, int dim, int heads, int t_depth, int c_depth, int precision, float dropout_p, int seed, int rng_offset) -> Tensor");
   m.def("planenet_bwd(Tensor params, Tensor x, Tensor t, Tensor dout, Tensor stash, int dim, int heads, int layers, int ffn, int precision, float dropout_p, int seed, int rng_offset) -> Tensor");
   m.def("resnet_fwd_stash(Tensor params, Tensor x, Tensor t, int t_stride, int n_out, int precision, int t_table) -> (Tensor, Tensor)");
   m.def("resnet_bwd(Tensor params, Tensor x, Tensor t, int t_stride, Tensor dout, int n_out, int precision, int t_table, Tensor? stash) -> Tensor");

@@ -792,22 +792,26 @@ class ProtBatch:
         return len(self.lens)
 
 
-def protnet_fwd(params, batch, t, dim=64, heads=4, t_depth=4, c_depth=3, precision=PREC_F32, want_stash=False, want_pool=False, want_encoding=False):
+def protnet_fwd(params, batch, t, dim=64, heads=4, t_depth=4, c_depth=3, precision=PREC_F32, want_stash=False, want_pool=False, want_encoding=False,
+                dropout_p=0.0, seed=0, rng_offset=0):
     """ProtNet forward on a ProtBatch: (out [B, 6] = (rot_g, shift_g), stash for protnet_bwd or empty, the head's input [B, 3 dim + 6]
-    or empty, rec_tf's output in the padded layout [2 B, max_len, dim] or empty)"""
+    or empty, rec_tf's output in the padded layout [2 B, max_len, dim] or empty).  dropout_p > 0: the training-mode forward (exact-fp32
+    form, needs want_stash; masks are a function of (seed, rng_offset), see so3x.h)"""
     params = _dev(params, "params").reshape(-1)
     tt = _dev(t, "t", torch.int64).reshape(-1)
     if tt.numel() != len(batch):
         raise ValueError("so3x: ProtNet needs one timestep per complex")
     return _call(ops().protnet_fwd, params, *batch.rec, batch.rec_off, *batch.lig, batch.lig_off, tt, int(batch.max_len), int(dim), int(heads),
-                 int(t_depth), int(c_depth), int(precision), bool(want_stash), bool(want_pool), bool(want_encoding))
+                 int(t_depth), int(c_depth), int(precision), bool(want_stash), bool(want_pool), bool(want_encoding), float(dropout_p), _s64(seed),
+                 _s64(rng_offset))
 
 
-def protnet_bwd(params, dout, stash, max_len, dim=64, heads=4, t_depth=4, c_depth=3, precision=PREC_F32):
+def protnet_bwd(params, dout, stash, max_len, dim=64, heads=4, t_depth=4, c_depth=3, precision=PREC_F32, dropout_p=0.0, seed=0, rng_offset=0):
     """d sum(out * dout) / d params (flat, state_dict order; zero for lig_tf, which the reference never runs) from protnet_fwd's stash"""
     params = _dev(params, "params").reshape(-1)
     dout = _dev(dout, "dout").reshape(-1, 6).contiguous()
-    return _call(ops().protnet_bwd, params, dout, stash, int(max_len), int(dim), int(heads), int(t_depth), int(c_depth), int(precision))
+    return _call(ops().protnet_bwd, params, dout, stash, int(max_len), int(dim), int(heads), int(t_depth), int(c_depth), int(precision), float(dropout_p),
+                 _s64(seed), _s64(rng_offset))
 
 
 # ----------------------------------------------------------------------------- SE(3) layer

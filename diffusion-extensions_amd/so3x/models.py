@@ -231,10 +231,10 @@ class _ProtNetFn(torch.autograd.Function):
     pose, reference diffusion.py:558-559)"""
 
     @staticmethod
-    def forward(ctx, t, flat_params, cfg, batch):
+    def forward(ctx, t, flat_params, cfg, batch, drop):
         from . import backend as _b
-        out, stash, _, _ = _b.protnet_fwd(flat_params, batch, t, *cfg, want_stash=True)
-        ctx.cfg, ctx.max_len = cfg, batch.max_len
+        out, stash, _, _ = _b.protnet_fwd(flat_params, batch, t, *cfg, want_stash=True, dropout_p=drop[0], seed=drop[1], rng_offset=drop[2])
+        ctx.cfg, ctx.max_len, ctx.drop = cfg, batch.max_len, drop
         ctx.save_for_backward(flat_params, stash)
         return out
 
@@ -242,7 +242,8 @@ class _ProtNetFn(torch.autograd.Function):
     def backward(ctx, dout):
         from . import backend as _b
         flat_params, stash = ctx.saved_tensors
-        return None, _b.protnet_bwd(flat_params, dout.contiguous(), stash, ctx.max_len, *ctx.cfg), None, None
+        p, seed, off = ctx.drop
+        return None, _b.protnet_bwd(flat_params, dout.contiguous(), stash, ctx.max_len, *ctx.cfg, dropout_p=p, seed=seed, rng_offset=off), None, None, None
 
 
 class ProtNet(FlatParamsMixin, nn.Module):
@@ -255,8 +256,9 @@ class ProtNet(FlatParamsMixin, nn.Module):
     `forward` does not run them.  It runs the hand-written kernels of libso3x (so3x_protnet_fwd / so3x_protnet_bwd) on the flat
     parameter buffer the module parameters are views of.  As in the reference BOTH chains are encoded by `rec_tf` (models.py:288,
     302); `lig_tf` is constructed, saved and loaded, never run, and gets a zero gradient (the reference leaves it None).
-    The reference trains in net.train() with nn.TransformerEncoderLayer's default dropout 0.1 (prot_train.py:75); the kernels run
-    the eval-mode arithmetic in either mode (dropout = 0), which is also what sampling (prot_test.py) uses.
+    `dropout` (torch's default 0.1, which the reference trains with: prot_train.py:75 `net.train()`) is applied in training mode at
+    rec_tf's four sites per layer by the exact-fp32 kernels, from counter-based masks keyed by (so3x.rng seed, a fresh offset per
+    forward) that the backward regenerates (so3x.h); eval mode -- sampling, prot_test.py -- runs the plain arithmetic.
     precision "fp32": exact-fp32 matrix-core products, any width, forward and backward; "bf16": the class-default width (dim 64,
     4 heads) with bf16 operands, inference only -- a forward that needs gradients runs the fp32 form.
 
@@ -264,10 +266,11 @@ class ProtNet(FlatParamsMixin, nn.Module):
     so3x.backend.ProtBatch (the same data already concatenated: what a loader builds once per batch); t int64 [B].
     Returns AffineGrad(rot_g [B, 3], shift_g [B, 3]) (se3=True) or the [B, 6] tensor."""
 
-    def __init__(self, dim=64, heads=4, t_depth=4, c_depth=3, se3=True, precision="fp32"):
+    def __init__(self, dim=64, heads=4, t_depth=4, c_depth=3, se3=True, precision="fp32", dropout=0.1):
         super().__init__()
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.dropout = dropout
         pos_dim, ang_dim = dim // 2, dim // 4
         res_dim = dim - (pos_dim + ang_dim)
         self.se3 = se3
@@ -310,7 +313,11 @@ class ProtNet(FlatParamsMixin, nn.Module):
             out, _, pool, enc = _b.protnet_fwd(self.flat_params_nograd(), batch, t, *self.cfg, want_pool=True, want_encoding=True)
             return out, pool, enc
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._wrap(_ProtNetFn.apply(t, self.flat_params(), self.cfg, batch))
+            from . import rng as _rng
+            drop = (0.0, 0, 0)
+            if self.training and self.dropout > 0:
+                drop = (float(self.dropout), _rng.seed(), _rng.next_offset())   # a fresh mask set per training-mode forward
+            return self._wrap(_ProtNetFn.apply(t, self.flat_params(), self.cfg, batch, drop))
         prec = _b.PREC_BF16 if self.precision == "bf16" else _b.PREC_F32
         return self._wrap(_b.protnet_fwd(self.flat_params_nograd(), batch, t, *self.cfg, precision=prec)[0])
 

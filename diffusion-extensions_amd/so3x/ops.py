@@ -273,7 +273,7 @@ def _(params, x, t, dout, stash, dim, heads, layers, ffn, precision, dropout_p, 
 
 @register_fake("so3x::protnet_fwd")
 def _(params, rec_res, rec_pos, rec_ang, rec_off, lig_res, lig_pos, lig_ang, lig_off, t, max_len, dim, heads, t_depth, c_depth, precision, want_stash,
-      want_pool, want_encoding):
+      want_pool, want_encoding, dropout_p, seed, rng_offset):
     B = t.numel()
     # an upper bound is all a fake needs: per padded token and layer 8 dim + 2048 + heads * max_len floats
     stash = (2 * B * max_len * (t_depth * (8 * dim + 2048 + heads * max_len) + 2 * c_depth * dim + 64) * 4 + (1 << 20)) if want_stash else 0
@@ -282,7 +282,7 @@ def _(params, rec_res, rec_pos, rec_ang, rec_off, lig_res, lig_pos, lig_ang, lig
 
 
 @register_fake("so3x::protnet_bwd")
-def _(params, dout, stash, max_len, dim, heads, t_depth, c_depth, precision):
+def _(params, dout, stash, max_len, dim, heads, t_depth, c_depth, precision, dropout_p, seed, rng_offset):
     return _f32(dout, (params.numel(),))
 
 

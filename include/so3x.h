@@ -380,7 +380,13 @@ int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, cons
  *   pool_out (optional) [B][3 dim + 6]: the head's input; enc_out (optional) [2 B][max_len][dim]: rec_tf's output in the padded
  *   layout (receptors first; rows past a chain's length hold what the reference's padded rows hold).
  * so3x_protnet_bwd: dparams[param_count] (overwritten) = d sum(out * dout) / d params for dout [B][6], from the stash of the
- *   forward.  (The inputs carry no gradient: they are a projection of the noised pose, diffusion.py:558-559.)  Deterministic. */
+ *   forward.  (The inputs carry no gradient: they are a projection of the noised pose, diffusion.py:558-559.)  Deterministic.
+ * dropout_p in [0, 1), seed, rng_offset (exact-fp32 form, needs a stash: it is a training forward): the training-mode arithmetic
+ *   the reference trains with (prot_train.py:75 `net.train()` on nn.TransformerEncoderLayer's default p = 0.1) -- rec_tf's four
+ *   dropout sites per layer, masks as so3x_planenet_fwd's (Philox4x32-10 pieces keyed by (seed, rng_offset << 8 | 4 l + site)) with
+ *   the element index e taken row-major in THIS library's padded tensors: [2 B][heads][max_len][max_len] for the probabilities,
+ *   [2 B max_len][dim] / [2 B max_len][2048] / [2 B max_len][dim] for the others (receptor chains first).  so3x_protnet_bwd regenerates
+ *   them from the same three values.  (The bf16 form is the inference form: dropout_p must be 0.) */
 int64_t so3x_protnet_param_count(int dim, int heads, int t_depth, int c_depth);
 size_t so3x_protnet_workspace_bytes(int64_t B, int64_t max_len, int64_t n_rec, int64_t n_lig, int dim, int heads, int t_depth, int c_depth,
                                     int precision);
@@ -388,9 +394,11 @@ size_t so3x_protnet_stash_bytes(int64_t B, int64_t max_len, int dim, int heads, 
 int so3x_protnet_fwd(so3x_stream_t s, const float* params, const float* rec_res, const float* rec_pos, const float* rec_ang, const int64_t* rec_off,
                      int64_t n_rec, const float* lig_res, const float* lig_pos, const float* lig_ang, const int64_t* lig_off, int64_t n_lig,
                      const int64_t* t, float* out, float* pool_out, float* enc_out, int64_t B, int64_t max_len, int dim, int heads, int t_depth,
-                     int c_depth, int precision, void* stash, void* workspace, size_t workspace_bytes);
+                     int c_depth, int precision, void* stash, void* workspace, size_t workspace_bytes, float dropout_p, uint64_t seed,
+                     uint64_t rng_offset);
 int so3x_protnet_bwd(so3x_stream_t s, const float* params, const float* dout, float* dparams, int64_t B, int64_t max_len, int dim, int heads,
-                     int t_depth, int c_depth, int precision, const void* stash, void* workspace, size_t workspace_bytes);
+                     int t_depth, int c_depth, int precision, const void* stash, void* workspace, size_t workspace_bytes, float dropout_p,
+                     uint64_t seed, uint64_t rng_offset);
 
 /* ------------------------------------------------------- sample-quality statistics */
 /* The pair sums behind util.MMD / Ker_2samp_test (util.py:254-312):

@@ -47,7 +47,7 @@ def build(golden, tag, precision="fp32"):
     g = golden["protnet"]
     dim, heads, t_depth, c_depth = (int(v) for v in g[tag + "_cfg"])
     torch.manual_seed(31)
-    net = ProtNet(dim=dim, heads=heads, t_depth=t_depth, c_depth=c_depth, precision=precision).eval()
+    net = ProtNet(dim=dim, heads=heads, t_depth=t_depth, c_depth=c_depth, precision=precision, dropout=0.0).eval()
     protnet_perturb(net, 7)
     for k, v in net.state_dict().items():                     # the weights ARE the ones the fixture was made with
         chk = g[f"{tag}_chk_{k}"]
@@ -329,3 +329,90 @@ def test_bf16_ragged_batch_equals_its_complexes_one_by_one(golden):
         small = ProtNet(dim=32, heads=2, t_depth=2, c_depth=4, precision="bf16").to(DEV)
         with torch.no_grad():
             small(to_dev(build(golden, "small")[1]), torch.zeros(5, dtype=torch.long, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------ training-mode dropout
+def protnet_with_masks(net, data, t, masks, keep, Lp):
+    """ProtNet's forward (reference models.py:275-319 over nn.TransformerEncoderLayer's post-norm arithmetic) in the kernels' own
+    padded layout -- both chain kinds padded to Lp and stacked [2 B, Lp, .], receptors first -- with GIVEN dropout masks:
+    masks[l] = (attention [2 B, H, Lp, Lp], block 1 [2 B, Lp, d], feed-forward [2 B, Lp, ffn], block 2 [2 B, Lp, d]).  Any dtype /
+    device of `net`.  Test infrastructure."""
+    import torch.nn.functional as Fn
+    from torch.nn.utils.rnn import pad_sequence
+    B = len(data)
+
+    def padded(seqs):
+        out = pad_sequence(seqs, batch_first=True)
+        return Fn.pad(out, (0, 0) * (out.dim() - 2) + (0, Lp - out.shape[1]))
+    chains = [p[0] for p in data] + [p[1] for p in data]
+    pos = padded([c.positions for c in chains])
+    ang = padded([c.angles for c in chains]).flatten(-2, -1)
+    res = padded([net.res_conv(c.residues[None].transpose(-1, -2)).transpose(-1, -2)[0] for c in chains])
+    msk = pos.any(dim=-1)
+    h = torch.cat((res, net.pos_emb(pos), net.ang_emb(ang)), dim=-1)
+    S, _, d = h.shape
+    H = net.heads
+    neg = torch.zeros(S, 1, 1, Lp, dtype=h.dtype).masked_fill(~msk[:, None, None, :], float("-inf"))
+    for l, layer in enumerate(net.rec_tf.encoder.layers):
+        ma, m1, mf, m2 = masks[l]
+        qkv = Fn.linear(h, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
+        q, k, v = (z.reshape(S, Lp, H, d // H).transpose(1, 2) for z in qkv.split(d, dim=2))
+        pr = torch.softmax(q @ k.transpose(2, 3) / (d // H) ** 0.5 + neg, dim=-1) * ma / keep
+        y = layer.self_attn.out_proj((pr @ v).transpose(1, 2).reshape(S, Lp, d)) * m1 / keep
+        x1 = layer.norm1(h + y)
+        y2 = layer.linear2(torch.relu(layer.linear1(x1)) * mf / keep) * m2 / keep
+        h = layer.norm2(x1 + y2)
+    enc = net.rec_tf.encoder.norm(h)
+    pools = [net.rec_emb_pool(enc[:B], msk[:B]), net.rec_pos_pool(enc[:B], pos[:B], msk[:B]),
+             net.lig_emb_pool(enc[B:], msk[B:]), net.lig_pos_pool(enc[B:], pos[B:], msk[B:])]
+    return net.last(torch.cat((net.time_emb(t), *pools), dim=-1))
+
+
+@pytest.mark.gpu
+def test_training_mode_dropout_vs_the_reference_arithmetic_with_the_same_masks(golden):
+    """net.train() with nn.TransformerEncoderLayer's dropout (prot_train.py:75): the kernels' masks are a documented function of
+    (seed, offset) (so3x.h; emulated here in numpy: tests/test_planenet.py:dropout_mask, whose Philox passes Random123's known
+    answers).  torch's own mask stream cannot be matched, so parity is the reference's ARITHMETIC in float64 run with these masks:
+    the output and every parameter gradient."""
+    import copy
+    from so3x import rng
+    from test_planenet import dropout_mask
+    net, data, g = build(golden, "small")
+    net.dropout = 0.1
+    net = net.to(DEV).train()
+    t = torch.from_numpy(g["small_t"]).to(DEV)
+    dout = torch.from_numpy(g["small_dout"]).to(DEV)
+    rng.manual_seed(1234)
+    seed, off = rng.seed(), rng.next_offset()
+    rng.manual_seed(1234)                                   # the forward below draws the same (seed, offset)
+    out = net(to_dev(data), t)
+    full = torch.cat((out.rot_g, out.shift_g), -1)
+    net.zero_grad(set_to_none=True)
+    (full * dout).sum().backward()
+    lengths = [tuple(int(x) for x in row) for row in g["small_lengths"]]
+    S, Lp, d, H, F = 2 * len(lengths), max(max(n) for n in lengths), net.dim, net.heads, 2048
+    keep = 1.0 - float(np.float32(0.1))
+    masks = []
+    for l in range(net.t_depth):
+        m = [dropout_mask(S * H * Lp * Lp, 0.1, seed, off, l, 0).reshape(S, H, Lp, Lp), dropout_mask(S * Lp * d, 0.1, seed, off, l, 1).reshape(S, Lp, d),
+             dropout_mask(S * Lp * F, 0.1, seed, off, l, 2).reshape(S, Lp, F), dropout_mask(S * Lp * d, 0.1, seed, off, l, 3).reshape(S, Lp, d)]
+        masks.append([torch.from_numpy(a.astype(np.float64)) for a in m])
+    ref = copy.deepcopy(net).cpu().double().eval()
+    ref.zero_grad(set_to_none=True)
+    data64 = [tuple(ProtData(*(a.double() for a in c)) for c in pair) for pair in data]
+    want = protnet_with_masks(ref, data64, t.cpu(), masks, keep, Lp)
+    (want * dout.cpu().double()).sum().backward()
+    assert float((full.detach().cpu().double() - want.detach()).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    different = protnet_with_masks(ref, data64, t.cpu(), [[torch.ones_like(a) for a in m] for m in masks], 1.0, Lp)
+    assert float((want - different).abs().max()) > 1e-3            # the masks matter
+    for (k, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert k.startswith("lig_tf.")
+            continue
+        scale = max(float(pr.grad.abs().max()), 1e-8)
+        assert float((p.grad.detach().cpu().double() - pr.grad).abs().max()) < 5e-4 * scale, k
+    # eval mode: no dropout, whatever the attribute says
+    net.eval()
+    with torch.no_grad():
+        a, b = net(to_dev(data), t), net(to_dev(data), t)
+    assert torch.equal(a.rot_g, b.rot_g) and float((torch.cat((a.rot_g, a.shift_g), -1).cpu() - torch.from_numpy(g["small_out"])).abs().max()) < 1e-5
