@@ -21,6 +21,7 @@
 // (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a lane's 8 accumulators of a 16-group are 16 contiguous bytes of the row, and
 // the same 16 bytes are its B-operand fragment of the next product -- no lane movement, no LDS (the weight images' K order absorbs
 // the permutation).
+#include <type_traits>
 #include "so3x_protnet.hpp"
 #include "so3x_math.hpp"
 
@@ -560,11 +561,6 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
   }
   __syncthreads();
   // attention of this wave's queries over the chain's keys, one head at a time
-#if defined(SO3X_AB_BUILD) && defined(PROT_AB_ATT_NOHEADS)   // timing ablation: no score / softmax / PV work
-  const int nchunk = 0;
-#else
-  const int nchunk = ntile ? (L + 31) >> 5 : 0;     // (a wave without queries multiplies nothing)
-#endif
   bf16x4 ob[4][4];       // [query tile][head]: the normalised head outputs, lane (query q, g): head features 4 g + r
   bf16x8 wqf[NH][2];     // the query rows of in_proj and their bias, all heads, loaded once (as the K / V fragments above)
   f32x4 bq[NH];
@@ -574,9 +570,10 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
     for (int ks = 0; ks < 2; ks++) wqf[h][ks] = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(16 * h + q) * 64 + 32 * ks + 8 * g);
     bq[h] = *reinterpret_cast<const f32x4*>(vec + 16 * h + 4 * g);
   }
+  // Q of all heads first (then the input fragments and the query weights are dead registers during the head loop)
+  bf16x4 qall[NH][4];
 #pragma unroll
-  for (int h = 0; h < NH; h++) {
-    bf16x4 qf[4];        // Q_h^T as the B operand of the 16x16x16 score product: lane (query q, kq = g): features 16 h + 4 g + j
+  for (int h = 0; h < NH; h++)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       f32x4 aq = bq[h];
@@ -585,102 +582,110 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
         for (int ks = 0; ks < 2; ks++) aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wqf[h][ks], xf[t][ks], aq, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) qf[t][r] = (bf16)aq[r];
+      for (int r = 0; r < 4; r++) qall[h][t][r] = (bf16)aq[r];
     }
-    // Softmax in TWO passes over the keys, both on the matrix pipe's spare time (it idles ~90 % of this kernel; the vector ALU is what
-    // it waits for).  Pass 1: the scores once for the exact row maxima (4 max per 32 keys and query; one cross-lane reduction per
-    // tile at the end).  Pass 2: the scores again with C = -max (- inf at masked keys): the product's result IS s - max, so a key costs
-    // one v_exp_f32 and half a pack -- no running maximum, no rescaling of the accumulators, no subtraction (the one-pass online form
-    // spent ~50 vector instructions per 32 keys and query tile; this one ~17).
-    f32x4 oacc[4], lacc[4];   // lacc: the softmax denominators, on the matrix pipe too: ones[16 x 32 keys] P^T -> every row = sum over the keys
-    float mloc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      lacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mloc[t] = -INFINITY;
-    }
+  // The whole head loop, specialised on the wave's number of query tiles NT (1 .. 4): every copy is straight-line over its tiles
+  // (the four tiles' MFMA -> exp -> pack -> MFMA chains interleave; a per-tile branch would fence them off from each other, and a
+  // merged "4 or fewer" form cost two register copies per accumulator and chunk), full key chunks and the one partial chunk apart
+  // (no per-chunk select between masked and unmasked C operands).
+  auto heads = [&](auto NTc) __attribute__((always_inline)) {
+    constexpr int NT = decltype(NTc)::value;
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; j++) ones[j] = (bf16)1.f;
+    const int nfull = L >> 5;               // chunks of 32 keys that lie wholly inside the chain
+    const bool part = (L & 31) != 0;
+    f32x4 mk0, mk1;                         // the partial chunk's key mask: 0 at the chain's keys, -inf past its end
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      mk0[r] = 32 * nfull + 4 * g + r >= L ? -INFINITY : 0.f;
+      mk1[r] = 32 * nfull + 16 + 4 * g + r >= L ? -INFINITY : 0.f;
+    }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto key_mask = [&](int key0, f32x4& c0, f32x4& c1) __attribute__((always_inline)) {   // 0 at the chain's keys, -inf past its end
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        c0[r] = key0 + 4 * g + r >= L ? -INFINITY : 0.f;
-        c1[r] = key0 + 16 + 4 * g + r >= L ? -INFINITY : 0.f;
+    for (int h = 0; h < NH; h++) {
+      bf16x4 qf[NT];       // Q_h^T as the B operand of the 16x16x16 score product: lane (query q, kq = g): features 16 h + 4 g + j
+#pragma unroll
+      for (int t = 0; t < NT; t++) qf[t] = qall[h][t];
+      // Softmax in TWO passes over the keys, both on the matrix pipe's spare time (it idles ~90 % of this kernel; the vector ALU is
+      // what it waits for).  Pass 1: the scores once for the exact row maxima (4 max per 32 keys and query; one cross-lane reduction
+      // per tile at the end).  Pass 2: the scores again with C = -max (- inf at masked keys): the product's result IS s - max, so a
+      // key costs one v_exp_f32 and half a pack -- no running maximum, no rescaling of the accumulators, no subtraction.
+      f32x4 oacc[NT], lacc[NT];   // lacc: the softmax denominators, on the matrix pipe too: ones[16 x 32 keys] P^T -> every row = sum over the keys
+      float mloc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        oacc[t] = zero4;
+        lacc[t] = zero4;
+        mloc[t] = -INFINITY;
       }
-    };
-    for (int c = 0; c < nchunk; c++) {      // pass 1
-      const int key0 = 32 * c;
-      const s16x4 k0 = *reinterpret_cast<const s16x4*>(Ks + (key0 + q) * KRS + 16 * h + 4 * g);
-      const s16x4 k1 = *reinterpret_cast<const s16x4*>(Ks + (key0 + 16 + q) * KRS + 16 * h + 4 * g);
-      f32x4 c0 = zero4, c1 = zero4;
-      if (key0 + 32 > L) key_mask(key0, c0, c1);
-      auto unit1 = [&](int t) __attribute__((always_inline)) {
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), c0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), c1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
-        mloc[t] = vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax3(s1[2], s1[3], mloc[t]));
+      auto pass1 = [&](int key0, const f32x4& c0, const f32x4& c1) __attribute__((always_inline)) {
+        const s16x4 k0 = *reinterpret_cast<const s16x4*>(Ks + (key0 + q) * KRS + 16 * h + 4 * g);
+        const s16x4 k1 = *reinterpret_cast<const s16x4*>(Ks + (key0 + 16 + q) * KRS + 16 * h + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), c0, 0, 0, 0);   // lane (query q, g): keys key0 + 4 g + r
+          const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), c1, 0, 0, 0);   //                 keys key0 + 16 + 4 g + r
+          mloc[t] = vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax3(s1[2], s1[3], mloc[t]));
+        }
       };
-      if (ntile == 4) {      // (the common case, branch-free: the four tiles' chains interleave)
+      for (int c = 0; c < nfull; c++) pass1(32 * c, zero4, zero4);
+      if (part) pass1(32 * nfull, mk0, mk1);
+      f32x4 cm[NT];                         // -max of the tile's queries (every chain holds a real key: finite), as the C operand
 #pragma unroll
-        for (int t = 0; t < 4; t++) unit1(t);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-          if (t < ntile) unit1(t);
+      for (int t = 0; t < NT; t++) {
+        const float m = -quad_max(mloc[t]);
+        cm[t] = f32x4{m, m, m, m};
       }
-    }
-    f32x4 cm[4];                            // -max of the tile's queries (every chunk holds a real key: finite), as the C operand
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const float m = -quad_max(mloc[t]);
-      cm[t] = f32x4{m, m, m, m};
-    }
-    for (int c = 0; c < nchunk; c++) {      // pass 2
-      const int key0 = 32 * c;
-      // K_h rows of the chunk's two 16-key tiles (A operands: lane (key q, kq = g): features 16 h + 4 g + j) and V_h^T (A operand of
+      // K_h rows of a chunk's two 16-key tiles (A operands: lane (key q, kq = g): features 16 h + 4 g + j) and V_h^T (A operand of
       // the 16x16x32 product: lane (feature q, kq = g): keys key0 + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3})
-      const s16x4 k0 = *reinterpret_cast<const s16x4*>(Ks + (key0 + q) * KRS + 16 * h + 4 * g);
-      const s16x4 k1 = *reinterpret_cast<const s16x4*>(Ks + (key0 + 16 + q) * KRS + 16 * h + 4 * g);
-      const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vt + (16 * h + q) * VRS + key0 + 4 * g);
-      const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vt + (16 * h + q) * VRS + key0 + 16 + 4 * g);
-      bf16x8 vf;
+      auto pass2 = [&](int key0, bool masked) __attribute__((always_inline)) {
+        const s16x4 k0 = *reinterpret_cast<const s16x4*>(Ks + (key0 + q) * KRS + 16 * h + 4 * g);
+        const s16x4 k1 = *reinterpret_cast<const s16x4*>(Ks + (key0 + 16 + q) * KRS + 16 * h + 4 * g);
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vt + (16 * h + q) * VRS + key0 + 4 * g);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vt + (16 * h + q) * VRS + key0 + 16 + 4 * g);
+        bf16x8 vf;
 #pragma unroll
-      for (int j = 0; j < 4; j++) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
-      const bool tail = key0 + 32 > L;
-      f32x4 m0 = zero4, m1 = zero4;
-      if (tail) key_mask(key0, m0, m1);
-      auto unit2 = [&](int t) __attribute__((always_inline)) {
-        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), tail ? cm[t] + m0 : cm[t], 0, 0, 0);
-        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), tail ? cm[t] + m1 : cm[t], 0, 0, 0);
-        u32x4 pw;
-        pw[0] = pack_bf16(ex2(d0[0]), ex2(d0[1]));
-        pw[1] = pack_bf16(ex2(d0[2]), ex2(d0[3]));
-        pw[2] = pack_bf16(ex2(d1[0]), ex2(d1[1]));
-        pw[3] = pack_bf16(ex2(d1[2]), ex2(d1[3]));
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-        // O_h^T[feature][query] += V_h^T[feature][32 keys] P^T[32 keys][query]: lane (query q, g): head features 4 g + r; the row sums likewise
-        oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[t], 0, 0, 0);
-        lacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc[t], 0, 0, 0);
+        for (int j = 0; j < 4; j++) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, __builtin_bit_cast(s16x4, qf[t]), masked ? cm[t] + mk0 : cm[t], 0, 0, 0);
+          const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, __builtin_bit_cast(s16x4, qf[t]), masked ? cm[t] + mk1 : cm[t], 0, 0, 0);
+          u32x4 pw;
+          pw[0] = pack_bf16(ex2(d0[0]), ex2(d0[1]));
+          pw[1] = pack_bf16(ex2(d0[2]), ex2(d0[3]));
+          pw[2] = pack_bf16(ex2(d1[0]), ex2(d1[1]));
+          pw[3] = pack_bf16(ex2(d1[2]), ex2(d1[3]));
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+          // O_h^T[feature][query] += V_h^T[feature][32 keys] P^T[32 keys][query]: lane (query q, g): head features 4 g + r; the row sums likewise
+          oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[t], 0, 0, 0);
+          lacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc[t], 0, 0, 0);
+        }
       };
-      if (ntile == 4) {
+      for (int c = 0; c < nfull; c++) pass2(32 * c, false);
+      if (part) pass2(32 * nfull, true);
 #pragma unroll
-        for (int t = 0; t < 4; t++) unit2(t);
-      } else {
+      for (int t = 0; t < NT; t++) {
+        const float l = lacc[t][0];
+        const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-          if (t < ntile) unit2(t);
+        for (int r = 0; r < 4; r++) ob[t][h][r] = (bf16)(oacc[t][r] * inv);
       }
     }
+  };
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const float l = lacc[t][0];
-      const float inv = l > 0.f ? 1.f / l : 0.f;
+  for (int t = 0; t < 4; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) ob[t][h][r] = (bf16)(oacc[t][r] * inv);
-    }
+    for (int h = 0; h < NH; h++) ob[t][h] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#if !(defined(SO3X_AB_BUILD) && defined(PROT_AB_ATT_NOHEADS))   // (timing ablation: no score / softmax / PV work)
+  switch (ntile) {
+    case 4: heads(std::integral_constant<int, 4>{}); break;
+    case 3: heads(std::integral_constant<int, 3>{}); break;
+    case 2: heads(std::integral_constant<int, 2>{}); break;
+    case 1: heads(std::integral_constant<int, 1>{}); break;
+    default: break;      // a wave without queries multiplies nothing
   }
+#endif
   // out-projection (16x16x32, K = two heads per step), residual, LayerNorm 1 -> y in storage order; weights and row constants first
   bf16x8 wof[4][2];
   f32x4 bo4[4], g14[4], be14[4];

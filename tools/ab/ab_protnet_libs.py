@@ -43,7 +43,7 @@ for path in libs:
     def call(l=l, ws=ws, nb=nb):
         rc = l.so3x_protnet_fwd(C.c_void_p(torch.cuda.current_stream().cuda_stream), P(params), P(rec[0]), P(rec[1]), P(rec[2]), P(rec[3]), C.c_int64(Bn * lr),
                                 P(lig[0]), P(lig[1]), P(lig[2]), P(lig[3]), C.c_int64(Bn * ll), P(t), P(out), None, None, C.c_int64(Bn), C.c_int64(max(lr, ll)),
-                                C.c_int(64), C.c_int(4), C.c_int(4), C.c_int(3), C.c_int(1), None, P(ws), C.c_size_t(nb))
+                                C.c_int(64), C.c_int(4), C.c_int(4), C.c_int(3), C.c_int(1), None, P(ws), C.c_size_t(nb), C.c_float(0.0), C.c_uint64(0), C.c_uint64(0))
         assert rc == 0, rc
     calls[path] = call
 for c in calls.values():
