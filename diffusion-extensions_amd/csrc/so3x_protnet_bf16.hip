@@ -932,17 +932,14 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
 // ------------------------------------------------------------------------------------------------ k_poolb
 // Per chain: the encoder's final LayerNorm, then PoolRN's and PoolPos's weighted sums (models.py:94-127) -- as k_pool of the exact
 // form, from the bf16 stream.  One residue per thread for the norm and the two logits, one (feature, quarter) per thread for the sums.
-__global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const float* __restrict__ prm, const POff po, const float* __restrict__ rpos,
+__global__ __launch_bounds__(256, 4) void k_poolb(const bf16* __restrict__ x, const float* __restrict__ prm, const POff po, const float* __restrict__ rpos,
                                                const float* __restrict__ lpos, const int* __restrict__ start, const int* __restrict__ len, int64_t B,
                                                int64_t n_rec, float* __restrict__ xs, float* __restrict__ pv, float* __restrict__ enc_dbg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float (*xn)[65] = reinterpret_cast<float (*)[65]>(smem);
-  float* we = reinterpret_cast<float*>(smem) + MAXL * 65;
-  float* wp = we + MAXL;
-  float (*pp)[3] = reinterpret_cast<float (*)[3]>(wp + MAXL);
-  float (*part)[64] = reinterpret_cast<float (*)[64]>(wp + MAXL + MAXL * 3);
-  float (*tail)[8] = reinterpret_cast<float (*)[8]>(wp + MAXL + MAXL * 3 + 4 * 64);
-  float* cst = wp + MAXL + MAXL * 3 + 4 * 64 + 4 * 8;      // [gamma | beta | wpool | wppool] in STORAGE order (position p: feature sigma)
+  // LDS holds per-residue scalars only (7 KB: many workgroups per CU hide each other's round trips -- the first form kept the
+  // normalised rows, 73 KB, two workgroups per CU, and spent its time waiting); phase 2 re-reads the bf16 rows (L2-hot) and
+  // normalises again: 3 flops per element.
+  __shared__ float we[MAXL], wp[MAXL], mu[MAXL], rs[MAXL], pp[MAXL][3];
+  __shared__ float part[4][64], tail[4][8], cst[256];      // cst: [gamma | beta | wpool | wppool] in STORAGE order (position p: feature sigma)
   const int s = blockIdx.x, tid = threadIdx.x;
   const int L = len[s], row0 = start[s];
   const bool lig = s >= B;
@@ -953,46 +950,63 @@ __global__ __launch_bounds__(256) void k_poolb(const bf16* __restrict__ x, const
     const int p = tid & 63, f = 16 * (p >> 4) + sigma16(p & 15), which = tid >> 6;
     cst[tid] = prm[(which == 0 ? po.rec_tf.gF : which == 1 ? po.rec_tf.bF : which == 2 ? q.wpool : q.wppool) + f];
   }
+  const float bpool = prm[q.bpool], bppool = prm[q.bppool];
   __syncthreads();
-  if (tid < L) {
-    const bf16* xr = x + (int64_t)(row0 + tid) * DM;
-    float v[64];
+  // phase 1: four lanes per residue (16 storage positions each), 64 residues per pass; the row statistics and the two logits are
+  // sums over the four lanes (two DPP quad exchanges)
+  auto quad = [](float v) __attribute__((always_inline)) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm 1,0,3,2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm 2,3,0,1
+    return v;
+  };
+  const int pt = tid & 3;
+  for (int base = 0; base < L; base += 64) {
+    const int tok = base + (tid >> 2);
+    const bool ok = tok < L;
+    float v[16];
+    {
+      const bf16* xr = x + (int64_t)(row0 + (ok ? tok : 0)) * DM + 16 * pt;
+      const bf16x8 u0 = *reinterpret_cast<const bf16x8*>(xr), u1 = *reinterpret_cast<const bf16x8*>(xr + 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { v[j] = (float)u0[j]; v[8 + j] = (float)u1[j]; }
+    }
     float sum = 0.f;
 #pragma unroll
-    for (int gi = 0; gi < 8; gi++) {
-      const bf16x8 u = *reinterpret_cast<const bf16x8*>(xr + 8 * gi);
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        v[8 * gi + j] = (float)u[j];
-        sum += v[8 * gi + j];
-      }
-    }
-    const float mean = sum * (1.f / 64.f);
+    for (int p = 0; p < 16; p++) sum += v[p];
+    const float mean = quad(sum) * (1.f / 64.f);
     float var = 0.f;
 #pragma unroll
-    for (int p = 0; p < 64; p++) var = fmaf(v[p] - mean, v[p] - mean, var);
-    const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + 1e-5f);
-    float a = prm[q.bpool], b = prm[q.bppool];
+    for (int p = 0; p < 16; p++) var = fmaf(v[p] - mean, v[p] - mean, var);
+    const float rstd = 1.f / sqrtf(quad(var) * (1.f / 64.f) + 1e-5f);
+    float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int p = 0; p < 64; p++) {
-      const float u = (v[p] - mean) * rstd * cst[p] + cst[64 + p];
-      xn[tid][p] = u;                                  // (storage order: the column sums below undo it when they write xs)
-      a = fmaf(u, cst[128 + p], a);
-      b = fmaf(u, cst[192 + p], b);
-      if (enc_dbg) enc_dbg[(int64_t)(row0 + tid) * DM + 16 * (p >> 4) + sigma16(p & 15)] = u;
+    for (int p = 0; p < 16; p++) {
+      const int sp = 16 * pt + p;
+      const float u = (v[p] - mean) * rstd * cst[sp] + cst[64 + sp];
+      a = fmaf(u, cst[128 + sp], a);
+      b = fmaf(u, cst[192 + sp], b);
+      if (enc_dbg && ok) enc_dbg[(int64_t)(row0 + tok) * DM + 16 * pt + sigma16(p)] = u;
     }
-    we[tid] = sigm(a);
-    wp[tid] = sigm(b);
-    pp[tid][0] = pos[(src0 + tid) * 3];
-    pp[tid][1] = pos[(src0 + tid) * 3 + 1];
-    pp[tid][2] = pos[(src0 + tid) * 3 + 2];
+    a = quad(a);
+    b = quad(b);
+    if (ok && pt == 0) {
+      we[tok] = sigm(a + bpool);
+      wp[tok] = sigm(b + bppool);
+      mu[tok] = mean;
+      rs[tok] = rstd;
+    }
+    if (ok && pt < 3) pp[tok][pt] = pos[(src0 + tok) * 3 + pt];
   }
   __syncthreads();
+  // column sums: thread (storage position c, quarter qu) over the residues l = qu, qu + 4, ...  (fixed order)
   const int c = tid & 63, qu = tid >> 6;
+  const float gam = cst[c], bet = cst[64 + c];
+  const bf16* xc = x + (int64_t)row0 * DM + c;
   float acc = 0.f, se = 0.f, sp = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
-#pragma unroll 8
+#pragma unroll 4
   for (int l = qu; l < L; l += 4) {
-    acc = fmaf(we[l], xn[l][c], acc);
+    const float u = ((float)xc[(int64_t)l * DM] - mu[l]) * rs[l] * gam + bet;
+    acc = fmaf(we[l], u, acc);
     if (c == 0) {
       se += we[l];
       sp += wp[l];
@@ -1063,8 +1077,7 @@ static WsB carve_ws(const Dims& s, int64_t n, void* mem) {
 }
 size_t bf16_workspace_bytes(const Dims& s, int64_t n_rec, int64_t n_lig) { return carve_ws(s, n_rec + n_lig, nullptr).bytes; }
 
-constexpr int POOL_LDS = (MAXL * 65 + MAXL * 2 + MAXL * 3 + 4 * 64 + 4 * 8 + 256) * 4;
-static PerDevice g_embed, g_attn, g_ffn, g_pool;
+static PerDevice g_embed, g_attn, g_ffn;
 
 int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* rres, const float* rpos, const float* rang, const int64_t* roff,
                  int64_t n_rec, const float* lres, const float* lpos, const float* lang, const int64_t* loff, int64_t n_lig, const int64_t* t,
@@ -1075,7 +1088,6 @@ int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* r
   const WsB w = carve_ws(s, n, workspace);
   TRY(ensure_dyn_lds(g_embed, (const void*)k_embed, EMB_LDS));
   TRY(ensure_dyn_lds(g_attn, (const void*)k_attn, ATT_LDS));
-  TRY(ensure_dyn_lds(g_pool, (const void*)k_poolb, POOL_LDS));
   int cap = 256;
   TRY(resident_blocks(g_ffn, (const void*)k_ffn, FFN_THREADS, FFN_LDS, &cap));
   hipLaunchKernelGGL(k_image, dim3(512), dim3(256), 0, st, prm, w.img, po, im, s.T, s.Cd);
@@ -1093,7 +1105,7 @@ int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* r
   }
   const float neg_emb = (float)(-(log(10000.0) / (DM / 2 - 1)));
   hipLaunchKernelGGL(k_time_embb, dim3((unsigned)((B * DM + 255) / 256)), dim3(256), 0, st, t, w.pv, B, neg_emb);
-  hipLaunchKernelGGL(k_poolb, dim3((unsigned)S), dim3(256), POOL_LDS, st, w.xa, prm, po, rpos, lpos, w.start, w.len, B, n_rec, w.xs, w.pv, (float*)nullptr);
+  hipLaunchKernelGGL(k_poolb, dim3((unsigned)S), dim3(256), 0, st, w.xa, prm, po, rpos, lpos, w.start, w.len, B, n_rec, w.xs, w.pv, (float*)nullptr);
   TRY(check_launch());
   const int d = DM, pw = s.pw();
   TRY(gemm(st, rowmajor(w.xs, d), transposed(prm + po.rec.wlin, d), w.pv + d, pw, (int)B, d, d, prm + po.rec.blin));
