@@ -827,30 +827,34 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
       buf = buf + 1 == FFN_NBUF ? 0 : buf + 1;
       const char* w2 = w1 + 64 * 64 * 2;
       const float* b1 = reinterpret_cast<const float*>(w2 + 64 * 64 * 2);
-      // Source order = issue order wanted: every LDS operand read is requested one phase before the MFMAs that take it (the W2
-      // fragments before the ReLU / pack block, the next half's W1 fragments and bias before the second product), so that a wave
-      // never sits on an LDS round trip with its partner wave doing the same.
-      bf16x8 a1[4];
-      f32x16 h[2];
-      auto load_w1 = [&](int ht) __attribute__((always_inline)) {
+      // A software pipeline over the chunk's two 32-unit halves, in SOURCE order = the issue order wanted:
+      //   P1(0) P1(1) | relu(0) | P2(0) | relu(1) | P2(1)        (P1 = W1 x + b1: 8 MFMAs; relu = ReLU + pack: 32 VALU; P2 = W2 h: 8 MFMAs)
+      // relu(0) runs on the vector ALU while P1(1)'s MFMAs are still in the matrix pipe, relu(1) while P2(0)'s are: the pipe is not
+      // left idle for a whole ReLU / pack block per half (66 us of the 470 per layer by ablation).  Every LDS operand read is
+      // requested a phase before its MFMAs.
+      f32x16 h[2][2];       // [half][token tile]
+      bf16x8 a1[2][4];
 #pragma unroll
-        for (int gi = 0; gi < 4; gi++) a1[gi] = lds_frag(w1, 32 * ht + c32, 2 * gi + hh);
+      for (int ht = 0; ht < 2; ht++) {
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) a1[ht][gi] = lds_frag(w1, 32 * ht + c32, 2 * gi + hh);
 #pragma unroll
         for (int tt = 0; tt < 2; tt++)     // the accumulators start as the bias, read per token tile from its own copy (no register copy)
 #pragma unroll
           for (int r4 = 0; r4 < 4; r4++) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1 + 64 * tt + 32 * ht + 8 * r4 + 4 * hh);
 #pragma unroll
-            for (int r = 0; r < 4; r++) h[tt][4 * r4 + r] = b4[r];
+            for (int r = 0; r < 4; r++) h[ht][tt][4 * r4 + r] = b4[r];
           }
-      };
-      load_w1(0);
+      }
 #pragma unroll
-      for (int ht = 0; ht < 2; ht++) {
+      for (int ht = 0; ht < 2; ht++)
 #pragma unroll
         for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-          for (int gi = 0; gi < 4; gi++) h[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[gi], xb[tt][gi], h[tt], 0, 0, 0);
+          for (int gi = 0; gi < 4; gi++) h[ht][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ht][gi], xb[tt][gi], h[ht][tt], 0, 0, 0);
+#pragma unroll
+      for (int ht = 0; ht < 2; ht++) {
         bf16x8 a2[2][2];
 #pragma unroll
         for (int ot = 0; ot < 2; ot++)
@@ -863,20 +867,19 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
 #if defined(SO3X_AB_BUILD) && defined(PROT_AB_NORELU)      // timing ablation: the accumulators' first words as they are
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            t0[r] = __builtin_bit_cast(uint32_t, h[tt][r]);
-            t1[r] = __builtin_bit_cast(uint32_t, h[tt][8 + r]);
+            t0[r] = __builtin_bit_cast(uint32_t, h[ht][tt][r]);
+            t1[r] = __builtin_bit_cast(uint32_t, h[ht][tt][8 + r]);
           }
 #else
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            t0[r] = relu_pk(pack_bf16(h[tt][2 * r], h[tt][2 * r + 1]));
-            t1[r] = relu_pk(pack_bf16(h[tt][8 + 2 * r], h[tt][9 + 2 * r]));
+            t0[r] = relu_pk(pack_bf16(h[ht][tt][2 * r], h[ht][tt][2 * r + 1]));
+            t1[r] = relu_pk(pack_bf16(h[ht][tt][8 + 2 * r], h[ht][tt][9 + 2 * r]));
           }
 #endif
           hb[tt][0] = __builtin_bit_cast(bf16x8, t0);
           hb[tt][1] = __builtin_bit_cast(bf16x8, t1);
         }
-        if (ht == 0) load_w1(1);
 #pragma unroll
         for (int ot = 0; ot < 2; ot++)
 #pragma unroll
