@@ -670,7 +670,7 @@ bool bf16_supported(const Dims& s);
 size_t bf16_workspace_bytes(const Dims& s, int64_t n_rec, int64_t n_lig);
 int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* rres, const float* rpos, const float* rang, const int64_t* roff,
                  int64_t n_rec, const float* lres, const float* lpos, const float* lang, const int64_t* loff, int64_t n_lig, const int64_t* t,
-                 float* out, float* pool_out, void* workspace);
+                 float* out, float* pool_out, float* enc_out, void* workspace);
 } }
 
 extern "C" {
@@ -706,11 +706,11 @@ int so3x_protnet_fwd(so3x_stream_t st, const float* params, const float* rec_res
   if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && (!stash || precision != SO3X_PREC_F32))) return SO3X_ERR_INVALID_ARG;   // dropout = a training forward
   if (B && (!params || !rec_res || !rec_pos || !rec_ang || !rec_off || !lig_res || !lig_pos || !lig_ang || !lig_off || !t || !out)) return SO3X_ERR_INVALID_ARG;
   if (precision != SO3X_PREC_F32 && precision != SO3X_PREC_BF16) return SO3X_ERR_UNSUPPORTED;
-  if (precision == SO3X_PREC_BF16 && (!bf16_supported(s) || stash || enc_out)) return SO3X_ERR_UNSUPPORTED;   // (the bf16 form is the inference form)
+  if (precision == SO3X_PREC_BF16 && (!bf16_supported(s) || stash)) return SO3X_ERR_UNSUPPORTED;   // (the bf16 form is the inference form)
   if (B == 0) return SO3X_OK;
   if (!workspace || workspace_bytes < so3x_protnet_workspace_bytes(B, max_len, n_rec, n_lig, dim, heads, t_depth, c_depth, precision)) return SO3X_ERR_WORKSPACE;
   if (precision == SO3X_PREC_BF16)
-    return forward_bf16((hipStream_t)st, s, params, rec_res, rec_pos, rec_ang, rec_off, n_rec, lig_res, lig_pos, lig_ang, lig_off, n_lig, t, out, pool_out, workspace);
+    return forward_bf16((hipStream_t)st, s, params, rec_res, rec_pos, rec_ang, rec_off, n_rec, lig_res, lig_pos, lig_ang, lig_off, n_lig, t, out, pool_out, enc_out, workspace);
   const Acts a = stash ? carve_acts(s, stash, true) : carve_acts(s, workspace, false);
   const Drop dr{dropout_p, seed, rng_offset};
   // (with a stash the workspace is idle in the forward: the backward's dP buffer holds a layer's dropped-out probabilities)

@@ -937,7 +937,7 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
 // form, from the bf16 stream.  One residue per thread for the norm and the two logits, one (feature, quarter) per thread for the sums.
 __global__ __launch_bounds__(256, 4) void k_poolb(const bf16* __restrict__ x, const float* __restrict__ prm, const POff po, const float* __restrict__ rpos,
                                                const float* __restrict__ lpos, const int* __restrict__ start, const int* __restrict__ len, int64_t B,
-                                               int64_t n_rec, float* __restrict__ xs, float* __restrict__ pv, float* __restrict__ enc_dbg) {
+                                               int64_t n_rec, float* __restrict__ xs, float* __restrict__ pv, float* __restrict__ enc_dbg, int64_t Lp) {
   // LDS holds per-residue scalars only (7 KB: many workgroups per CU hide each other's round trips -- the first form kept the
   // normalised rows, 73 KB, two workgroups per CU, and spent its time waiting); phase 2 re-reads the bf16 rows (L2-hot) and
   // normalises again: 3 flops per element.
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256, 4) void k_poolb(const bf16* __restrict__ x, co
       const float u = (v[p] - mean) * rstd * cst[sp] + cst[64 + sp];
       a = fmaf(u, cst[128 + sp], a);
       b = fmaf(u, cst[192 + sp], b);
-      if (enc_dbg && ok) enc_dbg[(int64_t)(row0 + tok) * DM + 16 * pt + sigma16(p)] = u;
+      if (enc_dbg && ok) enc_dbg[((int64_t)s * Lp + tok) * DM + 16 * pt + sigma16(p)] = u;   // (the exact form's padded layout)
     }
     a = quad(a);
     b = quad(b);
@@ -1084,7 +1084,7 @@ static PerDevice g_embed, g_attn, g_ffn;
 
 int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* rres, const float* rpos, const float* rang, const int64_t* roff,
                  int64_t n_rec, const float* lres, const float* lpos, const float* lang, const int64_t* loff, int64_t n_lig, const int64_t* t,
-                 float* out, float* pool_out, void* workspace) {
+                 float* out, float* pool_out, float* enc_out, void* workspace) {
   const POff po = param_offsets(s);
   const Img im = image_layout(s);
   const int64_t n = n_rec + n_lig, S = s.S(), B = s.B;
@@ -1108,7 +1108,11 @@ int forward_bf16(hipStream_t st, const Dims& s, const float* prm, const float* r
   }
   const float neg_emb = (float)(-(log(10000.0) / (DM / 2 - 1)));
   hipLaunchKernelGGL(k_time_embb, dim3((unsigned)((B * DM + 255) / 256)), dim3(256), 0, st, t, w.pv, B, neg_emb);
-  hipLaunchKernelGGL(k_poolb, dim3((unsigned)S), dim3(256), 0, st, w.xa, prm, po, rpos, lpos, w.start, w.len, B, n_rec, w.xs, w.pv, (float*)nullptr);
+  if (enc_out) {   // rec_tf's output in the exact form's padded layout [2 B][max_len][64] (rows past a chain's end: zero)
+    hipError_t e = hipMemsetAsync(enc_out, 0, (size_t)S * s.Lp * DM * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k_poolb, dim3((unsigned)S), dim3(256), 0, st, w.xa, prm, po, rpos, lpos, w.start, w.len, B, n_rec, w.xs, w.pv, enc_out, s.Lp);
   TRY(check_launch());
   const int d = DM, pw = s.pw();
   TRY(gemm(st, rowmajor(w.xs, d), transposed(prm + po.rec.wlin, d), w.pv + d, pw, (int)B, d, d, prm + po.rec.blin));

@@ -375,10 +375,10 @@ int so3x_planenet_bwd(so3x_stream_t s, const float* params, const float* x, cons
  *           (prot_train.py's own defaults -- dim 1024, 8 heads, t_depth 12, c_depth 8 -- included);
  *           SO3X_PREC_BF16: the class defaults' width (dim 64, 4 heads; any t_depth <= 8, c_depth <= 8, max_len <= 256): bf16
  *           operands / fp32 accumulate, one persistent workgroup per chain with the chain's activations in LDS; forward only
- *           (stash and enc_out must be NULL), else SO3X_ERR_UNSUPPORTED.
+ *           (stash must be NULL), else SO3X_ERR_UNSUPPORTED.
  * so3x_protnet_fwd: stash == NULL: inference.  stash != NULL (so3x_protnet_stash_bytes): activations kept for so3x_protnet_bwd.
  *   pool_out (optional) [B][3 dim + 6]: the head's input; enc_out (optional) [2 B][max_len][dim]: rec_tf's output in the padded
- *   layout (receptors first; rows past a chain's length hold what the reference's padded rows hold).
+ *   layout (receptors first; rows past a chain's length hold what the reference's padded rows hold -- exact form -- or zeros -- bf16 form).
  * so3x_protnet_bwd: dparams[param_count] (overwritten) = d sum(out * dout) / d params for dout [B][6], from the stash of the
  *   forward.  (The inputs carry no gradient: they are a projection of the noised pose, diffusion.py:558-559.)  Deterministic.
  * dropout_p in [0, 1), seed, rng_offset (exact-fp32 form, needs a stash: it is a training forward): the training-mode arithmetic

@@ -416,3 +416,50 @@ def test_training_mode_dropout_vs_the_reference_arithmetic_with_the_same_masks(g
     with torch.no_grad():
         a, b = net(to_dev(data), t), net(to_dev(data), t)
     assert torch.equal(a.rot_g, b.rot_g) and float((torch.cat((a.rot_g, a.shift_g), -1).cpu() - torch.from_numpy(g["small_out"])).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_bf16_edge_lengths_vs_the_fp32_form():
+    """chain lengths that hit every branch of the bf16 kernels -- 1 residue, one short of / exactly / one past a 16-, 32- and 64-row
+    tile, the 256-residue maximum, receptor shorter than its ligand -- against the exact-fp32 form on the same weights and inputs
+    (itself pinned to the reference).  Gate: 5e-2 of the output's scale.  What bf16 operands cost is a property of the WEIGHTS, not of
+    a length: every product rounds its operands to 8 bits, ~0.5 % of the activations' scale per encoder layer (measured per layer and
+    per chain, tools/ab/protnet_edge_dbg.py; an fp32 residual stream and exact sines were tried and change nothing): the golden
+    weights land at 2.2 % on the output, these at 3.4 %, the worst single complex below at 4.5 %."""
+    from so3x.models import ProtNet
+    lengths = [(1, 1), (15, 16), (17, 31), (32, 33), (63, 64), (65, 127), (128, 129), (255, 256), (256, 2), (3, 200)]
+    data = to_dev(synthetic_complexes(lengths, 77))
+    torch.manual_seed(5)
+    net = ProtNet(precision="bf16", dropout=0.0).eval()
+    protnet_perturb(net, 9)
+    net = net.to(DEV)
+    t = torch.randint(0, 1000, (len(lengths),), device=DEV)
+    with torch.no_grad():
+        got = net(data, t)
+        net.precision = "fp32"
+        want = net(data, t)
+    a, b = torch.cat((got.rot_g, got.shift_g), -1), torch.cat((want.rot_g, want.shift_g), -1)
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) < 5e-2 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+    # rec_tf's output, residue by residue (padded layout): no residue further than a fifth of the encoder's scale, the mean error a
+    # few per cent of it -- a wrong mask or tile boundary shows as O(1) differences at the affected residues
+    from so3x import backend as B
+    batch = B.ProtBatch.from_pairs(data)
+    with torch.no_grad():
+        e16 = B.protnet_fwd(net.flat_params_nograd(), batch, t, *net.cfg, precision=B.PREC_BF16, want_encoding=True)[3]
+        e32 = B.protnet_fwd(net.flat_params_nograd(), batch, t, *net.cfg, precision=B.PREC_F32, want_encoding=True)[3]
+    scale = float(e32.abs().max())
+    for i, (lr, ll) in enumerate(lengths):
+        for s_, L in ((i, lr), (len(lengths) + i, ll)):
+            d = (e16[s_, :L] - e32[s_, :L]).abs()
+            assert float(d.max()) < 0.25 * scale and float(d.mean()) < 0.05 * scale, (s_, L, float(d.max()), float(d.mean()), scale)
+            assert float(e16[s_, L:].abs().max() if L < e16.shape[1] else 0.0) == 0.0
+    # longer than the bf16 kernels hold in LDS: refused, not truncated
+    long = to_dev(synthetic_complexes([(257, 10)], 78))
+    net.precision = "bf16"
+    with pytest.raises(Exception):
+        with torch.no_grad():
+            net(long, t[:1])
+    net.precision = "fp32"
+    with torch.no_grad():
+        assert torch.isfinite(net(long, t[:1]).rot_g).all()
