@@ -42,12 +42,17 @@ __global__ __launch_bounds__(256) void k_cvt_f32(const bf16* __restrict__ src, f
 // ------------------------------------------------------------------------------------------------ GEMM
 // C[M][N] = act(A[M][K] W[N][K]^T + bias[N] (+ R[M][N])),  M % 128 == N % 128 == K % 64 == 0
 constexpr int BM = 128, BN = 128, BK = 64;
+// the 128-wide kernel's fp32 C tile in LDS: rows of 132 floats.  With 128 (512 bytes) the four row groups a wave's accumulator store
+// touches (lane >> 4) fell into the same banks -- 4-way conflicts on all 64 stores of the epilogue, 15-22 % of the kernel's LDS cycles
+// by PMC (r05); 132 puts them 16 banks apart.  67,584 bytes: dynamic LDS (two workgroups per CU still fit).
+constexpr int CLD = 132, GEMM128_LDS = BM * CLD * 4;
+static PerDevice g_gemm128[8];
 
 template <int EPI, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                       const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
                                                       int lda, int ldw, int ldc, int ldr, const GemmDrop gd) {
-  __shared__ __attribute__((aligned(16))) char smem[65536];   // 2 x (A tile 16 KB | W tile 16 KB); then the fp32 C tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A tile 16 KB | W tile 16 KB); then the fp32 C tile, rows of CLD floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int ntn = N / BN, nwg = ntn * (M / BM);
   // XCD-contiguous tile order (workgroup ids round-robin over the 8 XCDs; bijective for any nwg): tiles that share an A panel
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) sc[(wm * 64 + i * 16 + (lane >> 4) * 4 + e) * 128 + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
+      for (int e = 0; e < 4; e++) sc[(wm * 64 + i * 16 + (lane >> 4) * 4 + e) * CLD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
   __syncthreads();
   const int c4 = (tid & 31) * 4;
   const float4 bv = *reinterpret_cast<const float4*>(bias + tn * BN + c4);
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const int row = it * 8 + (tid >> 5);
-    float4 v = *reinterpret_cast<const float4*>(sc + row * 128 + c4);
+    float4 v = *reinterpret_cast<const float4*>(sc + row * CLD + c4);
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     const size_t grow = (size_t)tm * BM + row;
     if constexpr (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -427,7 +432,8 @@ static int gemm_bf16_t(hipStream_t s, const bf16* A, int lda, const bf16* W, int
     const int ntiles = (M / TB) * (N / TB);
     hipLaunchKernelGGL((k_gemm256_bf16<EPI, DROP>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
   } else {
-    hipLaunchKernelGGL((k_gemm_bf16<EPI, DROP>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
+    if (int rc = ensure_dyn_lds(g_gemm128[2 * EPI + (DROP ? 1 : 0)], (const void*)k_gemm_bf16<EPI, DROP>, GEMM128_LDS)) return rc;
+    hipLaunchKernelGGL((k_gemm_bf16<EPI, DROP>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), GEMM128_LDS, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
   }
   return check_launch();
 }
