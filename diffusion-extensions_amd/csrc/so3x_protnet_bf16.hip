@@ -521,6 +521,14 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
       xf[t][ks] = v;
     }
   }
+  bf16x8 wqf[NH][2];     // the query rows of in_proj and their bias, all heads: requested HERE, with the input rows and the K / V
+  f32x4 bq[NH];          // fragments below -- one round trip to L2 for all of them, not one per phase
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) wqf[h][ks] = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(16 * h + q) * 64 + 32 * ks + 8 * g);
+    bq[h] = *reinterpret_cast<const f32x4*>(vec + 16 * h + 4 * g);
+  }
   // K (rows 64 .. 127 of in_proj) and V (rows 128 .. 191) of this wave's residues -> LDS.  The 16 weight fragments and the biases are
   // loaded ONCE, ahead of the tile loop (the image sits in L2, ~1 us away: a load in front of every product made this phase 180 us
   // of the kernel's 530 at 4096 x 256: tools/ab/ab_protnet_libs.py).
@@ -562,14 +570,6 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
   __syncthreads();
   // attention of this wave's queries over the chain's keys, one head at a time
   bf16x4 ob[4][4];       // [query tile][head]: the normalised head outputs, lane (query q, g): head features 4 g + r
-  bf16x8 wqf[NH][2];     // the query rows of in_proj and their bias, all heads, loaded once (as the K / V fragments above)
-  f32x4 bq[NH];
-#pragma unroll
-  for (int h = 0; h < NH; h++) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) wqf[h][ks] = *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(16 * h + q) * 64 + 32 * ks + 8 * g);
-    bq[h] = *reinterpret_cast<const f32x4*>(vec + 16 * h + 4 * g);
-  }
   // Q of all heads first (then the input fragments and the query weights are dead registers during the head loop)
   bf16x4 qall[NH][4];
 #pragma unroll
@@ -686,6 +686,9 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
     default: break;      // a wave without queries multiplies nothing
   }
 #endif
+#if defined(SO3X_AB_BUILD) && defined(PROT_AB_ATT_NOOUT)   // timing ablation: no out-projection / LayerNorm / store
+  if (L >= 0) return;
+#endif
   // out-projection (16x16x32, K = two heads per step), residual, LayerNorm 1 -> y in storage order; weights and row constants first
   bf16x8 wof[4][2];
   f32x4 bo4[4], g14[4], be14[4];
@@ -696,6 +699,16 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
     bo4[ft] = *reinterpret_cast<const f32x4*>(vec + 192 + 16 * ft + 4 * g);
     g14[ft] = *reinterpret_cast<const f32x4*>(vec + 256 + 16 * ft + 4 * g);
     be14[ft] = *reinterpret_cast<const f32x4*>(vec + 320 + 16 * ft + 4 * g);
+  }
+  // the residual rows of all four tiles, requested together with the weights above (a load per tile inside the loop below was a
+  // round trip to memory per tile: 122 us of the kernel's 330 per layer by ablation)
+  bf16x4 xres[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int tok = tok0 + 16 * t + q;
+    const bf16* xr = x + (int64_t)(row0 + (tok < L ? tok : 0)) * DM;
+#pragma unroll
+    for (int ft = 0; ft < 4; ft++) xres[t][ft] = *reinterpret_cast<const bf16x4*>(xr + 16 * ft + sigma16_inv(4 * g));
   }
 #pragma unroll
   for (int t = 0; t < 4; t++) {
@@ -709,13 +722,12 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
     float v[4][4];
     float sum = 0.f;
     const bool ok = tok < L;
-    const bf16* xr = x + (int64_t)(row0 + (ok ? tok : 0)) * DM;
 #pragma unroll
     for (int ft = 0; ft < 4; ft++) {
       f32x4 acc = bo4[ft];
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wof[ft][ks], of[ks], acc, 0, 0, 0);   // lane (residue q, g): features 16 ft + 4 g + r
-      const bf16x4 xr4 = *reinterpret_cast<const bf16x4*>(xr + 16 * ft + sigma16_inv(4 * g));
+      const bf16x4 xr4 = xres[t][ft];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         v[ft][r] = acc[r] + (float)xr4[r];
@@ -753,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(const bf16* __restrict__ x, bf1
 // 8-wave workgroup stalled the whole CU at every chunk: measured 472 us per layer at 4096 x 256 against this form's 3xx).
 constexpr int FFN_THREADS = 256, FFN_TOK = FFN_THREADS;
 constexpr int FFN_NBUF = 3;        // chunk c + 2 is in flight while chunk c is multiplied
-constexpr int FFN_LDS = FFN_NBUF * (int)CHUNK_BYTES;
+constexpr int FFN_LDS = FFN_NBUF * (int)CHUNK_BYTES + 192 * 4;   // + [b2 | gamma2 | beta2]
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int qchunk) {   // the swizzled image's 16-byte chunk `qchunk` of `row`
 #if defined(SO3X_AB_BUILD) && defined(PROT_AB_NOLDS)       // timing ablation: operands made up in registers
@@ -771,6 +783,10 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
   const int c32 = lane & 31, hh = lane >> 5;
   const char* ffn = slab + im.ffn;
   const float* vec = reinterpret_cast<const float*>(slab + im.vec);
+  // the epilogue's row constants once per (persistent) workgroup: read from global at the end of every block they were a round trip
+  // to memory per block
+  float* cst = reinterpret_cast<float*>(smem + FFN_NBUF * CHUNK_BYTES);
+  if (tid < 192) cst[tid] = vec[384 + tid];
   const int64_t nblocks = (n + FFN_TOK - 1) / FFN_TOK;
   auto dma = [&](int chunk, int buf) {     // 16,896 bytes = 1056 x 16: lanes 0 .. 255 four times + 32 lanes of wave 0
     const char* src = ffn + (size_t)chunk * CHUNK_BYTES;
@@ -899,7 +915,7 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int f = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float v = yacc[tt][ot][r] + vec[384 + f] + (float)xb[tt][2 * ot + (r >> 3)][r & 7];
+          const float v = yacc[tt][ot][r] + cst[f] + (float)xb[tt][2 * ot + (r >> 3)][r & 7];
           yacc[tt][ot][r] = v;
           sum += v;
         }
@@ -923,7 +939,7 @@ __global__ __launch_bounds__(FFN_THREADS, 2) void k_ffn(const bf16* __restrict__
           for (int j = 0; j < 8; j++) {
             const int r = 8 * (gi & 1) + j, ot = gi >> 1;
             const int f = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            o[j] = (bf16)((yacc[tt][ot][r] - mean) * rstd * vec[448 + f] + vec[512 + f]);
+            o[j] = (bf16)((yacc[tt][ot][r] - mean) * rstd * cst[64 + f] + cst[128 + f]);
           }
           *reinterpret_cast<bf16x8*>(y + tok * DM + 16 * gi + 8 * hh) = o;
         }
