@@ -34,6 +34,7 @@ class Adam(torch.optim.Optimizer):
         self.net = net
         self.grad_scale = 1.0
         self._m = self._v = self._step = None
+        self._calls = 0          # update launches issued through this object (step / step_with_reduction); see skipped_steps
 
     def _state(self, flat):
         if self._m is None or self._m.device != flat.device or self._m.numel() != flat.numel():
@@ -55,6 +56,14 @@ class Adam(torch.optim.Optimizer):
     @property
     def step_count(self) -> int:
         return 0 if self._step is None else int(self._step[0].item())
+
+    def skipped_steps(self) -> int:
+        """Updates this optimizer LAUNCHED but the device did not apply: the update kernels leave parameters, moments and the step
+        count untouched when the gradient's first entry is not finite -- the all-NaN gradient of a training step whose in-kernel
+        hand-shake gave up (so3x.h) -- where torch.optim.Adam would write the NaN into the parameters.  A run that has genuinely
+        diverged therefore shows up HERE (and in its loss), not as NaN parameters: check it at your log cadence (one host read).
+        Launches replayed from a captured graph are not counted (TrainStepGraph checks the loss itself, `check_every`)."""
+        return self._calls - self.step_count()
 
     def step(self, closure=None):
         """torch.optim.Adam.step().  Not wrapped by torch.optim.Optimizer's profiling hook (see `hooked` below): step pre/post
@@ -84,6 +93,8 @@ class Adam(torch.optim.Optimizer):
             g = self.param_groups[0]
             frozen = [(a, b, flat[a:b].clone(), m[a:b].clone(), v[a:b].clone()) for a, b in self._frozen_slices()]
             _b.adam_step(flat, grad, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
+            if not torch.cuda.is_current_stream_capturing():
+                self._calls += 1
             for a, b, pf, pm, pv in frozen:
                 flat[a:b].copy_(pf); m[a:b].copy_(pm); v[a:b].copy_(pv)
         return loss
@@ -110,6 +121,8 @@ class Adam(torch.optim.Optimizer):
         m, v, step = self._state(flat)
         g = self.param_groups[0]
         _b.train_bwd_reduce_adam(buf, flat, m, v, step, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale)
+        if not torch.cuda.is_current_stream_capturing():
+            self._calls += 1
 
     def state_dict(self):
         return {"exp_avg": self._m, "exp_avg_sq": self._v, "step": self._step, "param_groups": [dict((k, v) for k, v in g.items() if k != "params")
@@ -120,5 +133,6 @@ class Adam(torch.optim.Optimizer):
         m, v, step = self._state(flat)
         if sd.get("exp_avg") is not None:
             m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"]); step.copy_(sd["step"])
+            self._calls = self.step_count()
         for g, s in zip(self.param_groups, sd.get("param_groups", [])):
             g.update(s)

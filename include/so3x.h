@@ -469,7 +469,10 @@ int so3x_prevstep_loss6(so3x_stream_t s, const float* sched, int T, const float*
  * so3x_adam_step   torch.optim.Adam.step() (so3_train.py:64,76; amsgrad = maximize = False) on flat buffers of n
  *                  floats: the gradient is multiplied by grad_scale first (1/world_size after a summed all-reduce).
  *                  step: TWO device floats, zero-initialised once by the caller: [0] = the step count, advanced by this
- *                  call (torch's state['step']), [1] = scratch. */
+ *                  call (torch's state['step']), [1] = scratch.  A gradient whose FIRST entry is not finite (the all-NaN
+ *                  gradient so3x_train_bwd_reduce writes after a timed-out hand-shake) makes the call a no-op: parameters, moments
+ *                  and step[0] stay as they were (torch.optim.Adam would write the NaN through) -- a caller counts its calls against
+ *                  step[0] to see skipped updates (so3x.optim.Adam.skipped_steps). */
 size_t so3x_train_workspace_bytes(int64_t n, int T);
 int so3x_train_fwd(so3x_stream_t s, const float* params, const float* sched, int T, const float* trap_q, const uint16_t* guide_q,
                    const float* x0, const int64_t* t, int64_t* t_used, int quirk_col0, const float* axes, const float* unif,
