@@ -24,7 +24,8 @@ KNOWN = {
     "k_bwd_stage<1, 1>": (64, "generic staged backward, bf16 with unbounded timesteps: parity / fallback path"),
 }
 HOT = ("k_p_sample_chain", "k_train_fused", "k_resnet_chain", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_fused<1, true>", "k_mlp_fwd_stash",
-       "k_mlp_fwd", "k_q_sample_target", "k_logprob_score", "k_igso3_sample", "k_bwd_reduce", "k_adam", "k_prep")
+       "k_mlp_fwd", "k_q_sample_target", "k_logprob_score", "k_igso3_sample", "k_bwd_reduce", "k_adam", "k_prep",
+       "prot::k_ffn", "k_attn", "prot::k_embed", "k_poolb")
 
 
 @pytest.fixture(scope="module")
@@ -47,6 +48,16 @@ def test_no_scratch_in_hot_kernels(usage):
         if row["scratch"] > allowed:
             bad.append(f"{short}: {row['scratch']} B/lane of scratch (allowed {allowed}), {row['VGPRs']} VGPRs + {row['AGPRs']} AGPRs")
     assert not bad, "register spills:\n" + "\n".join(bad)
+
+
+def test_register_budgets_of_the_protnet_kernels(usage):
+    """two workgroups per CU is what k_ffn / k_attn / k_embed count on (LDS sized for it): <= 256 registers, no scratch"""
+    seen = 0
+    for name, row in usage.items():
+        if "prot" in name and any(k in name for k in ("k_ffn", "k_attn", "k_embed")):
+            seen += 1
+            assert row["VGPRs"] + row["AGPRs"] <= 256 and row["occ"] >= 2 and row["scratch"] == 0, (name, row)
+    assert seen == 3
 
 
 def test_register_budgets_of_the_chain_kernels(usage):
