@@ -117,6 +117,17 @@ __device__ __forceinline__ Hand noise_sample(const NoiseArgs& na, uint64_t rng_o
   return hd;
 }
 
+// Index of the 256-entry SiLU table for a pre-activation coordinate: round to nearest, saturated to 0..255.
+__device__ __forceinline__ unsigned tab_index(float u) {
+  unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u, 0u, 0u);
+#if defined(SO3X_AB_BUILD) && defined(FUSED_AB_TAB_SPREAD)
+  // counters-only build (tools/ab/fused_bounds.sh): lane l reads an entry of bank group l mod 16, so the sixteen 16-byte reads of
+  // one LDS clock never share a bank; the values are wrong, the instruction stream is the same
+  idx = (idx & ~15u) | (threadIdx.x & 15u);
+#endif
+  return idx;
+}
+
 // SiLU and its derivative for one layer's 33 pre-activation coordinates u = 16 z + 127.5 (the MFMAs emit them: GATHER_TD image):
 // hp = silu(z) as packed bf16 pairs in the order of the next layer's B operand (word w of k-step k = hp[4 k + w]; word 16 = the
 // fifth k-step's first: feature 64 | the constant ones of rows 68, 69), dp = silu'(z) as packed f16 pairs in the same order.
@@ -133,7 +144,7 @@ __device__ __forceinline__ void activate_td(const f32x16 (&acc)[3], uint32_t (&h
     for (int i = 0; i < G; i++) {
       const int q = G * g + i;
       u[g & 1][i] = acc[q >> 4][q & 15];
-      const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[g & 1][i], 0u, 0u);  // round to nearest, saturated to 0..255
+      const unsigned idx = tab_index(u[g & 1][i]);
       e[g & 1][i] = *reinterpret_cast<const float4*>(tab + idx * 16);
     }
   };
@@ -143,7 +154,7 @@ __device__ __forceinline__ void activate_td(const f32x16 (&acc)[3], uint32_t (&h
 #pragma unroll
   for (int g = 0; g < NG; g++) {
     if (g + 1 < NG) lookups(g + 1);
-    else el = *reinterpret_cast<const float4*>(tab + __builtin_amdgcn_cvt_pk_u8_f32(ul, 0u, 0u) * 16);
+    else el = *reinterpret_cast<const float4*>(tab + tab_index(ul) * 16);
 #pragma unroll
     for (int i = 0; i < G; i += 2) {
       const float4 e0 = e[g & 1][i], e1 = e[g & 1][i + 1];
@@ -194,7 +205,7 @@ __device__ __forceinline__ void hidden_fwd_td(const char* __restrict__ wl, const
     for (int i = 0; i < G; i++) {
       const int q = G * g + i;
       u[g & 1][i] = acc[q >> 4][q & 15];
-      const unsigned idx = __builtin_amdgcn_cvt_pk_u8_f32(u[g & 1][i], 0u, 0u);  // round to nearest, saturated to 0..255
+      const unsigned idx = tab_index(u[g & 1][i]);
       e[g & 1][i] = *reinterpret_cast<const float4*>(tab + idx * 16);
     }
   };
@@ -214,7 +225,7 @@ __device__ __forceinline__ void hidden_fwd_td(const char* __restrict__ wl, const
     if (g == 2) { mm(6); mm(7); }
     if (g == 3) { mm(8); mm(9); }
     if (g + 1 < NG) lookups(g + 1);
-    else { ul = acc[2][0]; el = *reinterpret_cast<const float4*>(tab + __builtin_amdgcn_cvt_pk_u8_f32(ul, 0u, 0u) * 16); }
+    else { ul = acc[2][0]; el = *reinterpret_cast<const float4*>(tab + tab_index(ul) * 16); }
 #pragma unroll
     for (int i = 0; i < G; i += 2) {
       const float4 e0 = e[g & 1][i], e1 = e[g & 1][i + 1];

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B of so3x_train_fused ALONE (prep launch + the one kernel; raw C ABI through ctypes) between builds of libso3x.so, interleaved
-in one process, 2^19 rotations:   python tools/ab/ab_fused_libs.py build/libso3x_a.so build/libso3x_b.so ... [--json out.json] [--step]
+in one process, 2^19 rotations:   python tools/ab/ab_fused_libs.py build/libso3x_a.so build/libso3x_b.so ... [--json out.json] [--step] [--t-const]
 (--step: the whole training step -- + so3x_train_bwd_reduce_adam -- replayed as a captured hipGraph, as bench.py's train_step leg runs it)
+(--t-const: every rotation at timestep 500 instead of a drawn one -- the kernel then touches ONE row of the 4 MB inverse-CDF table;
+the FETCH_SIZE difference to the default run is what the table's cold fills cost: tools/ab/fused_bounds.sh)
 (timing builds made with tools/ab/build_variant.sh <name> "<flags>" so3x_train_fused.hip may compute garbage: only their time counts)"""
 import ctypes as C
 import json
@@ -21,6 +23,7 @@ args = sys.argv[1:]
 out = args[args.index("--json") + 1] if "--json" in args else None
 lg = int(args[args.index("--log2") + 1]) if "--log2" in args else 19
 STEP = "--step" in args
+TCONST = "--t-const" in args
 libs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] not in ("--json", "--log2"))] or [B.LIB_PATH]
 n, T = 1 << lg, 1000
 torch.manual_seed(0)
@@ -30,6 +33,7 @@ trap_q, _ = proc._tables()
 x0 = B.quat_to_rmat(torch.randn(n, 4, device=DEV))
 params = net.flat_data().clone()
 loss = torch.zeros(1, device=DEV)
+t_given = torch.full((n,), 500, dtype=torch.int64, device=DEV) if TCONST else None
 ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 calls = {}
@@ -43,7 +47,7 @@ for path in libs:
 
     def call(l=l, ws=ws, pl=pl, grad=grad, m=m, v=v, stp=stp):
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = l.so3x_train_fused(s, P(pl), P(proc._sched), C.c_int(T), P(trap_q), P(proc._guide_q), P(x0), None, None, C.c_int(1), None, None,
+        rc = l.so3x_train_fused(s, P(pl), P(proc._sched), C.c_int(T), P(trap_q), P(proc._guide_q), P(x0), P(t_given) if TCONST else None, None, C.c_int(1), None, None,
                                 C.c_uint64(1), C.c_uint64(0), P(ctr), C.c_int64(0), C.c_int64(n), P(loss), None, None, P(ws), C.c_size_t(ws.numel()))
         assert rc == 0, rc
         if STEP:
