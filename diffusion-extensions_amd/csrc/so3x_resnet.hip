@@ -300,7 +300,13 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
   // stash_x follows from the early / late schedule below).  Draining the stores at every chunk (vmcnt(0)) instead made
   // the 3.4 GB of dumps add to the compute time rather than hide under it.
   constexpr int DMA = dma_per_chunk<PREC>();
+#if defined(SO3X_AB_BUILD) && defined(RESNET_AB_NO_Y)
+  // timing build (tools/ab/wide_recompute_bound.sh): the training forward WITHOUT its Y dumps -- what a dX chain that recomputes
+  // Y_l = W_l X_l from the X dumps would leave of this kernel
+  constexpr int SY = 0, SX = !STASH ? 0 : 8 * (PREC == SO3X_PREC_BF16 ? 2 : 4);
+#else
   constexpr int SY = !STASH ? 0 : (PREC == SO3X_PREC_BF16 ? 2 : 4), SX = 8 * SY;
+#endif
   constexpr int DMA_OUT = STASH ? 0 : DMA;  // the two waits around the output layer stay conservative (once per pass)
   auto stash_x = [&](const Operand<PREC>& o, int l) {
     if constexpr (STASH && PREC == SO3X_PREC_BF16) {
@@ -312,6 +318,9 @@ __device__ __forceinline__ void forward(const char* __restrict__ gimg, char* rin
     }
   };
   auto stash_y = [&](const f32x16& a, int l, int to) {
+#if defined(SO3X_AB_BUILD) && defined(RESNET_AB_NO_Y)
+    return;
+#endif
     if constexpr (STASH && PREC == SO3X_PREC_BF16) {
       uint32_t p8[8];
 #pragma unroll
@@ -574,6 +583,9 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
     }
     const uint32_t dpk[3] = {h ? 0u : pack2(dd[0], dd[1]), h ? 0u : pack2(dd[2], dd[3]), h ? 0u : pack2(dd[4], dd[5])};
     f32x16 dx[8];
+#if defined(SO3X_AB_BUILD) && defined(RESNET_AB_2X)
+    f32x16 twice = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
     {  // dX_6 = W_out^T dout on the matrix cores: K slots 0..5 of one k-step carry dout (lower lane half), A from the image tail
       const u32x4 bq = {dpk[0], dpk[1], dpk[2], 0u};
       const bf16x8 bop = __builtin_bit_cast(bf16x8, bq);
@@ -637,9 +649,25 @@ k_resnet_bwd(const void* __restrict__ gimg_t, const float* __restrict__ dout, co
           }
         }
         dx[ti] = a;
+#if defined(SO3X_AB_BUILD) && defined(RESNET_AB_2X)
+        // timing build (tools/ab/wide_recompute_bound.sh): this tile's sixteen MFMAs a second time -- the matrix work a chain that
+        // recomputes Y_l = W_l X_l instead of reading it would add (its second weight stream and its X operand registers not counted)
+        {
+          f32x16 a2 = twice;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const u32x4 b = {dzop[4 * k], dzop[4 * k + 1], dzop[4 * k + 2], dzop[4 * k + 3]};
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * 64 + lane], __builtin_bit_cast(bf16x8, b), a2, 0, 0, 0);
+          }
+          twice = a2;
+        }
+#endif
         slot = slot == 2 ? 0 : slot + 1;
       }
     }
+#if defined(SO3X_AB_BUILD) && defined(RESNET_AB_2X)
+    if (twice[0] == 12345.678f) stash_dz[0] = 1;   // keeps the second product alive
+#endif
   }
 }
 
