@@ -773,6 +773,14 @@ def protnet_leg(torch, complexes=4096, rec_len=198, lig_len=58, reps=10):
                          "note": "the exact-fp32 form pads every chain to the longest one and keeps [chains][heads][L][L] probabilities: the parity "
                                  "form, not a throughput form; a bf16 backward is not built",
                          "timing": "HIP events; through autograd (zero_grad, forward, backward)"}
+    # the batch prot_train.py itself defaults to (--batch 4): 1,584 padded residues -- a regime of ~470 small launches, not of flops
+    n_s = 4
+    tb, tt = make(n_s)
+    dout = torch.randn(n_s, 6, device=dev)
+    step()
+    res["train_eval_reference_batch"] = {"complexes": n_s, "ms": min(timed(step, 10) for _ in range(3)), "dropout": 0.1,
+                                         "note": "prot_train.py:22 default batch; bound by launches and per-kernel latency (tools/ab/protnet_small_batch.py)",
+                                         "timing": "HIP events; through autograd (zero_grad, forward, backward)"}
     return res
 
 
@@ -864,6 +872,7 @@ def flat_roofline_keys(line):
         "cfg5_rigid_frac": get(se, "rigid_move", "frac"), "cfg5_noise_frac": get(se, "se3_q_sample_target", "frac"),
         "cfg5_protnet_fwd_frac": get(pt, "forward", "frac"), "cfg5_protnet_fwd_ms": get(pt, "forward", "ms"),
         "cfg5_protnet_train_frac": get(pt, "train_eval", "frac"), "cfg5_protnet_train_ms": get(pt, "train_eval", "ms"),
+        "cfg5_protnet_train_batch4_ms": get(pt, "train_eval_reference_batch", "ms"),
         "wide_chain_frac": get(wn, "chain", "frac"), "wide_train_step_ms": get(wn, "train_step", "ms_per_step"),
         "wide_train_step_frac": get(wn, "train_step", "frac_of_bf16_mfma_peak"),
         "planenet_fwd_256_frac": get(pn, "forward_32x256", "frac"), "planenet_fwd_256_ms": get(pn, "forward_32x256", "ms"),

@@ -113,30 +113,39 @@ int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K
   return check_launch();
 }
 
-// C = A B for a SMALL M x N and a LONG K (a weight gradient: K = every token of the batch): as gemm() the launch would be a handful of
-// workgroups walking all of K (dW of a 64-wide layer: ONE workgroup).  Here K is cut into chunks, one workgroup per (tile, chunk)
-// writes its partial product to slab[chunk][M][N], and k_splitk_sum adds the chunks in a fixed order (deterministic, no atomics).
-__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ slab, int nchunk, int64_t mn, int N, float* __restrict__ C, int64_t ldc) {
+// C = A B for a SMALL M x N and a LONG K (a weight gradient: K = every token of the batch; at the reference's own batch sizes the
+// 2048-long products of the feed-forward block as well): as gemm() the launch would be a handful of workgroups walking all of K (dW of
+// a 64-wide layer: ONE workgroup).  Here K is cut into chunks, one workgroup per (tile, chunk) writes its partial product to
+// slab[chunk][M][N], and k_splitk_sum adds the chunks in a fixed order (deterministic, no atomics), then the bias / the old C.
+__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ slab, int nchunk, int64_t mn, int N, float* __restrict__ C, int64_t ldc,
+                                                    const float* __restrict__ bias, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= mn) return;
   float acc = 0.f;
   for (int z = 0; z < nchunk; z++) acc += slab[(int64_t)z * mn + i];
-  C[(i / N) * ldc + i % N] = acc;
+  float* c = C + (i / N) * ldc + i % N;
+  if (bias) acc += bias[i % N];
+  if (accumulate) acc += *c;
+  *c = acc;
 }
-int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats) {
+int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats, const float* bias,
+                bool accumulate) {
   if (M <= 0 || N <= 0) return SO3X_OK;
   const int64_t tiles = (int64_t)((M + GB - 1) / GB) * ((N + GB - 1) / GB), mn = (int64_t)M * N;
   int nch = (int)(1024 / tiles);                                   // ~4 workgroups per CU
-  if ((int64_t)nch * 512 > K) nch = K / 512;                       // ... of at least 512 of K each
+  // ... of at least 512 of K each where that still fills the chip; down to 128 where it does not: at 1,584 tokens (prot_train.py's
+  // --batch 4) 512 made three chunks -- three workgroups of 33 sequential K tiles (27 us) for a 64 x 64 gradient
+  const int kmin = tiles * (K / 512) >= 256 ? 512 : 128;
+  if ((int64_t)nch * kmin > K) nch = K / kmin;
   if ((size_t)nch * (size_t)mn > slab_floats) nch = (int)(slab_floats / (size_t)mn);
-  if (nch < 2) return gemm(s, A, B, C, ldc, M, N, K);
+  if (nch < 2) return gemm(s, A, B, C, ldc, M, N, K, bias, 1.f, false, accumulate);
   const int kc = ((K + nch - 1) / nch + GK - 1) / GK * GK;
   nch = (K + kc - 1) / kc;
   GemmP p{A.p, B.p, slab, nullptr, M, N, K, A.s0, A.s1, B.s0, B.s1, N, 1, (int64_t)kc * A.s1, 0, (int64_t)kc * B.s0, 0, mn, 0, 1.f, 0, 0, kc};
   const int gy = (M + GB - 1) / GB;
   if (gy > 65535 || nch > 65535) return SO3X_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_gemm_f32, dim3((N + GB - 1) / GB, gy, nch), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, slab, nch, mn, N, C, ldc);
+  hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, slab, nch, mn, N, C, ldc, bias, accumulate ? 1 : 0);
   return check_launch();
 }
 
@@ -260,12 +269,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
 }
 
 // column sums in a fixed order: part[chunk][c] = sum over the chunk's rows of X[row][c] (* xhat[row][c] when r/stats are given:
-// LayerNorm's d gamma), then k_colsum_final adds the chunks.  CH rows per chunk.
+// LayerNorm's d gamma), then k_colsum_final adds the chunks.  ch rows per chunk (colsum_ch).
 __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X, int64_t ld, int64_t rows, int cols, const float* __restrict__ r,
-                                                     int64_t ldr, const float* __restrict__ stats, float* __restrict__ part) {
+                                                     int64_t ldr, const float* __restrict__ stats, float* __restrict__ part, int ch) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.y * CH, r1 = r0 + CH < rows ? r0 + CH : rows;
+  const int64_t r0 = (int64_t)blockIdx.y * ch, r1 = r0 + ch < rows ? r0 + ch : rows;
   float acc = 0.f;
   if (c < cols) {
     for (int64_t i = r0 + g; i < r1; i += 4) {
@@ -278,12 +287,29 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X
   __syncthreads();
   if (g == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// 32 columns per workgroup, eight groups of threads each walking every eighth chunk (four loads in flight), combined in a fixed order
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nchunks, int cols, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float acc = 0.f;
-  for (int i = 0; i < nchunks; i++) acc += part[(int64_t)i * cols + c];
-  out[c] = acc;
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int i = g;
+    for (; i + 24 < nchunks; i += 32) {
+      a0 += part[(int64_t)i * cols + c];
+      a1 += part[(int64_t)(i + 8) * cols + c];
+      a2 += part[(int64_t)(i + 16) * cols + c];
+      a3 += part[(int64_t)(i + 24) * cols + c];
+    }
+    for (; i < nchunks; i += 8) a0 += part[(int64_t)i * cols + c];
+  }
+  red[g][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) a += red[k][threadIdx.x];
+    out[c] = a;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_relu_bwd(float* __restrict__ df, const float* __restrict__ f, int64_t n, float scale) {
@@ -477,9 +503,9 @@ inline BwdBufs carve_bwd(const Shape& s, void* mem) {
 
 int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r, int64_t ldr,
            const float* stats) {
-  const int nch = (int)((rows + CH - 1) / CH);
-  hipLaunchKernelGGL(k_colsum_part, dim3((cols + 63) / 64, nch), dim3(256), 0, s, X, ld, rows, cols, r, ldr, stats, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, part, nch, cols, out);
+  const int ch = colsum_ch(rows), nch = (int)((rows + ch - 1) / ch);
+  hipLaunchKernelGGL(k_colsum_part, dim3((cols + 63) / 64, nch), dim3(256), 0, s, X, ld, rows, cols, r, ldr, stats, part, ch);
+  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 31) / 32), dim3(256), 0, s, part, nch, cols, out);
   return check_launch();
 }
 

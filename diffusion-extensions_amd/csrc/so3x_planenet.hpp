@@ -113,12 +113,26 @@ inline Mat transposed(const float* p, int64_t ld) { return Mat{p, 1, ld}; }   //
 int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, const float* bias = nullptr, float alpha = 1.f,
          bool relu = false, bool accumulate = false, int nb0 = 1, int nb1 = 1, int64_t sA0 = 0, int64_t sA1 = 0, int64_t sB0 = 0,
          int64_t sB1 = 0, int64_t sC0 = 0, int64_t sC1 = 0);
-// the same product (no bias / activation) for a small M x N and a long K, cut over K into slab[chunk][M][N] partials summed in a
+// the same product (no activation) for a small M x N and a long K, cut over K into slab[chunk][M][N] partials summed in a
 // fixed order: what a weight gradient over all tokens needs to fill the chip (falls back to gemm() when K is short)
-int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats);
+// (+ bias, + the old C when `accumulate`, both applied by the kernel that sums the chunks)
+int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats,
+                const float* bias = nullptr, bool accumulate = false);
 // out[c] = sum over rows of X[row][c] (* xhat[row][c] when r / stats are given), fixed order; part: colsum_chunks x cols floats
+// (rows per chunk: about rows / 256 -- between 32 and 512 -- so that a small matrix still makes ~256 chunks: at the reference's own
+//  batch sizes a fixed 512 left a bias gradient to four workgroups whose threads each walked 128 rows one dependent load after the other)
 constexpr int CH = 512;
-inline int colsum_chunks(const Shape& s) { return (int)((s.N() + CH - 1) / CH) + 1; }
+inline int colsum_ch(int64_t rows) {
+  const int64_t c = (rows / 256 + 31) / 32 * 32;
+  return (int)(c < 32 ? 32 : (c > CH ? CH : c));
+}
+// chunks to make room for so that colsum() of ANY matrix of at most `rows` rows fits (a plan sums token-level and batch-level matrices
+// through one buffer): at most 257 chunks while rows / 256 <= 512, rows / 512 beyond
+inline int colsum_chunks_for(int64_t rows) {
+  const int64_t large = (rows + CH - 1) / CH;
+  return (int)(large > 288 ? large : 288) + 1;
+}
+inline int colsum_chunks(const Shape& s) { return colsum_chunks_for(s.N()); }
 int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r = nullptr,
            int64_t ldr = 0, const float* stats = nullptr);
 // row kernels (one wave per row): r = a + b, y = LayerNorm(r) gamma + beta, stats = (mean, rstd); its backward; dS = P o (dP - rowsum(dP o P))

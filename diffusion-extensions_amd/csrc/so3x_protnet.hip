@@ -309,6 +309,8 @@ struct Acts {
   float *enc, *stF, *wE, *wP, *SE, *SP, *xs, *pv;
   float* hz[4];    // the head's pre-activations
   float* ha[4];    // and activations a_0 .. a_3
+  float* slab;     // split-K partials of the feed-forward block's second product (plane::gemm_splitk) when the batch is small
+  size_t slab_floats;
   size_t bytes;
 };
 // per_layer: every encoder layer keeps its own buffers (what the backward reads); else the layers share one set and h ping-pongs
@@ -362,6 +364,10 @@ inline Acts carve_acts(const Dims& s, void* mem, bool per_layer) {
     a.hz[i] = c.take<float>(B * d);
     a.ha[i] = c.take<float>(B * d);
   }
+  // gemm_splitk cuts K only while tiles x chunks <= 1024, i.e. chunks x M x N <= 1024 x 64 x 64 floats -- and not at all from 512
+  // row tiles on: nothing to reserve for a large batch
+  a.slab_floats = s.N() * (size_t)d < ((size_t)4 << 20) ? ((size_t)4 << 20) : 0;
+  a.slab = c.take<float>(a.slab_floats);
   a.bytes = c.off;
   return a;
 }
@@ -370,7 +376,7 @@ struct BwdBufs {
   float *dA, *dB, *dF, *dqkv, *dO, *dprobs, *dsp, *dsa, *dzh, *dxc, *gE, *gP, *dxs, *dpv, *dh0, *dh1, *dhz, *wtmp, *part, *slab;
   size_t bytes, slab_floats;
 };
-inline int part_chunks(const Dims& s) { return (int)((s.R() + plane::CH - 1) / plane::CH) + 1; }
+inline int part_chunks(const Dims& s) { return plane::colsum_chunks_for(s.R()); }
 inline BwdBufs carve_bwd(const Dims& s, void* mem) {
   BwdBufs b;
   Carve c(mem);
@@ -468,7 +474,7 @@ int forward_f32(hipStream_t st, const Dims& s, const float* prm, const float* rr
     TRY(plane::add_ln(st, h, k.r1, k.r1, k.x1, k.st1, prm + lo.g1, prm + lo.be1, N, d, 1e-5f));
     TRY(gemm(st, rowmajor(k.x1, d), transposed(prm + lo.w1, d), k.f, F, (int)N, F, d, prm + lo.b1, 1.f, true));
     if (dr.on()) TRY(dropout_apply(st, dr, l, DROP_FFN, k.f, k.f, N * F));   // (the stash holds the dropped-out activations: what linear2 saw)
-    TRY(gemm(st, rowmajor(k.f, F), transposed(prm + lo.w2, F), k.r2, d, (int)N, d, F, prm + lo.b2));
+    TRY(plane::gemm_splitk(st, rowmajor(k.f, F), transposed(prm + lo.w2, F), k.r2, d, (int)N, d, F, a.slab, a.slab_floats, prm + lo.b2));
     if (dr.on()) TRY(dropout_apply(st, dr, l, DROP_BLOCK2, k.r2, k.r2, N * d));
     TRY(plane::add_ln(st, k.x1, k.r2, k.r2, a.h[l + 1], k.st2, prm + lo.g2, prm + lo.be2, N, d, 1e-5f));
   }
@@ -587,7 +593,7 @@ int backward_f32(hipStream_t st, const Dims& s, const float* prm, const float* d
     TRY(plane::relu_bwd(st, w.dF, k.f, N * F, dr.on() ? dr.inv_keep() : 1.f));
     TRY(gemm_splitk(st, transposed(w.dF, F), rowmajor(k.x1, d), dprm + lo.w1, d, F, d, (int)N, w.slab, w.slab_floats));
     TRY(colsum(st, w.dF, F, N, F, dprm + lo.b1, w.part));
-    TRY(gemm(st, rowmajor(w.dF, F), rowmajor(prm + lo.w1, d), dalt, d, (int)N, d, F, nullptr, 1.f, false, true));   // dalt = d x1
+    TRY(plane::gemm_splitk(st, rowmajor(w.dF, F), rowmajor(prm + lo.w1, d), dalt, d, (int)N, d, F, w.slab, w.slab_floats, nullptr, true));   // dalt = d x1
     // norm1 over r1 = h + attn(h)
     TRY(colsum(st, dalt, d, N, d, dprm + lo.g1, w.part, k.r1, d, k.st1));
     TRY(colsum(st, dalt, d, N, d, dprm + lo.be1, w.part));
