@@ -44,93 +44,115 @@ __global__ __launch_bounds__(256) void k_cvt_f32(const bf16* __restrict__ src, f
 constexpr int BM = 128, BN = 128, BK = 64;
 // the 128-wide kernel's fp32 C tile in LDS: rows of 132 floats.  With 128 (512 bytes) the four row groups a wave's accumulator store
 // touches (lane >> 4) fell into the same banks -- 4-way conflicts on all 64 stores of the epilogue, 15-22 % of the kernel's LDS cycles
-// by PMC (r05); 132 puts them 16 banks apart.  67,584 bytes: dynamic LDS (two workgroups per CU still fit).
-constexpr int CLD = 132, GEMM128_LDS = BM * CLD * 4;
-static PerDevice g_gemm128[8];
+// by PMC (r05); 132 puts them 16 banks apart.  Dynamic LDS (two workgroups per CU still fit).
+constexpr int CLD = 132;
+// dynamic LDS of the MI-fragment form: the larger of its two staging buffers and its C tile (MI = 4: 67,584 bytes; MI = 2: 49,152)
+// (three stages for the short tile -- two K tiles in flight -- were measured: forward 425 -> 429 us at 32 x 256, not kept)
+template <int MI> constexpr int gemm128_stages() { return 2; }
+template <int MI> constexpr int gemm128_lds() {
+  return gemm128_stages<MI>() * (32 * MI * 128 + 16384) > 32 * MI * CLD * 4 ? gemm128_stages<MI>() * (32 * MI * 128 + 16384) : 32 * MI * CLD * 4;
+}
+static PerDevice g_gemm128[16];
 
-template <int EPI, bool DROP>
+// MI = 16-row fragments per wave along M: 4 -> a 128 x 128 tile, 2 -> a 64 x 128 tile (48 KB of staging + C).  The short tile is for
+// the products whose 128-row tiling would not fill the chip twice over: at the 8,192 tokens the reference trains PlaneNet with (32 x
+// 256, aircraft_rotate.py:17-30) a 512-wide output is 256 tiles -- ONE workgroup per CU, whose K tiles (one exposed load round trip
+// each: `vmcnt(0)` + barrier) then have nothing to overlap with: 4.3 GFLOP in 22 us.
+template <int EPI, bool DROP, int MI>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
                                                       const float* __restrict__ bias, const bf16* __restrict__ R, int M, int N, int K,
                                                       int lda, int ldw, int ldc, int ldr, const GemmDrop gd) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A tile 16 KB | W tile 16 KB); then the fp32 C tile, rows of CLD floats
+  constexpr int TM = 32 * MI, ABYTES = TM * 128, STAGE = ABYTES + 16384;   // A tile | W tile (16 KB)
+  constexpr int NST = gemm128_stages<MI>();                     // K tiles in LDS: the one being read + NST - 1 in flight
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NST x (A tile | W tile); then the fp32 C tile, rows of CLD floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int ntn = N / BN, nwg = ntn * (M / BM);
+  const int ntn = N / BN, nwg = ntn * (M / TM);
   // XCD-contiguous tile order (workgroup ids round-robin over the 8 XCDs; bijective for any nwg): tiles that share an A panel
   // run on one XCD and find it in that XCD's L2
   const int bid = blockIdx.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int tm = tile / ntn, tn = tile % ntn;
-  const bf16* Ag = A + (size_t)tm * BM * lda;
+  const bf16* Ag = A + (size_t)tm * TM * lda;
   const bf16* Wg = W + (size_t)tn * BN * ldw;
-  // staging: wave w moves rows 32 w .. 32 w + 31 of both tiles, 8 rows (1 KB) per LDS-DMA instruction; LDS position (row, chunk c)
-  // holds the row's 16-byte chunk c ^ ((row >> 1) & 7)
-  const int srow = wave * 32 + (lane >> 3);
+  // staging: wave w moves rows 32 w .. 32 w + 31 of the W tile and rows 8 MI w .. 8 MI (w + 1) - 1 of the A tile, 8 rows (1 KB) per
+  // LDS-DMA instruction; LDS position (row, chunk c) holds the row's 16-byte chunk c ^ ((row >> 1) & 7)
   auto stage = [&](int kt, int buf) {
-    char* sa = smem + buf * 32768;
-    char* sb = sa + 16384;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + ABYTES;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      const int row = wave * 8 * MI + i * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      GLDS16(Ag + (size_t)row * lda + kt * BK + ch * 8, sa + (wave * 8 * MI + i * 8) * 128);
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int row = srow + i * 8;
+      const int row = wave * 32 + i * 8 + (lane >> 3);
       const int ch = (lane & 7) ^ ((row >> 1) & 7);
-      GLDS16(Ag + (size_t)row * lda + kt * BK + ch * 8, sa + (wave * 32 + i * 8) * 128);
       GLDS16(Wg + (size_t)row * ldw + kt * BK + ch * 8, sb + (wave * 32 + i * 8) * 128);
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fsw = (lane >> 1) & 7;                       // ((row >> 1) & 7) of this lane's fragment rows (row = 16 x + (lane & 15))
-  const int arow = (wm * 64 + (lane & 15)) * 128, brow = (wn * 64 + (lane & 15)) * 128;
+  const int arow = (wm * 16 * MI + (lane & 15)) * 128, brow = (wn * 64 + (lane & 15)) * 128;
   const int KT = K / BK;
   stage(0, 0);
+  if (NST == 3 && KT > 1) stage(1, 1);
+  int buf = 0;
   for (int kt = 0; kt < KT; kt++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed
-    __syncthreads();                                     // ... everyone's have, and everyone is done reading the other buffer
-    if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
-    const char* sa = smem + (kt & 1) * 32768;
-    const char* sb = sa + 16384;
+    // this wave's pieces of tile kt have landed (vmcnt counts in issue order: with three stages the MI + 4 pieces of tile kt + 1
+    // may stay in flight)
+    if (NST == 3 && kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                     // ... everyone's have, and everyone is done reading the buffer staged next
+    if (kt + NST - 1 < KT) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    const char* sa = smem + buf * STAGE;
+    const char* sb = sa + ABYTES;
+    buf = buf == NST - 1 ? 0 : buf + 1;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       const int choff = ((4 * s + (lane >> 4)) ^ fsw) << 4;
-      bf16x8 a[4], b[4];
+      bf16x8 a[MI], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        a[i] = *reinterpret_cast<const bf16x8*>(sa + arow + i * 2048 + choff);
-        b[i] = *reinterpret_cast<const bf16x8*>(sb + brow + i * 2048 + choff);
-      }
+      for (int i = 0; i < MI; i++) a[i] = *reinterpret_cast<const bf16x8*>(sa + arow + i * 2048 + choff);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++) b[i] = *reinterpret_cast<const bf16x8*>(sb + brow + i * 2048 + choff);
+#pragma unroll
+      for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   __syncthreads();
-  float* sc = reinterpret_cast<float*>(smem);            // [128][128] fp32
+  float* sc = reinterpret_cast<float*>(smem);            // [TM][CLD] fp32
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) sc[(wm * 64 + i * 16 + (lane >> 4) * 4 + e) * CLD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
+      for (int e = 0; e < 4; e++) sc[(wm * 16 * MI + i * 16 + (lane >> 4) * 4 + e) * CLD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
   __syncthreads();
   const int c4 = (tid & 31) * 4;
   const float4 bv = *reinterpret_cast<const float4*>(bias + tn * BN + c4);
-  // the residual / mask values of this thread's 16 rows, all requested before the first C store (a load issued behind a store
+  // the residual / mask values of this thread's rows, all requested before the first C store (a load issued behind a store
   // cannot be waited for without retiring the store: vmcnt counts in issue order)
-  bf16x4 rall[16];
+  constexpr int NIT = TM / 8;
+  bf16x4 rall[NIT];
   if constexpr (EPI == EPI_RESID || EPI == EPI_MASK) {
 #pragma unroll
-    for (int it = 0; it < 16; it++)
-      rall[it] = *reinterpret_cast<const bf16x4*>(R + ((size_t)tm * BM + it * 8 + (tid >> 5)) * ldr + tn * BN + c4);
+    for (int it = 0; it < NIT; it++)
+      rall[it] = *reinterpret_cast<const bf16x4*>(R + ((size_t)tm * TM + it * 8 + (tid >> 5)) * ldr + tn * BN + c4);
   }
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
+  for (int it = 0; it < NIT; it++) {
     const int row = it * 8 + (tid >> 5);
     float4 v = *reinterpret_cast<const float4*>(sc + row * CLD + c4);
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    const size_t grow = (size_t)tm * BM + row;
+    const size_t grow = (size_t)tm * TM + row;
     if constexpr (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if constexpr (DROP && (EPI == EPI_RELU || EPI == EPI_RESID)) {
       {   // (four columns per thread: one half of a call's eight flags)
@@ -432,8 +454,14 @@ static int gemm_bf16_t(hipStream_t s, const bf16* A, int lda, const bf16* W, int
     const int ntiles = (M / TB) * (N / TB);
     hipLaunchKernelGGL((k_gemm256_bf16<EPI, DROP>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
   } else {
-    if (int rc = ensure_dyn_lds(g_gemm128[2 * EPI + (DROP ? 1 : 0)], (const void*)k_gemm_bf16<EPI, DROP>, GEMM128_LDS)) return rc;
-    hipLaunchKernelGGL((k_gemm_bf16<EPI, DROP>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), GEMM128_LDS, s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
+    if ((M / BM) * (N / BN) < 1024) {   // fewer than two rounds of 128-row tiles (two workgroups per CU): 64-row tiles
+      // (M % 128 == 0 is the entry point's contract, so 64 divides M)
+      if (int rc = ensure_dyn_lds(g_gemm128[8 + 2 * EPI + (DROP ? 1 : 0)], (const void*)k_gemm_bf16<EPI, DROP, 2>, gemm128_lds<2>())) return rc;
+      hipLaunchKernelGGL((k_gemm_bf16<EPI, DROP, 2>), dim3((unsigned)((M / 64) * (N / BN))), dim3(256), gemm128_lds<2>(), s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
+    } else {
+      if (int rc = ensure_dyn_lds(g_gemm128[2 * EPI + (DROP ? 1 : 0)], (const void*)k_gemm_bf16<EPI, DROP, 4>, gemm128_lds<4>())) return rc;
+      hipLaunchKernelGGL((k_gemm_bf16<EPI, DROP, 4>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), gemm128_lds<4>(), s, A, W, C, bias, R, M, N, K, lda, ldw, ldc, ldr, gd);
+    }
   }
   return check_launch();
 }
