@@ -1,6 +1,8 @@
 """ProtNet training evaluation (forward + backward, exact-fp32 form, dropout 0.1) at the batch sizes prot_train.py actually uses
 (default --batch 4): ms per evaluation by wall clock, i.e. with the host's launch overhead in it.
-   python tools/ab/protnet_small_batch.py [batch ...]"""
+   python tools/ab/protnet_small_batch.py [batch ...] [--script-defaults]
+(--script-defaults: the widths prot_train.py's argparse defaults give -- dim 1024, 8 heads, 12 encoder layers, 8 convolutions --
+instead of the class defaults 64 / 4 / 4 / 3)"""
 import os
 import sys
 import time
@@ -22,8 +24,10 @@ def chains(n, L):
 
 
 torch.manual_seed(0)
-net = ProtNet().to(dev).train()
-for n in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
+BIG = "--script-defaults" in sys.argv
+net = (ProtNet(dim=1024, heads=8, t_depth=12, c_depth=8) if BIG else ProtNet()).to(dev).train()
+print("parameters:", sum(p.numel() for p in net.parameters()))
+for n in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [4, 16, 64]:
     rec, roff = chains(n, lr)
     lig, loff = chains(n, ll)
     batch = B.ProtBatch(rec, lig, roff, loff, max(lr, ll), [(lr, ll)] * n)

@@ -8,6 +8,7 @@ from so3x import backend as B  # noqa: E402
 from so3x.models import ProtNet  # noqa: E402
 dev = torch.device("cuda:0")
 n, lr, ll = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 198, 58
+BIG = "--script-defaults" in sys.argv   # prot_train.py's argparse defaults: dim 1024, 8 heads, 12 layers, 8 convolutions
 g = torch.Generator(device=dev).manual_seed(1)
 
 
@@ -23,7 +24,7 @@ lig, loff = chains(ll)
 batch = B.ProtBatch(rec, lig, roff, loff, max(lr, ll), [(lr, ll)] * n)
 t = torch.randint(0, 1000, (n,), device=dev, generator=g)
 torch.manual_seed(0)
-net = ProtNet().to(dev).train()
+net = (ProtNet(dim=1024, heads=8, t_depth=12, c_depth=8) if BIG else ProtNet()).to(dev).train()
 dout = torch.randn(n, 6, device=dev)
 for _ in range(3):
     net.zero_grad(set_to_none=True)
