@@ -7,6 +7,7 @@
 //   k_gemm_tn        dW[n][k] = sum over tokens dY[tok][n] X[tok][k]: both operands token-major, so both MFMA operands come
 //                    from ds_read_b64_tr_b16; 128 x 128 output tiles, the token axis split over workgroups into fp32 slabs that
 //                    k_slab_reduce adds in a fixed order (deterministic, no atomics);
+//   k_gemm_tn256     the same product on 256 x 256 tiles (from 32,768 tokens on): fewer transposed reads per MFMA;
 //   k_attn_bwd_dq    dQ for 32 queries per wave: S^T, dP^T and dS^T with the query on the lane (as the forward), dQ^T = K^T dS^T
 //                    straight from the accumulator registers;
 //   k_attn_bwd_dkv   dK, dV for 32 keys per wave: S, dP with the key on the lane, dV^T += dO^T P and dK^T += Q^T dS from the
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void k_cvt_bf16_t(const float* __restrict__ pr
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X
+constexpr int TN256_MIN_TOKENS = 32768;   // below: the 128-wide form (more, smaller workgroups)
 // slab[split][n][k] = sum over the split's tokens of Y[tok][n0 + n] X[tok][k0 + k];  Nn % 128 == Kk % 128 == 0, tokens % 64 == 0
 // bpart (optional): the column sums of Y (the bias gradient of the same layer) ride along -- a ones vector as a fifth B operand
 // gives sum_tok Y[tok][n] in every column of a 16 x 16 accumulator; the k-tile index tk picks which 16-row block of its n range a
@@ -153,26 +155,181 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
   }
   reinterpret_cast<float4*>(out)[i] = a;
 }
-constexpr int64_t SLAB_FLOATS = (int64_t)8 * FF * D;   // room for 8 slabs of the largest matrix (or 32 of a 512 x 512 one)
-constexpr int64_t BIAS_PART_FLOATS = (int64_t)32 * FF; // behind them: up to 32 splits of the widest bias
+// ---- the large-T form: 256 x 256 output tiles, 8 waves (2 along n x 4 along k, 128 x 64 of the tile each) -------------------------
+// The 128-wide kernel is bound by its transposed LDS reads: two ds_read_b64_tr_b16 (4 clocks each) per fragment and one fragment per
+// MFMA and operand -- 64 LDS clocks per 32-token step and wave, 512 for the 8 waves of a CU, against 512 matrix-pipe clocks per SIMD:
+// the LDS would have to be busy every clock for the matrix pipe to be (measured: 0.70 PFLOP/s, pipe 28-36 % busy).  A wave that
+// owns 128 x 64 of a 256 x 256 tile reads 12 fragments for 32 MFMAs (0.75 reads per MFMA instead of 2).  K tiles are 32 tokens
+// (Y [32][256] | X [32][256] = 32 KB) through a FOUR-stage ring: three stages in flight behind the one being read (a 32-token
+// step is 0.43 us of MFMAs per SIMD; one stage ahead would expose the load round trip at one workgroup per CU), counted waits.
+// LDS rows are 512 bytes, chunk c of a row at c ^ swz16(row): the swizzle only moves a chunk inside its 256-byte half, where it
+// spreads the four rows a 16-lane group reads over the banks exactly as in the 128-wide image.
+// NKE (0 = no bias): the bias gradient's column sums ride along as in k_gemm_tn -- the n-block i of a wave (16 rows) is summed by the
+// workgroup of k-tile i % NKE, NKE = min(Kk / 256, 8).
+template <int NKE>
+__global__ __launch_bounds__(512, 1) void k_gemm_tn256(const bf16* __restrict__ Y, const bf16* __restrict__ X, float* __restrict__ slab, int T,
+                                                       int Nn, int Kk, int ldy, int ldx, int tok_per_split, float* __restrict__ bpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (Y tile [32 tok][256] 16 KB | X tile 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 2, wk = wave & 3;
+  const int nkt = Kk / 256, tn = blockIdx.x / nkt, tk = blockIdx.x % nkt, split = blockIdx.y;
+  const int t0 = split * tok_per_split, t1 = t0 + tok_per_split < T ? t0 + tok_per_split : T;
+  const int nt = t1 > t0 ? (t1 - t0) / 32 : 0;
+  const bf16* Yg = Y + (size_t)t0 * ldy + tn * 256;
+  const bf16* Xg = X + (size_t)t0 * ldx + tk * 256;
+  // staging: one LDS-DMA instruction = two 512-byte rows; a stage's 16 row pairs per operand go two to a wave
+  const int srow = lane >> 5, spos = lane & 31;
+  auto stage = [&](int j, int buf) {
+    char* sy = smem + buf * 32768;
+    char* sx = sy + 16384;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int rowpair = wave * 2 + i, row = 2 * rowpair + srow;
+      const int ch = spos ^ swz16(row);
+      glds16_asm(Yg + (size_t)(j * 32 + row) * ldy + ch * 8, sy + rowpair * 1024);
+      glds16_asm(Xg + (size_t)(j * 32 + row) * ldx + ch * 8, sx + rowpair * 1024);
+    }
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NB = NKE ? 8 / NKE : 1;
+  f32x4 accb[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool sums = NKE != 0 && bpart != nullptr && wk == 0 && tk < NKE;
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+  // transposed-read lane constants (as k_gemm_tn): the 16-lane group g reads tokens 8 g + (0..3) [+4], lane 4 q + p of the group
+  // supplies row q, columns 4 p .. 4 p + 3 of the 16-column block
+  const int g = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
+  const int sub = (p_ & 1) * 8, clo = p_ >> 1;
+  const int row0 = 8 * g + q_;
+  const int sw0 = swz16(row0), sw1 = swz16(row0 + 4);
+  for (int u = 0; u < 3; u++)
+    if (u < nt) stage(u, u);
+  for (int j = 0; j < nt; j++) {
+    // stage j has landed; up to two younger stages (four DMAs per wave each) stay in flight
+    const int younger = nt - 1 - j;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // ... everyone's has, and everyone is done reading stage j - 1's buffer
+    if (j + 3 < nt) stage(j + 3, (j + 3) & 3);
+    const char* ry = smem + (j & 3) * 32768 + row0 * 512;
+    const char* rx = ry + 16384;
+    bf16x8 a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int cy = 2 * (wn * 8 + i) + clo;
+      const s16x4 y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ry + ((cy ^ sw0) << 4) + sub));
+      const s16x4 y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ry + 2048 + ((cy ^ sw1) << 4) + sub));
+      a[i] = __builtin_bit_cast(bf16x8, (s16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]});
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int cx = 2 * (wk * 4 + i) + clo;
+      const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(rx + ((cx ^ sw0) << 4) + sub));
+      const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(rx + 2048 + ((cx ^ sw1) << 4) + sub));
+      b[i] = __builtin_bit_cast(bf16x8, (s16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]});
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+    if constexpr (NKE != 0) {
+      if (sums) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (i % NKE == tk) accb[i / NKE] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i / NKE], 0, 0, 0);
+      }
+    }
+  }
+  if constexpr (NKE != 0) {
+    if (sums && (lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (i % NKE == tk) {
+          float* bo = bpart + (size_t)split * Nn + tn * 256 + wn * 128 + i * 16 + g * 4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) bo[e] = accb[i / NKE][e];
+        }
+    }
+  }
+  // The tile goes out through LDS, 128 of its rows at a time (all 128 KB: [row][256] fp32, the row's 16-column block c at c ^
+  // ((row >> 2) & 15) so that the four row groups of an accumulator store land 64 bytes apart), and leaves as whole 1 KB rows of
+  // float4 stores.  (Straight from the accumulators every store instruction wrote four 64-byte pieces of four different rows:
+  // 64 MB of slabs per product at a fraction of the write rate.)
+  float* out = slab + (size_t)split * Nn * Kk + (size_t)(tn * 256) * Kk + tk * 256;
+  float* sc = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int hh = 0; hh < 2; hh++) {
+    __syncthreads();   // the ring (first pass) / the previous pass's rows have been read
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int row = wn * 64 + i * 16 + g * 4 + e, cb = wk * 4 + jj;     // row of this pass's 128, 16-column block of 16
+          sc[row * 256 + ((cb ^ ((row >> 2) & 15)) << 4) + (lane & 15)] = acc[4 * hh + i][jj][e];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int row = it * 8 + (tid >> 6), c4 = tid & 63;                     // float4 c4 of the row: block c4 >> 2, quarter c4 & 3
+      const float4 v = *reinterpret_cast<const float4*>(sc + row * 256 + (((c4 >> 2) ^ ((row >> 2) & 15)) << 4) + (c4 & 3) * 4);
+      const int trow = (row >> 6) * 128 + hh * 64 + (row & 63);               // tile row: wave row group wn, pass hh
+      *reinterpret_cast<float4*>(out + (size_t)trow * Kk + c4 * 4) = v;
+    }
+  }
+}
+constexpr int TN256_LDS = 4 * 32768;
+static PerDevice g_tn256[4];
+
+constexpr int64_t SLAB_FLOATS = (int64_t)16 * FF * D;  // room for 16 slabs of the largest matrix (or 64 of a 512 x 512 one)
+constexpr int64_t BIAS_PART_FLOATS = (int64_t)64 * FF; // behind them: up to 64 splits of the widest bias
 // dW[Nn][Kk] (fp32, overwritten) = Y[:T][:Nn]^T X[:T][:Kk].  The token axis is cut into as many slabs as keep ~512 workgroups busy
-// (2 per CU) and fit the slab buffer; the cut depends on the shapes only, so the summation order is fixed.
-// dbias (optional, [Nn]) = the column sums of Y, from the same pass (Kk >= 512: four k-tiles to spread them over).
+// (2 per CU; the 256-wide form: 256, one per CU) and fit the slab buffer; the cut depends on the shapes only, so the summation order
+// is fixed.  dbias (optional, [Nn]) = the column sums of Y, from the same pass (Kk >= 512: the k-tiles to spread them over).
 static int gemm_tn(hipStream_t s, const bf16* Y, int ldy, const bf16* X, int ldx, float* dW, int T, int Nn, int Kk, float* slab,
                    float* dbias = nullptr) {
   if (dbias && Kk < 512) return SO3X_ERR_INVALID_ARG;
   float* bpart = dbias ? slab + SLAB_FLOATS : nullptr;
   if (Nn % 128 || Kk % 128 || T % 64) return SO3X_ERR_INVALID_ARG;
-  const int tiles = (Nn / 128) * (Kk / 128);
-  int nsplit = (512 + tiles - 1) / tiles;
-  if (nsplit > 32) nsplit = 32;
-  if ((int64_t)nsplit * Nn * Kk > SLAB_FLOATS) nsplit = (int)(SLAB_FLOATS / ((int64_t)Nn * Kk));
-  if (nsplit > T / 64) nsplit = T / 64;
-  if (nsplit < 1) nsplit = 1;
-  const int per = ((T / 64 + nsplit - 1) / nsplit) * 64;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, nsplit), dim3(256), 0, s, Y, X, slab, T, Nn, Kk, ldy, ldx, per, bpart);
   const int64_t n4 = (int64_t)Nn * Kk / 4;
   const int nb4 = dbias ? Nn / 4 : 0;
+  int nsplit;
+  const int nkt256 = Kk / 256;
+  if (Nn % 256 == 0 && Kk % 256 == 0 && T >= TN256_MIN_TOKENS && (!dbias || nkt256 == 2 || nkt256 == 4 || nkt256 >= 8)) {
+    const int tiles = (Nn / 256) * nkt256;
+    nsplit = (256 + tiles - 1) / tiles;
+    if (nsplit > 64) nsplit = 64;
+    if ((int64_t)nsplit * Nn * Kk > SLAB_FLOATS) nsplit = (int)(SLAB_FLOATS / ((int64_t)Nn * Kk));
+    if (nsplit > T / 128) nsplit = T / 128;
+    if (nsplit < 1) nsplit = 1;
+    const int per = ((T / 32 + nsplit - 1) / nsplit) * 32;
+    const int nke = !dbias ? 0 : (nkt256 >= 8 ? 8 : nkt256);
+#define SO3X_TN256(NKE, SLOT)                                                                                                         \
+  {                                                                                                                                   \
+    if (int rc = ensure_dyn_lds(g_tn256[SLOT], (const void*)k_gemm_tn256<NKE>, TN256_LDS)) return rc;                                  \
+    hipLaunchKernelGGL(k_gemm_tn256<NKE>, dim3(tiles, nsplit), dim3(512), TN256_LDS, s, Y, X, slab, T, Nn, Kk, ldy, ldx, per, bpart);  \
+  }
+    if (nke == 0) SO3X_TN256(0, 0)
+    else if (nke == 2) SO3X_TN256(2, 1)
+    else if (nke == 4) SO3X_TN256(4, 2)
+    else SO3X_TN256(8, 3)
+#undef SO3X_TN256
+  } else {
+    const int tiles = (Nn / 128) * (Kk / 128);
+    nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > 32) nsplit = 32;
+    if ((int64_t)nsplit * Nn * Kk > SLAB_FLOATS) nsplit = (int)(SLAB_FLOATS / ((int64_t)Nn * Kk));
+    if (nsplit > T / 64) nsplit = T / 64;
+    if (nsplit < 1) nsplit = 1;
+    const int per = ((T / 64 + nsplit - 1) / nsplit) * 64;
+    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, nsplit), dim3(256), 0, s, Y, X, slab, T, Nn, Kk, ldy, ldx, per, bpart);
+  }
   hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + nb4 + 255) / 256)), dim3(256), 0, s, slab, nsplit, n4, dW, bpart, nb4, dbias);
   return check_launch();
 }

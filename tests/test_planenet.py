@@ -337,6 +337,38 @@ def test_full_width_bf16_backward_vs_reference_autograd(golden, P):
 
 
 @pytest.mark.gpu
+def test_bf16_large_batch_backward_equals_the_small_batch_backward(golden):
+    """From 32,768 tokens on the weight gradients take the 256 x 256-tile token-major product (k_gemm_tn256: other tiles, other
+    cuts of the token axis, its own bias column sums); the same clouds four at a time take the 128 x 128-tile one, which the
+    fixtures pin.  The gradient of a sum over clouds is the sum of the groups' gradients: the two must agree to the rounding of the
+    activations' bf16 forms and of fp32 sums taken in another order."""
+    net, _ = full_net(golden, "bf16")
+    net = net.to(DEV).train()
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(16, 2048, 3, device=DEV, generator=gen) * 0.5
+    t = torch.randint(0, 1000, (16,), device=DEV, generator=gen)
+    dout = torch.randn(16, 3, device=DEV, generator=gen)
+    net.zero_grad(set_to_none=True)
+    (net(x, t) * dout).sum().backward()
+    big = {k: p.grad.clone() for k, p in net.named_parameters()}
+    small = {k: torch.zeros_like(v) for k, v in big.items()}
+    for i in range(0, 16, 4):
+        net.zero_grad(set_to_none=True)
+        (net(x[i:i + 4], t[i:i + 4]) * dout[i:i + 4]).sum().backward()
+        for k, p in net.named_parameters():
+            small[k] += p.grad
+    for k in big:
+        assert torch.isfinite(big[k]).all(), k
+        rel = float((big[k] - small[k]).norm() / (small[k].norm() + 1e-30))
+        assert rel < 2e-3, (k, rel)
+    # deterministic
+    g1 = net.flat_grad().clone()
+    net.zero_grad(set_to_none=True)
+    (net(x[12:16], t[12:16]) * dout[12:16]).sum().backward()
+    assert torch.equal(net.flat_grad(), g1)
+
+
+@pytest.mark.gpu
 def test_bf16_backward_matches_the_fp32_form_on_odd_shapes(golden):
     """pad rows (tokens not a multiple of 128) and a half-empty last attention block must not leak into any gradient"""
     net32, _ = full_net(golden, "fp32")
