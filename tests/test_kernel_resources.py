@@ -25,7 +25,8 @@ KNOWN = {
 }
 HOT = ("k_p_sample_chain", "k_train_fused", "k_resnet_chain", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_fused<1, true>", "k_mlp_fwd_stash",
        "k_mlp_fwd", "k_q_sample_target", "k_logprob_score", "k_igso3_sample", "k_bwd_reduce", "k_adam", "k_prep",
-       "prot::k_ffn", "k_attn", "prot::k_embed", "k_poolb")
+       "prot::k_ffn", "k_attn", "prot::k_embed", "k_poolb",
+       "k_gemm256_bf16", "k_gemm_bf16", "k_gemm_tn256", "k_gemm_tn", "k_attn_fwd", "k_attn_bwd_dq", "k_attn_bwd_dkv", "k_gemm_f32")
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +36,7 @@ def usage():
 
 
 def test_every_kernel_source_compiles_and_reports(usage):
-    assert len(usage) >= 60
+    assert len(usage) >= 120
     for hot in HOT:
         assert any(hot in name for name in usage), f"{hot}: no such kernel in the build any more -- update this list"
 
@@ -65,3 +66,14 @@ def test_register_budgets_of_the_chain_kernels(usage):
     for name, row in usage.items():
         if "k_p_sample_chain<1" in name or "k_resnet_chain<1" in name:
             assert row["VGPRs"] + row["AGPRs"] <= 256 and row["occ"] >= 2, (name, row)
+
+
+def test_register_budgets_of_the_planenet_matrix_kernels(usage):
+    """the persistent / 8-wave kernels (k_gemm256_bf16, k_gemm_tn256: 512 threads, two waves per SIMD) and the attention kernels
+    (two workgroups of four waves per CU) count on 256 registers per lane: none spilled, two waves per SIMD"""
+    seen = 0
+    for name, row in usage.items():
+        if any(k in name for k in ("k_gemm256_bf16", "k_gemm_tn256", "k_attn_fwd", "k_attn_bwd_dq", "k_attn_bwd_dkv")):
+            seen += 1
+            assert row["VGPRs"] + row["AGPRs"] <= 256 and row["occ"] >= 2 and row["scratch"] == 0, (name, row)
+    assert seen >= 20

@@ -6,7 +6,8 @@ import os, re, subprocess, sys, tempfile
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diffusion-extensions_amd", "csrc")
 SOURCES = ("so3x_rotation.hip", "so3x_igso3.hip", "so3x_mlp.hip", "so3x_mlp_bwd.hip", "so3x_train_fused.hip", "so3x_diffusion.hip", "so3x_resnet.hip",
-           "so3x_se3.hip", "so3x_stats.hip", "so3x_rotgrad.hip", "so3x_optim.hip", "so3x_protnet.hip", "so3x_protnet_bf16.hip")
+           "so3x_se3.hip", "so3x_stats.hip", "so3x_rotgrad.hip", "so3x_optim.hip", "so3x_protnet.hip", "so3x_protnet_bf16.hip",
+           "so3x_planenet.hip", "so3x_planenet_bf16.hip", "so3x_planenet_bf16_bwd.hip")
 KEYS = {"VGPRs": r"VGPRs: (\d+)", "AGPRs": r"AGPRs: (\d+)", "scratch": r"ScratchSize \[bytes/lane\]: (\d+)",
         "occ": r"Occupancy \[waves/SIMD\]: (\d+)", "lds": r"LDS Size \[bytes/block\]: (\d+)"}
 # the build's flags (csrc/Makefile)
