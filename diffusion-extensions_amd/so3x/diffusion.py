@@ -10,6 +10,8 @@ Fast paths
 Reference behaviours kept by default and switchable: the column-0 CDF gather of the
 batched-eps sampler (`quirk_col0`), IGSO3(eps=1) chain initialisation.
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -69,6 +71,28 @@ class _FusedStep:
                 return False
         return True
 
+    def accumulate_ok(self):
+        """a plain backward() whose only complications are gradients to add to and frozen parameters"""
+        if self.buf is None or torch.is_anomaly_enabled():
+            return False
+        return not any(p._backward_hooks or p._post_accumulate_grad_hooks for p in self.net._flat_params if p.requires_grad)
+
+    def run_accumulate(self):
+        """what AccumulateGrad does, parameter by parameter: install the view where there is no gradient yet, add in place where
+        there is one, leave frozen parameters alone"""
+        net, buf = self.net, self.buf
+        self.buf = None
+        grad = _b.train_bwd_reduce(buf, gscale=None)
+        _b.TrainBuffers.release(buf)
+        with torch.no_grad():
+            for p, v in zip(net._flat_params, net._grad_views(grad)):
+                if v is None:
+                    continue
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    p.grad.add_(v)
+
     def run_direct(self):
         net, buf = self.net, self.buf
         self.buf = None
@@ -89,17 +113,28 @@ class _DirectBackward:
     __slots__ = ("step", "loss")
 
     def __init__(self, loss, step):
-        # A strong reference (`proc(x).backward()`: the temporary must outlive the attribute fetch), hence a cycle through the
-        # tensor's __dict__ -- which the first call breaks; a loss nobody differentiates is left to the cycle collector.
-        self.step, self.loss = step, loss
+        # The loss is held WEAKLY: a strong reference would close a cycle through the tensor's __dict__ that keeps the step's
+        # multi-MB buffers alive for every loss nobody differentiates (a validation pass with gradients enabled) until the cycle
+        # collector runs.  `proc(x).backward()` -- the temporary dies when the attribute has been fetched, before the call -- still
+        # works: the direct launch needs the step only, and the step is held strongly here.
+        self.step, self.loss = step, weakref.ref(loss)
 
     def __call__(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
-        st, loss = self.step, self.loss
-        loss.__dict__.pop("backward", None)
+        st, loss = self.step, self.loss()
+        if loss is not None:
+            loss.__dict__.pop("backward", None)
         if gradient is None and not retain_graph and not create_graph and inputs is None and st.direct_ok():
             st.run_direct()
             return None
-        return torch.Tensor.backward(loss, gradient, retain_graph, create_graph, inputs)
+        if loss is not None:
+            return torch.Tensor.backward(loss, gradient, retain_graph, create_graph, inputs)
+        # the loss was a temporary (`proc(x).backward()`) and is gone: what the engine would do with a plain backward() into
+        # existing or partly frozen gradients is simple enough to do here; anything else needs the tensor
+        if gradient is None and not retain_graph and not create_graph and inputs is None and st.accumulate_ok():
+            st.run_accumulate()
+            return None
+        raise RuntimeError("so3x: backward(...) with arguments, tensor hooks or anomaly mode needs the loss tensor alive: bind it to a "
+                           "name first (loss = proc(x); loss.backward(...))")
 
 
 class _FusedSkewvecLoss(torch.autograd.Function):
@@ -145,16 +180,18 @@ class _FusedSkewvecLoss(torch.autograd.Function):
             _b.TrainBuffers.release(st.buf)
             st.buf = None
         net = st.net
-        params = net._flat_params
-        if all(p.grad is None and not p._backward_hooks and not p._post_accumulate_grad_hooks for p in params if p.requires_grad):
-            # the usual loop (nothing to accumulate into, no tensor hooks to feed): the flat gradient becomes the .grad views
+        if torch.cuda.is_current_stream_capturing() and all(
+                p.grad is None and not p._backward_hooks and not p._post_accumulate_grad_hooks for p in net._flat_params if p.requires_grad):
+            # inside a graph capture (so3x.graphs.TrainStepGraph's generic form: `loss.backward()` of the captured step, nothing to
+            # accumulate into) the flat gradient is hung on the parameters here, without the engine's AccumulateGrad nodes:
+            # hipStreamEndCapture does not survive them on this stack (segmentation fault in capture_end, ROCm 7.2 / torch 2.10)
             net._install_flat_grad(grad)
-            return (None,) * (6 + len(params))
-        off, out = 0, []
-        for p in params:
-            out.append(grad[off:off + p.numel()].view_as(p) if p.requires_grad else None)
-            off += p.numel()
-        return (None,) * 6 + tuple(out)
+            return (None,) * (6 + len(net._flat_params))
+        # Per-parameter views of the flat gradient, whoever asked (backward(), backward(inputs=...), autograd.grad): the engine
+        # decides what becomes a .grad.  With nothing to accumulate into it installs the views as they are (no copy), and
+        # flat_grad() then recognises them as one flat tensor; the plain `loss.backward()` of the reference loop does not come
+        # through here at all (_DirectBackward).
+        return (None,) * 6 + tuple(st.net._grad_views(grad))
 
 
 def _fused_loss(net, proc, x_start, t, axes, unif):

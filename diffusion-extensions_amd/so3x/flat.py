@@ -92,9 +92,10 @@ class PreparedCache:
 
 class _FlatView(torch.autograd.Function):
     """The flat buffer as a differentiable function of the individual parameters (what torch.cat(params) would be, with
-    no copy either way).  backward: in the usual loop (`zero_grad(); loss.backward()`: every p.grad is None) the flat
-    gradient is installed as the parameters' .grad views directly; if gradients are being accumulated it is split into
-    views and autograd adds them."""
+    no copy either way).  backward: the flat gradient split into per-parameter views; in the usual loop (`zero_grad();
+    loss.backward()`: every p.grad is None) the engine installs them as they are, so the .grads ARE one flat tensor
+    (flat_grad() recognises it); accumulation, `backward(inputs=...)` and `torch.autograd.grad` get what they would from
+    torch.cat."""
 
     @staticmethod
     def forward(ctx, net, *params):
@@ -104,15 +105,12 @@ class _FlatView(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dflat):
         net = ctx.net
-        params = net._flat_params
-        if dflat.is_contiguous() and all(p.grad is None for p in params if p.requires_grad):
+        if dflat.is_cuda and dflat.is_contiguous() and torch.cuda.is_current_stream_capturing() and all(
+                p.grad is None and not p._backward_hooks and not p._post_accumulate_grad_hooks for p in net._flat_params if p.requires_grad):
+            # (inside a graph capture the gradient is hung on the parameters here: see _FusedSkewvecLoss.backward)
             net._install_flat_grad(dflat)
-            return (None,) * (1 + len(params))
-        off, out = 0, []
-        for p in params:
-            out.append(dflat[off:off + p.numel()].view_as(p) if p.requires_grad else None)
-            off += p.numel()
-        return (None, *out)
+            return (None,) * (1 + len(net._flat_params))
+        return (None, *net._grad_views(dflat.contiguous()))
 
 
 class FlatParamsMixin:
@@ -208,6 +206,16 @@ class FlatParamsMixin:
                 p.grad = dflat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         self._flat_grad = dflat
+
+    def _grad_views(self, dflat):
+        """per-parameter views of a flat gradient, for an autograd Function to return (None for frozen parameters); remembers
+        the flat tensor, so that flat_grad() finds it again if the engine installs the views as the .grads"""
+        off, out = 0, []
+        for p in self._flat_params:
+            out.append(dflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None)
+            off += p.numel()
+        self._flat_grad = dflat
+        return out
 
     def _persistent_grad(self):
         """(flat gradient buffer, its per-parameter views) for the training fast path's direct backward: allocated once per flat

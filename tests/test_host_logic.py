@@ -320,6 +320,15 @@ def test_score_network_parameters_live_in_one_flat_buffer(golden):
                    zip(net.net.parameters(), np.cumsum([0] + [q.numel() for q in net.net.parameters()])[:-1]))
         (net.flat_params() * w).sum().backward()                     # second backward without zero_grad: accumulate
         assert torch.equal(torch.cat([p.grad.reshape(-1) for p in net.net.parameters()]), 2 * w)
+        # torch.autograd.grad gets the gradients and leaves every .grad alone; backward(inputs=...) fills the named ones only
+        net.zero_grad(set_to_none=True)
+        ps = list(net.net.parameters())
+        gs = torch.autograd.grad((net.flat_params() * w).sum(), ps)
+        assert torch.equal(torch.cat([g_.reshape(-1) for g_ in gs]), w) and all(p.grad is None for p in ps)
+        (net.flat_params() * w).sum().backward(inputs=[ps[1]])
+        assert ps[1].grad is not None and all(p.grad is None for i, p in enumerate(ps) if i != 1)
+        assert torch.equal(ps[1].grad.reshape(-1), w[ps[0].numel():ps[0].numel() + ps[1].numel()])
+        assert net.flat_grad() is None and torch.equal(net.gather_flat_grad()[ps[0].numel():ps[0].numel() + ps[1].numel()], ps[1].grad.reshape(-1))
 
 
 def test_flat_buffer_check_notices_replaced_parameters_and_modules():

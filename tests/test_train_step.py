@@ -776,6 +776,33 @@ def test_direct_backward_is_the_engines_backward(mods):
     proc(x0).backward()                                               # no zero_grad: accumulated (through the engine)
     assert torch.allclose(net.gather_flat_grad(), 2 * g_direct, rtol=1e-6, atol=0)
 
+    # torch.autograd.grad and backward(inputs=...) get per-parameter gradients from the engine and touch no other .grad
+    rng.manual_seed(11)
+    net.zero_grad(set_to_none=True)
+    ps = list(net.parameters())
+    gs = torch.autograd.grad(proc(x0), ps)
+    assert all(p.grad is None for p in ps) and torch.equal(torch.cat([g_.reshape(-1) for g_ in gs]), g_direct)
+    rng.manual_seed(11)
+    loss = proc(x0)
+    loss.backward(inputs=[ps[2]])
+    assert ps[2].grad is not None and all(p.grad is None for i, p in enumerate(ps) if i != 2)
+    n0 = ps[0].numel() + ps[1].numel()
+    assert torch.equal(ps[2].grad.reshape(-1), g_direct[n0:n0 + ps[2].numel()])
+    net.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="bind it to a name"):
+        proc(x0).backward(inputs=[ps[2]])
+    # a loss nobody differentiates goes away with its last reference (no cycle through its `backward` attribute)
+    import gc
+    import weakref
+    gc.disable()
+    try:
+        loss = proc(x0)
+        w_ = weakref.ref(loss)
+        del loss
+        assert w_() is None
+    finally:
+        gc.enable()
+
     seen = []
     h = net.net[0].weight.register_hook(lambda g: seen.append(g.shape))
     _, g_hooked = grads(lambda l: l.backward())
