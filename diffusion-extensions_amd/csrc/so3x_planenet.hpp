@@ -118,21 +118,27 @@ int gemm(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K
 // (+ bias, + the old C when `accumulate`, both applied by the kernel that sums the chunks)
 int gemm_splitk(hipStream_t s, Mat A, Mat B, float* C, int64_t ldc, int M, int N, int K, float* slab, size_t slab_floats,
                 const float* bias = nullptr, bool accumulate = false);
-// out[c] = sum over rows of X[row][c] (* xhat[row][c] when r / stats are given), fixed order; part: colsum_chunks x cols floats
+// out[c] = sum over rows of X[row][c] (* xhat[row][c] when r / stats are given), fixed order; part: colsum_part_floats(rows, cols) floats
 // (rows per chunk: about rows / 256 -- between 32 and 512 -- so that a small matrix still makes ~256 chunks: at the reference's own
 //  batch sizes a fixed 512 left a bias gradient to four workgroups whose threads each walked 128 rows one dependent load after the other)
-constexpr int CH = 512;
-inline int colsum_ch(int64_t rows) {
-  const int64_t c = (rows / 256 + 31) / 32 * 32;
-  return (int)(c < 32 ? 32 : (c > CH ? CH : c));
+constexpr int CH = 512, COLSUM_NARROW_FLOATS = 65536;
+inline int colsum_ch(int64_t rows, int cols = 1 << 30) {
+  int64_t c = (rows / 256 + 31) / 32 * 32;
+  c = c < 32 ? 32 : (c > CH ? CH : c);
+  // a NARROW matrix (a 64-wide bias gradient is one workgroup per chunk) is cut finer: as many chunks as keep chunks x cols within
+  // COLSUM_NARROW_FLOATS of partials
+  const int64_t narrow = ((rows * (int64_t)cols + COLSUM_NARROW_FLOATS - 1) / COLSUM_NARROW_FLOATS + 31) / 32 * 32;
+  const int64_t cn = narrow < 32 ? 32 : narrow;
+  return (int)(cn < c ? cn : c);
 }
-// chunks to make room for so that colsum() of ANY matrix of at most `rows` rows fits (a plan sums token-level and batch-level matrices
-// through one buffer): at most 257 chunks while rows / 256 <= 512, rows / 512 beyond
-inline int colsum_chunks_for(int64_t rows) {
+// floats to make room for so that colsum() of ANY matrix of at most `rows` rows and at most `widest` columns fits (a plan sums
+// token-level and batch-level matrices through one buffer): by the rows rule at most 264 chunks while rows / 256 <= 512, rows / 512
+// beyond, of `widest` floats each; by the narrow rule COLSUM_NARROW_FLOATS plus one chunk
+inline size_t colsum_part_floats(int64_t rows, size_t widest) {
   const int64_t large = (rows + CH - 1) / CH;
-  return (int)(large > 288 ? large : 288) + 1;
+  const size_t by_rows = (size_t)((large > 288 ? large : 288) + 1) * widest, narrow = (size_t)COLSUM_NARROW_FLOATS + 2 * widest;
+  return by_rows > narrow ? by_rows : narrow;
 }
-inline int colsum_chunks(const Shape& s) { return colsum_chunks_for(s.N()); }
 int colsum(hipStream_t s, const float* X, int64_t ld, int64_t rows, int cols, float* out, float* part, const float* r = nullptr,
            int64_t ldr = 0, const float* stats = nullptr);
 // row kernels (one wave per row): r = a + b, y = LayerNorm(r) gamma + beta, stats = (mean, rstd); its backward; dS = P o (dP - rowsum(dP o P))

@@ -810,7 +810,7 @@ inline BwdB carve_bwd_b(const Shape& s, void* mem) {
   b.dpooled = c.take<float>((size_t)s.B * D);
   b.dxs = c.take<float>((size_t)s.B * D);
   b.slab = c.take<float>((size_t)(SLAB_FLOATS + BIAS_PART_FLOATS));
-  size_t part = (size_t)colsum_chunks(s) * FF;                                        // column sums, <= 2048 wide
+  size_t part = colsum_part_floats(s.N(), FF);                                        // column sums, <= 2048 wide
   const size_t lnp = (size_t)((Np + lnb_rows(Np) - 1) / lnb_rows(Np)) * 1024;       // LayerNorm / embedding partials
   const size_t pool = (size_t)s.B * ((s.P + PSLICE - 1) / PSLICE) * (D + 1);
   if (lnp > part) part = lnp;

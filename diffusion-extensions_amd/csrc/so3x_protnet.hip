@@ -152,6 +152,32 @@ __global__ __launch_bounds__(256) void k_softmax_masked(float* __restrict__ Sm, 
   const int lane = threadIdx.x & 63;
   const int n = len[row / rows_per_chain];
   float* r = Sm + row * cols;
+  if (cols <= 512) {   // the row in registers: one read and one write of it (the same operations in the same order as below)
+    float v[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = lane + 64 * j;
+      v[j] = c < n ? r[c] : 0.f;
+      if (c < n) m = fmaxf(m, v[j]);
+    }
+    m = wmax(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (lane + 64 * j < n) {
+        v[j] = expf(v[j] - m);
+        sum += v[j];
+      }
+    sum = wsum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = lane + 64 * j;
+      if (c < cols) r[c] = c < n ? v[j] * inv : 0.f;
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int c = lane; c < n; c += 64) m = fmaxf(m, r[c]);
   m = wmax(m);
@@ -376,7 +402,6 @@ struct BwdBufs {
   float *dA, *dB, *dF, *dqkv, *dO, *dprobs, *dsp, *dsa, *dzh, *dxc, *gE, *gP, *dxs, *dpv, *dh0, *dh1, *dhz, *wtmp, *part, *slab;
   size_t bytes, slab_floats;
 };
-inline int part_chunks(const Dims& s) { return plane::colsum_chunks_for(s.R()); }
 inline BwdBufs carve_bwd(const Dims& s, void* mem) {
   BwdBufs b;
   Carve c(mem);
@@ -400,7 +425,7 @@ inline BwdBufs carve_bwd(const Dims& s, void* mem) {
   b.dhz = c.take<float>(B * d);
   b.wtmp = c.take<float>((size_t)3 * d * (d > RES ? d : RES));
   const size_t widest = (size_t)(s.F > 3 * s.d ? s.F : 3 * s.d);
-  b.part = c.take<float>((size_t)part_chunks(s) * widest);
+  b.part = c.take<float>(plane::colsum_part_floats(s.R(), widest));
   // split-K partials of the weight gradients (plane::gemm_splitk): room for 32 chunks of the largest one, at least 8 M floats
   b.slab_floats = (size_t)32 * s.F * d > ((size_t)8 << 20) ? (size_t)32 * s.F * d : ((size_t)8 << 20);
   b.slab = c.take<float>(b.slab_floats);

@@ -34,15 +34,28 @@ for f in glob.glob(os.path.join(out, "pmc_*", "*kernel_trace.csv")):
         w = csv.DictWriter(g, fieldnames=cols)
         w.writeheader()
         w.writerows({c: r[c] for c in cols} for r in rows)
+# the counter files: ONE row per (dispatch, counter) -- the values of a counter's instances (XCDs, shader engines) added up, which is
+# the first thing the summariser does with them -- and only the dispatches of the kernels it reports (tools/profile_kernels.py); the
+# transformer legs of bench.py are thousands of small launches that nothing reads
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tools"))
+from profile_kernels import KERNELS
 keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
 for f in glob.glob(os.path.join(out, "pmc_*", "*counter_collection.csv")):
     rows = list(csv.DictReader(open(f)))
-    keep = [k for k in keep if rows and k in rows[0]]
-    rows = [{k: (r[k][:100] if k == "Kernel_Name" else r[k]) for k in keep} for r in rows]
+    cols = [k for k in keep if rows and k in rows[0]]
+    agg = {}
+    for r in rows:
+        if not any(k in r["Kernel_Name"] for k in KERNELS):
+            continue
+        key = (r["Dispatch_Id"], r["Counter_Name"])
+        if key in agg:
+            agg[key]["Counter_Value"] = repr(float(agg[key]["Counter_Value"]) + float(r["Counter_Value"]))
+        else:
+            agg[key] = {k: (r[k][:100] if k == "Kernel_Name" else r[k]) for k in cols}
     with open(f, "w", newline="") as g:
-        w = csv.DictWriter(g, fieldnames=keep)
+        w = csv.DictWriter(g, fieldnames=cols)
         w.writeheader()
-        w.writerows(rows)
+        w.writerows(agg.values())
 for f in glob.glob(os.path.join(out, "stats", "*kernel_trace.csv")):
     rows = list(csv.DictReader(open(f)))
     cols = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size", "Grid_Size_X", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size"]

@@ -65,9 +65,8 @@ if trace:
                "ms_1000_step_launches": [round(d, 3) for d in by.get(1000, [])]},
               open(os.path.join(dst, f"{tag}_chain_dispatches.json"), "w"), indent=1)
 
-KERNELS = ("k_p_sample_chain", "k_logprob_score", "k_resnet_chain", "k_train_fused", "k_bwd_fused", "k_mlp_fwd_stash", "k_mlp_fwd", "k_se3_q_sample_target",
-           "k_q_sample_target", "k_rigid_move", "k_resnet_fwd", "k_resnet_bwd", "k_resnet_dw", "k_bwd_reduce", "k_adam", "k_prep",
-           "k_gemm256_bf16", "k_gemm_bf16", "k_gemm_tn", "k_attn_fwd", "k_attn_bwd_dq", "k_attn_bwd_dkv", "k_ln_bf16", "k_ln_bwd_bf16")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from profile_kernels import KERNELS
 per = {}  # counter -> kernel -> list of per-dispatch values (summed over the agent's instances)
 unclassified = collections.Counter()   # counter -> k_p_sample_chain dispatches without a duration (dropped)
 legs = {}  # counter -> the k_logprob_score dispatches at 2^20 evaluations in dispatch order, split into bench.py's three legs
