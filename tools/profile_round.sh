@@ -13,12 +13,14 @@ python3 tools/csrc_digest.py > $out/csrc_sha256.txt
 python3 bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
 tail -1 $out/bench_stdout.txt > $out/bench_line.json
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o b -- python3 $R/bench.py --no-cpu-baseline > $out/stats.log 2>&1
+# (every profiler pass under its own `timeout`: a pass that dies with a malformed-packet error leaves rocprofv3 waiting on its queue
+#  for ever -- 44 minutes of a round's GPU budget, once)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o b -- python3 $R/bench.py --no-cpu-baseline > $out/stats.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" \
            "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 100 > $out/pmc_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 300 --warmup 100 > $out/pmc_$i.log 2>&1
 done
 # keep what tools/summarize_profiles.py reads, in a size gpurun copies back (<= 64 MiB for all of gpurun_out/): the counter files
 # with seven columns and kernel names cut to 100 characters, the PMC passes' own kernel traces cut to three columns

@@ -121,6 +121,10 @@ for cname, ks in sorted(per.items()):
         # "mean" = the MEDIAN over the dispatches of ONE launch shape (k_p_sample_chain's shapes are separate rows, see above)
         rows.append({"counter": cname, "kernel": k, "grid_size": grid, "dispatches": len(vals), "mean": statistics.median(vals),
                      "min": min(vals), "max": max(vals)})
+if not rows:
+    # (a round whose counter passes died: the bench line and the kernel statistics above are copied, the committed counter summaries
+    #  stay as they were -- bench.py goes on checking their digests against the sources)
+    sys.exit(f"{src}: no counter files -- {tag}_pmc_summary.csv and pmc_traffic.json left untouched")
 with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
